@@ -1,0 +1,174 @@
+/* yoloret_hip.h - C-ABI of libyoloret_hip.so: the MI355X (gfx950) detection-forward
+ * runtime behind yoloret_amd's Python surface.
+ *
+ * The reference (prakharg24/yoloret) has NO native / FFI interface: its path is
+ * Python calling TensorFlow kernels.  Each entry point below therefore cites
+ * the reference Python function (file:line under /root/reference/code) whose TF
+ * kernels it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - all tensors NHWC float32; `ld` = channel stride in floats (>= channels,
+ *     multiple of 4 unless stated); every device pointer 16-byte aligned.
+ *   - every function returns 0 on success, a negative yr_status otherwise, and
+ *     never throws; the message is available from yr_last_error().
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it
+ *     asynchronously, nothing synchronises.
+ *   - a handle is bound to the device that was current at yr_create and is not
+ *     thread-safe.
+ */
+#ifndef YOLORET_HIP_H
+#define YOLORET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YR_ABI_VERSION 1
+#define YR_MAX_SRC 4
+
+typedef enum {
+    YR_OK = 0,
+    YR_ERR_ARG = -1,     /* bad argument / unsupported shape */
+    YR_ERR_HIP = -2,     /* a HIP runtime call failed */
+    YR_ERR_STATE = -3    /* e.g. weights not loaded */
+} yr_status;
+
+typedef enum { YR_ACT_NONE = 0, YR_ACT_RELU6 = 1, YR_ACT_SWISH = 2, YR_ACT_SIGMOID = 3, YR_ACT_LEAKY = 4 } yr_act;
+
+/* How a source tensor is read by a consumer (folds Keras UpSampling2D /
+ * MaxPooling2D / Concatenate - model.py:139-144,157,164-166,253-255,307-308 -
+ * into the consumer's loads). */
+typedef enum { YR_X_IDENTITY = 0, YR_X_UP2 = 1, YR_X_MAXPOOL2 = 2, YR_X_MAXPOOL4 = 3 } yr_xform;
+
+/* One concatenated input segment.  (h,w) are the SOURCE's spatial dims; the
+ * consumer's dims follow from xform.  In plan ops `ptr` is unused and `buf`
+ * indexes the plan's buffer table; in yr_op_* calls `ptr` is the device pointer. */
+typedef struct {
+    const float* ptr;
+    int32_t buf;
+    int32_t h, w;
+    int32_t c;       /* channels taken from this source */
+    int32_t ld;      /* channel stride of the source buffer */
+    int32_t xform;   /* yr_xform */
+} yr_src;
+
+typedef enum {
+    YR_OP_STEM = 1,      /* Conv2D 3x3 s2 Cin=3 + BN + act            (MobileNetV2 Conv1 [3P]; efficientnet.py:636-645) */
+    YR_OP_POINTWISE = 2, /* Conv2D 1x1 (+bias)(+BN)(+act)(+residual)  (model.py:25-30,98-114,152-155,243-251; efficientnet.py:485-496,517-533) */
+    YR_OP_DEPTHWISE = 3, /* DepthwiseConv2D k3/k5 s1/s2 SAME + BN + act (model.py:20-24; efficientnet.py:501-510) */
+    YR_OP_SE_MEAN = 4,   /* Mean over H,W                              (efficientnet.py:391-403,417) */
+    YR_OP_SE_FC = 5,     /* 1x1+bias -> Swish -> 1x1+bias -> sigmoid   (efficientnet.py:419-434) */
+    YR_OP_WSUM = 6,      /* WeightedSum of 4 gathered sources          (model.py:117-137,157) */
+    YR_OP_GATHER = 7     /* materialise upsample/maxpool/concat        (standalone K5; testing / unfused use) */
+} yr_op_kind;
+
+/* One fused operation.  Weight-like fields are float offsets into the weight
+ * blob in plan ops (`wgt_off` etc.), or device pointers in yr_op_* calls. */
+typedef struct {
+    int32_t kind;         /* yr_op_kind */
+    int32_t act;          /* yr_act */
+    int32_t h, w;         /* OUTPUT spatial dims per image */
+    int32_t cin, cout;    /* logical channels (cin = sum of src[].c) */
+    int32_t k, stride;    /* DEPTHWISE / STEM kernel size and stride */
+    int32_t nsrc;
+    int32_t se_reduced;   /* SE_FC: hidden width */
+    yr_src src[YR_MAX_SRC];
+    /* output */
+    float* out;  int32_t out_buf;  int32_t out_ld;
+    /* optional residual added after BN (same shape as output) */
+    const float* res;  int32_t res_buf;  int32_t res_ld;
+    /* optional SE gate [B, gate_ld] multiplied onto the (single) source on load */
+    const float* gate;  int32_t gate_buf;  int32_t gate_ld;
+    /* parameters (device pointers, or float offsets into the blob when in a plan):
+     *   POINTWISE: wgt = Wt[cout][kp] (kp = sum of round_up(src.c,4), zero padded),
+     *              scale/shift [cout] (folded BN and/or bias)
+     *   DEPTHWISE: wgt = [k*k][round_up(c,4)] ; scale/shift [round_up(c,4)]
+     *   STEM:      wgt = [27][round_up(cout,4)] ; scale/shift [round_up(cout,4)]
+     *   SE_FC:     wgt = W1t[reduced][ldc], b1 [reduced], wgt2 = W2[reduced][ldc], b2 [ldc], ldc = round_up(c,4)
+     *   WSUM:      wgt = alpha[4] */
+    const float* wgt;    int64_t wgt_off;
+    const float* scale;  int64_t scale_off;
+    const float* shift;  int64_t shift_off;
+    const float* wgt2;   int64_t wgt2_off;
+    const float* b1;     int64_t b1_off;
+    const float* b2;     int64_t b2_off;
+} yr_op;
+
+/* Buffer table entry of a plan: per-image size in floats and either an arena
+ * offset (per-image floats; the runtime multiplies by batch) or an external
+ * slot (0 = input images, 1..3 = y1..y3). */
+typedef struct {
+    int64_t elems_per_image;
+    int64_t arena_off_per_image;   /* -1 for external buffers */
+    int32_t external_slot;         /* -1 for arena buffers */
+    int32_t pad_;
+} yr_buf;
+
+typedef struct yr_handle yr_handle;
+
+const char* yr_last_error(void);
+int yr_abi_version(void);
+
+/* ---- whole-graph runtime: replaces tf.keras.Model.__call__ on the graph built by
+ * yolov3_body (model.py:170-342; called at yolo.py:152, map.py:111). */
+int yr_create(const yr_op* ops, int n_ops, const yr_buf* bufs, int n_bufs, yr_handle** out);
+void yr_destroy(yr_handle* h);
+/* Copies the flat fp32 parameter blob (host) to the device; owned by the handle.
+ * Replaces tf.keras.Model.load_weights (yolo.py:87) once weights are in blob order. */
+int yr_load_weights(yr_handle* h, const float* host_blob, size_t n_floats);
+/* Bytes of caller-owned device workspace yr_forward needs for `batch` images. */
+size_t yr_workspace_bytes(const yr_handle* h, int batch);
+/* images [B,H,W,3] -> y1,y2,y3 raw logits [B,G,G,A*(C+5)], G = H/32, H/16, H/8. */
+int yr_forward(yr_handle* h, const float* images, int batch, float* y1, float* y2, float* y3,
+               void* workspace, size_t workspace_bytes, void* stream);
+/* Launch-count / per-kind breakdown of the plan (for reports). */
+int yr_plan_num_launches(const yr_handle* h);
+
+/* ---- single fused ops (device pointers inside `op`); parity-testable in isolation. */
+int yr_op_run(const yr_op* op, int batch, void* stream);
+
+/* ---- decode: replaces yolo_head + yolo_correct_boxes + yolo_boxes_and_scores
+ * (model.py:344-428) for the three scales at once, per image.
+ *   y[s]      [B,G_s,G_s,A*(C+5)] raw logits, s = 0,1,2 for strides 32,16,8
+ *   anchors   host, 9x(w,h) in the order of model_data/yolo_anchors.txt; scale s uses
+ *             anchor_mask [[6,7,8],[3,4,5],[0,1,2]][s] (model.py:444)
+ *   image_hw  device int32 [B,2] original image (h,w) per image
+ *   boxes     [B,N,4] (ymin,xmin,ymax,xmax) fp32, N = A*sum(G_s^2)
+ *   scores    [B,C,N] fp32, CLASS-MAJOR (score = conf*prob, model.py:426) */
+int yr_decode(const float* y1, const float* y2, const float* y3, int batch, int in_h, int in_w,
+              int num_anchors, int num_classes, int num_scales, const float* anchors_host,
+              const int32_t* image_hw, float* boxes, float* scores, void* stream);
+
+/* yolo_head alone (model.py:344-371): one scale, reference layouts
+ * box_xy/box_wh [B,G,G,A,2], conf [B,G,G,A,1], probs [B,G,G,A,C]; `scores` (nullable)
+ * receives conf*probs [B,G,G,A,C] (model.py:426). */
+int yr_yolo_head(const float* feats, int batch, int gh, int gw, int num_anchors, int num_classes,
+                 const float* anchors_host /*A x (w,h)*/, int in_h, int in_w,
+                 float* box_xy, float* box_wh, float* conf, float* probs, float* scores, void* stream);
+/* yolo_correct_boxes (model.py:374-399): n = number of (xy,wh) pairs per image. */
+int yr_correct_boxes(const float* box_xy, const float* box_wh, int batch, int64_t n_per_image,
+                     int in_h, int in_w, const int32_t* image_hw, float* boxes, void* stream);
+
+/* ---- per-(image,class) hard NMS: replaces the loop of tf.image.non_max_suppression
+ * calls at model.py:474-480 (NonMaxSuppressionV3 semantics).
+ *   out_idx [B,C,max_boxes] int32 box indices in pick order (unused tail = -1)
+ *   out_count [B,C] int32 */
+int yr_nms(const float* boxes, const float* scores, int batch, int n, int num_classes, int max_boxes,
+           float score_thr, float iou_thr, int32_t* out_idx, int32_t* out_count, void* stream);
+
+/* ---- gather + cast: model.py:481-490.  Fixed-size padded records so that the
+ * multi-GPU all-gather moves one dense tensor:
+ *   det [B, C*max_boxes, 6] int32 words = {ymin,xmin,ymax,xmax (int32, truncated),
+ *        score (fp32 bits), class (int32)}, rows ordered class-ascending then pick
+ *        order, compacted to the front; det_count [B] int32. */
+int yr_pack_detections(const float* boxes, const float* scores, const int32_t* nms_idx,
+                       const int32_t* nms_count, int batch, int n, int num_classes, int max_boxes,
+                       int32_t* det, int32_t* det_count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLORET_HIP_H */

@@ -1,0 +1,103 @@
+"""Whole-graph parity through the drop-in surface (yolov3_body -> Model -> yolo_eval) against
+the NumPy oracle on the same seeded weights and images.
+
+Bar (BASELINE.json north_star): fp32 logits within 1e-4 - applied as |a-b| <= 1e-4*max(1,|b|)
+ - and a bit-exact NMS index set.  The NMS stage is bit-exact on identical inputs
+(test_gpu_postprocess.py); end to end the decisions also depend on ~1e-6 logit differences, so
+here the oracle's post-processing is re-run on the GPU's own logits and must match exactly, and
+the agreement with the oracle's end-to-end detections is measured and bounded."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpost
+from oracle import model as om
+from oracle import params
+from tests.util import ANCHORS, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(model_name, hw, num_classes, seed=1234):
+    from yoloret_amd import layers as L
+    from yoloret_amd.yolo3.model import yolov3_body
+    m = yolov3_body(L.Input(shape=[hw[0], hw[1], 3]), model_name, 3, num_classes=num_classes)
+    P = params.ParamStore(seed)
+    return m, P
+
+
+def _run_both(dev, model_name, hw, b, num_classes=20):
+    m, P = _build(model_name, hw, num_classes)
+    x = params.synthetic_images(b, hw[0], hw[1])
+    ref = om.yolov3_body(P, x, model_name, 3, num_classes)
+    m.set_weights(P.values)  # the oracle's walk created every parameter the product needs
+    ys = m(torch.from_numpy(x).to(dev))
+    torch.cuda.synchronize()
+    return m, x, ref, ys
+
+
+@pytest.mark.parametrize('model_name,hw', [('mobilenetv2x75', (64, 64)), ('mobilenetv2x14', (64, 96)),
+                                           ('efficientnetb0', (64, 64)), ('efficientnetb3', (96, 64)),
+                                           ('efficientnetb0-lite', (64, 64))])
+def test_logits_small(dev, model_name, hw):
+    _, _, ref, ys = _run_both(dev, model_name, hw, 3)
+    for i, (y, r) in enumerate(zip(ys, ref)):
+        assert tuple(y.shape) == r.shape
+        assert_close(y.cpu().numpy(), r, 1e-4, '%s y%d' % (model_name, i + 1))
+
+
+def test_logits_416_and_detections(dev):
+    """BASELINE config 2's model at full resolution, small batch."""
+    from yoloret_amd.yolo3.model import yolo_eval
+    b = 2
+    m, x, ref, ys = _run_both(dev, 'mobilenetv2x75', (416, 416), b)
+    worst = 0.0
+    for i, (y, r) in enumerate(zip(ys, ref)):
+        assert tuple(y.shape) == (b, 416 // (32 >> i), 416 // (32 >> i), 3, 25)
+        worst = max(worst, assert_close(y.cpu().numpy(), r, 1e-4, 'y%d' % (i + 1)))
+    print('max scaled logit error vs oracle: %.2e' % worst)
+    res = yolo_eval(ys, ANCHORS, 3, 20, (416, 416), max_boxes=20, score_threshold=0.2, iou_threshold=0.5)
+    assert len(res) == b
+    agree = total = 0
+    for i in range(b):
+        gb, gs, gc = [t.cpu().numpy() for t in res[i]]
+        # (1) oracle post-processing on the GPU's own logits: must be identical
+        ob, os_, oc, gi = cpost.yolo_eval([y[i].cpu().numpy() for y in ys], ANCHORS, 3, 20, (416, 416), 20, 0.2, 0.5)
+        assert np.array_equal(gb, ob) and np.array_equal(gs, os_) and np.array_equal(gc, oc)
+        # (2) end to end vs the oracle's logits: same (class, index) picks except where a decision
+        # sits inside fp32 noise; require >= 98% agreement
+        rb, rs, rc, ri = cpost.yolo_eval([r[i] for r in ref], ANCHORS, 3, 20, (416, 416), 20, 0.2, 0.5)
+        ref_set = set(zip(rc.tolist(), ri.tolist()))
+        got_set = set(zip(gc.tolist(), gi.tolist()))
+        agree += len(ref_set & got_set)
+        total += len(ref_set)
+    print('end-to-end detection agreement: %d/%d' % (agree, total))
+    assert total > 0 and agree >= 0.98 * total
+
+
+def test_batch_equals_per_image(dev):
+    """Batched execution == the reference applied to each image independently."""
+    m, P = _build('mobilenetv2x75', (96, 96), 20)
+    x = params.synthetic_images(4, 96, 96)
+    om.yolov3_body(P, x[:1], 'mobilenetv2x75', 3, 20)
+    m.set_weights(P.values)
+    xd = torch.from_numpy(x).to(dev)
+    full = [y.clone() for y in m(xd)]
+    for i in range(4):
+        one = m(xd[i:i + 1].contiguous())
+        for a, bfull in zip(one, full):
+            assert torch.equal(a[0], bfull[i])
+
+
+def test_model_errors(dev):
+    from yoloret_amd import layers as L
+    from yoloret_amd.yolo3.model import yolov3_body
+    m = yolov3_body(L.Input(shape=[64, 64, 3]), 'mobilenetv2x75', 3, num_classes=20)
+    with pytest.raises(RuntimeError, match='weights'):
+        m(torch.zeros((1, 64, 64, 3), device=dev))
+    with pytest.raises(ValueError, match='missing parameters'):
+        m.set_weights({})
+    with pytest.raises(ValueError):
+        m(torch.zeros((1, 32, 64, 3), device=dev))
+    with pytest.raises(ValueError):
+        m(torch.zeros((1, 64, 64, 3)))  # CPU tensor: no fallback

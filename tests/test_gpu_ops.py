@@ -1,0 +1,296 @@
+"""Per-kernel parity: every fused HIP op (through the C-ABI, yr_op_run) against the NumPy
+oracle on the same seeded inputs.  fp32 tolerance 1e-5*max(1,|ref|) per op."""
+import ctypes
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn
+from tests.util import assert_close, from_dev, round_up, to_dev
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _rt():
+    from yoloret_amd import runtime as rt
+    return rt
+
+
+def _dev_vec(a, dev, n=None):
+    a = np.asarray(a, np.float32).ravel()
+    if n is not None and n != a.size:
+        p = np.zeros(n, np.float32)
+        p[:a.size] = a
+        a = p
+    return torch.from_numpy(a).to(dev)
+
+
+def _act_np(x, act):
+    return {'none': lambda v: v, 'relu6': nn.relu6, 'swish': nn.swish, 'sigmoid': nn.sigmoid,
+            'leaky': nn.leaky_relu}[act](x)
+
+
+def _xform_np(x, xf):
+    return {'identity': lambda v: v, 'up2': nn.upsample2, 'maxpool2': lambda v: nn.maxpool(v, 2),
+            'maxpool4': lambda v: nn.maxpool(v, 4)}[xf](x)
+
+
+def _src_dims(h, w, xf):
+    return {'identity': (h, w), 'up2': (h // 2, w // 2), 'maxpool2': (h * 2, w * 2), 'maxpool4': (h * 4, w * 4)}[xf]
+
+
+def run_pointwise(dev, rng, b, h, w, segs, cout, act='none', bn=True, residual=False, gate=False, out_ld=None):
+    rt = _rt()
+    srcs_np, srcs_dev = [], []
+    for c, xf in segs:
+        sh, sw = _src_dims(h, w, xf)
+        a = rng.standard_normal((b, sh, sw, c)).astype(np.float32)
+        srcs_np.append(a)
+        srcs_dev.append(to_dev(a, dev))
+    cin = sum(c for c, _ in segs)
+    wk = (rng.standard_normal((cin, cout)) * np.sqrt(2.0 / cin)).astype(np.float32)
+    kp = sum(round_up(c, 4) for c, _ in segs)
+    wt = np.zeros((cout, kp), np.float32)
+    d = kb = 0
+    for c, _ in segs:
+        wt[:, kb:kb + c] = wk[d:d + c].T
+        d += c
+        kb += round_up(c, 4)
+    x = nn.concat([_xform_np(a, xf) for a, (_, xf) in zip(srcs_np, segs)])
+    gate_np = None
+    if gate:
+        gate_np = rng.uniform(0.1, 1.0, (b, 1, 1, cin)).astype(np.float32)
+        x = gate_np * x
+    ref = nn.pointwise(x, wk)
+    scale = shift = None
+    if bn:
+        scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        shift = rng.normal(0, 0.3, cout).astype(np.float32)
+        ref = ref * scale + shift
+    ref = _act_np(ref.astype(np.float32), act)
+    res_np = None
+    if residual:
+        res_np = rng.standard_normal((b, h, w, cout)).astype(np.float32)
+        ref = ref + res_np
+    out_ld = round_up(cout, 4) if out_ld is None else out_ld
+    out = torch.full((b, h, w, out_ld), float('nan'), dtype=torch.float32, device=dev)
+    op = rt.new_op(rt.OP_POINTWISE, act)
+    op.h, op.w, op.cin, op.cout, op.nsrc = h, w, cin, cout, len(segs)
+    for i, (t, (c, xf)) in enumerate(zip(srcs_dev, segs)):
+        op.src[i] = rt.make_src(t, c=c, xform=xf)
+    keep = [_dev_vec(wt, dev)]
+    op.wgt = keep[0].data_ptr()
+    if bn:
+        keep += [_dev_vec(scale, dev), _dev_vec(shift, dev)]
+        op.scale, op.shift = keep[1].data_ptr(), keep[2].data_ptr()
+    if residual:
+        r = to_dev(res_np, dev)
+        keep.append(r)
+        op.res, op.res_ld = r.data_ptr(), r.shape[3]
+    if gate:
+        g = to_dev(gate_np.reshape(b, 1, 1, cin), dev)
+        keep.append(g)
+        op.gate, op.gate_ld = g.data_ptr(), g.shape[3]
+    op.out, op.out_ld = out.data_ptr(), out_ld
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    return assert_close(from_dev(out, cout), ref, TOL, 'pointwise %s' % (segs,))
+
+
+PW_CASES = [
+    # (h, w, segs, cout, act, bn, residual, gate, dense_out)
+    (13, 13, [(16, 'identity')], 96, 'relu6', True, False, False, False),
+    (13, 11, [(24, 'identity')], 16, 'none', True, False, False, False),
+    (7, 9, [(144, 'identity')], 24, 'none', True, True, False, False),
+    (13, 13, [(720, 'identity')], 120, 'none', True, True, False, False),
+    (26, 26, [(72, 'identity')], 432, 'relu6', True, False, False, False),
+    (13, 13, [(120, 'identity'), (96, 'maxpool2')], 512, 'relu6', True, False, False, False),
+    (26, 26, [(256, 'up2'), (72, 'identity'), (96, 'identity')], 256, 'relu6', True, False, False, False),
+    (12, 12, [(128, 'up2'), (24, 'identity'), (96, 'up2')], 128, 'relu6', True, False, False, False),
+    (13, 13, [(128, 'maxpool2'), (75, 'identity')], 256, 'relu6', True, False, False, False),
+    (13, 13, [(512, 'identity')], 75, 'none', True, False, True, False),
+    (13, 13, [(75, 'identity')], 75, 'none', False, False, False, True),   # y conv: dense 75-wide logits
+    (26, 26, [(24, 'maxpool4')], 48, 'none', False, False, False, False),  # rfcr_b4c
+    (5, 5, [(75, 'identity')], 255, 'swish', True, False, False, True),
+    (8, 8, [(37, 'identity'), (22, 'up2')], 50, 'leaky', True, True, False, False),
+    (1, 1, [(128, 'identity')], 32, 'sigmoid', True, False, False, False),
+]
+
+
+@pytest.mark.parametrize('case', PW_CASES, ids=[str(i) for i in range(len(PW_CASES))])
+def test_pointwise(dev, case):
+    h, w, segs, cout, act, bn, residual, gate, dense = case
+    rng = np.random.default_rng(zlib.crc32(str(case).encode()))
+    run_pointwise(dev, rng, 3, h, w, segs, cout, act, bn, residual, gate, out_ld=cout if dense else None)
+
+
+def test_pointwise_large_m(dev):
+    """block_1_expand's shape at batch 2: 208x208x16 -> 96 (M = 86528, ragged last tile)."""
+    rng = np.random.default_rng(7)
+    run_pointwise(dev, rng, 2, 208, 208, [(16, 'identity')], 96, 'relu6')
+
+
+DW_CASES = [(3, 1, 13, 13, 24), (3, 2, 26, 26, 96), (3, 2, 14, 10, 144), (5, 1, 26, 26, 48), (5, 2, 16, 16, 40),
+            (3, 1, 7, 5, 75), (3, 1, 52, 52, 128), (5, 2, 9, 9, 20), (3, 2, 9, 7, 8)]
+
+
+@pytest.mark.parametrize('k,s,h,w,c', DW_CASES)
+@pytest.mark.parametrize('act', ['relu6', 'swish'])
+def test_depthwise(dev, k, s, h, w, c, act):
+    rt = _rt()
+    rng = np.random.default_rng(k * 1000 + s * 100 + h + c)
+    b = 2
+    x = rng.standard_normal((b, h, w, c)).astype(np.float32)
+    wk = (rng.standard_normal((k, k, c)) * np.sqrt(2.0 / (k * k))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    shift = rng.normal(0, 0.3, c).astype(np.float32)
+    ref = _act_np((nn.depthwise(x, wk, s, 'same') * scale + shift).astype(np.float32), act)
+    ldc = round_up(c, 4)
+    xd = to_dev(x, dev, fill=0.0)  # pad channels meet zero weights; keep them finite
+    wd = np.zeros((k * k, ldc), np.float32)
+    wd[:, :c] = wk.reshape(k * k, c)
+    keep = [_dev_vec(wd, dev), _dev_vec(scale, dev, ldc), _dev_vec(shift, dev, ldc)]
+    ho, wo = ref.shape[1:3]
+    out = torch.full((b, ho, wo, ldc), float('nan'), dtype=torch.float32, device=dev)
+    op = rt.new_op(rt.OP_DEPTHWISE, act)
+    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc = ho, wo, c, c, k, s, 1
+    op.src[0] = rt.make_src(xd, c=c)
+    op.wgt, op.scale, op.shift = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
+    op.out, op.out_ld = out.data_ptr(), ldc
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    assert_close(from_dev(out, c), ref, TOL, 'depthwise')
+
+
+@pytest.mark.parametrize('hw,cout,act', [((64, 64), 24, 'relu6'), ((32, 96), 40, 'swish'), ((30, 22), 48, 'relu6')])
+def test_stem(dev, hw, cout, act):
+    rt = _rt()
+    rng = np.random.default_rng(cout)
+    b = 2
+    x = rng.random((b, hw[0], hw[1], 3), dtype=np.float32)
+    wk = (rng.standard_normal((3, 3, 3, cout)) * np.sqrt(2.0 / 27)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.3, cout).astype(np.float32)
+    ref = _act_np((nn.conv2d(x, wk, 2, 'same') * scale + shift).astype(np.float32), act)
+    ldw = round_up(cout, 4)
+    wd = np.zeros((27, ldw), np.float32)
+    wd[:, :cout] = wk.reshape(27, cout)
+    xd = torch.from_numpy(x).to(dev)
+    keep = [_dev_vec(wd, dev), _dev_vec(scale, dev, ldw), _dev_vec(shift, dev, ldw)]
+    ho, wo = ref.shape[1:3]
+    out = torch.full((b, ho, wo, ldw), float('nan'), dtype=torch.float32, device=dev)
+    op = rt.new_op(rt.OP_STEM, act)
+    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc = ho, wo, 3, cout, 3, 2, 1
+    op.src[0] = rt.make_src(xd, c=3, ld=3)
+    op.wgt, op.scale, op.shift = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
+    op.out, op.out_ld = out.data_ptr(), ldw
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    assert_close(from_dev(out, cout), ref, TOL, 'stem')
+
+
+@pytest.mark.parametrize('h,w,c,r', [(13, 13, 512, 128), (26, 26, 256, 64), (52, 52, 128, 32), (7, 5, 75, 6), (9, 9, 20, 1)])
+def test_squeeze_excite(dev, h, w, c, r):
+    rt = _rt()
+    rng = np.random.default_rng(c + r)
+    b = 3
+    x = rng.standard_normal((b, h, w, c)).astype(np.float32)
+    w1 = (rng.standard_normal((c, r)) * np.sqrt(2.0 / c)).astype(np.float32)
+    b1 = rng.normal(0, 0.1, r).astype(np.float32)
+    w2 = (rng.standard_normal((r, c)) * np.sqrt(2.0 / r)).astype(np.float32)
+    b2 = rng.normal(0, 0.1, c).astype(np.float32)
+    mean = nn.mean_hw(x)
+    gate = nn.sigmoid(nn.pointwise(nn.swish(nn.pointwise(mean, w1) + b1), w2) + b2)
+    ldc = round_up(c, 4)
+    xd = to_dev(x, dev)
+    md = torch.full((b, 1, 1, ldc), float('nan'), dtype=torch.float32, device=dev)
+    op = rt.new_op(rt.OP_SE_MEAN)
+    op.h, op.w, op.cin, op.cout, op.nsrc = 1, 1, c, c, 1
+    op.src[0] = rt.make_src(xd, c=c)
+    op.out, op.out_ld = md.data_ptr(), ldc
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    assert_close(from_dev(md, c), mean, TOL, 'se_mean')
+    w1t = np.zeros((r, ldc), np.float32)
+    w1t[:, :c] = w1.T
+    w2p = np.zeros((r, ldc), np.float32)
+    w2p[:, :c] = w2
+    keep = [_dev_vec(w1t, dev), _dev_vec(b1, dev), _dev_vec(w2p, dev), _dev_vec(b2, dev, ldc)]
+    gd = torch.full((b, 1, 1, ldc), float('nan'), dtype=torch.float32, device=dev)
+    op = rt.new_op(rt.OP_SE_FC)
+    op.h, op.w, op.cin, op.cout, op.nsrc, op.se_reduced = 1, 1, c, c, 1, r
+    op.src[0] = rt.make_src(md, c=c)
+    op.wgt, op.b1, op.wgt2, op.b2 = [k.data_ptr() for k in keep]
+    op.out, op.out_ld = gd.data_ptr(), ldc
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    assert_close(from_dev(gd, c), gate, TOL, 'se_fc')
+
+
+def test_weighted_sum_bit_exact(dev):
+    """model.py:134's left-to-right a0*x0+a1*x1+a2*x2+a3*x3 is reproduced exactly (no contraction)."""
+    rt = _rt()
+    rng = np.random.default_rng(3)
+    b, h, w, c = 2, 26, 26, 48
+    x0 = rng.standard_normal((b, h // 2, w // 2, c)).astype(np.float32)
+    x1 = rng.standard_normal((b, h, w, c)).astype(np.float32)
+    x2 = rng.standard_normal((b, h * 2, w * 2, c)).astype(np.float32)
+    x3 = rng.standard_normal((b, h, w, c)).astype(np.float32)
+    a = rng.uniform(0.5, 1.5, 4).astype(np.float32)
+    ref = a[0] * nn.upsample2(x0) + a[1] * x1 + a[2] * nn.maxpool(x2, 2) + a[3] * x3
+    ts = [to_dev(t, dev) for t in (x0, x1, x2, x3)]
+    ad = _dev_vec(a, dev)
+    out = torch.full((b, h, w, c), float('nan'), dtype=torch.float32, device=dev)
+    op = rt.new_op(rt.OP_WSUM)
+    op.h, op.w, op.cin, op.cout, op.nsrc = h, w, c, c, 4
+    for i, (t, xf) in enumerate(zip(ts, ['up2', 'identity', 'maxpool2', 'identity'])):
+        op.src[i] = rt.make_src(t, c=c, xform=xf)
+    op.wgt = ad.data_ptr()
+    op.out, op.out_ld = out.data_ptr(), c
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    assert np.array_equal(from_dev(out), ref)
+
+
+def test_gather_concat_bit_exact(dev):
+    rt = _rt()
+    rng = np.random.default_rng(4)
+    b, h, w = 2, 12, 8
+    segs = [(37, 'identity'), (22, 'up2'), (8, 'maxpool2'), (5, 'maxpool4')]
+    arrs, ts = [], []
+    for c, xf in segs:
+        sh, sw = _src_dims(h, w, xf)
+        a = rng.standard_normal((b, sh, sw, c)).astype(np.float32)
+        arrs.append(a)
+        ts.append(to_dev(a, dev))
+    ref = nn.concat([_xform_np(a, xf) for a, (_, xf) in zip(arrs, segs)])
+    ctot = ref.shape[-1]
+    out = torch.full((b, h, w, ctot), float('nan'), dtype=torch.float32, device=dev)
+    op = rt.new_op(rt.OP_GATHER)
+    op.h, op.w, op.cin, op.cout, op.nsrc = h, w, ctot, ctot, 4
+    for i, (t, (c, xf)) in enumerate(zip(ts, segs)):
+        op.src[i] = rt.make_src(t, c=c, xform=xf)
+    op.out, op.out_ld = out.data_ptr(), ctot
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    assert np.array_equal(from_dev(out), ref)
+
+
+def test_bad_arguments_report_errors(dev):
+    """C-ABI error behaviour: negative status + message, no exception across the boundary."""
+    rt = _rt()
+    op = rt.new_op(rt.OP_POINTWISE)
+    op.nsrc = 0
+    rc = rt.lib().yr_op_run(ctypes.byref(op), 1, None)
+    assert rc == -1 and b'nsrc' in rt.lib().yr_last_error()
+    with pytest.raises(rt.YoloretHipError):
+        rt.run_op(op, 1)
+    x = torch.zeros((1, 4, 4, 6), device=dev)  # ld not a multiple of 4
+    op = rt.new_op(rt.OP_POINTWISE)
+    op.h, op.w, op.cin, op.cout, op.nsrc = 4, 4, 6, 8, 1
+    op.src[0] = rt.make_src(x, c=6)
+    with pytest.raises(rt.YoloretHipError, match='multiple of 4'):
+        rt.run_op(op, 1)

@@ -1,0 +1,156 @@
+"""Decode / NMS / pack parity through the C-ABI.
+
+Bars: decode is BIT-EXACT against the C oracle (both pin exp to the same float32 algorithm
+and run without FMA contraction) and within 2e-6 relative of the NumPy/libm oracle; the NMS
+index set and order are BIT-EXACT against both oracles on identical boxes/scores; packed
+detections equal the oracle's yolo_eval output exactly."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpost
+from oracle import postprocess as pp
+from tests.util import ANCHORS
+
+pytestmark = pytest.mark.gpu
+
+
+def _rt():
+    from yoloret_amd import runtime as rt
+    return rt
+
+
+def _logits(rng, b, hw, c, scale=3.0):
+    return [(rng.standard_normal((b, hw[0] // s, hw[1] // s, 3, c + 5)) * scale).astype(np.float32)
+            for s in (32, 16, 8)]
+
+
+@pytest.mark.parametrize('hw,c,image_shapes', [
+    ((416, 416), 20, [(416, 416), (375, 500), (500, 375)]),
+    ((320, 320), 20, [(240, 320)]),
+    ((64, 96), 80, [(100, 333), (64, 96)]),
+])
+def test_decode_bit_exact_vs_c_oracle(dev, hw, c, image_shapes):
+    rt = _rt()
+    rng = np.random.default_rng(11)
+    b = len(image_shapes)
+    ys = _logits(rng, b, hw, c)
+    ys[0][0, 0, 0, 0, :] = [30.0, -30.0, 9.0, -9.0, 100.0] + [0.0] * c  # saturation / clip paths
+    yd = [torch.from_numpy(y).to(dev) for y in ys]
+    ihw = rt.image_hw_tensor(np.array(image_shapes), b, dev)
+    boxes, scores = rt.decode(yd, ANCHORS, c, ihw, hw)
+    torch.cuda.synchronize()
+    boxes, scores = boxes.cpu().numpy(), scores.cpu().numpy()
+    for i in range(b):
+        rb, rs = cpost.decode_image([y[i] for y in ys], ANCHORS, c, image_shapes[i])
+        assert np.array_equal(boxes[i], rb), 'boxes differ from the C oracle (image %d)' % i
+        assert np.array_equal(scores[i], rs), 'scores differ from the C oracle (image %d)' % i
+        nb, ns = pp.decode_image([y[i] for y in ys], ANCHORS, c, image_shapes[i])
+        assert np.allclose(boxes[i], nb, rtol=2e-6, atol=2e-4)  # boxes are in pixels (<= 500)
+        assert np.allclose(scores[i].T, ns, rtol=2e-6, atol=1e-7)
+
+
+def test_decode_zero_logits_kat(dev):
+    """all-zero logits, input 416, image (375,500)."""
+    rt = _rt()
+    ys = [torch.zeros((1, g, g, 3, 25), device=dev) for g in (13, 26, 52)]
+    ihw = rt.image_hw_tensor((375, 500), 1, dev)
+    boxes, scores = rt.decode(ys, ANCHORS, 20, ihw, (416, 416))
+    b = boxes[0].cpu().numpy()
+    assert (scores.cpu().numpy() == 0.25).all()
+    assert b[(6 * 13 + 6) * 3].astype(np.int32).tolist() == [133, 180, 241, 319]
+    assert b[2].astype(np.int32).tolist() == [0, 0, 152, 243]
+    assert b[(12 * 13 + 12) * 3 + 1].astype(np.int32).tolist() == [299, 387, 375, 500]
+    idx, cnt = rt.nms(boxes, scores, 20, 0.2, 0.5)
+    want = [0, 1, 2, 6, 10, 12, 16, 18, 20, 22, 24, 28, 30, 34, 36, 38, 43, 45, 51, 52]  # Appendix D.4
+    assert (cnt.cpu().numpy() == 20).all()
+    assert (idx.cpu().numpy()[0] == np.array(want)).all()
+
+
+def test_yolo_head_and_correct_boxes_layouts(dev):
+    rt = _rt()
+    rng = np.random.default_rng(5)
+    feats = (rng.standard_normal((2, 13, 13, 3, 25)) * 2).astype(np.float32)
+    fd = torch.from_numpy(feats).to(dev)
+    anchors = ANCHORS[[6, 7, 8]]
+    xy, wh, conf, probs, sc = rt.yolo_head(fd, anchors, (416, 416), with_scores=True)
+    ihw = rt.image_hw_tensor((375, 500), 2, dev)
+    boxes = rt.correct_boxes(xy, wh, (416, 416), ihw)
+    torch.cuda.synchronize()
+    for i in range(2):
+        rxy, rwh, rconf, rprobs = pp.yolo_head(feats[i], anchors, (416, 416))
+        assert np.allclose(xy[i].cpu().numpy(), rxy, rtol=2e-6, atol=1e-7)
+        assert np.allclose(wh[i].cpu().numpy(), rwh, rtol=2e-6, atol=1e-7)
+        assert np.allclose(conf[i].cpu().numpy(), rconf, rtol=2e-6, atol=1e-7)
+        assert np.allclose(probs[i].cpu().numpy(), rprobs, rtol=2e-6, atol=1e-7)
+        assert np.allclose(sc[i].cpu().numpy(), rconf * rprobs, rtol=3e-6, atol=1e-7)
+        rb = pp.yolo_correct_boxes(rxy, rwh, (416, 416), (375, 500))
+        assert np.allclose(boxes[i].cpu().numpy(), rb, rtol=3e-6, atol=3e-4)
+
+
+def _random_boxes(rng, n, size=416.0, degenerate=True):
+    cy, cx = rng.uniform(0, size, n), rng.uniform(0, size, n)
+    h, w = rng.uniform(2, size / 2, n), rng.uniform(2, size / 2, n)
+    b = np.stack([cy - h / 2, cx - w / 2, cy + h / 2, cx + w / 2], 1)
+    b = np.clip(b, 0, size).astype(np.float32)
+    if degenerate:
+        b[::17, 2] = b[::17, 0]          # zero-height boxes (area 0 -> IoU 0)
+        b[5::23] = b[5::23][:, [2, 3, 0, 1]]  # flipped corners (canonicalised by IOU())
+        b[7::29] = b[6::29][:len(b[7::29])]   # exact duplicates
+    return b
+
+
+@pytest.mark.parametrize('n,c,score_thr,ties', [(10647, 20, 0.2, False), (10647, 4, 0.0, False),
+                                                (3000, 7, 0.3, True), (100, 3, 0.99, False), (257, 2, 0.1, True)])
+def test_nms_bit_exact(dev, n, c, score_thr, ties):
+    rt = _rt()
+    rng = np.random.default_rng(n + c)
+    b = 2
+    boxes = np.stack([_random_boxes(rng, n) for _ in range(b)])
+    scores = rng.random((b, c, n), dtype=np.float32)
+    if ties:
+        scores = np.round(scores * 8) / 8  # many exactly equal scores -> index tie-break matters
+    scores = scores.astype(np.float32)
+    idx, cnt = rt.nms(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), 20, score_thr, 0.5)
+    torch.cuda.synchronize()
+    idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
+    for i in range(b):
+        for k in range(c):
+            ref = pp.non_max_suppression(boxes[i], scores[i, k], 20, 0.5, score_thr)
+            refc = cpost.nms(boxes[i], scores[i, k], 20, 0.5, score_thr)
+            assert np.array_equal(ref, refc)
+            assert cnt[i, k] == len(ref)
+            assert np.array_equal(idx[i, k, :len(ref)], ref), (i, k)
+            assert (idx[i, k, len(ref):] == -1).all()
+
+
+def test_nms_empty_and_single(dev):
+    rt = _rt()
+    boxes = torch.tensor([[[0., 0., 10., 10.], [1., 1., 9., 9.], [20., 20., 30., 30.]]], device=dev)
+    scores = torch.tensor([[[0.1, 0.1, 0.1], [0.9, 0.8, 0.7]]], device=dev)
+    idx, cnt = rt.nms(boxes, scores, 5, 0.5, 0.5)
+    assert cnt.cpu().tolist() == [[0, 2]]
+    assert idx.cpu().tolist() == [[[-1] * 5, [0, 2, -1, -1, -1]]]
+
+
+def test_pack_matches_oracle_eval(dev):
+    rt = _rt()
+    rng = np.random.default_rng(21)
+    b, c, hw = 3, 20, (416, 416)
+    ys = _logits(rng, b, hw, c, scale=2.5)
+    shapes = [(416, 416), (375, 500), (300, 300)]
+    yd = [torch.from_numpy(y).to(dev) for y in ys]
+    ihw = rt.image_hw_tensor(np.array(shapes), b, dev)
+    boxes, scores = rt.decode(yd, ANCHORS, c, ihw, hw)
+    idx, cnt = rt.nms(boxes, scores, 20, 0.2, 0.5)
+    det, dcnt = rt.pack_detections(boxes, scores, idx, cnt)
+    torch.cuda.synchronize()
+    det, dcnt = det.cpu().numpy(), dcnt.cpu().numpy()
+    for i in range(b):
+        rb, rs, rc, _ = cpost.yolo_eval([y[i] for y in ys], ANCHORS, 3, c, shapes[i], 20, 0.2, 0.5)
+        k = dcnt[i]
+        assert k == len(rs)
+        assert np.array_equal(det[i, :k, 0:4], rb)
+        assert np.array_equal(det[i, :k, 4].view(np.float32), rs)
+        assert np.array_equal(det[i, :k, 5], rc)
+        assert (det[i, k:, 5] == -1).all() and (det[i, k:, :5] == 0).all()

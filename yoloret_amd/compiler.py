@@ -1,0 +1,557 @@
+"""Lowers a ``yoloret_amd.layers`` graph to the fused op list libyoloret_hip.so executes.
+
+Fusions:
+  * Conv2D 1x1 [+bias] [+BatchNorm] [+ReLU6/Swish/sigmoid] [+Add]  -> one POINTWISE op
+    (BN folded to a per-channel scale/shift applied to the fp32 accumulator);
+  * UpSampling2D / MaxPooling2D / Concatenate feeding a 1x1 conv      -> folded into its loads
+    (never materialised); Multiply(SE gate, x) feeding a 1x1 conv     -> gate applied on load;
+  * DepthwiseConv2D + BatchNorm + activation                          -> one DEPTHWISE op;
+  * Conv2D 3x3 s2 on the 3-channel image + BatchNorm + activation     -> STEM op;
+  * Mean -> Conv+bias -> Swish -> Conv+bias -> sigmoid                -> SE_MEAN + SE_FC ops.
+Buffers are placed in one arena with liveness-based reuse; offsets are per image so the
+plan is batch-independent.
+"""
+import ctypes
+
+import numpy as np
+
+from . import runtime as rt
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class Buf:
+    def __init__(self, bid, h, w, c, ld, external_slot=-1, name=''):
+        self.id, self.h, self.w, self.c, self.ld = bid, h, w, c, ld
+        self.external_slot = external_slot
+        self.name = name
+        self.elems = h * w * ld
+        self.first_def = None
+        self.last_use = -1
+        self.offset = -1
+
+
+class Seg:
+    def __init__(self, buf, c, xform='identity'):
+        self.buf, self.c, self.xform = buf, c, xform
+
+
+class Value:
+    """How a symbolic tensor is read: concatenated segments, optionally SE-gated."""
+
+    def __init__(self, segs, gate=None):
+        self.segs, self.gate = segs, gate
+
+    @property
+    def plain(self):
+        return len(self.segs) == 1 and self.segs[0].xform == 'identity' and self.gate is None
+
+
+class OpRec:
+    """Python-side record of one fused op (turned into a ctypes YrOp at pack time)."""
+
+    def __init__(self, kind, name, **kw):
+        self.kind, self.name = kind, name
+        self.act = 'none'
+        self.h = self.w = self.cin = self.cout = 0
+        self.k = self.stride = 0
+        self.se_reduced = 0
+        self.srcs = []
+        self.out = None
+        self.res = None
+        self.gate = None
+        self.params = {}      # role -> numpy builder fn(weights) -> array
+        self.offsets = {}     # role -> float offset in blob
+        self.macs = 0
+        self.__dict__.update(kw)
+
+
+class Plan:
+    def __init__(self, ops, bufs, inputs, outputs, param_shapes, input_shape):
+        self.ops, self.bufs = ops, bufs
+        self.input_buf, self.output_bufs = inputs, outputs
+        self.param_shapes = param_shapes
+        self.input_shape = input_shape
+        self._assign_arena()
+        self._assign_blob_offsets()
+
+    # -- arena: first-fit with liveness reuse (offsets in floats per image, multiples of 4)
+    def _assign_arena(self):
+        arena = [b for b in self.bufs if b.external_slot < 0]
+        for b in arena:
+            assert b.first_def is not None, b.name
+            if b.last_use < b.first_def:
+                b.last_use = b.first_def
+        live = []  # (offset, size, last_use)
+        total = 0
+        for b in sorted(arena, key=lambda x: x.first_def):
+            live = [l for l in live if l[2] >= b.first_def]  # a buffer read by op i may not be overwritten by op i
+            size = round_up(b.elems, 4)
+            off = 0
+            for lo, ls, _ in sorted(live):
+                if off + size <= lo:
+                    break
+                off = max(off, lo + ls)
+            b.offset = off
+            live.append((off, size, b.last_use))
+            total = max(total, off + size)
+        self.arena_elems_per_image = total
+
+    def _assign_blob_offsets(self):
+        off = 0
+        self.blob_layout = []
+        for op in self.ops:
+            for role, (shape, _fn) in op.params.items():
+                n = int(np.prod(shape))
+                op.offsets[role] = off
+                self.blob_layout.append((op, role, off, shape))
+                off += round_up(n, 4)
+        self.blob_floats = max(off, 4)
+
+    def build_blob(self, weights):
+        blob = np.zeros(self.blob_floats, np.float32)
+        for op, role, off, shape in self.blob_layout:
+            arr = np.asarray(op.params[role][1](weights), np.float32)
+            assert tuple(arr.shape) == tuple(shape), (op.name, role, arr.shape, shape)
+            blob[off:off + arr.size] = arr.ravel()
+        return blob
+
+    def c_arrays(self):
+        ops = (rt.YrOp * len(self.ops))()
+        for i, r in enumerate(self.ops):
+            o = ops[i]
+            o.kind, o.act = r.kind, rt.ACT[r.act]
+            o.h, o.w, o.cin, o.cout, o.k, o.stride = r.h, r.w, r.cin, r.cout, r.k, r.stride
+            o.nsrc, o.se_reduced = len(r.srcs), r.se_reduced
+            for j, s in enumerate(r.srcs):
+                o.src[j].ptr = None
+                o.src[j].buf = s.buf.id
+                o.src[j].h, o.src[j].w, o.src[j].c, o.src[j].ld = s.buf.h, s.buf.w, s.c, s.buf.ld
+                o.src[j].xform = rt.XFORM[s.xform]
+            o.out_buf, o.out_ld = r.out.id, r.out.ld
+            o.res_buf, o.res_ld = (r.res.id, r.res.ld) if r.res is not None else (-1, 0)
+            o.gate_buf, o.gate_ld = (r.gate.id, r.gate.ld) if r.gate is not None else (-1, 0)
+            roles = {'wgt': 'wgt_off', 'scale': 'scale_off', 'shift': 'shift_off', 'wgt2': 'wgt2_off',
+                     'b1': 'b1_off', 'b2': 'b2_off'}
+            for role, field in roles.items():
+                setattr(o, field, r.offsets.get(role, -1))
+        bufs = (rt.YrBuf * len(self.bufs))()
+        for i, b in enumerate(self.bufs):
+            assert b.id == i
+            bufs[i].elems_per_image = b.elems
+            bufs[i].arena_off_per_image = b.offset if b.external_slot < 0 else -1
+            bufs[i].external_slot = b.external_slot
+        return ops, bufs
+
+    # -- reporting
+    def total_macs(self):
+        return sum(op.macs for op in self.ops)
+
+    def algorithmic_bytes_per_image(self, num_boxes=0, num_classes=0, batch=None):
+        """conv-granular activation reads+writes (+residual reads) in fp32;
+        upsample/maxpool/concat/wsum/SE-scale free; SE mean costs its C outputs."""
+        elems = 0
+        wsum_outs = set(op.out.id for op in self.ops if op.kind == rt.OP_WSUM)
+
+        def src_elems(op, s):
+            # SURVEY.md Appendix B accounting (the agreed figure: 198.9 MB/img for MBV2x0.75@416):
+            # the 4x4-pooled tap (rfcr_b4c) is counted at its pre-pool size, every other source
+            # at the consumer's size (td2 reads 26x26x424, bu2 reads 26x26x203).
+            if s.xform == 'maxpool4':
+                return s.buf.h * s.buf.w * s.c
+            return op.h * op.w * s.c
+
+        for op in self.ops:
+            if op.kind in (rt.OP_STEM, rt.OP_POINTWISE, rt.OP_DEPTHWISE):
+                if op.kind == rt.OP_POINTWISE and op.h == 1 and op.w == 1:
+                    continue
+                elems += op.h * op.w * op.cout
+                if op.kind == rt.OP_DEPTHWISE or op.kind == rt.OP_STEM:
+                    s = op.srcs[0]
+                    if s.buf.id not in wsum_outs:  # the weighted sum is folded into the DW's loads
+                        elems += s.buf.h * s.buf.w * s.c
+                else:
+                    elems += sum(src_elems(op, s) for s in op.srcs)
+                if op.res is not None:
+                    elems += op.h * op.w * op.cout
+            elif op.kind == rt.OP_WSUM:
+                elems += sum(s.buf.h * s.buf.w * s.c for s in op.srcs)
+            elif op.kind == rt.OP_SE_MEAN:
+                elems += op.cout
+        return elems * 4
+
+
+class Compiler:
+    def __init__(self, inputs, outputs):
+        self.inputs = inputs
+        self.outputs = list(outputs)
+        self.bufs = []
+        self.ops = []
+        self.values = {}       # Tensor -> Value
+        self.param_shapes = {}
+        self.consumers = {}
+
+    # ---------------------------------------------------------------- graph utilities
+    def _topo(self):
+        order, seen = [], set()
+
+        def visit(t):
+            n = t.node
+            if n is None or id(n) in seen:
+                return
+            seen.add(id(n))
+            for i in n.inputs:
+                visit(i)
+            order.append(n)
+
+        import sys
+        sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
+        for o in self.outputs:
+            visit(o)
+        for n in order:
+            for i in n.inputs:
+                self.consumers.setdefault(id(i), []).append(n)
+        return order
+
+    def _sole_consumer(self, t, op=None, **attrs):
+        cs = self.consumers.get(id(t), [])
+        if len(cs) != 1 or any(t is o for o in self.outputs):
+            return None
+        n = cs[0]
+        if op is not None and n.op != op:
+            return None
+        for k, v in attrs.items():
+            if n.attrs.get(k) != v:
+                return None
+        return n
+
+    def _new_buf(self, h, w, c, ld=None, external_slot=-1, name=''):
+        b = Buf(len(self.bufs), h, w, c, round_up(c, 4) if ld is None else ld, external_slot, name)
+        self.bufs.append(b)
+        return b
+
+    def _emit(self, op):
+        idx = len(self.ops)
+        self.ops.append(op)
+        op.out.first_def = idx if op.out.first_def is None else op.out.first_def
+        for s in op.srcs:
+            s.buf.last_use = max(s.buf.last_use, idx)
+        for b in (op.res, op.gate):
+            if b is not None:
+                b.last_use = max(b.last_use, idx)
+        return op
+
+    def _out_buf_for(self, t, name):
+        """Model outputs are written straight into the caller's dense y buffers."""
+        for slot, o in enumerate(self.outputs, start=1):
+            if t is o or (o.node is not None and o.node.op == 'reshape5' and o.node.inputs[0] is t):
+                h, w, c = t.shape
+                return self._new_buf(h, w, c, ld=c, external_slot=slot, name=name)
+        h, w, c = t.shape
+        return self._new_buf(h, w, c, name=name)
+
+    def _plain(self, t):
+        """Value of t as a single identity segment, materialising through GATHER if needed."""
+        v = self.values[id(t)]
+        if v.plain:
+            return v.segs[0]
+        if v.gate is not None:
+            raise NotImplementedError('SE-gated tensor consumed by something other than a 1x1 conv')
+        h, w, c = t.shape
+        out = self._new_buf(h, w, c, name=t.name + ':gather')
+        op = OpRec(rt.OP_GATHER, t.name + ':gather', h=h, w=w, cin=c, cout=c, srcs=list(v.segs), out=out)
+        self._emit(op)
+        seg = Seg(out, c)
+        self.values[id(t)] = Value([seg])
+        return seg
+
+    # ---------------------------------------------------------------- parameter helpers
+    @staticmethod
+    def _bn_fold(bn_node, bias_name, cout, pad_to=None):
+        """-> (scale_fn, shift_fn): y = acc*scale + shift  ==  BN(acc + bias)."""
+        n = cout if pad_to is None else pad_to
+
+        def parts(wd):
+            if bn_node is not None:
+                p = bn_node.name + '/'
+                g, b = wd[p + 'gamma'].astype(np.float64), wd[p + 'beta'].astype(np.float64)
+                m, v = wd[p + 'moving_mean'].astype(np.float64), wd[p + 'moving_variance'].astype(np.float64)
+                scale = g / np.sqrt(v + bn_node.attrs['epsilon'])
+                shift = b - m * scale
+            else:
+                scale, shift = np.ones(cout), np.zeros(cout)
+            if bias_name is not None:
+                shift = shift + wd[bias_name].astype(np.float64) * scale
+            return scale, shift
+
+        def pad(a):
+            out = np.zeros(n, np.float32)
+            out[:cout] = a
+            return out
+
+        return (lambda wd: pad(parts(wd)[0])), (lambda wd: pad(parts(wd)[1]))
+
+    def _absorb_bn_act(self, t):
+        """Follow t -> [BatchNorm] -> [act]; returns (bn_node|None, act, last_tensor)."""
+        bn = self._sole_consumer(t, 'batchnorm')
+        if bn is not None:
+            t = bn.output
+        a = self._sole_consumer(t, 'act')
+        act = 'none'
+        if a is not None:
+            act, t = a.attrs['kind'], a.output
+        return bn, act, t
+
+    # ---------------------------------------------------------------- lowering
+    def compile(self):
+        order = self._topo()
+        for n in order:
+            self.param_shapes.update(n.params)
+        x = self.inputs
+        h, w, c = x.shape
+        in_buf = self._new_buf(h, w, c, ld=c, external_slot=0, name='images')
+        in_buf.first_def = -1
+        self.values[id(x)] = Value([Seg(in_buf, c)])
+        done = set()
+        for n in order:
+            if id(n) in done:
+                continue
+            getattr(self, '_lower_' + n.op)(n, done)
+        outs = []
+        for o in self.outputs:
+            v = self.values[id(o)]
+            if not v.plain or v.segs[0].buf.external_slot < 1:
+                raise NotImplementedError('model outputs must be produced by a 1x1 convolution')
+            outs.append(v.segs[0].buf)
+        return Plan(self.ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape)
+
+    def _lower_conv2d(self, n, done):
+        x = n.inputs[0]
+        k, s = n.attrs['k'], n.attrs['stride']
+        cin, cout = x.shape[2], n.output.shape[2]
+        kname = n.name + '/kernel'
+        bias = n.name + '/bias' if n.attrs['use_bias'] else None
+        if k == 3 and s == 2 and cin == 3:
+            bn, act, last = self._absorb_bn_act(n.output)
+            src = self._plain(x)
+            if src.buf.ld != 3:
+                raise NotImplementedError('stem expects the dense 3-channel image')
+            out = self._out_buf_for(last, n.name)
+            ldw = round_up(cout, 4)
+            op = OpRec(rt.OP_STEM, n.name, act=act, h=last.shape[0], w=last.shape[1], cin=3, cout=cout, k=3,
+                       stride=2, srcs=[src], out=out, macs=last.shape[0] * last.shape[1] * 27 * cout)
+
+            def wfn(wd, kname=kname, ldw=ldw, cout=cout):
+                o = np.zeros((27, ldw), np.float32)
+                o[:, :cout] = wd[kname].reshape(27, cout)  # (ky,kx,ci) major == HWIO flattening
+                return o
+            sc, sh = self._bn_fold(bn, bias, cout, ldw)
+            op.params = {'wgt': ((27, ldw), wfn), 'scale': ((ldw,), sc), 'shift': ((ldw,), sh)}
+            self._emit(op)
+            self._finish(n, bn, last, out, done)
+            return
+        if k != 1 or s != 1:
+            raise NotImplementedError('Conv2D %dx%d stride %d with %d input channels is not on the detection path'
+                                      % (k, k, s, cin))
+        # squeeze-excite FC pair?
+        if x.shape[0] == 1 and x.shape[1] == 1 and self._try_se_fc(n, done):
+            return
+        bn, act, last = self._absorb_bn_act(n.output)
+        res = None
+        add = self._sole_consumer(last, 'add')
+        add_node = None
+        if add is not None:
+            other = add.inputs[0] if add.inputs[1] is last else add.inputs[1]
+            if id(other) in self.values:
+                res = self._plain(other).buf
+                add_node, last = add, add.output
+        v = self.values[id(x)]
+        segs = list(v.segs)
+        if len(segs) > rt.YR_MAX_SRC:
+            raise NotImplementedError('more than %d concatenated sources' % rt.YR_MAX_SRC)
+        out = self._out_buf_for(last, n.name)
+        hh, ww = last.shape[0], last.shape[1]
+        op = OpRec(rt.OP_POINTWISE, n.name, act=act, h=hh, w=ww, cin=cin, cout=cout, srcs=segs, out=out,
+                   res=res, gate=v.gate, macs=hh * ww * cin * cout)
+        kp = sum(round_up(sg.c, 4) for sg in segs)
+
+        def wfn(wd, kname=kname, segs=[sg.c for sg in segs], kp=kp, cout=cout):
+            wk = wd[kname].reshape(-1, cout)  # [cin, cout]
+            o = np.zeros((cout, kp), np.float32)
+            d = kb = 0
+            for c_ in segs:
+                o[:, kb:kb + c_] = wk[d:d + c_].T
+                d += c_
+                kb += round_up(c_, 4)
+            return o
+        op.params = {'wgt': ((cout, kp), wfn)}
+        if bn is not None or bias is not None:
+            sc, sh = self._bn_fold(bn, bias, cout)
+            op.params['scale'] = ((cout,), sc)
+            op.params['shift'] = ((cout,), sh)
+        self._emit(op)
+        self._finish(n, bn, last, out, done, add_node)
+
+    def _finish(self, n, bn, last, out, done, add_node=None):
+        """Mark absorbed nodes done and publish the op's output value."""
+        t = n.output
+        done.add(id(n))
+        while t is not last:
+            c = self.consumers[id(t)][0]
+            done.add(id(c))
+            t = c.output
+        self.values[id(last)] = Value([Seg(out, last.shape[2])])
+
+    def _try_se_fc(self, n, done):
+        """mean -> conv(+bias) -> Swish -> conv(+bias) -> sigmoid (efficientnet.py:417-434)."""
+        x = n.inputs[0]
+        if x.node is None or x.node.op != 'mean' or not n.attrs['use_bias']:
+            return False
+        a1 = self._sole_consumer(n.output, 'act', kind='swish')
+        if a1 is None:
+            return False
+        c2 = self._sole_consumer(a1.output, 'conv2d', k=1)
+        if c2 is None or not c2.attrs['use_bias']:
+            return False
+        a2 = self._sole_consumer(c2.output, 'act', kind='sigmoid')
+        if a2 is None:
+            return False
+        c, r = x.shape[2], n.output.shape[2]
+        if c2.output.shape[2] != c:
+            return False
+        src = self._plain(x)
+        ldc = round_up(c, 4)
+        out = self._new_buf(1, 1, c, name=n.name + ':gate')
+        op = OpRec(rt.OP_SE_FC, n.name, h=1, w=1, cin=c, cout=c, se_reduced=r, srcs=[src], out=out,
+                   macs=2 * c * r)
+        k1, b1, k2, b2 = n.name + '/kernel', n.name + '/bias', c2.name + '/kernel', c2.name + '/bias'
+
+        def w1(wd):
+            o = np.zeros((r, ldc), np.float32)
+            o[:, :c] = wd[k1].reshape(c, r).T
+            return o
+
+        def w2(wd):
+            o = np.zeros((r, ldc), np.float32)
+            o[:, :c] = wd[k2].reshape(r, c)
+            return o
+
+        def bb2(wd):
+            o = np.zeros(ldc, np.float32)
+            o[:c] = wd[b2]
+            return o
+        op.params = {'wgt': ((r, ldc), w1), 'b1': ((r,), lambda wd: wd[b1]), 'wgt2': ((r, ldc), w2),
+                     'b2': ((ldc,), bb2)}
+        self._emit(op)
+        for m in (n, a1, c2, a2):
+            done.add(id(m))
+        self.values[id(a2.output)] = Value([Seg(out, c)])
+        return True
+
+    def _lower_depthwise(self, n, done):
+        x = n.inputs[0]
+        k, s = n.attrs['k'], n.attrs['stride']
+        c = x.shape[2]
+        bn, act, last = self._absorb_bn_act(n.output)
+        src = self._plain(x)
+        out = self._out_buf_for(last, n.name)
+        ldc = round_up(c, 4)
+        op = OpRec(rt.OP_DEPTHWISE, n.name, act=act, h=last.shape[0], w=last.shape[1], cin=c, cout=c, k=k,
+                   stride=s, srcs=[src], out=out, macs=last.shape[0] * last.shape[1] * k * k * c)
+        kname = n.name + '/depthwise_kernel'
+
+        def wfn(wd):
+            o = np.zeros((k * k, ldc), np.float32)
+            o[:, :c] = wd[kname].reshape(k * k, c)
+            return o
+        sc, sh = self._bn_fold(bn, None, c, ldc)
+        op.params = {'wgt': ((k * k, ldc), wfn), 'scale': ((ldc,), sc), 'shift': ((ldc,), sh)}
+        self._emit(op)
+        self._finish(n, bn, last, out, done)
+
+    def _lower_mean(self, n, done):
+        x = n.inputs[0]
+        src = self._plain(x)
+        c = x.shape[2]
+        out = self._new_buf(1, 1, c, name=n.name)
+        self._emit(OpRec(rt.OP_SE_MEAN, n.name, h=1, w=1, cin=c, cout=c, srcs=[src], out=out))
+        done.add(id(n))
+        self.values[id(n.output)] = Value([Seg(out, c)])
+
+    def _lower_multiply(self, n, done):
+        a, b = n.inputs
+        gate, x = (a, b) if a.shape[0] * a.shape[1] == 1 else (b, a)
+        if gate.shape[:2] != (1, 1) or gate.shape[2] != x.shape[2]:
+            raise NotImplementedError('Multiply is only supported as the squeeze-excite gate')
+        g = self._plain(gate)
+        xs = self._plain(x)
+        done.add(id(n))
+        self.values[id(n.output)] = Value([xs], gate=g.buf)
+
+    def _lower_concat(self, n, done):
+        segs = []
+        for t in n.inputs:
+            v = self.values[id(t)]
+            if v.gate is not None:
+                raise NotImplementedError('concat of an SE-gated tensor')
+            segs.extend(v.segs)
+        done.add(id(n))
+        self.values[id(n.output)] = Value(segs)
+        if len(segs) > rt.YR_MAX_SRC:
+            self._plain(n.output)
+
+    def _xform(self, n, done, xf):
+        v = self.values[id(n.inputs[0])]
+        if v.gate is not None or any(s.xform != 'identity' for s in v.segs):
+            seg = self._plain(n.inputs[0])
+            v = Value([seg])
+        done.add(id(n))
+        self.values[id(n.output)] = Value([Seg(s.buf, s.c, xf) for s in v.segs])
+
+    def _lower_upsample2(self, n, done):
+        self._xform(n, done, 'up2')
+
+    def _lower_maxpool(self, n, done):
+        size = n.attrs['size']
+        if size not in (2, 4):
+            raise NotImplementedError('MaxPooling2D size %d' % size)
+        h, w = n.inputs[0].shape[:2]
+        if h % size or w % size:
+            raise NotImplementedError('MaxPooling2D on a size not divisible by the pool')
+        self._xform(n, done, 'maxpool%d' % size)
+
+    def _lower_wsum(self, n, done):
+        segs = []
+        for t in n.inputs:
+            v = self.values[id(t)]
+            if len(v.segs) != 1 or v.gate is not None:
+                segs.append(self._plain(t))
+            else:
+                segs.append(v.segs[0])
+        h, w, c = n.output.shape
+        out = self._out_buf_for(n.output, n.name)
+        aname = n.name + '/alpha'
+        op = OpRec(rt.OP_WSUM, n.name, h=h, w=w, cin=c, cout=c, srcs=segs, out=out)
+        op.params = {'wgt': ((4,), lambda wd: wd[aname])}
+        self._emit(op)
+        done.add(id(n))
+        self.values[id(n.output)] = Value([Seg(out, c)])
+
+    def _lower_reshape5(self, n, done):
+        done.add(id(n))
+        self.values[id(n.output)] = self.values[id(n.inputs[0])]
+
+    def _lower_batchnorm(self, n, done):
+        raise NotImplementedError('BatchNormalization %s does not follow a convolution' % n.name)
+
+    def _lower_act(self, n, done):
+        raise NotImplementedError('activation %s does not follow a fused convolution' % n.name)
+
+    def _lower_add(self, n, done):
+        raise NotImplementedError('Add %s does not follow a fused 1x1 convolution' % n.name)
+
+
+def compile_graph(inputs, outputs):
+    return Compiler(inputs, outputs).compile()

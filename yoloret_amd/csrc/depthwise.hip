@@ -1,0 +1,121 @@
+// Depthwise k x k convolution (k in {3,5}, stride in {1,2}, TF 'SAME' padding) with fused
+// BatchNorm scale/shift + ReLU6/Swish, NHWC, 4 channels (one float4) per lane.  Replaces TF's
+// DepthwiseConv2dNative + FusedBatchNormV3 + Relu6/Swish used by MobileNetV2's *_depthwise
+// layers [3P], reference code/yolo3/model.py:20-24 (RFCR 5x5) and
+// code/yolo3/efficientnet.py:501-510 (MBConv).
+//
+// Each lane produces XT consecutive output pixels of one row for one channel quad, so a
+// row of input taps is loaded once per XT outputs; consecutive lanes take consecutive
+// channel quads (16 B apart) => fully coalesced loads and stores.
+#include "yr_common.h"
+
+struct DwArgs {
+    const float* in;     // [B][Hi][Wi][ld_in]
+    const float* w;      // [K*K][ld_w] (channel-fastest)
+    const float* scale;  // [C]
+    const float* shift;  // [C]
+    float* out;          // [B][Ho][Wo][ld_out]
+    int B, Hi, Wi, Ho, Wo, C4;  // C4 = ceil(C/4)
+    int ld_in, ld_w, ld_out;
+    int pad_t, pad_l;
+    int act;
+    int xstrips;         // ceil(Wo / XT)
+    long long total;     // B*Ho*xstrips*C4
+};
+
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+    return make_float4(__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y),
+                       __builtin_fmaf(a.z, b.z, c.z), __builtin_fmaf(a.w, b.w, c.w));
+}
+
+template <int K, int S, int XT>
+__global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= a.total) return;
+    const int cq = (int)(gid % a.C4);
+    long long t = gid / a.C4;
+    const int xs = (int)(t % a.xstrips);
+    t /= a.xstrips;
+    const int y = (int)(t % a.Ho);
+    const int b = (int)(t / a.Ho);
+    const int c = cq * 4;
+    const int x0 = xs * XT;
+    constexpr int COLS = (XT - 1) * S + K;
+
+    float4 acc[XT];
+#pragma unroll
+    for (int i = 0; i < XT; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int iy0 = y * S - a.pad_t;
+    const int ix0 = x0 * S - a.pad_l;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        const int iy = iy0 + ky;
+        if (iy < 0 || iy >= a.Hi) continue;  // zero padding row
+        const float* rowp = a.in + ((size_t)(b * a.Hi + iy) * a.Wi) * a.ld_in + c;
+        float4 col[COLS];
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) {
+            const int ix = ix0 + j;
+            col[j] = (ix >= 0 && ix < a.Wi) ? *reinterpret_cast<const float4*>(rowp + (size_t)ix * a.ld_in)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const float4 wv = *reinterpret_cast<const float4*>(a.w + (size_t)(ky * K + kx) * a.ld_w + c);
+#pragma unroll
+            for (int i = 0; i < XT; ++i) acc[i] = fma4(col[i * S + kx], wv, acc[i]);
+        }
+    }
+    const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(a.shift + c);
+    float* op = a.out + ((size_t)(b * a.Ho + y) * a.Wo + x0) * a.ld_out + c;
+#pragma unroll
+    for (int i = 0; i < XT; ++i) {
+        if (x0 + i < a.Wo) {
+            float4 v = yr_apply_act4(fma4(acc[i], sc, sh), a.act);
+            *reinterpret_cast<float4*>(op + (size_t)i * a.ld_out) = v;
+        }
+    }
+}
+
+template <int K, int S, int XT>
+static int launch_dw(DwArgs a, hipStream_t s) {
+    a.xstrips = (a.Wo + XT - 1) / XT;
+    a.total = (long long)a.B * a.Ho * a.xstrips * a.C4;
+    const long long blocks = (a.total + 255) / 256;
+    YR_REQUIRE(blocks < (1ll << 31), "depthwise: grid too large");
+    hipLaunchKernelGGL((dw_kernel<K, S, XT>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
+int yr_launch_depthwise(const yr_op& op, int batch, hipStream_t s) {
+    YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY, "depthwise: needs one identity source");
+    const yr_src& in = op.src[0];
+    YR_REQUIRE(op.k == 3 || op.k == 5, "depthwise: kernel size %d unsupported", op.k);
+    YR_REQUIRE(op.stride == 1 || op.stride == 2, "depthwise: stride %d unsupported", op.stride);
+    YR_REQUIRE(in.c == op.cout && op.cin == op.cout, "depthwise: channel mismatch");
+    YR_REQUIRE(in.ld % 4 == 0 && op.out_ld % 4 == 0 && in.ld >= yr_round_up(in.c, 4) && op.out_ld >= yr_round_up(in.c, 4),
+               "depthwise: ld must be a multiple of 4 and cover round_up(c,4)");
+    YR_REQUIRE(in.ptr && op.out && op.wgt && op.scale && op.shift, "depthwise: null pointer");
+    YR_REQUIRE(((uintptr_t)in.ptr | (uintptr_t)op.out | (uintptr_t)op.wgt | (uintptr_t)op.scale | (uintptr_t)op.shift) % 16 == 0,
+               "depthwise: pointers must be 16-byte aligned");
+    DwArgs a;
+    a.in = in.ptr; a.w = op.wgt; a.scale = op.scale; a.shift = op.shift; a.out = op.out;
+    a.B = batch; a.Hi = in.h; a.Wi = in.w;
+    a.Ho = (in.h + op.stride - 1) / op.stride;
+    a.Wo = (in.w + op.stride - 1) / op.stride;
+    YR_REQUIRE(a.Ho == op.h && a.Wo == op.w, "depthwise: output dims %dx%d != SAME(%dx%d / %d)", op.h, op.w, in.h, in.w, op.stride);
+    a.C4 = (in.c + 3) / 4;
+    a.ld_in = in.ld; a.ld_w = yr_round_up(in.c, 4); a.ld_out = op.out_ld;
+    // TF 'SAME': pad_total = max((out-1)*s + k - in, 0); before = total/2 (extra goes bottom/right)
+    const int pth = (a.Ho - 1) * op.stride + op.k - in.h, ptw = (a.Wo - 1) * op.stride + op.k - in.w;
+    a.pad_t = (pth > 0 ? pth : 0) / 2;
+    a.pad_l = (ptw > 0 ? ptw : 0) / 2;
+    a.act = op.act;
+    if (op.k == 3 && op.stride == 1) return launch_dw<3, 1, 4>(a, s);
+    if (op.k == 3 && op.stride == 2) return launch_dw<3, 2, 2>(a, s);
+    if (op.k == 5 && op.stride == 1) return launch_dw<5, 1, 4>(a, s);
+    return launch_dw<5, 2, 2>(a, s);
+}

@@ -1,0 +1,218 @@
+// Small memory-bound ops around the convolutions:
+//   SE_MEAN  - tf.reduce_mean over H,W           (reference code/yolo3/efficientnet.py:391-403,417)
+//   SE_FC    - 1x1+bias -> Swish -> 1x1+bias -> sigmoid on the pooled vector (efficientnet.py:419-434);
+//              the Multiply (:435) is folded into the consumer pointwise kernel's loads.
+//   WSUM     - WeightedSum of 4 gathered tensors  (reference code/yolo3/model.py:117-137,157)
+//   GATHER   - materialised UpSampling2D / MaxPooling2D / Concatenate (model.py:139-144,164-166);
+//              the fast path folds these into consumer loads, this kernel exists for
+//              unfused use and for testing the gather machinery in isolation.
+#include "yr_common.h"
+
+// ------------------------------------------------------------------ SE mean
+struct MeanArgs {
+    const float* in;  // [B][HW][ld]
+    float* out;       // [B][ld_out]
+    int HW, C4, ld, ld_out, C;
+    float inv;        // unused (division keeps reduce_mean's sum/count form)
+};
+
+// grid (ceil(C4/16), B); block 256 = 16 pixel lanes x 16 channel quads.  Fixed summation
+// order => run-to-run deterministic.
+__global__ __launch_bounds__(256) void se_mean_kernel(MeanArgs a) {
+    __shared__ float4 part[16][16];
+    const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int cq = blockIdx.x * 16 + q;
+    const int b = blockIdx.y;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cq < a.C4) {
+        const float* p = a.in + (size_t)b * a.HW * a.ld + cq * 4;
+        for (int i = pl; i < a.HW; i += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)i * a.ld);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    part[pl][q] = s;
+    __syncthreads();
+    if (pl == 0 && cq < a.C4) {
+        float4 t = part[0][q];
+        for (int i = 1; i < 16; ++i) {
+            const float4 v = part[i][q];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        const float n = (float)a.HW;
+        float4 m = make_float4(t.x / n, t.y / n, t.z / n, t.w / n);
+        const int c = cq * 4;
+        if (c + 1 >= a.C) m.y = 0.f;
+        if (c + 2 >= a.C) m.z = 0.f;
+        if (c + 3 >= a.C) m.w = 0.f;
+        *reinterpret_cast<float4*>(a.out + (size_t)b * a.ld_out + c) = m;
+    }
+}
+
+int yr_launch_se_mean(const yr_op& op, int batch, hipStream_t s) {
+    YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY, "se_mean: needs one identity source");
+    const yr_src& in = op.src[0];
+    YR_REQUIRE(in.ptr && op.out && in.ld % 4 == 0 && op.out_ld % 4 == 0 && op.out_ld >= yr_round_up(in.c, 4),
+               "se_mean: bad pointers / strides");
+    MeanArgs a;
+    a.in = in.ptr; a.out = op.out; a.HW = in.h * in.w; a.C = in.c; a.C4 = (in.c + 3) / 4;
+    a.ld = in.ld; a.ld_out = op.out_ld; a.inv = 0.f;
+    hipLaunchKernelGGL(se_mean_kernel, dim3((a.C4 + 15) / 16, batch), dim3(256), 0, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
+// ------------------------------------------------------------------ SE FCs
+struct FcArgs {
+    const float* mean;  // [B][ld_mean]
+    const float* w1t;   // [R][ldc]   (transposed Keras kernel: hidden j, channel c)
+    const float* b1;    // [R]
+    const float* w2;    // [R][ldc]   (Keras kernel [1,1,R,C])
+    const float* b2;    // [ldc]
+    float* gate;        // [B][ld_gate]
+    int C, R, ldc, ld_mean, ld_gate;
+};
+
+// one block per image; dynamic LDS = (ldc + R) floats
+__global__ __launch_bounds__(256) void se_fc_kernel(FcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* mean = sm;            // [ldc]
+    float* hid = sm + a.ldc;     // [R]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < a.ldc; c += 256) mean[c] = (c < a.C) ? a.mean[(size_t)b * a.ld_mean + c] : 0.f;
+    __syncthreads();
+    for (int j = wave; j < a.R; j += 4) {
+        const float* wr = a.w1t + (size_t)j * a.ldc;
+        float s = 0.f;
+        for (int c = lane; c < a.C; c += 64) s = __builtin_fmaf(wr[c], mean[c], s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) hid[j] = yr_apply_act(s + a.b1[j], YR_ACT_SWISH);
+    }
+    __syncthreads();
+    for (int c = tid; c < a.ld_gate; c += 256) {
+        float v = 0.f;
+        if (c < a.C) {
+            float s = 0.f;
+            for (int j = 0; j < a.R; ++j) s = __builtin_fmaf(hid[j], a.w2[(size_t)j * a.ldc + c], s);
+            v = yr_sigmoid(s + a.b2[c]);
+        }
+        a.gate[(size_t)b * a.ld_gate + c] = v;
+    }
+}
+
+int yr_launch_se_fc(const yr_op& op, int batch, hipStream_t s) {
+    YR_REQUIRE(op.nsrc == 1, "se_fc: needs one source (the pooled vector)");
+    const yr_src& in = op.src[0];
+    YR_REQUIRE(in.ptr && op.out && op.wgt && op.wgt2 && op.b1 && op.b2, "se_fc: null pointer");
+    YR_REQUIRE(op.se_reduced >= 1 && in.c == op.cout, "se_fc: bad widths");
+    FcArgs a;
+    a.mean = in.ptr; a.w1t = op.wgt; a.b1 = op.b1; a.w2 = op.wgt2; a.b2 = op.b2; a.gate = op.out;
+    a.C = in.c; a.R = op.se_reduced; a.ldc = yr_round_up(in.c, 4); a.ld_mean = in.ld; a.ld_gate = op.out_ld;
+    YR_REQUIRE(op.out_ld >= a.ldc, "se_fc: gate ld too small");
+    const size_t lds = (size_t)(a.ldc + a.R) * sizeof(float);
+    YR_REQUIRE(lds <= 64 * 1024, "se_fc: widths too large for LDS");
+    hipLaunchKernelGGL(se_fc_kernel, dim3(batch), dim3(256), lds, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
+// ------------------------------------------------------------------ WeightedSum
+struct WsumArgs {
+    DSrc s[4];
+    const float* alpha;  // [4]
+    float* out;
+    int H, W, C4, ld_out;
+    long long total;
+};
+
+__global__ __launch_bounds__(256) void wsum_kernel(WsumArgs a) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= a.total) return;
+    const int cq = (int)(gid % a.C4);
+    long long t = gid / a.C4;
+    const int x = (int)(t % a.W);
+    t /= a.W;
+    const int y = (int)(t % a.H);
+    const int b = (int)(t / a.H);
+    const float a0 = a.alpha[0], a1 = a.alpha[1], a2 = a.alpha[2], a3 = a.alpha[3];
+    const float4 v0 = yr_load_src_quad(a.s[0], b, y, x, cq * 4);
+    const float4 v1 = yr_load_src_quad(a.s[1], b, y, x, cq * 4);
+    const float4 v2 = yr_load_src_quad(a.s[2], b, y, x, cq * 4);
+    const float4 v3 = yr_load_src_quad(a.s[3], b, y, x, cq * 4);
+    // reference order (model.py:134): a0*m0 + a1*m1 + a2*m2 + a3*m3, left to right, no contraction
+    float4 r;
+    r.x = a0 * v0.x + a1 * v1.x + a2 * v2.x + a3 * v3.x;
+    r.y = a0 * v0.y + a1 * v1.y + a2 * v2.y + a3 * v3.y;
+    r.z = a0 * v0.z + a1 * v1.z + a2 * v2.z + a3 * v3.z;
+    r.w = a0 * v0.w + a1 * v1.w + a2 * v2.w + a3 * v3.w;
+    *reinterpret_cast<float4*>(a.out + ((size_t)(b * a.H + y) * a.W + x) * a.ld_out + cq * 4) = r;
+}
+
+int yr_launch_wsum(const yr_op& op, int batch, hipStream_t s) {
+    YR_REQUIRE(op.nsrc == 4, "wsum: needs exactly 4 sources");
+    DSrcSet S;
+    int rc = yr_make_srcset(op, &S);
+    if (rc) return rc;
+    for (int i = 0; i < 4; ++i) YR_REQUIRE(op.src[i].c == op.cout, "wsum: source %d has %d channels, expected %d", i, op.src[i].c, op.cout);
+    YR_REQUIRE(op.wgt && op.out && op.out_ld % 4 == 0 && op.out_ld >= yr_round_up(op.cout, 4), "wsum: bad out/alpha");
+    WsumArgs a;
+    for (int i = 0; i < 4; ++i) a.s[i] = S.s[i];
+    a.alpha = op.wgt; a.out = op.out; a.H = op.h; a.W = op.w; a.C4 = (op.cout + 3) / 4; a.ld_out = op.out_ld;
+    a.total = (long long)batch * op.h * op.w * a.C4;
+    hipLaunchKernelGGL(wsum_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
+// ------------------------------------------------------------------ gather (materialise)
+struct GatherArgs {
+    DSrcSet S;
+    int dense_base[YR_MAX_SRC];  // start of each segment in the dense concat output
+    float* out;
+    int H, W, KQ, ld_out;
+    long long total;
+};
+
+__global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= a.total) return;
+    const int kq = (int)(gid % a.KQ);
+    long long t = gid / a.KQ;
+    const int x = (int)(t % a.W);
+    t /= a.W;
+    const int y = (int)(t % a.H);
+    const int b = (int)(t / a.H);
+    const int k = kq * 4;
+    int si = 0;
+    for (int i = 1; i < a.S.n; ++i)
+        if (k >= a.S.s[i].kbase) si = i;
+    DSrc s = a.S.s[0];
+    int db = a.dense_base[0];
+    if (si == 1) { s = a.S.s[1]; db = a.dense_base[1]; }
+    if (si == 2) { s = a.S.s[2]; db = a.dense_base[2]; }
+    if (si == 3) { s = a.S.s[3]; db = a.dense_base[3]; }
+    const int kk = k - s.kbase;
+    const float4 v = yr_load_src_quad(s, b, y, x, kk);
+    float* op = a.out + ((size_t)(b * a.H + y) * a.W + x) * a.ld_out + db + kk;
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    for (int j = 0; j < 4; ++j)
+        if (kk + j < s.c) op[j] = vv[j];
+}
+
+int yr_launch_gather(const yr_op& op, int batch, hipStream_t s) {
+    GatherArgs a;
+    int rc = yr_make_srcset(op, &a.S);
+    if (rc) return rc;
+    int dense = 0;
+    for (int i = 0; i < YR_MAX_SRC; ++i) {
+        a.dense_base[i] = dense;
+        if (i < op.nsrc) dense += op.src[i].c;
+    }
+    YR_REQUIRE(dense == op.cout && op.out && op.out_ld >= dense, "gather: cout %d != sum of sources %d (or bad out)", op.cout, dense);
+    a.out = op.out; a.H = op.h; a.W = op.w; a.KQ = a.S.kp / 4; a.ld_out = op.out_ld;
+    a.total = (long long)batch * op.h * op.w * a.KQ;
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}

@@ -1,0 +1,343 @@
+// Decode + per-class NMS + detection packing.  Replaces the TF kernels behind reference
+// code/yolo3/model.py: yolo_head :344-371, yolo_correct_boxes :374-399,
+// yolo_boxes_and_scores :402-428, and the per-class tf.image.non_max_suppression /
+// tf.gather / tf.cast loop of yolo_eval :474-490.
+//
+// Arithmetic is float32 in the reference's operation order with no FMA contraction
+// (library built with -ffp-contract=off) and exp() pinned to yr_expf, so that the results
+// are bit-identical to the C oracle (oracle/csrc/yr_oracle.c) on identical logits.
+#include "yr_common.h"
+
+// ------------------------------------------------------------------ letterbox inverse terms
+struct Letterbox {
+    float input_h, input_w, image_h, image_w, off_h, off_w, scale_h, scale_w, mul_h, mul_w;
+};
+
+// model.py:379-387 (all float32, same operation order)
+__device__ __forceinline__ Letterbox yr_letterbox(int in_h, int in_w, int img_h, int img_w) {
+    Letterbox L;
+    L.input_h = (float)in_h; L.input_w = (float)in_w;
+    L.image_h = (float)img_h; L.image_w = (float)img_w;
+    const float max_shape = fmaxf(L.image_h, L.image_w);
+    const float ratio_h = L.image_h / max_shape, ratio_w = L.image_w / max_shape;
+    const float boxed_h = L.input_h * ratio_h, boxed_w = L.input_w * ratio_w;
+    L.off_h = (L.input_h - boxed_h) / 2.0f; L.off_w = (L.input_w - boxed_w) / 2.0f;
+    L.scale_h = L.image_h / boxed_h; L.scale_w = L.image_w / boxed_w;
+    L.mul_h = L.input_h * L.scale_h; L.mul_w = L.input_w * L.scale_w;
+    return L;
+}
+
+__device__ __forceinline__ float yr_clip(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// model.py:386-398
+__device__ __forceinline__ float4 yr_correct_box(const Letterbox& L, float bx, float by, float bw, float bh) {
+    const float cy = (by * L.input_h - L.off_h) * L.scale_h;
+    const float cx = (bx * L.input_w - L.off_w) * L.scale_w;
+    const float hh = bh * L.mul_h, ww = bw * L.mul_w;
+    return make_float4(yr_clip(cy - hh / 2.0f, 0.0f, L.image_h), yr_clip(cx - ww / 2.0f, 0.0f, L.image_w),
+                       yr_clip(cy + hh / 2.0f, 0.0f, L.image_h), yr_clip(cx + ww / 2.0f, 0.0f, L.image_w));
+}
+
+// ------------------------------------------------------------------ fused decode (3 scales)
+struct DecodeArgs {
+    const float* y[3];
+    int gh[3], gw[3];
+    int nstart[3];      // first box index of each scale
+    int tile_start[4];  // first block of each scale along grid.x
+    float anchors[3][8][2];
+    int num_scales, A, C, N, in_h, in_w;
+    const int32_t* image_hw;
+    float* boxes;   // [B][N][4]
+    float* scores;  // [B][C][N]
+};
+
+#define DEC_TILE 256
+// grid (tiles, B); block 256: one lane per box; the tile's logits are contiguous in HBM and
+// staged through LDS with coalesced loads (row stride C+5 floats; odd strides are conflict-free).
+__global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.y;
+    int s = 0;
+    if (a.num_scales > 1 && (int)blockIdx.x >= a.tile_start[1]) s = 1;
+    if (a.num_scales > 2 && (int)blockIdx.x >= a.tile_start[2]) s = 2;
+    const int gh = a.gh[s], gw = a.gw[s];
+    const int ns = gh * gw * a.A;
+    const int t0 = ((int)blockIdx.x - a.tile_start[s]) * DEC_TILE;
+    const int cnt = min(DEC_TILE, ns - t0);
+    const int row = a.C + 5;
+    const float* src = a.y[s] + ((size_t)b * ns + t0) * row;
+    for (int i = threadIdx.x; i < cnt * row; i += 256) sm[i] = src[i];
+    __syncthreads();
+    const int j = threadIdx.x;
+    if (j >= cnt) return;
+    const float* t = sm + j * row;
+    const int n = t0 + j;
+    const int an = n % a.A;
+    const int cell = n / a.A;
+    const int w = cell % gw, h = cell / gw;
+    const Letterbox L = yr_letterbox(a.in_h, a.in_w, a.image_hw[b * 2], a.image_hw[b * 2 + 1]);
+    // model.py:363-367
+    const float bx = (yr_sigmoid(t[0]) + (float)w) / (float)gw;
+    const float by = (yr_sigmoid(t[1]) + (float)h) / (float)gh;
+    const float bw = yr_expf(t[2]) * a.anchors[s][an][0] / L.input_w;
+    const float bh = yr_expf(t[3]) * a.anchors[s][an][1] / L.input_h;
+    const float conf = yr_sigmoid(t[4]);
+    const int gn = a.nstart[s] + n;
+    *reinterpret_cast<float4*>(a.boxes + ((size_t)b * a.N + gn) * 4) = yr_correct_box(L, bx, by, bw, bh);
+    float* sp = a.scores + (size_t)b * a.C * a.N + gn;
+    for (int c = 0; c < a.C; ++c) sp[(size_t)c * a.N] = conf * yr_sigmoid(t[5 + c]);  // model.py:426
+}
+
+extern "C" int yr_decode(const float* y1, const float* y2, const float* y3, int batch, int in_h, int in_w,
+                         int num_anchors, int num_classes, int num_scales, const float* anchors_host,
+                         const int32_t* image_hw, float* boxes, float* scores, void* stream) {
+    YR_REQUIRE(num_scales >= 1 && num_scales <= 3, "decode: num_scales must be 1..3");
+    YR_REQUIRE(num_anchors >= 1 && num_anchors <= 8, "decode: num_anchors must be 1..8");
+    YR_REQUIRE(in_h % 32 == 0 && in_w % 32 == 0 && in_h > 0 && in_w > 0, "decode: input size must be a multiple of 32");
+    YR_REQUIRE(y1 && anchors_host && image_hw && boxes && scores && batch > 0, "decode: null pointer / empty batch");
+    DecodeArgs a;
+    const float* ys[3] = {y1, y2, y3};
+    const int total_anchors = 3 * num_anchors;
+    int n = 0, tiles = 0;
+    for (int s = 0; s < 3; ++s) {
+        a.y[s] = ys[s < num_scales ? s : 0];
+        const int stride = 32 >> s;
+        a.gh[s] = in_h / stride; a.gw[s] = in_w / stride;
+        a.nstart[s] = n; a.tile_start[s] = tiles;
+        if (s < num_scales) {
+            YR_REQUIRE(ys[s] != nullptr, "decode: y%d is null", s + 1);
+            // anchor_mask = [[6,7,8],[3,4,5],[0,1,2]][-num_scales:] (model.py:444-445)
+            const int mask_row = 3 - num_scales + s;           // row of the full mask table
+            const int first = total_anchors - (mask_row + 1) * num_anchors;
+            for (int k = 0; k < num_anchors; ++k) {
+                a.anchors[s][k][0] = anchors_host[(first + k) * 2];
+                a.anchors[s][k][1] = anchors_host[(first + k) * 2 + 1];
+            }
+            const int ns = a.gh[s] * a.gw[s] * num_anchors;
+            n += ns; tiles += (ns + DEC_TILE - 1) / DEC_TILE;
+        }
+    }
+    a.tile_start[3] = tiles;
+    a.num_scales = num_scales; a.A = num_anchors; a.C = num_classes; a.N = n; a.in_h = in_h; a.in_w = in_w;
+    a.image_hw = image_hw; a.boxes = boxes; a.scores = scores;
+    const size_t lds = (size_t)DEC_TILE * (num_classes + 5) * sizeof(float);
+    YR_REQUIRE(lds <= 160 * 1024, "decode: too many classes for the LDS tile");
+    hipLaunchKernelGGL(decode_kernel, dim3(tiles, batch), dim3(256), lds, (hipStream_t)stream, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
+// ------------------------------------------------------------------ yolo_head / yolo_correct_boxes (reference layouts)
+struct HeadArgs {
+    const float* feats;
+    float anchors[8][2];
+    int gh, gw, A, C, in_h, in_w;
+    long long total;  // B*gh*gw*A
+    float *xy, *wh, *conf, *probs, *scores;
+};
+
+__global__ __launch_bounds__(256) void yolo_head_kernel(HeadArgs a) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= a.total) return;
+    const int an = (int)(gid % a.A);
+    const long long cell = gid / a.A;
+    const int w = (int)(cell % a.gw);
+    const int h = (int)((cell / a.gw) % a.gh);
+    const float* t = a.feats + (size_t)gid * (a.C + 5);
+    a.xy[gid * 2] = (yr_sigmoid(t[0]) + (float)w) / (float)a.gw;
+    a.xy[gid * 2 + 1] = (yr_sigmoid(t[1]) + (float)h) / (float)a.gh;
+    a.wh[gid * 2] = yr_expf(t[2]) * a.anchors[an][0] / (float)a.in_w;
+    a.wh[gid * 2 + 1] = yr_expf(t[3]) * a.anchors[an][1] / (float)a.in_h;
+    const float conf = yr_sigmoid(t[4]);
+    a.conf[gid] = conf;
+    for (int c = 0; c < a.C; ++c) {
+        const float p = yr_sigmoid(t[5 + c]);
+        a.probs[(size_t)gid * a.C + c] = p;
+        if (a.scores) a.scores[(size_t)gid * a.C + c] = conf * p;  // model.py:426
+    }
+}
+
+extern "C" int yr_yolo_head(const float* feats, int batch, int gh, int gw, int num_anchors, int num_classes,
+                            const float* anchors_host, int in_h, int in_w, float* box_xy, float* box_wh,
+                            float* conf, float* probs, float* scores, void* stream) {
+    YR_REQUIRE(feats && anchors_host && box_xy && box_wh && conf && probs, "yolo_head: null pointer");
+    YR_REQUIRE(num_anchors >= 1 && num_anchors <= 8 && batch > 0 && gh > 0 && gw > 0, "yolo_head: bad sizes");
+    HeadArgs a;
+    a.feats = feats; a.gh = gh; a.gw = gw; a.A = num_anchors; a.C = num_classes; a.in_h = in_h; a.in_w = in_w;
+    for (int k = 0; k < num_anchors; ++k) { a.anchors[k][0] = anchors_host[k * 2]; a.anchors[k][1] = anchors_host[k * 2 + 1]; }
+    a.total = (long long)batch * gh * gw * num_anchors;
+    a.xy = box_xy; a.wh = box_wh; a.conf = conf; a.probs = probs; a.scores = scores;
+    hipLaunchKernelGGL(yolo_head_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
+__global__ __launch_bounds__(256) void correct_boxes_kernel(const float* xy, const float* wh, long long n_per_image,
+                                                            long long total, int in_h, int in_w,
+                                                            const int32_t* image_hw, float* boxes) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int b = (int)(gid / n_per_image);
+    const Letterbox L = yr_letterbox(in_h, in_w, image_hw[b * 2], image_hw[b * 2 + 1]);
+    *reinterpret_cast<float4*>(boxes + gid * 4) = yr_correct_box(L, xy[gid * 2], xy[gid * 2 + 1], wh[gid * 2], wh[gid * 2 + 1]);
+}
+
+extern "C" int yr_correct_boxes(const float* box_xy, const float* box_wh, int batch, int64_t n_per_image, int in_h,
+                                int in_w, const int32_t* image_hw, float* boxes, void* stream) {
+    YR_REQUIRE(box_xy && box_wh && image_hw && boxes && batch > 0 && n_per_image > 0, "correct_boxes: bad arguments");
+    const long long total = (long long)batch * n_per_image;
+    hipLaunchKernelGGL(correct_boxes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       box_xy, box_wh, (long long)n_per_image, total, in_h, in_w, image_hw, boxes);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
+// ------------------------------------------------------------------ NMS
+// NonMaxSuppression's IOU() [3P], float32, same operation order as the oracle.
+__device__ __forceinline__ float yr_iou(float4 bi, float4 bj) {
+    const float ymin_i = fminf(bi.x, bi.z), xmin_i = fminf(bi.y, bi.w);
+    const float ymax_i = fmaxf(bi.x, bi.z), xmax_i = fmaxf(bi.y, bi.w);
+    const float ymin_j = fminf(bj.x, bj.z), xmin_j = fminf(bj.y, bj.w);
+    const float ymax_j = fmaxf(bj.x, bj.z), xmax_j = fmaxf(bj.y, bj.w);
+    const float area_i = (ymax_i - ymin_i) * (xmax_i - xmin_i);
+    const float area_j = (ymax_j - ymin_j) * (xmax_j - xmin_j);
+    if (area_i <= 0.0f || area_j <= 0.0f) return 0.0f;
+    const float iy = fmaxf(fminf(ymax_i, ymax_j) - fmaxf(ymin_i, ymin_j), 0.0f);
+    const float ix = fmaxf(fminf(xmax_i, xmax_j) - fmaxf(xmin_i, xmin_j), 0.0f);
+    const float inter = iy * ix;
+    return inter / (area_i + area_j - inter);
+}
+
+struct NmsArgs {
+    const float* boxes;   // [B][N][4]
+    const float* scores;  // [B][C][N]
+    int N, C, max_boxes;
+    float score_thr, iou_thr;
+    int32_t* out_idx;     // [B][C][max_boxes]
+    int32_t* out_count;   // [B][C]
+};
+
+#define NMS_DEAD (-__builtin_inff())
+// grid (C, B); one workgroup per (image, class).  key[i] = score if still a candidate else -inf,
+// resident in LDS.  Each round: arg-max by (score desc, index asc) with wave shuffles, select,
+// then every lane suppresses its candidates whose IoU with the pick exceeds the threshold -
+// the same set and order as TF's pop-and-test loop.
+__global__ __launch_bounds__(256) void nms_kernel(NmsArgs a) {
+    extern __shared__ float key[];
+    __shared__ float ws[4];
+    __shared__ int wi[4];
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* sc = a.scores + ((size_t)b * a.C + c) * a.N;
+    const float4* bx = reinterpret_cast<const float4*>(a.boxes) + (size_t)b * a.N;
+    for (int i = tid; i < a.N; i += 256) {
+        const float s = sc[i];
+        key[i] = (s > a.score_thr) ? s : NMS_DEAD;
+    }
+    __syncthreads();
+    int32_t* oi = a.out_idx + ((size_t)b * a.C + c) * a.max_boxes;
+    int picked = 0;
+    for (; picked < a.max_boxes; ++picked) {
+        float bs = NMS_DEAD;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < a.N; i += 256) {
+            const float s = key[i];
+            if (s > bs) { bs = s; bi = i; }  // ascending scan: first (smallest-index) max is kept
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float s2 = __shfl_xor(bs, o);
+            const int i2 = __shfl_xor(bi, o);
+            if (s2 > bs || (s2 == bs && i2 < bi)) { bs = s2; bi = i2; }
+        }
+        if (lane == 0) { ws[wave] = bs; wi[wave] = bi; }
+        __syncthreads();
+        bs = ws[0]; bi = wi[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (ws[w] > bs || (ws[w] == bs && wi[w] < bi)) { bs = ws[w]; bi = wi[w]; }
+        if (!(bs > NMS_DEAD)) break;  // uniform: no candidate left
+        if (tid == 0) { oi[picked] = bi; key[bi] = NMS_DEAD; }
+        const float4 pb = bx[bi];
+        __syncthreads();
+        for (int i = tid; i < a.N; i += 256) {
+            if (key[i] > NMS_DEAD) {
+                if (yr_iou(pb, bx[i]) > a.iou_thr) key[i] = NMS_DEAD;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) a.out_count[(size_t)b * a.C + c] = picked;
+    for (int i = picked + tid; i < a.max_boxes; i += 256) oi[i] = -1;
+}
+
+extern "C" int yr_nms(const float* boxes, const float* scores, int batch, int n, int num_classes, int max_boxes,
+                      float score_thr, float iou_thr, int32_t* out_idx, int32_t* out_count, void* stream) {
+    YR_REQUIRE(boxes && scores && out_idx && out_count, "nms: null pointer");
+    YR_REQUIRE(batch > 0 && n > 0 && num_classes > 0 && max_boxes > 0, "nms: bad sizes");
+    YR_REQUIRE(((uintptr_t)boxes % 16) == 0, "nms: boxes must be 16-byte aligned");
+    const size_t lds = (size_t)n * sizeof(float);
+    YR_REQUIRE(lds <= 150 * 1024, "nms: %d boxes per image exceed the LDS-resident limit (38400)", n);
+    static bool attr_set = false;
+    if (!attr_set) {
+        YR_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    NmsArgs a;
+    a.boxes = boxes; a.scores = scores; a.N = n; a.C = num_classes; a.max_boxes = max_boxes;
+    a.score_thr = score_thr; a.iou_thr = iou_thr; a.out_idx = out_idx; a.out_count = out_count;
+    hipLaunchKernelGGL(nms_kernel, dim3(num_classes, batch), dim3(256), lds, (hipStream_t)stream, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
+// ------------------------------------------------------------------ pack detections
+struct PackArgs {
+    const float* boxes; const float* scores; const int32_t* idx; const int32_t* cnt;
+    int N, C, max_boxes;
+    int32_t* det; int32_t* det_count;
+};
+
+// one block per image: exclusive prefix over the class counts, then gather + truncate-cast
+// (model.py:481-490: class-ascending, pick order inside a class).
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
+    extern __shared__ int pre[];  // [C+1]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int s = 0;
+        for (int c = 0; c < a.C; ++c) { pre[c] = s; s += a.cnt[(size_t)b * a.C + c]; }
+        pre[a.C] = s;
+        a.det_count[b] = s;
+    }
+    __syncthreads();
+    const int K = pre[a.C];
+    const int slots = a.C * a.max_boxes;
+    int32_t* d = a.det + (size_t)b * slots * 6;
+    for (int t = tid; t < slots; t += 256) {
+        const int c = t / a.max_boxes, j = t - c * a.max_boxes;
+        if (j < a.cnt[(size_t)b * a.C + c]) {
+            const int i = a.idx[((size_t)b * a.C + c) * a.max_boxes + j];
+            const float4 bx = reinterpret_cast<const float4*>(a.boxes)[(size_t)b * a.N + i];
+            int32_t* r = d + (size_t)(pre[c] + j) * 6;
+            r[0] = (int32_t)bx.x; r[1] = (int32_t)bx.y; r[2] = (int32_t)bx.z; r[3] = (int32_t)bx.w;  // tf.cast truncates
+            r[4] = __float_as_int(a.scores[((size_t)b * a.C + c) * a.N + i]);
+            r[5] = c;
+        }
+    }
+    for (int t = K + tid; t < slots; t += 256) {
+        int32_t* r = d + (size_t)t * 6;
+        r[0] = r[1] = r[2] = r[3] = 0; r[4] = 0; r[5] = -1;
+    }
+}
+
+extern "C" int yr_pack_detections(const float* boxes, const float* scores, const int32_t* nms_idx,
+                                  const int32_t* nms_count, int batch, int n, int num_classes, int max_boxes,
+                                  int32_t* det, int32_t* det_count, void* stream) {
+    YR_REQUIRE(boxes && scores && nms_idx && nms_count && det && det_count, "pack: null pointer");
+    YR_REQUIRE(batch > 0 && n > 0 && num_classes > 0 && max_boxes > 0, "pack: bad sizes");
+    PackArgs a;
+    a.boxes = boxes; a.scores = scores; a.idx = nms_idx; a.cnt = nms_count; a.N = n; a.C = num_classes;
+    a.max_boxes = max_boxes; a.det = det; a.det_count = det_count;
+    hipLaunchKernelGGL(pack_kernel, dim3(batch), dim3(256), (num_classes + 1) * sizeof(int), (hipStream_t)stream, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}

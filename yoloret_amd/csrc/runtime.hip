@@ -1,0 +1,144 @@
+// Plan runtime: owns the device copy of the parameter blob and the static op list produced
+// by yoloret_amd.compiler; replays it on the caller's stream.  This is what stands in for
+// tf.keras.Model.__call__ on the graph built by yolov3_body (reference
+// code/yolo3/model.py:170-342, called at code/yolo.py:152 and code/yolo3/map.py:111).
+#include <string.h>
+
+#include <vector>
+
+#include "yr_common.h"
+
+static thread_local char g_err[512] = "";
+
+void yr_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* yr_last_error(void) { return g_err; }
+extern "C" int yr_abi_version(void) { return YR_ABI_VERSION; }
+
+static int dispatch(const yr_op& op, int batch, hipStream_t s) {
+    switch (op.kind) {
+        case YR_OP_STEM: return yr_launch_stem(op, batch, s);
+        case YR_OP_POINTWISE: return yr_launch_pointwise(op, batch, s);
+        case YR_OP_DEPTHWISE: return yr_launch_depthwise(op, batch, s);
+        case YR_OP_SE_MEAN: return yr_launch_se_mean(op, batch, s);
+        case YR_OP_SE_FC: return yr_launch_se_fc(op, batch, s);
+        case YR_OP_WSUM: return yr_launch_wsum(op, batch, s);
+        case YR_OP_GATHER: return yr_launch_gather(op, batch, s);
+        default: yr_set_error("unknown op kind %d", op.kind); return YR_ERR_ARG;
+    }
+}
+
+extern "C" int yr_op_run(const yr_op* op, int batch, void* stream) {
+    YR_REQUIRE(op != nullptr && batch > 0, "yr_op_run: null op or empty batch");
+    return dispatch(*op, batch, (hipStream_t)stream);
+}
+
+struct yr_handle {
+    std::vector<yr_op> ops;
+    std::vector<yr_buf> bufs;
+    int64_t arena_per_image = 0;  // floats
+    float* weights = nullptr;
+    size_t n_weights = 0;
+    int device = 0;
+};
+
+extern "C" int yr_create(const yr_op* ops, int n_ops, const yr_buf* bufs, int n_bufs, yr_handle** out) {
+    YR_REQUIRE(ops && bufs && out && n_ops > 0 && n_bufs > 0, "yr_create: bad arguments");
+    yr_handle* h = new yr_handle();
+    h->ops.assign(ops, ops + n_ops);
+    h->bufs.assign(bufs, bufs + n_bufs);
+    if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
+    for (const yr_buf& b : h->bufs) {
+        if (b.external_slot < 0) {
+            if (b.arena_off_per_image < 0 || b.arena_off_per_image % 4 != 0 || b.elems_per_image <= 0) {
+                delete h;
+                yr_set_error("yr_create: arena buffer with bad offset/size");
+                return YR_ERR_ARG;
+            }
+            const int64_t end = b.arena_off_per_image + b.elems_per_image;
+            if (end > h->arena_per_image) h->arena_per_image = end;
+        } else if (b.external_slot > 3) {
+            delete h;
+            yr_set_error("yr_create: external slot %d out of range", b.external_slot);
+            return YR_ERR_ARG;
+        }
+    }
+    auto buf_ok = [&](int32_t b) { return b >= 0 && b < n_bufs; };
+    for (const yr_op& op : h->ops) {
+        bool ok = buf_ok(op.out_buf) && op.nsrc >= 1 && op.nsrc <= YR_MAX_SRC;
+        for (int i = 0; ok && i < op.nsrc; ++i) ok = buf_ok(op.src[i].buf);
+        if (ok && op.res_buf >= 0) ok = buf_ok(op.res_buf);
+        if (ok && op.gate_buf >= 0) ok = buf_ok(op.gate_buf);
+        if (!ok) {
+            delete h;
+            yr_set_error("yr_create: op references a buffer outside the table");
+            return YR_ERR_ARG;
+        }
+    }
+    *out = h;
+    return YR_OK;
+}
+
+extern "C" void yr_destroy(yr_handle* h) {
+    if (!h) return;
+    if (h->weights) (void)hipFree(h->weights);
+    delete h;
+}
+
+extern "C" int yr_load_weights(yr_handle* h, const float* host_blob, size_t n_floats) {
+    YR_REQUIRE(h && host_blob && n_floats > 0, "yr_load_weights: bad arguments");
+    if (h->weights) { (void)hipFree(h->weights); h->weights = nullptr; }
+    YR_CHECK_HIP(hipMalloc((void**)&h->weights, n_floats * sizeof(float)));
+    YR_CHECK_HIP(hipMemcpy(h->weights, host_blob, n_floats * sizeof(float), hipMemcpyHostToDevice));
+    h->n_weights = n_floats;
+    return YR_OK;
+}
+
+extern "C" size_t yr_workspace_bytes(const yr_handle* h, int batch) {
+    if (!h || batch <= 0) return 0;
+    return (size_t)h->arena_per_image * (size_t)batch * sizeof(float);
+}
+
+extern "C" int yr_plan_num_launches(const yr_handle* h) { return h ? (int)h->ops.size() : 0; }
+
+extern "C" int yr_forward(yr_handle* h, const float* images, int batch, float* y1, float* y2, float* y3,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    YR_REQUIRE(h && images && batch > 0, "yr_forward: bad arguments");
+    if (!h->weights) { yr_set_error("yr_forward: weights not loaded"); return YR_ERR_STATE; }
+    YR_REQUIRE(workspace_bytes >= yr_workspace_bytes(h, batch) && (workspace || h->arena_per_image == 0),
+               "yr_forward: workspace too small (%zu < %zu)", workspace_bytes, yr_workspace_bytes(h, batch));
+    YR_REQUIRE(((uintptr_t)workspace % 16) == 0, "yr_forward: workspace must be 16-byte aligned");
+    float* ext[4] = {const_cast<float*>(images), y1, y2, y3};
+    float* ws = static_cast<float*>(workspace);
+    auto bufptr = [&](int32_t b) -> float* {
+        const yr_buf& d = h->bufs[b];
+        if (d.external_slot >= 0) return ext[d.external_slot];
+        return ws + (size_t)d.arena_off_per_image * (size_t)batch;
+    };
+    auto wptr = [&](int64_t off) -> const float* { return off >= 0 ? h->weights + off : nullptr; };
+    hipStream_t s = (hipStream_t)stream;
+    for (size_t i = 0; i < h->ops.size(); ++i) {
+        yr_op op = h->ops[i];
+        for (int k = 0; k < op.nsrc; ++k) op.src[k].ptr = bufptr(op.src[k].buf);
+        op.out = bufptr(op.out_buf);
+        op.res = op.res_buf >= 0 ? bufptr(op.res_buf) : nullptr;
+        op.gate = op.gate_buf >= 0 ? bufptr(op.gate_buf) : nullptr;
+        op.wgt = wptr(op.wgt_off); op.scale = wptr(op.scale_off); op.shift = wptr(op.shift_off);
+        op.wgt2 = wptr(op.wgt2_off); op.b1 = wptr(op.b1_off); op.b2 = wptr(op.b2_off);
+        if (op.out == nullptr) { yr_set_error("yr_forward: op %zu writes a null external buffer", i); return YR_ERR_ARG; }
+        const int rc = dispatch(op, batch, s);
+        if (rc != YR_OK) {
+            char tmp[400];
+            strncpy(tmp, g_err, sizeof(tmp) - 1);
+            tmp[sizeof(tmp) - 1] = 0;
+            yr_set_error("op %zu (kind %d): %s", i, op.kind, tmp);
+            return rc;
+        }
+    }
+    return YR_OK;
+}

@@ -1,0 +1,164 @@
+// Shared host/device helpers for libyoloret_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/yoloret_hip.h"
+
+void yr_set_error(const char* fmt, ...);
+
+#define YR_CHECK_HIP(expr)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            yr_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return YR_ERR_HIP;                                                          \
+        }                                                                               \
+    } while (0)
+
+#define YR_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            yr_set_error(__VA_ARGS__);        \
+            return YR_ERR_ARG;                \
+        }                                     \
+    } while (0)
+
+#define YR_LAUNCH_CHECK() YR_CHECK_HIP(hipGetLastError())
+
+// per-kind launchers (defined in the .hip files); `op` holds device pointers.
+int yr_launch_stem(const yr_op& op, int batch, hipStream_t s);
+int yr_launch_pointwise(const yr_op& op, int batch, hipStream_t s);
+int yr_launch_depthwise(const yr_op& op, int batch, hipStream_t s);
+int yr_launch_se_mean(const yr_op& op, int batch, hipStream_t s);
+int yr_launch_se_fc(const yr_op& op, int batch, hipStream_t s);
+int yr_launch_wsum(const yr_op& op, int batch, hipStream_t s);
+int yr_launch_gather(const yr_op& op, int batch, hipStream_t s);
+
+static inline int yr_round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------- device side
+// The library is built with -ffp-contract=off: every fused multiply-add below is an
+// explicit fmaf, so results do not depend on the optimiser's contraction choices.
+
+// Pinned float32 exp: the same steps as oracle/csrc/yr_oracle.c:yro_expf (Cody-Waite
+// reduction + degree-5 polynomial; each step one IEEE op) => bit-identical to the C oracle.
+__device__ __forceinline__ float yr_expf(float x) {
+    x = fminf(x, 88.0f);
+    x = fmaxf(x, -87.0f);
+    float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float y = __builtin_fmaf(p, r * r, r) + 1.0f;
+    int e = ((int)n + 127) << 23;
+    return y * __int_as_float(e);
+}
+__device__ __forceinline__ float yr_sigmoid(float x) { return 1.0f / (1.0f + yr_expf(-x)); }
+
+__device__ __forceinline__ float yr_apply_act(float v, int act) {
+    switch (act) {
+        case YR_ACT_RELU6: return fminf(fmaxf(v, 0.0f), 6.0f);
+        case YR_ACT_SWISH: return v * yr_sigmoid(v);
+        case YR_ACT_SIGMOID: return yr_sigmoid(v);
+        case YR_ACT_LEAKY: return v >= 0.0f ? v : v * 0.1f;
+        default: return v;
+    }
+}
+__device__ __forceinline__ float4 yr_apply_act4(float4 v, int act) {
+    return make_float4(yr_apply_act(v.x, act), yr_apply_act(v.y, act), yr_apply_act(v.z, act), yr_apply_act(v.w, act));
+}
+__device__ __forceinline__ float4 yr_max4(float4 a, float4 b) {
+    return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+
+// Device view of one concatenated source segment (see yr_src).
+struct DSrc {
+    const float* ptr;
+    int h, w;      // source spatial dims
+    int c;         // channels taken
+    int ld;        // channel stride
+    int xform;     // yr_xform
+    int kbase;     // start of this segment in the consumer's padded k-space (multiple of 4)
+};
+
+struct DSrcSet {
+    DSrc s[YR_MAX_SRC];
+    int n;
+    int kp;        // total padded k (sum of round_up(c,4))
+};
+
+// Loads channels [kk, kk+4) of segment `s` for consumer pixel (b,y,x); lanes beyond
+// the segment's channel count are returned as 0 (never multiplied through).
+__device__ __forceinline__ float4 yr_load_src_quad(const DSrc& s, int b, int y, int x, int kk) {
+    float4 v;
+    if (s.xform == YR_X_IDENTITY) {
+        v = *reinterpret_cast<const float4*>(s.ptr + ((size_t)(b * s.h + y) * s.w + x) * s.ld + kk);
+    } else if (s.xform == YR_X_UP2) {
+        v = *reinterpret_cast<const float4*>(s.ptr + ((size_t)(b * s.h + (y >> 1)) * s.w + (x >> 1)) * s.ld + kk);
+    } else {
+        const int p = (s.xform == YR_X_MAXPOOL2) ? 2 : 4;
+        const float* base = s.ptr + ((size_t)(b * s.h + y * p) * s.w + x * p) * s.ld + kk;
+        v = *reinterpret_cast<const float4*>(base);
+        for (int dy = 0; dy < p; ++dy)
+            for (int dx = 0; dx < p; ++dx)
+                v = yr_max4(v, *reinterpret_cast<const float4*>(base + ((size_t)dy * s.w + dx) * s.ld));
+    }
+    const int rem = s.c - kk;
+    if (rem < 4) {
+        if (rem < 4) v.w = 0.0f;
+        if (rem < 3) v.z = 0.0f;
+        if (rem < 2) v.y = 0.0f;
+    }
+    return v;
+}
+
+// k in the padded k-space -> (segment, offset); returns zero quad when k >= kp.
+__device__ __forceinline__ float4 yr_load_cat_quad(const DSrcSet& S, int b, int y, int x, int k) {
+    if (k >= S.kp) return make_float4(0.f, 0.f, 0.f, 0.f);
+    int si = 0;
+#pragma unroll
+    for (int i = 1; i < YR_MAX_SRC; ++i)
+        if (i < S.n && k >= S.s[i].kbase) si = i;
+    // select fields without dynamic indexing of the struct array (keeps it in SGPRs)
+    DSrc s = S.s[0];
+    if (si == 1) s = S.s[1];
+    if (si == 2) s = S.s[2];
+    if (si == 3) s = S.s[3];
+    return yr_load_src_quad(s, b, y, x, k - s.kbase);
+}
+#endif
+
+// host: build a DSrcSet from a yr_op (validates alignment); out_h/out_w are the consumer dims.
+#ifdef __HIPCC__
+static inline int yr_make_srcset(const yr_op& op, DSrcSet* S) {
+    if (op.nsrc < 1 || op.nsrc > YR_MAX_SRC) { yr_set_error("nsrc=%d out of range", op.nsrc); return YR_ERR_ARG; }
+    int k = 0;
+    S->n = op.nsrc;
+    for (int i = 0; i < YR_MAX_SRC; ++i) {
+        DSrc& d = S->s[i];
+        if (i >= op.nsrc) { d = S->s[0]; d.kbase = 1 << 30; continue; }
+        const yr_src& s = op.src[i];
+        int eh = s.h, ew = s.w;
+        if (s.xform == YR_X_UP2) { eh *= 2; ew *= 2; }
+        else if (s.xform == YR_X_MAXPOOL2) { eh /= 2; ew /= 2; }
+        else if (s.xform == YR_X_MAXPOOL4) { eh /= 4; ew /= 4; }
+        else if (s.xform != YR_X_IDENTITY) { yr_set_error("bad xform %d", s.xform); return YR_ERR_ARG; }
+        if (eh != op.h || ew != op.w) { yr_set_error("src %d dims %dx%d (xform %d) do not give %dx%d", i, s.h, s.w, s.xform, op.h, op.w); return YR_ERR_ARG; }
+        if (s.ld % 4 != 0 || s.ld < yr_round_up(s.c, 4)) { yr_set_error("src %d: ld=%d must be a multiple of 4 and >= round_up(c=%d,4)", i, s.ld, s.c); return YR_ERR_ARG; }
+        if (((uintptr_t)s.ptr) % 16 != 0 || s.ptr == nullptr) { yr_set_error("src %d pointer null or not 16-byte aligned", i); return YR_ERR_ARG; }
+        d.ptr = s.ptr; d.h = s.h; d.w = s.w; d.c = s.c; d.ld = s.ld; d.xform = s.xform; d.kbase = k;
+        k += yr_round_up(s.c, 4);
+    }
+    S->kp = k;
+    return YR_OK;
+}
+#endif

@@ -1,0 +1,125 @@
+"""``Model``: what ``tf.keras.Model(inputs, outputs)`` is to the reference's detection
+path (reference code/yolo3/model.py:342 returns ``AdvLossModel(backbone.inputs, [y1,y2,y3])``,
+which on this path is only a callable container; code/yolo.py:87,152 call
+``load_weights`` and ``__call__`` on it).
+
+Holds the compiled plan, the parameter dict and the native handle; ``__call__`` enqueues
+the whole forward on the current HIP stream through one C-ABI call (yr_forward).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import runtime as rt
+from .compiler import compile_graph
+
+
+class Model:
+    def __init__(self, inputs, outputs, name=None):
+        self.inputs = inputs if isinstance(inputs, (list, tuple)) else [inputs]
+        self.outputs = list(outputs)
+        self.name = name
+        self.plan = compile_graph(self.inputs[0], self.outputs)
+        self._weights = None
+        self._blob = None
+        self._handles = {}     # device index -> yr_handle*
+        self._workspace = {}   # device index -> torch.uint8 tensor
+        self._out_anchors = [o.node.attrs['num_anchors'] if o.node is not None and o.node.op == 'reshape5' else None
+                             for o in self.outputs]
+
+    # ------------------------------------------------------------------ parameters
+    @property
+    def param_shapes(self):
+        """{keras-style parameter name: shape} for every live layer."""
+        return dict(self.plan.param_shapes)
+
+    def count_params(self):
+        return int(sum(int(np.prod(s)) for s in self.plan.param_shapes.values()))
+
+    def set_weights(self, weights):
+        """weights: mapping name -> array covering every entry of ``param_shapes``."""
+        wd = {}
+        missing = [k for k in self.plan.param_shapes if k not in weights]
+        if missing:
+            raise ValueError('missing parameters: %s%s' % (', '.join(missing[:8]), ' ...' if len(missing) > 8 else ''))
+        for k, shape in self.plan.param_shapes.items():
+            a = np.asarray(weights[k], np.float32)
+            if a.size != int(np.prod(shape)):
+                raise ValueError('parameter %s has %d elements, expected shape %s' % (k, a.size, (shape,)))
+            wd[k] = a.reshape(shape)
+        self._weights = wd
+        self._blob = self.plan.build_blob(wd)
+        for dev, h in self._handles.items():
+            with torch.cuda.device(dev):
+                rt.check(rt.lib().yr_load_weights(h, self._blob.ctypes.data_as(ctypes.c_void_p), self._blob.size))
+
+    def get_weights(self):
+        return dict(self._weights) if self._weights is not None else None
+
+    def load_weights(self, path):
+        """Loads an ``.npz`` written by ``save_weights`` (name -> array).  Keras HDF5
+        checkpoints (reference code/yolo.py:87) need the offline converter - SURVEY.md 8(f)-2."""
+        if str(path).endswith('.h5'):
+            raise NotImplementedError('Keras HDF5 import is not available (no h5py); convert to .npz')
+        with np.load(path) as z:
+            self.set_weights({k: z[k] for k in z.files})
+
+    def save_weights(self, path):
+        if self._weights is None:
+            raise RuntimeError('no weights set')
+        np.savez(path, **self._weights)
+
+    # ------------------------------------------------------------------ execution
+    def _handle(self, device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        h = self._handles.get(idx)
+        if h is None:
+            if self._blob is None:
+                raise RuntimeError('weights have not been set (set_weights / load_weights)')
+            ops, bufs = self.plan.c_arrays()
+            hp = ctypes.c_void_p()
+            with torch.cuda.device(idx):
+                rt.check(rt.lib().yr_create(ops, len(ops), bufs, len(bufs), ctypes.byref(hp)))
+                rt.check(rt.lib().yr_load_weights(hp, self._blob.ctypes.data_as(ctypes.c_void_p), self._blob.size))
+            self._handles[idx] = h = hp
+        return idx, h
+
+    def workspace_bytes(self, batch):
+        return self.plan.arena_elems_per_image * batch * 4
+
+    def __call__(self, x, out=None):
+        h, w, c = self.plan.input_shape
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
+            raise ValueError('input must be a float32 CUDA tensor [B,%d,%d,%d] (NHWC)' % (h, w, c))
+        if x.dim() != 4 or tuple(x.shape[1:]) != (h, w, c):
+            raise ValueError('input shape %s does not match the model input [B,%d,%d,%d]' % (tuple(x.shape), h, w, c))
+        x = x.contiguous()
+        b = x.shape[0]
+        idx, hd = self._handle(x.device)
+        need = self.workspace_bytes(b)
+        ws = self._workspace.get(idx)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+            self._workspace[idx] = ws
+        ys = out
+        if ys is None:
+            ys = [torch.empty((b, ob.h, ob.w, ob.c), dtype=torch.float32, device=x.device)
+                  for ob in self.plan.output_bufs]
+        yp = [rt._ptr(y) for y in ys] + [None] * (3 - len(ys))
+        with torch.cuda.device(idx):
+            rt.check(rt.lib().yr_forward(hd, rt._ptr(x), b, yp[0], yp[1], yp[2], rt._ptr(ws), ws.numel(),
+                                         rt.stream_ptr(x.device)))
+        res = []
+        for y, a in zip(ys, self._out_anchors):
+            res.append(y.view(b, y.shape[1], y.shape[2], a, y.shape[3] // a) if a else y)
+        return res
+
+    predict = __call__
+
+    def __del__(self):
+        try:
+            for h in self._handles.values():
+                rt.lib().yr_destroy(h)
+        except Exception:
+            pass

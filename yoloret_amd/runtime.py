@@ -1,0 +1,228 @@
+"""ctypes binding of libyoloret_hip.so (include/yoloret_hip.h).
+
+PyTorch-ROCm tensors are only the containers (device memory + streams); every
+arithmetic step happens in the HIP kernels behind the C-ABI.  There is no CPU
+fallback: if the library is missing, loading fails loudly.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libyoloret_hip.so')
+
+YR_MAX_SRC = 4
+ACT = {'none': 0, None: 0, 'relu6': 1, 'swish': 2, 'sigmoid': 3, 'leaky': 4}
+XFORM = {'identity': 0, 'up2': 1, 'maxpool2': 2, 'maxpool4': 3}
+OP_STEM, OP_POINTWISE, OP_DEPTHWISE, OP_SE_MEAN, OP_SE_FC, OP_WSUM, OP_GATHER = 1, 2, 3, 4, 5, 6, 7
+OP_NAMES = {1: 'stem', 2: 'pointwise', 3: 'depthwise', 4: 'se_mean', 5: 'se_fc', 6: 'wsum', 7: 'gather'}
+
+
+class YrSrc(ctypes.Structure):
+    _fields_ = [('ptr', ctypes.c_void_p), ('buf', ctypes.c_int32), ('h', ctypes.c_int32), ('w', ctypes.c_int32),
+                ('c', ctypes.c_int32), ('ld', ctypes.c_int32), ('xform', ctypes.c_int32)]
+
+
+class YrOp(ctypes.Structure):
+    _fields_ = [('kind', ctypes.c_int32), ('act', ctypes.c_int32), ('h', ctypes.c_int32), ('w', ctypes.c_int32),
+                ('cin', ctypes.c_int32), ('cout', ctypes.c_int32), ('k', ctypes.c_int32), ('stride', ctypes.c_int32),
+                ('nsrc', ctypes.c_int32), ('se_reduced', ctypes.c_int32),
+                ('src', YrSrc * YR_MAX_SRC),
+                ('out', ctypes.c_void_p), ('out_buf', ctypes.c_int32), ('out_ld', ctypes.c_int32),
+                ('res', ctypes.c_void_p), ('res_buf', ctypes.c_int32), ('res_ld', ctypes.c_int32),
+                ('gate', ctypes.c_void_p), ('gate_buf', ctypes.c_int32), ('gate_ld', ctypes.c_int32),
+                ('wgt', ctypes.c_void_p), ('wgt_off', ctypes.c_int64),
+                ('scale', ctypes.c_void_p), ('scale_off', ctypes.c_int64),
+                ('shift', ctypes.c_void_p), ('shift_off', ctypes.c_int64),
+                ('wgt2', ctypes.c_void_p), ('wgt2_off', ctypes.c_int64),
+                ('b1', ctypes.c_void_p), ('b1_off', ctypes.c_int64),
+                ('b2', ctypes.c_void_p), ('b2_off', ctypes.c_int64)]
+
+
+class YrBuf(ctypes.Structure):
+    _fields_ = [('elems_per_image', ctypes.c_int64), ('arena_off_per_image', ctypes.c_int64),
+                ('external_slot', ctypes.c_int32), ('pad_', ctypes.c_int32)]
+
+
+EXPORTS = ['yr_last_error', 'yr_abi_version', 'yr_create', 'yr_destroy', 'yr_load_weights', 'yr_workspace_bytes',
+           'yr_forward', 'yr_plan_num_launches', 'yr_op_run', 'yr_decode', 'yr_yolo_head', 'yr_correct_boxes',
+           'yr_nms', 'yr_pack_detections']
+
+_lib = None
+
+
+class YoloretHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libyoloret_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise YoloretHipError(
+                'libyoloret_hip.so is missing (%s). Build it with `python -m yoloret_amd.build` '
+                '(hipcc --offload-arch=gfx950); there is no CPU fallback.' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.yr_last_error.restype = ctypes.c_char_p
+        L.yr_abi_version.restype = ctypes.c_int
+        L.yr_workspace_bytes.restype = ctypes.c_size_t
+        L.yr_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.yr_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.yr_destroy.argtypes = [ctypes.c_void_p]
+        L.yr_destroy.restype = None
+        L.yr_load_weights.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        L.yr_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.yr_plan_num_launches.argtypes = [ctypes.c_void_p]
+        L.yr_op_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.yr_decode.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 5
+        L.yr_yolo_head.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + \
+            [ctypes.c_void_p] * 6
+        L.yr_correct_boxes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.yr_nms.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_float] + \
+            [ctypes.c_void_p] * 3
+        L.yr_pack_detections.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3
+        if L.yr_abi_version() != 1:
+            raise YoloretHipError('libyoloret_hip.so ABI version mismatch')
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise YoloretHipError('libyoloret_hip: %s (status %d)' % (lib().yr_last_error().decode(), rc))
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _require_cuda_f32(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError('%s must be a contiguous float32 CUDA tensor' % name)
+
+
+def make_src(t, c=None, xform='identity', ld=None):
+    """yr_src for a [B,H,W,ld] tensor of which `c` channels are taken."""
+    s = YrSrc()
+    s.ptr = t.data_ptr()
+    s.buf = -1
+    s.h, s.w = t.shape[1], t.shape[2]
+    s.ld = t.shape[3] if ld is None else ld
+    s.c = s.ld if c is None else c
+    s.xform = XFORM[xform] if isinstance(xform, str) else int(xform)
+    return s
+
+
+def run_op(op, batch):
+    check(lib().yr_op_run(ctypes.byref(op), int(batch), stream_ptr()))
+
+
+def new_op(kind, act='none'):
+    op = YrOp()
+    op.kind = kind
+    op.act = ACT[act] if not isinstance(act, int) else act
+    op.out_buf = op.res_buf = op.gate_buf = -1
+    for f in ('wgt_off', 'scale_off', 'shift_off', 'wgt2_off', 'b1_off', 'b2_off'):
+        setattr(op, f, -1)
+    return op
+
+
+# ----------------------------------------------------------------------------- post-processing wrappers
+def num_boxes(in_h, in_w, num_anchors=3, num_scales=3):
+    return sum((in_h // (32 >> s)) * (in_w // (32 >> s)) * num_anchors for s in range(num_scales))
+
+
+def decode(ys, anchors, num_classes, image_hw, input_hw, num_scales=3):
+    """ys: list of [B,G,G,A*(C+5)] (or [B,G,G,A,C+5]) logits -> boxes [B,N,4], scores [B,C,N]."""
+    for i, y in enumerate(ys[:num_scales]):
+        _require_cuda_f32(y, 'y%d' % (i + 1))
+    b = ys[0].shape[0]
+    anchors = np.ascontiguousarray(np.asarray(anchors, np.float32).reshape(-1, 2))
+    a = anchors.shape[0] // 3
+    in_h, in_w = int(input_hw[0]), int(input_hw[1])
+    n = num_boxes(in_h, in_w, a, num_scales)
+    dev = ys[0].device
+    boxes = torch.empty((b, n, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((b, num_classes, n), dtype=torch.float32, device=dev)
+    yp = [_ptr(ys[i]) if i < num_scales else None for i in range(3)]
+    check(lib().yr_decode(yp[0], yp[1], yp[2], b, in_h, in_w, a, num_classes, num_scales,
+                          anchors.ctypes.data_as(ctypes.c_void_p), _ptr(image_hw), _ptr(boxes), _ptr(scores),
+                          stream_ptr()))
+    return boxes, scores
+
+
+def nms(boxes, scores, max_boxes=20, score_threshold=.6, iou_threshold=.5):
+    """boxes [B,N,4], scores [B,C,N] -> idx [B,C,max] int32 (-1 padded), count [B,C] int32."""
+    _require_cuda_f32(boxes, 'boxes')
+    _require_cuda_f32(scores, 'scores')
+    b, c, n = scores.shape
+    idx = torch.empty((b, c, max_boxes), dtype=torch.int32, device=boxes.device)
+    cnt = torch.empty((b, c), dtype=torch.int32, device=boxes.device)
+    check(lib().yr_nms(_ptr(boxes), _ptr(scores), b, n, c, int(max_boxes), float(score_threshold),
+                       float(iou_threshold), _ptr(idx), _ptr(cnt), stream_ptr()))
+    return idx, cnt
+
+
+def pack_detections(boxes, scores, idx, cnt):
+    """-> det [B, C*max, 6] int32 words, det_count [B] int32 (see yoloret_hip.h)."""
+    b, c, n = scores.shape
+    max_boxes = idx.shape[2]
+    det = torch.empty((b, c * max_boxes, 6), dtype=torch.int32, device=boxes.device)
+    det_count = torch.empty((b,), dtype=torch.int32, device=boxes.device)
+    check(lib().yr_pack_detections(_ptr(boxes), _ptr(scores), _ptr(idx), _ptr(cnt), b, n, c, max_boxes,
+                                   _ptr(det), _ptr(det_count), stream_ptr()))
+    return det, det_count
+
+
+def yolo_head(feats, anchors, input_hw, with_scores=False):
+    """feats [B,G,G,A,C+5] -> box_xy, box_wh [B,G,G,A,2], conf [B,G,G,A,1], probs [B,G,G,A,C]
+    (+ scores = conf*probs [B,G,G,A,C] when with_scores)."""
+    _require_cuda_f32(feats, 'feats')
+    b, gh, gw, a, ch = feats.shape
+    c = ch - 5
+    anchors = np.ascontiguousarray(np.asarray(anchors, np.float32).reshape(-1, 2))
+    if anchors.shape[0] != a:
+        raise ValueError('yolo_head: %d anchors for %d anchor slots' % (anchors.shape[0], a))
+    dev = feats.device
+    xy = torch.empty((b, gh, gw, a, 2), dtype=torch.float32, device=dev)
+    wh = torch.empty((b, gh, gw, a, 2), dtype=torch.float32, device=dev)
+    conf = torch.empty((b, gh, gw, a, 1), dtype=torch.float32, device=dev)
+    probs = torch.empty((b, gh, gw, a, c), dtype=torch.float32, device=dev)
+    scores = torch.empty_like(probs) if with_scores else None
+    check(lib().yr_yolo_head(_ptr(feats), b, gh, gw, a, c, anchors.ctypes.data_as(ctypes.c_void_p),
+                             int(input_hw[0]), int(input_hw[1]), _ptr(xy), _ptr(wh), _ptr(conf), _ptr(probs),
+                             _ptr(scores), stream_ptr()))
+    return (xy, wh, conf, probs, scores) if with_scores else (xy, wh, conf, probs)
+
+
+def correct_boxes(box_xy, box_wh, input_hw, image_hw):
+    _require_cuda_f32(box_xy, 'box_xy')
+    _require_cuda_f32(box_wh, 'box_wh')
+    b = box_xy.shape[0]
+    n = box_xy[0].numel() // 2
+    boxes = torch.empty(tuple(box_xy.shape[:-1]) + (4,), dtype=torch.float32, device=box_xy.device)
+    check(lib().yr_correct_boxes(_ptr(box_xy), _ptr(box_wh), b, n, int(input_hw[0]), int(input_hw[1]),
+                                 _ptr(image_hw), _ptr(boxes), stream_ptr()))
+    return boxes
+
+
+def image_hw_tensor(image_shape, batch, device):
+    """image_shape: (h,w) or [B,2] -> int32 [B,2] device tensor."""
+    if isinstance(image_shape, torch.Tensor):
+        t = image_shape.to(device=device, dtype=torch.int32).reshape(-1, 2)
+    else:
+        t = torch.as_tensor(np.asarray(image_shape).reshape(-1, 2).astype(np.int32), device=device)
+    if t.shape[0] == 1 and batch > 1:
+        t = t.expand(batch, 2)
+    if t.shape[0] != batch:
+        raise ValueError('image_shape must be (h,w) or one (h,w) per image')
+    return t.contiguous()

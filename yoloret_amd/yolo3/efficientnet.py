@@ -1,0 +1,275 @@
+"""EfficientNet / MBConv / SE graph builders - host-side mirror of reference
+code/yolo3/efficientnet.py for the detection forward path (inference only).
+
+Same names, argument meaning and error behaviour as the reference
+(``BlockArgs``, ``GlobalParams``, ``BlockDecoder``, ``efficientnet``,
+``efficientnet_params``, ``get_model_params``, ``round_filters``,
+``round_repeats``, ``Swish``, ``Mean``, ``SEBlock``, ``MBConvBlock``,
+``EfficientNet``, ``EfficientNetB0..B7``), but layers come from
+``yoloret_amd.layers`` and record a graph that is lowered to HIP kernels.
+Layers that Keras would auto-name take explicit names via ``name=`` so that a
+weight dict is reproducible: ``stage{n}_block{r}_{expand,dw,se_reduce,se_expand,project}[_BN]``.
+"""
+import collections
+import math
+import re
+
+from .. import layers as L
+from ..layers import Mean, Swish  # re-exported: efficientnet.py:327-331, :391-403
+
+GlobalParams = collections.namedtuple('GlobalParams', [
+    'batch_norm_momentum', 'batch_norm_epsilon', 'dropout_rate', 'data_format', 'num_classes',
+    'width_coefficient', 'depth_coefficient', 'depth_divisor', 'min_depth', 'drop_connect_rate'])
+GlobalParams.__new__.__defaults__ = (None,) * len(GlobalParams._fields)
+
+BlockArgs = collections.namedtuple('BlockArgs', [
+    'kernel_size', 'num_repeat', 'input_filters', 'output_filters', 'expand_ratio', 'id_skip',
+    'strides', 'se_ratio'])
+BlockArgs.__new__.__defaults__ = (None,) * len(BlockArgs._fields)
+
+
+class BlockDecoder(object):
+    """Block-string notation (efficientnet.py:133-200)."""
+
+    def _decode_block_string(self, block_string):
+        assert isinstance(block_string, str)
+        options = {}
+        for op in block_string.split('_'):
+            splits = re.split(r'(\d.*)', op)
+            if len(splits) >= 2:
+                key, value = splits[:2]
+                options[key] = value
+        if 's' not in options or len(options['s']) != 2:
+            raise ValueError('Strides options should be a pair of integers.')
+        return BlockArgs(kernel_size=int(options['k']), num_repeat=int(options['r']),
+                         input_filters=int(options['i']), output_filters=int(options['o']),
+                         expand_ratio=int(options['e']), id_skip=('noskip' not in block_string),
+                         se_ratio=float(options['se']) if 'se' in options else None,
+                         strides=[int(options['s'][0]), int(options['s'][1])])
+
+    def _encode_block_string(self, block):
+        args = ['r%d' % block.num_repeat, 'k%d' % block.kernel_size,
+                's%d%d' % (block.strides[0], block.strides[1]), 'e%s' % block.expand_ratio,
+                'i%d' % block.input_filters, 'o%d' % block.output_filters]
+        if block.se_ratio is not None and 0 < block.se_ratio <= 1:
+            args.append('se%s' % block.se_ratio)
+        if block.id_skip is False:
+            args.append('noskip')
+        return '_'.join(args)
+
+    def decode(self, string_list):
+        assert isinstance(string_list, list)
+        return [self._decode_block_string(s) for s in string_list]
+
+    def encode(self, blocks_args):
+        return [self._encode_block_string(b) for b in blocks_args]
+
+
+def efficientnet(width_coefficient=None, depth_coefficient=None, dropout_rate=0.2, drop_connect_rate=0.2):
+    """Stage table + global params (efficientnet.py:203-228)."""
+    blocks_args = [
+        'r1_k3_s11_e1_i32_o16_se0.25', 'r2_k3_s22_e6_i16_o24_se0.25', 'r2_k5_s22_e6_i24_o40_se0.25',
+        'r3_k3_s22_e6_i40_o80_se0.25', 'r3_k5_s11_e6_i80_o112_se0.25', 'r4_k5_s22_e6_i112_o192_se0.25',
+        'r1_k3_s11_e6_i192_o320_se0.25']
+    global_params = GlobalParams(batch_norm_momentum=0.99, batch_norm_epsilon=1e-3, dropout_rate=dropout_rate,
+                                 drop_connect_rate=drop_connect_rate, data_format='channels_last',
+                                 num_classes=1000, width_coefficient=width_coefficient,
+                                 depth_coefficient=depth_coefficient, depth_divisor=8, min_depth=None)
+    return BlockDecoder().decode(blocks_args), global_params
+
+
+def efficientnet_params(model_name):
+    """(width, depth, resolution, dropout) per model name (efficientnet.py:231-244)."""
+    params_dict = {
+        'efficientnet-b0': (1.0, 1.0, 224, 0.2), 'efficientnet-b1': (1.0, 1.1, 240, 0.2),
+        'efficientnet-b2': (1.1, 1.2, 260, 0.3), 'efficientnet-b3': (1.2, 1.4, 300, 0.3),
+        'efficientnet-b4': (1.4, 1.8, 380, 0.4), 'efficientnet-b5': (1.6, 2.2, 456, 0.4),
+        'efficientnet-b6': (1.8, 2.6, 528, 0.5), 'efficientnet-b7': (2.0, 3.1, 600, 0.5)}
+    return params_dict[model_name]
+
+
+def get_model_params(model_name, override_params=None):
+    """efficientnet.py:247-267.  Unlike the reference this does not mutate (or print)
+    the caller's dict; 'drop_rate' is still accepted and ignored, and unknown keys
+    still raise ValueError (from namedtuple._replace)."""
+    if model_name.startswith('efficientnet'):
+        width_coefficient, depth_coefficient, input_shape, dropout_rate = efficientnet_params(model_name)
+        blocks_args, global_params = efficientnet(width_coefficient, depth_coefficient, dropout_rate)
+    else:
+        raise NotImplementedError('model name is not pre-defined: %s' % model_name)
+    override_params = dict(override_params or {})
+    override_params.pop('drop_rate', None)
+    if override_params:
+        global_params = global_params._replace(**override_params)
+    return blocks_args, global_params, input_shape
+
+
+def round_filters(filters, global_params):
+    """efficientnet.py:364-380."""
+    multiplier = global_params.width_coefficient
+    divisor = global_params.depth_divisor
+    min_depth = global_params.min_depth
+    if not multiplier:
+        return filters
+    filters *= multiplier
+    min_depth = min_depth or divisor
+    new_filters = max(min_depth, int(filters + divisor / 2) // divisor * divisor)
+    if new_filters < 0.9 * filters:
+        new_filters += divisor
+    return int(new_filters)
+
+
+def round_repeats(repeats, global_params):
+    """efficientnet.py:383-388."""
+    multiplier = global_params.depth_coefficient
+    if not multiplier:
+        return repeats
+    return int(math.ceil(multiplier * repeats))
+
+
+def _require_channels_last(global_params):
+    if global_params.data_format not in (None, 'channels_last'):
+        raise ValueError('only data_format="channels_last" (NHWC) is supported on MI355X')
+
+
+def SEBlock(block_args, global_params, quantize=False, name='se'):
+    """Squeeze-excite (efficientnet.py:406-438)."""
+    num_reduced_filters = max(1, int(block_args.input_filters * block_args.se_ratio))
+    filters = block_args.input_filters * block_args.expand_ratio
+    _require_channels_last(global_params)
+
+    def block(inputs):
+        x = Mean([1, 2], name=name + '_se_mean')(inputs)
+        x = L.Conv2D(num_reduced_filters, kernel_size=[1, 1], strides=[1, 1], padding='same', use_bias=True,
+                     name=name + '_se_reduce')(x)
+        x = Swish(name=name + '_se_swish')(x)
+        x = L.Conv2D(filters, kernel_size=[1, 1], strides=[1, 1], padding='same', use_bias=True,
+                     name=name + '_se_expand')(x)
+        x = L.Activation('sigmoid', name=name + '_se_sigmoid')(x)
+        return L.Multiply(name=name + '_se_mul')([x, inputs])
+
+    return block
+
+
+def MBConvBlock(block_args, global_params, drop_connect_rate=None, quantize=False, name='mbconv', lite=False):
+    """MBConv at inference (efficientnet.py:467-536); DropConnect (:334-361) is the identity.
+    ``lite`` is build-defined (no reference counterpart): no SE, ReLU6 instead of Swish."""
+    eps = global_params.batch_norm_epsilon
+    mom = global_params.batch_norm_momentum
+    _require_channels_last(global_params)
+    has_se = (block_args.se_ratio is not None) and (block_args.se_ratio > 0) and (block_args.se_ratio <= 1) and not lite
+    filters = block_args.input_filters * block_args.expand_ratio
+    kernel_size = block_args.kernel_size
+    act = (lambda n: L.ReLU(6., name=n)) if lite else (lambda n: Swish(name=n))
+
+    def block(inputs):
+        if block_args.expand_ratio != 1:
+            x = L.Conv2D(filters, kernel_size=[1, 1], strides=[1, 1], padding='same', use_bias=False,
+                         name=name + '_expand')(inputs)
+            x = L.BatchNormalization(momentum=mom, epsilon=eps, name=name + '_expand_BN')(x)
+            x = act(name + '_expand_act')(x)
+        else:
+            x = inputs
+        x = L.DepthwiseConv2D([kernel_size, kernel_size], strides=block_args.strides, padding='same',
+                              use_bias=False, name=name + '_dw')(x)
+        x = L.BatchNormalization(momentum=mom, epsilon=eps, name=name + '_dw_BN')(x)
+        x = act(name + '_dw_act')(x)
+        if has_se:
+            x = SEBlock(block_args, global_params, quantize=quantize, name=name)(x)
+        x = L.Conv2D(block_args.output_filters, kernel_size=[1, 1], strides=[1, 1], padding='same',
+                     use_bias=False, name=name + '_project')(x)
+        x = L.BatchNormalization(momentum=mom, epsilon=eps, name=name + '_project_BN')(x)
+        if block_args.id_skip:
+            if all(s == 1 for s in block_args.strides) and block_args.input_filters == block_args.output_filters:
+                x = L.Add(name=name + '_add')([x, inputs])
+        return x
+
+    return block
+
+
+class BackboneModel:
+    """What the reference gets back from tf.keras.Model(inputs, outputs) for a backbone:
+    ``inputs``, ``output`` and ``get_layer(name).output`` (model.py:186-190,213-217)."""
+
+    def __init__(self, inputs, output, named):
+        self.inputs = [inputs]
+        self.output = output
+        self._named = named
+
+    def get_layer(self, name):
+        class _L:
+            pass
+        if name not in self._named:
+            raise ValueError('No such layer: %s' % name)
+        layer = _L()
+        layer.output = self._named[name]
+        layer.name = name
+        return layer
+
+
+def EfficientNet(input_shape, block_args_list, global_params, include_top=True, pooling=None,
+                 input_tensor=None, quantize=False, lite=False, last_stage=None):
+    """efficientnet.py:611-710 with include_top=False semantics for detection.  Stage ends are
+    exposed as layers ``stage{n}`` (the reference taps them by Keras auto-names ``add_17`` ...,
+    model.py:213-217, valid only for B3; positional names work for every width/depth)."""
+    if include_top:
+        raise ValueError('the detection path builds EfficientNet with include_top=False')
+    eps = global_params.batch_norm_epsilon
+    mom = global_params.batch_norm_momentum
+    _require_channels_last(global_params)
+    inputs = input_tensor if input_tensor is not None else L.Input(shape=input_shape)
+    act = (lambda n: L.ReLU(6., name=n)) if lite else (lambda n: Swish(name=n))
+    x = L.Conv2D(filters=round_filters(32, global_params), kernel_size=[3, 3], strides=[2, 2], padding='same',
+                 use_bias=False, name='stem_conv')(inputs)
+    x = L.BatchNormalization(momentum=mom, epsilon=eps, name='stem_BN')(x)
+    x = act('stem_act')(x)
+    named = {}
+    for si, block_args in enumerate(block_args_list, start=1):
+        if last_stage is not None and si > last_stage:
+            break
+        assert block_args.num_repeat > 0
+        block_args = block_args._replace(
+            input_filters=round_filters(block_args.input_filters, global_params),
+            output_filters=round_filters(block_args.output_filters, global_params),
+            num_repeat=round_repeats(block_args.num_repeat, global_params))
+        x = MBConvBlock(block_args, global_params, name='stage%d_block0' % si, lite=lite)(x)
+        if block_args.num_repeat > 1:
+            block_args = block_args._replace(input_filters=block_args.output_filters, strides=[1, 1])
+        for rep in range(1, block_args.num_repeat):
+            x = MBConvBlock(block_args, global_params, name='stage%d_block%d' % (si, rep), lite=lite)(x)
+        named['stage%d' % si] = x
+    return BackboneModel(inputs, x, named)
+
+
+def _get_model_by_name(model_name, input_shape=None, include_top=True, weights=None, classes=1000,
+                       pooling=None, input_tensor=None, lite=False):
+    """efficientnet.py:713-791 minus the ImageNet download (no network; weights are loaded
+    into the whole detector afterwards)."""
+    if weights not in {None}:
+        raise ValueError('pretrained backbone weights are not available offline; pass weights=None and '
+                         'load a full detector weight file instead')
+    block_args_list, global_params, default_input_shape = get_model_params(model_name, override_params={'num_classes': classes})
+    if input_shape is None:
+        input_shape = (default_input_shape, default_input_shape, 3)
+    # only stages 1..6 feed the detector
+    return EfficientNet(input_shape, block_args_list, global_params, include_top=include_top, pooling=pooling,
+                        input_tensor=input_tensor, lite=lite, last_stage=6)
+
+
+def _make(name):
+    def f(include_top=True, input_shape=None, weights=None, classes=1000, pooling=None, input_tensor=None, lite=False):
+        return _get_model_by_name(name, include_top=include_top, input_shape=input_shape, weights=weights,
+                                  classes=classes, pooling=pooling, input_tensor=input_tensor, lite=lite)
+    f.__name__ = 'EfficientNetB' + name[-1]
+    f.__doc__ = 'efficientnet.py:793-910 (%s), truncated after stage 6 for detection.' % name
+    return f
+
+
+EfficientNetB0 = _make('efficientnet-b0')
+EfficientNetB1 = _make('efficientnet-b1')
+EfficientNetB2 = _make('efficientnet-b2')
+EfficientNetB3 = _make('efficientnet-b3')
+EfficientNetB4 = _make('efficientnet-b4')
+EfficientNetB5 = _make('efficientnet-b5')
+EfficientNetB6 = _make('efficientnet-b6')
+EfficientNetB7 = _make('efficientnet-b7')
