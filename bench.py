@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""Headline bench: images/sec of the detection forward path (backbone -> RFCR -> heads ->
+decode -> per-class NMS -> packed detections [-> all-gather when N>1]) on synthetic batches that
+are already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]:
+MobileNetV2-0.75x @416, batch 64, fp32, random weights.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job img/s,
+`roofline` for the dominant kernel symbol (measured live with hipEvents), `roofline_step` for the
+whole step against the conv-granular algorithmic bytes of SURVEY.md 8(d), and `cpu_baseline` =
+the oracle's torch-CPU port timed on this box's host cores (N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy peak 6290
+FP32_PEAK_TFLOPS = 157.3  # fp32 vector == fp32 MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='images per GPU per step (weak scaling)')
+    ap.add_argument('--model', default='mobilenetv2x75')
+    ap.add_argument('--size', type=int, default=416)
+    ap.add_argument('--classes', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline sample')
+    ap.add_argument('--profile-iters', type=int, default=3)
+    ap.add_argument('--per-op', action='store_true', help='also print the per-op table to stderr')
+    return ap.parse_args()
+
+
+def cpu_baseline(model_name, size, classes, anchors, seconds):
+    """The oracle's torch-CPU port (oneDNN) + C decode/NMS on all host cores; bounded sample."""
+    from oracle import cpost, params, torch_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = params.ParamStore(1234, 'survey')
+    ref = torch_ref.TorchReference(P, model_name, 3, classes)
+    b = 8
+    x = params.synthetic_images(b, size, size)
+
+    def one():
+        ys = ref(x)
+        for i in range(b):
+            cpost.yolo_eval([y[i] for y in ys], anchors, 3, classes, (size, size), 20, 0.2, 0.5)
+    one()  # warm-up (oneDNN primitive creation)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += b
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 4096:
+            break
+    return {'value': round(n / dt, 2), 'unit': 'img/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d images (batches of %d) of the same %s@%d workload through oracle/torch_ref.py '
+                      '(torch-CPU/oneDNN fp32) + oracle C decode/NMS, %.1f s' % (n, b, model_name, size, dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (a.gpus, a.gpus))
+    import torch.distributed as dist
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from yoloret_amd import layers as L
+    from yoloret_amd import weights as W
+    from yoloret_amd.parallel import DetectionGatherer
+    from yoloret_amd.pipeline import DetectionPipeline
+    from yoloret_amd.yolo3.model import yolov3_body
+    from yoloret_amd.yolo3.utils import get_anchors
+
+    anchors = get_anchors('model_data/yolo_anchors.txt')
+    model = yolov3_body(L.Input(shape=[a.size, a.size, 3]), a.model, 3, num_classes=a.classes)
+    model.set_weights(W.synthetic_weights(model, 1234, 'survey'))
+    pipe = DetectionPipeline(model, anchors, a.classes, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5)
+    gather = DetectionGatherer()
+    b = a.batch
+    x = torch.from_numpy(W.synthetic_images(b, a.size, a.size, seed=20240416 + rank)).to(dev)
+    image_hw = torch.tensor([[a.size, a.size]] * b, dtype=torch.int32, device=dev)
+
+    def step():
+        det, cnt = pipe(x, image_hw)
+        return gather(det, cnt, pipe.record)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / a.steps * 1e3
+    value = world * b * a.steps / elapsed
+
+    out = None
+    if rank == 0:
+        plan = model.plan
+        n_boxes = pipe.n
+        alg_fwd = plan.algorithmic_bytes_per_image()
+        alg_dec = n_boxes * (a.classes + 5) * 4 + n_boxes * (4 + a.classes) * 4
+        alg_img = alg_fwd + alg_dec + plan.weight_bytes() / b
+        flops_img = 2.0 * plan.total_macs()
+        # ---- live per-kernel measurement (hipEvent pair around every launch, same stream)
+        prof = model.profile(x, iters=a.profile_iters)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ys = pipe.forward(x)
+        post_ms = np.zeros(3)
+        reps = 5
+        for _ in range(reps):
+            v = pipe._buffers(b, dev)
+            ev[0].record()
+            from yoloret_amd import runtime as rt
+            rt.decode([y for y in v['ys']], anchors, a.classes, image_hw, (a.size, a.size))
+            ev[1].record()
+            rt.nms(v['boxes'], v['scores'], 20, 0.2, 0.5)
+            ev[2].record()
+            rt.pack_detections(v['boxes'], v['scores'], v['idx'], v['cnt'])
+            ev[3].record()
+            torch.cuda.synchronize(dev)
+            post_ms += [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
+        post_ms /= reps
+        rows = prof + [
+            dict(name='decode', kind='decode', kernel='decode_kernel', ms=post_ms[0], macs=0, bytes=alg_dec * b),
+            dict(name='nms', kind='nms', kernel='nms_kernel', ms=post_ms[1], macs=0,
+                 bytes=(a.classes * n_boxes * 4 + n_boxes * 16) * b),
+            dict(name='pack', kind='pack', kernel='pack_kernel', ms=post_ms[2], macs=0, bytes=0)]
+        by = {}
+        for r in rows:
+            k = by.setdefault(r['kernel'], dict(ms=0.0, bytes=0, macs=0, launches=0))
+            k['ms'] += r['ms']; k['bytes'] += r['bytes']; k['macs'] += r['macs']; k['launches'] += 1
+        dom = max(by, key=lambda k: by[k]['ms'])
+        d = by[dom]
+        avg_ms = d['ms'] / d['launches']
+        ach = d['bytes'] / d['launches'] / (avg_ms * 1e-3) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': dom, 'launches_per_step': d['launches'],
+                    'avg_launch_ms': round(avg_ms, 4), 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'tflops': round(2.0 * d['macs'] / (d['ms'] * 1e-3) / 1e12, 2)}
+        per_gpu = value / world
+        step_gbs = per_gpu * alg_img / 1e9
+        roofline_step = {'bound': 'hbm', 'achieved': round(step_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(step_gbs / HBM_PEAK_GBS, 4), 'alg_bytes_per_image': int(alg_img),
+                         'tflops': round(per_gpu * flops_img / 1e12, 2),
+                         'frac_fp32_peak': round(per_gpu * flops_img / 1e12 / FP32_PEAK_TFLOPS, 4),
+                         'sum_kernel_ms': round(sum(r['ms'] for r in rows), 3),
+                         'launches_per_step': len(rows)}
+        if a.per_op:
+            for r in sorted(rows, key=lambda r: -r['ms']):
+                gbs = r['bytes'] / (r['ms'] * 1e-3) / 1e9 if r['ms'] > 0 else 0
+                tf = 2.0 * r['macs'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0
+                sys.stderr.write('%-24s %-22s %8.4f ms %8.1f GB/s %7.2f TF\n' % (r['name'], r['kernel'], r['ms'], gbs, tf))
+            for k, v in sorted(by.items(), key=lambda kv: -kv[1]['ms']):
+                sys.stderr.write('SYMBOL %-24s n=%3d total %8.4f ms  %8.1f GB/s\n'
+                                 % (k, v['launches'], v['ms'], v['bytes'] / (v['ms'] * 1e-3) / 1e9 if v['ms'] else 0))
+        # ---- p50 per-image latency at B=1 (the second half of BASELINE.json's metric)
+        p50 = None
+        if world == 1:
+            x1 = x[:1].contiguous()
+            hw1 = image_hw[:1].contiguous()
+            for _ in range(20):
+                pipe(x1, hw1)
+            torch.cuda.synchronize(dev)
+            ts = []
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(200):
+                e0.record()
+                pipe(x1, hw1)
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            p50 = round(float(np.median(ts)), 4)
+        out = {'metric': 'images/sec (+ p50 per-image ms) MobileNetV2-0.75x @416, 1/2/4/8 MI355X',
+               'value': round(value, 1), 'unit': 'img/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+               'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
+               'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': '%s @%d, batch %d per GPU, fp32, random weights (SURVEY 8(d) recipe), C=%d: '
+                                      'forward + decode + per-class NMS + pack%s'
+                                      % (a.model, a.size, b, a.classes, ' + all-gather of detections' if world > 1 else ''),
+                          'global_batch': b * world, 'parallelism': 'dp%d (image-sharded)' % world},
+               'p50_ms_b1': p50, 'roofline': roofline, 'roofline_step': roofline_step}
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(a.model, a.size, a.classes, anchors, a.cpu_seconds)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

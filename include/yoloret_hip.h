@@ -62,7 +62,9 @@ typedef enum {
     YR_OP_SE_MEAN = 4,   /* Mean over H,W                              (efficientnet.py:391-403,417) */
     YR_OP_SE_FC = 5,     /* 1x1+bias -> Swish -> 1x1+bias -> sigmoid   (efficientnet.py:419-434) */
     YR_OP_WSUM = 6,      /* WeightedSum of 4 gathered sources          (model.py:117-137,157) */
-    YR_OP_GATHER = 7     /* materialise upsample/maxpool/concat        (standalone K5; testing / unfused use) */
+    YR_OP_GATHER = 7,    /* materialise upsample/maxpool/concat        (standalone K5; testing / unfused use) */
+    YR_OP_MBCONV = 8     /* fused inverted-residual block: expand 1x1+BN+act -> DW3x3+BN+act -> project 1x1+BN (+residual)
+                            (MobileNetV2 block_* [3P]; SE-free MBConv, efficientnet.py:467-536); the expanded tensor stays in LDS */
 } yr_op_kind;
 
 /* One fused operation.  Weight-like fields are float offsets into the weight
@@ -88,7 +90,11 @@ typedef struct {
      *   DEPTHWISE: wgt = [k*k][round_up(c,4)] ; scale/shift [round_up(c,4)]
      *   STEM:      wgt = [27][round_up(cout,4)] ; scale/shift [round_up(cout,4)]
      *   SE_FC:     wgt = W1t[reduced][ldc], b1 [reduced], wgt2 = W2[reduced][ldc], b2 [ldc], ldc = round_up(c,4)
-     *   WSUM:      wgt = alpha[4] */
+     *   WSUM:      wgt = alpha[4]
+     *   MBCONV:    se_reduced = expanded width Cexp, ldE = round_up(Cexp,4); wgt = expand Wt[Cexp][round_up(cin,4)]
+     *              (null: no expand stage), scale/shift = expand BN [ldE]; wgt2 = DW [9][ldE] ++ DW scale [ldE] ++
+     *              DW shift [ldE]; b1 = project Wt[cout][ldE]; b2 = project scale [ldo] ++ shift [ldo], ldo = round_up(cout,4);
+     *              res (optional) must alias src[0] (the residual is taken from the on-chip input tile) */
     const float* wgt;    int64_t wgt_off;
     const float* scale;  int64_t scale_off;
     const float* shift;  int64_t shift_off;
@@ -124,7 +130,13 @@ size_t yr_workspace_bytes(const yr_handle* h, int batch);
 /* images [B,H,W,3] -> y1,y2,y3 raw logits [B,G,G,A*(C+5)], G = H/32, H/16, H/8. */
 int yr_forward(yr_handle* h, const float* images, int batch, float* y1, float* y2, float* y3,
                void* workspace, size_t workspace_bytes, void* stream);
-/* Launch-count / per-kind breakdown of the plan (for reports). */
+/* Measurement aid: the same replay with a hipEvent pair around every op, `iters` times.
+ * ms_per_op [n_ops] gets each op's average duration; kernel_names [n_ops] (nullable) gets a static
+ * string naming the kernel symbol the op dispatched to.  Synchronises the stream. */
+int yr_forward_profile(yr_handle* h, const float* images, int batch, float* y1, float* y2, float* y3,
+                       void* workspace, size_t workspace_bytes, void* stream, int iters,
+                       float* ms_per_op, const char** kernel_names);
+/* Number of kernel launches one yr_forward enqueues. */
 int yr_plan_num_launches(const yr_handle* h);
 
 /* ---- single fused ops (device pointers inside `op`); parity-testable in isolation. */

@@ -18,16 +18,16 @@ from tests.util import ANCHORS, assert_close
 pytestmark = pytest.mark.gpu
 
 
-def _build(model_name, hw, num_classes, seed=1234):
+def _build(model_name, hw, num_classes, seed=1234, recipe='conditioned'):
     from yoloret_amd import layers as L
     from yoloret_amd.yolo3.model import yolov3_body
     m = yolov3_body(L.Input(shape=[hw[0], hw[1], 3]), model_name, 3, num_classes=num_classes)
-    P = params.ParamStore(seed)
+    P = params.ParamStore(seed, recipe)
     return m, P
 
 
-def _run_both(dev, model_name, hw, b, num_classes=20):
-    m, P = _build(model_name, hw, num_classes)
+def _run_both(dev, model_name, hw, b, num_classes=20, recipe='conditioned'):
+    m, P = _build(model_name, hw, num_classes, recipe=recipe)
     x = params.synthetic_images(b, hw[0], hw[1])
     ref = om.yolov3_body(P, x, model_name, 3, num_classes)
     m.set_weights(P.values)  # the oracle's walk created every parameter the product needs
@@ -75,6 +75,29 @@ def test_logits_416_and_detections(dev):
     assert total > 0 and agree >= 0.98 * total
 
 
+def test_logits_survey_recipe_vs_fp64(dev):
+    """SURVEY.md 8(d)'s weight recipe amplifies rounding noise ~1e3x (oracle/params.py): NumPy fp32
+    and NumPy fp64 already differ by ~1e-3 on it, so a 1e-4 bar against ANY fp32 implementation is
+    not meaningful there.  The bar instead: measured against the fp64 oracle, the HIP path must be
+    no less accurate than the NumPy fp32 oracle (x1.5 slack)."""
+    b, hw = 1, (416, 416)
+    m, P = _build('mobilenetv2x75', hw, 20, recipe='survey')
+    x = params.synthetic_images(b, *hw)
+    ref32 = om.yolov3_body(P, x, 'mobilenetv2x75', 3, 20)
+    ref64 = om.yolov3_body(P, x.astype(np.float64), 'mobilenetv2x75', 3, 20)
+    m.set_weights(P.values)
+    ys = m(torch.from_numpy(x).to(dev))
+    torch.cuda.synchronize()
+    for i, (y, r32, r64) in enumerate(zip(ys, ref32, ref64)):
+        den = np.maximum(1.0, np.abs(r64))
+        e_gpu = np.abs(y.cpu().numpy().astype(np.float64) - r64) / den
+        e_np = np.abs(r32.astype(np.float64) - r64) / den
+        print('y%d  max/mean scaled error vs fp64:  HIP %.2e / %.2e   NumPy-fp32 %.2e / %.2e'
+              % (i + 1, e_gpu.max(), e_gpu.mean(), e_np.max(), e_np.mean()))
+        assert e_gpu.mean() <= 1.5 * e_np.mean() + 1e-6
+        assert e_gpu.max() <= 1.5 * e_np.max() + 1e-5
+
+
 def test_batch_equals_per_image(dev):
     """Batched execution == the reference applied to each image independently."""
     m, P = _build('mobilenetv2x75', (96, 96), 20)
@@ -101,3 +124,27 @@ def test_model_errors(dev):
         m(torch.zeros((1, 32, 64, 3), device=dev))
     with pytest.raises(ValueError):
         m(torch.zeros((1, 64, 64, 3)))  # CPU tensor: no fallback
+
+
+def test_unfused_plan_matches_fused(dev):
+    """The fused inverted-residual kernel and the unfused op chain agree (and both match the oracle)."""
+    from yoloret_amd import layers as L
+    from yoloret_amd.yolo3.model import yolov3_body
+    import os
+    hw = (96, 96)
+    P = params.ParamStore(1234)
+    x = params.synthetic_images(2, *hw)
+    ref = om.yolov3_body(P, x, 'mobilenetv2x75', 3, 20)
+    outs = {}
+    for fuse in ('1', '0'):
+        os.environ['YOLORET_FUSE'] = fuse
+        try:
+            m = yolov3_body(L.Input(shape=[hw[0], hw[1], 3]), 'mobilenetv2x75', 3, num_classes=20)
+        finally:
+            os.environ.pop('YOLORET_FUSE', None)
+        kinds = set(o.kind for o in m.plan.ops)
+        assert (8 in kinds) == (fuse == '1')
+        m.set_weights(P.values)
+        outs[fuse] = [y.cpu().numpy() for y in m(torch.from_numpy(x).to(dev))]
+        for y, r in zip(outs[fuse], ref):
+            assert_close(y, r, 1e-4, 'fuse=%s' % fuse)

@@ -101,7 +101,8 @@ def _random_boxes(rng, n, size=416.0, degenerate=True):
 
 
 @pytest.mark.parametrize('n,c,score_thr,ties', [(10647, 20, 0.2, False), (10647, 4, 0.0, False),
-                                                (3000, 7, 0.3, True), (100, 3, 0.99, False), (257, 2, 0.1, True)])
+                                                (3000, 7, 0.3, True), (100, 3, 0.99, False), (257, 2, 0.1, True),
+                                                (30000, 2, 0.3, False), (25200, 3, 0.2, True)])
 def test_nms_bit_exact(dev, n, c, score_thr, ties):
     rt = _rt()
     rng = np.random.default_rng(n + c)

@@ -12,6 +12,7 @@ Buffers are placed in one arena with liveness-based reuse; offsets are per image
 plan is batch-independent.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -74,14 +75,32 @@ class Plan:
         self.input_buf, self.output_bufs = inputs, outputs
         self.param_shapes = param_shapes
         self.input_shape = input_shape
+        self._liveness()
         self._assign_arena()
         self._assign_blob_offsets()
+
+    def _liveness(self):
+        """(Re)derive first definition / last use from the final op list, drop buffers that no op
+        touches any more (intermediates removed by fusion) and renumber the table."""
+        for b in self.bufs:
+            b.first_def, b.last_use = None, -1
+        self.input_buf.first_def = -1
+        for i, op in enumerate(self.ops):
+            if op.out.first_def is None:
+                op.out.first_def = i
+            for s in op.srcs:
+                s.buf.last_use = max(s.buf.last_use, i)
+            for b in (op.res, op.gate):
+                if b is not None:
+                    b.last_use = max(b.last_use, i)
+        self.bufs = [b for b in self.bufs if b.first_def is not None]
+        for i, b in enumerate(self.bufs):
+            b.id = i
 
     # -- arena: first-fit with liveness reuse (offsets in floats per image, multiples of 4)
     def _assign_arena(self):
         arena = [b for b in self.bufs if b.external_slot < 0]
         for b in arena:
-            assert b.first_def is not None, b.name
             if b.last_use < b.first_def:
                 b.last_use = b.first_def
         live = []  # (offset, size, last_use)
@@ -149,11 +168,12 @@ class Plan:
     def total_macs(self):
         return sum(op.macs for op in self.ops)
 
-    def algorithmic_bytes_per_image(self, num_boxes=0, num_classes=0, batch=None):
-        """SURVEY.md 8(d): conv-granular activation reads+writes (+residual reads) in fp32;
-        upsample/maxpool/concat/wsum/SE-scale free; SE mean costs its C outputs."""
-        elems = 0
-        wsum_outs = set(op.out.id for op in self.ops if op.kind == rt.OP_WSUM)
+    def algorithmic_bytes_per_op(self):
+        """Per-op share of SURVEY.md 8(d)'s bytes_alg, per image, fp32: conv-granular activation
+        reads + writes (+ residual reads); upsample / maxpool / concat / SE-scale free; the weighted
+        sum is charged its source reads and its consumer DW no input read (they are one fused op
+        in the accounting); SE mean costs its C outputs."""
+        wsum_outs = set(id(op.out) for op in self.ops if op.kind == rt.OP_WSUM)
 
         def src_elems(op, s):
             # SURVEY.md Appendix B accounting (the agreed figure: 198.9 MB/img for MBV2x0.75@416):
@@ -163,28 +183,129 @@ class Plan:
                 return s.buf.h * s.buf.w * s.c
             return op.h * op.w * s.c
 
-        for op in self.ops:
+        def elems_of(op):
+            elems = 0
+            if op.kind == rt.OP_MBCONV:
+                # the accounting stays conv-granular (the figure everyone computes from): a fused
+                # block is charged what its three convolutions would move unfused
+                return sum(elems_of(f) for f in op.fused)
             if op.kind in (rt.OP_STEM, rt.OP_POINTWISE, rt.OP_DEPTHWISE):
-                if op.kind == rt.OP_POINTWISE and op.h == 1 and op.w == 1:
-                    continue
-                elems += op.h * op.w * op.cout
-                if op.kind == rt.OP_DEPTHWISE or op.kind == rt.OP_STEM:
-                    s = op.srcs[0]
-                    if s.buf.id not in wsum_outs:  # the weighted sum is folded into the DW's loads
-                        elems += s.buf.h * s.buf.w * s.c
-                else:
-                    elems += sum(src_elems(op, s) for s in op.srcs)
-                if op.res is not None:
+                if not (op.kind == rt.OP_POINTWISE and op.h == 1 and op.w == 1):
                     elems += op.h * op.w * op.cout
+                    if op.kind == rt.OP_DEPTHWISE or op.kind == rt.OP_STEM:
+                        s = op.srcs[0]
+                        if id(s.buf) not in wsum_outs:
+                            elems += s.buf.h * s.buf.w * s.c
+                    else:
+                        elems += sum(src_elems(op, s) for s in op.srcs)
+                    if op.res is not None:
+                        elems += op.h * op.w * op.cout
             elif op.kind == rt.OP_WSUM:
                 elems += sum(s.buf.h * s.buf.w * s.c for s in op.srcs)
             elif op.kind == rt.OP_SE_MEAN:
                 elems += op.cout
-        return elems * 4
+            return elems
+
+        return [elems_of(op) * 4 for op in self.ops]
+
+    def hbm_bytes_per_op(self):
+        """What each op actually has to move through HBM per image when intermediates of fused ops
+        stay on chip (reads of every source + writes of the output, fp32)."""
+        out = []
+        for op in self.ops:
+            rd = sum(s.buf.h * s.buf.w * s.c for s in op.srcs)
+            if op.kind == rt.OP_POINTWISE and op.res is not None:
+                rd += op.h * op.w * op.cout
+            out.append((rd + op.out.h * op.out.w * op.out.c) * 4)
+        return out
+
+    def algorithmic_bytes_per_image(self):
+        return sum(self.algorithmic_bytes_per_op())
+
+    def weight_bytes(self):
+        return int(sum(int(np.prod(s)) for s in self.param_shapes.values())) * 4
+
+
+# Measured on MI355X (profiles/, round 1): the fused kernel beats the three-kernel chain on the
+# high-resolution, narrow blocks (MobileNetV2 block_1..5: Cin <= 32), where the expanded tensor is
+# 81 % of the traffic; on the deep 26x26 / 13x13 blocks its 8x8 tiles under-fill the chip and the
+# unfused GEMMs win, so those stay unfused until the kernel grows a large-M variant.
+FUSE_MAX_CIN = int(os.environ.get('YOLORET_FUSE_MAX_CIN', '32'))
+
+
+def fuse_inverted_residuals(ops, output_buf_ids):
+    """Peephole over the lowered op list: [POINTWISE expand+act ->] DEPTHWISE 3x3+act -> POINTWISE
+    project (+residual == block input) becomes one MBCONV op whose expanded tensors never reach HBM."""
+    readers = {}
+    for op in ops:
+        for s in op.srcs:
+            readers[s.buf.id] = readers.get(s.buf.id, 0) + 1
+        for b in (op.res, op.gate):
+            if b is not None:
+                readers[b.id] = readers.get(b.id, 0) + 1
+
+    def private(buf):  # read by exactly one op and not a model output
+        return readers.get(buf.id, 0) == 1 and buf.id not in output_buf_ids and buf.external_slot < 0
+
+    def plain1(op):
+        return len(op.srcs) == 1 and op.srcs[0].xform == 'identity' and op.gate is None
+
+    out, i = [], 0
+    while i < len(ops):
+        e = ops[i]
+        exp = dw = proj = None
+        j = i
+        if (e.kind == rt.OP_POINTWISE and plain1(e) and e.res is None and e.act in ('relu6', 'swish')
+                and private(e.out) and 'scale' in e.params and not (e.h == 1 and e.w == 1) and j + 1 < len(ops)):
+            exp, j = e, j + 1
+        d = ops[j] if j < len(ops) else None
+        if (d is not None and d.kind == rt.OP_DEPTHWISE and d.k == 3 and plain1(d) and private(d.out)
+                and (exp is None or (d.srcs[0].buf is exp.out and d.act == exp.act)) and d.act in ('relu6', 'swish')
+                and d.srcs[0].buf.ld == round_up(d.cin, 4) and j + 1 < len(ops)):
+            p = ops[j + 1]
+            block_in = exp.srcs[0] if exp is not None else d.srcs[0]
+            if (p.kind == rt.OP_POINTWISE and plain1(p) and p.srcs[0].buf is d.out and p.act == 'none'
+                    and 'scale' in p.params and p.cout <= 224 and block_in.buf.ld % 4 == 0
+                    and exp is not None and block_in.c <= FUSE_MAX_CIN
+                    and (p.res is None or (p.res is block_in.buf and d.stride == 1 and p.cout == block_in.c))):
+                dw, proj = d, p
+        if proj is None:
+            out.append(e)
+            i += 1
+            continue
+        block_in = exp.srcs[0] if exp is not None else dw.srcs[0]
+        cexp, cout = dw.cin, proj.cout
+        lde, ldo = round_up(cexp, 4), round_up(cout, 4)
+        m = OpRec(rt.OP_MBCONV, (exp or dw).name.rsplit('_', 1)[0] + '_mbconv', act=dw.act, h=proj.h, w=proj.w,
+                  cin=block_in.c, cout=cout, k=3, stride=dw.stride, se_reduced=cexp, srcs=[block_in], out=proj.out,
+                  res=proj.res, macs=(exp.macs if exp else 0) + dw.macs + proj.macs)
+        m.fused = [o for o in (exp, dw, proj) if o is not None]
+
+        def padded(fn, n, ld):
+            def f(wd):
+                o = np.zeros(ld, np.float32)
+                o[:n] = fn(wd)[:n]
+                return o
+            return f
+        if exp is not None:
+            m.params['wgt'] = exp.params['wgt']
+            m.params['scale'] = ((lde,), padded(exp.params['scale'][1], cexp, lde))
+            m.params['shift'] = ((lde,), padded(exp.params['shift'][1], cexp, lde))
+        dwp = dw.params
+        m.params['wgt2'] = ((11 * lde,), lambda wd, dwp=dwp: np.concatenate(
+            [dwp['wgt'][1](wd).ravel(), dwp['scale'][1](wd), dwp['shift'][1](wd)]))
+        m.params['b1'] = proj.params['wgt']
+        pp_ = proj.params
+        m.params['b2'] = ((2 * ldo,), lambda wd, pp_=pp_, cout=cout, ldo=ldo: np.concatenate(
+            [padded(pp_['scale'][1], cout, ldo)(wd), padded(pp_['shift'][1], cout, ldo)(wd)]))
+        out.append(m)
+        i = j + 2
+    return out
 
 
 class Compiler:
-    def __init__(self, inputs, outputs):
+    def __init__(self, inputs, outputs, fuse=True):
+        self.fuse = fuse
         self.inputs = inputs
         self.outputs = list(outputs)
         self.bufs = []
@@ -325,7 +446,10 @@ class Compiler:
             if not v.plain or v.segs[0].buf.external_slot < 1:
                 raise NotImplementedError('model outputs must be produced by a 1x1 convolution')
             outs.append(v.segs[0].buf)
-        return Plan(self.ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape)
+        ops = self.ops
+        if self.fuse:
+            ops = fuse_inverted_residuals(ops, set(b.id for b in outs))
+        return Plan(ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape)
 
     def _lower_conv2d(self, n, done):
         x = n.inputs[0]
@@ -553,5 +677,5 @@ class Compiler:
         raise NotImplementedError('Add %s does not follow a fused 1x1 convolution' % n.name)
 
 
-def compile_graph(inputs, outputs):
-    return Compiler(inputs, outputs).compile()
+def compile_graph(inputs, outputs, fuse=True):
+    return Compiler(inputs, outputs, fuse).compile()

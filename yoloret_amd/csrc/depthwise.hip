@@ -85,6 +85,10 @@ static int launch_dw(DwArgs a, hipStream_t s) {
     a.total = (long long)a.B * a.Ho * a.xstrips * a.C4;
     const long long blocks = (a.total + 255) / 256;
     YR_REQUIRE(blocks < (1ll << 31), "depthwise: grid too large");
+    static char nm[32];
+    static const int nm_len = snprintf(nm, sizeof(nm), "dw_kernel<%d,%d,%d>", K, S, XT);
+    (void)nm_len;
+    yr_note_kernel(nm);
     hipLaunchKernelGGL((dw_kernel<K, S, XT>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;

@@ -57,6 +57,7 @@ int yr_launch_se_mean(const yr_op& op, int batch, hipStream_t s) {
     MeanArgs a;
     a.in = in.ptr; a.out = op.out; a.HW = in.h * in.w; a.C = in.c; a.C4 = (in.c + 3) / 4;
     a.ld = in.ld; a.ld_out = op.out_ld; a.inv = 0.f;
+    yr_note_kernel("se_mean_kernel");
     hipLaunchKernelGGL(se_mean_kernel, dim3((a.C4 + 15) / 16, batch), dim3(256), 0, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
@@ -73,31 +74,50 @@ struct FcArgs {
     int C, R, ldc, ld_mean, ld_gate;
 };
 
-// one block per image; dynamic LDS = (ldc + R) floats
-__global__ __launch_bounds__(256) void se_fc_kernel(FcArgs a) {
+// One workgroup of 1024 threads per image; dynamic LDS = (ldc + R + 1024) floats.
+//   fc1: one wave per hidden unit j (16 in flight), lanes stride the channels (coalesced W1t rows);
+//   fc2: thread (jg, c): partial sum over j = jg, jg+JS, ... of hid[j]*W2[j][c] (coalesced across c),
+//        combined through LDS in a fixed order (deterministic).
+#define SE_FC_THREADS 1024
+__global__ __launch_bounds__(SE_FC_THREADS) void se_fc_kernel(FcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* mean = sm;            // [ldc]
-    float* hid = sm + a.ldc;     // [R]
+    float* mean = sm;                 // [ldc]
+    float* hid = sm + a.ldc;          // [R]
+    float* part = hid + a.R;          // [SE_FC_THREADS]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int c = tid; c < a.ldc; c += 256) mean[c] = (c < a.C) ? a.mean[(size_t)b * a.ld_mean + c] : 0.f;
+    for (int c = tid; c < a.ldc; c += SE_FC_THREADS) mean[c] = (c < a.C) ? a.mean[(size_t)b * a.ld_mean + c] : 0.f;
     __syncthreads();
-    for (int j = wave; j < a.R; j += 4) {
+    for (int j = wave; j < a.R; j += SE_FC_THREADS / 64) {
         const float* wr = a.w1t + (size_t)j * a.ldc;
         float s = 0.f;
+#pragma unroll 8
         for (int c = lane; c < a.C; c += 64) s = __builtin_fmaf(wr[c], mean[c], s);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0) hid[j] = yr_apply_act(s + a.b1[j], YR_ACT_SWISH);
     }
     __syncthreads();
-    for (int c = tid; c < a.ld_gate; c += 256) {
-        float v = 0.f;
-        if (c < a.C) {
-            float s = 0.f;
-            for (int j = 0; j < a.R; ++j) s = __builtin_fmaf(hid[j], a.w2[(size_t)j * a.ldc + c], s);
-            v = yr_sigmoid(s + a.b2[c]);
+    const int cp = (a.C + 63) / 64 * 64;
+    const int js = cp <= SE_FC_THREADS ? SE_FC_THREADS / cp : 1;   // j-groups working on one channel chunk
+    for (int c0 = 0; c0 < a.ld_gate; c0 += SE_FC_THREADS) {       // one pass unless C > 1024
+        const int jg = tid / cp, c = c0 + (js > 1 ? tid % cp : tid);
+        float s = 0.f;
+        if (jg < js && c < a.C) {
+#pragma unroll 4
+            for (int j = jg; j < a.R; j += js) s = __builtin_fmaf(hid[j], a.w2[(size_t)j * a.ldc + c], s);
         }
-        a.gate[(size_t)b * a.ld_gate + c] = v;
+        part[tid] = s;
+        __syncthreads();
+        if (jg == 0 && c < a.ld_gate) {
+            float v = 0.f;
+            if (c < a.C) {
+                float t = part[tid];
+                for (int g = 1; g < js; ++g) t += part[g * cp + tid];
+                v = yr_sigmoid(t + a.b2[c]);
+            }
+            a.gate[(size_t)b * a.ld_gate + c] = v;
+        }
+        __syncthreads();
     }
 }
 
@@ -110,9 +130,10 @@ int yr_launch_se_fc(const yr_op& op, int batch, hipStream_t s) {
     a.mean = in.ptr; a.w1t = op.wgt; a.b1 = op.b1; a.w2 = op.wgt2; a.b2 = op.b2; a.gate = op.out;
     a.C = in.c; a.R = op.se_reduced; a.ldc = yr_round_up(in.c, 4); a.ld_mean = in.ld; a.ld_gate = op.out_ld;
     YR_REQUIRE(op.out_ld >= a.ldc, "se_fc: gate ld too small");
-    const size_t lds = (size_t)(a.ldc + a.R) * sizeof(float);
+    const size_t lds = (size_t)(a.ldc + a.R + SE_FC_THREADS) * sizeof(float);
     YR_REQUIRE(lds <= 64 * 1024, "se_fc: widths too large for LDS");
-    hipLaunchKernelGGL(se_fc_kernel, dim3(batch), dim3(256), lds, s, a);
+    yr_note_kernel("se_fc_kernel");
+    hipLaunchKernelGGL(se_fc_kernel, dim3(batch), dim3(SE_FC_THREADS), lds, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
 }
@@ -160,6 +181,7 @@ int yr_launch_wsum(const yr_op& op, int batch, hipStream_t s) {
     for (int i = 0; i < 4; ++i) a.s[i] = S.s[i];
     a.alpha = op.wgt; a.out = op.out; a.H = op.h; a.W = op.w; a.C4 = (op.cout + 3) / 4; a.ld_out = op.out_ld;
     a.total = (long long)batch * op.h * op.w * a.C4;
+    yr_note_kernel("wsum_kernel");
     hipLaunchKernelGGL(wsum_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
@@ -212,6 +234,7 @@ int yr_launch_gather(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(dense == op.cout && op.out && op.out_ld >= dense, "gather: cout %d != sum of sources %d (or bad out)", op.cout, dense);
     a.out = op.out; a.H = op.h; a.W = op.w; a.KQ = a.S.kp / 4; a.ld_out = op.out_ld;
     a.total = (long long)batch * op.h * op.w * a.KQ;
+    yr_note_kernel("gather_kernel");
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;

@@ -164,6 +164,10 @@ template <int PT, int CT, int WM, int WN>
 static int launch_cfg(const PwArgs& a, hipStream_t s) {
     constexpr int BM = 16 * PT * WM, BN = 16 * CT * WN;
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
+    static char nm[40];
+    static const int nm_len = snprintf(nm, sizeof(nm), "pw_kernel<%d,%d,%d,%d>", PT, CT, WM, WN);
+    (void)nm_len;
+    yr_note_kernel(nm);
     hipLaunchKernelGGL((pw_kernel<PT, CT, WM, WN>), grid, dim3(256), 0, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
@@ -190,17 +194,35 @@ int yr_launch_pointwise(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(M > 0 && M < (1ll << 31), "pointwise: pixel count %lld out of range", M);
     a.M = (int)M;
     a.out_ld = op.out_ld; a.res_ld = op.res_ld; a.gate_ld = op.gate_ld; a.act = op.act;
+    // ---- tile selection.  Candidates (BM x BN); big-M layers take 128-row tiles, layers with few
+    // pixels (13x13 / 26x26 maps) take 64-row tiles and, if still short of ~2 workgroups per CU,
+    // narrower cout tiles - these layers are latency/occupancy-bound, not bandwidth-bound.
+    struct Cfg { int bm, bn; int (*fn)(const PwArgs&, hipStream_t); };
+    static const Cfg big[] = {{256, 16, launch_cfg<4, 1, 4, 1>}, {128, 32, launch_cfg<2, 2, 4, 1>},
+                              {128, 48, launch_cfg<2, 3, 4, 1>}, {128, 64, launch_cfg<4, 2, 2, 2>},
+                              {128, 80, launch_cfg<2, 5, 4, 1>}, {128, 96, launch_cfg<4, 3, 2, 2>},
+                              {128, 128, launch_cfg<4, 4, 2, 2>}};
+    static const Cfg small[] = {{64, 16, launch_cfg<1, 1, 4, 1>}, {64, 32, launch_cfg<1, 2, 4, 1>},
+                                {64, 48, launch_cfg<1, 3, 4, 1>}, {64, 64, launch_cfg<1, 4, 4, 1>},
+                                {64, 80, launch_cfg<1, 5, 4, 1>}, {64, 96, launch_cfg<1, 6, 4, 1>},
+                                {64, 128, launch_cfg<1, 8, 4, 1>}};
     const int N = op.cout;
-    if (N <= 16) return launch_cfg<4, 1, 4, 1>(a, s);       // 256 x 16
-    if (N <= 32) return launch_cfg<2, 2, 4, 1>(a, s);       // 128 x 32
-    if (N <= 48) return launch_cfg<2, 3, 4, 1>(a, s);       // 128 x 48
-    if (N <= 64) return launch_cfg<4, 2, 2, 2>(a, s);       // 128 x 64
-    if (N <= 80) return launch_cfg<2, 5, 4, 1>(a, s);       // 128 x 80
-    if (N <= 96) return launch_cfg<4, 3, 2, 2>(a, s);       // 128 x 96
-    if (N <= 128) return launch_cfg<4, 4, 2, 2>(a, s);      // 128 x 128
-    // wide outputs: tile N by 128 when it divides well, else by 96 / 64
-    const int w128 = (N + 127) / 128 * 128, w96 = (N + 95) / 96 * 96, w64 = (N + 63) / 64 * 64;
-    if (w128 <= w96 && w128 <= w64) return launch_cfg<4, 4, 2, 2>(a, s);
-    if (w96 <= w64) return launch_cfg<4, 3, 2, 2>(a, s);
-    return launch_cfg<4, 2, 2, 2>(a, s);
+    // cost model (seconds, rough): activations re-read once per cout tile (mostly from L2/MALL),
+    // MFMA work on the padded cout width, and a penalty when the grid cannot fill the chip.
+    const double Md = (double)a.M, Kd = (double)a.S.kp;
+    auto cost = [&](const Cfg& c) {
+        const double ntn = (double)((N + c.bn - 1) / c.bn), npad = ntn * c.bn;
+        const double nblk = (double)((a.M + c.bm - 1) / c.bm) * ntn;
+        const double t_mem = (Md * Kd * 4.0 * (1.0 + 0.3 * (ntn - 1.0)) + Md * N * 4.0) / 4.0e12;
+        const double t_cmp = 2.0 * Md * npad * Kd / (c.bm >= 128 ? 60.0e12 : 45.0e12);
+        const double fill = nblk < 512.0 ? 512.0 / nblk : 1.0;
+        return (t_mem + t_cmp) * fill;
+    };
+    const Cfg* best = &big[0];
+    double bc = cost(big[0]);
+    for (int i = 0; i < 7; ++i) {
+        if (cost(big[i]) < bc) { bc = cost(big[i]); best = &big[i]; }
+        if (cost(small[i]) < bc) { bc = cost(small[i]); best = &small[i]; }
+    }
+    return best->fn(a, s);
 }

@@ -270,22 +270,95 @@ __global__ __launch_bounds__(256) void nms_kernel(NmsArgs a) {
     for (int i = picked + tid; i < a.max_boxes; i += 256) oi[i] = -1;
 }
 
+// Compacting variant (the fast path, N < 65536 and N*6 bytes of LDS): every lane owns the strided
+// slots {tid + NMS_T*j}; the survivors of the score filter are packed to the front of the lane's own
+// slots as (score, uint16 index), so no cross-lane synchronisation is needed for the lists.  One
+// round = block arg-max of the lanes' cached bests, then each lane walks only ITS live entries:
+// drops the pick and everything with IoU > thr, re-packs in place and finds its next best on the fly.
+// Work per round is proportional to the number of live candidates, not to N.
+#define NMS_T 1024  // threads per workgroup: more lanes = fewer live entries per lane = shorter rounds
+__global__ __launch_bounds__(NMS_T) void nms_compact_kernel(NmsArgs a) {
+    extern __shared__ float ks[];                                      // [N] scores of live entries
+    unsigned short* ki = reinterpret_cast<unsigned short*>(ks + a.N);  // [N] their box indices
+    __shared__ float ws[NMS_T / 64];
+    __shared__ int wi[NMS_T / 64];
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* sc = a.scores + ((size_t)b * a.C + c) * a.N;
+    const float4* bx = reinterpret_cast<const float4*>(a.boxes) + (size_t)b * a.N;
+    int n = 0;
+    float ls = NMS_DEAD;  // this lane's best live (score, index); index ascending inside a lane
+    int li = 0x7fffffff;
+    for (int i = tid; i < a.N; i += NMS_T) {
+        const float s = sc[i];
+        if (s > a.score_thr) {
+            ks[tid + NMS_T * n] = s;
+            ki[tid + NMS_T * n] = (unsigned short)i;
+            ++n;
+            if (s > ls) { ls = s; li = i; }
+        }
+    }
+    int32_t* oi = a.out_idx + ((size_t)b * a.C + c) * a.max_boxes;
+    int picked = 0;
+    for (; picked < a.max_boxes; ++picked) {
+        float bs = ls;
+        int bi = li;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float s2 = __shfl_xor(bs, o);
+            const int i2 = __shfl_xor(bi, o);
+            if (s2 > bs || (s2 == bs && i2 < bi)) { bs = s2; bi = i2; }
+        }
+        if (lane == 0) { ws[wave] = bs; wi[wave] = bi; }
+        __syncthreads();
+        bs = ws[0]; bi = wi[0];
+#pragma unroll
+        for (int w = 1; w < NMS_T / 64; ++w)
+            if (ws[w] > bs || (ws[w] == bs && wi[w] < bi)) { bs = ws[w]; bi = wi[w]; }
+        __syncthreads();  // ws/wi are rewritten next round
+        if (!(bs > NMS_DEAD)) break;  // uniform: no candidate left
+        if (tid == 0) oi[picked] = bi;
+        const float4 pb = bx[bi];
+        int m = 0;
+        ls = NMS_DEAD; li = 0x7fffffff;
+        for (int j = 0; j < n; ++j) {
+            const float s = ks[tid + NMS_T * j];
+            const int i = ki[tid + NMS_T * j];
+            if (i == bi) continue;
+            if (yr_iou(pb, bx[i]) > a.iou_thr) continue;
+            ks[tid + NMS_T * m] = s;
+            ki[tid + NMS_T * m] = (unsigned short)i;
+            ++m;
+            if (s > ls) { ls = s; li = i; }
+        }
+        n = m;
+    }
+    if (tid == 0) a.out_count[(size_t)b * a.C + c] = picked;
+    for (int i = picked + tid; i < a.max_boxes; i += NMS_T) oi[i] = -1;
+}
+
 extern "C" int yr_nms(const float* boxes, const float* scores, int batch, int n, int num_classes, int max_boxes,
                       float score_thr, float iou_thr, int32_t* out_idx, int32_t* out_count, void* stream) {
     YR_REQUIRE(boxes && scores && out_idx && out_count, "nms: null pointer");
     YR_REQUIRE(batch > 0 && n > 0 && num_classes > 0 && max_boxes > 0, "nms: bad sizes");
     YR_REQUIRE(((uintptr_t)boxes % 16) == 0, "nms: boxes must be 16-byte aligned");
-    const size_t lds = (size_t)n * sizeof(float);
-    YR_REQUIRE(lds <= 150 * 1024, "nms: %d boxes per image exceed the LDS-resident limit (38400)", n);
+    const size_t lds_limit = 150 * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        YR_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        YR_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        YR_CHECK_HIP(hipFuncSetAttribute((const void*)nms_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
         attr_set = true;
     }
     NmsArgs a;
     a.boxes = boxes; a.scores = scores; a.N = n; a.C = num_classes; a.max_boxes = max_boxes;
     a.score_thr = score_thr; a.iou_thr = iou_thr; a.out_idx = out_idx; a.out_count = out_count;
-    hipLaunchKernelGGL(nms_kernel, dim3(num_classes, batch), dim3(256), lds, (hipStream_t)stream, a);
+    const size_t lds_compact = (size_t)n * 6 + 16;
+    if (n < 65536 && lds_compact <= lds_limit) {
+        hipLaunchKernelGGL(nms_compact_kernel, dim3(num_classes, batch), dim3(NMS_T), lds_compact, (hipStream_t)stream, a);
+    } else {
+        const size_t lds = (size_t)n * sizeof(float);
+        YR_REQUIRE(lds <= lds_limit, "nms: %d boxes per image exceed the LDS-resident limit (38400)", n);
+        hipLaunchKernelGGL(nms_kernel, dim3(num_classes, batch), dim3(256), lds, (hipStream_t)stream, a);
+    }
     YR_LAUNCH_CHECK();
     return YR_OK;
 }

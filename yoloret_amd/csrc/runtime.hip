@@ -17,6 +17,9 @@ void yr_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local const char* g_kernel = "";
+void yr_note_kernel(const char* name) { g_kernel = name; }
+
 extern "C" const char* yr_last_error(void) { return g_err; }
 extern "C" int yr_abi_version(void) { return YR_ABI_VERSION; }
 
@@ -29,6 +32,7 @@ static int dispatch(const yr_op& op, int batch, hipStream_t s) {
         case YR_OP_SE_FC: return yr_launch_se_fc(op, batch, s);
         case YR_OP_WSUM: return yr_launch_wsum(op, batch, s);
         case YR_OP_GATHER: return yr_launch_gather(op, batch, s);
+        case YR_OP_MBCONV: return yr_launch_mbconv(op, batch, s);
         default: yr_set_error("unknown op kind %d", op.kind); return YR_ERR_ARG;
     }
 }
@@ -106,39 +110,92 @@ extern "C" size_t yr_workspace_bytes(const yr_handle* h, int batch) {
 
 extern "C" int yr_plan_num_launches(const yr_handle* h) { return h ? (int)h->ops.size() : 0; }
 
-extern "C" int yr_forward(yr_handle* h, const float* images, int batch, float* y1, float* y2, float* y3,
-                          void* workspace, size_t workspace_bytes, void* stream) {
-    YR_REQUIRE(h && images && batch > 0, "yr_forward: bad arguments");
-    if (!h->weights) { yr_set_error("yr_forward: weights not loaded"); return YR_ERR_STATE; }
-    YR_REQUIRE(workspace_bytes >= yr_workspace_bytes(h, batch) && (workspace || h->arena_per_image == 0),
-               "yr_forward: workspace too small (%zu < %zu)", workspace_bytes, yr_workspace_bytes(h, batch));
-    YR_REQUIRE(((uintptr_t)workspace % 16) == 0, "yr_forward: workspace must be 16-byte aligned");
-    float* ext[4] = {const_cast<float*>(images), y1, y2, y3};
-    float* ws = static_cast<float*>(workspace);
+static int resolve_op(const yr_handle* h, size_t i, int batch, float* const ext[4], float* ws, yr_op* out) {
+    yr_op op = h->ops[i];
     auto bufptr = [&](int32_t b) -> float* {
         const yr_buf& d = h->bufs[b];
         if (d.external_slot >= 0) return ext[d.external_slot];
         return ws + (size_t)d.arena_off_per_image * (size_t)batch;
     };
     auto wptr = [&](int64_t off) -> const float* { return off >= 0 ? h->weights + off : nullptr; };
+    for (int k = 0; k < op.nsrc; ++k) op.src[k].ptr = bufptr(op.src[k].buf);
+    op.out = bufptr(op.out_buf);
+    op.res = op.res_buf >= 0 ? bufptr(op.res_buf) : nullptr;
+    op.gate = op.gate_buf >= 0 ? bufptr(op.gate_buf) : nullptr;
+    op.wgt = wptr(op.wgt_off); op.scale = wptr(op.scale_off); op.shift = wptr(op.shift_off);
+    op.wgt2 = wptr(op.wgt2_off); op.b1 = wptr(op.b1_off); op.b2 = wptr(op.b2_off);
+    if (op.out == nullptr) { yr_set_error("op %zu writes a null external buffer", i); return YR_ERR_ARG; }
+    *out = op;
+    return YR_OK;
+}
+
+static int check_forward_args(yr_handle* h, const float* images, int batch, void* workspace, size_t workspace_bytes) {
+    YR_REQUIRE(h && images && batch > 0, "yr_forward: bad arguments");
+    if (!h->weights) { yr_set_error("yr_forward: weights not loaded"); return YR_ERR_STATE; }
+    YR_REQUIRE(workspace_bytes >= yr_workspace_bytes(h, batch) && (workspace || h->arena_per_image == 0),
+               "yr_forward: workspace too small (%zu < %zu)", workspace_bytes, yr_workspace_bytes(h, batch));
+    YR_REQUIRE(((uintptr_t)workspace % 16) == 0, "yr_forward: workspace must be 16-byte aligned");
+    return YR_OK;
+}
+
+static int fail_op(size_t i, int kind, int rc) {
+    char tmp[400];
+    strncpy(tmp, g_err, sizeof(tmp) - 1);
+    tmp[sizeof(tmp) - 1] = 0;
+    yr_set_error("op %zu (kind %d): %s", i, kind, tmp);
+    return rc;
+}
+
+extern "C" int yr_forward(yr_handle* h, const float* images, int batch, float* y1, float* y2, float* y3,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_forward_args(h, images, batch, workspace, workspace_bytes);
+    if (rc) return rc;
+    float* ext[4] = {const_cast<float*>(images), y1, y2, y3};
     hipStream_t s = (hipStream_t)stream;
     for (size_t i = 0; i < h->ops.size(); ++i) {
-        yr_op op = h->ops[i];
-        for (int k = 0; k < op.nsrc; ++k) op.src[k].ptr = bufptr(op.src[k].buf);
-        op.out = bufptr(op.out_buf);
-        op.res = op.res_buf >= 0 ? bufptr(op.res_buf) : nullptr;
-        op.gate = op.gate_buf >= 0 ? bufptr(op.gate_buf) : nullptr;
-        op.wgt = wptr(op.wgt_off); op.scale = wptr(op.scale_off); op.shift = wptr(op.shift_off);
-        op.wgt2 = wptr(op.wgt2_off); op.b1 = wptr(op.b1_off); op.b2 = wptr(op.b2_off);
-        if (op.out == nullptr) { yr_set_error("yr_forward: op %zu writes a null external buffer", i); return YR_ERR_ARG; }
-        const int rc = dispatch(op, batch, s);
-        if (rc != YR_OK) {
-            char tmp[400];
-            strncpy(tmp, g_err, sizeof(tmp) - 1);
-            tmp[sizeof(tmp) - 1] = 0;
-            yr_set_error("op %zu (kind %d): %s", i, op.kind, tmp);
-            return rc;
-        }
+        yr_op op;
+        rc = resolve_op(h, i, batch, ext, static_cast<float*>(workspace), &op);
+        if (rc == YR_OK) rc = dispatch(op, batch, s);
+        if (rc != YR_OK) return fail_op(i, h->ops[i].kind, rc);
     }
     return YR_OK;
+}
+
+// Same replay with a hipEvent pair around every op, `iters` times; ms_per_op[i] receives the
+// average duration of op i and kernel_names[i] (if non-null) a pointer to a static string naming
+// the kernel symbol it dispatched to.  Synchronises the stream; for measurement only.
+extern "C" int yr_forward_profile(yr_handle* h, const float* images, int batch, float* y1, float* y2, float* y3,
+                                  void* workspace, size_t workspace_bytes, void* stream, int iters,
+                                  float* ms_per_op, const char** kernel_names) {
+    int rc = check_forward_args(h, images, batch, workspace, workspace_bytes);
+    if (rc) return rc;
+    YR_REQUIRE(iters > 0 && ms_per_op, "yr_forward_profile: bad arguments");
+    float* ext[4] = {const_cast<float*>(images), y1, y2, y3};
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = h->ops.size();
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev) YR_CHECK_HIP(hipEventCreate(&e));
+    std::vector<double> acc(n, 0.0);
+    for (int it = 0; it < iters && rc == YR_OK; ++it) {
+        YR_CHECK_HIP(hipEventRecord(ev[0], s));
+        for (size_t i = 0; i < n; ++i) {
+            yr_op op;
+            rc = resolve_op(h, i, batch, ext, static_cast<float*>(workspace), &op);
+            if (rc == YR_OK) rc = dispatch(op, batch, s);
+            if (rc != YR_OK) { rc = fail_op(i, h->ops[i].kind, rc); break; }
+            if (kernel_names) kernel_names[i] = g_kernel;
+            YR_CHECK_HIP(hipEventRecord(ev[i + 1], s));
+        }
+        if (rc != YR_OK) break;
+        YR_CHECK_HIP(hipStreamSynchronize(s));
+        for (size_t i = 0; i < n; ++i) {
+            float ms = 0.f;
+            YR_CHECK_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            acc[i] += ms;
+        }
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    if (rc == YR_OK)
+        for (size_t i = 0; i < n; ++i) ms_per_op[i] = (float)(acc[i] / iters);
+    return rc;
 }

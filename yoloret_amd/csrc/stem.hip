@@ -75,6 +75,7 @@ int yr_launch_stem(const yr_op& op, int batch, hipStream_t s) {
     a.total = (long long)batch * a.Ho * a.Wo * a.C4;
     const long long blocks = (a.total + 255) / 256;
     YR_REQUIRE(blocks < (1ll << 31), "stem: grid too large");
+    yr_note_kernel("stem_kernel");
     hipLaunchKernelGGL(stem_kernel, dim3((unsigned)blocks), dim3(256), 27 * a.ldw * sizeof(float), s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;

@@ -8,6 +8,8 @@
 #include "../../include/yoloret_hip.h"
 
 void yr_set_error(const char* fmt, ...);
+// records the symbol the last launcher dispatched to (read back by yr_forward_profile)
+void yr_note_kernel(const char* name);
 
 #define YR_CHECK_HIP(expr)                                                              \
     do {                                                                                \
@@ -36,6 +38,7 @@ int yr_launch_se_mean(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_se_fc(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_wsum(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_gather(const yr_op& op, int batch, hipStream_t s);
+int yr_launch_mbconv(const yr_op& op, int batch, hipStream_t s);
 
 static inline int yr_round_up(int v, int m) { return (v + m - 1) / m * m; }
 

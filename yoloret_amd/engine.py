@@ -7,6 +7,7 @@ Holds the compiled plan, the parameter dict and the native handle; ``__call__`` 
 the whole forward on the current HIP stream through one C-ABI call (yr_forward).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -16,11 +17,13 @@ from .compiler import compile_graph
 
 
 class Model:
-    def __init__(self, inputs, outputs, name=None):
+    def __init__(self, inputs, outputs, name=None, fuse=None):
+        if fuse is None:
+            fuse = os.environ.get('YOLORET_FUSE', '1') != '0'
         self.inputs = inputs if isinstance(inputs, (list, tuple)) else [inputs]
         self.outputs = list(outputs)
         self.name = name
-        self.plan = compile_graph(self.inputs[0], self.outputs)
+        self.plan = compile_graph(self.inputs[0], self.outputs, fuse)
         self._weights = None
         self._blob = None
         self._handles = {}     # device index -> yr_handle*
@@ -116,6 +119,30 @@ class Model:
         return res
 
     predict = __call__
+
+    def profile(self, x, iters=5):
+        """Per-op timing (hipEvent pair around every launch, averaged over `iters` replays).
+        Returns a list of dicts: name, kind, kernel (symbol), ms, macs, bytes (algorithmic in+out+residual)."""
+        x = x.contiguous()
+        b = x.shape[0]
+        idx, hd = self._handle(x.device)
+        self(x)  # allocates the workspace and validates the input
+        ws = self._workspace[idx]
+        ys = [torch.empty((b, ob.h, ob.w, ob.c), dtype=torch.float32, device=x.device)
+              for ob in self.plan.output_bufs]
+        n = len(self.plan.ops)
+        ms = (ctypes.c_float * n)()
+        names = (ctypes.c_char_p * n)()
+        with torch.cuda.device(idx):
+            rt.check(rt.lib().yr_forward_profile(hd, rt._ptr(x), b, rt._ptr(ys[0]), rt._ptr(ys[1]), rt._ptr(ys[2]),
+                                                 rt._ptr(ws), ws.numel(), rt.stream_ptr(x.device), int(iters),
+                                                 ms, names))
+        out = []
+        per_op_bytes = self.plan.algorithmic_bytes_per_op()
+        for i, op in enumerate(self.plan.ops):
+            out.append(dict(name=op.name, kind=rt.OP_NAMES[op.kind], kernel=(names[i] or b'').decode(),
+                            ms=float(ms[i]), macs=op.macs * b, bytes=per_op_bytes[i] * b))
+        return out
 
     def __del__(self):
         try:

@@ -1,0 +1,72 @@
+"""Device-resident detection pipeline: forward -> decode -> per-(image,class) NMS -> packed
+records, i.e. what ``YoloModel.call`` does after image parsing (reference code/yolo.py:152,161)
+for a whole batch, with every buffer preallocated so a step is launches only.
+
+Output records are fixed-size (include/yoloret_hip.h: det int32 [B, C*max_boxes, 6] + det_count
+[B]) so that the multi-GPU exchange is one dense all-gather (yoloret_amd.parallel).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import runtime as rt
+
+
+class DetectionPipeline:
+    def __init__(self, model, anchors, num_classes, num_scales=3, max_boxes=20, score_threshold=.2,
+                 iou_threshold=.5):
+        self.model = model
+        self.anchors = np.ascontiguousarray(np.asarray(anchors, np.float32).reshape(-1, 2))
+        self.num_classes, self.num_scales = int(num_classes), int(num_scales)
+        self.max_boxes, self.score_threshold, self.iou_threshold = int(max_boxes), float(score_threshold), float(iou_threshold)
+        self.input_hw = tuple(model.plan.input_shape[:2])
+        self.num_anchors = self.anchors.shape[0] // 3
+        self.n = rt.num_boxes(self.input_hw[0], self.input_hw[1], self.num_anchors, self.num_scales)
+        self._bufs = {}
+
+    def _buffers(self, b, dev):
+        key = (b, dev)
+        v = self._bufs.get(key)
+        if v is None:
+            c, n, mb = self.num_classes, self.n, self.max_boxes
+            f32, i32 = torch.float32, torch.int32
+            v = dict(
+                ys=[torch.empty((b, ob.h, ob.w, ob.c), dtype=f32, device=dev) for ob in self.model.plan.output_bufs],
+                boxes=torch.empty((b, n, 4), dtype=f32, device=dev),
+                scores=torch.empty((b, c, n), dtype=f32, device=dev),
+                idx=torch.empty((b, c, mb), dtype=i32, device=dev),
+                cnt=torch.empty((b, c), dtype=i32, device=dev),
+                record=torch.empty(b * c * mb * 6 + b, dtype=i32, device=dev))
+            # det and det_count are views of ONE buffer so the multi-GPU exchange is a single
+            # all-gather without staging copies
+            v['det'] = v['record'][:b * c * mb * 6].view(b, c * mb, 6)
+            v['det_count'] = v['record'][b * c * mb * 6:]
+            self._bufs = {key: v}  # keep one batch shape resident
+        return v
+
+    def forward(self, x):
+        """images [B,H,W,3] -> raw logits (views of the pipeline's y buffers)."""
+        return self.model(x, out=self._buffers(x.shape[0], x.device)['ys'])
+
+    def postprocess(self, ys, image_hw):
+        b, dev = ys[0].shape[0], ys[0].device
+        v = self._buffers(b, dev)
+        L, s = rt.lib(), rt.stream_ptr(dev)
+        yp = [rt._ptr(ys[i]) if i < self.num_scales else None for i in range(3)]
+        rt.check(L.yr_decode(yp[0], yp[1], yp[2], b, self.input_hw[0], self.input_hw[1], self.num_anchors,
+                             self.num_classes, self.num_scales, self.anchors.ctypes.data_as(ctypes.c_void_p),
+                             rt._ptr(image_hw), rt._ptr(v['boxes']), rt._ptr(v['scores']), s))
+        rt.check(L.yr_nms(rt._ptr(v['boxes']), rt._ptr(v['scores']), b, self.n, self.num_classes, self.max_boxes,
+                          self.score_threshold, self.iou_threshold, rt._ptr(v['idx']), rt._ptr(v['cnt']), s))
+        rt.check(L.yr_pack_detections(rt._ptr(v['boxes']), rt._ptr(v['scores']), rt._ptr(v['idx']), rt._ptr(v['cnt']),
+                                      b, self.n, self.num_classes, self.max_boxes, rt._ptr(v['det']),
+                                      rt._ptr(v['det_count']), s))
+        self.record = v['record']
+        return v['det'], v['det_count']
+
+    def __call__(self, x, image_hw):
+        """x [B,H,W,3] CUDA f32; image_hw int32 [B,2] CUDA (original image sizes).
+        Returns (det, det_count) - buffers owned by the pipeline, overwritten by the next call."""
+        ys = self.forward(x)
+        return self.postprocess(ys, image_hw)

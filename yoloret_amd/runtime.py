@@ -16,8 +16,8 @@ LIB_PATH = os.path.join(_HERE, 'libyoloret_hip.so')
 YR_MAX_SRC = 4
 ACT = {'none': 0, None: 0, 'relu6': 1, 'swish': 2, 'sigmoid': 3, 'leaky': 4}
 XFORM = {'identity': 0, 'up2': 1, 'maxpool2': 2, 'maxpool4': 3}
-OP_STEM, OP_POINTWISE, OP_DEPTHWISE, OP_SE_MEAN, OP_SE_FC, OP_WSUM, OP_GATHER = 1, 2, 3, 4, 5, 6, 7
-OP_NAMES = {1: 'stem', 2: 'pointwise', 3: 'depthwise', 4: 'se_mean', 5: 'se_fc', 6: 'wsum', 7: 'gather'}
+OP_STEM, OP_POINTWISE, OP_DEPTHWISE, OP_SE_MEAN, OP_SE_FC, OP_WSUM, OP_GATHER, OP_MBCONV = 1, 2, 3, 4, 5, 6, 7, 8
+OP_NAMES = {1: 'stem', 2: 'pointwise', 3: 'depthwise', 4: 'se_mean', 5: 'se_fc', 6: 'wsum', 7: 'gather', 8: 'mbconv'}
 
 
 class YrSrc(ctypes.Structure):
@@ -47,7 +47,7 @@ class YrBuf(ctypes.Structure):
 
 
 EXPORTS = ['yr_last_error', 'yr_abi_version', 'yr_create', 'yr_destroy', 'yr_load_weights', 'yr_workspace_bytes',
-           'yr_forward', 'yr_plan_num_launches', 'yr_op_run', 'yr_decode', 'yr_yolo_head', 'yr_correct_boxes',
+           'yr_forward', 'yr_forward_profile', 'yr_plan_num_launches', 'yr_op_run', 'yr_decode', 'yr_yolo_head', 'yr_correct_boxes',
            'yr_nms', 'yr_pack_detections']
 
 _lib = None
@@ -77,6 +77,9 @@ def lib():
         L.yr_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.yr_plan_num_launches.argtypes = [ctypes.c_void_p]
+        L.yr_forward_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.yr_op_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.yr_decode.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 5
         L.yr_yolo_head.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + \
