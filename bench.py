@@ -42,13 +42,29 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline sample')
     ap.add_argument('--profile-iters', type=int, default=3)
     ap.add_argument('--per-op', action='store_true', help='also print the per-op table to stderr')
+    ap.add_argument('--no-latency', action='store_true',
+                    help='skip the batch-1 p50 loop (use under rocprofv3 so that every launch is a batch-%d launch)' % 64)
     return ap.parse_args()
+
+
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU
+    box reports 256 logical CPUs but runs the job under a 16-CPU quota; oversubscribing it 16x made the
+    oneDNN baseline ~100x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def cpu_baseline(model_name, size, classes, anchors, seconds):
     """The oracle's torch-CPU port (oneDNN) + C decode/NMS on all host cores; bounded sample."""
     from oracle import cpost, params, torch_ref
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     P = params.ParamStore(1234, 'survey')
     ref = torch_ref.TorchReference(P, model_name, 3, classes)
@@ -159,7 +175,8 @@ def main():
         post_ms /= reps
         rows = prof + [
             dict(name='decode', kind='decode', kernel='decode_kernel', ms=post_ms[0], macs=0, bytes=alg_dec * b),
-            dict(name='nms', kind='nms', kernel='nms_kernel', ms=post_ms[1], macs=0,
+            dict(name='nms', kind='nms', kernel='nms_compact_kernel' if n_boxes * 6 + 16 <= 150 * 1024 else 'nms_kernel',
+                 ms=post_ms[1], macs=0,
                  bytes=(a.classes * n_boxes * 4 + n_boxes * 16) * b),
             dict(name='pack', kind='pack', kernel='pack_kernel', ms=post_ms[2], macs=0, bytes=0)]
         by = {}
@@ -174,6 +191,18 @@ def main():
                     'avg_launch_ms': round(avg_ms, 4), 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
                     'tflops': round(2.0 * d['macs'] / (d['ms'] * 1e-3) / 1e12, 2)}
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+        # (profiles/rNN_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KiB, see tools/rocpd_summary.py); None if absent
+        try:
+            import glob
+            tfile = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))[-1]
+            tr = json.load(open(tfile)).get(dom)
+            if tr and a.batch == 64 and a.model == 'mobilenetv2x75' and a.size == 416:
+                roofline['traffic'] = tr['traffic_bytes']
+                roofline['traffic_source'] = os.path.relpath(tfile, ROOT)
+                roofline['alg_bytes_per_launch'] = int(d['bytes'] / d['launches'])
+        except (IndexError, OSError, ValueError):
+            pass
         per_gpu = value / world
         step_gbs = per_gpu * alg_img / 1e9
         roofline_step = {'bound': 'hbm', 'achieved': round(step_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -192,7 +221,7 @@ def main():
                                  % (k, v['launches'], v['ms'], v['bytes'] / (v['ms'] * 1e-3) / 1e9 if v['ms'] else 0))
         # ---- p50 per-image latency at B=1 (the second half of BASELINE.json's metric)
         p50 = None
-        if world == 1:
+        if world == 1 and not a.no_latency:
             x1 = x[:1].contiguous()
             hw1 = image_hw[:1].contiguous()
             for _ in range(20):

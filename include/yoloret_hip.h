@@ -142,6 +142,11 @@ int yr_plan_num_launches(const yr_handle* h);
 /* ---- single fused ops (device pointers inside `op`); parity-testable in isolation. */
 int yr_op_run(const yr_op* op, int batch, void* stream);
 
+/* ---- preprocessing (the step before the path): decoded uint8 [ih,iw,3] image (device) ->
+ * letterboxed float32 [H,W,3] network input.  Replaces tf.io.decode_image(dtype=float32)'s /255
+ * (yolo.py:106) + letterbox_image (utils.py:67-83: bilinear half-pixel resize, zero pad). */
+int yr_letterbox(const unsigned char* src_u8, int ih, int iw, float* dst, int H, int W, void* stream);
+
 /* ---- decode: replaces yolo_head + yolo_correct_boxes + yolo_boxes_and_scores
  * (model.py:344-428) for the three scales at once, per image.
  *   y[s]      [B,G_s,G_s,A*(C+5)] raw logits, s = 0,1,2 for strides 32,16,8

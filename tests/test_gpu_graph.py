@@ -136,12 +136,16 @@ def test_unfused_plan_matches_fused(dev):
     x = params.synthetic_images(2, *hw)
     ref = om.yolov3_body(P, x, 'mobilenetv2x75', 3, 20)
     outs = {}
+    from yoloret_amd import compiler
     for fuse in ('1', '0'):
         os.environ['YOLORET_FUSE'] = fuse
+        saved = compiler.FUSE_MAX_CIN, compiler.FUSE_MIN_PIXELS
+        compiler.FUSE_MAX_CIN, compiler.FUSE_MIN_PIXELS = 1 << 20, 0  # fuse every eligible block, also the deep ones
         try:
             m = yolov3_body(L.Input(shape=[hw[0], hw[1], 3]), 'mobilenetv2x75', 3, num_classes=20)
         finally:
             os.environ.pop('YOLORET_FUSE', None)
+            compiler.FUSE_MAX_CIN, compiler.FUSE_MIN_PIXELS = saved
         kinds = set(o.kind for o in m.plan.ops)
         assert (8 in kinds) == (fuse == '1')
         m.set_weights(P.values)

@@ -1,0 +1,77 @@
+"""Drop-in wrappers (yoloret_amd.yolo.YoloModel / YOLO) and the GPU letterbox, against the oracle."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpost
+from oracle import model as om
+from oracle import params, preprocess
+from tests.util import ANCHORS
+
+pytestmark = pytest.mark.gpu
+
+
+def _png(arr):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(arr).save(buf, format='PNG')
+    return buf.getvalue()
+
+
+@pytest.mark.parametrize('ihw,size', [((375, 500), (416, 416)), ((500, 375), (416, 416)), ((64, 64), (96, 96)),
+                                      ((1080, 1920), (320, 320)), ((33, 17), (64, 96))])
+def test_letterbox_bit_exact(dev, ihw, size):
+    from yoloret_amd import runtime as rt
+    rng = np.random.default_rng(ihw[0])
+    img = rng.integers(0, 256, (ihw[0], ihw[1], 3), dtype=np.uint8)
+    ref, _ = preprocess.letterbox_image(img, size)
+    out = rt.letterbox(torch.from_numpy(img).to(dev), size).cpu().numpy()
+    assert np.array_equal(out, ref)
+
+
+def test_yolo_facade_end_to_end(dev):
+    """YOLO(FLAGS).detect_image(bytes, draw=False) == oracle(parse -> body -> yolo_eval) on the same weights."""
+    from yoloret_amd.yolo import YOLO
+    from yoloret_amd.yolo3.enums import BACKBONE
+    size = (96, 96)
+    y = YOLO({'model': 'synthetic:7', 'input_size': size, 'backbone': BACKBONE.MOBILENETV2x75, 'score': 0.2, 'nms': 0.5})
+    assert len(y.class_names) == 20 and y.anchors.shape == (9, 2) and len(y.colors) == 20
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (75, 100, 3), dtype=np.uint8)
+    boxes, scores, classes = y.detect_image(_png(img), draw=False)
+    # oracle on the same parameters (the product's synthetic weights feed the oracle's graph walk)
+    class Given(params.ParamStore):
+        pass
+    P = Given(7, 'survey')
+    P.values = dict(y.yolo_model.model.get_weights())
+    x, _ = preprocess.letterbox_image(img, size)
+    ys = om.yolov3_body(P, x[None], 'mobilenetv2x75', 3, 20)
+    # detections must equal the oracle's post-processing of the GPU's own logits ...
+    gl = y.yolo_model._pipe._buffers(1, dev)['ys']
+    ob, os_, oc, _ = cpost.yolo_eval([g[0].cpu().numpy().reshape(r.shape[1:]) for g, r in zip(gl, ys)], ANCHORS, 3, 20,
+                                     (75, 100), 20, 0.2, 0.5)
+    assert np.array_equal(boxes, ob) and np.array_equal(scores, os_) and np.array_equal(classes, oc)
+    assert boxes.dtype == np.int32 and scores.dtype == np.float32 and classes.dtype == np.int32
+    assert boxes[:, 2].max() <= 75 and boxes[:, 3].max() <= 100    # clipped to the ORIGINAL image (h, w)
+    # ... and the logits themselves track the oracle's on this (ill-conditioned, 'survey') recipe loosely
+    for g, r in zip(gl, ys):
+        assert np.abs(g[0].cpu().numpy().reshape(r.shape[1:]) - r[0]).max() < 5e-2
+    with pytest.raises(NotImplementedError):
+        y.detect_image(_png(img), draw=True)
+
+
+def test_yolomodel_batch_of_images(dev):
+    from functools import partial
+    from yoloret_amd.yolo import YoloModel
+    from yoloret_amd.yolo3.model import yolov3_body
+    body = partial(yolov3_body, model_name='mobilenetv2x75', num_anchors=3, num_classes=20)
+    ym = YoloModel(body, 9, 3, ['c%d' % i for i in range(20)], 'synthetic', ANCHORS, (64, 64), score=0.2, nms=0.5)
+    rng = np.random.default_rng(2)
+    imgs = [rng.integers(0, 256, s + (3,), dtype=np.uint8) for s in [(50, 70), (64, 64), (90, 30)]]
+    batch = ym([_png(i) for i in imgs])
+    assert len(batch) == 3
+    for img, (b, s, c) in zip(imgs, batch):
+        one = ym([_png(img)])
+        assert torch.equal(one[0], b) and torch.equal(one[1], s) and torch.equal(one[2], c)

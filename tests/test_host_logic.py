@@ -1,0 +1,160 @@
+"""Host-side logic that needs no GPU: the graph builder / compiler against SURVEY.md's tables,
+the drop-in surface's argument handling, weight recipes, and that the C-ABI library loads and
+exports every symbol include/yoloret_hip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import model as om
+from oracle import params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(name='mobilenetv2x75', size=416, classes=20, **kw):
+    from yoloret_amd import layers as L
+    from yoloret_amd.yolo3.model import yolov3_body
+    return yolov3_body(L.Input(shape=[size, size, 3]), name, 3, num_classes=classes, **kw)
+
+
+@pytest.mark.parametrize('name,size,macs_m', [('mobilenetv2x75', 416, 1069.3), ('mobilenetv2x14', 512, 3325.7),
+                                              ('efficientnetb0', 416, 1626.1), ('efficientnetb3', 640, 7679.7)])
+def test_macs_match_survey(name, size, macs_m):
+    assert abs(_model(name, size).plan.total_macs() / 1e6 - macs_m) < 0.06
+
+
+def test_plan_structure_and_accounting():
+    from yoloret_amd import compiler, runtime as rt
+    saved = compiler.FUSE_MAX_CIN
+    try:
+        compiler.FUSE_MAX_CIN = 0       # unfused plan = SURVEY.md Appendix B rows
+        p = _model().plan
+    finally:
+        compiler.FUSE_MAX_CIN = saved
+    kinds = [o.kind for o in p.ops]
+    assert kinds.count(rt.OP_POINTWISE) == 55 and kinds.count(rt.OP_DEPTHWISE) == 23 and kinds.count(rt.OP_STEM) == 1
+    assert kinds.count(rt.OP_SE_MEAN) == 6 and kinds.count(rt.OP_SE_FC) == 6 and kinds.count(rt.OP_WSUM) == 1
+    assert kinds.count(rt.OP_GATHER) == 0   # upsample / maxpool / concat never materialised
+    assert abs(p.algorithmic_bytes_per_image() / 1e6 - 198.9) < 0.2
+    widths = {o.name: o.cin for o in p.ops}
+    assert widths['td1_conv'] == 216 and widths['td2_conv'] == 424 and widths['td3_conv'] == 248
+    assert widths['bu2_conv'] == 203 and widths['bu1_conv'] == 331
+    assert [(b.h, b.w, b.c) for b in p.output_bufs] == [(13, 13, 75), (26, 26, 75), (52, 52, 75)]
+    fused = _model().plan
+    assert any(o.kind == rt.OP_MBCONV for o in fused.ops)
+    assert abs(fused.algorithmic_bytes_per_image() - p.algorithmic_bytes_per_image()) < 1  # accounting is fusion-invariant
+    assert fused.total_macs() == p.total_macs()
+    assert fused.arena_elems_per_image < p.arena_elems_per_image
+
+
+def test_arena_has_no_overlapping_live_buffers():
+    p = _model('efficientnetb0', 64).plan
+    arena = [b for b in p.bufs if b.external_slot < 0]
+    for i, a in enumerate(arena):
+        for b in arena[i + 1:]:
+            overlap_t = not (a.last_use < b.first_def or b.last_use < a.first_def)
+            overlap_m = not (a.offset + a.elems <= b.offset or b.offset + b.elems <= a.offset)
+            assert not (overlap_t and overlap_m), (a.name, b.name)
+
+
+@pytest.mark.parametrize('name', ['mobilenetv2x75', 'mobilenetv2x14', 'efficientnetb0', 'efficientnetb3', 'efficientnetb0-lite'])
+def test_parameter_inventory_matches_oracle(name):
+    m = _model(name, 64)
+    P = params.ParamStore(3)
+    om.yolov3_body(P, params.synthetic_images(1, 64, 64), name, 3, 20)
+    want = {k: v.shape for k, v in P.values.items() if not re.match(r'td\d_y/', k)}  # top-down y convs are dead (panet)
+    assert {k: tuple(v) for k, v in m.param_shapes.items()} == {k: tuple(v) for k, v in want.items()}
+
+
+@pytest.mark.parametrize('recipe', ['survey', 'conditioned'])
+def test_product_weight_recipe_equals_oracle_recipe(recipe):
+    from yoloret_amd.weights import synthetic_images, synthetic_weights
+    m = _model('mobilenetv2x75', 64)
+    P = params.ParamStore(1234, recipe)
+    om.yolov3_body(P, params.synthetic_images(1, 64, 64), 'mobilenetv2x75', 3, 20)
+    w = synthetic_weights(m, 1234, recipe)
+    for k, v in w.items():
+        assert np.array_equal(v, P.values[k]), k
+    assert np.array_equal(synthetic_images(2, 32, 32), params.synthetic_images(2, 32, 32))
+
+
+def test_blob_folds_batchnorm():
+    m = _model('mobilenetv2x75', 64)
+    from yoloret_amd.weights import synthetic_weights
+    w = synthetic_weights(m, 1, 'survey')
+    blob = m.plan.build_blob(w)
+    op = next(o for o in m.plan.ops if o.name == 'block_20_conv')
+    off = op.offsets['scale']
+    g, v = w['block_20_BN/gamma'], w['block_20_BN/moving_variance']
+    assert np.allclose(blob[off:off + 256], g / np.sqrt(v + 1e-3), rtol=1e-6)
+
+
+def test_surface_errors_and_defaults():
+    from yoloret_amd import layers as L
+    from yoloret_amd.yolo3 import efficientnet as E
+    from yoloret_amd.yolo3.model import YoloEval, _make_divisible, yolov3_body
+    with pytest.raises(ValueError):
+        yolov3_body(L.Input(shape=[64, 64, 3]), 'resnet50', 3, num_classes=20)
+    with pytest.raises(ValueError):      # unknown GlobalParams field, as namedtuple._replace in the reference
+        yolov3_body(L.Input(shape=[64, 64, 3]), 'mobilenetv2x75', 3, num_classes=20, bogus=1)
+    with pytest.raises(ValueError):
+        yolov3_body(L.Input(shape=[60, 64, 3]), 'mobilenetv2x75', 3, num_classes=20)
+    yolov3_body(L.Input(shape=[64, 64, 3]), 'mobilenetv2x75', 3, num_classes=20, drop_rate=0.2, data_format='channels_last')
+    with pytest.raises(NotImplementedError):
+        E.get_model_params('resnet', {})
+    with pytest.raises(ValueError):
+        E.BlockDecoder()._decode_block_string('r1_k3_s1_e1_i32_o16')
+    a = E.BlockDecoder().decode(['r2_k5_s22_e6_i24_o40_se0.25'])[0]
+    assert (a.kernel_size, a.num_repeat, a.strides, a.se_ratio) == (5, 2, [2, 2], 0.25)
+    assert E.BlockDecoder().encode([a]) == ['r2_k5_s22_e6_i24_o40_se0.25']
+    assert _make_divisible(24 * 0.75, 8) == 24 and _make_divisible(7, 8) == 8
+    ev = YoloEval(np.zeros((9, 2)), 3, 20)
+    assert ev.get_config()['max_boxes'] == 20 and ev.score_threshold == .6 and ev.iou_threshold == .5
+
+
+def test_utils():
+    from yoloret_amd.yolo3.utils import compose, get_anchors, get_classes
+    assert compose(lambda x: x + 1, lambda x: x * 2)(3) == 8
+    with pytest.raises(ValueError):
+        compose()
+    a = get_anchors('model_data/yolo_anchors.txt')
+    assert a.shape == (9, 2) and a.dtype == np.float32 and a[0].tolist() == [10, 13] and a[-1].tolist() == [373, 326]
+    assert len(get_classes('model_data/voc_classes.txt')) == 20 and len(get_classes('model_data/coco_classes.txt')) == 80
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    from yoloret_amd import build, runtime as rt
+    lib = build.build()
+    L = ctypes.CDLL(lib)
+    header = open(os.path.join(ROOT, 'include', 'yoloret_hip.h')).read()
+    declared = set(re.findall(r'\b(yr_[a-z_0-9]+)\s*\(', header))
+    assert declared, 'no declarations parsed'
+    for sym in declared:
+        assert hasattr(L, sym), 'libyoloret_hip.so does not export %s' % sym
+    assert declared == set(rt.EXPORTS)
+    L.yr_abi_version.restype = ctypes.c_int
+    assert L.yr_abi_version() == 1
+    # struct layouts agree with the header's field order (spot check on sizes)
+    assert ctypes.sizeof(rt.YrSrc) == 32 and ctypes.sizeof(rt.YrBuf) == 24
+
+
+def test_product_does_not_import_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'yoloret_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', src, re.M):
+                    bad.append(f)
+    assert not bad, 'product modules import the test oracle: %s' % bad
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from yoloret_amd import runtime as rt
+    monkeypatch.setattr(rt, '_lib', None)
+    monkeypatch.setattr(rt, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(rt.YoloretHipError, match='no CPU fallback'):
+        rt.lib()

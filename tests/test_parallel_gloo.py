@@ -1,0 +1,83 @@
+"""N>1 path on CPU: world_size-2 gloo processes run the shard bookkeeping + the single all-gather of
+packed detection records (yoloret_amd.parallel) and must reproduce the single-rank result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_records(global_batch, slots, seed=0):
+    rng = np.random.default_rng(seed)
+    det = rng.integers(0, 1000, (global_batch, slots, 6), dtype=np.int32)
+    cnt = rng.integers(0, slots + 1, (global_batch,), dtype=np.int32)
+    for i in range(global_batch):
+        det[i, cnt[i]:] = 0
+    return det, cnt
+
+
+def _worker(rank, world, port, q, use_record):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from yoloret_amd.parallel import DetectionGatherer, shard_range
+    det, cnt = _fake_records(8, 40)
+    lo, hi = shard_range(8, rank, world)
+    d, c = torch.from_numpy(det[lo:hi].copy()), torch.from_numpy(cnt[lo:hi].copy())
+    record = None
+    if use_record:
+        record = torch.cat([d.reshape(-1), c])
+        d = record[:d.numel()].view(d.shape)
+        c = record[d.numel():]
+    g = DetectionGatherer()
+    for _ in range(2):  # second call reuses the preallocated buffers
+        all_det, all_cnt = g(d, c, record)
+    q.put((rank, all_det.numpy().copy(), all_cnt.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('use_record', [False, True])
+def test_all_gather_of_detections_world2(use_record):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, use_record)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    det, cnt = _fake_records(8, 40)
+    for rank, d, c in got:
+        assert np.array_equal(d, det) and np.array_equal(c, cnt), 'rank %d gathered wrong records' % rank
+
+
+def test_shard_range():
+    from yoloret_amd.parallel import shard_range
+    assert [shard_range(512, r, 8) for r in (0, 7)] == [(0, 64), (448, 512)]
+    with pytest.raises(ValueError):
+        shard_range(10, 0, 4)
+
+
+def test_world1_is_identity():
+    from yoloret_amd.parallel import DetectionGatherer
+    d, c = torch.zeros((2, 4, 6), dtype=torch.int32), torch.zeros(2, dtype=torch.int32)
+    a, b = DetectionGatherer()(d, c)
+    assert a is d and b is c

@@ -48,7 +48,7 @@ class YrBuf(ctypes.Structure):
 
 EXPORTS = ['yr_last_error', 'yr_abi_version', 'yr_create', 'yr_destroy', 'yr_load_weights', 'yr_workspace_bytes',
            'yr_forward', 'yr_forward_profile', 'yr_plan_num_launches', 'yr_op_run', 'yr_decode', 'yr_yolo_head', 'yr_correct_boxes',
-           'yr_nms', 'yr_pack_detections']
+           'yr_nms', 'yr_pack_detections', 'yr_letterbox']
 
 _lib = None
 
@@ -89,6 +89,8 @@ def lib():
         L.yr_nms.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_float] + \
             [ctypes.c_void_p] * 3
         L.yr_pack_detections.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3
+        L.yr_letterbox.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_void_p]
         if L.yr_abi_version() != 1:
             raise YoloretHipError('libyoloret_hip.so ABI version mismatch')
         _lib = L
@@ -216,6 +218,19 @@ def correct_boxes(box_xy, box_wh, input_hw, image_hw):
     check(lib().yr_correct_boxes(_ptr(box_xy), _ptr(box_wh), b, n, int(input_hw[0]), int(input_hw[1]),
                                  _ptr(image_hw), _ptr(boxes), stream_ptr()))
     return boxes
+
+
+def letterbox(image_u8, input_hw, out=None):
+    """image_u8: uint8 CUDA tensor [ih,iw,3] -> float32 [H,W,3] letterboxed network input."""
+    if not (isinstance(image_u8, torch.Tensor) and image_u8.is_cuda and image_u8.dtype == torch.uint8
+            and image_u8.dim() == 3 and image_u8.shape[2] == 3 and image_u8.is_contiguous()):
+        raise ValueError('image must be a contiguous uint8 CUDA tensor [h,w,3]')
+    h, w = int(input_hw[0]), int(input_hw[1])
+    if out is None:
+        out = torch.empty((h, w, 3), dtype=torch.float32, device=image_u8.device)
+    check(lib().yr_letterbox(_ptr(image_u8), image_u8.shape[0], image_u8.shape[1], _ptr(out), h, w,
+                             stream_ptr(image_u8.device)))
+    return out
 
 
 def image_hw_tensor(image_shape, batch, device):
