@@ -35,7 +35,7 @@ def _decode_to_u8(image_bytes):
     """tf.io.decode_image(channels=3) on the host: encoded bytes -> uint8 [h,w,3]."""
     from PIL import Image
     img = Image.open(io.BytesIO(image_bytes)).convert('RGB')
-    return np.asarray(img, dtype=np.uint8)
+    return np.array(img, dtype=np.uint8)  # a writable copy
 
 
 class YoloModel:
