@@ -4,9 +4,12 @@
 // layers [3P], reference code/yolo3/model.py:20-24 (RFCR 5x5) and
 // code/yolo3/efficientnet.py:501-510 (MBConv).
 //
-// Each lane produces XT consecutive output pixels of one row for one channel quad, so a
-// row of input taps is loaded once per XT outputs; consecutive lanes take consecutive
-// channel quads (16 B apart) => fully coalesced loads and stores.
+// Each lane produces a YT x XT patch of output pixels for one channel quad: an input row is
+// loaded once per XT outputs and reused by up to K/S vertically adjacent outputs from registers.
+// Consecutive lanes take consecutive channel quads (16 B apart) => fully coalesced loads and
+// stores.  Workgroups are walked in XCD-contiguous order so that vertically adjacent output rows
+// (which share K-S input rows) are processed on the same XCD and hit its L2 (the round-robin
+// default was measured to fetch each input row ~3x from HBM - profiles/r01_pmc_fetch.txt).
 #include "yr_common.h"
 
 struct DwArgs {
@@ -19,8 +22,9 @@ struct DwArgs {
     int ld_in, ld_w, ld_out;
     int pad_t, pad_l;
     int act;
-    int xstrips;         // ceil(Wo / XT)
-    long long total;     // B*Ho*xstrips*C4
+    int xstrips, ystrips;  // ceil(Wo / XT), ceil(Ho / YT)
+    long long total;       // B*ystrips*xstrips*C4
+    unsigned nblocks;
 };
 
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
@@ -28,29 +32,32 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
                        __builtin_fmaf(a.z, b.z, c.z), __builtin_fmaf(a.w, b.w, c.w));
 }
 
-template <int K, int S, int XT>
+template <int K, int S, int XT, int YT>
 __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long gid = (long long)yr_xcd_swizzle(blockIdx.x, a.nblocks) * 256 + threadIdx.x;
     if (gid >= a.total) return;
     const int cq = (int)(gid % a.C4);
     long long t = gid / a.C4;
     const int xs = (int)(t % a.xstrips);
     t /= a.xstrips;
-    const int y = (int)(t % a.Ho);
-    const int b = (int)(t / a.Ho);
+    const int ys = (int)(t % a.ystrips);
+    const int b = (int)(t / a.ystrips);
     const int c = cq * 4;
-    const int x0 = xs * XT;
+    const int x0 = xs * XT, y0 = ys * YT;
     constexpr int COLS = (XT - 1) * S + K;
+    constexpr int ROWS = (YT - 1) * S + K;
 
-    float4 acc[XT];
+    float4 acc[YT][XT];
 #pragma unroll
-    for (int i = 0; i < XT; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < YT; ++j)
+#pragma unroll
+        for (int i = 0; i < XT; ++i) acc[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    const int iy0 = y * S - a.pad_t;
+    const int iy0 = y0 * S - a.pad_t;
     const int ix0 = x0 * S - a.pad_l;
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-        const int iy = iy0 + ky;
+    for (int r = 0; r < ROWS; ++r) {
+        const int iy = iy0 + r;
         if (iy < 0 || iy >= a.Hi) continue;  // zero padding row
         const float* rowp = a.in + ((size_t)(b * a.Hi + iy) * a.Wi) * a.ld_in + c;
         float4 col[COLS];
@@ -60,36 +67,48 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
             col[j] = (ix >= 0 && ix < a.Wi) ? *reinterpret_cast<const float4*>(rowp + (size_t)ix * a.ld_in)
                                             : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        // input row r feeds output row j through kernel row ky = r - j*S
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-            const float4 wv = *reinterpret_cast<const float4*>(a.w + (size_t)(ky * K + kx) * a.ld_w + c);
+        for (int j = 0; j < YT; ++j) {
+            const int ky = r - j * S;
+            if (ky < 0 || ky >= K) continue;
 #pragma unroll
-            for (int i = 0; i < XT; ++i) acc[i] = fma4(col[i * S + kx], wv, acc[i]);
+            for (int kx = 0; kx < K; ++kx) {
+                const float4 wv = *reinterpret_cast<const float4*>(a.w + (size_t)(ky * K + kx) * a.ld_w + c);
+#pragma unroll
+                for (int i = 0; i < XT; ++i) acc[j][i] = fma4(col[i * S + kx], wv, acc[j][i]);
+            }
         }
     }
     const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
     const float4 sh = *reinterpret_cast<const float4*>(a.shift + c);
-    float* op = a.out + ((size_t)(b * a.Ho + y) * a.Wo + x0) * a.ld_out + c;
 #pragma unroll
-    for (int i = 0; i < XT; ++i) {
-        if (x0 + i < a.Wo) {
-            float4 v = yr_apply_act4(fma4(acc[i], sc, sh), a.act);
-            *reinterpret_cast<float4*>(op + (size_t)i * a.ld_out) = v;
+    for (int j = 0; j < YT; ++j) {
+        if (y0 + j >= a.Ho) continue;
+        float* op = a.out + ((size_t)(b * a.Ho + y0 + j) * a.Wo + x0) * a.ld_out + c;
+#pragma unroll
+        for (int i = 0; i < XT; ++i) {
+            if (x0 + i < a.Wo) {
+                float4 v = yr_apply_act4(fma4(acc[j][i], sc, sh), a.act);
+                *reinterpret_cast<float4*>(op + (size_t)i * a.ld_out) = v;
+            }
         }
     }
 }
 
-template <int K, int S, int XT>
+template <int K, int S, int XT, int YT>
 static int launch_dw(DwArgs a, hipStream_t s) {
     a.xstrips = (a.Wo + XT - 1) / XT;
-    a.total = (long long)a.B * a.Ho * a.xstrips * a.C4;
+    a.ystrips = (a.Ho + YT - 1) / YT;
+    a.total = (long long)a.B * a.ystrips * a.xstrips * a.C4;
     const long long blocks = (a.total + 255) / 256;
     YR_REQUIRE(blocks < (1ll << 31), "depthwise: grid too large");
+    a.nblocks = (unsigned)blocks;
     static char nm[32];
-    static const int nm_len = snprintf(nm, sizeof(nm), "dw_kernel<%d,%d,%d>", K, S, XT);
+    static const int nm_len = snprintf(nm, sizeof(nm), "dw_kernel<%d,%d,%d,%d>", K, S, XT, YT);
     (void)nm_len;
     yr_note_kernel(nm);
-    hipLaunchKernelGGL((dw_kernel<K, S, XT>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((dw_kernel<K, S, XT, YT>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
 }
@@ -118,8 +137,10 @@ int yr_launch_depthwise(const yr_op& op, int batch, hipStream_t s) {
     a.pad_t = (pth > 0 ? pth : 0) / 2;
     a.pad_l = (ptw > 0 ? ptw : 0) / 2;
     a.act = op.act;
-    if (op.k == 3 && op.stride == 1) return launch_dw<3, 1, 4>(a, s);
-    if (op.k == 3 && op.stride == 2) return launch_dw<3, 2, 2>(a, s);
-    if (op.k == 5 && op.stride == 1) return launch_dw<5, 1, 4>(a, s);
-    return launch_dw<5, 2, 2>(a, s);
+    // small maps (13x13, 26x26) keep 1-row patches so the grid still fills the chip
+    const bool big = (long long)batch * a.Ho * a.Wo * a.C4 >= (1ll << 21);
+    if (op.k == 3 && op.stride == 1) return big ? launch_dw<3, 1, 4, 2>(a, s) : launch_dw<3, 1, 4, 1>(a, s);
+    if (op.k == 3 && op.stride == 2) return big ? launch_dw<3, 2, 2, 2>(a, s) : launch_dw<3, 2, 2, 1>(a, s);
+    if (op.k == 5 && op.stride == 1) return launch_dw<5, 1, 4, 1>(a, s);
+    return launch_dw<5, 2, 2, 1>(a, s);
 }

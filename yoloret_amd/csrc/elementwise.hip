@@ -16,27 +16,39 @@ struct MeanArgs {
     float inv;        // unused (division keeps reduce_mean's sum/count form)
 };
 
-// grid (ceil(C4/16), B); block 256 = 16 pixel lanes x 16 channel quads.  Fixed summation
+// grid (ceil(C4/16), B); block 1024 = 64 pixel lanes x 16 channel quads.  Fixed summation
 // order => run-to-run deterministic.
-__global__ __launch_bounds__(256) void se_mean_kernel(MeanArgs a) {
-    __shared__ float4 part[16][16];
+#define SE_MEAN_PL 64
+__global__ __launch_bounds__(1024) void se_mean_kernel(MeanArgs a) {
+    __shared__ float4 part[SE_MEAN_PL][16];
     const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int cq = blockIdx.x * 16 + q;
     const int b = blockIdx.y;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cq < a.C4) {
         const float* p = a.in + (size_t)b * a.HW * a.ld + cq * 4;
-        for (int i = pl; i < a.HW; i += 16) {
+#pragma unroll 4
+        for (int i = pl; i < a.HW; i += SE_MEAN_PL) {
             const float4 v = *reinterpret_cast<const float4*>(p + (size_t)i * a.ld);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     }
     part[pl][q] = s;
     __syncthreads();
+    // two-level fixed-order combine: 64 -> 8 -> 1
+    if (pl < 8 && cq < a.C4) {
+        float4 t = part[pl * 8][q];
+        for (int i = 1; i < 8; ++i) {
+            const float4 v = part[pl * 8 + i][q];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        part[pl * 8][q] = t;
+    }
+    __syncthreads();
     if (pl == 0 && cq < a.C4) {
         float4 t = part[0][q];
-        for (int i = 1; i < 16; ++i) {
-            const float4 v = part[i][q];
+        for (int i = 1; i < 8; ++i) {
+            const float4 v = part[i * 8][q];
             t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
         }
         const float n = (float)a.HW;
@@ -58,7 +70,7 @@ int yr_launch_se_mean(const yr_op& op, int batch, hipStream_t s) {
     a.in = in.ptr; a.out = op.out; a.HW = in.h * in.w; a.C = in.c; a.C4 = (in.c + 3) / 4;
     a.ld = in.ld; a.ld_out = op.out_ld; a.inv = 0.f;
     yr_note_kernel("se_mean_kernel");
-    hipLaunchKernelGGL(se_mean_kernel, dim3((a.C4 + 15) / 16, batch), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(se_mean_kernel, dim3((a.C4 + 15) / 16, batch), dim3(1024), 0, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
 }

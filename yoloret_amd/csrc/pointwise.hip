@@ -11,6 +11,10 @@
 //   D: lane holds pixel j=l&15, couts (l>>4)*4+r  -> one float4 store of 4 consecutive couts.
 // A 16-wide k chunk is staged in LDS; lane group g reads k = k0+4g..4g+3 as one
 // ds_read_b128 and uses component s in MFMA step s (the same k permutation on both operands).
+// The next chunk's global loads are issued before the current chunk's MFMAs (register
+// double-buffering), so HBM/L2 latency overlaps the matrix pipe inside one workgroup.
+#include <stdlib.h>
+
 #include "yr_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -32,10 +36,15 @@ struct PwArgs {
 };
 
 // PT/CT: 16-wide pixel / cout MFMA tiles per wave; WM x WN waves (WM*WN == 4).
-template <int PT, int CT, int WM, int WN>
+// SIMPLE: one identity source (optionally SE-gated) -> a pixel's channels are one contiguous row (the
+// common case: every backbone expand/project and most head convs); otherwise the generic gather
+// through per-source row pointers (upsample / maxpool / concat folded into the loads).
+template <int PT, int CT, int WM, int WN, bool SIMPLE>
 __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     constexpr int BM = 16 * PT * WM;
     constexpr int BN = 16 * CT * WN;
+    constexpr int A_PASSES = BM / 64;
+    constexpr int B_PASSES = (BN + 63) / 64;
     __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * PW_LDS_LD];
     float* As = lds;                   // [BM][PW_LDS_LD] activations
     float* Bs = lds + BM * PW_LDS_LD;  // [BN][PW_LDS_LD] weights
@@ -44,26 +53,104 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // 1-D grid walked in XCD-contiguous order with the cout tile fastest: the cout tiles of one pixel
+    // tile run back to back on one XCD, so the activation tile is re-read from that XCD's L2.
+    const unsigned ntn = (a.N + BN - 1) / BN;
+    const unsigned L = yr_xcd_swizzle(blockIdx.x, gridDim.x);
+    const int m0 = (int)(L / ntn) * BM;
+    const int n0 = (int)(L % ntn) * BN;
+    const int kp = a.S.kp;
 
-    // loader mapping: quad kq of row r (+64 per pass)
+    // loader mapping: quad kq of row lr (+64 per pass)
     const int lr = tid >> 2, kq = tid & 3;
-    constexpr int A_PASSES = BM / 64;
-    constexpr int B_PASSES = (BN + 63) / 64;
-    int pb[A_PASSES], py[A_PASSES], px[A_PASSES];
     bool pv[A_PASSES];
+    const float* arow[A_PASSES];               // SIMPLE: the pixel's row
+    const float* grow[A_PASSES];               // SE gate row of the pixel's image (or null)
+    const float* srow[A_PASSES][YR_MAX_SRC];   // generic: per-source row pointer of the pixel (xform folded in)
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
         const int m = m0 + lr + p * 64;
         pv[p] = m < a.M;
         const int mm = pv[p] ? m : 0;
         const int hw = a.H * a.W;
-        pb[p] = mm / hw;
-        const int rem = mm - pb[p] * hw;
-        py[p] = rem / a.W;
-        px[p] = rem - py[p] * a.W;
+        const int b = mm / hw;
+        grow[p] = a.gate ? a.gate + (size_t)b * a.gate_ld : nullptr;
+        if (SIMPLE) {
+            arow[p] = a.S.s[0].ptr + (size_t)mm * a.S.s[0].ld;
+        } else {
+            arow[p] = nullptr;
+            const int rem = mm - b * hw;
+            const int y = rem / a.W, x = rem - y * a.W;
+#pragma unroll
+            for (int si = 0; si < YR_MAX_SRC; ++si) {
+                const DSrc& d = a.S.s[si];
+                int sy = y, sx = x;
+                if (d.xform == YR_X_UP2) { sy = y >> 1; sx = x >> 1; }
+                else if (d.xform == YR_X_MAXPOOL2) { sy = y * 2; sx = x * 2; }
+                else if (d.xform == YR_X_MAXPOOL4) { sy = y * 4; sx = x * 4; }
+                srow[p][si] = d.ptr + ((size_t)(b * d.h + sy) * d.w + sx) * d.ld;
+            }
+        }
     }
+    const float* brow[B_PASSES];
+    bool bvld[B_PASSES];
+#pragma unroll
+    for (int p = 0; p < B_PASSES; ++p) {
+        const int n = n0 + lr + p * 64;
+        bvld[p] = (lr + p * 64 < BN) && n < a.N;
+        brow[p] = a.wt + (size_t)(bvld[p] ? n : 0) * kp;
+    }
+
+    float4 ra[A_PASSES], rb[B_PASSES];
+    auto fetch = [&](int k0) {
+        const int k = k0 + kq * 4;
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pv[p] && k < kp) {
+                int cvalid;
+                if (SIMPLE) {
+                    v = *reinterpret_cast<const float4*>(arow[p] + k);
+                    cvalid = a.S.s[0].c - k;
+                } else {
+                    // segment of this quad (kbase of unused segments is huge), then a pre-offset row pointer
+                    int si = 0;
+#pragma unroll
+                    for (int i = 1; i < YR_MAX_SRC; ++i)
+                        if (k >= a.S.s[i].kbase) si = i;
+                    const float* rp = srow[p][0];
+                    int kb = a.S.s[0].kbase, cc = a.S.s[0].c, xf = a.S.s[0].xform, sw = a.S.s[0].w, sld = a.S.s[0].ld;
+#pragma unroll
+                    for (int i = 1; i < YR_MAX_SRC; ++i)
+                        if (si == i) { rp = srow[p][i]; kb = a.S.s[i].kbase; cc = a.S.s[i].c; xf = a.S.s[i].xform; sw = a.S.s[i].w; sld = a.S.s[i].ld; }
+                    rp += k - kb;
+                    v = *reinterpret_cast<const float4*>(rp);
+                    if (xf >= YR_X_MAXPOOL2) {
+                        const int pool = xf == YR_X_MAXPOOL2 ? 2 : 4;
+                        for (int dy = 0; dy < pool; ++dy)
+                            for (int dx = 0; dx < pool; ++dx)
+                                v = yr_max4(v, *reinterpret_cast<const float4*>(rp + ((size_t)dy * sw + dx) * sld));
+                    }
+                    cvalid = cc - (k - kb);
+                }
+                if (cvalid < 4) { v.w = 0.f; if (cvalid < 3) v.z = 0.f; if (cvalid < 2) v.y = 0.f; }
+                if (grow[p] != nullptr) {
+                    const float4 gt = *reinterpret_cast<const float4*>(grow[p] + k);
+                    v.x *= gt.x;  // lanes beyond the channel count stay exactly 0 (gate padding may be anything)
+                    v.y = cvalid > 1 ? v.y * gt.y : 0.f;
+                    v.z = cvalid > 2 ? v.z * gt.z : 0.f;
+                    v.w = cvalid > 3 ? v.w * gt.w : 0.f;
+                }
+            }
+            ra[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < B_PASSES; ++p) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bvld[p] && k < kp) v = *reinterpret_cast<const float4*>(brow[p] + k);
+            rb[p] = v;
+        }
+    };
 
     f32x4 acc[CT][PT];
 #pragma unroll
@@ -72,38 +159,18 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
         for (int p = 0; p < PT; ++p) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int g = lane >> 4, li = lane & 15;
-    const int kp = a.S.kp;
+    fetch(0);
     for (int k0 = 0; k0 < kp; k0 += PW_BK) {
-        const int k = k0 + kq * 4;
-        // ---- stage activations
+        // ---- registers -> LDS
 #pragma unroll
-        for (int p = 0; p < A_PASSES; ++p) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pv[p]) {
-                v = yr_load_cat_quad(a.S, pb[p], py[p], px[p], k);
-                if (a.gate != nullptr && k < kp) {
-                    const float4 gt = *reinterpret_cast<const float4*>(a.gate + (size_t)pb[p] * a.gate_ld + k);
-                    const int rem = a.S.s[0].c - k;  // lanes beyond the channel count stay exactly 0
-                    v.x *= gt.x;
-                    v.y = rem > 1 ? v.y * gt.y : 0.f;
-                    v.z = rem > 2 ? v.z * gt.z : 0.f;
-                    v.w = rem > 3 ? v.w * gt.w : 0.f;
-                }
-            }
-            *reinterpret_cast<float4*>(As + (lr + p * 64) * PW_LDS_LD + kq * 4) = v;
-        }
-        // ---- stage weights
+        for (int p = 0; p < A_PASSES; ++p)
+            *reinterpret_cast<float4*>(As + (lr + p * 64) * PW_LDS_LD + kq * 4) = ra[p];
 #pragma unroll
-        for (int p = 0; p < B_PASSES; ++p) {
-            const int r = lr + p * 64;
-            if (r < BN) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int n = n0 + r;
-                if (n < a.N && k < kp) v = *reinterpret_cast<const float4*>(a.wt + (size_t)n * kp + k);
-                *reinterpret_cast<float4*>(Bs + r * PW_LDS_LD + kq * 4) = v;
-            }
-        }
+        for (int p = 0; p < B_PASSES; ++p)
+            if (lr + p * 64 < BN) *reinterpret_cast<float4*>(Bs + (lr + p * 64) * PW_LDS_LD + kq * 4) = rb[p];
         __syncthreads();
+        // ---- next chunk's global loads fly while this chunk's MFMAs run
+        if (k0 + PW_BK < kp) fetch(k0 + PW_BK);
         // ---- fragments + MFMA
         f32x4 wf[CT], xf[PT];
 #pragma unroll
@@ -163,12 +230,15 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
 template <int PT, int CT, int WM, int WN>
 static int launch_cfg(const PwArgs& a, hipStream_t s) {
     constexpr int BM = 16 * PT * WM, BN = 16 * CT * WN;
-    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
-    static char nm[40];
-    static const int nm_len = snprintf(nm, sizeof(nm), "pw_kernel<%d,%d,%d,%d>", PT, CT, WM, WN);
+    dim3 grid((unsigned)((a.M + BM - 1) / BM) * (unsigned)((a.N + BN - 1) / BN));
+    const bool simple = a.S.n == 1 && a.S.s[0].xform == YR_X_IDENTITY;
+    static char nm[2][48];
+    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "pw_kernel<%d,%d,%d,%d,0>", PT, CT, WM, WN) +
+                              snprintf(nm[1], sizeof(nm[1]), "pw_kernel<%d,%d,%d,%d,1>", PT, CT, WM, WN);
     (void)nm_len;
-    yr_note_kernel(nm);
-    hipLaunchKernelGGL((pw_kernel<PT, CT, WM, WN>), grid, dim3(256), 0, s, a);
+    yr_note_kernel(nm[simple ? 1 : 0]);
+    if (simple) hipLaunchKernelGGL((pw_kernel<PT, CT, WM, WN, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pw_kernel<PT, CT, WM, WN, false>), grid, dim3(256), 0, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
 }
@@ -198,15 +268,24 @@ int yr_launch_pointwise(const yr_op& op, int batch, hipStream_t s) {
     // pixels (13x13 / 26x26 maps) take 64-row tiles and, if still short of ~2 workgroups per CU,
     // narrower cout tiles - these layers are latency/occupancy-bound, not bandwidth-bound.
     struct Cfg { int bm, bn; int (*fn)(const PwArgs&, hipStream_t); };
-    static const Cfg big[] = {{256, 16, launch_cfg<4, 1, 4, 1>}, {128, 32, launch_cfg<2, 2, 4, 1>},
-                              {128, 48, launch_cfg<2, 3, 4, 1>}, {128, 64, launch_cfg<4, 2, 2, 2>},
-                              {128, 80, launch_cfg<2, 5, 4, 1>}, {128, 96, launch_cfg<4, 3, 2, 2>},
-                              {128, 128, launch_cfg<4, 4, 2, 2>}};
-    static const Cfg small[] = {{64, 16, launch_cfg<1, 1, 4, 1>}, {64, 32, launch_cfg<1, 2, 4, 1>},
-                                {64, 48, launch_cfg<1, 3, 4, 1>}, {64, 64, launch_cfg<1, 4, 4, 1>},
-                                {64, 80, launch_cfg<1, 5, 4, 1>}, {64, 96, launch_cfg<1, 6, 4, 1>},
-                                {64, 128, launch_cfg<1, 8, 4, 1>}};
+    static const Cfg cfgs[] = {{256, 16, launch_cfg<4, 1, 4, 1>}, {128, 32, launch_cfg<2, 2, 4, 1>},
+                               {128, 48, launch_cfg<2, 3, 4, 1>}, {128, 64, launch_cfg<4, 2, 2, 2>},
+                               {128, 80, launch_cfg<2, 5, 4, 1>}, {128, 96, launch_cfg<4, 3, 2, 2>},
+                               {128, 128, launch_cfg<4, 4, 2, 2>},
+                               {64, 16, launch_cfg<1, 1, 4, 1>}, {64, 32, launch_cfg<1, 2, 4, 1>},
+                               {64, 48, launch_cfg<1, 3, 4, 1>}, {64, 64, launch_cfg<1, 4, 4, 1>},
+                               {64, 80, launch_cfg<1, 5, 4, 1>}, {64, 96, launch_cfg<1, 6, 4, 1>},
+                               {64, 128, launch_cfg<1, 8, 4, 1>}};
+    constexpr int NCFG = sizeof(cfgs) / sizeof(cfgs[0]);
     const int N = op.cout;
+    // tuning override: YR_PW_CFG="BMxBN" forces one tile shape for every layer (experiments only)
+    static const char* force = getenv("YR_PW_CFG");
+    if (force) {
+        int bm = 0, bn = 0;
+        if (sscanf(force, "%dx%d", &bm, &bn) == 2)
+            for (int i = 0; i < NCFG; ++i)
+                if (cfgs[i].bm == bm && cfgs[i].bn == bn) return cfgs[i].fn(a, s);
+    }
     // cost model (seconds, rough): activations re-read once per cout tile (mostly from L2/MALL),
     // MFMA work on the padded cout width, and a penalty when the grid cannot fill the chip.
     const double Md = (double)a.M, Kd = (double)a.S.kp;
@@ -218,11 +297,9 @@ int yr_launch_pointwise(const yr_op& op, int batch, hipStream_t s) {
         const double fill = nblk < 512.0 ? 512.0 / nblk : 1.0;
         return (t_mem + t_cmp) * fill;
     };
-    const Cfg* best = &big[0];
-    double bc = cost(big[0]);
-    for (int i = 0; i < 7; ++i) {
-        if (cost(big[i]) < bc) { bc = cost(big[i]); best = &big[i]; }
-        if (cost(small[i]) < bc) { bc = cost(small[i]); best = &small[i]; }
-    }
+    const Cfg* best = &cfgs[0];
+    double bc = cost(cfgs[0]);
+    for (int i = 1; i < NCFG; ++i)
+        if (cost(cfgs[i]) < bc) { bc = cost(cfgs[i]); best = &cfgs[i]; }
     return best->fn(a, s);
 }

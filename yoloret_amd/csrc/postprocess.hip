@@ -270,70 +270,126 @@ __global__ __launch_bounds__(256) void nms_kernel(NmsArgs a) {
     for (int i = picked + tid; i < a.max_boxes; i += 256) oi[i] = -1;
 }
 
-// Compacting variant (the fast path, N < 65536 and N*6 bytes of LDS): every lane owns the strided
-// slots {tid + NMS_T*j}; the survivors of the score filter are packed to the front of the lane's own
-// slots as (score, uint16 index), so no cross-lane synchronisation is needed for the lists.  One
-// round = block arg-max of the lanes' cached bests, then each lane walks only ITS live entries:
-// drops the pick and everything with IoU > thr, re-packs in place and finds its next best on the fly.
-// Work per round is proportional to the number of live candidates, not to N.
-#define NMS_T 1024  // threads per workgroup: more lanes = fewer live entries per lane = shorter rounds
-__global__ __launch_bounds__(NMS_T) void nms_compact_kernel(NmsArgs a) {
-    extern __shared__ float ks[];                                      // [N] scores of live entries
-    unsigned short* ki = reinterpret_cast<unsigned short*>(ks + a.N);  // [N] their box indices
-    __shared__ float ws[NMS_T / 64];
-    __shared__ int wi[NMS_T / 64];
+// Lazy greedy NMS - the order TF's kernel itself works in (N < 65536).  One workgroup of T lanes per
+// (image, class):
+//   1. candidates (score > thr) are compacted with wave ballots into an LDS list of `cap` entries
+//      (score + uint16 index); lane t owns entries t, t+T, ... and insertion-sorts them once by
+//      (score desc, index asc), so popping its best is O(1) (advance a head pointer, prefetch that box);
+//   2. one step = pop the block-wide best - its box travels through the shuffle reduction, so there is no
+//      dependent global load - and test it ONLY against the boxes selected so far (every wave redundantly,
+//      lanes = selected boxes, __any): select or drop.  On typical data that is ~max_boxes steps of O(1)
+//      work instead of max_boxes sweeps over thousands of candidates.
+// The rounds are latency-bound, so throughput comes from the number of problems resident per CU: the first
+// launch uses T=256 and cap=NMS_CAP1 (6144 entries = 36 KB LDS, 4 problems/CU); a problem with more candidates is flagged
+// (count = -1) and redone by a second launch with T=1024 and cap=N (only flagged problems do any work).
+#ifndef NMS_CAP1
+#define NMS_CAP1 6144  // first-pass list capacity (36 KB of LDS: 4 problems per CU)
+#endif
+struct NmsLazyArgs {
+    NmsArgs a;
+    int cap;            // list capacity (entries)
+    int only_overflow;  // second pass: handle only problems flagged -1
+};
+
+template <int T>
+__global__ __launch_bounds__(T) void nms_lazy_kernel(NmsLazyArgs L) {
+    const NmsArgs& a = L.a;
+    extern __shared__ float4 nms_lds[];
+    float4* selb = nms_lds;                                                   // [max_boxes] selected boxes
+    float* ks = reinterpret_cast<float*>(selb + a.max_boxes);                 // [cap] scores
+    unsigned short* ki = reinterpret_cast<unsigned short*>(ks + L.cap);      // [cap] box indices
+    __shared__ float ws[T / 64];
+    __shared__ int wi[T / 64];
+    __shared__ float4 wb[T / 64];
+    __shared__ int cnt;
     const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (L.only_overflow && a.out_count[(size_t)b * a.C + c] != -1) return;  // solved by the first pass
     const float* sc = a.scores + ((size_t)b * a.C + c) * a.N;
     const float4* bx = reinterpret_cast<const float4*>(a.boxes) + (size_t)b * a.N;
-    int n = 0;
-    float ls = NMS_DEAD;  // this lane's best live (score, index); index ascending inside a lane
-    int li = 0x7fffffff;
-    for (int i = tid; i < a.N; i += NMS_T) {
-        const float s = sc[i];
-        if (s > a.score_thr) {
-            ks[tid + NMS_T * n] = s;
-            ki[tid + NMS_T * n] = (unsigned short)i;
-            ++n;
-            if (s > ls) { ls = s; li = i; }
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < a.N; i0 += T) {
+        const int i = i0 + tid;
+        const float s = i < a.N ? sc[i] : 0.f;
+        const bool keep = i < a.N && s > a.score_thr;
+        const unsigned long long mask = __ballot(keep);
+        int base = 0;
+        if (lane == 0 && mask) base = atomicAdd(&cnt, __popcll(mask));
+        base = __shfl(base, 0);
+        if (keep) {
+            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+            if (pos < L.cap) { ks[pos] = s; ki[pos] = (unsigned short)i; }
         }
     }
+    __syncthreads();
+    const int total = cnt;
     int32_t* oi = a.out_idx + ((size_t)b * a.C + c) * a.max_boxes;
-    int picked = 0;
-    for (; picked < a.max_boxes; ++picked) {
+    if (total > L.cap) {  // uniform
+        if (tid == 0) a.out_count[(size_t)b * a.C + c] = -1;
+        return;
+    }
+    const int n = total > tid ? (total - tid + T - 1) / T : 0;
+    for (int j = 1; j < n; ++j) {
+        const float s = ks[tid + T * j];
+        const unsigned short i = ki[tid + T * j];
+        int k = j - 1;
+        while (k >= 0) {
+            const float sk = ks[tid + T * k];
+            const unsigned short ik = ki[tid + T * k];
+            if (sk > s || (sk == s && ik < i)) break;
+            ks[tid + T * (k + 1)] = sk;
+            ki[tid + T * (k + 1)] = ik;
+            --k;
+        }
+        ks[tid + T * (k + 1)] = s;
+        ki[tid + T * (k + 1)] = i;
+    }
+    int head = 0;
+    float ls; int li; float4 lb;
+    auto load_head = [&]() {
+        if (head < n) { ls = ks[tid + T * head]; li = ki[tid + T * head]; lb = bx[li]; }
+        else { ls = NMS_DEAD; li = 0x7fffffff; lb = make_float4(0.f, 0.f, 0.f, 0.f); }
+    };
+    load_head();
+    int nsel = 0;
+    while (nsel < a.max_boxes) {
         float bs = ls;
         int bi = li;
+        float4 pb = lb;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float s2 = __shfl_xor(bs, o);
             const int i2 = __shfl_xor(bi, o);
-            if (s2 > bs || (s2 == bs && i2 < bi)) { bs = s2; bi = i2; }
+            const float q0 = __shfl_xor(pb.x, o), q1 = __shfl_xor(pb.y, o), q2 = __shfl_xor(pb.z, o), q3 = __shfl_xor(pb.w, o);
+            if (s2 > bs || (s2 == bs && i2 < bi)) { bs = s2; bi = i2; pb = make_float4(q0, q1, q2, q3); }
         }
-        if (lane == 0) { ws[wave] = bs; wi[wave] = bi; }
+        if (lane == 0) { ws[wave] = bs; wi[wave] = bi; wb[wave] = pb; }
         __syncthreads();
+        int bw = 0;
         bs = ws[0]; bi = wi[0];
 #pragma unroll
-        for (int w = 1; w < NMS_T / 64; ++w)
-            if (ws[w] > bs || (ws[w] == bs && wi[w] < bi)) { bs = ws[w]; bi = wi[w]; }
-        __syncthreads();  // ws/wi are rewritten next round
-        if (!(bs > NMS_DEAD)) break;  // uniform: no candidate left
-        if (tid == 0) oi[picked] = bi;
-        const float4 pb = bx[bi];
-        int m = 0;
-        ls = NMS_DEAD; li = 0x7fffffff;
-        for (int j = 0; j < n; ++j) {
-            const float s = ks[tid + NMS_T * j];
-            const int i = ki[tid + NMS_T * j];
-            if (i == bi) continue;
-            if (yr_iou(pb, bx[i]) > a.iou_thr) continue;
-            ks[tid + NMS_T * m] = s;
-            ki[tid + NMS_T * m] = (unsigned short)i;
-            ++m;
-            if (s > ls) { ls = s; li = i; }
+        for (int w = 1; w < T / 64; ++w)
+            if (ws[w] > bs || (ws[w] == bs && wi[w] < bi)) { bs = ws[w]; bi = wi[w]; bw = w; }
+        pb = wb[bw];
+        if (!(bs > NMS_DEAD)) break;  // uniform: nothing left
+        // the owner advances to its next best entry (that box's load overlaps the test below)
+        if (li == bi) {
+            ++head;
+            load_head();
         }
-        n = m;
+        // suppressed by an already selected box?  (lanes stride the selected list; same answer in every wave)
+        bool sup = false;
+        for (int j = lane; j < nsel; j += 64) sup = sup || (yr_iou(pb, selb[j]) > a.iou_thr);
+        const bool suppressed = __any(sup);
+        __syncthreads();  // everyone is done with ws/wi/wb and selb before they change
+        if (!suppressed) {
+            if (tid == 0) { oi[nsel] = bi; selb[nsel] = pb; }
+            ++nsel;
+            __syncthreads();  // selb[nsel-1] visible
+        }
     }
-    if (tid == 0) a.out_count[(size_t)b * a.C + c] = picked;
-    for (int i = picked + tid; i < a.max_boxes; i += NMS_T) oi[i] = -1;
+    if (tid == 0) a.out_count[(size_t)b * a.C + c] = nsel;
+    for (int i = nsel + tid; i < a.max_boxes; i += T) oi[i] = -1;
 }
 
 extern "C" int yr_nms(const float* boxes, const float* scores, int batch, int n, int num_classes, int max_boxes,
@@ -345,19 +401,31 @@ extern "C" int yr_nms(const float* boxes, const float* scores, int batch, int n,
     static bool attr_set = false;
     if (!attr_set) {
         YR_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
-        YR_CHECK_HIP(hipFuncSetAttribute((const void*)nms_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        YR_CHECK_HIP(hipFuncSetAttribute((const void*)nms_lazy_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        YR_CHECK_HIP(hipFuncSetAttribute((const void*)nms_lazy_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
         attr_set = true;
     }
-    NmsArgs a;
+    NmsLazyArgs L;
+    NmsArgs& a = L.a;
     a.boxes = boxes; a.scores = scores; a.N = n; a.C = num_classes; a.max_boxes = max_boxes;
     a.score_thr = score_thr; a.iou_thr = iou_thr; a.out_idx = out_idx; a.out_count = out_count;
-    const size_t lds_compact = (size_t)n * 6 + 16;
-    if (n < 65536 && lds_compact <= lds_limit) {
-        hipLaunchKernelGGL(nms_compact_kernel, dim3(num_classes, batch), dim3(NMS_T), lds_compact, (hipStream_t)stream, a);
+    const size_t sel_bytes = (size_t)max_boxes * sizeof(float4);
+    const size_t lds_full = sel_bytes + (size_t)n * 6 + 16;
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 65536 && lds_full <= lds_limit) {
+        // pass 1: capped lists for every problem; pass 2: full-capacity lists, only where pass 1 overflowed
+        L.cap = n < NMS_CAP1 ? n : NMS_CAP1;
+        L.only_overflow = 0;
+        hipLaunchKernelGGL(nms_lazy_kernel<256>, dim3(num_classes, batch), dim3(256), sel_bytes + (size_t)L.cap * 6 + 16, st, L);
+        if (L.cap < n) {
+            L.cap = n;
+            L.only_overflow = 1;
+            hipLaunchKernelGGL(nms_lazy_kernel<1024>, dim3(num_classes, batch), dim3(1024), lds_full, st, L);
+        }
     } else {
         const size_t lds = (size_t)n * sizeof(float);
         YR_REQUIRE(lds <= lds_limit, "nms: %d boxes per image exceed the LDS-resident limit (38400)", n);
-        hipLaunchKernelGGL(nms_kernel, dim3(num_classes, batch), dim3(256), lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(nms_kernel, dim3(num_classes, batch), dim3(256), lds, st, a);
     }
     YR_LAUNCH_CHECK();
     return YR_OK;

@@ -83,6 +83,16 @@ __device__ __forceinline__ float4 yr_max4(float4 a, float4 b) {
     return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
 }
 
+// XCD-aware block order (cdna_hip_programming.md T1): hardware block b runs on XCD b % 8, each XCD has
+// its own L2.  Map hardware ids so that every XCD walks a CONTIGUOUS range of logical blocks; logical
+// neighbours (adjacent rows of a depthwise map, the cout tiles of one pixel tile) then share an L2.
+// Bijective for any grid size; only speed depends on the placement assumption.
+__device__ __forceinline__ unsigned yr_xcd_swizzle(unsigned bid, unsigned nb) {
+    const unsigned q = nb >> 3, r = nb & 7u;
+    const unsigned x = bid & 7u, i = bid >> 3;
+    return x * q + (x < r ? x : r) + i;
+}
+
 // Device view of one concatenated source segment (see yr_src).
 struct DSrc {
     const float* ptr;
