@@ -136,6 +136,11 @@ int yr_forward(yr_handle* h, const float* images, int batch, float* y1, float* y
 int yr_forward_profile(yr_handle* h, const float* images, int batch, float* y1, float* y2, float* y3,
                        void* workspace, size_t workspace_bytes, void* stream, int iters,
                        float* ms_per_op, const char** kernel_names);
+/* Per-op tile autotuning for `batch` images: times every pointwise tile shape on every pointwise op and
+ * remembers the fastest for later yr_forward calls with the same batch (numerics do not depend on the
+ * shape).  Runs the forward once first; synchronises the stream. */
+int yr_autotune(yr_handle* h, const float* images, int batch, float* y1, float* y2, float* y3,
+                void* workspace, size_t workspace_bytes, void* stream, int iters);
 /* Number of kernel launches one yr_forward enqueues. */
 int yr_plan_num_launches(const yr_handle* h);
 

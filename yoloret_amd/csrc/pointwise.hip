@@ -278,6 +278,8 @@ int yr_launch_pointwise(const yr_op& op, int batch, hipStream_t s) {
                                {64, 128, launch_cfg<1, 8, 4, 1>}};
     constexpr int NCFG = sizeof(cfgs) / sizeof(cfgs[0]);
     const int N = op.cout;
+    // autotuned choice (yr_autotune stores the fastest shape per op and batch): op.k = 1 + index
+    if (op.k >= 1 && op.k <= NCFG) return cfgs[op.k - 1].fn(a, s);
     // tuning override: YR_PW_CFG="BMxBN" forces one tile shape for every layer (experiments only)
     static const char* force = getenv("YR_PW_CFG");
     if (force) {
@@ -303,3 +305,6 @@ int yr_launch_pointwise(const yr_op& op, int batch, hipStream_t s) {
         if (cost(cfgs[i]) < bc) { bc = cost(cfgs[i]); best = &cfgs[i]; }
     return best->fn(a, s);
 }
+
+// number of tile shapes yr_launch_pointwise can be forced to through op.k (1-based)
+int yr_pointwise_num_cfgs() { return 14; }

@@ -4,6 +4,7 @@
 // code/yolo3/model.py:170-342, called at code/yolo.py:152 and code/yolo3/map.py:111).
 #include <string.h>
 
+#include <map>
 #include <vector>
 
 #include "yr_common.h"
@@ -48,6 +49,7 @@ struct yr_handle {
     int64_t arena_per_image = 0;  // floats
     float* weights = nullptr;
     size_t n_weights = 0;
+    std::map<int, std::vector<int>> tuned;  // batch -> per-op pointwise tile choice (1-based, 0 = heuristic)
     int device = 0;
 };
 
@@ -125,6 +127,10 @@ static int resolve_op(const yr_handle* h, size_t i, int batch, float* const ext[
     op.wgt = wptr(op.wgt_off); op.scale = wptr(op.scale_off); op.shift = wptr(op.shift_off);
     op.wgt2 = wptr(op.wgt2_off); op.b1 = wptr(op.b1_off); op.b2 = wptr(op.b2_off);
     if (op.out == nullptr) { yr_set_error("op %zu writes a null external buffer", i); return YR_ERR_ARG; }
+    if (op.kind == YR_OP_POINTWISE) {
+        auto it = h->tuned.find(batch);
+        op.k = it != h->tuned.end() ? it->second[i] : 0;
+    }
     *out = op;
     return YR_OK;
 }
@@ -197,5 +203,50 @@ extern "C" int yr_forward_profile(yr_handle* h, const float* images, int batch, 
     for (auto& e : ev) (void)hipEventDestroy(e);
     if (rc == YR_OK)
         for (size_t i = 0; i < n; ++i) ms_per_op[i] = (float)(acc[i] / iters);
+    return rc;
+}
+
+// Per-op tile autotuning for one batch size: runs the forward once (so every buffer holds real data), then
+// times every pointwise tile shape on every pointwise op (hipEvents, `iters` launches each) and remembers
+// the fastest; later yr_forward calls with the same batch use those shapes.  Results do not depend on the
+// tile shape (the k-summation order is the same for every shape), only the speed does.  Synchronises.
+extern "C" int yr_autotune(yr_handle* h, const float* images, int batch, float* y1, float* y2, float* y3,
+                           void* workspace, size_t workspace_bytes, void* stream, int iters) {
+    int rc = check_forward_args(h, images, batch, workspace, workspace_bytes);
+    if (rc) return rc;
+    YR_REQUIRE(iters > 0, "yr_autotune: iters must be positive");
+    h->tuned.erase(batch);
+    rc = yr_forward(h, images, batch, y1, y2, y3, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    float* ext[4] = {const_cast<float*>(images), y1, y2, y3};
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    YR_CHECK_HIP(hipEventCreate(&e0));
+    YR_CHECK_HIP(hipEventCreate(&e1));
+    std::vector<int> best(h->ops.size(), 0);
+    const int ncfg = yr_pointwise_num_cfgs();
+    for (size_t i = 0; i < h->ops.size() && rc == YR_OK; ++i) {
+        if (h->ops[i].kind != YR_OP_POINTWISE) continue;
+        yr_op op;
+        rc = resolve_op(h, i, batch, ext, static_cast<float*>(workspace), &op);
+        if (rc) break;
+        float best_ms = 1e30f;
+        for (int c = 0; c <= ncfg && rc == YR_OK; ++c) {   // c == 0: the heuristic's own pick
+            op.k = c;
+            rc = dispatch(op, batch, s);                    // warm-up
+            if (rc) break;
+            YR_CHECK_HIP(hipEventRecord(e0, s));
+            for (int it = 0; it < iters && rc == YR_OK; ++it) rc = dispatch(op, batch, s);
+            YR_CHECK_HIP(hipEventRecord(e1, s));
+            YR_CHECK_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            YR_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best_ms * 0.97f) { best_ms = ms; best[i] = c; }  // a later shape must win by >3 % (noise)
+        }
+        if (rc != YR_OK) rc = fail_op(i, h->ops[i].kind, rc);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc == YR_OK) h->tuned[batch] = best;
     return rc;
 }

@@ -26,6 +26,8 @@ class Model:
         self.plan = compile_graph(self.inputs[0], self.outputs, fuse)
         self._weights = None
         self._blob = None
+        self.autotune = os.environ.get('YOLORET_AUTOTUNE', '1') != '0'
+        self._tuned = set()    # (device index, batch) pairs already autotuned
         self._handles = {}     # device index -> yr_handle*
         self._workspace = {}   # device index -> torch.uint8 tensor
         self._out_anchors = [o.node.attrs['num_anchors'] if o.node is not None and o.node.op == 'reshape5' else None
@@ -111,6 +113,12 @@ class Model:
                   for ob in self.plan.output_bufs]
         yp = [rt._ptr(y) for y in ys] + [None] * (3 - len(ys))
         with torch.cuda.device(idx):
+            if self.autotune and (idx, b) not in self._tuned:
+                # first call with this batch size: time every pointwise tile shape per layer once (~0.1 s);
+                # the choice changes speed only, never results
+                self._tuned.add((idx, b))
+                rt.check(rt.lib().yr_autotune(hd, rt._ptr(x), b, yp[0], yp[1], yp[2], rt._ptr(ws), ws.numel(),
+                                              rt.stream_ptr(x.device), 3))
             rt.check(rt.lib().yr_forward(hd, rt._ptr(x), b, yp[0], yp[1], yp[2], rt._ptr(ws), ws.numel(),
                                          rt.stream_ptr(x.device)))
         res = []

@@ -47,7 +47,7 @@ class YrBuf(ctypes.Structure):
 
 
 EXPORTS = ['yr_last_error', 'yr_abi_version', 'yr_create', 'yr_destroy', 'yr_load_weights', 'yr_workspace_bytes',
-           'yr_forward', 'yr_forward_profile', 'yr_plan_num_launches', 'yr_op_run', 'yr_decode', 'yr_yolo_head', 'yr_correct_boxes',
+           'yr_forward', 'yr_forward_profile', 'yr_autotune', 'yr_plan_num_launches', 'yr_op_run', 'yr_decode', 'yr_yolo_head', 'yr_correct_boxes',
            'yr_nms', 'yr_pack_detections', 'yr_letterbox']
 
 _lib = None
@@ -80,6 +80,8 @@ def lib():
         L.yr_forward_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                          ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.yr_autotune.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
         L.yr_op_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.yr_decode.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 5
         L.yr_yolo_head.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + \
