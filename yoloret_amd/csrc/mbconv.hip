@@ -54,19 +54,34 @@ __global__ __launch_bounds__(256) void mbconv_kernel(MbArgs a) {
     const int iy0 = oy0 * S - a.pad_t, ix0 = ox0 * S - a.pad_l;
 
     // ---- 1. input halo tile -> LDS (zero outside the image and beyond Cin)
+    //      Loads are issued in batches of XB before the first LDS store of the batch: otherwise every
+    //      iteration pays a full HBM round trip (store-after-load ordering), measured 1.9x on the stem.
     {
         const int kq = a.kpi >> 2;
-        for (int idx = tid; idx < PH * kq; idx += 256) {
-            const int p = idx / kq, q = idx - p * kq;
-            const int hy = p / IW, hx = p - hy * IW;
-            const int iy = iy0 + hy, ix = ix0 + hx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
-                v = *reinterpret_cast<const float4*>(a.x + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.ld_in + q * 4);
-                const int rem = a.Cin - q * 4;
-                if (rem < 4) { v.w = 0.f; if (rem < 3) v.z = 0.f; if (rem < 2) v.y = 0.f; }
+        constexpr int XB = 6;
+        for (int base = 0; base < PH * kq; base += 256 * XB) {
+            float4 v[XB];
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int p = idx / kq, q = idx - p * kq;
+                const int hy = p / IW, hx = p - hy * IW;
+                const int iy = iy0 + hy, ix = ix0 + hx;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < PH * kq && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
+                    v[u] = *reinterpret_cast<const float4*>(a.x + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.ld_in + q * 4);
+                    const int rem = a.Cin - q * 4;
+                    if (rem < 4) { v[u].w = 0.f; if (rem < 3) v[u].z = 0.f; if (rem < 2) v[u].y = 0.f; }
+                }
             }
-            *reinterpret_cast<float4*>(Xs + p * ldx + q * 4) = v;
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
+                const int idx = base + u * 256 + tid;
+                if (idx < PH * kq) {
+                    const int p = idx / kq, q = idx - p * kq;
+                    *reinterpret_cast<float4*>(Xs + p * ldx + q * 4) = v[u];
+                }
+            }
         }
     }
 
@@ -79,17 +94,23 @@ __global__ __launch_bounds__(256) void mbconv_kernel(MbArgs a) {
 
     for (int e0 = 0; e0 < a.Cexp; e0 += MB_EC) {
         // ---- 2. chunk parameters -> LDS (zeros beyond Cexp so padded channels contribute act(0)=0)
-        for (int i = tid; i < 13 * MB_EC; i += 256) {
-            const int r = i / MB_EC, ch = i - r * MB_EC;
-            const int e = e0 + ch;
-            float v = 0.f;
-            if (e < a.Cexp) {
-                if (r < 9) v = a.wdw[(size_t)r * a.ldE + e];
-                else if (r == 9) v = a.sd[e];
-                else if (r == 10) v = a.hd[e];
-                else if (a.has_expand) v = (r == 11) ? a.se[e] : a.he[e];
+        {
+            constexpr int NP = (13 * MB_EC + 255) / 256;
+            float pv[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {  // all loads first, then the LDS stores (one round trip)
+                const int i = tid + u * 256;
+                const int r = i / MB_EC, ch = i - r * MB_EC;
+                const int e = e0 + ch;
+                pv[u] = 0.f;
+                if (i < 13 * MB_EC && e < a.Cexp) {
+                    const float* src = r < 9 ? a.wdw + (size_t)r * a.ldE : (r == 9 ? a.sd : (r == 10 ? a.hd : (r == 11 ? a.se : a.he)));
+                    if (r < 11 || a.has_expand) pv[u] = src[e];
+                }
             }
-            Ps[i] = v;
+#pragma unroll
+            for (int u = 0; u < NP; ++u)
+                if (tid + u * 256 < 13 * MB_EC) Ps[tid + u * 256] = pv[u];
         }
         __syncthreads();  // Xs (first chunk) and Ps visible; previous chunk's readers of Es are done (loop-end barrier)
 

@@ -66,7 +66,20 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
     const int cnt = min(DEC_TILE, ns - t0);
     const int row = a.C + 5;
     const float* src = a.y[s] + ((size_t)b * ns + t0) * row;
-    for (int i = threadIdx.x; i < cnt * row; i += 256) sm[i] = src[i];
+    // batches of 8 loads before their LDS stores (a store after each load would serialise the HBM round trips)
+    for (int i0 = 0; i0 < cnt * row; i0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256 + threadIdx.x;
+            v[u] = i < cnt * row ? src[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256 + threadIdx.x;
+            if (i < cnt * row) sm[i] = v[u];
+        }
+    }
     __syncthreads();
     const int j = threadIdx.x;
     if (j >= cnt) return;

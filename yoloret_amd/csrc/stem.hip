@@ -2,9 +2,16 @@
 // Replaces Conv2D + FusedBatchNormV3 + Relu6 of MobileNetV2's Conv1 [3P] and the EfficientNet
 // stem (reference code/yolo3/efficientnet.py:636-645).
 //
-// One lane = one output pixel x one cout quad, cout-quad fastest: stores are perfectly
-// coalesced float4s; the 27 input taps are shared by the Cout/4 neighbouring lanes through L1.
+// One workgroup = an 8 x 32 tile of output pixels, one lane per pixel, all output channels in
+// registers.  The 17 x 65 x 3 input halo tile is staged in LDS with coalesced row loads (every input
+// element is read from HBM once); the 27 x Cout weights are wave-uniform and come through the scalar
+// cache (s_load), so the inner loop is 27 LDS reads + 27*Cout FMAs per pixel.
 #include "yr_common.h"
+
+#define ST_TH 8
+#define ST_TW 32
+#define ST_IH (2 * ST_TH + 1)
+#define ST_IW (2 * ST_TW + 1)
 
 struct StemArgs {
     const float* in;     // [B][Hi][Wi][3] dense
@@ -12,49 +19,89 @@ struct StemArgs {
     const float* scale;  // [ldw]
     const float* shift;  // [ldw]
     float* out;          // [B][Ho][Wo][ld_out]
-    int B, Hi, Wi, Ho, Wo, C4, ldw, ld_out, pad_t, pad_l, act;
-    long long total;
+    int B, Hi, Wi, Ho, Wo, ldw, ld_out, pad_t, pad_l, act, tiles_x, tiles_y;
 };
 
+template <int CQ>  // cout quads held per lane
 __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];  // [27][ldw]
-    for (int i = threadIdx.x; i < 27 * a.ldw; i += 256) wl[i] = a.w[i];
+    __shared__ float tile[ST_IH * ST_IW * 3];
+    __shared__ __attribute__((aligned(16))) float wl[27 * CQ * 4];
+    __shared__ __attribute__((aligned(16))) float otile[256 * CQ * 4];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 27 * CQ * 4; i += 256) wl[i] = a.w[i];  // ldw == CQ*4 (checked by the launcher)
+    const int t = blockIdx.x;
+    const int b = t / (a.tiles_x * a.tiles_y);
+    const int r = t - b * a.tiles_x * a.tiles_y;
+    const int ty0 = (r / a.tiles_x) * ST_TH, tx0 = (r % a.tiles_x) * ST_TW;
+    const int iy0 = ty0 * 2 - a.pad_t, ix0 = tx0 * 2 - a.pad_l;
+    // input tile -> LDS: ST_IH rows of ST_IW*3 contiguous floats (zero outside the image)
+    // (all loads are issued before the first LDS store: one HBM round trip per workgroup, not 13)
+    constexpr int NLD = (ST_IH * ST_IW * 3 + 255) / 256;
+    float stage[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int i = tid + u * 256;
+        const int ry = i / (ST_IW * 3), rc = i - ry * (ST_IW * 3);
+        const int iy = iy0 + ry, ixc = ix0 * 3 + rc;  // ixc = ix*3 + ci
+        stage[u] = 0.f;
+        if (i < ST_IH * ST_IW * 3 && iy >= 0 && iy < a.Hi && ixc >= 0 && ixc < a.Wi * 3)
+            stage[u] = a.in[((size_t)b * a.Hi + iy) * a.Wi * 3 + ixc];
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u)
+        if (tid + u * 256 < ST_IH * ST_IW * 3) tile[tid + u * 256] = stage[u];
     __syncthreads();
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= a.total) return;
-    const int cq = (int)(gid % a.C4);
-    long long t = gid / a.C4;
-    const int x = (int)(t % a.Wo);
-    t /= a.Wo;
-    const int y = (int)(t % a.Ho);
-    const int b = (int)(t / a.Ho);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int py = tid / ST_TW, px = tid - py * ST_TW;
+    float4 acc[CQ];
 #pragma unroll
+    for (int q = 0; q < CQ; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the tap loops stay rolled: fully unrolled, the compiler hoists all 27*CQ weight reads and spills
+#pragma unroll 1
     for (int ky = 0; ky < 3; ++ky) {
-        const int iy = y * 2 - a.pad_t + ky;
-        if (iy < 0 || iy >= a.Hi) continue;
+        const float* rowp = tile + (py * 2 + ky) * (ST_IW * 3) + px * 6;
+#pragma unroll 3
+        for (int j = 0; j < 9; ++j) {  // j = kx*3 + ci: 9 contiguous floats of the row
+            const float v = rowp[j];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = x * 2 - a.pad_l + kx;
-            if (ix < 0 || ix >= a.Wi) continue;
-            const float* p = a.in + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * 3;
-#pragma unroll
-            for (int ci = 0; ci < 3; ++ci) {
-                const float v = p[ci];
-                const float4 wv = *reinterpret_cast<const float4*>(wl + ((ky * 3 + kx) * 3 + ci) * a.ldw + cq * 4);
-                acc.x = __builtin_fmaf(v, wv.x, acc.x);
-                acc.y = __builtin_fmaf(v, wv.y, acc.y);
-                acc.z = __builtin_fmaf(v, wv.z, acc.z);
-                acc.w = __builtin_fmaf(v, wv.w, acc.w);
+            for (int q = 0; q < CQ; ++q) {
+                const float4 wv = *reinterpret_cast<const float4*>(wl + ((ky * 9 + j) * CQ + q) * 4);  // LDS broadcast
+                acc[q].x = __builtin_fmaf(v, wv.x, acc[q].x);
+                acc[q].y = __builtin_fmaf(v, wv.y, acc[q].y);
+                acc[q].z = __builtin_fmaf(v, wv.z, acc[q].z);
+                acc[q].w = __builtin_fmaf(v, wv.w, acc[q].w);
             }
         }
     }
-    const float4 sc = *reinterpret_cast<const float4*>(a.scale + cq * 4);
-    const float4 sh = *reinterpret_cast<const float4*>(a.shift + cq * 4);
-    float4 v = make_float4(__builtin_fmaf(acc.x, sc.x, sh.x), __builtin_fmaf(acc.y, sc.y, sh.y),
-                           __builtin_fmaf(acc.z, sc.z, sh.z), __builtin_fmaf(acc.w, sc.w, sh.w));
-    v = yr_apply_act4(v, a.act);
-    *reinterpret_cast<float4*>(a.out + ((size_t)(b * a.Ho + y) * a.Wo + x) * a.ld_out + cq * 4) = v;
+    // BN + activation, then through LDS so that the tile is written as whole contiguous rows
+    // (a lane owns 4*CQ consecutive floats of ONE pixel; written directly, each store instruction would
+    // touch 64 different cache lines)
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+        const float4 sc = *reinterpret_cast<const float4*>(a.scale + q * 4);
+        const float4 sh = *reinterpret_cast<const float4*>(a.shift + q * 4);
+        float4 v = make_float4(__builtin_fmaf(acc[q].x, sc.x, sh.x), __builtin_fmaf(acc[q].y, sc.y, sh.y),
+                               __builtin_fmaf(acc[q].z, sc.z, sh.z), __builtin_fmaf(acc[q].w, sc.w, sh.w));
+        *reinterpret_cast<float4*>(otile + (tid * CQ + q) * 4) = yr_apply_act4(v, a.act);
+    }
+    __syncthreads();
+    for (int i = tid; i < 256 * CQ; i += 256) {
+        const int p = i / CQ, q = i - p * CQ;
+        const int oy = ty0 + p / ST_TW, ox = tx0 + (p % ST_TW);
+        if (oy < a.Ho && ox < a.Wo)
+            *reinterpret_cast<float4*>(a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.ld_out + q * 4) =
+                *reinterpret_cast<const float4*>(otile + i * 4);
+    }
+}
+
+template <int CQ>
+static int launch_stem(const StemArgs& a, hipStream_t s) {
+    static char nm[24];
+    static const int nm_len = snprintf(nm, sizeof(nm), "stem_kernel<%d>", CQ);
+    (void)nm_len;
+    yr_note_kernel(nm);
+    hipLaunchKernelGGL(stem_kernel<CQ>, dim3((unsigned)(a.B * a.tiles_x * a.tiles_y)), dim3(256), 0, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
 }
 
 int yr_launch_stem(const yr_op& op, int batch, hipStream_t s) {
@@ -67,16 +114,24 @@ int yr_launch_stem(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(a.in && a.w && a.scale && a.shift && a.out, "stem: null pointer");
     a.B = batch; a.Hi = in.h; a.Wi = in.w; a.Ho = (in.h + 1) / 2; a.Wo = (in.w + 1) / 2;
     YR_REQUIRE(a.Ho == op.h && a.Wo == op.w, "stem: output dims mismatch");
-    a.C4 = (op.cout + 3) / 4; a.ldw = a.C4 * 4; a.ld_out = op.out_ld;
+    a.ldw = yr_round_up(op.cout, 4); a.ld_out = op.out_ld;
     YR_REQUIRE(op.out_ld % 4 == 0 && op.out_ld >= a.ldw, "stem: out_ld must be a multiple of 4 and >= round_up(cout,4)");
     const int pth = (a.Ho - 1) * 2 + 3 - in.h, ptw = (a.Wo - 1) * 2 + 3 - in.w;
     a.pad_t = (pth > 0 ? pth : 0) / 2; a.pad_l = (ptw > 0 ? ptw : 0) / 2;
     a.act = op.act;
-    a.total = (long long)batch * a.Ho * a.Wo * a.C4;
-    const long long blocks = (a.total + 255) / 256;
-    YR_REQUIRE(blocks < (1ll << 31), "stem: grid too large");
-    yr_note_kernel("stem_kernel");
-    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)blocks), dim3(256), 27 * a.ldw * sizeof(float), s, a);
-    YR_LAUNCH_CHECK();
-    return YR_OK;
+    a.tiles_x = (a.Wo + ST_TW - 1) / ST_TW; a.tiles_y = (a.Ho + ST_TH - 1) / ST_TH;
+    YR_REQUIRE((long long)batch * a.tiles_x * a.tiles_y < (1ll << 31), "stem: grid too large");
+    const int cq = a.ldw / 4;
+    // the kernel holds exactly ldw/4 cout quads per lane (no guards in the unrolled FMA block)
+    switch (cq) {
+        case 2: return launch_stem<2>(a, s);
+        case 4: return launch_stem<4>(a, s);
+        case 6: return launch_stem<6>(a, s);      // MobileNetV2 x0.75 (24)
+        case 8: return launch_stem<8>(a, s);      // EfficientNet-B0 (32)
+        case 10: return launch_stem<10>(a, s);    // EfficientNet-B3 (40)
+        case 12: return launch_stem<12>(a, s);    // MobileNetV2 x1.4 (48), EfficientNet-B4
+        case 14: return launch_stem<14>(a, s);
+        case 16: return launch_stem<16>(a, s);
+        default: yr_set_error("stem: %d output channels: only multiples of 8 up to 64 are supported", op.cout); return YR_ERR_ARG;
+    }
 }
