@@ -19,9 +19,11 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define MB_EC 48        // expanded channels per chunk (every MobileNetV2 / EfficientNet width is a multiple)
-#define MB_ECT 3        // = MB_EC / 16
-#define MB_LDES 52      // Es row stride (floats): 13 x 16 B, odd => conflict-free b128 rows
+// Expanded channels per chunk: 48 for stride 1 (every MobileNetV2 / EfficientNet width is a multiple), 32 for
+// stride 2, whose 4.5x larger halo tile would otherwise cap residency at 3 workgroups per CU (measured:
+// block_1 0.52 -> 0.44 ms with 32, block_2 0.35 -> 0.39 ms with 32).  Es row stride = EC + 4 floats
+// (an odd number of 16-byte slots => conflict-free ds_read_b128 across consecutive pixels).
+#define MB_CHUNK(S) ((S) == 2 ? 32 : 48)
 
 struct MbArgs {
     const float* x; float* out;
@@ -34,7 +36,8 @@ struct MbArgs {
 };
 
 template <int TH, int TW, int S, int CTO>
-__global__ __launch_bounds__(256) void mbconv_kernel(MbArgs a) {
+__global__ __launch_bounds__(256, (CTO <= 2 ? 4 : 1)) void mbconv_kernel(MbArgs a) {  // narrow: <= 128 VGPRs -> 4 WGs/CU
+    constexpr int MB_EC = MB_CHUNK(S), MB_ECT = MB_EC / 16, MB_LDES = MB_EC + 4;
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, PH = IH * IW;
     constexpr int OPX = TH * TW, NMT_O = OPX / 16, NMT_H = (PH + 15) / 16;
     constexpr int MTO = (NMT_O + 3) / 4;
@@ -116,13 +119,44 @@ __global__ __launch_bounds__(256) void mbconv_kernel(MbArgs a) {
 
         // ---- 3. expand GEMM over this wave's halo pixel tiles -> Es
         if (a.has_expand) {
+            // narrow inputs (Cin <= 32): the chunk's weight fragments (<= 2 k-steps x 3 tiles) are loaded once
+            // per wave and reused by all of its pixel tiles - otherwise every pixel tile waits for an L2 round trip
+            const bool hoist = a.kpi <= 32;
+            f32x4 wfe0[MB_ECT], wfe1[MB_ECT];
+#pragma unroll
+            for (int c = 0; c < MB_ECT; ++c) {
+                const int e = e0 + c * 16 + li;
+                wfe0[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                wfe1[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (hoist && e < a.Cexp) {
+                    if (g * 4 < a.kpi) wfe0[c] = *reinterpret_cast<const f32x4*>(a.wet + (size_t)e * a.kpi + g * 4);
+                    if (16 + g * 4 < a.kpi) wfe1[c] = *reinterpret_cast<const f32x4*>(a.wet + (size_t)e * a.kpi + 16 + g * 4);
+                }
+            }
             for (int mt = wave; mt < NMT_H; mt += 4) {
                 const int p = mt * 16 + li;
                 const int pc = p < PH ? p : PH - 1;
                 f32x4 acc_e[MB_ECT];
 #pragma unroll
                 for (int c = 0; c < MB_ECT; ++c) acc_e[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                for (int k0 = 0; k0 < a.kpi; k0 += 16) {
+                if (hoist) {
+                    f32x4 x0 = (f32x4){0.f, 0.f, 0.f, 0.f}, x1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (g * 4 < a.kpi) x0 = *reinterpret_cast<const f32x4*>(Xs + pc * ldx + g * 4);
+                    if (16 + g * 4 < a.kpi) x1 = *reinterpret_cast<const f32x4*>(Xs + pc * ldx + 16 + g * 4);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int c = 0; c < MB_ECT; ++c)
+                            acc_e[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfe0[c][s], x0[s], acc_e[c], 0, 0, 0);
+                    if (a.kpi > 16) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+#pragma unroll
+                            for (int c = 0; c < MB_ECT; ++c)
+                                acc_e[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfe1[c][s], x1[s], acc_e[c], 0, 0, 0);
+                    }
+                }
+                for (int k0 = 0; k0 < (hoist ? 0 : a.kpi); k0 += 16) {
                     const int k = k0 + g * 4;
                     f32x4 xf = (f32x4){0.f, 0.f, 0.f, 0.f};
                     if (k < a.kpi) xf = *reinterpret_cast<const f32x4*>(Xs + pc * ldx + k);
@@ -245,6 +279,7 @@ __global__ __launch_bounds__(256) void mbconv_kernel(MbArgs a) {
 template <int TH, int TW, int S, int CTO>
 static int launch_mb(const MbArgs& a, int batch, hipStream_t s) {
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, PH = IH * IW;
+    constexpr int MB_EC = MB_CHUNK(S), MB_LDES = MB_EC + 4;
     const size_t lds = ((size_t)PH * (a.kpi + 4) + (a.has_expand ? (size_t)PH * MB_LDES : 0) + 13 * MB_EC) * sizeof(float);
     YR_REQUIRE(lds <= 160 * 1024, "mbconv: LDS tile of %zu bytes does not fit", lds);
     static bool attr = false;
