@@ -42,6 +42,8 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline sample')
     ap.add_argument('--profile-iters', type=int, default=3)
     ap.add_argument('--per-op', action='store_true', help='also print the per-op table to stderr')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='initialise RCCL and issue the detection all-gather even with one rank (single-GPU check of the N>1 path)')
     ap.add_argument('--no-latency', action='store_true',
                     help='skip the batch-1 p50 loop (use under rocprofv3 so that every launch is a batch-%d launch)' % 64)
     return ap.parse_args()
@@ -101,9 +103,11 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from yoloret_amd import layers as L
     from yoloret_amd import weights as W
@@ -116,7 +120,7 @@ def main():
     model = yolov3_body(L.Input(shape=[a.size, a.size, 3]), a.model, 3, num_classes=a.classes)
     model.set_weights(W.synthetic_weights(model, 1234, 'survey'))
     pipe = DetectionPipeline(model, anchors, a.classes, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5)
-    gather = DetectionGatherer()
+    gather = DetectionGatherer(always=a.force_dist)
     b = a.batch
     x = torch.from_numpy(W.synthetic_images(b, a.size, a.size, seed=20240416 + rank)).to(dev)
     image_hw = torch.tensor([[a.size, a.size]] * b, dtype=torch.int32, device=dev)
@@ -127,7 +131,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -139,7 +143,7 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -247,7 +251,7 @@ def main():
                'p50_ms_b1': p50, 'roofline': roofline, 'roofline_step': roofline_step}
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.model, a.size, a.classes, anchors, a.cpu_seconds)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -23,9 +23,11 @@ def shard_range(global_batch, rank, world_size):
 class DetectionGatherer:
     """Preallocated all-gather of (det, det_count); result rows are in global image order."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, always=False):
+        """always=True issues the collective even for a 1-rank group (exercises RCCL on a single GPU)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.always = always and dist.is_initialized()
         self._out = None
         self._send = None
 
@@ -33,7 +35,7 @@ class DetectionGatherer:
         """det int32 [b, S, 6], det_count int32 [b] (local shard) -> ([W*b, S, 6], [W*b]).
         `record`: the flat buffer both are views of (DetectionPipeline.record) - sent as is;
         without it the two tensors are first staged into one message."""
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return det, det_count
         b, s, six = det.shape
         words = b * s * six + b
