@@ -232,6 +232,7 @@ class Plan:
 # unfused GEMMs win, so those stay unfused until the kernel grows a large-M variant.
 FUSE_MAX_CIN = int(os.environ.get('YOLORET_FUSE_MAX_CIN', '32'))
 FUSE_MIN_PIXELS = int(os.environ.get('YOLORET_FUSE_MIN_PIXELS', '1600'))  # output H*W of the block
+FUSE_NO_EXPAND = os.environ.get('YOLORET_FUSE_NO_EXPAND', '0') != '0'    # also fuse DW+project blocks without expand
 
 
 def fuse_inverted_residuals(ops, output_buf_ids):
@@ -267,7 +268,8 @@ def fuse_inverted_residuals(ops, output_buf_ids):
             block_in = exp.srcs[0] if exp is not None else d.srcs[0]
             if (p.kind == rt.OP_POINTWISE and plain1(p) and p.srcs[0].buf is d.out and p.act == 'none'
                     and 'scale' in p.params and p.cout <= 224 and block_in.buf.ld % 4 == 0
-                    and exp is not None and block_in.c <= FUSE_MAX_CIN and p.h * p.w >= FUSE_MIN_PIXELS
+                    and (exp is not None or FUSE_NO_EXPAND) and block_in.c <= FUSE_MAX_CIN
+                    and p.h * p.w >= FUSE_MIN_PIXELS
                     and (p.res is None or (p.res is block_in.buf and d.stride == 1 and p.cout == block_in.c))):
                 dw, proj = d, p
         if proj is None:
