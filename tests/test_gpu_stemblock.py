@@ -1,0 +1,65 @@
+"""Fused network-entry kernel (stem 3x3 s2 + BN + act -> DW 3x3 + BN + act -> project 1x1 + BN) against the
+three oracle ops composed, through yr_op_run."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn
+from tests.util import assert_close, from_dev, round_up
+
+pytestmark = pytest.mark.gpu
+
+
+def _vec(a, dev, n=None):
+    a = np.asarray(a, np.float32).ravel()
+    if n is not None and n != a.size:
+        p = np.zeros(n, np.float32)
+        p[:a.size] = a
+        a = p
+    return torch.from_numpy(a).to(dev)
+
+
+CASES = [((64, 64), 24, 16, 'relu6'), ((416, 416), 24, 16, 'relu6'), ((32, 96), 48, 24, 'relu6'),
+         ((30, 22), 32, 16, 'swish'), ((50, 34), 40, 24, 'relu6')]
+
+
+@pytest.mark.parametrize('hw,c1,cout,act', CASES)
+def test_stemblock(dev, hw, c1, cout, act):
+    from yoloret_amd import runtime as rt
+    rng = np.random.default_rng(zlib.crc32(str((hw, c1, cout)).encode()))
+    b = 2
+    x = rng.random((b, hw[0], hw[1], 3), dtype=np.float32)
+    actf = {'relu6': nn.relu6, 'swish': nn.swish}[act]
+    ws = (rng.standard_normal((3, 3, 3, c1)) * np.sqrt(2.0 / 27)).astype(np.float32)
+    ss, hs = rng.uniform(0.5, 1.5, c1).astype(np.float32), rng.normal(0, 0.3, c1).astype(np.float32)
+    wd = (rng.standard_normal((3, 3, c1)) * np.sqrt(2.0 / 9)).astype(np.float32)
+    sd, hd = rng.uniform(0.5, 1.5, c1).astype(np.float32), rng.normal(0, 0.3, c1).astype(np.float32)
+    wp = (rng.standard_normal((c1, cout)) * np.sqrt(1.0 / c1)).astype(np.float32)
+    sp, hp = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.3, cout).astype(np.float32)
+    t = actf((nn.conv2d(x, ws, 2, 'same') * ss + hs).astype(np.float32))
+    t = actf((nn.depthwise(t, wd, 1, 'same') * sd + hd).astype(np.float32))
+    ref = (nn.pointwise(t, wp) * sp + hp).astype(np.float32)
+    c1p, ldo, cop = round_up(c1, 4), round_up(cout, 4), round_up(cout, 8)
+
+    def per_pair(w, scale, shift):    # [taps][c1] + BN -> [c1p/2][taps x 2 | scale 2 | shift 2]  (include/yoloret_hip.h)
+        rows = np.zeros((w.shape[0] + 2, c1p), np.float32)
+        rows[:-2, :c1], rows[-2, :c1], rows[-1, :c1] = w, scale, shift
+        return np.ascontiguousarray(rows.reshape(-1, c1p // 2, 2).transpose(1, 0, 2))
+    wpp = np.zeros((c1p, cop), np.float32)
+    wpp[:c1, :cout] = wp
+    pb = np.zeros((2, cop), np.float32)
+    pb[0, :cout], pb[1, :cout] = sp, hp
+    keep = [_vec(per_pair(ws.reshape(27, c1), ss, hs), dev), _vec(per_pair(wd.reshape(9, c1), sd, hd), dev),
+            _vec(wpp, dev), _vec(pb, dev)]
+    xd = torch.from_numpy(x).to(dev)
+    out = torch.full((b, ref.shape[1], ref.shape[2], ldo), float('nan'), dtype=torch.float32, device=dev)
+    op = rt.new_op(rt.OP_STEMBLOCK, act)
+    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc, op.se_reduced = ref.shape[1], ref.shape[2], 3, cout, 3, 2, 1, c1
+    op.src[0] = rt.make_src(xd, c=3, ld=3)
+    op.wgt, op.wgt2, op.b1, op.b2 = [k.data_ptr() for k in keep]
+    op.out, op.out_ld = out.data_ptr(), ldo
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    assert_close(from_dev(out, cout), ref, 3e-5, 'stemblock')

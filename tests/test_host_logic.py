@@ -28,12 +28,12 @@ def test_macs_match_survey(name, size, macs_m):
 
 def test_plan_structure_and_accounting():
     from yoloret_amd import compiler, runtime as rt
-    saved = compiler.FUSE_MAX_CIN
+    saved = compiler.FUSE_MAX_CIN, compiler.FUSE_STEM
     try:
-        compiler.FUSE_MAX_CIN = 0       # unfused plan = SURVEY.md Appendix B rows
+        compiler.FUSE_MAX_CIN, compiler.FUSE_STEM = 0, False   # unfused plan = SURVEY.md Appendix B rows
         p = _model().plan
     finally:
-        compiler.FUSE_MAX_CIN = saved
+        compiler.FUSE_MAX_CIN, compiler.FUSE_STEM = saved
     kinds = [o.kind for o in p.ops]
     assert kinds.count(rt.OP_POINTWISE) == 55 and kinds.count(rt.OP_DEPTHWISE) == 23 and kinds.count(rt.OP_STEM) == 1
     assert kinds.count(rt.OP_SE_MEAN) == 6 and kinds.count(rt.OP_SE_FC) == 6 and kinds.count(rt.OP_WSUM) == 1
@@ -44,7 +44,7 @@ def test_plan_structure_and_accounting():
     assert widths['bu2_conv'] == 203 and widths['bu1_conv'] == 331
     assert [(b.h, b.w, b.c) for b in p.output_bufs] == [(13, 13, 75), (26, 26, 75), (52, 52, 75)]
     fused = _model().plan
-    assert any(o.kind == rt.OP_MBCONV for o in fused.ops)
+    assert any(o.kind == rt.OP_MBCONV for o in fused.ops) and fused.ops[0].kind == rt.OP_STEMBLOCK
     assert abs(fused.algorithmic_bytes_per_image() - p.algorithmic_bytes_per_image()) < 1  # accounting is fusion-invariant
     assert fused.total_macs() == p.total_macs()
     assert fused.arena_elems_per_image < p.arena_elems_per_image

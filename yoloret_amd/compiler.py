@@ -185,7 +185,7 @@ class Plan:
 
         def elems_of(op):
             elems = 0
-            if op.kind == rt.OP_MBCONV:
+            if op.kind in (rt.OP_MBCONV, rt.OP_STEMBLOCK):
                 # the accounting stays conv-granular (the figure everyone computes from): a fused
                 # block is charged what its three convolutions would move unfused
                 return sum(elems_of(f) for f in op.fused)
@@ -233,6 +233,8 @@ class Plan:
 FUSE_MAX_CIN = int(os.environ.get('YOLORET_FUSE_MAX_CIN', '32'))
 FUSE_MIN_PIXELS = int(os.environ.get('YOLORET_FUSE_MIN_PIXELS', '1600'))  # output H*W of the block
 FUSE_NO_EXPAND = os.environ.get('YOLORET_FUSE_NO_EXPAND', '0') != '0'    # also fuse DW+project blocks without expand
+FUSE_STEM = os.environ.get('YOLORET_FUSE_STEM', '1') != '0'              # stem + first (expand-free) block in one kernel
+STEMBLOCK_WIDTHS = {(12, 16), (16, 16), (16, 24), (20, 24), (24, 16), (24, 24)}  # (C1p/2, round_up(cout,8)) built in stemblock.hip
 
 
 def fuse_inverted_residuals(ops, output_buf_ids):
@@ -252,9 +254,51 @@ def fuse_inverted_residuals(ops, output_buf_ids):
     def plain1(op):
         return len(op.srcs) == 1 and op.srcs[0].xform == 'identity' and op.gate is None
 
+    def pad_to(fn, n, ld):
+        def f(wd):
+            o = np.zeros(ld, np.float32)
+            o[:n] = fn(wd)[:n]
+            return o
+        return f
+
     out, i = [], 0
     while i < len(ops):
         e = ops[i]
+        # ---- network entry: STEM -> DEPTHWISE 3x3 s1 -> POINTWISE project (MobileNetV2 Conv1 + block 0)
+        if FUSE_STEM and e.kind == rt.OP_STEM and private(e.out) and i + 2 < len(ops) and e.act in ('relu6', 'swish'):
+            d, p = ops[i + 1], ops[i + 2]
+            if (d.kind == rt.OP_DEPTHWISE and d.k == 3 and d.stride == 1 and plain1(d) and d.srcs[0].buf is e.out
+                    and d.act == e.act and private(d.out) and p.kind == rt.OP_POINTWISE and plain1(p)
+                    and p.srcs[0].buf is d.out and p.act == 'none' and p.res is None and 'scale' in p.params
+                    and (round_up(e.cout, 4) // 2, round_up(p.cout, 8)) in STEMBLOCK_WIDTHS):
+                c1, cout = e.cout, p.cout
+                c1p, cop = round_up(c1, 4), round_up(cout, 8)
+                m = OpRec(rt.OP_STEMBLOCK, e.name + '_block0', act=e.act, h=p.h, w=p.w, cin=3, cout=cout, k=3, stride=2,
+                          se_reduced=c1, srcs=[e.srcs[0]], out=p.out, macs=e.macs + d.macs + p.macs)
+                m.fused = [e, d, p]
+
+                def per_pair(prm, taps, c1p=c1p):
+                    """[taps][c1p] weights + scale/shift [c1p]  ->  [c1p/2][taps x 2 | scale 2 | shift 2]"""
+                    def f(wd):
+                        w = prm['wgt'][1](wd).reshape(taps, -1)[:, :c1p]
+                        rows = np.concatenate([w, pad_to(prm['scale'][1], c1p, c1p)(wd)[None],
+                                               pad_to(prm['shift'][1], c1p, c1p)(wd)[None]])     # [taps+2][c1p]
+                        return np.ascontiguousarray(rows.reshape(taps + 2, c1p // 2, 2).transpose(1, 0, 2)).reshape(c1p // 2, -1)
+                    return ((c1p // 2, (taps + 2) * 2), f)
+
+                def proj_w(wd, pw=p.params['wgt'][1], c1p=c1p, cop=cop, cout=cout):
+                    o = np.zeros((c1p, cop), np.float32)
+                    o[:, :cout] = pw(wd)[:, :c1p].T       # pointwise layout is Wt[cout][kp]
+                    return o
+                pp2 = p.params
+                m.params['wgt'] = per_pair(e.params, 27)
+                m.params['wgt2'] = per_pair(d.params, 9)
+                m.params['b1'] = ((c1p, cop), proj_w)
+                m.params['b2'] = ((2 * cop,), lambda wd, pp2=pp2, cout=cout, cop=cop: np.concatenate(
+                    [pad_to(pp2['scale'][1], cout, cop)(wd), pad_to(pp2['shift'][1], cout, cop)(wd)]))
+                out.append(m)
+                i += 3
+                continue
         exp = dw = proj = None
         j = i
         if (e.kind == rt.OP_POINTWISE and plain1(e) and e.res is None and e.act in ('relu6', 'swish')

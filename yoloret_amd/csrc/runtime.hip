@@ -34,6 +34,7 @@ static int dispatch(const yr_op& op, int batch, hipStream_t s) {
         case YR_OP_WSUM: return yr_launch_wsum(op, batch, s);
         case YR_OP_GATHER: return yr_launch_gather(op, batch, s);
         case YR_OP_MBCONV: return yr_launch_mbconv(op, batch, s);
+        case YR_OP_STEMBLOCK: return yr_launch_stemblock(op, batch, s);
         default: yr_set_error("unknown op kind %d", op.kind); return YR_ERR_ARG;
     }
 }

@@ -1,0 +1,211 @@
+// Fused network entry: stem Conv2D 3x3 s2 (Cin=3) + BN + act  ->  depthwise 3x3 s1 + BN + act  ->
+// project 1x1 + BN, one kernel.  For MobileNetV2 this is Conv1 + the "expanded_conv" block (block 0,
+// which has no expand stage) [3P; reference code/yolo3/override.py:339]: the 208x208x24 stem output
+// and depthwise output (2 x 4.15 MB per image at 416, written and re-read by the unfused chain) never
+// leave the CU - HBM sees the 2.08 MB image in and the 2.77 MB block output out.
+//
+// One workgroup (4 waves) = a 14 x 14 tile of block-output pixels, whose 16 x 16 stem-output halo tile is
+// exactly one halo pixel per lane.  The kernel is VALU-bound (1248 MACs per output pixel against 19 bytes
+// of HBM traffic), so it is laid out for the FMA pipe, not for bandwidth:
+//   * lane = pixel, every lane computes ALL channels of its pixel.  Weights are therefore wave-uniform
+//     and are read through the constant address space (s_load -> SGPR operands of the FMAs): no LDS or
+//     VGPR traffic for weights at all;
+//   * channels go in pairs held as float2 so every FMA issues as v_pk_fma_f32 (two MACs per lane per issue);
+//   * the loops over channel pairs are rolled: one pair's weights are one contiguous s_load burst (host
+//     layout [CP][...], <= 70 SGPRs live, no SGPR spills); everything inside is straight-line;
+//   * LDS holds only the 33 x 33 x 3 input tile and the stem-output halo tile Es[CP][256] (float2 per
+//     lane: conflict-free writes, and the depthwise taps read lane-consecutive float2s).  The depthwise
+//     result goes straight from registers into the projection.
+#include "yr_common.h"
+
+#define SB_T 14             // output tile edge
+#define SB_E (SB_T + 2)     // stem-output halo tile edge (== 16: one halo pixel per lane of 256)
+#define SB_I (2 * SB_E + 1) // input tile edge (pixels)
+#define SB_TS 100           // LDS row stride of the input tile (99 floats used)
+#define SB_WS 58            // stem floats per channel pair:      27 taps x 2 | scale 2 | shift 2
+#define SB_WD 22            // depthwise floats per channel pair:  9 taps x 2 | scale 2 | shift 2
+
+typedef const float __attribute__((address_space(4))) * kptr;  // uniform reads of this become s_load
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct SbArgs {
+    const float* in;   // [B][Hi][Wi][3]
+    float* out;        // [B][Ho][Wo][ld_out]   (Ho = ceil(Hi/2))
+    const float* ws;   // stem       [CP][SB_WS]
+    const float* wd;   // depthwise  [CP][SB_WD]
+    const float* wp;   // project    [2*CP][COP]
+    const float* bp;   // project    scale [COP] ++ shift [COP]
+    int Hi, Wi, Ho, Wo, Cout, ld_out, pad_t, pad_l, act, tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ v2f sb_fma(v2f x, v2f y, v2f z) { return __builtin_elementwise_fma(x, y, z); }
+
+template <bool RELU6>
+__device__ __forceinline__ v2f sb_act(v2f v, int act) {
+    if (RELU6) return (v2f){fminf(fmaxf(v.x, 0.f), 6.f), fminf(fmaxf(v.y, 0.f), 6.f)};
+    return (v2f){yr_apply_act(v.x, act), yr_apply_act(v.y, act)};
+}
+
+template <int CP, int COP, bool RELU6>
+__global__ __launch_bounds__(256, 4) void stemblock_kernel(SbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* tile = lds;                                           // [SB_I][SB_TS]
+    v2f* Es = reinterpret_cast<v2f*>(lds);                       // [CP][256]; overlays the tile once it is consumed
+    const int tid = threadIdx.x;
+    const int t = (int)yr_xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tpi = a.tiles_x * a.tiles_y;
+    const int b = t / tpi, r = t - b * tpi;
+    const int ty = r / a.tiles_x;
+    const int oy0 = ty * SB_T, ox0 = (r - ty * a.tiles_x) * SB_T;
+    const int iy0 = 2 * (oy0 - 1) - a.pad_t, ix0 = 2 * (ox0 - 1) - a.pad_l;  // input coords of halo pixel (0,0), tap (0,0)
+
+    // ---- phase 0: input tile -> LDS (zero outside the image = the stem's SAME padding); loads first, stores after
+    {
+        constexpr int NEL = SB_I * SB_I * 3, NLD = (NEL + 255) / 256;
+        float st[NLD];
+        const float* img = a.in + (size_t)b * a.Hi * a.Wi * 3;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = tid + u * 256;
+            const int ry = i / (SB_I * 3), rc = i - ry * (SB_I * 3);
+            const int iy = iy0 + ry, ixc = ix0 * 3 + rc;
+            st[u] = 0.f;
+            if (i < NEL && iy >= 0 && iy < a.Hi && ixc >= 0 && ixc < a.Wi * 3) st[u] = img[(size_t)iy * a.Wi * 3 + ixc];
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = tid + u * 256;
+            const int ry = i / (SB_I * 3), rc = i - ry * (SB_I * 3);
+            if (i < NEL) tile[ry * SB_TS + rc] = st[u];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: lane = halo pixel; stem conv, all channels, one pair per (rolled) iteration -> Es
+    {
+        const int ey = tid >> 4, ex = tid & 15;
+        const int sy = oy0 - 1 + ey, sx = ox0 - 1 + ex;
+        const bool valid = sy >= 0 && sy < a.Ho && sx >= 0 && sx < a.Wo;  // outside: zero (the depthwise's SAME padding)
+        float in[27];
+        const float* tp = tile + (2 * ey) * SB_TS + 6 * ex;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int j = 0; j < 9; ++j) in[ky * 9 + j] = tp[ky * SB_TS + j];
+        __syncthreads();  // the input tile is in registers now: Es overlays it
+        const kptr ws = (kptr)a.ws;
+#pragma unroll 1
+        for (int p = 0; p < CP; ++p) {
+            const kptr w = ws + p * SB_WS;
+            v2f acc = {0.f, 0.f}, acc2 = {0.f, 0.f};  // two chains (taps 0-13 | 14-26) for issue-level parallelism
+#pragma unroll
+            for (int k = 0; k < 14; ++k) acc = sb_fma((v2f){in[k], in[k]}, (v2f){w[2 * k], w[2 * k + 1]}, acc);
+#pragma unroll
+            for (int k = 14; k < 27; ++k) acc2 = sb_fma((v2f){in[k], in[k]}, (v2f){w[2 * k], w[2 * k + 1]}, acc2);
+            acc += acc2;
+            acc = sb_act<RELU6>(sb_fma(acc, (v2f){w[54], w[55]}, (v2f){w[56], w[57]}), a.act);
+            if (!valid) acc = (v2f){0.f, 0.f};
+            Es[p * 256 + tid] = acc;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: lane = output pixel; depthwise 3x3 + BN + act in registers, projected immediately
+    if (tid < SB_T * SB_T) {
+        const int py = tid / SB_T, px = tid - py * SB_T;
+        const int gy = oy0 + py, gx = ox0 + px;
+        v2f o[COP / 2];
+#pragma unroll
+        for (int n = 0; n < COP / 2; ++n) o[n] = (v2f){0.f, 0.f};
+        const kptr wd = (kptr)a.wd;
+        const kptr wp = (kptr)a.wp;
+        const v2f* e0 = Es + py * SB_E + px;
+#pragma unroll 1
+        for (int p = 0; p < CP; ++p) {
+            const kptr w = wd + p * SB_WD;
+            const kptr pw = wp + p * 2 * COP;
+            const v2f* e = e0 + p * 256;
+            v2f d = {0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int k = ky * 3 + kx;
+                    d = sb_fma(e[ky * SB_E + kx], (v2f){w[2 * k], w[2 * k + 1]}, d);
+                }
+            d = sb_act<RELU6>(sb_fma(d, (v2f){w[18], w[19]}, (v2f){w[20], w[21]}), a.act);
+#pragma unroll
+            for (int n = 0; n < COP / 2; ++n) o[n] = sb_fma((v2f){d.x, d.x}, (v2f){pw[2 * n], pw[2 * n + 1]}, o[n]);
+#pragma unroll
+            for (int n = 0; n < COP / 2; ++n) o[n] = sb_fma((v2f){d.y, d.y}, (v2f){pw[COP + 2 * n], pw[COP + 2 * n + 1]}, o[n]);
+        }
+        if (gy < a.Ho && gx < a.Wo) {
+            const kptr bp = (kptr)a.bp;
+            float* op = a.out + (((size_t)b * a.Ho + gy) * a.Wo + gx) * a.ld_out;
+#pragma unroll
+            for (int n = 0; n < COP / 2; ++n) o[n] = sb_fma(o[n], (v2f){bp[2 * n], bp[2 * n + 1]}, (v2f){bp[COP + 2 * n], bp[COP + 2 * n + 1]});
+#pragma unroll
+            for (int n = 0; n < COP; n += 4) {
+                if (n + 3 < a.Cout && (a.ld_out & 3) == 0) {
+                    *reinterpret_cast<float4*>(op + n) = make_float4(o[n / 2].x, o[n / 2].y, o[n / 2 + 1].x, o[n / 2 + 1].y);
+                } else {
+                    if (n < a.Cout) op[n] = o[n / 2].x;
+                    if (n + 1 < a.Cout) op[n + 1] = o[n / 2].y;
+                    if (n + 2 < a.Cout) op[n + 2] = o[n / 2 + 1].x;
+                    if (n + 3 < a.Cout) op[n + 3] = o[n / 2 + 1].y;
+                }
+            }
+        }
+    }
+}
+
+template <int CP, int COP>
+static int launch_sb(const SbArgs& a, int batch, hipStream_t s) {
+    constexpr size_t n_tile = (size_t)SB_I * SB_TS, n_es = (size_t)CP * 256 * 2;
+    constexpr size_t lds = (n_tile > n_es ? n_tile : n_es) * sizeof(float);
+    static_assert(lds <= 64 * 1024, "stemblock LDS tile too large");
+    static char nm[40];
+    static const int nm_len = snprintf(nm, sizeof(nm), "stemblock_kernel<%d,%d>", CP, COP);
+    (void)nm_len;
+    yr_note_kernel(nm);
+    const dim3 grid((unsigned)(batch * a.tiles_x * a.tiles_y));
+    if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((stemblock_kernel<CP, COP, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((stemblock_kernel<CP, COP, false>), grid, dim3(256), lds, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
+// op fields: src[0] = dense 3-channel image; cin = 3; se_reduced = C1 (stem width); cout; k = 3; stride = 2;
+// act = stem/DW activation.  With CP = round_up(C1,4)/2 channel pairs, COP = round_up(cout,8), all zero padded:
+//   wgt  = stem, per channel pair:      [CP][27 taps (ky,kx,ci) x 2 | BN scale 2 | BN shift 2]   (58 floats per pair)
+//   wgt2 = depthwise, per channel pair: [CP][ 9 taps (ky,kx)    x 2 | BN scale 2 | BN shift 2]   (22 floats per pair)
+//   b1   = project W[2*CP][COP] (input-channel major);  b2 = project BN scale [COP] ++ shift [COP].
+int yr_launch_stemblock(const yr_op& op, int batch, hipStream_t s) {
+    YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY && op.src[0].c == 3 && op.src[0].ld == 3,
+               "stemblock: needs one dense 3-channel source");
+    YR_REQUIRE(op.k == 3 && op.stride == 2, "stemblock: the stem is 3x3 stride 2");
+    const yr_src& in = op.src[0];
+    SbArgs a;
+    a.in = in.ptr; a.out = op.out;
+    YR_REQUIRE(op.se_reduced >= 1 && op.cout >= 1, "stemblock: bad widths (C1=%d, Cout=%d)", op.se_reduced, op.cout);
+    const int c1p = yr_round_up(op.se_reduced, 4), cop = yr_round_up(op.cout, 8);
+    YR_REQUIRE(in.ptr && op.out && op.wgt && op.wgt2 && op.b1 && op.b2, "stemblock: null pointer");
+    a.ws = op.wgt; a.wd = op.wgt2; a.wp = op.b1; a.bp = op.b2;
+    a.Cout = op.cout;
+    a.Hi = in.h; a.Wi = in.w; a.Ho = (in.h + 1) / 2; a.Wo = (in.w + 1) / 2;
+    YR_REQUIRE(a.Ho == op.h && a.Wo == op.w && op.out_ld >= op.cout, "stemblock: output dims mismatch");
+    a.ld_out = op.out_ld;
+    const int pth = (a.Ho - 1) * 2 + 3 - in.h, ptw = (a.Wo - 1) * 2 + 3 - in.w;
+    a.pad_t = (pth > 0 ? pth : 0) / 2; a.pad_l = (ptw > 0 ? ptw : 0) / 2;
+    a.act = op.act;
+    a.tiles_x = (a.Wo + SB_T - 1) / SB_T; a.tiles_y = (a.Ho + SB_T - 1) / SB_T;
+    switch (c1p / 2 * 100 + cop) {
+        case 1216: return launch_sb<12, 16>(a, batch, s);
+        case 1616: return launch_sb<16, 16>(a, batch, s);
+        case 1624: return launch_sb<16, 24>(a, batch, s);
+        case 2024: return launch_sb<20, 24>(a, batch, s);
+        case 2416: return launch_sb<24, 16>(a, batch, s);
+        case 2424: return launch_sb<24, 24>(a, batch, s);
+        default: yr_set_error("stemblock: widths C1=%d Cout=%d unsupported", op.se_reduced, op.cout); return YR_ERR_ARG;
+    }
+}
