@@ -65,13 +65,21 @@ typedef enum {
     YR_OP_GATHER = 7,    /* materialise upsample/maxpool/concat        (standalone K5; testing / unfused use) */
     YR_OP_MBCONV = 8,    /* fused inverted-residual block: expand 1x1+BN+act -> DW3x3+BN+act -> project 1x1+BN (+residual)
                             (MobileNetV2 block_* [3P]; SE-free MBConv, efficientnet.py:467-536); the expanded tensor stays in LDS */
-    YR_OP_STEMBLOCK = 9  /* fused network entry: stem Conv2D 3x3 s2 (Cin=3)+BN+act -> DW3x3 s1+BN+act -> project 1x1+BN
+    YR_OP_STEMBLOCK = 9, /* fused network entry: stem Conv2D 3x3 s2 (Cin=3)+BN+act -> DW3x3 s1+BN+act -> project 1x1+BN
                             (MobileNetV2 Conv1 + expanded_conv block [3P]); se_reduced = stem width C1.  Parameters are packed
                             per channel PAIR (CP = round_up(C1,4)/2, COP = round_up(cout,8), zero padded; scale/shift unused):
                             wgt  = stem      [CP][27 taps (ky,kx,ci) x 2 | BN scale 2 | BN shift 2],
                             wgt2 = depthwise [CP][ 9 taps (ky,kx)    x 2 | BN scale 2 | BN shift 2],
                             b1   = project W[2*CP][COP] (input-channel major), b2 = project BN scale[COP] ++ shift[COP].
                             Built for (CP,COP) in {(12,16),(16,16),(16,24),(20,24),(24,16),(24,24)}; others: YR_ERR_ARG */
+    YR_OP_MBLANE = 10    /* the MBCONV block (same layers, same op fields) in the lane-per-pixel formulation for narrow
+                            block inputs (Cin <= 32): packed-fp32 FMA with scalar-register weights instead of MFMA.
+                            se_reduced = Cexp; parameters packed per expanded-channel PAIR, P = round_up(ceil(Cexp/2),8),
+                            CINP = round_up(Cin,4), COP = round_up(cout,8), zero padded; scale/shift unused:
+                            wgt  = expand    [P][CINP x 2 (input-channel major) | BN scale 2 | BN shift 2],
+                            wgt2 = depthwise [P][9 taps (ky,kx) x 2 | BN scale 2 | BN shift 2],
+                            b1   = project W[2P][COP] (expanded-channel major), b2 = project BN scale[COP] ++ shift[COP].
+                            Built for (CINP/4,COP) in {(4,16),(4,24),(6,24),(6,32),(6,40),(8,32),(8,40),(8,48)} */
 } yr_op_kind;
 
 /* One fused operation.  Weight-like fields are float offsets into the weight

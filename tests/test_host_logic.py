@@ -43,8 +43,11 @@ def test_plan_structure_and_accounting():
     assert widths['td1_conv'] == 216 and widths['td2_conv'] == 424 and widths['td3_conv'] == 248
     assert widths['bu2_conv'] == 203 and widths['bu1_conv'] == 331
     assert [(b.h, b.w, b.c) for b in p.output_bufs] == [(13, 13, 75), (26, 26, 75), (52, 52, 75)]
-    fused = _model().plan
-    assert any(o.kind == rt.OP_MBCONV for o in fused.ops) and fused.ops[0].kind == rt.OP_STEMBLOCK
+    fm = _model()
+    fused = fm.plan
+    from yoloret_amd.weights import synthetic_weights
+    assert np.isfinite(fused.build_blob(synthetic_weights(fm, 1, 'survey'))).all()   # every fused packing runs
+    assert sum(o.kind == rt.OP_MBLANE for o in fused.ops) == 5 and fused.ops[0].kind == rt.OP_STEMBLOCK
     assert abs(fused.algorithmic_bytes_per_image() - p.algorithmic_bytes_per_image()) < 1  # accounting is fusion-invariant
     assert fused.total_macs() == p.total_macs()
     assert fused.arena_elems_per_image < p.arena_elems_per_image

@@ -185,7 +185,7 @@ class Plan:
 
         def elems_of(op):
             elems = 0
-            if op.kind in (rt.OP_MBCONV, rt.OP_STEMBLOCK):
+            if op.kind in (rt.OP_MBCONV, rt.OP_STEMBLOCK, rt.OP_MBLANE):
                 # the accounting stays conv-granular (the figure everyone computes from): a fused
                 # block is charged what its three convolutions would move unfused
                 return sum(elems_of(f) for f in op.fused)
@@ -234,7 +234,9 @@ FUSE_MAX_CIN = int(os.environ.get('YOLORET_FUSE_MAX_CIN', '32'))
 FUSE_MIN_PIXELS = int(os.environ.get('YOLORET_FUSE_MIN_PIXELS', '1600'))  # output H*W of the block
 FUSE_NO_EXPAND = os.environ.get('YOLORET_FUSE_NO_EXPAND', '0') != '0'    # also fuse DW+project blocks without expand
 FUSE_STEM = os.environ.get('YOLORET_FUSE_STEM', '1') != '0'              # stem + first (expand-free) block in one kernel
-STEMBLOCK_WIDTHS = {(12, 16), (16, 16), (16, 24), (20, 24), (24, 16), (24, 24)}  # (C1p/2, round_up(cout,8)) built in stemblock.hip
+FUSE_LANE = os.environ.get('YOLORET_FUSE_LANE', '1') != '0'              # narrow fused blocks use mblane.hip instead of mbconv.hip
+MBLANE_WIDTHS = {(4, 16), (4, 24), (6, 24), (6, 32), (6, 40), (8, 32), (8, 40), (8, 48)}  # (CINP/4, round_up(cout,8)) built in mblane.hip
+STEMBLOCK_WIDTHS ={(12, 16), (16, 16), (16, 24), (20, 24), (24, 16), (24, 24)}  # (C1p/2, round_up(cout,8)) built in stemblock.hip
 
 
 def fuse_inverted_residuals(ops, output_buf_ids):
@@ -334,6 +336,38 @@ def fuse_inverted_residuals(ops, output_buf_ids):
                 o[:n] = fn(wd)[:n]
                 return o
             return f
+        cinp, cop = round_up(block_in.c, 4), round_up(cout, 8)
+        if FUSE_LANE and exp is not None and (cinp // 4, cop) in MBLANE_WIDTHS and proj.out.ld % 2 == 0:
+            # lane-per-pixel formulation (mblane.hip): everything packed per expanded-channel pair
+            m.kind, m.name = rt.OP_MBLANE, m.name.replace('_mbconv', '_mblane')
+            npair = round_up((cexp + 1) // 2, 8)
+            e2 = 2 * npair
+
+            def pairs(rows, scale, shift, e2=e2, cexp=cexp):
+                """rows [K][>=cexp] + BN [>=cexp]  ->  [P][K x 2 | scale 2 | shift 2]"""
+                full = np.zeros((rows.shape[0] + 2, e2), np.float32)
+                full[:-2, :cexp], full[-2, :cexp], full[-1, :cexp] = rows[:, :cexp], scale[:cexp], shift[:cexp]
+                return np.ascontiguousarray(full.reshape(-1, e2 // 2, 2).transpose(1, 0, 2)).reshape(e2 // 2, -1)
+            ep, dwp, pp_ = exp.params, dw.params, proj.params
+
+            def expand_w(wd, ep=ep, cinp=cinp, pairs=pairs):
+                wt = ep['wgt'][1](wd)                      # pointwise layout Wt[cexp][kp]
+                rows = np.zeros((cinp, wt.shape[0]), np.float32)
+                rows[:wt.shape[1]] = wt.T[:cinp]
+                return pairs(rows, ep['scale'][1](wd), ep['shift'][1](wd))
+
+            def proj_w(wd, pp_=pp_, e2=e2, cop=cop, cout=cout, cexp=cexp):
+                o = np.zeros((e2, cop), np.float32)
+                o[:cexp, :cout] = pp_['wgt'][1](wd)[:, :cexp].T
+                return o
+            m.params['wgt'] = ((npair, cinp * 2 + 4), expand_w)
+            m.params['wgt2'] = ((npair, 22), lambda wd, dwp=dwp, pairs=pairs: pairs(dwp['wgt'][1](wd), dwp['scale'][1](wd), dwp['shift'][1](wd)))
+            m.params['b1'] = ((e2, cop), proj_w)
+            m.params['b2'] = ((2 * cop,), lambda wd, pp_=pp_, cout=cout, cop=cop: np.concatenate(
+                [padded(pp_['scale'][1], cout, cop)(wd), padded(pp_['shift'][1], cout, cop)(wd)]))
+            out.append(m)
+            i = j + 2
+            continue
         if exp is not None:
             m.params['wgt'] = exp.params['wgt']
             m.params['scale'] = ((lde,), padded(exp.params['scale'][1], cexp, lde))

@@ -35,6 +35,7 @@ static int dispatch(const yr_op& op, int batch, hipStream_t s) {
         case YR_OP_GATHER: return yr_launch_gather(op, batch, s);
         case YR_OP_MBCONV: return yr_launch_mbconv(op, batch, s);
         case YR_OP_STEMBLOCK: return yr_launch_stemblock(op, batch, s);
+        case YR_OP_MBLANE: return yr_launch_mblane(op, batch, s);
         default: yr_set_error("unknown op kind %d", op.kind); return YR_ERR_ARG;
     }
 }

@@ -17,9 +17,9 @@ YR_MAX_SRC = 4
 ACT = {'none': 0, None: 0, 'relu6': 1, 'swish': 2, 'sigmoid': 3, 'leaky': 4}
 XFORM = {'identity': 0, 'up2': 1, 'maxpool2': 2, 'maxpool4': 3}
 OP_STEM, OP_POINTWISE, OP_DEPTHWISE, OP_SE_MEAN, OP_SE_FC, OP_WSUM, OP_GATHER, OP_MBCONV = 1, 2, 3, 4, 5, 6, 7, 8
-OP_STEMBLOCK = 9
+OP_STEMBLOCK, OP_MBLANE = 9, 10
 OP_NAMES = {1: 'stem', 2: 'pointwise', 3: 'depthwise', 4: 'se_mean', 5: 'se_fc', 6: 'wsum', 7: 'gather', 8: 'mbconv',
-            9: 'stemblock'}
+            9: 'stemblock', 10: 'mblane'}
 
 
 class YrSrc(ctypes.Structure):
