@@ -79,7 +79,7 @@ typedef enum {
                             wgt  = expand    [P][CINP x 2 (input-channel major) | BN scale 2 | BN shift 2],
                             wgt2 = depthwise [P][9 taps (ky,kx) x 2 | BN scale 2 | BN shift 2],
                             b1   = project W[2P][COP] (expanded-channel major), b2 = project BN scale[COP] ++ shift[COP].
-                            Built for (CINP/4,COP) in {(4,16),(4,24),(6,24),(6,32),(6,40),(8,32),(8,40),(8,48)} */
+                            Built for (CINP/4,COP) in {(4,16),(4,24),(6,24),(6,32),(6,40),(6,48),(8,32),(8,40),(8,48)} */
 } yr_op_kind;
 
 /* One fused operation.  Weight-like fields are float offsets into the weight

@@ -22,6 +22,8 @@ CASES = [
     (15, 17, 32, 192, 40, 1, False, 'swish'),    # SE-free MBConv flavour
     (8, 8, 16, 100, 20, 1, False, 'relu6'),      # expanded width not a multiple of 16, cout not a multiple of 4
     (21, 9, 14, 50, 14, 1, True, 'relu6'),       # cin / cout with pad lanes (NaN-filled by to_dev)
+    (52, 52, 24, 144, 48, 2, False, 'relu6'),    # block_6: wide projection (second row loaded after the first)
+    (20, 20, 32, 192, 48, 1, False, 'relu6'),    # widest built shape
 ]
 
 

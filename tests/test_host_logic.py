@@ -47,7 +47,7 @@ def test_plan_structure_and_accounting():
     fused = fm.plan
     from yoloret_amd.weights import synthetic_weights
     assert np.isfinite(fused.build_blob(synthetic_weights(fm, 1, 'survey'))).all()   # every fused packing runs
-    assert sum(o.kind == rt.OP_MBLANE for o in fused.ops) == 5 and fused.ops[0].kind == rt.OP_STEMBLOCK
+    assert sum(o.kind == rt.OP_MBLANE for o in fused.ops) == 6 and fused.ops[0].kind == rt.OP_STEMBLOCK  # block_1..6
     assert abs(fused.algorithmic_bytes_per_image() - p.algorithmic_bytes_per_image()) < 1  # accounting is fusion-invariant
     assert fused.total_macs() == p.total_macs()
     assert fused.arena_elems_per_image < p.arena_elems_per_image

@@ -14,7 +14,7 @@ SOURCES = ['runtime.hip', 'pointwise.hip', 'depthwise.hip', 'stem.hip', 'element
 # -ffp-contract=off: decode/NMS must match the oracle's IEEE operation order bit for bit;
 # every intended fused multiply-add in the kernels is an explicit fmaf / MFMA.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math',
-         '-Wall', '-Wno-unused-function']
+         '-Wall', '-Wno-unused-function'] + os.environ.get('YOLORET_HIPCC_FLAGS', '').split()  # e.g. -DPW_BK=64 (experiments)
 
 
 def _stale():

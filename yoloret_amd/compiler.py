@@ -235,7 +235,8 @@ FUSE_MIN_PIXELS = int(os.environ.get('YOLORET_FUSE_MIN_PIXELS', '1600'))  # outp
 FUSE_NO_EXPAND = os.environ.get('YOLORET_FUSE_NO_EXPAND', '0') != '0'    # also fuse DW+project blocks without expand
 FUSE_STEM = os.environ.get('YOLORET_FUSE_STEM', '1') != '0'              # stem + first (expand-free) block in one kernel
 FUSE_LANE = os.environ.get('YOLORET_FUSE_LANE', '1') != '0'              # narrow fused blocks use mblane.hip instead of mbconv.hip
-MBLANE_WIDTHS = {(4, 16), (4, 24), (6, 24), (6, 32), (6, 40), (8, 32), (8, 40), (8, 48)}  # (CINP/4, round_up(cout,8)) built in mblane.hip
+FUSE_LANE_MIN_PIXELS = int(os.environ.get('YOLORET_FUSE_LANE_MIN_PIXELS', '600'))  # mblane still wins on 26x26 outputs (block_6)
+MBLANE_WIDTHS = {(4, 16), (4, 24), (6, 24), (6, 32), (6, 40), (6, 48), (8, 32), (8, 40), (8, 48)}  # (CINP/4, round_up(cout,8)) built in mblane.hip
 STEMBLOCK_WIDTHS ={(12, 16), (16, 16), (16, 24), (20, 24), (24, 16), (24, 24)}  # (C1p/2, round_up(cout,8)) built in stemblock.hip
 
 
@@ -255,6 +256,10 @@ def fuse_inverted_residuals(ops, output_buf_ids):
 
     def plain1(op):
         return len(op.srcs) == 1 and op.srcs[0].xform == 'identity' and op.gate is None
+
+    def lane_ok(exp, block_in, proj):  # the lane-per-pixel kernel (mblane.hip) is built for this block shape
+        return (FUSE_LANE and exp is not None and proj.out.ld % 2 == 0
+                and (round_up(block_in.c, 4) // 4, round_up(proj.cout, 8)) in MBLANE_WIDTHS)
 
     def pad_to(fn, n, ld):
         def f(wd):
@@ -312,10 +317,11 @@ def fuse_inverted_residuals(ops, output_buf_ids):
                 and d.srcs[0].buf.ld == round_up(d.cin, 4) and j + 1 < len(ops)):
             p = ops[j + 1]
             block_in = exp.srcs[0] if exp is not None else d.srcs[0]
+            lane = lane_ok(exp, block_in, p)
             if (p.kind == rt.OP_POINTWISE and plain1(p) and p.srcs[0].buf is d.out and p.act == 'none'
                     and 'scale' in p.params and p.cout <= 224 and block_in.buf.ld % 4 == 0
                     and (exp is not None or FUSE_NO_EXPAND) and block_in.c <= FUSE_MAX_CIN
-                    and p.h * p.w >= FUSE_MIN_PIXELS
+                    and p.h * p.w >= (FUSE_LANE_MIN_PIXELS if lane else FUSE_MIN_PIXELS)
                     and (p.res is None or (p.res is block_in.buf and d.stride == 1 and p.cout == block_in.c))):
                 dw, proj = d, p
         if proj is None:
@@ -337,7 +343,7 @@ def fuse_inverted_residuals(ops, output_buf_ids):
                 return o
             return f
         cinp, cop = round_up(block_in.c, 4), round_up(cout, 8)
-        if FUSE_LANE and exp is not None and (cinp // 4, cop) in MBLANE_WIDTHS and proj.out.ld % 2 == 0:
+        if lane_ok(exp, block_in, proj):
             # lane-per-pixel formulation (mblane.hip): everything packed per expanded-channel pair
             m.kind, m.name = rt.OP_MBLANE, m.name.replace('_mbconv', '_mblane')
             npair = round_up((cexp + 1) // 2, 8)

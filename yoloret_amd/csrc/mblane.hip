@@ -96,36 +96,43 @@ __device__ __forceinline__ void ml_dw_project(const v2f* e, kptr w, kptr pw, v2f
     v16f wa = *(k16ptr)w;            // taps 0..7
     v4f wb = *(k4ptr)(w + 16);       // tap 8, BN scale
     v2f wc = *(k2ptr)(w + 20);       // BN shift
-    constexpr int NP8 = COP / 4;     // 2*COP floats of projection weights = NP8 groups of 8
-    v8f pv[NP8];
+#define ML_PIN_EV "+v"(ev[0]), "+v"(ev[1]), "+v"(ev[2]), "+v"(ev[3]), "+v"(ev[4]), "+v"(ev[5]), "+v"(ev[6]), "+v"(ev[7]), "+v"(ev[8])
+    constexpr int NR = COP / 8;      // one projection row = COP floats = NR groups of 8
+    constexpr bool BOTH = COP <= 24; // both rows fit the SGPR budget next to the depthwise weights (22 + 2*COP <= 70)
+    v8f r0[NR], r1[NR];
 #pragma unroll
-    for (int i = 0; i < NP8; ++i) pv[i] = *(k8ptr)(pw + 8 * i);
-    if constexpr (NP8 == 4)
-        asm volatile("" : "+v"(ev[0]), "+v"(ev[1]), "+v"(ev[2]), "+v"(ev[3]), "+v"(ev[4]), "+v"(ev[5]), "+v"(ev[6]), "+v"(ev[7]), "+v"(ev[8]),
-                     "+s"(wa), "+s"(wb), "+s"(wc), "+s"(pv[0]), "+s"(pv[1]), "+s"(pv[2]), "+s"(pv[3]));
-    else if constexpr (NP8 == 6)
-        asm volatile("" : "+v"(ev[0]), "+v"(ev[1]), "+v"(ev[2]), "+v"(ev[3]), "+v"(ev[4]), "+v"(ev[5]), "+v"(ev[6]), "+v"(ev[7]), "+v"(ev[8]),
-                     "+s"(wa), "+s"(wb), "+s"(wc), "+s"(pv[0]), "+s"(pv[1]), "+s"(pv[2]), "+s"(pv[3]), "+s"(pv[4]), "+s"(pv[5]));
-    else  // wider projections: SGPR budget does not hold every row at once; pin the LDS reads and the depthwise weights only
-        asm volatile("" : "+v"(ev[0]), "+v"(ev[1]), "+v"(ev[2]), "+v"(ev[3]), "+v"(ev[4]), "+v"(ev[5]), "+v"(ev[6]), "+v"(ev[7]), "+v"(ev[8]),
-                     "+s"(wa), "+s"(wb), "+s"(wc));
+    for (int i = 0; i < NR; ++i) r0[i] = *(k8ptr)(pw + 8 * i);
+    if constexpr (BOTH) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) r1[i] = *(k8ptr)(pw + COP + 8 * i);
+    }
+    if constexpr (NR == 2) asm volatile("" : ML_PIN_EV, "+s"(wa), "+s"(wb), "+s"(wc), "+s"(r0[0]), "+s"(r0[1]), "+s"(r1[0]), "+s"(r1[1]));
+    else if constexpr (NR == 3) asm volatile("" : ML_PIN_EV, "+s"(wa), "+s"(wb), "+s"(wc), "+s"(r0[0]), "+s"(r0[1]), "+s"(r0[2]), "+s"(r1[0]), "+s"(r1[1]), "+s"(r1[2]));
+    else if constexpr (NR == 4) asm volatile("" : ML_PIN_EV, "+s"(wa), "+s"(wb), "+s"(wc), "+s"(r0[0]), "+s"(r0[1]), "+s"(r0[2]), "+s"(r0[3]));
+    else if constexpr (NR == 5) asm volatile("" : ML_PIN_EV, "+s"(wa), "+s"(wb), "+s"(wc), "+s"(r0[0]), "+s"(r0[1]), "+s"(r0[2]), "+s"(r0[3]), "+s"(r0[4]));
+    else asm volatile("" : ML_PIN_EV, "+s"(wa), "+s"(wb), "+s"(wc), "+s"(r0[0]), "+s"(r0[1]), "+s"(r0[2]), "+s"(r0[3]), "+s"(r0[4]), "+s"(r0[5]));
+#undef ML_PIN_EV
     v2f d = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 8; ++k) d = ml_fma(ev[k], (v2f){wa[2 * k], wa[2 * k + 1]}, d);
     d = ml_fma(ev[8], (v2f){wb[0], wb[1]}, d);
     d = ml_act<RELU6>(ml_fma(d, (v2f){wb[2], wb[3]}, wc), act);
 #pragma unroll
-    for (int n = 0; n < COP / 2; ++n) o[n] = ml_fma((v2f){d.x, d.x}, (v2f){pv[n / 4][(2 * n) % 8], pv[n / 4][(2 * n) % 8 + 1]}, o[n]);
+    for (int n = 0; n < COP / 2; ++n) o[n] = ml_fma((v2f){d.x, d.x}, (v2f){r0[n / 4][(2 * n) % 8], r0[n / 4][(2 * n) % 8 + 1]}, o[n]);
+    if constexpr (!BOTH) {  // wide projections: the second row is loaded (one burst, one wait) once the first is consumed
 #pragma unroll
-    for (int n = 0; n < COP / 2; ++n) {
-        const int i = COP + 2 * n;
-        o[n] = ml_fma((v2f){d.y, d.y}, (v2f){pv[i / 8][i % 8], pv[i / 8][i % 8 + 1]}, o[n]);
+        for (int i = 0; i < NR; ++i) r1[i] = *(k8ptr)(pw + COP + 8 * i);
+        if constexpr (NR == 4) asm volatile("" : "+s"(r1[0]), "+s"(r1[1]), "+s"(r1[2]), "+s"(r1[3]));
+        else if constexpr (NR == 5) asm volatile("" : "+s"(r1[0]), "+s"(r1[1]), "+s"(r1[2]), "+s"(r1[3]), "+s"(r1[4]));
+        else asm volatile("" : "+s"(r1[0]), "+s"(r1[1]), "+s"(r1[2]), "+s"(r1[3]), "+s"(r1[4]), "+s"(r1[5]));
     }
+#pragma unroll
+    for (int n = 0; n < COP / 2; ++n) o[n] = ml_fma((v2f){d.y, d.y}, (v2f){r1[n / 4][(2 * n) % 8], r1[n / 4][(2 * n) % 8 + 1]}, o[n]);
 }
 
 // ------------------------------------------------------------------------------------------ stride 1
 template <int CQ, int COP, bool RELU6>
-__global__ __launch_bounds__(256, 4) void mblane_s1_kernel(MlArgs a) {
+__global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s1_kernel(MlArgs a) {
     constexpr int T = 14, WE = 8 * CQ + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     v2f* Es = reinterpret_cast<v2f*>(lds);  // [2][ML_CH][256]
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(256, 4) void mblane_s1_kernel(MlArgs a) {
 
 // ------------------------------------------------------------------------------------------ stride 2
 template <int CQ, int COP, bool RELU6>
-__global__ __launch_bounds__(256, 4) void mblane_s2_kernel(MlArgs a) {
+__global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s2_kernel(MlArgs a) {
     constexpr int TH = 7, TW = 8, IH = 2 * TH + 1, IW = 2 * TW + 1, WE = 8 * CQ + 4;
     static_assert(IH * IW <= 256 && COP % 8 == 0, "tile / width assumptions");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -285,6 +292,7 @@ static int launch_ml_widths(const MlArgs& a, int cq, int cop, int batch, hipStre
         case 640: return launch_ml<S, 6, 40>(a, batch, s);
         case 832: return launch_ml<S, 8, 32>(a, batch, s);
         case 840: return launch_ml<S, 8, 40>(a, batch, s);
+        case 648: return launch_ml<S, 6, 48>(a, batch, s);
         case 848: return launch_ml<S, 8, 48>(a, batch, s);
         default: yr_set_error("mblane: widths Cin=%d Cout=%d unsupported", a.Cin, a.Cout); return YR_ERR_ARG;
     }

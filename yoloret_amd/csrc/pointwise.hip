@@ -19,8 +19,12 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define PW_BK 16
-#define PW_LDS_LD 20  // padded row stride (floats) of the staged tiles
+#ifndef PW_BK
+#define PW_BK 16                 // k depth staged per barrier pair (multiple of 16; measured: 32 is 6 % and 64 is 13 % slower end to end)
+#endif
+#define PW_KQ (PW_BK / 4)        // float4 quads per staged row
+#define PW_RPP (256 / PW_KQ)     // rows loaded per pass of the 256 threads
+#define PW_LDS_LD (PW_BK + 4)    // padded row stride (floats): an odd number of 16-byte slots
 
 struct PwArgs {
     DSrcSet S;
@@ -43,8 +47,8 @@ template <int PT, int CT, int WM, int WN, bool SIMPLE>
 __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     constexpr int BM = 16 * PT * WM;
     constexpr int BN = 16 * CT * WN;
-    constexpr int A_PASSES = BM / 64;
-    constexpr int B_PASSES = (BN + 63) / 64;
+    constexpr int A_PASSES = BM / PW_RPP;
+    constexpr int B_PASSES = (BN + PW_RPP - 1) / PW_RPP;
     __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * PW_LDS_LD];
     float* As = lds;                   // [BM][PW_LDS_LD] activations
     float* Bs = lds + BM * PW_LDS_LD;  // [BN][PW_LDS_LD] weights
@@ -62,14 +66,14 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     const int kp = a.S.kp;
 
     // loader mapping: quad kq of row lr (+64 per pass)
-    const int lr = tid >> 2, kq = tid & 3;
+    const int lr = tid / PW_KQ, kq = tid % PW_KQ;
     bool pv[A_PASSES];
     const float* arow[A_PASSES];               // SIMPLE: the pixel's row
     const float* grow[A_PASSES];               // SE gate row of the pixel's image (or null)
     const float* srow[A_PASSES][YR_MAX_SRC];   // generic: per-source row pointer of the pixel (xform folded in)
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
-        const int m = m0 + lr + p * 64;
+        const int m = m0 + lr + p * PW_RPP;
         pv[p] = m < a.M;
         const int mm = pv[p] ? m : 0;
         const int hw = a.H * a.W;
@@ -96,8 +100,8 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     bool bvld[B_PASSES];
 #pragma unroll
     for (int p = 0; p < B_PASSES; ++p) {
-        const int n = n0 + lr + p * 64;
-        bvld[p] = (lr + p * 64 < BN) && n < a.N;
+        const int n = n0 + lr + p * PW_RPP;
+        bvld[p] = (lr + p * PW_RPP < BN) && n < a.N;
         brow[p] = a.wt + (size_t)(bvld[p] ? n : 0) * kp;
     }
 
@@ -164,28 +168,32 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
         // ---- registers -> LDS
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p)
-            *reinterpret_cast<float4*>(As + (lr + p * 64) * PW_LDS_LD + kq * 4) = ra[p];
+            *reinterpret_cast<float4*>(As + (lr + p * PW_RPP) * PW_LDS_LD + kq * 4) = ra[p];
 #pragma unroll
         for (int p = 0; p < B_PASSES; ++p)
-            if (lr + p * 64 < BN) *reinterpret_cast<float4*>(Bs + (lr + p * 64) * PW_LDS_LD + kq * 4) = rb[p];
+            if (lr + p * PW_RPP < BN) *reinterpret_cast<float4*>(Bs + (lr + p * PW_RPP) * PW_LDS_LD + kq * 4) = rb[p];
         __syncthreads();
         // ---- next chunk's global loads fly while this chunk's MFMAs run
         if (k0 + PW_BK < kp) fetch(k0 + PW_BK);
-        // ---- fragments + MFMA
-        f32x4 wf[CT], xf[PT];
+        // ---- fragments + MFMA, 16 k per sub-step (sub-steps wholly beyond kp are skipped: uniform)
 #pragma unroll
-        for (int c = 0; c < CT; ++c)
-            wf[c] = *reinterpret_cast<const f32x4*>(Bs + ((wn * CT + c) * 16 + li) * PW_LDS_LD + g * 4);
-#pragma unroll
-        for (int p = 0; p < PT; ++p)
-            xf[p] = *reinterpret_cast<const f32x4*>(As + ((wm * PT + p) * 16 + li) * PW_LDS_LD + g * 4);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int kk = 0; kk < PW_BK; kk += 16) {
+            if (k0 + kk >= kp) break;
+            f32x4 wf[CT], xf[PT];
 #pragma unroll
             for (int c = 0; c < CT; ++c)
+                wf[c] = *reinterpret_cast<const f32x4*>(Bs + ((wn * CT + c) * 16 + li) * PW_LDS_LD + kk + g * 4);
 #pragma unroll
-                for (int p = 0; p < PT; ++p)
-                    acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][s], xf[p][s], acc[c][p], 0, 0, 0);
+            for (int p = 0; p < PT; ++p)
+                xf[p] = *reinterpret_cast<const f32x4*>(As + ((wm * PT + p) * 16 + li) * PW_LDS_LD + kk + g * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int p = 0; p < PT; ++p)
+                        acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][s], xf[p][s], acc[c][p], 0, 0, 0);
+        }
         __syncthreads();
     }
 
