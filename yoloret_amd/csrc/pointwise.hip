@@ -105,14 +105,19 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
         brow[p] = a.wt + (size_t)(bvld[p] ? n : 0) * kp;
     }
 
-    float4 ra[A_PASSES], rb[B_PASSES];
+    // fetch() only ISSUES loads (raw values + the pixel's gate quad); masking and the gate multiply happen in
+    // stage(), one iteration later, right before the LDS store.  Touching the loaded registers inside fetch()
+    // would put the s_waitcnt - a full L2/HBM round trip - in front of the MFMAs of every k chunk.
+    float4 ra[A_PASSES], rg[A_PASSES], rb[B_PASSES];
+    int cv[A_PASSES];  // valid channels in the fetched quad (<= 0: none)
     auto fetch = [&](int k0) {
         const int k = k0 + kq * 4;
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 gt = make_float4(1.f, 1.f, 1.f, 1.f);
+            int cvalid = 0;
             if (pv[p] && k < kp) {
-                int cvalid;
                 if (SIMPLE) {
                     v = *reinterpret_cast<const float4*>(arow[p] + k);
                     cvalid = a.S.s[0].c - k;
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
                         if (si == i) { rp = srow[p][i]; kb = a.S.s[i].kbase; cc = a.S.s[i].c; xf = a.S.s[i].xform; sw = a.S.s[i].w; sld = a.S.s[i].ld; }
                     rp += k - kb;
                     v = *reinterpret_cast<const float4*>(rp);
-                    if (xf >= YR_X_MAXPOOL2) {
+                    if (xf >= YR_X_MAXPOOL2) {  // pooled sources are reduced here (the only path that waits in fetch)
                         const int pool = xf == YR_X_MAXPOOL2 ? 2 : 4;
                         for (int dy = 0; dy < pool; ++dy)
                             for (int dx = 0; dx < pool; ++dx)
@@ -137,16 +142,9 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
                     }
                     cvalid = cc - (k - kb);
                 }
-                if (cvalid < 4) { v.w = 0.f; if (cvalid < 3) v.z = 0.f; if (cvalid < 2) v.y = 0.f; }
-                if (grow[p] != nullptr) {
-                    const float4 gt = *reinterpret_cast<const float4*>(grow[p] + k);
-                    v.x *= gt.x;  // lanes beyond the channel count stay exactly 0 (gate padding may be anything)
-                    v.y = cvalid > 1 ? v.y * gt.y : 0.f;
-                    v.z = cvalid > 2 ? v.z * gt.z : 0.f;
-                    v.w = cvalid > 3 ? v.w * gt.w : 0.f;
-                }
+                if (grow[p] != nullptr) gt = *reinterpret_cast<const float4*>(grow[p] + k);
             }
-            ra[p] = v;
+            ra[p] = v; rg[p] = gt; cv[p] = cvalid;
         }
 #pragma unroll
         for (int p = 0; p < B_PASSES; ++p) {
@@ -154,6 +152,17 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
             if (bvld[p] && k < kp) v = *reinterpret_cast<const float4*>(brow[p] + k);
             rb[p] = v;
         }
+    };
+    // the fetched quad with pad lanes zeroed (the source's pad lanes and the gate's may hold anything) and gated
+    auto staged = [&](int p) {
+        float4 v = ra[p];
+        const float4 gt = rg[p];
+        const int cvalid = cv[p];
+        v.x = cvalid > 0 ? v.x * gt.x : 0.f;
+        v.y = cvalid > 1 ? v.y * gt.y : 0.f;
+        v.z = cvalid > 2 ? v.z * gt.z : 0.f;
+        v.w = cvalid > 3 ? v.w * gt.w : 0.f;
+        return v;
     };
 
     f32x4 acc[CT][PT];
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
         // ---- registers -> LDS
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p)
-            *reinterpret_cast<float4*>(As + (lr + p * PW_RPP) * PW_LDS_LD + kq * 4) = ra[p];
+            *reinterpret_cast<float4*>(As + (lr + p * PW_RPP) * PW_LDS_LD + kq * 4) = staged(p);
 #pragma unroll
         for (int p = 0; p < B_PASSES; ++p)
             if (lr + p * PW_RPP < BN) *reinterpret_cast<float4*>(Bs + (lr + p * PW_RPP) * PW_LDS_LD + kq * 4) = rb[p];
