@@ -42,7 +42,7 @@ def _src_dims(h, w, xf):
     return {'identity': (h, w), 'up2': (h // 2, w // 2), 'maxpool2': (h * 2, w * 2), 'maxpool4': (h * 4, w * 4)}[xf]
 
 
-def run_pointwise(dev, rng, b, h, w, segs, cout, act='none', bn=True, residual=False, gate=False, out_ld=None):
+def run_pointwise(dev, rng, b, h, w, segs, cout, act='none', bn=True, residual=False, gate=False, out_ld=None, cfg=0):
     rt = _rt()
     srcs_np, srcs_dev = [], []
     for c, xf in segs:
@@ -95,9 +95,12 @@ def run_pointwise(dev, rng, b, h, w, segs, cout, act='none', bn=True, residual=F
         keep.append(g)
         op.gate, op.gate_ld = g.data_ptr(), g.shape[3]
     op.out, op.out_ld = out.data_ptr(), out_ld
+    op.k = cfg            # 0: heuristic tile shape; 1..yr_pointwise_num_cfgs(): forced (15..: the LDS-free direct kernel)
     rt.run_op(op, b)
     torch.cuda.synchronize()
-    return assert_close(from_dev(out, cout), ref, TOL, 'pointwise %s' % (segs,))
+    got = from_dev(out, cout)
+    assert_close(got, ref, TOL, 'pointwise %s cfg %d' % (segs, cfg))
+    return got
 
 
 PW_CASES = [
@@ -125,6 +128,19 @@ def test_pointwise(dev, case):
     h, w, segs, cout, act, bn, residual, gate, dense = case
     rng = np.random.default_rng(zlib.crc32(str(case).encode()))
     run_pointwise(dev, rng, 3, h, w, segs, cout, act, bn, residual, gate, out_ld=cout if dense else None)
+
+
+@pytest.mark.parametrize('case', PW_CASES, ids=[str(i) for i in range(len(PW_CASES))])
+def test_pointwise_direct_kernel(dev, case):
+    """The LDS-free kernel (forced tile shapes 15..29) == oracle, and bit-identical to the LDS-staged kernel:
+    both run the same MFMA sequence per output, which is what lets yr_autotune swap shapes freely."""
+    h, w, segs, cout, act, bn, residual, gate, dense = case
+    outs = []
+    for cfg in (0, 15, 16, 19, 22, 24, 27, 29):
+        rng = np.random.default_rng(zlib.crc32(str(case).encode()))
+        outs.append(run_pointwise(dev, rng, 3, h, w, segs, cout, act, bn, residual, gate, out_ld=cout if dense else None, cfg=cfg))
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
 
 
 def test_pointwise_large_m(dev):

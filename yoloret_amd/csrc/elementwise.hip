@@ -99,6 +99,8 @@ __global__ __launch_bounds__(SE_FC_THREADS) void se_fc_kernel(FcArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int c = tid; c < a.ldc; c += SE_FC_THREADS) mean[c] = (c < a.C) ? a.mean[(size_t)b * a.ld_mean + c] : 0.f;
     __syncthreads();
+    // the kernel is pure latency (64 workgroups, weights from L2): keep several rows' loads in flight per wave
+#pragma unroll 4
     for (int j = wave; j < a.R; j += SE_FC_THREADS / 64) {
         const float* wr = a.w1t + (size_t)j * a.ldc;
         float s = 0.f;
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(SE_FC_THREADS) void se_fc_kernel(FcArgs a) {
         const int jg = tid / cp, c = c0 + (js > 1 ? tid % cp : tid);
         float s = 0.f;
         if (jg < js && c < a.C) {
-#pragma unroll 4
+#pragma unroll 16
             for (int j = jg; j < a.R; j += js) s = __builtin_fmaf(hid[j], a.w2[(size_t)j * a.ldc + c], s);
         }
         part[tid] = s;

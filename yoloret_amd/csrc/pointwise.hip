@@ -22,6 +22,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef PW_BK
 #define PW_BK 16                 // k depth staged per barrier pair (multiple of 16; measured: 32 is 6 % and 64 is 13 % slower end to end)
 #endif
+#ifndef PW_PF2_MAX_TILES
+#define PW_PF2_MAX_TILES 0       // tiles (PT*CT) per wave up to which TWO k chunks are prefetched (measured: never pays here)
+#endif
 #define PW_KQ (PW_BK / 4)        // float4 quads per staged row
 #define PW_RPP (256 / PW_KQ)     // rows loaded per pass of the 256 threads
 #define PW_LDS_LD (PW_BK + 4)    // padded row stride (floats): an odd number of 16-byte slots
@@ -108,9 +111,11 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     // fetch() only ISSUES loads (raw values + the pixel's gate quad); masking and the gate multiply happen in
     // stage(), one iteration later, right before the LDS store.  Touching the loaded registers inside fetch()
     // would put the s_waitcnt - a full L2/HBM round trip - in front of the MFMAs of every k chunk.
-    float4 ra[A_PASSES], rg[A_PASSES], rb[B_PASSES];
-    int cv[A_PASSES];  // valid channels in the fetched quad (<= 0: none)
-    auto fetch = [&](int k0) {
+    struct Regs {
+        float4 ra[A_PASSES], rg[A_PASSES], rb[B_PASSES];
+        int cv[A_PASSES];  // valid channels in the fetched quad (<= 0: none)
+    };
+    auto fetch = [&](int k0, Regs& R) {
         const int k = k0 + kq * 4;
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p) {
@@ -144,20 +149,20 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
                 }
                 if (grow[p] != nullptr) gt = *reinterpret_cast<const float4*>(grow[p] + k);
             }
-            ra[p] = v; rg[p] = gt; cv[p] = cvalid;
+            R.ra[p] = v; R.rg[p] = gt; R.cv[p] = cvalid;
         }
 #pragma unroll
         for (int p = 0; p < B_PASSES; ++p) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (bvld[p] && k < kp) v = *reinterpret_cast<const float4*>(brow[p] + k);
-            rb[p] = v;
+            R.rb[p] = v;
         }
     };
     // the fetched quad with pad lanes zeroed (the source's pad lanes and the gate's may hold anything) and gated
-    auto staged = [&](int p) {
-        float4 v = ra[p];
-        const float4 gt = rg[p];
-        const int cvalid = cv[p];
+    auto staged = [&](const Regs& R, int p) {
+        float4 v = R.ra[p];
+        const float4 gt = R.rg[p];
+        const int cvalid = R.cv[p];
         v.x = cvalid > 0 ? v.x * gt.x : 0.f;
         v.y = cvalid > 1 ? v.y * gt.y : 0.f;
         v.z = cvalid > 2 ? v.z * gt.z : 0.f;
@@ -172,19 +177,21 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
         for (int p = 0; p < PT; ++p) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int g = lane >> 4, li = lane & 15;
-    fetch(0);
-    for (int k0 = 0; k0 < kp; k0 += PW_BK) {
-        // ---- registers -> LDS
+    // One k chunk: registers -> LDS, barrier, refill the register set with the chunk DEPTH ahead, fragments + MFMA,
+    // barrier.  Small tiles (<= 4 MFMA tiles per wave: <= 512 matrix cycles per chunk) keep two chunks of global
+    // loads in flight, larger ones one (their MFMA phase already covers an L2 round trip; the extra registers cost
+    // occupancy: measured).
+    constexpr int DEPTH = (PT * CT <= PW_PF2_MAX_TILES) ? 2 : 1;
+    auto step = [&](int k0, Regs& R) {
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p)
-            *reinterpret_cast<float4*>(As + (lr + p * PW_RPP) * PW_LDS_LD + kq * 4) = staged(p);
+            *reinterpret_cast<float4*>(As + (lr + p * PW_RPP) * PW_LDS_LD + kq * 4) = staged(R, p);
 #pragma unroll
         for (int p = 0; p < B_PASSES; ++p)
-            if (lr + p * PW_RPP < BN) *reinterpret_cast<float4*>(Bs + (lr + p * PW_RPP) * PW_LDS_LD + kq * 4) = rb[p];
+            if (lr + p * PW_RPP < BN) *reinterpret_cast<float4*>(Bs + (lr + p * PW_RPP) * PW_LDS_LD + kq * 4) = R.rb[p];
         __syncthreads();
-        // ---- next chunk's global loads fly while this chunk's MFMAs run
-        if (k0 + PW_BK < kp) fetch(k0 + PW_BK);
-        // ---- fragments + MFMA, 16 k per sub-step (sub-steps wholly beyond kp are skipped: uniform)
+        if (k0 + DEPTH * PW_BK < kp) fetch(k0 + DEPTH * PW_BK, R);
+        // fragments + MFMA, 16 k per sub-step (sub-steps wholly beyond kp are skipped: uniform)
 #pragma unroll
         for (int kk = 0; kk < PW_BK; kk += 16) {
             if (k0 + kk >= kp) break;
@@ -204,6 +211,18 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
                         acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][s], xf[p][s], acc[c][p], 0, 0, 0);
         }
         __syncthreads();
+    };
+    Regs R0;
+    fetch(0, R0);
+    if constexpr (DEPTH == 2) {
+        Regs R1;
+        fetch(PW_BK, R1);  // beyond kp: zeros, never staged
+        for (int k0 = 0; k0 < kp; k0 += 2 * PW_BK) {
+            step(k0, R0);
+            if (k0 + PW_BK < kp) step(k0 + PW_BK, R1);
+        }
+    } else {
+        for (int k0 = 0; k0 < kp; k0 += PW_BK) step(k0, R0);
     }
 
     // ---- epilogue: BN scale/shift, activation, residual, store (4 consecutive couts per lane)
@@ -242,6 +261,218 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
             }
         }
     }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// Direct variant: no LDS, no barriers.  Every wave owns 16*PT pixels x 16*CT couts and loads BOTH MFMA
+// operands straight from global memory in the operand layout (lane l: row l&15, k quad l>>4 - one 64-byte
+// segment per row and instruction; measured on MI355X with tools/ldpat.hip: this map streams at the same
+// 6.4 TB/s from HBM as the 4-adjacent-lanes map, and > 5 TB/s from L2).  D register sets keep D k chunks of
+// loads in flight per wave; waves never wait for each other.  Weight fragments are re-read per wave from
+// L1/L2 (a layer's weights are <= 350 KB).  Same MFMA sequence per output as pw_kernel => bit-identical.
+// MODE 0: generic gather (upsample / maxpool / concat sources), 1: one identity source, 2: identity + SE gate.
+template <int PT, int CT, int D, int MODE>
+__global__ __launch_bounds__(256) void pwd_kernel(PwArgs a) {
+    constexpr int BM = 64 * PT, BN = 16 * CT;
+    constexpr bool SIMPLE = MODE != 0, GATE = MODE == 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const unsigned ntn = (a.N + BN - 1) / BN;
+    const unsigned L = yr_xcd_swizzle(blockIdx.x, gridDim.x);
+    const int m0 = (int)(L / ntn) * BM + wave * 16 * PT;
+    const int n0 = (int)(L % ntn) * BN;
+    const int kp = a.S.kp;
+    const int kl = g * 4;  // this lane's k offset inside a 16-deep chunk
+
+    bool pv[PT];
+    const float* arow[PT];
+    const float* grow[PT];
+    const float* srow[PT][YR_MAX_SRC];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int m = m0 + p * 16 + li;
+        pv[p] = m < a.M;
+        const int mm = pv[p] ? m : 0;
+        const int hw = a.H * a.W;
+        const int b = mm / hw;
+        grow[p] = GATE ? a.gate + (size_t)b * a.gate_ld : nullptr;
+        if (SIMPLE) {
+            arow[p] = a.S.s[0].ptr + (size_t)mm * a.S.s[0].ld;
+        } else {
+            arow[p] = nullptr;
+            const int rem = mm - b * hw;
+            const int y = rem / a.W, x = rem - y * a.W;
+#pragma unroll
+            for (int si = 0; si < YR_MAX_SRC; ++si) {
+                const DSrc& d = a.S.s[si];
+                int sy = y, sx = x;
+                if (d.xform == YR_X_UP2) { sy = y >> 1; sx = x >> 1; }
+                else if (d.xform == YR_X_MAXPOOL2) { sy = y * 2; sx = x * 2; }
+                else if (d.xform == YR_X_MAXPOOL4) { sy = y * 4; sx = x * 4; }
+                srow[p][si] = d.ptr + ((size_t)(b * d.h + sy) * d.w + sx) * d.ld;
+            }
+        }
+    }
+    const float* brow[CT];
+    bool bv[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int n = n0 + c * 16 + li;
+        bv[c] = n < a.N;
+        brow[c] = a.wt + (size_t)(bv[c] ? n : 0) * kp;
+    }
+
+    struct Frag {
+        float4 x[PT], w[CT];
+        float4 gt[GATE ? PT : 1];
+        int cv[PT];
+    };
+    auto load = [&](int k0, Frag& F) {  // issue only: nothing here may read a loaded register
+        const int k = k0 + kl;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int cvalid = 0;
+            if (pv[p] && k < kp) {
+                if (SIMPLE) {
+                    v = *reinterpret_cast<const float4*>(arow[p] + k);
+                    cvalid = a.S.s[0].c - k;
+                    if (GATE) F.gt[p] = *reinterpret_cast<const float4*>(grow[p] + k);
+                } else {
+                    int si = 0;
+#pragma unroll
+                    for (int i = 1; i < YR_MAX_SRC; ++i)
+                        if (k >= a.S.s[i].kbase) si = i;
+                    const float* rp = srow[p][0];
+                    int kb = a.S.s[0].kbase, cc = a.S.s[0].c, xf = a.S.s[0].xform, sw = a.S.s[0].w, sld = a.S.s[0].ld;
+#pragma unroll
+                    for (int i = 1; i < YR_MAX_SRC; ++i)
+                        if (si == i) { rp = srow[p][i]; kb = a.S.s[i].kbase; cc = a.S.s[i].c; xf = a.S.s[i].xform; sw = a.S.s[i].w; sld = a.S.s[i].ld; }
+                    rp += k - kb;
+                    v = *reinterpret_cast<const float4*>(rp);
+                    if (xf >= YR_X_MAXPOOL2) {  // pooled sources are reduced here (the only path that waits at issue)
+                        const int pool = xf == YR_X_MAXPOOL2 ? 2 : 4;
+                        for (int dy = 0; dy < pool; ++dy)
+                            for (int dx = 0; dx < pool; ++dx)
+                                v = yr_max4(v, *reinterpret_cast<const float4*>(rp + ((size_t)dy * sw + dx) * sld));
+                    }
+                    cvalid = cc - (k - kb);
+                }
+            } else if (GATE) {
+                F.gt[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            F.x[p] = v; F.cv[p] = cvalid;
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bv[c] && k < kp) v = *reinterpret_cast<const float4*>(brow[c] + k);
+            F.w[c] = v;
+        }
+    };
+
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int p = 0; p < PT; ++p) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool need_mask = GATE || (!SIMPLE) || (a.S.s[0].c & 3) != 0;  // uniform: most layers have whole quads only
+
+    auto use = [&](const Frag& F) {
+        float xf[PT][4];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            float4 v = F.x[p];
+            if (need_mask) {  // pad lanes of the source (and of the gate) may hold anything: force exact zeros
+                const int cvalid = F.cv[p];
+                const float4 gt = GATE ? F.gt[p] : make_float4(1.f, 1.f, 1.f, 1.f);
+                v.x = cvalid > 0 ? (GATE ? v.x * gt.x : v.x) : 0.f;
+                v.y = cvalid > 1 ? (GATE ? v.y * gt.y : v.y) : 0.f;
+                v.z = cvalid > 2 ? (GATE ? v.z * gt.z : v.z) : 0.f;
+                v.w = cvalid > 3 ? (GATE ? v.w * gt.w : v.w) : 0.f;
+            }
+            xf[p][0] = v.x; xf[p][1] = v.y; xf[p][2] = v.z; xf[p][3] = v.w;
+        }
+        const float* wq = reinterpret_cast<const float*>(&F.w[0]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int p = 0; p < PT; ++p)
+                    acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[c * 4 + s], xf[p][s], acc[c][p], 0, 0, 0);
+    };
+
+    Frag F[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) load(d * 16, F[d]);  // chunks beyond kp load nothing (zeros) and are never used
+    for (int k0 = 0; k0 < kp; k0 += 16 * D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int k = k0 + d * 16;
+            if (k < kp) {
+                use(F[d]);
+                load(k + 16 * D, F[d]);
+            }
+        }
+    }
+
+    // ---- epilogue: BN scale/shift, activation, residual, store (4 consecutive couts per lane)
+    const bool vec_out = (a.out_ld & 3) == 0;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int n = n0 + c * 16 + g * 4;
+        if (n >= a.N) continue;
+        float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < a.N) {
+                if (a.scale) sc[r] = a.scale[n + r];
+                if (a.shift) sh[r] = a.shift[n + r];
+            }
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int m = m0 + p * 16 + li;
+            if (m >= a.M) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = yr_apply_act(__builtin_fmaf(acc[c][p][r], sc[r], sh[r]), a.act);
+            if (a.res) {
+                const float* rp = a.res + (size_t)m * a.res_ld + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < a.N) v[r] += rp[r];
+            }
+            float* op = a.out + (size_t)m * a.out_ld + n;
+            if (vec_out && n + 3 < a.N) {
+                *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < a.N) op[r] = v[r];
+            }
+        }
+    }
+}
+
+template <int PT, int CT>
+static int launch_direct(const PwArgs& a, hipStream_t s) {
+    constexpr int BM = 64 * PT, BN = 16 * CT;
+    constexpr int D = PT * CT <= 2 ? 4 : (PT * CT <= 6 ? 3 : 2);
+    dim3 grid((unsigned)((a.M + BM - 1) / BM) * (unsigned)((a.N + BN - 1) / BN));
+    const int mode = (a.S.n == 1 && a.S.s[0].xform == YR_X_IDENTITY) ? (a.gate ? 2 : 1) : 0;
+    if (mode == 0 && a.gate) { yr_set_error("pointwise: an SE gate needs one identity source"); return YR_ERR_ARG; }
+    static char nm[3][48];
+    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "pwd_kernel<%d,%d,%d,0>", PT, CT, D) +
+                              snprintf(nm[1], sizeof(nm[1]), "pwd_kernel<%d,%d,%d,1>", PT, CT, D) +
+                              snprintf(nm[2], sizeof(nm[2]), "pwd_kernel<%d,%d,%d,2>", PT, CT, D);
+    (void)nm_len;
+    yr_note_kernel(nm[mode]);
+    if (mode == 1) hipLaunchKernelGGL((pwd_kernel<PT, CT, D, 1>), grid, dim3(256), 0, s, a);
+    else if (mode == 2) hipLaunchKernelGGL((pwd_kernel<PT, CT, D, 2>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pwd_kernel<PT, CT, D, 0>), grid, dim3(256), 0, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
 }
 
 template <int PT, int CT, int WM, int WN>
@@ -292,7 +523,15 @@ int yr_launch_pointwise(const yr_op& op, int batch, hipStream_t s) {
                                {64, 16, launch_cfg<1, 1, 4, 1>}, {64, 32, launch_cfg<1, 2, 4, 1>},
                                {64, 48, launch_cfg<1, 3, 4, 1>}, {64, 64, launch_cfg<1, 4, 4, 1>},
                                {64, 80, launch_cfg<1, 5, 4, 1>}, {64, 96, launch_cfg<1, 6, 4, 1>},
-                               {64, 128, launch_cfg<1, 8, 4, 1>}};
+                               {64, 128, launch_cfg<1, 8, 4, 1>},
+                               // direct (LDS-free) variants, BM = 64*PT, BN = 16*CT
+                               {64, 16, launch_direct<1, 1>}, {64, 32, launch_direct<1, 2>}, {64, 48, launch_direct<1, 3>},
+                               {64, 64, launch_direct<1, 4>}, {64, 80, launch_direct<1, 5>}, {64, 96, launch_direct<1, 6>},
+                               {64, 128, launch_direct<1, 8>},
+                               {128, 32, launch_direct<2, 2>}, {128, 48, launch_direct<2, 3>}, {128, 64, launch_direct<2, 4>},
+                               {128, 80, launch_direct<2, 5>}, {128, 96, launch_direct<2, 6>},
+                               {256, 32, launch_direct<4, 2>}, {256, 48, launch_direct<4, 3>}, {256, 64, launch_direct<4, 4>}};
+    constexpr int NLDS = 14;  // the first NLDS entries are the LDS-staged kernel (the heuristic below only ranks those)
     constexpr int NCFG = sizeof(cfgs) / sizeof(cfgs[0]);
     const int N = op.cout;
     // autotuned choice (yr_autotune stores the fastest shape per op and batch): op.k = 1 + index
@@ -318,10 +557,10 @@ int yr_launch_pointwise(const yr_op& op, int batch, hipStream_t s) {
     };
     const Cfg* best = &cfgs[0];
     double bc = cost(cfgs[0]);
-    for (int i = 1; i < NCFG; ++i)
+    for (int i = 1; i < NLDS; ++i)
         if (cost(cfgs[i]) < bc) { bc = cost(cfgs[i]); best = &cfgs[i]; }
     return best->fn(a, s);
 }
 
 // number of tile shapes yr_launch_pointwise can be forced to through op.k (1-based)
-int yr_pointwise_num_cfgs() { return 14; }
+int yr_pointwise_num_cfgs() { return 29; }
