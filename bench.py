@@ -187,26 +187,44 @@ def main():
             dict(name='pack', kind='pack', kernel='pack_kernel', ms=post_ms[2], macs=0, bytes=0)]
         by = {}
         for r in rows:
-            k = by.setdefault(r['kernel'], dict(ms=0.0, bytes=0, macs=0, launches=0))
+            k = by.setdefault(r['kernel'], dict(ms=0.0, bytes=0, hbm=0, macs=0, launches=0))
             k['ms'] += r['ms']; k['bytes'] += r['bytes']; k['macs'] += r['macs']; k['launches'] += 1
+            k['hbm'] += r.get('hbm_bytes', r['bytes'])
         dom = max(by, key=lambda k: by[k]['ms'])
         d = by[dom]
         avg_ms = d['ms'] / d['launches']
-        ach = d['bytes'] / d['launches'] / (avg_ms * 1e-3) / 1e9
-        roofline = {'bound': 'hbm', 'kernel': dom, 'launches_per_step': d['launches'],
-                    'avg_launch_ms': round(avg_ms, 4), 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
-                    'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
-                    'tflops': round(2.0 * d['macs'] / (d['ms'] * 1e-3) / 1e12, 2)}
+        # The dominant kernel against the roofline that bounds it.  For a fused block kernel (mblane / stemblock)
+        # the bytes that still cross HBM are the block's input + output only, so it is bound by the fp32 pipe
+        # (packed FMA and fp32 MFMA share the 157.3 TFLOP/s dense peak); an unfused conv is bound by HBM.
+        gbs = d['hbm'] / d['launches'] / (avg_ms * 1e-3) / 1e9
+        tfl = 2.0 * d['macs'] / (d['ms'] * 1e-3) / 1e12
+        if tfl / FP32_PEAK_TFLOPS > gbs / HBM_PEAK_GBS:
+            roofline = {'bound': 'mfma', 'kernel': dom, 'launches_per_step': d['launches'], 'avg_launch_ms': round(avg_ms, 4),
+                        'achieved': round(tfl, 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(tfl / FP32_PEAK_TFLOPS, 4), 'traffic': None,
+                        'flops_per_launch': int(2.0 * d['macs'] / d['launches']), 'hbm_gbs': round(gbs, 1)}
+        else:
+            roofline = {'bound': 'hbm', 'kernel': dom, 'launches_per_step': d['launches'], 'avg_launch_ms': round(avg_ms, 4),
+                        'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None, 'tflops': round(tfl, 2)}
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
         # (profiles/rNN_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KiB, see tools/rocpd_summary.py); None if absent
         try:
             import glob
             tfile = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))[-1]
-            tr = json.load(open(tfile)).get(dom)
+            # rocprof prints template bools as true/false; the launchers name shapes without them (pw: as 1/0)
+            table = {}
+            for key, val in json.load(open(tfile)).items():
+                key = key.replace(' ', '')
+                if key.startswith('pw'):
+                    key = key.replace(',true>', ',1>').replace(',false>', ',0>')
+                table[key.replace(',true>', '>').replace(',false>', '>')] = val
+            tr = table.get(dom)
             if tr and a.batch == 64 and a.model == 'mobilenetv2x75' and a.size == 416:
                 roofline['traffic'] = tr['traffic_bytes']
                 roofline['traffic_source'] = os.path.relpath(tfile, ROOT)
-                roofline['alg_bytes_per_launch'] = int(d['bytes'] / d['launches'])
+                roofline['alg_bytes_per_launch'] = int(d['bytes'] / d['launches'])   # conv-granular
+                roofline['min_hbm_bytes_per_launch'] = int(d['hbm'] / d['launches'])  # fused: block in + out
         except (IndexError, OSError, ValueError):
             pass
         per_gpu = value / world

@@ -6,6 +6,8 @@ Bar (BASELINE.json north_star): fp32 logits within 1e-4 - applied as |a-b| <= 1e
 (test_gpu_postprocess.py); end to end the decisions also depend on ~1e-6 logit differences, so
 here the oracle's post-processing is re-run on the GPU's own logits and must match exactly, and
 the agreement with the oracle's end-to-end detections is measured and bounded."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -152,3 +154,33 @@ def test_unfused_plan_matches_fused(dev):
         outs[fuse] = [y.cpu().numpy() for y in m(torch.from_numpy(x).to(dev))]
         for y, r in zip(outs[fuse], ref):
             assert_close(y, r, 1e-4, 'fuse=%s' % fuse)
+
+
+def test_tuning_table_round_trip(dev, tmp_path, monkeypatch):
+    """yr_autotune's table can be saved (yr_get_tuning) and installed in a fresh handle (yr_set_tuning, via
+    YOLORET_TUNE_CACHE): same logits bit for bit, no trial launches the second time."""
+    import json
+    from yoloret_amd import layers as L
+    from yoloret_amd import runtime as rt
+    from yoloret_amd.yolo3.model import yolov3_body
+    cache = tmp_path / 'tuned.json'
+    monkeypatch.setenv('YOLORET_TUNE_CACHE', str(cache))
+    monkeypatch.setenv('YOLORET_AUTOTUNE', '1')
+    P = params.ParamStore(7, 'conditioned')
+    x = torch.from_numpy(params.synthetic_images(2, 96, 96)).to(dev)
+    outs = []
+    for _ in range(2):
+        m = yolov3_body(L.Input(shape=[96, 96, 3]), 'mobilenetv2x75', 3, num_classes=20)
+        om.yolov3_body(P, params.synthetic_images(1, 96, 96), 'mobilenetv2x75', 3, 20)
+        m.set_weights(P.values)
+        outs.append([y.cpu().numpy() for y in m(x)])
+    table = json.load(open(cache))
+    (key, cfg), = table.items()
+    assert key.endswith(':2') and len(cfg) == len(m.plan.ops)
+    assert all((c == 0) or (o.kind == rt.OP_POINTWISE) for c, o in zip(cfg, m.plan.ops)) and any(cfg)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    bad = (ctypes.c_int32 * 3)(1, 2, 3)
+    idx, hd = m._handle(x.device)
+    with pytest.raises(rt.YoloretHipError, match='yr_set_tuning'):
+        rt.check(rt.lib().yr_set_tuning(hd, 2, bad, 3))

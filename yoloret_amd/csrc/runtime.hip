@@ -114,6 +114,27 @@ extern "C" size_t yr_workspace_bytes(const yr_handle* h, int batch) {
 
 extern "C" int yr_plan_num_launches(const yr_handle* h) { return h ? (int)h->ops.size() : 0; }
 
+extern "C" int yr_get_tuning(const yr_handle* h, int batch, int32_t* cfg, int n) {
+    YR_REQUIRE(h && cfg && n == (int)h->ops.size(), "yr_get_tuning: bad arguments (n must equal yr_plan_num_launches)");
+    auto it = h->tuned.find(batch);
+    if (it == h->tuned.end()) { yr_set_error("yr_get_tuning: batch %d has not been tuned", batch); return YR_ERR_STATE; }
+    for (int i = 0; i < n; ++i) cfg[i] = it->second[i];
+    return YR_OK;
+}
+
+extern "C" int yr_set_tuning(yr_handle* h, int batch, const int32_t* cfg, int n) {
+    YR_REQUIRE(h && cfg && batch > 0 && n == (int)h->ops.size(), "yr_set_tuning: bad arguments (n must equal yr_plan_num_launches)");
+    const int ncfg = yr_pointwise_num_cfgs();
+    std::vector<int> t(n, 0);
+    for (int i = 0; i < n; ++i) {
+        YR_REQUIRE(cfg[i] >= 0 && cfg[i] <= ncfg && (cfg[i] == 0 || h->ops[i].kind == YR_OP_POINTWISE),
+                   "yr_set_tuning: entry %d = %d is not a valid tile shape for that op", i, cfg[i]);
+        t[i] = cfg[i];
+    }
+    h->tuned[batch] = t;
+    return YR_OK;
+}
+
 static int resolve_op(const yr_handle* h, size_t i, int batch, float* const ext[4], float* ws, yr_op* out) {
     yr_op op = h->ops[i];
     auto bufptr = [&](int32_t b) -> float* {

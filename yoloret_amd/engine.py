@@ -117,8 +117,10 @@ class Model:
                 # first call with this batch size: time every pointwise tile shape per layer once (~0.1 s);
                 # the choice changes speed only, never results
                 self._tuned.add((idx, b))
-                rt.check(rt.lib().yr_autotune(hd, rt._ptr(x), b, yp[0], yp[1], yp[2], rt._ptr(ws), ws.numel(),
-                                              rt.stream_ptr(x.device), 3))
+                if not self._load_tuning(hd, b):
+                    rt.check(rt.lib().yr_autotune(hd, rt._ptr(x), b, yp[0], yp[1], yp[2], rt._ptr(ws), ws.numel(),
+                                                  rt.stream_ptr(x.device), 3))
+                    self._save_tuning(hd, b)
             rt.check(rt.lib().yr_forward(hd, rt._ptr(x), b, yp[0], yp[1], yp[2], rt._ptr(ws), ws.numel(),
                                          rt.stream_ptr(x.device)))
         res = []
@@ -127,6 +129,45 @@ class Model:
         return res
 
     predict = __call__
+
+    # ---- tuning cache: YOLORET_TUNE_CACHE=<file.json> keeps the autotuned tile table across processes
+    # (tune once, deploy many; also keeps profiler runs free of the tuner's trial launches)
+    def _tune_key(self, b):
+        import zlib
+        sig = zlib.crc32(' '.join('%s:%d:%d:%d' % (o.name, o.kind, o.cin, o.cout) for o in self.plan.ops).encode())
+        return '%08x:%d' % (sig, b)
+
+    def _load_tuning(self, hd, b):
+        path = os.environ.get('YOLORET_TUNE_CACHE')
+        if not path or not os.path.exists(path):
+            return False
+        import json
+        try:
+            table = json.load(open(path)).get(self._tune_key(b))
+        except (OSError, ValueError):
+            return False
+        n = len(self.plan.ops)
+        if not isinstance(table, list) or len(table) != n:
+            return False
+        arr = (ctypes.c_int32 * n)(*[int(v) for v in table])
+        rt.check(rt.lib().yr_set_tuning(hd, b, arr, n))
+        return True
+
+    def _save_tuning(self, hd, b):
+        path = os.environ.get('YOLORET_TUNE_CACHE')
+        if not path:
+            return
+        import json
+        n = len(self.plan.ops)
+        arr = (ctypes.c_int32 * n)()
+        rt.check(rt.lib().yr_get_tuning(hd, b, arr, n))
+        try:
+            data = json.load(open(path)) if os.path.exists(path) else {}
+        except (OSError, ValueError):
+            data = {}
+        data[self._tune_key(b)] = list(arr)
+        with open(path, 'w') as f:
+            json.dump(data, f)
 
     def profile(self, x, iters=5):
         """Per-op timing (hipEvent pair around every launch, averaged over `iters` replays).
@@ -147,9 +188,10 @@ class Model:
                                                  ms, names))
         out = []
         per_op_bytes = self.plan.algorithmic_bytes_per_op()
+        per_op_hbm = self.plan.hbm_bytes_per_op()   # fused ops: only what still has to cross HBM (block in + out)
         for i, op in enumerate(self.plan.ops):
             out.append(dict(name=op.name, kind=rt.OP_NAMES[op.kind], kernel=(names[i] or b'').decode(),
-                            ms=float(ms[i]), macs=op.macs * b, bytes=per_op_bytes[i] * b))
+                            ms=float(ms[i]), macs=op.macs * b, bytes=per_op_bytes[i] * b, hbm_bytes=per_op_hbm[i] * b))
         return out
 
     def __del__(self):

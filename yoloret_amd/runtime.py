@@ -49,7 +49,7 @@ class YrBuf(ctypes.Structure):
 
 
 EXPORTS = ['yr_last_error', 'yr_abi_version', 'yr_create', 'yr_destroy', 'yr_load_weights', 'yr_workspace_bytes',
-           'yr_forward', 'yr_forward_profile', 'yr_autotune', 'yr_plan_num_launches', 'yr_op_run', 'yr_decode', 'yr_yolo_head', 'yr_correct_boxes',
+           'yr_forward', 'yr_forward_profile', 'yr_autotune', 'yr_get_tuning', 'yr_set_tuning', 'yr_plan_num_launches', 'yr_op_run', 'yr_decode', 'yr_yolo_head', 'yr_correct_boxes',
            'yr_nms', 'yr_pack_detections', 'yr_letterbox']
 
 _lib = None
@@ -84,6 +84,8 @@ def lib():
                                          ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.yr_autotune.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+        L.yr_get_tuning.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.yr_set_tuning.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.yr_op_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.yr_decode.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 5
         L.yr_yolo_head.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + \
