@@ -75,3 +75,35 @@ def test_yolomodel_batch_of_images(dev):
     for img, (b, s, c) in zip(imgs, batch):
         one = ym([_png(img)])
         assert torch.equal(one[0], b) and torch.equal(one[1], s) and torch.equal(one[2], c)
+
+
+def test_pipeline_hip_graph_replay_is_identical(dev):
+    """DetectionPipeline.enable_graph(): the captured step replays to the same records as eager launches,
+    also after the inputs change (the graph reads its own static input copies)."""
+    from yoloret_amd import layers as L
+    from yoloret_amd.pipeline import DetectionPipeline
+    from yoloret_amd.weights import synthetic_images, synthetic_weights
+    from yoloret_amd.yolo3.model import yolov3_body
+    hw = (96, 96)
+    m = yolov3_body(L.Input(shape=[hw[0], hw[1], 3]), 'mobilenetv2x75', 3, num_classes=20)
+    m.set_weights(synthetic_weights(m, 5, 'survey'))
+    pipe = DetectionPipeline(m, ANCHORS, 20, score_threshold=.2)
+    ihw = torch.tensor([[96, 96], [80, 60]], dtype=torch.int32, device=dev)
+    xs = [torch.from_numpy(synthetic_images(2, *hw) * s).to(dev) for s in (1.0, 0.5)]
+    eager = []
+    for x in xs:
+        det, cnt = pipe(x, ihw)
+        eager.append((det.cpu().numpy().copy(), cnt.cpu().numpy().copy()))
+    pipe.enable_graph(True)
+    for rep in range(2):
+        for x, (d0, c0) in zip(xs, eager):
+            det, cnt = pipe(x, ihw)
+            torch.cuda.synchronize()
+            assert np.array_equal(cnt.cpu().numpy(), c0)
+            for i in range(2):
+                k = int(c0[i])
+                assert np.array_equal(det.cpu().numpy()[i, :k], d0[i, :k])
+    assert eager[0][1].sum() > 0
+    pipe.enable_graph(False)
+    det, cnt = pipe(xs[0], ihw)
+    assert np.array_equal(cnt.cpu().numpy(), eager[0][1])

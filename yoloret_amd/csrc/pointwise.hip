@@ -9,83 +9,35 @@
 //   A operand = weights  (lane l: cout i=l&15, k-group g=l>>4)
 //   B operand = pixels   (lane l: pixel j=l&15, k-group g=l>>4)
 //   D: lane holds pixel j=l&15, couts (l>>4)*4+r  -> one float4 store of 4 consecutive couts.
-// A 16-wide k chunk is staged in LDS; lane group g reads k = k0+4g..4g+3 as one
-// ds_read_b128 and uses component s in MFMA step s (the same k permutation on both operands).
-// The next chunk's global loads are issued before the current chunk's MFMAs (register
-// double-buffering), so HBM/L2 latency overlaps the matrix pipe inside one workgroup.
+// Lane group g uses k = k0+4g..4g+3 of a 16-deep chunk, component s in MFMA step s (the same k
+// permutation on both operands).  Two kernels run that same MFMA sequence per output (bit-identical):
+//   pw_kernel  (pointwise_lds.hip) - the chunk is staged through LDS by coalesced loads;
+//   pwd_kernel (this file)         - no LDS, no barriers: every wave loads both operands straight into
+//                                    operand layout and keeps D chunks of loads in flight.
+// This file also holds the dispatcher (tile-shape table, heuristic, autotune hook).
 #include <stdlib.h>
 
-#include "yr_common.h"
+#include "pw_common.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+// One output row (pixel) of the activation operand: where its channels come from.
+// MODE 0: generic gather (upsample / maxpool / concat sources), 1: one identity source, 2: identity + SE gate.
+template <int MODE>
+struct PwRow {
+    const float* arow;               // MODE != 0: the pixel's contiguous row
+    const float* grow;               // MODE == 2: SE gate row of the pixel's image
+    const float* srow[YR_MAX_SRC];   // MODE == 0: per-source row pointer (xform folded in)
+    bool valid;
 
-#ifndef PW_BK
-#define PW_BK 16                 // k depth staged per barrier pair (multiple of 16; measured: 32 is 6 % and 64 is 13 % slower end to end)
-#endif
-#ifndef PW_PF2_MAX_TILES
-#define PW_PF2_MAX_TILES 0       // tiles (PT*CT) per wave up to which TWO k chunks are prefetched (measured: never pays here)
-#endif
-#define PW_KQ (PW_BK / 4)        // float4 quads per staged row
-#define PW_RPP (256 / PW_KQ)     // rows loaded per pass of the 256 threads
-#define PW_LDS_LD (PW_BK + 4)    // padded row stride (floats): an odd number of 16-byte slots
-
-struct PwArgs {
-    DSrcSet S;
-    const float* wt;      // [N][kp]
-    const float* scale;   // [N] or null
-    const float* shift;   // [N] or null
-    const float* res;     // residual [M][res_ld] or null
-    const float* gate;    // SE gate [B][gate_ld] or null
-    float* out;           // [M][out_ld]
-    int M, H, W, N;
-    int out_ld, res_ld, gate_ld;
-    int act;
-};
-
-// PT/CT: 16-wide pixel / cout MFMA tiles per wave; WM x WN waves (WM*WN == 4).
-// SIMPLE: one identity source (optionally SE-gated) -> a pixel's channels are one contiguous row (the
-// common case: every backbone expand/project and most head convs); otherwise the generic gather
-// through per-source row pointers (upsample / maxpool / concat folded into the loads).
-template <int PT, int CT, int WM, int WN, bool SIMPLE>
-__global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
-    constexpr int BM = 16 * PT * WM;
-    constexpr int BN = 16 * CT * WN;
-    constexpr int A_PASSES = BM / PW_RPP;
-    constexpr int B_PASSES = (BN + PW_RPP - 1) / PW_RPP;
-    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * PW_LDS_LD];
-    float* As = lds;                   // [BM][PW_LDS_LD] activations
-    float* Bs = lds + BM * PW_LDS_LD;  // [BN][PW_LDS_LD] weights
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave % WM, wn = wave / WM;
-    // 1-D grid walked in XCD-contiguous order with the cout tile fastest: the cout tiles of one pixel
-    // tile run back to back on one XCD, so the activation tile is re-read from that XCD's L2.
-    const unsigned ntn = (a.N + BN - 1) / BN;
-    const unsigned L = yr_xcd_swizzle(blockIdx.x, gridDim.x);
-    const int m0 = (int)(L / ntn) * BM;
-    const int n0 = (int)(L % ntn) * BN;
-    const int kp = a.S.kp;
-
-    // loader mapping: quad kq of row lr (+64 per pass)
-    const int lr = tid / PW_KQ, kq = tid % PW_KQ;
-    bool pv[A_PASSES];
-    const float* arow[A_PASSES];               // SIMPLE: the pixel's row
-    const float* grow[A_PASSES];               // SE gate row of the pixel's image (or null)
-    const float* srow[A_PASSES][YR_MAX_SRC];   // generic: per-source row pointer of the pixel (xform folded in)
-#pragma unroll
-    for (int p = 0; p < A_PASSES; ++p) {
-        const int m = m0 + lr + p * PW_RPP;
-        pv[p] = m < a.M;
-        const int mm = pv[p] ? m : 0;
+    __device__ __forceinline__ void init(const PwArgs& a, int m) {
+        valid = m < a.M;
+        const int mm = valid ? m : 0;
         const int hw = a.H * a.W;
         const int b = mm / hw;
-        grow[p] = a.gate ? a.gate + (size_t)b * a.gate_ld : nullptr;
-        if (SIMPLE) {
-            arow[p] = a.S.s[0].ptr + (size_t)mm * a.S.s[0].ld;
+        grow = MODE == 2 ? a.gate + (size_t)b * a.gate_ld : nullptr;
+        arow = nullptr;
+        if (MODE != 0) {
+            arow = a.S.s[0].ptr + (size_t)mm * a.S.s[0].ld;
         } else {
-            arow[p] = nullptr;
             const int rem = mm - b * hw;
             const int y = rem / a.W, x = rem - y * a.W;
 #pragma unroll
@@ -95,186 +47,68 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
                 if (d.xform == YR_X_UP2) { sy = y >> 1; sx = x >> 1; }
                 else if (d.xform == YR_X_MAXPOOL2) { sy = y * 2; sx = x * 2; }
                 else if (d.xform == YR_X_MAXPOOL4) { sy = y * 4; sx = x * 4; }
-                srow[p][si] = d.ptr + ((size_t)(b * d.h + sy) * d.w + sx) * d.ld;
+                srow[si] = d.ptr + ((size_t)(b * d.h + sy) * d.w + sx) * d.ld;
             }
         }
     }
-    const float* brow[B_PASSES];
-    bool bvld[B_PASSES];
+
+    // Issue the loads of the quad at k (raw k may lie beyond kp: clamped).  v: raw channels, gt: gate quad
+    // (MODE 2), cv: how many of the quad's channels are real (<= 0: none).  Nothing here reads a loaded
+    // register and every load is unconditional: rows beyond M read row 0 (their outputs are never stored), the
+    // k tail re-reads the last quad (zeroed through cv).  Loads under divergent branches make the compiler's
+    // s_waitcnt insertion stop counting and emit vmcnt(0), which serialises every prefetch behind the newest load.
+    __device__ __forceinline__ void issue(const PwArgs& a, int kraw, int kp, float4& v, float4& gt, int& cv) const {
+        const int k = kraw < kp ? kraw : kp - 4;
+        int cvalid;
+        if (MODE != 0) {
+            v = *reinterpret_cast<const float4*>(arow + k);
+            cvalid = a.S.s[0].c - k;
+            if (MODE == 2) gt = *reinterpret_cast<const float4*>(grow + k);
+        } else {
+            // segment of this quad (kbase of unused segments is huge), then a pre-offset row pointer
+            int si = 0;
 #pragma unroll
-    for (int p = 0; p < B_PASSES; ++p) {
-        const int n = n0 + lr + p * PW_RPP;
-        bvld[p] = (lr + p * PW_RPP < BN) && n < a.N;
-        brow[p] = a.wt + (size_t)(bvld[p] ? n : 0) * kp;
+            for (int i = 1; i < YR_MAX_SRC; ++i)
+                if (k >= a.S.s[i].kbase) si = i;
+            const float* rp = srow[0];
+            int kb = a.S.s[0].kbase, cc = a.S.s[0].c, xf = a.S.s[0].xform, sw = a.S.s[0].w, sld = a.S.s[0].ld;
+#pragma unroll
+            for (int i = 1; i < YR_MAX_SRC; ++i)
+                if (si == i) { rp = srow[i]; kb = a.S.s[i].kbase; cc = a.S.s[i].c; xf = a.S.s[i].xform; sw = a.S.s[i].w; sld = a.S.s[i].ld; }
+            rp += k - kb;
+            v = *reinterpret_cast<const float4*>(rp);
+            if (xf >= YR_X_MAXPOOL2) {  // pooled sources are reduced here (the only path that waits at issue)
+                const int pool = xf == YR_X_MAXPOOL2 ? 2 : 4;
+                for (int dy = 0; dy < pool; ++dy)
+                    for (int dx = 0; dx < pool; ++dx)
+                        v = yr_max4(v, *reinterpret_cast<const float4*>(rp + ((size_t)dy * sw + dx) * sld));
+            }
+            cvalid = cc - (k - kb);
+        }
+        cv = (valid && kraw < kp) ? cvalid : 0;
     }
+};
 
-    // fetch() only ISSUES loads (raw values + the pixel's gate quad); masking and the gate multiply happen in
-    // stage(), one iteration later, right before the LDS store.  Touching the loaded registers inside fetch()
-    // would put the s_waitcnt - a full L2/HBM round trip - in front of the MFMAs of every k chunk.
-    struct Regs {
-        float4 ra[A_PASSES], rg[A_PASSES], rb[B_PASSES];
-        int cv[A_PASSES];  // valid channels in the fetched quad (<= 0: none)
-    };
-    auto fetch = [&](int k0, Regs& R) {
-        const int k = k0 + kq * 4;
-#pragma unroll
-        for (int p = 0; p < A_PASSES; ++p) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 gt = make_float4(1.f, 1.f, 1.f, 1.f);
-            int cvalid = 0;
-            if (pv[p] && k < kp) {
-                if (SIMPLE) {
-                    v = *reinterpret_cast<const float4*>(arow[p] + k);
-                    cvalid = a.S.s[0].c - k;
-                } else {
-                    // segment of this quad (kbase of unused segments is huge), then a pre-offset row pointer
-                    int si = 0;
-#pragma unroll
-                    for (int i = 1; i < YR_MAX_SRC; ++i)
-                        if (k >= a.S.s[i].kbase) si = i;
-                    const float* rp = srow[p][0];
-                    int kb = a.S.s[0].kbase, cc = a.S.s[0].c, xf = a.S.s[0].xform, sw = a.S.s[0].w, sld = a.S.s[0].ld;
-#pragma unroll
-                    for (int i = 1; i < YR_MAX_SRC; ++i)
-                        if (si == i) { rp = srow[p][i]; kb = a.S.s[i].kbase; cc = a.S.s[i].c; xf = a.S.s[i].xform; sw = a.S.s[i].w; sld = a.S.s[i].ld; }
-                    rp += k - kb;
-                    v = *reinterpret_cast<const float4*>(rp);
-                    if (xf >= YR_X_MAXPOOL2) {  // pooled sources are reduced here (the only path that waits in fetch)
-                        const int pool = xf == YR_X_MAXPOOL2 ? 2 : 4;
-                        for (int dy = 0; dy < pool; ++dy)
-                            for (int dx = 0; dx < pool; ++dx)
-                                v = yr_max4(v, *reinterpret_cast<const float4*>(rp + ((size_t)dy * sw + dx) * sld));
-                    }
-                    cvalid = cc - (k - kb);
-                }
-                if (grow[p] != nullptr) gt = *reinterpret_cast<const float4*>(grow[p] + k);
-            }
-            R.ra[p] = v; R.rg[p] = gt; R.cv[p] = cvalid;
-        }
-#pragma unroll
-        for (int p = 0; p < B_PASSES; ++p) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bvld[p] && k < kp) v = *reinterpret_cast<const float4*>(brow[p] + k);
-            R.rb[p] = v;
-        }
-    };
-    // the fetched quad with pad lanes zeroed (the source's pad lanes and the gate's may hold anything) and gated
-    auto staged = [&](const Regs& R, int p) {
-        float4 v = R.ra[p];
-        const float4 gt = R.rg[p];
-        const int cvalid = R.cv[p];
-        v.x = cvalid > 0 ? v.x * gt.x : 0.f;
-        v.y = cvalid > 1 ? v.y * gt.y : 0.f;
-        v.z = cvalid > 2 ? v.z * gt.z : 0.f;
-        v.w = cvalid > 3 ? v.w * gt.w : 0.f;
-        return v;
-    };
-
-    f32x4 acc[CT][PT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int p = 0; p < PT; ++p) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int g = lane >> 4, li = lane & 15;
-    // One k chunk: registers -> LDS, barrier, refill the register set with the chunk DEPTH ahead, fragments + MFMA,
-    // barrier.  Small tiles (<= 4 MFMA tiles per wave: <= 512 matrix cycles per chunk) keep two chunks of global
-    // loads in flight, larger ones one (their MFMA phase already covers an L2 round trip; the extra registers cost
-    // occupancy: measured).
-    constexpr int DEPTH = (PT * CT <= PW_PF2_MAX_TILES) ? 2 : 1;
-    auto step = [&](int k0, Regs& R) {
-#pragma unroll
-        for (int p = 0; p < A_PASSES; ++p)
-            *reinterpret_cast<float4*>(As + (lr + p * PW_RPP) * PW_LDS_LD + kq * 4) = staged(R, p);
-#pragma unroll
-        for (int p = 0; p < B_PASSES; ++p)
-            if (lr + p * PW_RPP < BN) *reinterpret_cast<float4*>(Bs + (lr + p * PW_RPP) * PW_LDS_LD + kq * 4) = R.rb[p];
-        __syncthreads();
-        if (k0 + DEPTH * PW_BK < kp) fetch(k0 + DEPTH * PW_BK, R);
-        // fragments + MFMA, 16 k per sub-step (sub-steps wholly beyond kp are skipped: uniform)
-#pragma unroll
-        for (int kk = 0; kk < PW_BK; kk += 16) {
-            if (k0 + kk >= kp) break;
-            f32x4 wf[CT], xf[PT];
-#pragma unroll
-            for (int c = 0; c < CT; ++c)
-                wf[c] = *reinterpret_cast<const f32x4*>(Bs + ((wn * CT + c) * 16 + li) * PW_LDS_LD + kk + g * 4);
-#pragma unroll
-            for (int p = 0; p < PT; ++p)
-                xf[p] = *reinterpret_cast<const f32x4*>(As + ((wm * PT + p) * 16 + li) * PW_LDS_LD + kk + g * 4);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int c = 0; c < CT; ++c)
-#pragma unroll
-                    for (int p = 0; p < PT; ++p)
-                        acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][s], xf[p][s], acc[c][p], 0, 0, 0);
-        }
-        __syncthreads();
-    };
-    Regs R0;
-    fetch(0, R0);
-    if constexpr (DEPTH == 2) {
-        Regs R1;
-        fetch(PW_BK, R1);  // beyond kp: zeros, never staged
-        for (int k0 = 0; k0 < kp; k0 += 2 * PW_BK) {
-            step(k0, R0);
-            if (k0 + PW_BK < kp) step(k0 + PW_BK, R1);
-        }
-    } else {
-        for (int k0 = 0; k0 < kp; k0 += PW_BK) step(k0, R0);
-    }
-
-    // ---- epilogue: BN scale/shift, activation, residual, store (4 consecutive couts per lane)
-    const bool vec_out = (a.out_ld & 3) == 0;
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        const int n = n0 + (wn * CT + c) * 16 + g * 4;
-        if (n >= a.N) continue;
-        float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (n + r < a.N) {
-                if (a.scale) sc[r] = a.scale[n + r];
-                if (a.shift) sh[r] = a.shift[n + r];
-            }
-#pragma unroll
-        for (int p = 0; p < PT; ++p) {
-            const int m = m0 + (wm * PT + p) * 16 + li;
-            if (m >= a.M) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = yr_apply_act(__builtin_fmaf(acc[c][p][r], sc[r], sh[r]), a.act);
-            if (a.res) {
-                const float* rp = a.res + (size_t)m * a.res_ld + n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < a.N) v[r] += rp[r];
-            }
-            float* op = a.out + (size_t)m * a.out_ld + n;
-            if (vec_out && n + 3 < a.N) {
-                *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < a.N) op[r] = v[r];
-            }
-        }
-    }
+// the fetched quad with pad lanes zeroed (the source's pad lanes and the gate's may hold anything) and gated
+template <int MODE>
+__device__ __forceinline__ float4 pw_finish(float4 v, const float4& gt, int cvalid) {
+    v.x = cvalid > 0 ? (MODE == 2 ? v.x * gt.x : v.x) : 0.f;
+    v.y = cvalid > 1 ? (MODE == 2 ? v.y * gt.y : v.y) : 0.f;
+    v.z = cvalid > 2 ? (MODE == 2 ? v.z * gt.z : v.z) : 0.f;
+    v.w = cvalid > 3 ? (MODE == 2 ? v.w * gt.w : v.w) : 0.f;
+    return v;
 }
 
-// ----------------------------------------------------------------------------------------------------------
-// Direct variant: no LDS, no barriers.  Every wave owns 16*PT pixels x 16*CT couts and loads BOTH MFMA
-// operands straight from global memory in the operand layout (lane l: row l&15, k quad l>>4 - one 64-byte
-// segment per row and instruction; measured on MI355X with tools/ldpat.hip: this map streams at the same
-// 6.4 TB/s from HBM as the 4-adjacent-lanes map, and > 5 TB/s from L2).  D register sets keep D k chunks of
-// loads in flight per wave; waves never wait for each other.  Weight fragments are re-read per wave from
-// L1/L2 (a layer's weights are <= 350 KB).  Same MFMA sequence per output as pw_kernel => bit-identical.
-// MODE 0: generic gather (upsample / maxpool / concat sources), 1: one identity source, 2: identity + SE gate.
+// ------------------------------------------------------------------------------------------ direct kernel
+// Every wave owns 16*PT pixels x 16*CT couts and loads BOTH MFMA operands straight from global memory in the
+// operand layout (lane l: row l&15, k quad l>>4 - one 64-byte segment per row and instruction; measured on
+// MI355X with tools/ldpat.hip: this map streams at the same 6.4 TB/s from HBM as the 4-adjacent-lanes map, and
+// > 5 TB/s from L2).  D register sets keep D k chunks of loads in flight per wave (the steady-state loop is
+// branch-free, so the compiler counts outstanding loads exactly: s_waitcnt vmcnt(11/10/9) for D = 4); waves
+// never wait for each other.  Weight fragments are re-read per wave from L1/L2 (a layer's weights <= 350 KB).
 template <int PT, int CT, int D, int MODE>
 __global__ __launch_bounds__(256) void pwd_kernel(PwArgs a) {
     constexpr int BM = 64 * PT, BN = 16 * CT;
-    constexpr bool SIMPLE = MODE != 0, GATE = MODE == 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const unsigned ntn = (a.N + BN - 1) / BN;
@@ -284,91 +118,28 @@ __global__ __launch_bounds__(256) void pwd_kernel(PwArgs a) {
     const int kp = a.S.kp;
     const int kl = g * 4;  // this lane's k offset inside a 16-deep chunk
 
-    bool pv[PT];
-    const float* arow[PT];
-    const float* grow[PT];
-    const float* srow[PT][YR_MAX_SRC];
+    PwRow<MODE> row[PT];
 #pragma unroll
-    for (int p = 0; p < PT; ++p) {
-        const int m = m0 + p * 16 + li;
-        pv[p] = m < a.M;
-        const int mm = pv[p] ? m : 0;
-        const int hw = a.H * a.W;
-        const int b = mm / hw;
-        grow[p] = GATE ? a.gate + (size_t)b * a.gate_ld : nullptr;
-        if (SIMPLE) {
-            arow[p] = a.S.s[0].ptr + (size_t)mm * a.S.s[0].ld;
-        } else {
-            arow[p] = nullptr;
-            const int rem = mm - b * hw;
-            const int y = rem / a.W, x = rem - y * a.W;
-#pragma unroll
-            for (int si = 0; si < YR_MAX_SRC; ++si) {
-                const DSrc& d = a.S.s[si];
-                int sy = y, sx = x;
-                if (d.xform == YR_X_UP2) { sy = y >> 1; sx = x >> 1; }
-                else if (d.xform == YR_X_MAXPOOL2) { sy = y * 2; sx = x * 2; }
-                else if (d.xform == YR_X_MAXPOOL4) { sy = y * 4; sx = x * 4; }
-                srow[p][si] = d.ptr + ((size_t)(b * d.h + sy) * d.w + sx) * d.ld;
-            }
-        }
-    }
+    for (int p = 0; p < PT; ++p) row[p].init(a, m0 + p * 16 + li);
     const float* brow[CT];
-    bool bv[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int n = n0 + c * 16 + li;
-        bv[c] = n < a.N;
-        brow[c] = a.wt + (size_t)(bv[c] ? n : 0) * kp;
+        brow[c] = a.wt + (size_t)(n < a.N ? n : 0) * kp;  // rows beyond N feed couts that are never stored
     }
 
     struct Frag {
         float4 x[PT], w[CT];
-        float4 gt[GATE ? PT : 1];
+        float4 gt[MODE == 2 ? PT : 1];
         int cv[PT];
     };
-    auto load = [&](int k0, Frag& F) {  // issue only: nothing here may read a loaded register
-        const int k = k0 + kl;
+    auto load = [&](int chunk, Frag& F) {
+        const int kraw = chunk * 16 + kl;
 #pragma unroll
-        for (int p = 0; p < PT; ++p) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            int cvalid = 0;
-            if (pv[p] && k < kp) {
-                if (SIMPLE) {
-                    v = *reinterpret_cast<const float4*>(arow[p] + k);
-                    cvalid = a.S.s[0].c - k;
-                    if (GATE) F.gt[p] = *reinterpret_cast<const float4*>(grow[p] + k);
-                } else {
-                    int si = 0;
+        for (int p = 0; p < PT; ++p) row[p].issue(a, kraw, kp, F.x[p], F.gt[MODE == 2 ? p : 0], F.cv[p]);
+        const int k = kraw < kp ? kraw : kp - 4;  // the k tail of the weights meets zeroed activations
 #pragma unroll
-                    for (int i = 1; i < YR_MAX_SRC; ++i)
-                        if (k >= a.S.s[i].kbase) si = i;
-                    const float* rp = srow[p][0];
-                    int kb = a.S.s[0].kbase, cc = a.S.s[0].c, xf = a.S.s[0].xform, sw = a.S.s[0].w, sld = a.S.s[0].ld;
-#pragma unroll
-                    for (int i = 1; i < YR_MAX_SRC; ++i)
-                        if (si == i) { rp = srow[p][i]; kb = a.S.s[i].kbase; cc = a.S.s[i].c; xf = a.S.s[i].xform; sw = a.S.s[i].w; sld = a.S.s[i].ld; }
-                    rp += k - kb;
-                    v = *reinterpret_cast<const float4*>(rp);
-                    if (xf >= YR_X_MAXPOOL2) {  // pooled sources are reduced here (the only path that waits at issue)
-                        const int pool = xf == YR_X_MAXPOOL2 ? 2 : 4;
-                        for (int dy = 0; dy < pool; ++dy)
-                            for (int dx = 0; dx < pool; ++dx)
-                                v = yr_max4(v, *reinterpret_cast<const float4*>(rp + ((size_t)dy * sw + dx) * sld));
-                    }
-                    cvalid = cc - (k - kb);
-                }
-            } else if (GATE) {
-                F.gt[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            F.x[p] = v; F.cv[p] = cvalid;
-        }
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bv[c] && k < kp) v = *reinterpret_cast<const float4*>(brow[c] + k);
-            F.w[c] = v;
-        }
+        for (int c = 0; c < CT; ++c) F.w[c] = *reinterpret_cast<const float4*>(brow[c] + k);
     };
 
     f32x4 acc[CT][PT];
@@ -376,21 +147,16 @@ __global__ __launch_bounds__(256) void pwd_kernel(PwArgs a) {
     for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int p = 0; p < PT; ++p) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool need_mask = GATE || (!SIMPLE) || (a.S.s[0].c & 3) != 0;  // uniform: most layers have whole quads only
+    // uniform: most layers have whole quads and whole 16-deep chunks only, and then nothing needs masking
+    // (rows beyond M only feed outputs that are never stored)
+    const bool need_mask = MODE != 1 || (a.S.s[0].c & 3) != 0 || (kp & 15) != 0;
 
     auto use = [&](const Frag& F) {
         float xf[PT][4];
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
             float4 v = F.x[p];
-            if (need_mask) {  // pad lanes of the source (and of the gate) may hold anything: force exact zeros
-                const int cvalid = F.cv[p];
-                const float4 gt = GATE ? F.gt[p] : make_float4(1.f, 1.f, 1.f, 1.f);
-                v.x = cvalid > 0 ? (GATE ? v.x * gt.x : v.x) : 0.f;
-                v.y = cvalid > 1 ? (GATE ? v.y * gt.y : v.y) : 0.f;
-                v.z = cvalid > 2 ? (GATE ? v.z * gt.z : v.z) : 0.f;
-                v.w = cvalid > 3 ? (GATE ? v.w * gt.w : v.w) : 0.f;
-            }
+            if (need_mask) v = pw_finish<MODE>(v, F.gt[MODE == 2 ? p : 0], F.cv[p]);
             xf[p][0] = v.x; xf[p][1] = v.y; xf[p][2] = v.z; xf[p][3] = v.w;
         }
         const float* wq = reinterpret_cast<const float*>(&F.w[0]);
@@ -403,17 +169,25 @@ __global__ __launch_bounds__(256) void pwd_kernel(PwArgs a) {
                     acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[c * 4 + s], xf[p][s], acc[c][p], 0, 0, 0);
     };
 
+    const int nch = (kp + 15) >> 4;  // chunk j lives in F[j % D]
     Frag F[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) load(d * 16, F[d]);  // chunks beyond kp load nothing (zeros) and are never used
-    for (int k0 = 0; k0 < kp; k0 += 16 * D) {
+    for (int d = 0; d < D; ++d)
+        if (d < nch) load(d, F[d]);
+    int j0 = 0;
+    for (; j0 + 2 * D - 1 < nch; j0 += D) {  // steady state, branch-free: the whole next group exists
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const int k = k0 + d * 16;
-            if (k < kp) {
-                use(F[d]);
-                load(k + 16 * D, F[d]);
-            }
+            use(F[d]);
+            load(j0 + D + d, F[d]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2 * D - 1; ++t) {    // drain: at most 2D-1 chunks left, the later ones still to be loaded
+        const int j = j0 + t;
+        if (j < nch) {
+            use(F[t % D]);
+            if (j + D < nch) load(j + D, F[t % D]);
         }
     }
 
@@ -475,21 +249,8 @@ static int launch_direct(const PwArgs& a, hipStream_t s) {
     return YR_OK;
 }
 
-template <int PT, int CT, int WM, int WN>
-static int launch_cfg(const PwArgs& a, hipStream_t s) {
-    constexpr int BM = 16 * PT * WM, BN = 16 * CT * WN;
-    dim3 grid((unsigned)((a.M + BM - 1) / BM) * (unsigned)((a.N + BN - 1) / BN));
-    const bool simple = a.S.n == 1 && a.S.s[0].xform == YR_X_IDENTITY;
-    static char nm[2][48];
-    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "pw_kernel<%d,%d,%d,%d,0>", PT, CT, WM, WN) +
-                              snprintf(nm[1], sizeof(nm[1]), "pw_kernel<%d,%d,%d,%d,1>", PT, CT, WM, WN);
-    (void)nm_len;
-    yr_note_kernel(nm[simple ? 1 : 0]);
-    if (simple) hipLaunchKernelGGL((pw_kernel<PT, CT, WM, WN, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((pw_kernel<PT, CT, WM, WN, false>), grid, dim3(256), 0, s, a);
-    YR_LAUNCH_CHECK();
-    return YR_OK;
-}
+template <int SHAPE>
+static int launch_lds(const PwArgs& a, hipStream_t s) { return yr_pw_launch_lds(SHAPE, a, s); }
 
 int yr_launch_pointwise(const yr_op& op, int batch, hipStream_t s) {
     PwArgs a;
@@ -506,6 +267,7 @@ int yr_launch_pointwise(const yr_op& op, int batch, hipStream_t s) {
         YR_REQUIRE(op.nsrc == 1 && op.gate_ld % 4 == 0 && op.gate_ld >= a.S.kp, "pointwise: SE gate needs a single source and gate_ld >= kp");
         YR_REQUIRE(((uintptr_t)op.gate % 16) == 0, "pointwise: gate must be 16-byte aligned");
     }
+    YR_REQUIRE(a.S.kp >= 4, "pointwise: no input channels");
     a.wt = op.wgt; a.scale = op.scale; a.shift = op.shift; a.res = op.res; a.gate = op.gate; a.out = op.out;
     a.H = op.h; a.W = op.w; a.N = op.cout;
     const long long M = (long long)batch * op.h * op.w;
@@ -516,14 +278,12 @@ int yr_launch_pointwise(const yr_op& op, int batch, hipStream_t s) {
     // pixels (13x13 / 26x26 maps) take 64-row tiles and, if still short of ~2 workgroups per CU,
     // narrower cout tiles - these layers are latency/occupancy-bound, not bandwidth-bound.
     struct Cfg { int bm, bn; int (*fn)(const PwArgs&, hipStream_t); };
-    static const Cfg cfgs[] = {{256, 16, launch_cfg<4, 1, 4, 1>}, {128, 32, launch_cfg<2, 2, 4, 1>},
-                               {128, 48, launch_cfg<2, 3, 4, 1>}, {128, 64, launch_cfg<4, 2, 2, 2>},
-                               {128, 80, launch_cfg<2, 5, 4, 1>}, {128, 96, launch_cfg<4, 3, 2, 2>},
-                               {128, 128, launch_cfg<4, 4, 2, 2>},
-                               {64, 16, launch_cfg<1, 1, 4, 1>}, {64, 32, launch_cfg<1, 2, 4, 1>},
-                               {64, 48, launch_cfg<1, 3, 4, 1>}, {64, 64, launch_cfg<1, 4, 4, 1>},
-                               {64, 80, launch_cfg<1, 5, 4, 1>}, {64, 96, launch_cfg<1, 6, 4, 1>},
-                               {64, 128, launch_cfg<1, 8, 4, 1>},
+    static const Cfg cfgs[] = {{256, 16, launch_lds<0>}, {128, 32, launch_lds<1>}, {128, 48, launch_lds<2>},
+                               {128, 64, launch_lds<3>}, {128, 80, launch_lds<4>}, {128, 96, launch_lds<5>},
+                               {128, 128, launch_lds<6>},
+                               {64, 16, launch_lds<7>}, {64, 32, launch_lds<8>}, {64, 48, launch_lds<9>},
+                               {64, 64, launch_lds<10>}, {64, 80, launch_lds<11>}, {64, 96, launch_lds<12>},
+                               {64, 128, launch_lds<13>},
                                // direct (LDS-free) variants, BM = 64*PT, BN = 16*CT
                                {64, 16, launch_direct<1, 1>}, {64, 32, launch_direct<1, 2>}, {64, 48, launch_direct<1, 3>},
                                {64, 64, launch_direct<1, 4>}, {64, 80, launch_direct<1, 5>}, {64, 96, launch_direct<1, 6>},

@@ -68,5 +68,42 @@ class DetectionPipeline:
     def __call__(self, x, image_hw):
         """x [B,H,W,3] CUDA f32; image_hw int32 [B,2] CUDA (original image sizes).
         Returns (det, det_count) - buffers owned by the pipeline, overwritten by the next call."""
+        if self.use_graph:
+            return self._replay(x, image_hw)
         ys = self.forward(x)
         return self.postprocess(ys, image_hw)
+
+    # ---- HIP-graph replay: the whole step (about 80 launches) is captured once per (batch, device) and replayed
+    # as one graph launch.  It pays when the step is launch-bound, i.e. at small batches (batch-1 latency).
+    use_graph = False
+
+    def enable_graph(self, on=True):
+        self.use_graph = bool(on)
+        if not on:
+            self._graphs = {}
+        return self
+
+    def _replay(self, x, image_hw):
+        key = (x.shape[0], x.device)
+        if not hasattr(self, '_graphs'):
+            self._graphs = {}
+        g = self._graphs.get(key)
+        if g is None:
+            # eager warm-up first: tile autotuning, one-time kernel attributes and buffer allocation must not
+            # happen inside the capture
+            for _ in range(2):
+                self.postprocess(self.forward(x), image_hw)
+            torch.cuda.synchronize(x.device)
+            xs, hws = x.clone(), image_hw.clone()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.postprocess(self.forward(xs), hws)
+            g = self._graphs[key] = (graph, xs, hws, out)
+            self._graphs = {key: g}  # one resident shape, like the buffers
+        graph, xs, hws, out = g
+        if x.data_ptr() != xs.data_ptr():
+            xs.copy_(x)
+        if image_hw.data_ptr() != hws.data_ptr():
+            hws.copy_(image_hw)
+        graph.replay()
+        return out
