@@ -293,10 +293,11 @@ __global__ __launch_bounds__(256) void nms_kernel(NmsArgs a) {
 //      lanes = selected boxes, __any): select or drop.  On typical data that is ~max_boxes steps of O(1)
 //      work instead of max_boxes sweeps over thousands of candidates.
 // The rounds are latency-bound, so throughput comes from the number of problems resident per CU: the first
-// launch uses T=256 and cap=NMS_CAP1 (6144 entries = 36 KB LDS, 4 problems/CU); a problem with more candidates is flagged
+// launch uses T=256 and cap=NMS_CAP1 (5200 entries = 31.2 KB LDS, 5 problems/CU); a problem with more candidates is flagged
 // (count = -1) and redone by a second launch with T=1024 and cap=N (only flagged problems do any work).
 #ifndef NMS_CAP1
-#define NMS_CAP1 6144  // first-pass list capacity (36 KB of LDS: 4 problems per CU)
+#define NMS_CAP1 5200  // first-pass list capacity: the largest that still fits 5 problems per CU (measured on the bench
+                       // data: 6144 -> 4/CU 0.157 ms, 5200 -> 5/CU 0.114 ms, 4096 -> 0.234 ms because overflows take the second pass)
 #endif
 struct NmsLazyArgs {
     NmsArgs a;
