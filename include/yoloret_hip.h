@@ -183,6 +183,15 @@ int yr_letterbox(const unsigned char* src_u8, int ih, int iw, float* dst, int H,
 int yr_decode(const float* y1, const float* y2, const float* y3, int batch, int in_h, int in_w,
               int num_anchors, int num_classes, int num_scales, const float* anchors_host,
               const int32_t* image_hw, float* boxes, float* scores, void* stream);
+/* The same with the zoom-in test-time-augmentation pass of yolo_boxes_and_scores (model.py:408-417, enabled by
+ * YoloModel.call(zoom_in=True), yolo.py:154-159): z[s] are the logits of the network run on the centre crop;
+ * their box_xy / box_wh are mapped back as xy*zoom_mul + zoom_add, wh*zoom_mul (the reference hard-codes
+ * 224/416 and (416-224)/(2*416)) and concatenated with the plain pass on the ANCHOR axis, so a cell holds 2A
+ * boxes: boxes [B,2N,4], scores [B,C,2N], index ((h*G+w)*2A + pass*A + a) inside a scale. */
+int yr_decode_zoom(const float* y1, const float* y2, const float* y3, const float* z1, const float* z2,
+                   const float* z3, float zoom_mul, float zoom_add, int batch, int in_h, int in_w,
+                   int num_anchors, int num_classes, int num_scales, const float* anchors_host,
+                   const int32_t* image_hw, float* boxes, float* scores, void* stream);
 
 /* yolo_head alone (model.py:344-371): one scale, reference layouts
  * box_xy/box_wh [B,G,G,A,2], conf [B,G,G,A,1], probs [B,G,G,A,C]; `scores` (nullable)

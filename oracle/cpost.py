@@ -48,13 +48,35 @@ def expf(x):
     return np.array([L.yro_expf(float(v)) for v in x.ravel()], np.float32).reshape(x.shape)
 
 
-def decode_image(yolo_outputs, anchors, num_classes, image_shape, num_scales=3):
-    """One image: list of [G,G,A,C+5] -> boxes [N,4] f32, scores class-major [C,N] f32."""
+# model.py:411-412: the zoom pass is mapped back with these hard-coded constants (python floats -> fp32 tensors)
+ZOOM_MUL = np.float32(224 / 416)
+ZOOM_ADD = np.float32((416 - 224) / (2 * 416))
+
+
+def decode_image(yolo_outputs, anchors, num_classes, image_shape, num_scales=3, zoom_outputs=None):
+    """One image: list of [G,G,A,C+5] -> boxes [N,4] f32, scores class-major [C,N] f32.
+    With zoom_outputs (the zoom-in TTA pass, model.py:408-417) every cell holds 2A boxes and N doubles."""
     L = lib()
     anchors = np.ascontiguousarray(anchors, np.float32)
     mask = ANCHOR_MASK[-num_scales:]
     A = yolo_outputs[0].shape[2]
     N = sum(y.shape[0] * y.shape[1] * A for y in yolo_outputs[:num_scales])
+    if zoom_outputs is not None:
+        N *= 2
+        in_h, in_w = yolo_outputs[0].shape[0] * 32, yolo_outputs[0].shape[1] * 32
+        boxes = np.empty((N, 4), np.float32)
+        scores = np.empty((num_classes, N), np.float32)
+        n0 = 0
+        for l in range(num_scales):
+            y = np.ascontiguousarray(yolo_outputs[l], np.float32)
+            z = np.ascontiguousarray(zoom_outputs[l], np.float32)
+            assert z.shape == y.shape
+            a = np.ascontiguousarray(anchors[mask[l]])
+            L.yro_decode_scale_zoom(_p(y), _p(z), y.shape[0], y.shape[1], A, num_classes, _p(a), in_h, in_w,
+                                    int(image_shape[0]), int(image_shape[1]), ctypes.c_float(ZOOM_MUL),
+                                    ctypes.c_float(ZOOM_ADD), n0, N, _p(boxes), _p(scores))
+            n0 += y.shape[0] * y.shape[1] * A * 2
+        return boxes, scores
     in_h, in_w = yolo_outputs[0].shape[0] * 32, yolo_outputs[0].shape[1] * 32
     boxes = np.empty((N, 4), np.float32)
     scores = np.empty((num_classes, N), np.float32)
@@ -98,6 +120,6 @@ def eval_image(boxes, scores_cm, max_boxes=20, score_threshold=.6, iou_threshold
 
 
 def yolo_eval(yolo_outputs, anchors, num_scales, num_classes, image_shape, max_boxes=20,
-              score_threshold=.6, iou_threshold=.5):
-    b, s = decode_image(yolo_outputs, anchors, num_classes, image_shape, num_scales)
+              score_threshold=.6, iou_threshold=.5, zoom_outputs=None):
+    b, s = decode_image(yolo_outputs, anchors, num_classes, image_shape, num_scales, zoom_outputs)
     return eval_image(b, s, max_boxes, score_threshold, iou_threshold)

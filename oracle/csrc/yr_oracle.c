@@ -77,6 +77,52 @@ void yro_decode_scale(const float* feats, int gh, int gw, int A, int C, const fl
             }
 }
 
+/* The zoom-in test-time-augmentation branch of yolo_boxes_and_scores (model.py:408-417): a second set of
+ * logits (the network run on a centre crop) is decoded by yolo_head with the same anchors, its boxes are mapped
+ * back by box_xy_z*zoom_mul + zoom_add and box_wh_z*zoom_mul (model.py:411-412; the reference hard-codes
+ * zoom_mul = 224/416, zoom_add = (416-224)/(2*416)), and xy / wh / confidence / class probabilities are
+ * concatenated on the ANCHOR axis (tf.concat(..., -2), :414-417) before yolo_correct_boxes.  So a cell holds
+ * 2A boxes: n = (h*G_w+w)*2A + a for the plain pass and + A for the zoom pass; N counts both. */
+void yro_decode_scale_zoom(const float* feats, const float* zoom_feats, int gh, int gw, int A, int C,
+                           const float* anchors, int in_h, int in_w, int img_h, int img_w,
+                           float zoom_mul, float zoom_add, int n0, int N, float* boxes, float* scores) {
+    const float input_h = (float)in_h, input_w = (float)in_w;
+    const float image_h = (float)img_h, image_w = (float)img_w;
+    const float max_shape = fmaxf(image_h, image_w);
+    const float ratio_h = image_h / max_shape, ratio_w = image_w / max_shape;
+    const float boxed_h = input_h * ratio_h, boxed_w = input_w * ratio_w;
+    const float off_h = (input_h - boxed_h) / 2.0f, off_w = (input_w - boxed_w) / 2.0f;
+    const float scale_h = image_h / boxed_h, scale_w = image_w / boxed_w;
+    const float hw_mul_h = input_h * scale_h, hw_mul_w = input_w * scale_w;
+    for (int h = 0; h < gh; ++h)
+        for (int w = 0; w < gw; ++w)
+            for (int pass = 0; pass < 2; ++pass)
+                for (int a = 0; a < A; ++a) {
+                    const int cell = h * gw + w;
+                    const float* t = (pass ? zoom_feats : feats) + (size_t)(cell * A + a) * (C + 5);
+                    float bx = (yro_sigmoid(t[0]) + (float)w) / (float)gw;
+                    float by = (yro_sigmoid(t[1]) + (float)h) / (float)gh;
+                    float bw = yro_expf(t[2]) * anchors[a * 2 + 0] / input_w;
+                    float bh = yro_expf(t[3]) * anchors[a * 2 + 1] / input_h;
+                    if (pass) {
+                        bx = bx * zoom_mul + zoom_add; by = by * zoom_mul + zoom_add;
+                        bw = bw * zoom_mul; bh = bh * zoom_mul;
+                    }
+                    float conf = yro_sigmoid(t[4]);
+                    float cy = (by * input_h - off_h) * scale_h;
+                    float cx = (bx * input_w - off_w) * scale_w;
+                    float hh = bh * hw_mul_h, ww = bw * hw_mul_w;
+                    const int n = cell * 2 * A + pass * A + a;
+                    float* o = boxes + (size_t)(n0 + n) * 4;
+                    o[0] = clipf(cy - hh / 2.0f, 0.0f, image_h);
+                    o[1] = clipf(cx - ww / 2.0f, 0.0f, image_w);
+                    o[2] = clipf(cy + hh / 2.0f, 0.0f, image_h);
+                    o[3] = clipf(cx + ww / 2.0f, 0.0f, image_w);
+                    for (int c = 0; c < C; ++c)
+                        scores[(size_t)c * N + n0 + n] = conf * yro_sigmoid(t[5 + c]);
+                }
+}
+
 /* NonMaxSuppression's IOU() [3P]. */
 float yro_iou(const float* bi, const float* bj) {
     const float ymin_i = fminf(bi[0], bi[2]), xmin_i = fminf(bi[1], bi[3]);

@@ -58,24 +58,34 @@ def yolo_correct_boxes(box_xy, box_wh, input_shape, image_shape):
         np.clip(box_maxes[..., 1:2], F(0), image_shape[1])], -1).astype(np.float32)
 
 
-def yolo_boxes_and_scores(feats, anchors, num_classes, input_shape, image_shape):
-    """model.py:402-428 (zoom_feats branch is never enabled by callers)."""
+def yolo_boxes_and_scores(feats, anchors, num_classes, input_shape, image_shape, zoom_feats=None):
+    """model.py:402-428.  zoom_feats (:408-417, the zoom-in TTA pass; no caller enables it): decoded with the
+    same head, mapped back with the hard-coded 224/416 constants and concatenated on the anchor axis."""
     box_xy, box_wh, conf, probs = yolo_head(feats, anchors, input_shape)
+    if zoom_feats is not None:
+        xy_z, wh_z, conf_z, probs_z = yolo_head(zoom_feats, anchors, input_shape)
+        xy_z = xy_z * F(224 / 416) + F((416 - 224) / (2 * 416))
+        wh_z = wh_z * F(224 / 416)
+        box_xy = np.concatenate([box_xy, xy_z], -2)
+        box_wh = np.concatenate([box_wh, wh_z], -2)
+        conf = np.concatenate([conf, conf_z], -2)
+        probs = np.concatenate([probs, probs_z], -2)
     boxes = yolo_correct_boxes(box_xy, box_wh, input_shape, image_shape).reshape(-1, 4)
     scores = (conf * probs).reshape(-1, num_classes)
     return boxes, scores
 
 
-def decode_image(yolo_outputs, anchors, num_classes, image_shape, num_scales=3):
+def decode_image(yolo_outputs, anchors, num_classes, image_shape, num_scales=3, zoom_outputs=None):
     """The concat of model.py:453-469 for one image: boxes [N,4], scores [N,C];
-    scale order 32,16,8; flat index ((h*G+w)*A+a) inside a scale."""
+    scale order 32,16,8; flat index ((h*G+w)*A+a) inside a scale (2A per cell with zoom_outputs)."""
     anchors = np.asarray(anchors, np.float32)
     mask = ANCHOR_MASK[-num_scales:]
     input_shape = (yolo_outputs[0].shape[0] * 32, yolo_outputs[0].shape[1] * 32)  # model.py:449
     bs, ss = [], []
     for l in range(num_scales):
         b, s = yolo_boxes_and_scores(yolo_outputs[l], anchors[mask[l]], num_classes,
-                                     input_shape, image_shape)
+                                     input_shape, image_shape,
+                                     None if zoom_outputs is None else zoom_outputs[l])
         bs.append(b)
         ss.append(s)
     return np.concatenate(bs, 0), np.concatenate(ss, 0)
@@ -141,9 +151,9 @@ def nms_bruteforce(boxes, scores, max_output_size, iou_threshold, score_threshol
 
 
 def yolo_eval(yolo_outputs, anchors, num_scales, num_classes, image_shape, max_boxes=20,
-              score_threshold=.6, iou_threshold=.5, return_indices=False):
+              score_threshold=.6, iou_threshold=.5, return_indices=False, zoom_outputs=None):
     """model.py:431-491 for ONE image (yolo_outputs: list of [G,G,A,C+5])."""
-    boxes, box_scores = decode_image(yolo_outputs, anchors, num_classes, image_shape, num_scales)
+    boxes, box_scores = decode_image(yolo_outputs, anchors, num_classes, image_shape, num_scales, zoom_outputs)
     boxes_, scores_, classes_, idxs = [], [], [], []
     for c in range(num_classes):
         nms_index = non_max_suppression(boxes, box_scores[:, c], max_boxes,

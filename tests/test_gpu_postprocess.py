@@ -155,3 +155,38 @@ def test_pack_matches_oracle_eval(dev):
         assert np.array_equal(det[i, :k, 4].view(np.float32), rs)
         assert np.array_equal(det[i, :k, 5], rc)
         assert (det[i, k:, 5] == -1).all() and (det[i, k:, :5] == 0).all()
+
+
+@pytest.mark.parametrize('hw,c,image_shapes', [((416, 416), 20, [(375, 500), (416, 416)]), ((64, 96), 7, [(100, 333)])])
+def test_decode_zoom_tta_bit_exact(dev, hw, c, image_shapes):
+    """yr_decode_zoom (the zoom-in TTA branch, model.py:408-417): 2A boxes per cell, bit-exact vs the C oracle,
+    and the full yolo_eval over the doubled box set equals the oracle's."""
+    rt = _rt()
+    from yoloret_amd.yolo3.model import yolo_eval, yolo_boxes_and_scores
+    rng = np.random.default_rng(23)
+    b = len(image_shapes)
+    ys, zs = _logits(rng, b, hw, c), _logits(rng, b, hw, c)
+    yd = [torch.from_numpy(y).to(dev) for y in ys]
+    zd = [torch.from_numpy(z).to(dev) for z in zs]
+    ihw = rt.image_hw_tensor(np.array(image_shapes), b, dev)
+    boxes, scores = rt.decode(yd, ANCHORS, c, ihw, hw, zoom_ys=zd)
+    torch.cuda.synchronize()
+    boxes, scores = boxes.cpu().numpy(), scores.cpu().numpy()
+    n = rt.num_boxes(hw[0], hw[1])
+    assert boxes.shape == (b, 2 * n, 4) and scores.shape == (b, c, 2 * n)
+    for i in range(b):
+        rb, rs = cpost.decode_image([y[i] for y in ys], ANCHORS, c, image_shapes[i], zoom_outputs=[z[i] for z in zs])
+        assert np.array_equal(boxes[i], rb) and np.array_equal(scores[i], rs)
+    res = yolo_eval(yd, ANCHORS, 3, c, np.array(image_shapes), score_threshold=.3, zoom_outputs=zd)
+    res = [res] if b == 1 else res
+    for i in range(b):
+        ob, os_, oc, _ = cpost.yolo_eval([y[i] for y in ys], ANCHORS, 3, c, image_shapes[i], 20, .3, .5,
+                                         zoom_outputs=[z[i] for z in zs])
+        assert np.array_equal(res[i][0].cpu().numpy(), ob) and np.array_equal(res[i][1].cpu().numpy(), os_)
+        assert np.array_equal(res[i][2].cpu().numpy(), oc)
+    # the per-scale reference-layout helper agrees with the fused kernel (scale 0 of image 0)
+    bx, sc = yolo_boxes_and_scores(yd[0][:1], ANCHORS[[6, 7, 8]], c, hw, image_shapes[0], zoom_feats=zd[0][:1])
+    n0 = (hw[0] // 32) * (hw[1] // 32) * 6
+    assert np.array_equal(bx.cpu().numpy(), boxes[0, :n0]) and np.array_equal(sc.cpu().numpy(), scores[0, :, :n0].T)
+    with pytest.raises(ValueError):
+        rt.decode(yd, ANCHORS, c, ihw, hw, zoom_ys=[zd[0], zd[0], zd[2]])

@@ -107,3 +107,26 @@ def test_pipeline_hip_graph_replay_is_identical(dev):
     pipe.enable_graph(False)
     det, cnt = pipe(xs[0], ihw)
     assert np.array_equal(cnt.cpu().numpy(), eager[0][1])
+
+
+def test_yolomodel_zoom_in_tta(dev):
+    """YoloModel.call([bytes], zoom_in=True) (yolo.py:154-159): second pass over tf.image.central_crop of the image,
+    merged by the zoom branch of the decode.  Equals the oracle's yolo_eval(zoom_outputs=...) on the GPU's own logits
+    of the two letterboxed inputs (the oracle letterboxes the host-side crop)."""
+    from yoloret_amd.yolo import YOLO, central_crop
+    from yoloret_amd import runtime as rt
+    from yoloret_amd.yolo3.enums import BACKBONE
+    size = (96, 96)
+    y = YOLO({'model': 'synthetic:9', 'input_size': size, 'backbone': BACKBONE.MOBILENETV2x75, 'score': 0.2, 'nms': 0.5})
+    ym = y.yolo_model
+    img = np.random.default_rng(3).integers(0, 256, (90, 120, 3), dtype=np.uint8)
+    boxes, scores, classes = ym.call([_png(img)], zoom_in=True)
+    crop = central_crop(img, rt.ZOOM_RATIO)
+    xs = [torch.from_numpy(preprocess.letterbox_image(im, size)[0][None]).to(dev) for im in (img, crop)]
+    la = [t.cpu().numpy()[0] for t in ym.model(xs[0])]
+    lz = [t.cpu().numpy()[0] for t in ym.model(xs[1])]
+    ob, os_, oc, _ = cpost.yolo_eval(la, ANCHORS, 3, 20, (90, 120), 20, 0.2, 0.5, zoom_outputs=lz)
+    assert np.array_equal(boxes.cpu().numpy(), ob) and np.array_equal(scores.cpu().numpy(), os_)
+    assert np.array_equal(classes.cpu().numpy(), oc) and len(oc) > 0
+    plain = ym.call([_png(img)])   # the default path still runs on the same object afterwards
+    assert plain[0].dtype == torch.int32 and plain[0].shape[1] == 4

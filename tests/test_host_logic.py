@@ -161,3 +161,18 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(rt, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(rt.YoloretHipError, match='no CPU fallback'):
         rt.lib()
+
+
+def test_central_crop_matches_tf_rule():
+    """tf.image.central_crop: start = int((n - n*f)/2), size = n - 2*start (the zoom-in pass, yolo.py:108-109)."""
+    from yoloret_amd import runtime as rt
+    from yoloret_amd.yolo import central_crop
+    img = np.arange(10 * 7 * 3, dtype=np.uint8).reshape(10, 7, 3)
+    out = central_crop(img, 0.5)
+    assert out.shape == (6, 5, 3) and np.array_equal(out, img[2:8, 1:6])
+    assert central_crop(img, 1.0).shape == (10, 7, 3)
+    z = central_crop(np.zeros((375, 500, 3), np.uint8), rt.ZOOM_RATIO)
+    assert z.shape == (375 - 2 * int((375 - 375 * rt.ZOOM_RATIO) / 2), 500 - 2 * int((500 - 500 * rt.ZOOM_RATIO) / 2), 3)
+    assert abs(rt.ZOOM_RATIO - 0.2899) < 1e-4 and abs(rt.ZOOM_MUL - 224 / 416) < 1e-7
+    with pytest.raises(ValueError):
+        central_crop(img, 0.0)

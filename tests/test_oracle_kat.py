@@ -138,3 +138,27 @@ def test_numpy_graph_matches_torch_graph(name, hw):
     b = torch_ref.TorchReference(P, name)(x)
     for u, v in zip(a, b):
         assert u.shape == v.shape and np.abs(u - v).max() < 5e-5
+
+
+def test_zoom_tta_decode_known_answers():
+    """The zoom-in TTA branch (model.py:408-417): zero logits put every plain box centre at its cell centre and every
+    zoom box centre at centre*224/416 + 96/416, with 224/416 of the size; C and NumPy oracles agree."""
+    from oracle import cpost, postprocess as pp
+    from tests.util import ANCHORS
+    ys = [np.zeros((g, g, 3, 7), np.float32) for g in (13, 26, 52)]
+    b, s = cpost.decode_image(ys, ANCHORS, 2, (416, 416), zoom_outputs=ys)
+    nb, ns = pp.decode_image(ys, ANCHORS, 2, (416, 416), zoom_outputs=ys)
+    assert b.shape == (2 * 10647, 4) and np.allclose(b, nb, atol=1e-3) and np.allclose(s.T, ns, atol=1e-7)
+    assert (s == 0.25).all()
+    # scale 0 (stride 32, 13x13), cell (h=3, w=6), anchor (116, 90): plain box, then its zoom twin A=3 entries later
+    n = (3 * 13 + 6) * 6
+    cy = lambda box: (box[0] + box[2]) / 2
+    cx = lambda box: (box[1] + box[3]) / 2
+    assert cy(b[n]) == pytest.approx(3.5 / 13 * 416, rel=1e-6) and cx(b[n]) == pytest.approx(6.5 / 13 * 416, rel=1e-6)
+    assert b[n][2] - b[n][0] == pytest.approx(90.0, rel=1e-6) and b[n][3] - b[n][1] == pytest.approx(116.0, rel=1e-6)
+    assert cy(b[n + 3]) == pytest.approx(3.5 / 13 * 224 + 96, rel=1e-6)    # (y*224/416 + 96/416) * 416
+    assert cx(b[n + 3]) == pytest.approx(6.5 / 13 * 224 + 96, rel=1e-6)    # = 208: the centre maps to the centre
+    assert b[n + 3][2] - b[n + 3][0] == pytest.approx(90.0 * 224 / 416, rel=1e-5)
+    # the plain pass is embedded unchanged
+    b0, s0 = cpost.decode_image(ys, ANCHORS, 2, (416, 416))
+    assert np.array_equal(b[:169 * 6].reshape(169, 2, 3, 4)[:, 0].reshape(-1, 4), b0[:169 * 3])

@@ -41,6 +41,9 @@ __device__ __forceinline__ float4 yr_correct_box(const Letterbox& L, float bx, f
 // ------------------------------------------------------------------ fused decode (3 scales)
 struct DecodeArgs {
     const float* y[3];
+    const float* z[3];      // zoom-in TTA pass (model.py:408-417) or null
+    int passes;             // 1, or 2 with the zoom pass: a cell then holds 2A boxes (concat on the anchor axis)
+    float zoom_mul, zoom_add;
     int gh[3], gw[3];
     int nstart[3];      // first box index of each scale
     int tile_start[4];  // first block of each scale along grid.x
@@ -65,7 +68,8 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
     const int t0 = ((int)blockIdx.x - a.tile_start[s]) * DEC_TILE;
     const int cnt = min(DEC_TILE, ns - t0);
     const int row = a.C + 5;
-    const float* src = a.y[s] + ((size_t)b * ns + t0) * row;
+    const int pass = (int)blockIdx.z;  // 0: the plain logits, 1: the zoom pass
+    const float* src = (pass ? a.z[s] : a.y[s]) + ((size_t)b * ns + t0) * row;
     // batches of 8 loads before their LDS stores (a store after each load would serialise the HBM round trips)
     for (int i0 = 0; i0 < cnt * row; i0 += 256 * 8) {
         float v[8];
@@ -90,20 +94,24 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
     const int w = cell % gw, h = cell / gw;
     const Letterbox L = yr_letterbox(a.in_h, a.in_w, a.image_hw[b * 2], a.image_hw[b * 2 + 1]);
     // model.py:363-367
-    const float bx = (yr_sigmoid(t[0]) + (float)w) / (float)gw;
-    const float by = (yr_sigmoid(t[1]) + (float)h) / (float)gh;
-    const float bw = yr_expf(t[2]) * a.anchors[s][an][0] / L.input_w;
-    const float bh = yr_expf(t[3]) * a.anchors[s][an][1] / L.input_h;
+    float bx = (yr_sigmoid(t[0]) + (float)w) / (float)gw;
+    float by = (yr_sigmoid(t[1]) + (float)h) / (float)gh;
+    float bw = yr_expf(t[2]) * a.anchors[s][an][0] / L.input_w;
+    float bh = yr_expf(t[3]) * a.anchors[s][an][1] / L.input_h;
+    if (pass) {  // model.py:411-412 (multiply, then add: two roundings, no contraction)
+        bx = bx * a.zoom_mul + a.zoom_add; by = by * a.zoom_mul + a.zoom_add;
+        bw = bw * a.zoom_mul; bh = bh * a.zoom_mul;
+    }
     const float conf = yr_sigmoid(t[4]);
-    const int gn = a.nstart[s] + n;
+    const int gn = a.passes == 1 ? a.nstart[s] + n : (a.nstart[s] + cell * a.A) * 2 + pass * a.A + an;
     *reinterpret_cast<float4*>(a.boxes + ((size_t)b * a.N + gn) * 4) = yr_correct_box(L, bx, by, bw, bh);
     float* sp = a.scores + (size_t)b * a.C * a.N + gn;
     for (int c = 0; c < a.C; ++c) sp[(size_t)c * a.N] = conf * yr_sigmoid(t[5 + c]);  // model.py:426
 }
 
-extern "C" int yr_decode(const float* y1, const float* y2, const float* y3, int batch, int in_h, int in_w,
-                         int num_anchors, int num_classes, int num_scales, const float* anchors_host,
-                         const int32_t* image_hw, float* boxes, float* scores, void* stream) {
+static int decode_launch(const float* y1, const float* y2, const float* y3, const float* const* zoom, float zoom_mul,
+                         float zoom_add, int batch, int in_h, int in_w, int num_anchors, int num_classes, int num_scales,
+                         const float* anchors_host, const int32_t* image_hw, float* boxes, float* scores, void* stream) {
     YR_REQUIRE(num_scales >= 1 && num_scales <= 3, "decode: num_scales must be 1..3");
     YR_REQUIRE(num_anchors >= 1 && num_anchors <= 8, "decode: num_anchors must be 1..8");
     YR_REQUIRE(in_h % 32 == 0 && in_w % 32 == 0 && in_h > 0 && in_w > 0, "decode: input size must be a multiple of 32");
@@ -114,6 +122,8 @@ extern "C" int yr_decode(const float* y1, const float* y2, const float* y3, int 
     int n = 0, tiles = 0;
     for (int s = 0; s < 3; ++s) {
         a.y[s] = ys[s < num_scales ? s : 0];
+        a.z[s] = zoom ? zoom[s < num_scales ? s : 0] : nullptr;
+        if (zoom && s < num_scales) YR_REQUIRE(zoom[s] != nullptr, "decode: zoom logits %d are null", s + 1);
         const int stride = 32 >> s;
         a.gh[s] = in_h / stride; a.gw[s] = in_w / stride;
         a.nstart[s] = n; a.tile_start[s] = tiles;
@@ -131,13 +141,31 @@ extern "C" int yr_decode(const float* y1, const float* y2, const float* y3, int 
         }
     }
     a.tile_start[3] = tiles;
-    a.num_scales = num_scales; a.A = num_anchors; a.C = num_classes; a.N = n; a.in_h = in_h; a.in_w = in_w;
+    a.passes = zoom ? 2 : 1; a.zoom_mul = zoom_mul; a.zoom_add = zoom_add;
+    a.num_scales = num_scales; a.A = num_anchors; a.C = num_classes; a.N = n * a.passes; a.in_h = in_h; a.in_w = in_w;
     a.image_hw = image_hw; a.boxes = boxes; a.scores = scores;
     const size_t lds = (size_t)DEC_TILE * (num_classes + 5) * sizeof(float);
     YR_REQUIRE(lds <= 160 * 1024, "decode: too many classes for the LDS tile");
-    hipLaunchKernelGGL(decode_kernel, dim3(tiles, batch), dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(decode_kernel, dim3(tiles, batch, a.passes), dim3(256), lds, (hipStream_t)stream, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
+}
+
+extern "C" int yr_decode(const float* y1, const float* y2, const float* y3, int batch, int in_h, int in_w,
+                         int num_anchors, int num_classes, int num_scales, const float* anchors_host,
+                         const int32_t* image_hw, float* boxes, float* scores, void* stream) {
+    return decode_launch(y1, y2, y3, nullptr, 1.f, 0.f, batch, in_h, in_w, num_anchors, num_classes, num_scales,
+                         anchors_host, image_hw, boxes, scores, stream);
+}
+
+extern "C" int yr_decode_zoom(const float* y1, const float* y2, const float* y3, const float* z1, const float* z2,
+                              const float* z3, float zoom_mul, float zoom_add, int batch, int in_h, int in_w,
+                              int num_anchors, int num_classes, int num_scales, const float* anchors_host,
+                              const int32_t* image_hw, float* boxes, float* scores, void* stream) {
+    const float* zoom[3] = {z1, z2, z3};
+    YR_REQUIRE(z1 != nullptr, "decode: zoom logits are null");
+    return decode_launch(y1, y2, y3, zoom, zoom_mul, zoom_add, batch, in_h, in_w, num_anchors, num_classes, num_scales,
+                         anchors_host, image_hw, boxes, scores, stream);
 }
 
 // ------------------------------------------------------------------ yolo_head / yolo_correct_boxes (reference layouts)

@@ -49,7 +49,7 @@ class YrBuf(ctypes.Structure):
 
 
 EXPORTS = ['yr_last_error', 'yr_abi_version', 'yr_create', 'yr_destroy', 'yr_load_weights', 'yr_workspace_bytes',
-           'yr_forward', 'yr_forward_profile', 'yr_autotune', 'yr_get_tuning', 'yr_set_tuning', 'yr_plan_num_launches', 'yr_op_run', 'yr_decode', 'yr_yolo_head', 'yr_correct_boxes',
+           'yr_forward', 'yr_forward_profile', 'yr_autotune', 'yr_get_tuning', 'yr_set_tuning', 'yr_plan_num_launches', 'yr_op_run', 'yr_decode', 'yr_decode_zoom', 'yr_yolo_head', 'yr_correct_boxes',
            'yr_nms', 'yr_pack_detections', 'yr_letterbox']
 
 _lib = None
@@ -88,6 +88,7 @@ def lib():
         L.yr_set_tuning.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.yr_op_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.yr_decode.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 5
+        L.yr_decode_zoom.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_float] * 2 + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 5
         L.yr_yolo_head.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + \
             [ctypes.c_void_p] * 6
         L.yr_correct_boxes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
@@ -152,10 +153,36 @@ def num_boxes(in_h, in_w, num_anchors=3, num_scales=3):
     return sum((in_h // (32 >> s)) * (in_w // (32 >> s)) * num_anchors for s in range(num_scales))
 
 
-def decode(ys, anchors, num_classes, image_hw, input_hw, num_scales=3):
-    """ys: list of [B,G,G,A*(C+5)] (or [B,G,G,A,C+5]) logits -> boxes [B,N,4], scores [B,C,N]."""
+# model.py:411-412: the zoom-in TTA pass is mapped back with these hard-coded constants
+ZOOM_MUL = float(np.float32(224 / 416))
+ZOOM_ADD = float(np.float32((416 - 224) / (2 * 416)))
+ZOOM_RATIO = (224 * 224) / (416 * 416)     # utils.py:7: the central_crop fraction of the zoom pass (yolo.py:108-109)
+
+
+def decode(ys, anchors, num_classes, image_hw, input_hw, num_scales=3, zoom_ys=None):
+    """ys: list of [B,G,G,A*(C+5)] (or [B,G,G,A,C+5]) logits -> boxes [B,N,4], scores [B,C,N].
+    zoom_ys: the logits of the zoom-in TTA pass (model.py:408-417) -> boxes [B,2N,4], scores [B,C,2N]."""
     for i, y in enumerate(ys[:num_scales]):
         _require_cuda_f32(y, 'y%d' % (i + 1))
+    if zoom_ys is not None:
+        for i, (y, z) in enumerate(zip(ys[:num_scales], zoom_ys[:num_scales])):
+            _require_cuda_f32(z, 'zoom y%d' % (i + 1))
+            if z.shape != y.shape:
+                raise ValueError('zoom y%d has shape %s, expected %s' % (i + 1, tuple(z.shape), tuple(y.shape)))
+        b = ys[0].shape[0]
+        anchors = np.ascontiguousarray(np.asarray(anchors, np.float32).reshape(-1, 2))
+        a = anchors.shape[0] // 3
+        in_h, in_w = int(input_hw[0]), int(input_hw[1])
+        n = 2 * num_boxes(in_h, in_w, a, num_scales)
+        dev = ys[0].device
+        boxes = torch.empty((b, n, 4), dtype=torch.float32, device=dev)
+        scores = torch.empty((b, num_classes, n), dtype=torch.float32, device=dev)
+        yp = [_ptr(ys[i]) if i < num_scales else None for i in range(3)]
+        zp = [_ptr(zoom_ys[i]) if i < num_scales else None for i in range(3)]
+        check(lib().yr_decode_zoom(yp[0], yp[1], yp[2], zp[0], zp[1], zp[2], ZOOM_MUL, ZOOM_ADD, b, in_h, in_w, a,
+                                   num_classes, num_scales, anchors.ctypes.data_as(ctypes.c_void_p), _ptr(image_hw),
+                                   _ptr(boxes), _ptr(scores), stream_ptr()))
+        return boxes, scores
     b = ys[0].shape[0]
     anchors = np.ascontiguousarray(np.asarray(anchors, np.float32).reshape(-1, 2))
     a = anchors.shape[0] // 3

@@ -27,7 +27,7 @@ from . import runtime as rt
 from .pipeline import DetectionPipeline
 from .weights import synthetic_weights
 from .yolo3.enums import BACKBONE
-from .yolo3.model import YoloEval, unpack_detections, yolov3_body
+from .yolo3.model import YoloEval, unpack_detections, yolo_eval_packed, yolov3_body
 from .yolo3.utils import get_anchors, get_classes
 
 
@@ -73,9 +73,9 @@ class YoloModel:
 
     def parse_image(self, image, zoom_in=False):
         """yolo.py:105-112: returns (decoded uint8 image [h,w,3] on the host, letterboxed float32 [H,W,3] on the GPU)."""
-        if zoom_in:
-            raise NotImplementedError('zoom-in TTA (yolo.py:108-109,154-159) is not enabled by any caller')
         decoded = _decode_to_u8(image) if isinstance(image, (bytes, bytearray)) else np.ascontiguousarray(image, np.uint8)
+        if zoom_in:
+            decoded = central_crop(decoded, rt.ZOOM_RATIO)   # yolo.py:108-109
         letterboxed = rt.letterbox(torch.from_numpy(decoded).to(self.device), self.input_shapes)
         return decoded, letterboxed
 
@@ -93,13 +93,34 @@ class YoloModel:
             rt.letterbox(torch.from_numpy(decoded).to(self.device), self.input_shapes, out=x[i])
             shapes.append(decoded.shape[:2])
         image_hw = rt.image_hw_tensor(np.asarray(shapes, np.int32), b, self.device)
-        det, cnt = self._pipe(x, image_hw)
+        if zoom_in:
+            # yolo.py:154-159: a second pass over the central crop of every image, merged inside the decode
+            xz = torch.empty_like(x)
+            for i, img in enumerate(input):
+                _, lb = self.parse_image(img, zoom_in=True)
+                xz[i].copy_(lb)
+            ys = [y.clone() for y in self.model(x)]
+            det, cnt = yolo_eval_packed(ys, self.anchors, self.num_scales, self.num_classes, image_hw, 20, self.score,
+                                        self.nms, zoom_outputs=self.model(xz))
+        else:
+            det, cnt = self._pipe(x, image_hw)
         res = unpack_detections(det, cnt)
         if self.with_classes:
             res = [(bx, sc, [self.classes[int(c)] for c in cl.tolist()]) for bx, sc, cl in res]
         return res[0] if b == 1 else res
 
     __call__ = call
+
+
+def central_crop(image, central_fraction):
+    """tf.image.central_crop [3P] on a host [h,w,c] array: per axis, start = int((n - n*fraction) / 2) and
+    size = n - 2*start (yolo.py:108-109 passes the AREA ratio 224^2/416^2 as the per-axis fraction)."""
+    if not 0.0 < central_fraction <= 1.0:
+        raise ValueError('central_fraction must be within (0, 1]')
+    h, w = image.shape[:2]
+    y0 = int((h - h * central_fraction) / 2)
+    x0 = int((w - w * central_fraction) / 2)
+    return np.ascontiguousarray(image[y0:h - y0, x0:w - x0])
 
 
 class YOLO(object):

@@ -185,10 +185,19 @@ def yolo_correct_boxes(box_xy, box_wh, input_shape, image_shape):
 def yolo_boxes_and_scores(feats, anchors, num_classes, input_shape, image_shape, zoom_feats=None):
     """model.py:402-428.  Returns boxes [B*G*G*A,4] and scores [B*G*G*A,C], batch folded in
     exactly like the reference's reshapes (:425,427)."""
-    if zoom_feats is not None:
-        raise NotImplementedError('zoom-in TTA (model.py:408-417) is not enabled by any caller')
     box_xy, box_wh, _, _, box_scores = rt.yolo_head(feats.contiguous(), anchors, _hw(input_shape),
                                                      with_scores=True)
+    if zoom_feats is not None:
+        # zoom-in TTA (model.py:408-417): same head on the second set of logits, mapped back with the reference's
+        # hard-coded constants, concatenated on the anchor axis.  This per-scale, reference-layout helper glues the
+        # two head outputs with elementwise tensor ops (multiply, then add: the same two fp32 roundings); the fused
+        # path (yolo_eval / yr_decode_zoom) does it inside the decode kernel.
+        xy_z, wh_z, _, _, scores_z = rt.yolo_head(zoom_feats.contiguous(), anchors, _hw(input_shape), with_scores=True)
+        xy_z = xy_z * rt.ZOOM_MUL + rt.ZOOM_ADD
+        wh_z = wh_z * rt.ZOOM_MUL
+        box_xy = torch.cat([box_xy, xy_z], -2)
+        box_wh = torch.cat([box_wh, wh_z], -2)
+        box_scores = torch.cat([box_scores, scores_z], -2)
     boxes = yolo_correct_boxes(box_xy, box_wh, input_shape, image_shape).reshape(-1, 4)
     return boxes, box_scores.reshape(-1, num_classes)
 
@@ -200,24 +209,24 @@ def yolo_eval(yolo_outputs, anchors, num_scales, num_classes, image_shape, max_b
     yolo_outputs: [y1,y2,y3] CUDA tensors [B,G,G,A,C+5]; image_shape: (h,w) or [B,2].
     B==1: returns (boxes int32 [K,4] (ymin,xmin,ymax,xmax), scores f32 [K], classes int32 [K]),
     class-ascending then NMS pick order.  B>1: returns a list of such triples, one per image."""
-    if zoom_outputs is not None:
-        raise NotImplementedError('zoom-in TTA (model.py:454-459) is not enabled by any caller')
     det, cnt = yolo_eval_packed(yolo_outputs, anchors, num_scales, num_classes, image_shape, max_boxes,
-                                score_threshold, iou_threshold)
+                                score_threshold, iou_threshold, zoom_outputs=zoom_outputs)
     res = unpack_detections(det, cnt)
     return res[0] if len(res) == 1 else res
 
 
 def yolo_eval_packed(yolo_outputs, anchors, num_scales, num_classes, image_shape, max_boxes=20,
-                     score_threshold=.6, iou_threshold=.5):
+                     score_threshold=.6, iou_threshold=.5, zoom_outputs=None):
     """Device-resident form of ``yolo_eval``: decode -> per-(image,class) NMS -> packed records.
-    Returns det int32 [B, C*max_boxes, 6] and det_count int32 [B] (layout: include/yoloret_hip.h)."""
+    Returns det int32 [B, C*max_boxes, 6] and det_count int32 [B] (layout: include/yoloret_hip.h).
+    zoom_outputs: the logits of the zoom-in TTA pass (model.py:454-459); the NMS then runs over 2N boxes."""
     ys = [y.contiguous() for y in yolo_outputs[:num_scales]]
+    zs = None if zoom_outputs is None else [z.contiguous() for z in zoom_outputs[:num_scales]]
     b = ys[0].shape[0]
     anchors = np.asarray(anchors, np.float32).reshape(-1, 2)
     input_hw = (ys[0].shape[1] * 32, ys[0].shape[2] * 32)  # model.py:449
     hw = rt.image_hw_tensor(image_shape, b, ys[0].device)
-    boxes, scores = rt.decode(ys, anchors, num_classes, hw, input_hw, num_scales)
+    boxes, scores = rt.decode(ys, anchors, num_classes, hw, input_hw, num_scales, zoom_ys=zs)
     idx, count = rt.nms(boxes, scores, max_boxes, score_threshold, iou_threshold)
     return rt.pack_detections(boxes, scores, idx, count)
 
