@@ -41,7 +41,15 @@ typedef enum { YR_ACT_NONE = 0, YR_ACT_RELU6 = 1, YR_ACT_SWISH = 2, YR_ACT_SIGMO
 /* How a source tensor is read by a consumer (folds Keras UpSampling2D /
  * MaxPooling2D / Concatenate - model.py:139-144,157,164-166,253-255,307-308 -
  * into the consumer's loads). */
-typedef enum { YR_X_IDENTITY = 0, YR_X_UP2 = 1, YR_X_MAXPOOL2 = 2, YR_X_MAXPOOL4 = 3 } yr_xform;
+typedef enum {
+    YR_X_IDENTITY = 0, YR_X_UP2 = 1, YR_X_MAXPOOL2 = 2, YR_X_MAXPOOL4 = 3,
+    /* POINTWISE only, last source only: NOT part of the k space.  Its `cout` channels, gathered with nearest 2x
+     * upsampling, are added to the accumulator before BatchNorm.  A 1x1 convolution commutes with nearest
+     * upsampling (W.[up2(a); b] = up2(Wa.a) + Wb.b), so the compiler computes the upsampled share of a concat conv
+     * at the source resolution and hands it in this way (model.py:253-255,273-275: UpSampling2D + Concatenate feeding
+     * the first 1x1 conv of the top-down heads). */
+    YR_X_UP2_ADD = 4
+} yr_xform;
 
 /* One concatenated input segment.  (h,w) are the SOURCE's spatial dims; the
  * consumer's dims follow from xform.  In plan ops `ptr` is unused and `buf`

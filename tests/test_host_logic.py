@@ -28,12 +28,12 @@ def test_macs_match_survey(name, size, macs_m):
 
 def test_plan_structure_and_accounting():
     from yoloret_amd import compiler, runtime as rt
-    saved = compiler.FUSE_MAX_CIN, compiler.FUSE_STEM
+    saved = compiler.FUSE_MAX_CIN, compiler.FUSE_STEM, compiler.HOIST_UPSAMPLE
     try:
-        compiler.FUSE_MAX_CIN, compiler.FUSE_STEM = 0, False   # unfused plan = SURVEY.md Appendix B rows
+        compiler.FUSE_MAX_CIN, compiler.FUSE_STEM, compiler.HOIST_UPSAMPLE = 0, False, False   # unfused plan = SURVEY.md Appendix B rows
         p = _model().plan
     finally:
-        compiler.FUSE_MAX_CIN, compiler.FUSE_STEM = saved
+        compiler.FUSE_MAX_CIN, compiler.FUSE_STEM, compiler.HOIST_UPSAMPLE = saved
     kinds = [o.kind for o in p.ops]
     assert kinds.count(rt.OP_POINTWISE) == 55 and kinds.count(rt.OP_DEPTHWISE) == 23 and kinds.count(rt.OP_STEM) == 1
     assert kinds.count(rt.OP_SE_MEAN) == 6 and kinds.count(rt.OP_SE_FC) == 6 and kinds.count(rt.OP_WSUM) == 1

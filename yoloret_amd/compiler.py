@@ -189,6 +189,8 @@ class Plan:
                 # the accounting stays conv-granular (the figure everyone computes from): a fused
                 # block is charged what its three convolutions would move unfused
                 return sum(elems_of(f) for f in op.fused)
+            if getattr(op, 'accounted_in', None):
+                return 0   # the low-resolution half of a hoisted conv: charged to the conv it was split from
             if op.kind in (rt.OP_STEM, rt.OP_POINTWISE, rt.OP_DEPTHWISE):
                 if not (op.kind == rt.OP_POINTWISE and op.h == 1 and op.w == 1):
                     elems += op.h * op.w * op.cout
@@ -197,7 +199,7 @@ class Plan:
                         if id(s.buf) not in wsum_outs:
                             elems += s.buf.h * s.buf.w * s.c
                     else:
-                        elems += sum(src_elems(op, s) for s in op.srcs)
+                        elems += sum(src_elems(op, s) for s in getattr(op, 'accounting_srcs', op.srcs))
                     if op.res is not None:
                         elems += op.h * op.w * op.cout
             elif op.kind == rt.OP_WSUM:
@@ -238,6 +240,51 @@ FUSE_LANE = os.environ.get('YOLORET_FUSE_LANE', '1') != '0'              # narro
 FUSE_LANE_MIN_PIXELS = int(os.environ.get('YOLORET_FUSE_LANE_MIN_PIXELS', '600'))  # mblane still wins on 26x26 outputs (block_6)
 MBLANE_WIDTHS = {(4, 16), (4, 24), (6, 24), (6, 32), (6, 40), (6, 48), (8, 32), (8, 40), (8, 48)}  # (CINP/4, round_up(cout,8)) built in mblane.hip
 STEMBLOCK_WIDTHS ={(12, 16), (16, 16), (16, 24), (20, 24), (24, 16), (24, 24)}  # (C1p/2, round_up(cout,8)) built in stemblock.hip
+
+
+HOIST_UPSAMPLE = os.environ.get('YOLORET_HOIST', '1') != '0'
+
+
+def hoist_upsampled_sources(ops, bufs):
+    """A 1x1 convolution commutes with nearest-neighbour upsampling: W.[up2(a); b] = up2(Wa.a) + Wb.b.  The FPN
+    top-down convs (td2_conv, td3_conv: model.py:253-255,273-275 feed `Concatenate([UpSampling2D(x), b])` into the
+    first 1x1 conv of make_last_layers) take 60-90 % of their input channels from 2x-upsampled maps, so that share
+    of the GEMM is computed at the SOURCE resolution (a quarter of the pixels) into a small buffer P, and the
+    full-resolution conv keeps only the remaining sources and adds up2(P) to its accumulator before BatchNorm
+    (source xform 'up2_add').  Same mathematics, a different fp32 summation grouping (inside the 1e-4 logit bar);
+    td3_conv drops from 248 to 24 input channels at 52x52, td2_conv from 424 to 168 at 26x26."""
+    out = []
+    for op in ops:
+        lo = [s for s in op.srcs if s.xform == 'up2']
+        hi = [s for s in op.srcs if s.xform != 'up2']
+        ok = (op.kind == rt.OP_POINTWISE and op.gate is None and lo and hi and len(hi) + 1 <= rt.YR_MAX_SRC
+              and len(set((s.buf.h, s.buf.w) for s in lo)) == 1 and not (op.h == 1 and op.w == 1)
+              and sum(s.c for s in lo) >= sum(s.c for s in hi))
+        if not ok:
+            out.append(op)
+            continue
+        pads = [round_up(s.c, 4) for s in op.srcs]
+        base = [sum(pads[:i]) for i in range(len(pads))]
+        lo_cols = [(base[i], pads[i]) for i, s in enumerate(op.srcs) if s.xform == 'up2']
+        hi_cols = [(base[i], pads[i]) for i, s in enumerate(op.srcs) if s.xform != 'up2']
+        wshape, wfn = op.params['wgt']
+        h_lo, w_lo = lo[0].buf.h, lo[0].buf.w
+        p = Buf(len(bufs), h_lo, w_lo, op.cout, round_up(op.cout, 4), name=op.name + '_lowres')
+        bufs.append(p)
+
+        def cols(sel, wfn=wfn):
+            return lambda wd: np.ascontiguousarray(np.concatenate([wfn(wd)[:, b:b + n] for b, n in sel], axis=1))
+        low = OpRec(rt.OP_POINTWISE, op.name + '_lowres', act='none', h=h_lo, w=w_lo, cin=sum(s.c for s in lo),
+                    cout=op.cout, srcs=[Seg(s.buf, s.c, 'identity') for s in lo], out=p, macs=0)
+        low.params = {'wgt': ((op.cout, sum(n for _, n in lo_cols)), cols(lo_cols))}
+        low.accounted_in = op.name     # its traffic and MACs are part of `op` in the conv-granular accounting
+        top = OpRec(rt.OP_POINTWISE, op.name, act=op.act, h=op.h, w=op.w, cin=sum(s.c for s in hi), cout=op.cout,
+                    srcs=hi + [Seg(p, op.cout, 'up2_add')], out=op.out, res=op.res, macs=op.macs)
+        top.params = dict(op.params)
+        top.params['wgt'] = ((op.cout, sum(n for _, n in hi_cols)), cols(hi_cols))
+        top.accounting_srcs = list(op.srcs)   # SURVEY 8(d) charges the conv its original (concatenated) input
+        out += [low, top]
+    return out
 
 
 def fuse_inverted_residuals(ops, output_buf_ids):
@@ -535,6 +582,8 @@ class Compiler:
             outs.append(v.segs[0].buf)
         ops = self.ops
         if self.fuse:
+            if HOIST_UPSAMPLE:
+                ops = hoist_upsampled_sources(ops, self.bufs)
             ops = fuse_inverted_residuals(ops, set(b.id for b in outs))
         return Plan(ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape)
 

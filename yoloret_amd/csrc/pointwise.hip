@@ -208,7 +208,12 @@ __global__ __launch_bounds__(256) void pwd_kernel(PwArgs a) {
         for (int p = 0; p < PT; ++p) {
             const int m = m0 + p * 16 + li;
             if (m >= a.M) continue;
-            float v[4];
+            float v[4], pa[4];
+            if (a.pre) {  // uniform: the low-resolution share of a hoisted concat conv joins the accumulator before BN
+                pw_pre_addend(a, m, n, pa);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[c][p][r] += pa[r];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = yr_apply_act(__builtin_fmaf(acc[c][p][r], sc[r], sh[r]), a.act);
             if (a.res) {
@@ -252,8 +257,19 @@ static int launch_direct(const PwArgs& a, hipStream_t s) {
 template <int SHAPE>
 static int launch_lds(const PwArgs& a, hipStream_t s) { return yr_pw_launch_lds(SHAPE, a, s); }
 
-int yr_launch_pointwise(const yr_op& op, int batch, hipStream_t s) {
+int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
     PwArgs a;
+    yr_op op = op_in;
+    a.pre = nullptr; a.pre_ld = 0;
+    if (op.nsrc >= 2 && op.src[op.nsrc - 1].xform == YR_X_UP2_ADD) {  // not a k-space source: see yr_xform
+        const yr_src& p = op.src[op.nsrc - 1];
+        YR_REQUIRE(p.ptr && p.c == op.cout && p.ld >= op.cout && p.h * 2 == op.h && p.w * 2 == op.w,
+                   "pointwise: the up2_add source must be [B,%d,%d,cout=%d]", op.h / 2, op.w / 2, op.cout);
+        a.pre = p.ptr; a.pre_ld = p.ld;
+        op.nsrc -= 1;
+    }
+    for (int i = 0; i < op.nsrc; ++i)
+        YR_REQUIRE(op.src[i].xform != YR_X_UP2_ADD, "pointwise: up2_add is only valid as the last of >= 2 sources");
     int rc = yr_make_srcset(op, &a.S);
     if (rc) return rc;
     int cin = 0;

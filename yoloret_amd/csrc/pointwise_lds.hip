@@ -214,7 +214,12 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
         for (int p = 0; p < PT; ++p) {
             const int m = m0 + (wm * PT + p) * 16 + li;
             if (m >= a.M) continue;
-            float v[4];
+            float v[4], pa[4];
+            if (a.pre) {  // uniform: the low-resolution share of a hoisted concat conv joins the accumulator before BN
+                pw_pre_addend(a, m, n, pa);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[c][p][r] += pa[r];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = yr_apply_act(__builtin_fmaf(acc[c][p][r], sc[r], sh[r]), a.act);
             if (a.res) {

@@ -11,11 +11,30 @@ struct PwArgs {
     const float* shift;   // [N] or null
     const float* res;     // residual [M][res_ld] or null
     const float* gate;    // SE gate [B][gate_ld] or null
+    const float* pre;     // YR_X_UP2_ADD source [B][H/2][W/2][pre_ld] added to the accumulator before BN, or null
     float* out;           // [M][out_ld]
     int M, H, W, N;
-    int out_ld, res_ld, gate_ld;
+    int out_ld, res_ld, gate_ld, pre_ld;
     int act;
 };
+
+// The pre-BatchNorm addend of output pixel m, couts n..n+3 (zeros without one): nearest 2x upsampling of `pre`.
+__device__ __forceinline__ void pw_pre_addend(const PwArgs& a, int m, int n, float (&p)[4]) {
+    p[0] = p[1] = p[2] = p[3] = 0.f;
+    if (a.pre == nullptr) return;
+    const int hw = a.H * a.W;
+    const int b = m / hw, rem = m - b * hw;
+    const int y = rem / a.W, x = rem - y * a.W;
+    const float* src = a.pre + ((size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.pre_ld + n;
+    if (n + 3 < a.N && (a.pre_ld & 3) == 0) {  // n is a multiple of 4: one 16-byte load
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (n + r < a.N) p[r] = src[r];
+}
 
 // LDS-staged kernel, tile shape index 0..13: (BM x BN) = 256x16, 128x32, 128x48, 128x64, 128x80, 128x96, 128x128,
 // 64x16, 64x32, 64x48, 64x64, 64x80, 64x96, 64x128
