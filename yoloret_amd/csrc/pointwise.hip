@@ -225,6 +225,11 @@ __global__ __launch_bounds__(256) void pwd_kernel(PwArgs a) {
             float* op = a.out + (size_t)m * a.out_ld + n;
             if (vec_out && n + 3 < a.N) {
                 *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+            } else if (n + 3 < a.N) {
+                // dense rows (the 75-wide logit outputs): still ONE 16-byte store per lane, only 4-byte aligned
+                // (global_store_dwordx4 takes dword-aligned addresses); four dword stores per lane cost the y
+                // convs 40 % of their time
+                *reinterpret_cast<f32x4u*>(op) = (f32x4u){v[0], v[1], v[2], v[3]};
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)

@@ -231,6 +231,8 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
             float* op = a.out + (size_t)m * a.out_ld + n;
             if (vec_out && n + 3 < a.N) {
                 *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+            } else if (n + 3 < a.N) {
+                *reinterpret_cast<f32x4u*>(op) = (f32x4u){v[0], v[1], v[2], v[3]};  // dense rows: dword-aligned 16-byte store
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)

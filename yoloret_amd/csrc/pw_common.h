@@ -3,6 +3,7 @@
 #include "yr_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at a dword-aligned address
 
 struct PwArgs {
     DSrcSet S;
