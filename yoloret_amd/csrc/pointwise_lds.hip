@@ -111,10 +111,15 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
                         if (si == i) { rp = srow[p][i]; kb = a.S.s[i].kbase; cc = a.S.s[i].c; xf = a.S.s[i].xform; sw = a.S.s[i].w; sld = a.S.s[i].ld; }
                     rp += k - kb;
                     v = *reinterpret_cast<const float4*>(rp);
-                    if (xf >= YR_X_MAXPOOL2) {  // pooled sources are reduced here (the only path that waits in fetch)
-                        const int pool = xf == YR_X_MAXPOOL2 ? 2 : 4;
-                        for (int dy = 0; dy < pool; ++dy)
-                            for (int dx = 0; dx < pool; ++dx)
+                    if (xf == YR_X_MAXPOOL2) {  // pooled sources are reduced here (the only path that waits in fetch):
+                        // the three other taps are issued together - ONE round trip, not one per tap
+                        const float4 v1 = *reinterpret_cast<const float4*>(rp + sld);
+                        const float4 v2 = *reinterpret_cast<const float4*>(rp + (size_t)sw * sld);
+                        const float4 v3 = *reinterpret_cast<const float4*>(rp + ((size_t)sw + 1) * sld);
+                        v = yr_max4(yr_max4(v, v1), yr_max4(v2, v3));
+                    } else if (xf == YR_X_MAXPOOL4) {
+                        for (int dy = 0; dy < 4; ++dy)
+                            for (int dx = 0; dx < 4; ++dx)
                                 v = yr_max4(v, *reinterpret_cast<const float4*>(rp + ((size_t)dy * sw + dx) * sld));
                     }
                     cvalid = cc - (k - kb);
