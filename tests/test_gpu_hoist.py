@@ -92,3 +92,53 @@ def test_compiler_hoists_the_top_down_convs(dev):
         model.set_weights(P.values)
         for y, r in zip(model(torch.from_numpy(x).to(dev)), ref):
             assert_close(y.cpu().numpy().reshape(r.shape), r, 1e-4, 'hoisted graph')
+
+
+@pytest.mark.parametrize('case', [(52, 52, 75, 128, 'relu6'), (12, 20, 24, 48, 'none'), (6, 10, 37, 50, 'swish')],
+                         ids=['bu3_down', 'rfcr_b3c', 'ragged'])
+def test_pointwise_with_pooled_output(dev, case):
+    """stride = 2 on a pointwise op: out = MaxPooling2D(2)(act(BN(conv(x)))) written by the conv itself, for the
+    LDS-staged and the direct kernel (forced tile shapes); identical to pooling the unfused result."""
+    from yoloret_amd import runtime as rt
+    h, w, cin, cout, act = case
+    rng = np.random.default_rng(zlib.crc32(str(case).encode()))
+    b = 3
+    x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
+    wk = (rng.standard_normal((cin, cout)) * np.sqrt(2.0 / cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.3, cout).astype(np.float32)
+    act_np = {'relu6': nn.relu6, 'swish': nn.swish, 'none': lambda v: v}[act]
+    full = act_np((nn.pointwise(x, wk) * scale + shift).astype(np.float32))
+    ref = nn.maxpool(full, 2)
+    wt = np.zeros((cout, round_up(cin, 4)), np.float32)
+    wt[:, :cin] = wk.T
+    xd = to_dev(x, dev)
+    keep = [torch.from_numpy(a).to(dev) for a in (wt, scale, shift)]
+    outs = []
+    for cfg in (0, 2, 9, 15, 17, 23):
+        op = rt.new_op(rt.OP_POINTWISE, act)
+        op.h, op.w, op.cin, op.cout, op.nsrc, op.stride, op.k = h // 2, w // 2, cin, cout, 1, 2, cfg
+        op.src[0] = rt.make_src(xd, c=cin)
+        op.wgt, op.scale, op.shift = [t.data_ptr() for t in keep]
+        out = torch.full((b, h // 2, w // 2, round_up(cout, 4)), float('nan'), dtype=torch.float32, device=dev)
+        op.out, op.out_ld = out.data_ptr(), out.shape[3]
+        rt.run_op(op, b)
+        torch.cuda.synchronize()
+        outs.append(from_dev(out, cout))
+        assert_close(outs[-1], ref, 3e-5, 'pooled conv %s cfg %d' % (case, cfg))
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+    full_d = _pw(rt, dev, [(xd, cin, 'identity')], wt, cout, h, w, b, act, scale, shift)
+    assert np.array_equal(nn.maxpool(from_dev(full_d, cout), 2), outs[0])   # exactly the pooled unfused result
+
+
+def test_compiler_pools_in_the_producer(dev):
+    from yoloret_amd import layers as L
+    from yoloret_amd.yolo3.model import yolov3_body
+    m = yolov3_body(L.Input(shape=[128, 128, 3]), 'mobilenetv2x75', 3, num_classes=20)
+    pooled = {o.name: o for o in m.plan.ops if getattr(o, 'stride', 0) == 2 and o.kind == 2}
+    assert set(pooled) == {'bu3_down_conv', 'bu2_down_conv', 'rfcr_b3c'}
+    assert (pooled['bu3_down_conv'].h, pooled['bu3_down_conv'].w) == (8, 8)
+    assert not any(s.xform == 'maxpool2' and s.buf.name.endswith('_pooled') for o in m.plan.ops for s in o.srcs)
+    bu2 = next(o for o in m.plan.ops if o.name == 'bu2_conv')
+    assert [s.xform for s in bu2.srcs] == ['identity', 'identity']

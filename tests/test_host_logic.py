@@ -28,12 +28,15 @@ def test_macs_match_survey(name, size, macs_m):
 
 def test_plan_structure_and_accounting():
     from yoloret_amd import compiler, runtime as rt
-    saved = compiler.FUSE_MAX_CIN, compiler.FUSE_STEM, compiler.HOIST_UPSAMPLE
+    knobs = ('FUSE_MAX_CIN', 'FUSE_STEM', 'HOIST_UPSAMPLE', 'POOL_IN_PRODUCER')
+    saved = [getattr(compiler, k) for k in knobs]
     try:
-        compiler.FUSE_MAX_CIN, compiler.FUSE_STEM, compiler.HOIST_UPSAMPLE = 0, False, False   # unfused plan = SURVEY.md Appendix B rows
+        for k, v in zip(knobs, (0, False, False, False)):   # every rewrite off: the plan = SURVEY.md Appendix B rows
+            setattr(compiler, k, v)
         p = _model().plan
     finally:
-        compiler.FUSE_MAX_CIN, compiler.FUSE_STEM, compiler.HOIST_UPSAMPLE = saved
+        for k, v in zip(knobs, saved):
+            setattr(compiler, k, v)
     kinds = [o.kind for o in p.ops]
     assert kinds.count(rt.OP_POINTWISE) == 55 and kinds.count(rt.OP_DEPTHWISE) == 23 and kinds.count(rt.OP_STEM) == 1
     assert kinds.count(rt.OP_SE_MEAN) == 6 and kinds.count(rt.OP_SE_FC) == 6 and kinds.count(rt.OP_WSUM) == 1

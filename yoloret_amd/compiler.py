@@ -192,6 +192,9 @@ class Plan:
             if getattr(op, 'accounted_in', None):
                 return 0   # the low-resolution half of a hoisted conv: charged to the conv it was split from
             if op.kind in (rt.OP_STEM, rt.OP_POINTWISE, rt.OP_DEPTHWISE):
+                if hasattr(op, 'accounting_hw'):   # pooled-output conv: charged at the conv's own resolution
+                    ah, aw = op.accounting_hw
+                    return (ah * aw * op.cout + sum(ah * aw * s.c for s in op.srcs))
                 if not (op.kind == rt.OP_POINTWISE and op.h == 1 and op.w == 1):
                     elems += op.h * op.w * op.cout
                     if op.kind == rt.OP_DEPTHWISE or op.kind == rt.OP_STEM:
@@ -202,8 +205,8 @@ class Plan:
                         elems += sum(src_elems(op, s) for s in getattr(op, 'accounting_srcs', op.srcs))
                     if op.res is not None:
                         elems += op.h * op.w * op.cout
-            elif op.kind == rt.OP_WSUM:
-                elems += sum(s.buf.h * s.buf.w * s.c for s in op.srcs)
+            elif op.kind == rt.OP_WSUM:   # (a source pooled by its producer is still charged at its pre-pool size)
+                elems += sum(int(np.prod(getattr(s.buf, 'accounting_hw', (s.buf.h, s.buf.w)))) * s.c for s in op.srcs)
             elif op.kind == rt.OP_SE_MEAN:
                 elems += op.cout
             return elems
@@ -285,6 +288,37 @@ def hoist_upsampled_sources(ops, bufs):
         top.accounting_srcs = list(op.srcs)   # SURVEY 8(d) charges the conv its original (concatenated) input
         out += [low, top]
     return out
+
+
+POOL_IN_PRODUCER = os.environ.get('YOLORET_POOL_FUSE', '1') != '0'
+
+
+def pool_into_producers(ops, bufs, output_buf_ids):
+    """`downsample_layer` = MaxPooling2D(2) (model.py:139-144) sits right after the bottom-up 1x1 convs and RFCR's
+    b3 conv, and its input has no other reader.  Instead of writing the full-resolution map and letting the consumer
+    take the maximum of four loads per element, the producing pointwise op stores the pooled map itself (op.stride =
+    2: GEMM rows in 2x2-quad-major order, window maximum across four lanes): a quarter of the bytes written, a
+    quarter read.  Arithmetic is unchanged (max of the same finished values)."""
+    readers = {}
+    for op in ops:
+        for s in op.srcs:
+            readers.setdefault(id(s.buf), []).append((op, s))
+        for b in (op.res, op.gate):
+            if b is not None:
+                readers.setdefault(id(b), []).append((op, None))
+    for op in ops:
+        rd = readers.get(id(op.out), [])
+        if (op.kind != rt.OP_POINTWISE or op.res is not None or op.out.external_slot >= 0 or op.out.id in output_buf_ids
+                or not rd or any(s is None or s.xform != 'maxpool2' for _, s in rd) or op.h % 2 or op.w % 2
+                or any(s.xform == 'up2_add' for s in op.srcs) or getattr(op, 'stride', 0) == 2):
+            continue
+        q = Buf(len(bufs), op.h // 2, op.w // 2, op.out.c, op.out.ld, name=op.out.name + '_pooled')
+        bufs.append(q)
+        op.accounting_hw = q.accounting_hw = (op.h, op.w)   # SURVEY 8(d) charges the conv its full-resolution output
+        op.out, op.h, op.w, op.stride = q, op.h // 2, op.w // 2, 2
+        for _, s in rd:
+            s.buf, s.xform = q, 'identity'
+    return ops
 
 
 def fuse_inverted_residuals(ops, output_buf_ids):
@@ -584,6 +618,8 @@ class Compiler:
         if self.fuse:
             if HOIST_UPSAMPLE:
                 ops = hoist_upsampled_sources(ops, self.bufs)
+            if POOL_IN_PRODUCER:
+                ops = pool_into_producers(ops, self.bufs, set(b.id for b in outs))
             ops = fuse_inverted_residuals(ops, set(b.id for b in outs))
         return Plan(ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape)
 

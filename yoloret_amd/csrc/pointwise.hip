@@ -30,7 +30,7 @@ struct PwRow {
 
     __device__ __forceinline__ void init(const PwArgs& a, int m) {
         valid = m < a.M;
-        const int mm = valid ? m : 0;
+        const int mm = pw_pixel_of_row(a, valid ? m : 0);
         const int hw = a.H * a.W;
         const int b = mm / hw;
         grow = MODE == 2 ? a.gate + (size_t)b * a.gate_ld : nullptr;
@@ -227,7 +227,13 @@ __global__ __launch_bounds__(256) void pwd_kernel(PwArgs a) {
                 for (int r = 0; r < 4; ++r)
                     if (n + r < a.N) v[r] += rp[r];
             }
-            float* op = a.out + (size_t)m * a.out_ld + n;
+            int orow = m;
+            if (a.pool) {  // uniform: MaxPooling2D(2) of the finished values; the window = 4 adjacent lanes (whole quads
+                pw_pool4(v);  // are valid or not together: M is a multiple of 4)
+                if (li & 3) continue;
+                orow = m >> 2;
+            }
+            float* op = a.out + (size_t)orow * a.out_ld + n;
             if (vec_out && n + 3 < a.N) {
                 *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
             } else if (n + 3 < a.N) {
@@ -280,6 +286,16 @@ int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
     }
     for (int i = 0; i < op.nsrc; ++i)
         YR_REQUIRE(op.src[i].xform != YR_X_UP2_ADD, "pointwise: up2_add is only valid as the last of >= 2 sources");
+    // stride 2 on a POINTWISE op: the output is MaxPooling2D(2) of the conv (+BN+act) result (model.py:139-144 after
+    // the bottom-up convs); op.h/op.w are the pooled OUTPUT dims, the sources sit at twice that
+    a.pool = 0;
+    if (op.stride == 2) {
+        YR_REQUIRE(a.pre == nullptr && op.res == nullptr, "pointwise: a pooled output takes no residual / up2_add");
+        a.pool = 1;
+        op.h *= 2; op.w *= 2;
+    } else {
+        YR_REQUIRE(op.stride == 0 || op.stride == 1, "pointwise: stride %d unsupported", op.stride);
+    }
     int rc = yr_make_srcset(op, &a.S);
     if (rc) return rc;
     int cin = 0;

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     for (int p = 0; p < A_PASSES; ++p) {
         const int m = m0 + lr + p * PW_RPP;
         pv[p] = m < a.M;
-        const int mm = pv[p] ? m : 0;
+        const int mm = pw_pixel_of_row(a, pv[p] ? m : 0);
         const int hw = a.H * a.W;
         const int b = mm / hw;
         grow[p] = a.gate ? a.gate + (size_t)b * a.gate_ld : nullptr;
@@ -233,7 +233,13 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
                 for (int r = 0; r < 4; ++r)
                     if (n + r < a.N) v[r] += rp[r];
             }
-            float* op = a.out + (size_t)m * a.out_ld + n;
+            int orow = m;
+            if (a.pool) {  // uniform: MaxPooling2D(2) across the 4 adjacent lanes of a window (see pw_common.h)
+                pw_pool4(v);
+                if (li & 3) continue;
+                orow = m >> 2;
+            }
+            float* op = a.out + (size_t)orow * a.out_ld + n;
             if (vec_out && n + 3 < a.N) {
                 *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
             } else if (n + 3 < a.N) {

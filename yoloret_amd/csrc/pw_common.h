@@ -17,7 +17,29 @@ struct PwArgs {
     int M, H, W, N;
     int out_ld, res_ld, gate_ld, pre_ld;
     int act;
+    int pool;             // 1: the output is MaxPooling2D(2)(conv output); H, W, M stay the CONV's (pre-pool) dims
 };
+
+// GEMM row -> conv pixel.  Plain: identity.  Pooled output: rows are walked in 2x2-quad-major order, so the four
+// pixels of a pooling window sit in four ADJACENT lanes of one MFMA tile and the window maximum is two DPP steps.
+__device__ __forceinline__ int pw_pixel_of_row(const PwArgs& a, int m) {
+    if (!a.pool) return m;
+    const int q = m >> 2, sub = m & 3;
+    const int wq = a.W >> 1, hwq = (a.H >> 1) * wq;
+    const int b = q / hwq, r = q - b * hwq;
+    const int yq = r / wq, xq = r - yq * wq;
+    return (b * a.H + 2 * yq + (sub >> 1)) * a.W + 2 * xq + (sub & 1);
+}
+
+// MaxPooling2D(2) of the finished (BN + activation) values across the four lanes of a pooling window; lane
+// (row & 3) == 0 then owns the result, which goes to pooled pixel row >> 2.
+__device__ __forceinline__ void pw_pool4(float (&v)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        v[r] = fmaxf(v[r], __shfl_xor(v[r], 1));
+        v[r] = fmaxf(v[r], __shfl_xor(v[r], 2));
+    }
+}
 
 // The pre-BatchNorm addend of output pixel m, couts n..n+3 (zeros without one): nearest 2x upsampling of `pre`.
 __device__ __forceinline__ void pw_pre_addend(const PwArgs& a, int m, int n, float (&p)[4]) {
