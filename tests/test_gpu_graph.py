@@ -184,3 +184,21 @@ def test_tuning_table_round_trip(dev, tmp_path, monkeypatch):
     idx, hd = m._handle(x.device)
     with pytest.raises(rt.YoloretHipError, match='yr_set_tuning'):
         rt.check(rt.lib().yr_set_tuning(hd, 2, bad, 3))
+
+
+@pytest.mark.parametrize('name,size', [('mobilenetv2x75', 352), ('mobilenetv2x14', 224)])
+def test_odd_grids_with_all_graph_rewrites(dev, name, size):
+    """Input sizes whose grids are odd (352 -> 11/22/44, 224 -> 7/14/28): the hoisted (up2_add) and pooled-output
+    convs, the lane-per-pixel blocks and the ragged tiles of every kernel against the oracle's torch-CPU graph."""
+    from oracle import torch_ref
+    from yoloret_amd import layers as L
+    from yoloret_amd.yolo3.model import yolov3_body
+    m = yolov3_body(L.Input(shape=[size, size, 3]), name, 3, num_classes=20)
+    assert sum(o.name.endswith('_lowres') for o in m.plan.ops) == 2
+    assert sum(getattr(o, 'stride', 0) == 2 and o.kind == 2 for o in m.plan.ops) == 3
+    P = params.ParamStore(77, 'conditioned')
+    x = params.synthetic_images(2, size, size)
+    ref = torch_ref.TorchReference(P, name, 3, 20)(x)
+    m.set_weights(P.values)
+    for y, r in zip(m(torch.from_numpy(x).to(dev)), ref):
+        assert_close(y.cpu().numpy().reshape(r.shape), r, 1e-4, '%s@%d' % (name, size))
