@@ -104,7 +104,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     use_dist = world > 1 or a.force_dist
+    # RCCL prints a banner (hostname, library path, ...) on STDOUT when the first communicator is created; stdout
+    # must carry exactly one JSON line, so fd 1 points at stderr until the set-up step (which runs the first
+    # collective) is over
+    saved_stdout = None
     if use_dist:
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
@@ -137,6 +144,10 @@ def main():
 
     step()  # one-time setup outside every timed/warm-up count: buffer allocation + per-layer tile autotuning
     sync()
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     for _ in range(a.warmup):
         step()
     sync()
