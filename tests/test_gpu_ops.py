@@ -244,6 +244,13 @@ def test_squeeze_excite(dev, h, w, c, r):
     rt.run_op(op, b)
     torch.cuda.synchronize()
     assert_close(from_dev(gd, c), gate, TOL, 'se_fc')
+    # the merged form (SE_FC pools the full map itself; its own fixed summation order)
+    g2 = torch.full((b, 1, 1, ldc), float('nan'), dtype=torch.float32, device=dev)
+    op.src[0] = rt.make_src(xd, c=c)
+    op.out = g2.data_ptr()
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    assert_close(from_dev(g2, c), gate, TOL, 'se_fc with the mean merged in')
 
 
 def test_weighted_sum_bit_exact(dev):

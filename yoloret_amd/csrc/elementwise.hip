@@ -77,6 +77,8 @@ int yr_launch_se_mean(const yr_op& op, int batch, hipStream_t s) {
 
 // ------------------------------------------------------------------ SE FCs
 struct FcArgs {
+    const float* map;   // HW > 1: the full map [B][HW][ld_map] whose spatial mean is the FC input (SE_MEAN merged in)
+    int HW, ld_map;
     const float* mean;  // [B][ld_mean]
     const float* w1t;   // [R][ldc]   (transposed Keras kernel: hidden j, channel c)
     const float* b1;    // [R]
@@ -97,7 +99,46 @@ __global__ __launch_bounds__(SE_FC_THREADS) void se_fc_kernel(FcArgs a) {
     float* hid = sm + a.ldc;          // [R]
     float* part = hid + a.R;          // [SE_FC_THREADS]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int c = tid; c < a.ldc; c += SE_FC_THREADS) mean[c] = (c < a.C) ? a.mean[(size_t)b * a.ld_mean + c] : 0.f;
+    if (a.HW > 1) {
+        // tf.reduce_mean over H,W first (the SE_MEAN op merged into this launch).  All channel quads at once:
+        // C4P = next power of two >= C4 quads x (1024 / C4P) pixel lanes, then one fixed-order combine over the
+        // pixel lanes (deterministic; the summation grouping differs from se_mean_kernel's by fp32 rounding only).
+        float4* red = reinterpret_cast<float4*>(sm + ((a.ldc + a.R + SE_FC_THREADS + 3) & ~3));  // [PL][C4P], 16-byte aligned
+        const int C4 = (a.C + 3) >> 2;
+        int c4p = 1;
+        while (c4p < C4 && c4p < SE_FC_THREADS) c4p <<= 1;
+        const int PL = SE_FC_THREADS / c4p;
+        for (int q0 = 0; q0 < C4; q0 += c4p) {   // one pass unless C > 4096
+            const int cq = q0 + (tid & (c4p - 1)), pl = tid / c4p;
+            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cq < C4) {
+                const float* p = a.map + (size_t)b * a.HW * a.ld_map + cq * 4;
+#pragma unroll 8
+                for (int i = pl; i < a.HW; i += PL) {
+                    const float4 v = *reinterpret_cast<const float4*>(p + (size_t)i * a.ld_map);
+                    s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+                }
+            }
+            red[tid] = s4;
+            __syncthreads();
+            if (pl == 0 && cq < C4) {
+                float4 t = red[tid];
+                for (int i = 1; i < PL; ++i) {
+                    const float4 v = red[i * c4p + tid];
+                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+                }
+                const float n = (float)a.HW;
+                const int c = cq * 4;
+                mean[c] = t.x / n;
+                if (c + 1 < a.ldc) mean[c + 1] = c + 1 < a.C ? t.y / n : 0.f;
+                if (c + 2 < a.ldc) mean[c + 2] = c + 2 < a.C ? t.z / n : 0.f;
+                if (c + 3 < a.ldc) mean[c + 3] = c + 3 < a.C ? t.w / n : 0.f;
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int c = tid; c < a.ldc; c += SE_FC_THREADS) mean[c] = (c < a.C) ? a.mean[(size_t)b * a.ld_mean + c] : 0.f;
+    }
     __syncthreads();
     // the kernel is pure latency (64 workgroups, weights from L2): keep several rows' loads in flight per wave
 #pragma unroll 4
@@ -141,10 +182,12 @@ int yr_launch_se_fc(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(in.ptr && op.out && op.wgt && op.wgt2 && op.b1 && op.b2, "se_fc: null pointer");
     YR_REQUIRE(op.se_reduced >= 1 && in.c == op.cout, "se_fc: bad widths");
     FcArgs a;
+    a.map = in.ptr; a.HW = in.h * in.w; a.ld_map = in.ld;   // h*w > 1: the pooled vector is computed here (SE_MEAN merged)
+    YR_REQUIRE(a.HW == 1 || (in.ld % 4 == 0 && ((uintptr_t)in.ptr % 16) == 0), "se_fc: the map to pool must be float4-addressable");
     a.mean = in.ptr; a.w1t = op.wgt; a.b1 = op.b1; a.w2 = op.wgt2; a.b2 = op.b2; a.gate = op.out;
     a.C = in.c; a.R = op.se_reduced; a.ldc = yr_round_up(in.c, 4); a.ld_mean = in.ld; a.ld_gate = op.out_ld;
     YR_REQUIRE(op.out_ld >= a.ldc, "se_fc: gate ld too small");
-    const size_t lds = (size_t)(a.ldc + a.R + SE_FC_THREADS) * sizeof(float);
+    const size_t lds = (size_t)((a.ldc + a.R + SE_FC_THREADS + 3) & ~3) * sizeof(float) + (a.HW > 1 ? SE_FC_THREADS * sizeof(float4) : 0);
     YR_REQUIRE(lds <= 64 * 1024, "se_fc: widths too large for LDS");
     yr_note_kernel("se_fc_kernel");
     hipLaunchKernelGGL(se_fc_kernel, dim3(batch), dim3(SE_FC_THREADS), lds, s, a);
