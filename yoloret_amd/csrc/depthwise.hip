@@ -139,7 +139,9 @@ int yr_launch_depthwise(const yr_op& op, int batch, hipStream_t s) {
     a.act = op.act;
     // small maps (13x13, 26x26) keep 1-row patches so the grid still fills the chip
     const bool big = (long long)batch * a.Ho * a.Wo * a.C4 >= (1ll << 21);
-    if (op.k == 3 && op.stride == 1) return big ? launch_dw<3, 1, 4, 2>(a, s) : launch_dw<3, 1, 4, 1>(a, s);
+    // stride 1: 4x1 patches beat 4x2, 2x1, 2x2, 8x1 and 13x1 on every 13/26/52 map of the flagship (tools/dw_probe.py):
+    // the neighbouring rows' re-reads hit L2, and the shorter patch keeps more loads in flight per CU
+    if (op.k == 3 && op.stride == 1) return launch_dw<3, 1, 4, 1>(a, s);
     if (op.k == 3 && op.stride == 2) return big ? launch_dw<3, 2, 2, 2>(a, s) : launch_dw<3, 2, 2, 1>(a, s);
     if (op.k == 5 && op.stride == 1) return launch_dw<5, 1, 4, 1>(a, s);
     return launch_dw<5, 2, 2, 1>(a, s);

@@ -19,91 +19,6 @@
 
 #include "pw_common.h"
 
-// One output row (pixel) of the activation operand: where its channels come from.
-// MODE 0: generic gather (upsample / maxpool / concat sources), 1: one identity source, 2: identity + SE gate.
-template <int MODE>
-struct PwRow {
-    const float* arow;               // MODE != 0: the pixel's contiguous row
-    const float* grow;               // MODE == 2: SE gate row of the pixel's image
-    const float* srow[YR_MAX_SRC];   // MODE == 0: per-source row pointer (xform folded in)
-    bool valid;
-
-    __device__ __forceinline__ void init(const PwArgs& a, int m) {
-        valid = m < a.M;
-        const int mm = pw_pixel_of_row(a, valid ? m : 0);
-        const int hw = a.H * a.W;
-        const int b = mm / hw;
-        grow = MODE == 2 ? a.gate + (size_t)b * a.gate_ld : nullptr;
-        arow = nullptr;
-        if (MODE != 0) {
-            arow = a.S.s[0].ptr + (size_t)mm * a.S.s[0].ld;
-        } else {
-            const int rem = mm - b * hw;
-            const int y = rem / a.W, x = rem - y * a.W;
-#pragma unroll
-            for (int si = 0; si < YR_MAX_SRC; ++si) {
-                const DSrc& d = a.S.s[si];
-                int sy = y, sx = x;
-                if (d.xform == YR_X_UP2) { sy = y >> 1; sx = x >> 1; }
-                else if (d.xform == YR_X_MAXPOOL2) { sy = y * 2; sx = x * 2; }
-                else if (d.xform == YR_X_MAXPOOL4) { sy = y * 4; sx = x * 4; }
-                srow[si] = d.ptr + ((size_t)(b * d.h + sy) * d.w + sx) * d.ld;
-            }
-        }
-    }
-
-    // Issue the loads of the quad at k (raw k may lie beyond kp: clamped).  v: raw channels, gt: gate quad
-    // (MODE 2), cv: how many of the quad's channels are real (<= 0: none).  Nothing here reads a loaded
-    // register and every load is unconditional: rows beyond M read row 0 (their outputs are never stored), the
-    // k tail re-reads the last quad (zeroed through cv).  Loads under divergent branches make the compiler's
-    // s_waitcnt insertion stop counting and emit vmcnt(0), which serialises every prefetch behind the newest load.
-    __device__ __forceinline__ void issue(const PwArgs& a, int kraw, int kp, float4& v, float4& gt, int& cv) const {
-        const int k = kraw < kp ? kraw : kp - 4;
-        int cvalid;
-        if (MODE != 0) {
-            v = *reinterpret_cast<const float4*>(arow + k);
-            cvalid = a.S.s[0].c - k;
-            if (MODE == 2) gt = *reinterpret_cast<const float4*>(grow + k);
-        } else {
-            // segment of this quad (kbase of unused segments is huge), then a pre-offset row pointer
-            int si = 0;
-#pragma unroll
-            for (int i = 1; i < YR_MAX_SRC; ++i)
-                if (k >= a.S.s[i].kbase) si = i;
-            const float* rp = srow[0];
-            int kb = a.S.s[0].kbase, cc = a.S.s[0].c, xf = a.S.s[0].xform, sw = a.S.s[0].w, sld = a.S.s[0].ld;
-#pragma unroll
-            for (int i = 1; i < YR_MAX_SRC; ++i)
-                if (si == i) { rp = srow[i]; kb = a.S.s[i].kbase; cc = a.S.s[i].c; xf = a.S.s[i].xform; sw = a.S.s[i].w; sld = a.S.s[i].ld; }
-            rp += k - kb;
-            v = *reinterpret_cast<const float4*>(rp);
-            if (xf == YR_X_MAXPOOL2) {  // pooled sources are reduced here (the only path that waits at issue):
-                // the three other taps are issued together - ONE round trip, not one per tap
-                const float4 v1 = *reinterpret_cast<const float4*>(rp + sld);
-                const float4 v2 = *reinterpret_cast<const float4*>(rp + (size_t)sw * sld);
-                const float4 v3 = *reinterpret_cast<const float4*>(rp + ((size_t)sw + 1) * sld);
-                v = yr_max4(yr_max4(v, v1), yr_max4(v2, v3));
-            } else if (xf == YR_X_MAXPOOL4) {
-                for (int dy = 0; dy < 4; ++dy)
-                    for (int dx = 0; dx < 4; ++dx)
-                        v = yr_max4(v, *reinterpret_cast<const float4*>(rp + ((size_t)dy * sw + dx) * sld));
-            }
-            cvalid = cc - (k - kb);
-        }
-        cv = (valid && kraw < kp) ? cvalid : 0;
-    }
-};
-
-// the fetched quad with pad lanes zeroed (the source's pad lanes and the gate's may hold anything) and gated
-template <int MODE>
-__device__ __forceinline__ float4 pw_finish(float4 v, const float4& gt, int cvalid) {
-    v.x = cvalid > 0 ? (MODE == 2 ? v.x * gt.x : v.x) : 0.f;
-    v.y = cvalid > 1 ? (MODE == 2 ? v.y * gt.y : v.y) : 0.f;
-    v.z = cvalid > 2 ? (MODE == 2 ? v.z * gt.z : v.z) : 0.f;
-    v.w = cvalid > 3 ? (MODE == 2 ? v.w * gt.w : v.w) : 0.f;
-    return v;
-}
-
 // ------------------------------------------------------------------------------------------ direct kernel
 // Every wave owns 16*PT pixels x 16*CT couts and loads BOTH MFMA operands straight from global memory in the
 // operand layout (lane l: row l&15, k quad l>>4 - one 64-byte segment per row and instruction; measured on

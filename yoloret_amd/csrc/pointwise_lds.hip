@@ -1,14 +1,18 @@
 // Pointwise (1x1) convolution, LDS-staged MFMA kernel (see pointwise.hip for the GEMM view, the direct
 // variant and the dispatcher).  A 16-wide k chunk is staged in LDS by coalesced loads (4 adjacent lanes = 64
 // bytes of a row); lane group g reads k = k0+4g..4g+3 as one ds_read_b128 and uses component s in MFMA step s.
-// The next chunk's global loads are issued before the current chunk's MFMAs (register double buffering).
+// The next chunk's (small tiles: the next two chunks') global loads are issued before the current chunk's MFMAs
+// (register double buffering); every load is unconditional, so the compiler waits for them by count.
+#include <type_traits>
+
 #include "pw_common.h"
 
 #ifndef PW_BK
 #define PW_BK 16                 // k depth staged per barrier pair (multiple of 16; measured: 32 is 6 % and 64 is 13 % slower end to end)
 #endif
 #ifndef PW_PF2_MAX_TILES
-#define PW_PF2_MAX_TILES 0       // tiles (PT*CT) per wave up to which TWO k chunks are prefetched (measured: never pays here)
+#define PW_PF2_MAX_TILES 4       // tiles (PT*CT) per wave up to which TWO k chunks are prefetched (measured end to end:
+                                 // 3 and 4 are equal, 6 is 1 % and "all" 1.5 % slower - the second register set costs occupancy)
 #endif
 #define PW_KQ (PW_BK / 4)        // float4 quads per staged row
 #define PW_RPP (256 / PW_KQ)     // rows loaded per pass of the 256 threads
@@ -42,165 +46,118 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
 
     // loader mapping: quad kq of row lr (+64 per pass)
     const int lr = tid / PW_KQ, kq = tid % PW_KQ;
-    bool pv[A_PASSES];
-    const float* arow[A_PASSES];               // SIMPLE: the pixel's row
-    const float* grow[A_PASSES];               // SE gate row of the pixel's image (or null)
-    const float* srow[A_PASSES][YR_MAX_SRC];   // generic: per-source row pointer of the pixel (xform folded in)
-#pragma unroll
-    for (int p = 0; p < A_PASSES; ++p) {
-        const int m = m0 + lr + p * PW_RPP;
-        pv[p] = m < a.M;
-        const int mm = pw_pixel_of_row(a, pv[p] ? m : 0);
-        const int hw = a.H * a.W;
-        const int b = mm / hw;
-        grow[p] = a.gate ? a.gate + (size_t)b * a.gate_ld : nullptr;
-        if (SIMPLE) {
-            arow[p] = a.S.s[0].ptr + (size_t)mm * a.S.s[0].ld;
-        } else {
-            arow[p] = nullptr;
-            const int rem = mm - b * hw;
-            const int y = rem / a.W, x = rem - y * a.W;
-#pragma unroll
-            for (int si = 0; si < YR_MAX_SRC; ++si) {
-                const DSrc& d = a.S.s[si];
-                int sy = y, sx = x;
-                if (d.xform == YR_X_UP2) { sy = y >> 1; sx = x >> 1; }
-                else if (d.xform == YR_X_MAXPOOL2) { sy = y * 2; sx = x * 2; }
-                else if (d.xform == YR_X_MAXPOOL4) { sy = y * 4; sx = x * 4; }
-                srow[p][si] = d.ptr + ((size_t)(b * d.h + sy) * d.w + sx) * d.ld;
-            }
-        }
-    }
+    constexpr int MODE = SIMPLE ? 2 : 0;
+    const bool gated = SIMPLE && a.gate != nullptr;
+    PwRow<MODE> row[A_PASSES];
+    pw_unroll<A_PASSES>([&](auto P) __attribute__((always_inline)) {
+        constexpr int p = decltype(P)::value;
+        row[p].init(a, m0 + lr + p * PW_RPP);
+        if (SIMPLE && !gated) row[p].grow = a.wt;  // ungated: the gate load becomes a (cached, ignored) weight quad
+    });
     const float* brow[B_PASSES];
-    bool bvld[B_PASSES];
-#pragma unroll
-    for (int p = 0; p < B_PASSES; ++p) {
+    pw_unroll<B_PASSES>([&](auto P) __attribute__((always_inline)) {
+        constexpr int p = decltype(P)::value;
         const int n = n0 + lr + p * PW_RPP;
-        bvld[p] = (lr + p * PW_RPP < BN) && n < a.N;
-        brow[p] = a.wt + (size_t)(bvld[p] ? n : 0) * kp;
-    }
+        brow[p] = a.wt + (size_t)(n < a.N ? n : 0) * kp;  // rows beyond N feed couts that are never stored
+    });
 
-    // fetch() only ISSUES loads (raw values + the pixel's gate quad); masking and the gate multiply happen in
-    // stage(), one iteration later, right before the LDS store.  Touching the loaded registers inside fetch()
-    // would put the s_waitcnt - a full L2/HBM round trip - in front of the MFMAs of every k chunk.
-    struct Regs {
-        float4 ra[A_PASSES], rg[A_PASSES], rb[B_PASSES];
-        int cv[A_PASSES];  // valid channels in the fetched quad (<= 0: none)
-    };
-    auto fetch = [&](int k0, Regs& R) {
-        const int k = k0 + kq * 4;
-#pragma unroll
-        for (int p = 0; p < A_PASSES; ++p) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 gt = make_float4(1.f, 1.f, 1.f, 1.f);
-            int cvalid = 0;
-            if (pv[p] && k < kp) {
-                if (SIMPLE) {
-                    v = *reinterpret_cast<const float4*>(arow[p] + k);
-                    cvalid = a.S.s[0].c - k;
-                } else {
-                    // segment of this quad (kbase of unused segments is huge), then a pre-offset row pointer
-                    int si = 0;
-#pragma unroll
-                    for (int i = 1; i < YR_MAX_SRC; ++i)
-                        if (k >= a.S.s[i].kbase) si = i;
-                    const float* rp = srow[p][0];
-                    int kb = a.S.s[0].kbase, cc = a.S.s[0].c, xf = a.S.s[0].xform, sw = a.S.s[0].w, sld = a.S.s[0].ld;
-#pragma unroll
-                    for (int i = 1; i < YR_MAX_SRC; ++i)
-                        if (si == i) { rp = srow[p][i]; kb = a.S.s[i].kbase; cc = a.S.s[i].c; xf = a.S.s[i].xform; sw = a.S.s[i].w; sld = a.S.s[i].ld; }
-                    rp += k - kb;
-                    v = *reinterpret_cast<const float4*>(rp);
-                    if (xf == YR_X_MAXPOOL2) {  // pooled sources are reduced here (the only path that waits in fetch):
-                        // the three other taps are issued together - ONE round trip, not one per tap
-                        const float4 v1 = *reinterpret_cast<const float4*>(rp + sld);
-                        const float4 v2 = *reinterpret_cast<const float4*>(rp + (size_t)sw * sld);
-                        const float4 v3 = *reinterpret_cast<const float4*>(rp + ((size_t)sw + 1) * sld);
-                        v = yr_max4(yr_max4(v, v1), yr_max4(v2, v3));
-                    } else if (xf == YR_X_MAXPOOL4) {
-                        for (int dy = 0; dy < 4; ++dy)
-                            for (int dx = 0; dx < 4; ++dx)
-                                v = yr_max4(v, *reinterpret_cast<const float4*>(rp + ((size_t)dy * sw + dx) * sld));
-                    }
-                    cvalid = cc - (k - kb);
-                }
-                if (grow[p] != nullptr) gt = *reinterpret_cast<const float4*>(grow[p] + k);
-            }
-            R.ra[p] = v; R.rg[p] = gt; R.cv[p] = cvalid;
-        }
-#pragma unroll
-        for (int p = 0; p < B_PASSES; ++p) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bvld[p] && k < kp) v = *reinterpret_cast<const float4*>(brow[p] + k);
-            R.rb[p] = v;
-        }
-    };
-    // the fetched quad with pad lanes zeroed (the source's pad lanes and the gate's may hold anything) and gated
-    auto staged = [&](const Regs& R, int p) {
-        float4 v = R.ra[p];
-        const float4 gt = R.rg[p];
-        const int cvalid = R.cv[p];
-        v.x = cvalid > 0 ? v.x * gt.x : 0.f;
-        v.y = cvalid > 1 ? v.y * gt.y : 0.f;
-        v.z = cvalid > 2 ? v.z * gt.z : 0.f;
-        v.w = cvalid > 3 ? v.w * gt.w : 0.f;
-        return v;
-    };
-
+    const int g = lane >> 4, li = lane & 15;
     f32x4 acc[CT][PT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int p = 0; p < PT; ++p) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int g = lane >> 4, li = lane & 15;
-    // One k chunk: registers -> LDS, barrier, refill the register set with the chunk DEPTH ahead, fragments + MFMA,
-    // barrier.  Small tiles (<= 4 MFMA tiles per wave: <= 512 matrix cycles per chunk) keep two chunks of global
-    // loads in flight, larger ones one (their MFMA phase already covers an L2 round trip; the extra registers cost
-    // occupancy: measured).
-    constexpr int DEPTH = (PT * CT <= PW_PF2_MAX_TILES) ? 2 : 1;
-    auto step = [&](int k0, Regs& R) {
+    // The k loop, instantiated with and without pooled-source support: only the rare pooled gathers pay for the
+    // branches (and the vmcnt(0) waits they force) around the extra taps.
+    auto k_loop = [&](auto pools_tag) __attribute__((always_inline)) {
+        constexpr bool POOLS = decltype(pools_tag)::value;
+        // fetch() only ISSUES loads (raw values + the pixel's gate quad), all of them unconditional (PwRow::issue):
+        // masking and the gate multiply happen in stage(), one or two chunks later, right before the LDS store.
+        // Touching the loaded registers inside fetch() would put the s_waitcnt - a full L2/HBM round trip - in
+        // front of the MFMAs of every k chunk.
+        struct Regs {
+            float4 ra[A_PASSES], rg[A_PASSES], rb[B_PASSES];
+            int cv[A_PASSES];  // valid channels in the fetched quad (<= 0: none)
+        };
+        auto fetch = [&](int k0, Regs& R) __attribute__((always_inline)) {
+            const int kraw = k0 + kq * 4;
+            const int k = kraw < kp ? kraw : kp - 4;
+            pw_unroll<A_PASSES>([&](auto P) __attribute__((always_inline)) {
+                constexpr int p = decltype(P)::value;
+                row[p].template issue<POOLS>(a, kraw, kp, R.ra[p], R.rg[p], R.cv[p]);
+            });
+            pw_unroll<B_PASSES>([&](auto P) __attribute__((always_inline)) {
+                constexpr int p = decltype(P)::value;
+                R.rb[p] = *reinterpret_cast<const float4*>(brow[p] + k);
+            });
+        };
+
+        // One k chunk: registers -> LDS, barrier, refill the register set with the chunk DEPTH ahead, fragments + MFMA,
+        // barrier.  With DEPTH 2 two chunks of global loads are in flight per wave; the loop body is two steps on
+        // alternating register sets and every fetch is unconditional, so the compiler counts the outstanding loads
+        // exactly and a step waits only for ITS set.  A dead step (odd chunk count) stages zeros and skips the MFMAs.
+        constexpr int DEPTH = (PT * CT <= PW_PF2_MAX_TILES) ? 2 : 1;
+        auto step = [&](int k0, Regs& R, bool live) __attribute__((always_inline)) {
+            pw_unroll<A_PASSES>([&](auto P) __attribute__((always_inline)) {
+                constexpr int p = decltype(P)::value;
+                const float4 v = gated ? pw_finish<2>(R.ra[p], R.rg[p], R.cv[p]) : pw_finish<1>(R.ra[p], R.rg[p], R.cv[p]);
+                *reinterpret_cast<float4*>(As + (lr + p * PW_RPP) * PW_LDS_LD + kq * 4) = v;
+            });
+            pw_unroll<B_PASSES>([&](auto P) __attribute__((always_inline)) {
+                constexpr int p = decltype(P)::value;
+                const float4 v = R.rb[p];
+                if ((p + 1) * PW_RPP <= BN || lr + p * PW_RPP < BN)  // only a partial last pass tests the lane
+                    *reinterpret_cast<float4*>(Bs + (lr + p * PW_RPP) * PW_LDS_LD + kq * 4) = v;
+            });
+            __syncthreads();
+            fetch(k0 + DEPTH * PW_BK, R);
+            // fragments + MFMA, 16 k per sub-step (sub-steps wholly beyond kp are skipped: uniform)
+            if (live) {
 #pragma unroll
-        for (int p = 0; p < A_PASSES; ++p)
-            *reinterpret_cast<float4*>(As + (lr + p * PW_RPP) * PW_LDS_LD + kq * 4) = staged(R, p);
+                for (int kk = 0; kk < PW_BK; kk += 16) {
+                    if (k0 + kk >= kp) break;
+                    f32x4 wf[CT], xf[PT];
 #pragma unroll
-        for (int p = 0; p < B_PASSES; ++p)
-            if (lr + p * PW_RPP < BN) *reinterpret_cast<float4*>(Bs + (lr + p * PW_RPP) * PW_LDS_LD + kq * 4) = R.rb[p];
-        __syncthreads();
-        if (k0 + DEPTH * PW_BK < kp) fetch(k0 + DEPTH * PW_BK, R);
-        // fragments + MFMA, 16 k per sub-step (sub-steps wholly beyond kp are skipped: uniform)
-#pragma unroll
-        for (int kk = 0; kk < PW_BK; kk += 16) {
-            if (k0 + kk >= kp) break;
-            f32x4 wf[CT], xf[PT];
-#pragma unroll
-            for (int c = 0; c < CT; ++c)
-                wf[c] = *reinterpret_cast<const f32x4*>(Bs + ((wn * CT + c) * 16 + li) * PW_LDS_LD + kk + g * 4);
-#pragma unroll
-            for (int p = 0; p < PT; ++p)
-                xf[p] = *reinterpret_cast<const f32x4*>(As + ((wm * PT + p) * 16 + li) * PW_LDS_LD + kk + g * 4);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int c = 0; c < CT; ++c)
+                    for (int c = 0; c < CT; ++c)
+                        wf[c] = *reinterpret_cast<const f32x4*>(Bs + ((wn * CT + c) * 16 + li) * PW_LDS_LD + kk + g * 4);
 #pragma unroll
                     for (int p = 0; p < PT; ++p)
-                        acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][s], xf[p][s], acc[c][p], 0, 0, 0);
+                        xf[p] = *reinterpret_cast<const f32x4*>(As + ((wm * PT + p) * 16 + li) * PW_LDS_LD + kk + g * 4);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int c = 0; c < CT; ++c)
+#pragma unroll
+                            for (int p = 0; p < PT; ++p)
+                                acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][s], xf[p][s], acc[c][p], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        };
+        Regs R0;
+        fetch(0, R0);
+        if constexpr (DEPTH == 2) {
+            Regs R1;
+            __builtin_amdgcn_sched_barrier(0);  // R0's loads must be issued first: the loop waits for them by COUNT
+            fetch(PW_BK, R1);
+            __builtin_amdgcn_sched_barrier(0);
+            for (int k0 = 0; k0 < kp; k0 += 2 * PW_BK) {
+                step(k0, R0, true);
+                step(k0 + PW_BK, R1, k0 + PW_BK < kp);
+            }
+        } else {
+            for (int k0 = 0; k0 < kp; k0 += PW_BK) step(k0, R0, true);
         }
-        __syncthreads();
     };
-    Regs R0;
-    fetch(0, R0);
-    if constexpr (DEPTH == 2) {
-        Regs R1;
-        fetch(PW_BK, R1);  // beyond kp: zeros, never staged
-        for (int k0 = 0; k0 < kp; k0 += 2 * PW_BK) {
-            step(k0, R0);
-            if (k0 + PW_BK < kp) step(k0 + PW_BK, R1);
-        }
-    } else {
-        for (int k0 = 0; k0 < kp; k0 += PW_BK) step(k0, R0);
+    bool pooled = false;
+    if (!SIMPLE) {
+#pragma unroll
+        for (int i = 0; i < YR_MAX_SRC; ++i)
+            pooled |= a.S.s[i].xform == YR_X_MAXPOOL2 || a.S.s[i].xform == YR_X_MAXPOOL4;
     }
+    if (pooled) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
 
     // ---- epilogue: BN scale/shift, activation, residual, store (4 consecutive couts per lane)
     const bool vec_out = (a.out_ld & 3) == 0;

@@ -1,9 +1,30 @@
 // Shared by pointwise.hip (direct kernel + dispatcher) and pointwise_lds.hip (LDS-staged kernel).
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "yr_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at a dword-aligned address
+typedef f32x4 __attribute__((address_space(1))) pw_gf4;                // 4 floats in GLOBAL memory (global_load, not flat_load)
+__device__ __forceinline__ float4 pw_ldg(const pw_gf4* q, size_t i = 0) {
+    const f32x4 v = q[i];  // a native vector: HIP's float4 class would bind a generic reference and load flat again
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): loops over register arrays whose indices are
+// constants for the FRONT END.  A `#pragma unroll` loop is unrolled late; until then the arrays are stack objects
+// with a dynamic index, and what the optimiser does to them in between (address selects, conditional accesses)
+// can leave them in scratch memory for good.
+template <class F, int... I>
+__device__ __forceinline__ void pw_unroll_impl(F& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void pw_unroll(F f) {
+    pw_unroll_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 struct PwArgs {
     DSrcSet S;
@@ -57,6 +78,119 @@ __device__ __forceinline__ void pw_pre_addend(const PwArgs& a, int m, int n, flo
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (n + r < a.N) p[r] = src[r];
+}
+
+// One output row (pixel) of the activation operand: where its channels come from.
+// MODE 0: generic gather (upsample / maxpool / concat sources), 1: one identity source, 2: identity + SE gate.
+// The per-source row pointers are four named members, not an array: after unrolling, LLVM folds a select between
+// loads of two array slots into ONE load with a selected address, which pins the array in scratch memory and puts
+// a scratch round trip in front of every activation load.
+static_assert(YR_MAX_SRC == 4, "PwRow spells out four sources");
+template <int MODE>
+struct PwRow {
+    const float* arow;               // MODE != 0: the pixel's contiguous row
+    const float* grow;               // MODE == 2: SE gate row of the pixel's image
+    const float *s0, *s1, *s2, *s3;  // MODE == 0: per-source row pointer (xform folded in)
+    bool valid;
+
+    static __device__ __forceinline__ const float* source_row(const DSrc& d, int b, int y, int x) {
+        int sy = y, sx = x;
+        if (d.xform == YR_X_UP2) { sy = y >> 1; sx = x >> 1; }
+        else if (d.xform == YR_X_MAXPOOL2) { sy = y * 2; sx = x * 2; }
+        else if (d.xform == YR_X_MAXPOOL4) { sy = y * 4; sx = x * 4; }
+        return d.ptr + ((size_t)(b * d.h + sy) * d.w + sx) * d.ld;
+    }
+
+    __device__ __forceinline__ void init(const PwArgs& a, int m) {
+        valid = m < a.M;
+        const int mm = pw_pixel_of_row(a, valid ? m : 0);
+        const int hw = a.H * a.W;
+        const int b = mm / hw;
+        grow = MODE == 2 ? a.gate + (size_t)b * a.gate_ld : nullptr;
+        arow = s0 = s1 = s2 = s3 = nullptr;
+        if (MODE != 0) {
+            arow = a.S.s[0].ptr + (size_t)mm * a.S.s[0].ld;
+        } else {
+            const int rem = mm - b * hw;
+            const int y = rem / a.W, x = rem - y * a.W;
+            s0 = source_row(a.S.s[0], b, y, x) - a.S.s[0].kbase;  // pre-offset: channel k of the conv is s_i[k]
+            s1 = source_row(a.S.s[1], b, y, x) - a.S.s[1].kbase;
+            s2 = source_row(a.S.s[2], b, y, x) - a.S.s[2].kbase;
+            s3 = source_row(a.S.s[3], b, y, x) - a.S.s[3].kbase;
+        }
+    }
+
+    // Issue the loads of the quad at k (raw k may lie beyond kp: clamped).  v: raw channels, gt: gate quad
+    // (MODE 2), cv: how many of the quad's channels are real (<= 0: none).  Nothing here reads a loaded
+    // register and the main load is unconditional: rows beyond M read row 0 (their outputs are never stored), the
+    // k tail re-reads the last quad (zeroed through cv).  When EVERY load sits under a branch the compiler's
+    // s_waitcnt insertion must assume the path that issued none and emits vmcnt(0), which serialises every
+    // prefetch behind the newest load; only the extra taps of pooled sources stay conditional here.
+    // POOLS = false promises that no source is pooled (the caller checked): the code is then straight-line.
+    template <bool POOLS = true>
+    __device__ __forceinline__ void issue(const PwArgs& a, int kraw, int kp, float4& v, float4& gt, int& cv) const {
+        const int k = kraw < kp ? kraw : kp - 4;
+        int cvalid;
+        if (MODE != 0) {
+            v = *reinterpret_cast<const float4*>(arow + k);
+            cvalid = a.S.s[0].c - k;
+            if (MODE == 2) gt = *reinterpret_cast<const float4*>(grow + k);
+        } else {
+            // segment of this quad (kbase ascends; unused segments have a huge kbase).  Everything that is picked
+            // per lane is first made an opaque VALUE (empty asm / readfirstlane): a select between two loads (of
+            // stack slots or of kernel-argument fields) is otherwise folded into ONE load from a selected address -
+            // scratch traffic for the pointers, a per-lane global load of the argument block for the fields.
+            const bool g1 = k >= a.S.s[1].kbase, g2 = k >= a.S.s[2].kbase, g3 = k >= a.S.s[3].kbase;
+            const float *p0 = s0, *p1 = s1, *p2 = s2, *p3 = s3;  // pre-offset by -kbase (init)
+            asm("" : "+v"(p0));
+            asm("" : "+v"(p1));
+            asm("" : "+v"(p2));
+            asm("" : "+v"(p3));
+            const float* rp = g3 ? p3 : g2 ? p2 : g1 ? p1 : p0;
+#define PW_PICK(name, e0, e1, e2, e3)                                                                   \
+    const int name##0 = __builtin_amdgcn_readfirstlane(e0), name##1 = __builtin_amdgcn_readfirstlane(e1), \
+              name##2 = __builtin_amdgcn_readfirstlane(e2), name##3 = __builtin_amdgcn_readfirstlane(e3); \
+    const int name = g3 ? name##3 : g2 ? name##2 : g1 ? name##1 : name##0;
+            PW_PICK(kend, a.S.s[0].kbase + a.S.s[0].c, a.S.s[1].kbase + a.S.s[1].c, a.S.s[2].kbase + a.S.s[2].c,
+                    a.S.s[3].kbase + a.S.s[3].c)
+            cvalid = kend - k;
+            // the selected pointer is spelled as a GLOBAL one: a generic (flat) load would also count on lgkmcnt, so
+            // every wait for an LDS read would wait for the prefetch as well
+            const pw_gf4* q = (const pw_gf4*)(rp + k);
+            v = pw_ldg(q);
+            int xf = 0, sw = 0, sld = 0;
+            if (POOLS) {
+                PW_PICK(xfp, a.S.s[0].xform, a.S.s[1].xform, a.S.s[2].xform, a.S.s[3].xform)
+                PW_PICK(swp, a.S.s[0].w, a.S.s[1].w, a.S.s[2].w, a.S.s[3].w)
+                PW_PICK(sldp, a.S.s[0].ld, a.S.s[1].ld, a.S.s[2].ld, a.S.s[3].ld)
+                xf = xfp; sw = swp; sld = sldp;
+            }
+#undef PW_PICK
+            if (!POOLS) {
+            } else if (xf == YR_X_MAXPOOL2) {  // pooled sources are reduced here (the only path that waits at issue):
+                // the three other taps are issued together - ONE round trip, not one per tap (sld % 4 == 0)
+                const float4 v1 = pw_ldg(q, sld >> 2);
+                const float4 v2 = pw_ldg(q, ((size_t)sw * sld) >> 2);
+                const float4 v3 = pw_ldg(q, (((size_t)sw + 1) * sld) >> 2);
+                v = yr_max4(yr_max4(v, v1), yr_max4(v2, v3));
+            } else if (xf == YR_X_MAXPOOL4) {
+                for (int dy = 0; dy < 4; ++dy)
+                    for (int dx = 0; dx < 4; ++dx)
+                        v = yr_max4(v, pw_ldg(q, (((size_t)dy * sw + dx) * sld) >> 2));
+            }
+        }
+        cv = (valid && kraw < kp) ? cvalid : 0;
+    }
+};
+
+// the fetched quad with pad lanes zeroed (the source's pad lanes and the gate's may hold anything) and gated
+template <int MODE>
+__device__ __forceinline__ float4 pw_finish(float4 v, const float4& gt, int cvalid) {
+    v.x = cvalid > 0 ? (MODE == 2 ? v.x * gt.x : v.x) : 0.f;
+    v.y = cvalid > 1 ? (MODE == 2 ? v.y * gt.y : v.y) : 0.f;
+    v.z = cvalid > 2 ? (MODE == 2 ? v.z * gt.z : v.z) : 0.f;
+    v.w = cvalid > 3 ? (MODE == 2 ? v.w * gt.w : v.w) : 0.f;
+    return v;
 }
 
 // LDS-staged kernel, tile shape index 0..13: (BM x BN) = 256x16, 128x32, 128x48, 128x64, 128x80, 128x96, 128x128,

@@ -4,7 +4,9 @@
 // code/yolo3/model.py:170-342, called at code/yolo.py:152 and code/yolo3/map.py:111).
 #include <string.h>
 
+#include <algorithm>
 #include <map>
+#include <utility>
 #include <vector>
 
 #include "yr_common.h"
@@ -253,18 +255,68 @@ extern "C" int yr_autotune(yr_handle* h, const float* images, int batch, float* 
         yr_op op;
         rc = resolve_op(h, i, batch, ext, static_cast<float*>(workspace), &op);
         if (rc) break;
-        float best_ms = 1e30f;
-        for (int c = 0; c <= ncfg && rc == YR_OK; ++c) {   // c == 0: the heuristic's own pick
+        auto time_cfg = [&](int c, float* ms) -> int {
             op.k = c;
-            rc = dispatch(op, batch, s);                    // warm-up
-            if (rc) break;
+            int r = dispatch(op, batch, s);                 // warm-up
+            if (r) return r;
             YR_CHECK_HIP(hipEventRecord(e0, s));
-            for (int it = 0; it < iters && rc == YR_OK; ++it) rc = dispatch(op, batch, s);
+            for (int it = 0; it < iters && r == YR_OK; ++it) r = dispatch(op, batch, s);
             YR_CHECK_HIP(hipEventRecord(e1, s));
             YR_CHECK_HIP(hipEventSynchronize(e1));
+            YR_CHECK_HIP(hipEventElapsedTime(ms, e0, e1));
+            return r;
+        };
+        // The launch as the forward pass sees it: right behind its predecessor (whose tail it overlaps and whose
+        // output is what the caches hold), one launch per sample.  Back-to-back repeats of one op flatter some
+        // shapes by up to 30 % (measured: td2_conv, block_7_expand).
+        yr_op prev;
+        bool have_prev = false;
+        if (i > 0) {
+            rc = resolve_op(h, i - 1, batch, ext, static_cast<float*>(workspace), &prev);
+            if (rc) break;
+            if (h->ops[i - 1].kind == YR_OP_POINTWISE) prev.k = best[i - 1];
+            have_prev = true;
+        }
+        auto time_in_context = [&](int c, float* ms) -> int {
+            op.k = c;
+            *ms = 1e30f;
+            for (int it = 0; it < iters; ++it) {
+                int r = have_prev ? dispatch(prev, batch, s) : YR_OK;
+                if (r) return r;
+                YR_CHECK_HIP(hipEventRecord(e0, s));
+                r = dispatch(op, batch, s);
+                if (r) return r;
+                YR_CHECK_HIP(hipEventRecord(e1, s));
+                YR_CHECK_HIP(hipEventSynchronize(e1));
+                float t = 0.f;
+                YR_CHECK_HIP(hipEventElapsedTime(&t, e0, e1));
+                if (t < *ms) *ms = t;
+            }
+            return YR_OK;
+        };
+        // round 1: every shape, repeated launches (c == 0: the heuristic's own pick); round 2: the FINALISTS in
+        // context, interleaved, each scored by its minimum - one noisy sample must not crown (or sink) a shape
+        constexpr int FINALISTS = 5, ROUNDS = 3;
+        std::vector<std::pair<float, int>> first;
+        for (int c = 0; c <= ncfg && rc == YR_OK; ++c) {
             float ms = 0.f;
-            YR_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
-            if (ms < best_ms * 0.97f) { best_ms = ms; best[i] = c; }  // a later shape must win by >3 % (noise)
+            rc = time_cfg(c, &ms);
+            first.push_back({ms, c});
+        }
+        if (rc == YR_OK) {
+            std::stable_sort(first.begin(), first.end());
+            if ((int)first.size() > FINALISTS) first.resize(FINALISTS);
+            for (auto& f : first) f.first = 1e30f;
+            for (int r = 0; r < ROUNDS && rc == YR_OK; ++r)
+                for (auto& f : first) {
+                    float ms = 0.f;
+                    rc = time_in_context(f.second, &ms);
+                    if (rc) break;
+                    if (ms < f.first) f.first = ms;
+                }
+            float best_ms = 1e30f;
+            for (auto& f : first)   // earlier in round-1 order wins ties within 1 %
+                if (f.first < best_ms * 0.99f) { best_ms = f.first; best[i] = f.second; }
         }
         if (rc != YR_OK) rc = fail_op(i, h->ops[i].kind, rc);
     }
