@@ -23,7 +23,7 @@
 // common case: every backbone expand/project and most head convs); otherwise the generic gather
 // through per-source row pointers (upsample / maxpool / concat folded into the loads).
 template <int PT, int CT, int WM, int WN, bool SIMPLE>
-__global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
+__global__ __launch_bounds__(256, (PT * CT >= 16 ? 2 : 4)) void pw_kernel(PwArgs a) {
     constexpr int BM = 16 * PT * WM;
     constexpr int BN = 16 * CT * WN;
     constexpr int A_PASSES = BM / PW_RPP;
@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * PW_LDS_LD];
     float* As = lds;                   // [BM][PW_LDS_LD] activations
     float* Bs = lds + BM * PW_LDS_LD;  // [BN][PW_LDS_LD] weights
+    __shared__ __attribute__((aligned(16))) float ss[2 * BN];  // the tile's BN scale | shift (read by the epilogue)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -43,6 +44,14 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     const int m0 = (int)(L / ntn) * BM;
     const int n0 = (int)(L % ntn) * BN;
     const int kp = a.S.kp;
+
+    // the tile's BatchNorm scale / shift go to LDS now (behind the k loop's barriers by the time they are read):
+    // fetched in the epilogue they would cost every tile an L2 round trip with nothing left to hide it
+    if (tid < BN) {
+        const int n = n0 + tid < a.N ? n0 + tid : a.N - 1;
+        ss[tid] = a.scale ? a.scale[n] : 1.f;
+        ss[BN + tid] = a.shift ? a.shift[n] : 0.f;
+    }
 
     // loader mapping: quad kq of row lr (+64 per pass)
     const int lr = tid / PW_KQ, kq = tid % PW_KQ;
@@ -159,52 +168,54 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     if (pooled) k_loop(std::true_type{});
     else k_loop(std::false_type{});
 
-    // ---- epilogue: BN scale/shift, activation, residual, store (4 consecutive couts per lane)
+    // ---- epilogue: (pre-BN addend,) BN scale/shift, activation, (residual,) (2x2 max,) store: 4 consecutive couts
+    // per lane.  Branches are uniform or guard stores only; every load is unconditional (pw_load_quad): a load under
+    // a per-lane branch is followed by its own s_waitcnt, one L2 round trip per element group with nothing to hide it.
     const bool vec_out = (a.out_ld & 3) == 0;
+    const bool vec_res = (a.res_ld & 3) == 0, vec_pre = (a.pre_ld & 3) == 0;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-        const int n = n0 + (wn * CT + c) * 16 + g * 4;
-        if (n >= a.N) continue;
-        float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (n + r < a.N) {
-                if (a.scale) sc[r] = a.scale[n + r];
-                if (a.shift) sh[r] = a.shift[n + r];
-            }
+        const int nl = (wn * CT + c) * 16 + g * 4;
+        const int n = n0 + nl;
+        const int cnt = a.N - n;           // real couts in this quad (<= 0: none)
+        const int nld = cnt > 0 ? n : 0;   // the column dead quads load from
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(ss + nl);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(ss + BN + nl);
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
             const int m = m0 + (wm * PT + p) * 16 + li;
-            if (m >= a.M) continue;
-            float v[4], pa[4];
-            if (a.pre) {  // uniform: the low-resolution share of a hoisted concat conv joins the accumulator before BN
-                pw_pre_addend(a, m, n, pa);
+            const int ml = m < a.M ? m : a.M - 1;
+            float v[4], q[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[c][p][r] += pa[r];
+            for (int r = 0; r < 4; ++r) v[r] = acc[c][p][r];
+            if (a.pre) {  // uniform: the low-resolution share of a hoisted concat conv joins the accumulator before BN
+                pw_load_quad(a.pre, pw_pre_row(a, ml), a.pre_ld, nld, a.N, vec_pre, q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += q[r];
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = yr_apply_act(__builtin_fmaf(acc[c][p][r], sc[r], sh[r]), a.act);
-            if (a.res) {
-                const float* rp = a.res + (size_t)m * a.res_ld + n;
+            for (int r = 0; r < 4; ++r) v[r] = yr_apply_act(__builtin_fmaf(v[r], sc[r], sh[r]), a.act);
+            if (a.res) {  // uniform
+                pw_load_quad(a.res, (size_t)ml, a.res_ld, nld, a.N, vec_res, q);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < a.N) v[r] += rp[r];
+                for (int r = 0; r < 4; ++r) v[r] += q[r];
             }
             int orow = m;
+            bool keep = m < a.M && cnt > 0;
             if (a.pool) {  // uniform: MaxPooling2D(2) across the 4 adjacent lanes of a window (see pw_common.h)
                 pw_pool4(v);
-                if (li & 3) continue;
+                keep = keep && (li & 3) == 0;
                 orow = m >> 2;
             }
+            if (!keep) continue;
             float* op = a.out + (size_t)orow * a.out_ld + n;
-            if (vec_out && n + 3 < a.N) {
-                *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-            } else if (n + 3 < a.N) {
-                *reinterpret_cast<f32x4u*>(op) = (f32x4u){v[0], v[1], v[2], v[3]};  // dense rows: dword-aligned 16-byte store
+            if (cnt >= 4) {
+                if (vec_out) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                else *reinterpret_cast<f32x4u*>(op) = (f32x4u){v[0], v[1], v[2], v[3]};  // dense rows: dword-aligned 16-byte store
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < a.N) op[r] = v[r];
+                for (int r = 0; r < 3; ++r)
+                    if (r < cnt) op[r] = v[r];
             }
         }
     }

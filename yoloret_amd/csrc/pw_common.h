@@ -80,6 +80,29 @@ __device__ __forceinline__ void pw_pre_addend(const PwArgs& a, int m, int n, flo
         if (n + r < a.N) p[r] = src[r];
 }
 
+// Epilogue loads are UNCONDITIONAL (clamped addresses, results of dead lanes ignored): a load under a per-lane branch
+// is followed by its own s_waitcnt, and a tile's epilogue then pays one L2 round trip per element group instead of
+// one per tile.  Quad n..n+3 of row `row` ([.][ld] floats, N real channels, n a multiple of 4 and < N): one 16-byte
+// load when the pitch allows it (`vec`: ld % 4 == 0, so the quad lies inside the row), else four clamped dwords.
+__device__ __forceinline__ void pw_load_quad(const float* base, size_t row, int ld, int n, int N, bool vec, float (&q)[4]) {
+    const float* rp = base + row * ld;
+    if (vec) {
+        const float4 t = *reinterpret_cast<const float4*>(rp + n);
+        q[0] = t.x; q[1] = t.y; q[2] = t.z; q[3] = t.w;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q[r] = rp[n + r < N ? n + r : N - 1];
+    }
+}
+
+// Row of the YR_X_UP2_ADD source that output pixel m (a conv pixel, m < M) takes its pre-BatchNorm addend from.
+__device__ __forceinline__ size_t pw_pre_row(const PwArgs& a, int m) {
+    const int hw = a.H * a.W;
+    const int b = m / hw, rem = m - b * hw;
+    const int y = rem / a.W, x = rem - y * a.W;
+    return (size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1);
+}
+
 // One output row (pixel) of the activation operand: where its channels come from.
 // MODE 0: generic gather (upsample / maxpool / concat sources), 1: one identity source, 2: identity + SE gate.
 // The per-source row pointers are four named members, not an array: after unrolling, LLVM folds a select between
