@@ -22,8 +22,16 @@
 // SIMPLE: one identity source (optionally SE-gated) -> a pixel's channels are one contiguous row (the
 // common case: every backbone expand/project and most head convs); otherwise the generic gather
 // through per-source row pointers (upsample / maxpool / concat folded into the loads).
+// Blocks per CU the register allocator must make room for.  Left alone the compiler is generous (84-172 registers);
+// asked, it fits the same code into 54-128 without spilling (the exceptions below are the shapes that would spill;
+// 5 blocks for the 4-7 tile shapes measured no better than 4).
+constexpr int pw_min_blocks(int pt, int ct, bool simple) {
+    const int tiles = pt * ct;
+    return tiles >= 16 ? 2 : (pt == 4 && (ct == 1 || (!simple && ct >= 3))) ? 3 : tiles >= 4 ? 4 : 6;
+}
+
 template <int PT, int CT, int WM, int WN, bool SIMPLE>
-__global__ __launch_bounds__(256, (PT * CT >= 16 ? 2 : 4)) void pw_kernel(PwArgs a) {
+__global__ __launch_bounds__(256, pw_min_blocks(PT, CT, SIMPLE)) void pw_kernel(PwArgs a) {
     constexpr int BM = 16 * PT * WM;
     constexpr int BN = 16 * CT * WN;
     constexpr int A_PASSES = BM / PW_RPP;
