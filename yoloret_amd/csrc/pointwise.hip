@@ -111,58 +111,25 @@ __global__ __launch_bounds__(256) void pwd_kernel(PwArgs a) {
         }
     }
 
-    // ---- epilogue: BN scale/shift, activation, residual, store (4 consecutive couts per lane)
+    // ---- epilogue (pw_finish_quad): 4 consecutive couts per lane.  The BN scale / shift of ALL the wave's couts are
+    // fetched first, unconditionally (clamped): loads under per-lane branches each wait for their own round trip.
     const bool vec_out = (a.out_ld & 3) == 0;
+    const bool vec_res = (a.res_ld & 3) == 0, vec_pre = (a.pre_ld & 3) == 0;
+    f32x4 sc[CT], sh[CT];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        const int n = n0 + c * 16 + g * 4;
-        if (n >= a.N) continue;
-        float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (n + r < a.N) {
-                if (a.scale) sc[r] = a.scale[n + r];
-                if (a.shift) sh[r] = a.shift[n + r];
-            }
-#pragma unroll
-        for (int p = 0; p < PT; ++p) {
-            const int m = m0 + p * 16 + li;
-            if (m >= a.M) continue;
-            float v[4], pa[4];
-            if (a.pre) {  // uniform: the low-resolution share of a hoisted concat conv joins the accumulator before BN
-                pw_pre_addend(a, m, n, pa);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[c][p][r] += pa[r];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = yr_apply_act(__builtin_fmaf(acc[c][p][r], sc[r], sh[r]), a.act);
-            if (a.res) {
-                const float* rp = a.res + (size_t)m * a.res_ld + n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < a.N) v[r] += rp[r];
-            }
-            int orow = m;
-            if (a.pool) {  // uniform: MaxPooling2D(2) of the finished values; the window = 4 adjacent lanes (whole quads
-                pw_pool4(v);  // are valid or not together: M is a multiple of 4)
-                if (li & 3) continue;
-                orow = m >> 2;
-            }
-            float* op = a.out + (size_t)orow * a.out_ld + n;
-            if (vec_out && n + 3 < a.N) {
-                *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-            } else if (n + 3 < a.N) {
-                // dense rows (the 75-wide logit outputs): still ONE 16-byte store per lane, only 4-byte aligned
-                // (global_store_dwordx4 takes dword-aligned addresses); four dword stores per lane cost the y
-                // convs 40 % of their time
-                *reinterpret_cast<f32x4u*>(op) = (f32x4u){v[0], v[1], v[2], v[3]};
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < a.N) op[r] = v[r];
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + c * 16 + g * 4 + r;
+            const int nc = n < a.N ? n : a.N - 1;
+            sc[c][r] = a.scale ? a.scale[nc] : 1.f;
+            sh[c][r] = a.shift ? a.shift[nc] : 0.f;
         }
-    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+            pw_finish_quad(a, acc[c][p], sc[c], sh[c], m0 + p * 16 + li, n0 + c * 16 + g * 4, li, vec_out, vec_res, vec_pre);
 }
 
 template <int PT, int CT>

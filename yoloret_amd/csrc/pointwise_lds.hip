@@ -184,48 +184,11 @@ __global__ __launch_bounds__(256, pw_min_blocks(PT, CT, SIMPLE)) void pw_kernel(
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int nl = (wn * CT + c) * 16 + g * 4;
-        const int n = n0 + nl;
-        const int cnt = a.N - n;           // real couts in this quad (<= 0: none)
-        const int nld = cnt > 0 ? n : 0;   // the column dead quads load from
         const f32x4 sc = *reinterpret_cast<const f32x4*>(ss + nl);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(ss + BN + nl);
 #pragma unroll
-        for (int p = 0; p < PT; ++p) {
-            const int m = m0 + (wm * PT + p) * 16 + li;
-            const int ml = m < a.M ? m : a.M - 1;
-            float v[4], q[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[c][p][r];
-            if (a.pre) {  // uniform: the low-resolution share of a hoisted concat conv joins the accumulator before BN
-                pw_load_quad(a.pre, pw_pre_row(a, ml), a.pre_ld, nld, a.N, vec_pre, q);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += q[r];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = yr_apply_act(__builtin_fmaf(v[r], sc[r], sh[r]), a.act);
-            if (a.res) {  // uniform
-                pw_load_quad(a.res, (size_t)ml, a.res_ld, nld, a.N, vec_res, q);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += q[r];
-            }
-            int orow = m;
-            bool keep = m < a.M && cnt > 0;
-            if (a.pool) {  // uniform: MaxPooling2D(2) across the 4 adjacent lanes of a window (see pw_common.h)
-                pw_pool4(v);
-                keep = keep && (li & 3) == 0;
-                orow = m >> 2;
-            }
-            if (!keep) continue;
-            float* op = a.out + (size_t)orow * a.out_ld + n;
-            if (cnt >= 4) {
-                if (vec_out) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-                else *reinterpret_cast<f32x4u*>(op) = (f32x4u){v[0], v[1], v[2], v[3]};  // dense rows: dword-aligned 16-byte store
-            } else {
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-                    if (r < cnt) op[r] = v[r];
-            }
-        }
+        for (int p = 0; p < PT; ++p)
+            pw_finish_quad(a, acc[c][p], sc, sh, m0 + (wm * PT + p) * 16 + li, n0 + nl, li, vec_out, vec_res, vec_pre);
     }
 }
 

@@ -62,24 +62,6 @@ __device__ __forceinline__ void pw_pool4(float (&v)[4]) {
     }
 }
 
-// The pre-BatchNorm addend of output pixel m, couts n..n+3 (zeros without one): nearest 2x upsampling of `pre`.
-__device__ __forceinline__ void pw_pre_addend(const PwArgs& a, int m, int n, float (&p)[4]) {
-    p[0] = p[1] = p[2] = p[3] = 0.f;
-    if (a.pre == nullptr) return;
-    const int hw = a.H * a.W;
-    const int b = m / hw, rem = m - b * hw;
-    const int y = rem / a.W, x = rem - y * a.W;
-    const float* src = a.pre + ((size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.pre_ld + n;
-    if (n + 3 < a.N && (a.pre_ld & 3) == 0) {  // n is a multiple of 4: one 16-byte load
-        const float4 v = *reinterpret_cast<const float4*>(src);
-        p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
-        return;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (n + r < a.N) p[r] = src[r];
-}
-
 // Epilogue loads are UNCONDITIONAL (clamped addresses, results of dead lanes ignored): a load under a per-lane branch
 // is followed by its own s_waitcnt, and a tile's epilogue then pays one L2 round trip per element group instead of
 // one per tile.  Quad n..n+3 of row `row` ([.][ld] floats, N real channels, n a multiple of 4 and < N): one 16-byte
@@ -101,6 +83,50 @@ __device__ __forceinline__ size_t pw_pre_row(const PwArgs& a, int m) {
     const int b = m / hw, rem = m - b * hw;
     const int y = rem / a.W, x = rem - y * a.W;
     return (size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1);
+}
+
+// The epilogue of one accumulator quad: output row m (a GEMM row; it may lie beyond M), couts n..n+3 (n may lie
+// beyond N).  (Pre-BN addend,) BN scale/shift, activation, (residual,) (2x2 max,) store.  Branches are uniform or
+// guard stores only.  li: the lane's row within its 16-row MFMA tile (the pooling window = lanes li&~3 .. +3).
+__device__ __forceinline__ void pw_finish_quad(const PwArgs& a, const f32x4& acc, const f32x4& sc, const f32x4& sh, int m,
+                                               int n, int li, bool vec_out, bool vec_res, bool vec_pre) {
+    const int cnt = a.N - n;           // real couts in this quad (<= 0: none)
+    const int nld = cnt > 0 ? n : 0;   // the column dead quads load from
+    const int ml = m < a.M ? m : a.M - 1;
+    float v[4], q[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[r];
+    if (a.pre) {  // uniform: the low-resolution share of a hoisted concat conv joins the accumulator before BN
+        pw_load_quad(a.pre, pw_pre_row(a, ml), a.pre_ld, nld, a.N, vec_pre, q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += q[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = yr_apply_act(__builtin_fmaf(v[r], sc[r], sh[r]), a.act);
+    if (a.res) {  // uniform
+        pw_load_quad(a.res, (size_t)ml, a.res_ld, nld, a.N, vec_res, q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += q[r];
+    }
+    int orow = m;
+    bool keep = m < a.M && cnt > 0;
+    if (a.pool) {  // uniform: MaxPooling2D(2) across the 4 adjacent lanes of a window
+        pw_pool4(v);
+        keep = keep && (li & 3) == 0;
+        orow = m >> 2;
+    }
+    if (!keep) return;
+    float* op = a.out + (size_t)orow * a.out_ld + n;
+    if (cnt >= 4) {
+        // dense rows (the 75-wide logit outputs): still ONE 16-byte store per lane, only 4-byte aligned
+        // (global_store_dwordx4 takes dword-aligned addresses); four dword stores cost the y convs 40 % of their time
+        if (vec_out) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+        else *reinterpret_cast<f32x4u*>(op) = (f32x4u){v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            if (r < cnt) op[r] = v[r];
+    }
 }
 
 // One output row (pixel) of the activation operand: where its channels come from.
