@@ -144,6 +144,14 @@ def main():
 
     step()  # one-time setup outside every timed/warm-up count: buffer allocation + per-layer tile autotuning
     sync()
+    # The set-up also brings the device to its sustained clocks: the tuner's ~0.5 s of launches do that as a side
+    # effect, a cached tile table (YOLORET_TUNE_CACHE) would skip them and measure 3-4 % low (measured: 22.0k vs
+    # 21.2k img/s).  A fixed quarter second of untimed steps makes both paths start from the same state.
+    t_ramp = time.perf_counter() + 0.25
+    while time.perf_counter() < t_ramp:
+        step()
+        torch.cuda.synchronize(dev)
+    sync()
     if saved_stdout is not None:
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
