@@ -202,3 +202,30 @@ def test_odd_grids_with_all_graph_rewrites(dev, name, size):
     m.set_weights(P.values)
     for y, r in zip(m(torch.from_numpy(x).to(dev)), ref):
         assert_close(y.cpu().numpy().reshape(r.shape), r, 1e-4, '%s@%d' % (name, size))
+
+
+@pytest.mark.parametrize('model_name', ['mobilenetv2x75', 'efficientnetb0'])
+def test_small_batch_plan(dev, model_name):
+    """Batches up to Model.small_batch run the plan without block fusion (its own handle, blob and tile table); it
+    meets the same 1e-4 bar, and one model object serves both plans side by side."""
+    from yoloret_amd import runtime as rt
+    hw = (128, 128)
+    m, P = _build(model_name, hw, 20)
+    x = params.synthetic_images(6, hw[0], hw[1])
+    ref = om.yolov3_body(P, x, model_name, 3, 20)
+    m.set_weights(P.values)
+    m.small_batch = 4
+    assert m.variant(2) == 'latency' and m.variant(6) == 'throughput'
+    xt = torch.from_numpy(x).to(dev)
+    small = [y.cpu().numpy() for y in m(xt[:2])]      # latency plan
+    big = [y.cpu().numpy() for y in m(xt)]            # throughput plan, same object
+    again = [y.cpu().numpy() for y in m(xt[2:5])]     # latency plan again (3 images)
+    lat_kinds = set(o.kind for o in m.plan_for(2).ops)
+    assert rt.OP_MBLANE not in lat_kinds and rt.OP_MBCONV not in lat_kinds
+    for i, r in enumerate(ref):
+        assert_close(small[i], r[:2], 1e-4, 'latency plan, output %d' % i)
+        assert_close(big[i], r, 1e-4, 'throughput plan, output %d' % i)
+        assert_close(again[i], r[2:5], 1e-4, 'latency plan (3 images), output %d' % i)
+    assert len(m._handles) == 2
+    rows = m.profile(xt[:1], iters=2)
+    assert len(rows) == len(m.plan_for(1).ops) and all(r['ms'] > 0 for r in rows)

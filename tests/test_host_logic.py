@@ -56,6 +56,28 @@ def test_plan_structure_and_accounting():
     assert fused.arena_elems_per_image < p.arena_elems_per_image
 
 
+def test_plan_variants(monkeypatch):
+    """Batches up to small_batch run the plan without block fusion; both plans carry the same parameters, MACs and
+    conv-granular bytes, and pack the same weights."""
+    from yoloret_amd import runtime as rt
+    from yoloret_amd.weights import synthetic_weights
+    monkeypatch.setenv('YOLORET_SMALL_BATCH', '4')
+    m = _model()
+    assert m.small_batch == 4 and [m.variant(b) for b in (1, 4, 5, 64)] == ['latency', 'latency', 'throughput', 'throughput']
+    lat, thr = m.plan_for(1), m.plan_for(64)
+    assert thr is m.plan and lat is not thr and m.plan_for(3) is lat
+    kinds = [o.kind for o in lat.ops]
+    assert rt.OP_MBLANE not in kinds and rt.OP_MBCONV not in kinds and kinds[0] == rt.OP_STEMBLOCK
+    assert kinds.count(rt.OP_SE_MEAN) == 6 and kinds.count(rt.OP_DEPTHWISE) == 22
+    assert lat.param_shapes == thr.param_shapes and lat.total_macs() == thr.total_macs()
+    assert abs(lat.algorithmic_bytes_per_image() - thr.algorithmic_bytes_per_image()) < 1
+    assert [(b.h, b.w, b.c) for b in lat.output_bufs] == [(b.h, b.w, b.c) for b in thr.output_bufs]
+    m.set_weights(synthetic_weights(m, 1, 'survey'))
+    assert np.isfinite(m._blob_of('latency')).all() and not np.array_equal(m._blob_of('latency'), m._blob_of('throughput'))
+    monkeypatch.setenv('YOLORET_SMALL_BATCH', '0')
+    assert _model().variant(1) == 'throughput'
+
+
 def test_arena_has_no_overlapping_live_buffers():
     p = _model('efficientnetb0', 64).plan
     arena = [b for b in p.bufs if b.external_slot < 0]

@@ -350,9 +350,11 @@ def pool_into_producers(ops, bufs, output_buf_ids):
     return ops
 
 
-def fuse_inverted_residuals(ops, output_buf_ids):
+def fuse_inverted_residuals(ops, output_buf_ids, blocks=True):
     """Peephole over the lowered op list: [POINTWISE expand+act ->] DEPTHWISE 3x3+act -> POINTWISE
-    project (+residual == block input) becomes one MBCONV op whose expanded tensors never reach HBM."""
+    project (+residual == block input) becomes one MBCONV op whose expanded tensors never reach HBM.
+    blocks=False (the small-batch plan) keeps only the network-entry fusion (stem + first block)."""
+    max_cin = FUSE_MAX_CIN if blocks else 0
     readers = {}
     for op in ops:
         for s in op.srcs:
@@ -430,7 +432,7 @@ def fuse_inverted_residuals(ops, output_buf_ids):
             lane = lane_ok(exp, block_in, p)
             if (p.kind == rt.OP_POINTWISE and plain1(p) and p.srcs[0].buf is d.out and p.act == 'none'
                     and 'scale' in p.params and p.cout <= 224 and block_in.buf.ld % 4 == 0
-                    and (exp is not None or FUSE_NO_EXPAND) and block_in.c <= FUSE_MAX_CIN
+                    and (exp is not None or FUSE_NO_EXPAND) and block_in.c <= max_cin
                     and p.h * p.w >= (FUSE_LANE_MIN_PIXELS if lane else FUSE_MIN_PIXELS)
                     and (p.res is None or (p.res is block_in.buf and d.stride == 1 and p.cout == block_in.c))):
                 dw, proj = d, p
@@ -649,9 +651,14 @@ class Compiler:
                 ops = hoist_upsampled_sources(ops, self.bufs)
             if POOL_IN_PRODUCER:
                 ops = pool_into_producers(ops, self.bufs, set(b.id for b in outs))
-            if MERGE_SE_MEAN:
+            # fuse == 'latency': the plan for batches of a few images.  A fused inverted-residual block is ONE long
+            # workgroup chain (block_4 at batch 1: 14 workgroups x 60 us) where its three unfused launches take 10 us
+            # each, and the merged SE launch pools 2704 pixels in one workgroup: at batch <= 4 the unfused plan is
+            # 20 % faster end to end (0.92 -> 0.73 ms at batch 1), from batch 8 on the fused one wins.
+            latency = self.fuse == 'latency'
+            if MERGE_SE_MEAN and not latency:
                 ops = merge_se_mean(ops)
-            ops = fuse_inverted_residuals(ops, set(b.id for b in outs))
+            ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency)
         return Plan(ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape)
 
     def _lower_conv2d(self, n, done):

@@ -24,8 +24,12 @@ class Model:
         self.outputs = list(outputs)
         self.name = name
         self.plan = compile_graph(self.inputs[0], self.outputs, fuse)
+        # batches of up to SMALL_BATCH images run a second plan without block fusion (compiler.py: 'latency');
+        # compiled on first use, same parameters, its own weight blob / handle / tile table
+        self.small_batch = int(os.environ.get('YOLORET_SMALL_BATCH', '4')) if fuse is True else 0
+        self._plans = {'throughput': self.plan}
         self._weights = None
-        self._blob = None
+        self._blobs = {}
         self.autotune = os.environ.get('YOLORET_AUTOTUNE', '1') != '0'
         self._tuned = set()    # (device index, batch) pairs already autotuned
         self._handles = {}     # device index -> yr_handle*
@@ -54,10 +58,11 @@ class Model:
                 raise ValueError('parameter %s has %d elements, expected shape %s' % (k, a.size, (shape,)))
             wd[k] = a.reshape(shape)
         self._weights = wd
-        self._blob = self.plan.build_blob(wd)
-        for dev, h in self._handles.items():
+        self._blobs = {}
+        for (dev, variant), h in self._handles.items():
+            blob = self._blob_of(variant)
             with torch.cuda.device(dev):
-                rt.check(rt.lib().yr_load_weights(h, self._blob.ctypes.data_as(ctypes.c_void_p), self._blob.size))
+                rt.check(rt.lib().yr_load_weights(h, blob.ctypes.data_as(ctypes.c_void_p), blob.size))
 
     def get_weights(self):
         return dict(self._weights) if self._weights is not None else None
@@ -76,22 +81,40 @@ class Model:
         np.savez(path, **self._weights)
 
     # ------------------------------------------------------------------ execution
-    def _handle(self, device):
+    def variant(self, batch):
+        """Which plan a batch of this size runs: 'latency' (no block fusion) up to small_batch images."""
+        return 'latency' if 0 < batch <= self.small_batch else 'throughput'
+
+    def plan_for(self, batch):
+        v = self.variant(batch)
+        if v not in self._plans:
+            self._plans[v] = compile_graph(self.inputs[0], self.outputs, v)
+        return self._plans[v]
+
+    def _blob_of(self, variant):
+        if self._weights is None:
+            raise RuntimeError('weights have not been set (set_weights / load_weights)')
+        if variant not in self._blobs:
+            self._blobs[variant] = self._plans[variant].build_blob(self._weights)
+        return self._blobs[variant]
+
+    def _handle(self, device, batch=0):
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        h = self._handles.get(idx)
+        variant = self.variant(batch)
+        h = self._handles.get((idx, variant))
         if h is None:
-            if self._blob is None:
-                raise RuntimeError('weights have not been set (set_weights / load_weights)')
-            ops, bufs = self.plan.c_arrays()
+            plan = self.plan_for(batch)
+            blob = self._blob_of(variant)
+            ops, bufs = plan.c_arrays()
             hp = ctypes.c_void_p()
             with torch.cuda.device(idx):
                 rt.check(rt.lib().yr_create(ops, len(ops), bufs, len(bufs), ctypes.byref(hp)))
-                rt.check(rt.lib().yr_load_weights(hp, self._blob.ctypes.data_as(ctypes.c_void_p), self._blob.size))
-            self._handles[idx] = h = hp
+                rt.check(rt.lib().yr_load_weights(hp, blob.ctypes.data_as(ctypes.c_void_p), blob.size))
+            self._handles[(idx, variant)] = h = hp
         return idx, h
 
     def workspace_bytes(self, batch):
-        return self.plan.arena_elems_per_image * batch * 4
+        return self.plan_for(batch).arena_elems_per_image * batch * 4
 
     def __call__(self, x, out=None):
         h, w, c = self.plan.input_shape
@@ -101,7 +124,7 @@ class Model:
             raise ValueError('input shape %s does not match the model input [B,%d,%d,%d]' % (tuple(x.shape), h, w, c))
         x = x.contiguous()
         b = x.shape[0]
-        idx, hd = self._handle(x.device)
+        idx, hd = self._handle(x.device, b)
         need = self.workspace_bytes(b)
         ws = self._workspace.get(idx)
         if ws is None or ws.numel() < need:
@@ -134,7 +157,7 @@ class Model:
     # (tune once, deploy many; also keeps profiler runs free of the tuner's trial launches)
     def _tune_key(self, b):
         import zlib
-        sig = zlib.crc32(' '.join('%s:%d:%d:%d' % (o.name, o.kind, o.cin, o.cout) for o in self.plan.ops).encode())
+        sig = zlib.crc32(' '.join('%s:%d:%d:%d' % (o.name, o.kind, o.cin, o.cout) for o in self.plan_for(b).ops).encode())
         return '%08x:%d' % (sig, b)
 
     def _load_tuning(self, hd, b):
@@ -146,7 +169,7 @@ class Model:
             table = json.load(open(path)).get(self._tune_key(b))
         except (OSError, ValueError):
             return False
-        n = len(self.plan.ops)
+        n = len(self.plan_for(b).ops)
         if not isinstance(table, list) or len(table) != n:
             return False
         arr = (ctypes.c_int32 * n)(*[int(v) for v in table])
@@ -158,7 +181,7 @@ class Model:
         if not path:
             return
         import json
-        n = len(self.plan.ops)
+        n = len(self.plan_for(b).ops)
         arr = (ctypes.c_int32 * n)()
         rt.check(rt.lib().yr_get_tuning(hd, b, arr, n))
         try:
@@ -174,12 +197,13 @@ class Model:
         Returns a list of dicts: name, kind, kernel (symbol), ms, macs, bytes (algorithmic in+out+residual)."""
         x = x.contiguous()
         b = x.shape[0]
-        idx, hd = self._handle(x.device)
+        plan = self.plan_for(b)
+        idx, hd = self._handle(x.device, b)
         self(x)  # allocates the workspace and validates the input
         ws = self._workspace[idx]
         ys = [torch.empty((b, ob.h, ob.w, ob.c), dtype=torch.float32, device=x.device)
-              for ob in self.plan.output_bufs]
-        n = len(self.plan.ops)
+              for ob in plan.output_bufs]
+        n = len(plan.ops)
         ms = (ctypes.c_float * n)()
         names = (ctypes.c_char_p * n)()
         with torch.cuda.device(idx):
@@ -187,9 +211,9 @@ class Model:
                                                  rt._ptr(ws), ws.numel(), rt.stream_ptr(x.device), int(iters),
                                                  ms, names))
         out = []
-        per_op_bytes = self.plan.algorithmic_bytes_per_op()
-        per_op_hbm = self.plan.hbm_bytes_per_op()   # fused ops: only what still has to cross HBM (block in + out)
-        for i, op in enumerate(self.plan.ops):
+        per_op_bytes = plan.algorithmic_bytes_per_op()
+        per_op_hbm = plan.hbm_bytes_per_op()   # fused ops: only what still has to cross HBM (block in + out)
+        for i, op in enumerate(plan.ops):
             out.append(dict(name=op.name, kind=rt.OP_NAMES[op.kind], kernel=(names[i] or b'').decode(),
                             ms=float(ms[i]), macs=op.macs * b, bytes=per_op_bytes[i] * b, hbm_bytes=per_op_hbm[i] * b))
         return out
