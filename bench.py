@@ -146,11 +146,10 @@ def main():
     sync()
     # The set-up also brings the device to its sustained clocks: the tuner's ~0.5 s of launches do that as a side
     # effect, a cached tile table (YOLORET_TUNE_CACHE) would skip them and measure 3-4 % low (measured: 22.0k vs
-    # 21.2k img/s).  A fixed quarter second of untimed steps makes both paths start from the same state.
-    t_ramp = time.perf_counter() + 0.25
-    while time.perf_counter() < t_ramp:
+    # 21.2k img/s).  A fixed 80 untimed steps (about a quarter second; a COUNT, not a duration: with N > 1 every
+    # step is a collective, so all ranks must run the same number) make both paths start from the same state.
+    for _ in range(80):
         step()
-        torch.cuda.synchronize(dev)
     sync()
     if saved_stdout is not None:
         sys.stdout.flush()
