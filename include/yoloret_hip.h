@@ -48,7 +48,16 @@ typedef enum {
      * upsampling (W.[up2(a); b] = up2(Wa.a) + Wb.b), so the compiler computes the upsampled share of a concat conv
      * at the source resolution and hands it in this way (model.py:253-255,273-275: UpSampling2D + Concatenate feeding
      * the first 1x1 conv of the top-down heads). */
-    YR_X_UP2_ADD = 4
+    YR_X_UP2_ADD = 4,
+    /* POINTWISE only, the single source: the source is read THROUGH DepthwiseConv2D 3x3 (TF 'SAME') + BatchNorm +
+     * activation, i.e. the conv's input channel k at an output pixel is act(BN(sum over the 3x3 taps of
+     * dw_w[tap][k] * src[pixel*stride + tap][k])) - the depthwise stage of an inverted-residual block folded into
+     * the loads of its projection (MobileNetV2 block_* [3P] depthwise + project; efficientnet.py:501-533).  The
+     * depthwise result (the block's widest tensor besides the expand output) never reaches HBM; values are
+     * bit-identical to a DEPTHWISE op followed by the same POINTWISE op.  Op fields: src[0] = the depthwise INPUT
+     * (its h, w), op.h/op.w = the depthwise OUTPUT dims, se_reduced = stride | (yr_act of the depthwise stage << 8),
+     * wgt2 = depthwise weights [9][ld], b1 / b2 = its folded BN scale / shift [ld], ld = round_up(src.c, 4). */
+    YR_X_DW3 = 5
 } yr_xform;
 
 /* One concatenated input segment.  (h,w) are the SOURCE's spatial dims; the

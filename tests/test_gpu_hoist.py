@@ -142,3 +142,31 @@ def test_compiler_pools_in_the_producer(dev):
     assert not any(s.xform == 'maxpool2' and s.buf.name.endswith('_pooled') for o in m.plan.ops for s in o.srcs)
     bu2 = next(o for o in m.plan.ops if o.name == 'bu2_conv')
     assert [s.xform for s in bu2.srcs] == ['identity', 'identity']
+
+
+@pytest.mark.parametrize('name,size', [('mobilenetv2x75', 224), ('mobilenetv2x14', 160)])
+def test_depthwise_folded_into_project_is_bit_identical(dev, name, size):
+    """compiler.fold_depthwise_into_project (xform 'dw3', opt-in): the projection computes its block's depthwise stage
+    in its own loader with dw_kernel's arithmetic, so the logits equal the unfolded plan's bit for bit (stride 1 and 2,
+    borders, odd maps: 224/32 = 7, 160/32 = 5)."""
+    from yoloret_amd import compiler, layers as L, runtime as rt
+    from yoloret_amd.weights import synthetic_images, synthetic_weights
+    from yoloret_amd.yolo3.model import yolov3_body
+    outs = {}
+    for fold in (False, True):
+        saved = compiler.FOLD_DW
+        compiler.FOLD_DW = fold
+        try:
+            m = yolov3_body(L.Input(shape=[size, size, 3]), name, 3, num_classes=20)
+        finally:
+            compiler.FOLD_DW = saved
+        m.small_batch = 0
+        folded = [o for o in m.plan.ops if o.kind == rt.OP_POINTWISE and o.srcs[0].xform == 'dw3']
+        assert (len(folded) >= 5) == fold
+        if fold:
+            assert {o.se_reduced & 0xff for o in folded} == {1, 2}
+        m.set_weights(synthetic_weights(m, 7, 'conditioned'))
+        x = torch.from_numpy(synthetic_images(3, size, size)).to(dev)
+        outs[fold] = [y.cpu().numpy() for y in m(x)]
+    for a, b in zip(outs[False], outs[True]):
+        assert np.array_equal(a, b)

@@ -56,6 +56,28 @@ def test_plan_structure_and_accounting():
     assert fused.arena_elems_per_image < p.arena_elems_per_image
 
 
+def test_fold_depthwise_plan_keeps_the_accounting():
+    from yoloret_amd import compiler, runtime as rt
+    from yoloret_amd.weights import synthetic_weights
+    base = _model().plan
+    saved = compiler.FOLD_DW
+    compiler.FOLD_DW = True
+    try:
+        fm = _model()
+    finally:
+        compiler.FOLD_DW = saved
+    p = fm.plan
+    folded = [o for o in p.ops if o.kind == rt.OP_POINTWISE and o.srcs[0].xform == 'dw3']
+    assert [o.name for o in folded] == ['block_%d_project' % i for i in range(7, 16)]   # block_16: cout 240 > one tile
+    assert sum(o.kind == rt.OP_DEPTHWISE for o in p.ops) == sum(o.kind == rt.OP_DEPTHWISE for o in base.ops) - 9
+    assert p.total_macs() == base.total_macs()
+    assert abs(p.algorithmic_bytes_per_image() - base.algorithmic_bytes_per_image()) < 1
+    assert p.arena_elems_per_image <= base.arena_elems_per_image
+    assert np.isfinite(p.build_blob(synthetic_weights(fm, 1, 'survey'))).all()
+    b13 = next(o for o in folded if o.name == 'block_13_project')
+    assert b13.se_reduced == (2 | (rt.ACT['relu6'] << 8)) and (b13.srcs[0].buf.h, b13.h) == (26, 13)
+
+
 def test_plan_variants(monkeypatch):
     """Batches up to small_batch run the plan without block fusion; both plans carry the same parameters, MACs and
     conv-granular bytes, and pack the same weights."""

@@ -185,9 +185,10 @@ class Plan:
 
         def elems_of(op):
             elems = 0
-            if op.kind in (rt.OP_MBCONV, rt.OP_STEMBLOCK, rt.OP_MBLANE):
+            if getattr(op, 'fused', None):
                 # the accounting stays conv-granular (the figure everyone computes from): a fused
-                # block is charged what its three convolutions would move unfused
+                # op (block kernels; a projection with its depthwise stage folded into the loads) is
+                # charged what its convolutions would move unfused
                 return sum(elems_of(f) for f in op.fused)
             if getattr(op, 'accounted_in', None):
                 return 0   # the low-resolution half of a hoisted conv: charged to the conv it was split from
@@ -348,6 +349,51 @@ def pool_into_producers(ops, bufs, output_buf_ids):
         for _, s in rd:
             s.buf, s.xform = q, 'identity'
     return ops
+
+
+# Off by default (measured, MBV2x0.75@416 batch 64): the folded projection equals depthwise + projection on the 26x26
+# blocks (0.046 vs 0.048 ms, 0.0735 vs 0.075 ms) and loses on the 13x13 ones (0.081 vs 0.056 ms): a 64-row tile per
+# workgroup leaves the depthwise arithmetic to 2-3 workgroups per CU where dw_kernel spreads it over 8 waves per SIMD.
+# 21.4k vs 21.9k img/s end to end.  Kept (bit-identical, tested) for maps with more pixels per layer.
+FOLD_DW = os.environ.get('YOLORET_FOLD_DW', '0') != '0'
+FOLD_DW_MAX_COUT = int(os.environ.get('YOLORET_FOLD_DW_MAX_COUT', '128'))   # one cout tile: the depthwise work is done once
+FOLD_DW_MAX_C = 1088                                                       # 11 * round_up(C,4) floats of LDS <= 48 KB
+
+
+def fold_depthwise_into_project(ops, output_buf_ids):
+    """DEPTHWISE 3x3 (+BN+act) whose only reader is a plain POINTWISE projection: the projection reads the
+    depthwise INPUT through xform 'dw3' and computes the depthwise stage in its loader (pointwise_lds.hip, PwDwRow),
+    bit-identically; the depthwise output - as wide as the expand output - never reaches HBM.  Only where the
+    projection has a single cout tile (cout <= FOLD_DW_MAX_COUT), so the depthwise work is not repeated."""
+    readers = {}
+    for op in ops:
+        for s in op.srcs:
+            readers[s.buf.id] = readers.get(s.buf.id, 0) + 1
+        for b in (op.res, op.gate):
+            if b is not None:
+                readers[b.id] = readers.get(b.id, 0) + 1
+    out, i = [], 0
+    while i < len(ops):
+        d = ops[i]
+        p = ops[i + 1] if i + 1 < len(ops) else None
+        if (p is not None and d.kind == rt.OP_DEPTHWISE and d.k == 3 and d.stride in (1, 2)
+                and len(d.srcs) == 1 and d.srcs[0].xform == 'identity' and d.srcs[0].c == d.srcs[0].buf.c
+                and p.kind == rt.OP_POINTWISE and len(p.srcs) == 1 and p.srcs[0].buf is d.out
+                and p.srcs[0].xform == 'identity' and p.gate is None and not getattr(p, 'stride', 0)
+                and readers.get(d.out.id, 0) == 1 and d.out.id not in output_buf_ids
+                and p.cout <= FOLD_DW_MAX_COUT and d.cout <= FOLD_DW_MAX_C and 'scale' in p.params):
+            f = OpRec(rt.OP_POINTWISE, p.name, act=p.act, h=p.h, w=p.w, cin=p.cin, cout=p.cout,
+                      srcs=[Seg(d.srcs[0].buf, d.srcs[0].c, 'dw3')], out=p.out, res=p.res,
+                      se_reduced=d.stride | (rt.ACT[d.act] << 8), macs=p.macs + d.macs)
+            f.params = dict(p.params)
+            f.params['wgt2'], f.params['b1'], f.params['b2'] = d.params['wgt'], d.params['scale'], d.params['shift']
+            f.fused = [d, p]
+            out.append(f)
+            i += 2
+            continue
+        out.append(d)
+        i += 1
+    return out
 
 
 def fuse_inverted_residuals(ops, output_buf_ids, blocks=True):
@@ -659,6 +705,8 @@ class Compiler:
             if MERGE_SE_MEAN and not latency:
                 ops = merge_se_mean(ops)
             ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency)
+            if FOLD_DW and not latency:
+                ops = fold_depthwise_into_project(ops, set(b.id for b in outs))
         return Plan(ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape)
 
     def _lower_conv2d(self, n, done):

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void wsum_kernel(WsumArgs a) {
 int yr_launch_wsum(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(op.nsrc == 4, "wsum: needs exactly 4 sources");
     DSrcSet S;
+    for (int i = 0; i < op.nsrc && i < YR_MAX_SRC; ++i) YR_REQUIRE(op.src[i].xform != YR_X_DW3, "dw3 sources are a POINTWISE feature");
     int rc = yr_make_srcset(op, &S);
     if (rc) return rc;
     for (int i = 0; i < 4; ++i) YR_REQUIRE(op.src[i].c == op.cout, "wsum: source %d has %d channels, expected %d", i, op.src[i].c, op.cout);
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
 
 int yr_launch_gather(const yr_op& op, int batch, hipStream_t s) {
     GatherArgs a;
+    for (int i = 0; i < op.nsrc && i < YR_MAX_SRC; ++i) YR_REQUIRE(op.src[i].xform != YR_X_DW3, "dw3 sources are a POINTWISE feature");
     int rc = yr_make_srcset(op, &a.S);
     if (rc) return rc;
     int dense = 0;

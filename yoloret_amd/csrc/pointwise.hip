@@ -180,6 +180,24 @@ int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
     }
     int rc = yr_make_srcset(op, &a.S);
     if (rc) return rc;
+    // the depthwise stage of an inverted-residual block folded into this conv's loads (yr_xform: YR_X_DW3)
+    a.dw_w = a.dw_scale = a.dw_shift = nullptr;
+    a.dw_stride = a.dw_act = a.dw_pad_t = a.dw_pad_l = 0;
+    const bool dw = op.src[0].xform == YR_X_DW3;
+    if (dw) {
+        const yr_src& e = op.src[0];
+        YR_REQUIRE(a.pre == nullptr && !a.pool && op.gate == nullptr, "pointwise: a dw3 source takes no up2_add / pooled output / SE gate");
+        YR_REQUIRE(op.wgt2 && op.b1 && op.b2 && (((uintptr_t)op.wgt2 | (uintptr_t)op.b1 | (uintptr_t)op.b2) % 16) == 0,
+                   "pointwise: dw3 source needs 16-byte aligned wgt2 / b1 / b2");
+        YR_REQUIRE(11ll * a.S.kp * (long long)sizeof(float) <= 48 * 1024, "pointwise: dw3 source with %d channels does not fit LDS", e.c);
+        a.dw_w = op.wgt2; a.dw_scale = op.b1; a.dw_shift = op.b2;
+        a.dw_stride = op.se_reduced & 0xff;
+        a.dw_act = (op.se_reduced >> 8) & 0xff;
+        // TF 'SAME': pad_total = max((out-1)*s + k - in, 0); before = total/2 (extra goes bottom/right)
+        const int pth = (op.h - 1) * a.dw_stride + 3 - e.h, ptw = (op.w - 1) * a.dw_stride + 3 - e.w;
+        a.dw_pad_t = (pth > 0 ? pth : 0) / 2;
+        a.dw_pad_l = (ptw > 0 ? ptw : 0) / 2;
+    }
     int cin = 0;
     for (int i = 0; i < op.nsrc; ++i) cin += op.src[i].c;
     YR_REQUIRE(cin == op.cin, "pointwise: sum of source channels %d != cin %d", cin, op.cin);
@@ -219,6 +237,10 @@ int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
     constexpr int NCFG = sizeof(cfgs) / sizeof(cfgs[0]);
     const int N = op.cout;
     // autotuned choice (yr_autotune stores the fastest shape per op and batch): op.k = 1 + index
+    if (dw) {  // LDS-staged kernel only; shapes it is not built for fall back inside yr_pw_launch_lds
+        const int shape = (op.k >= 1 && op.k <= NLDS) ? op.k - 1 : -1;
+        return yr_pw_launch_lds(shape, a, s);
+    }
     if (op.k >= 1 && op.k <= NCFG) return cfgs[op.k - 1].fn(a, s);
     // tuning override: YR_PW_CFG="BMxBN" forces one tile shape for every layer (experiments only)
     static const char* force = getenv("YR_PW_CFG");

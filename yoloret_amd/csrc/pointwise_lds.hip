@@ -27,11 +27,15 @@
 // 5 blocks for the 4-7 tile shapes measured no better than 4).
 constexpr int pw_min_blocks(int pt, int ct, bool simple) {
     const int tiles = pt * ct;
-    return tiles >= 16 ? 2 : (pt == 4 && (ct == 1 || (!simple && ct >= 3))) ? 3 : tiles >= 4 ? 4 : 6;
+    return tiles >= 16 ? 2 : (pt == 4 && ct == 1 && !simple) ? 2 : (pt == 4 && (ct == 1 || (!simple && ct >= 3))) ? 3 : tiles >= 4 ? 4 : (simple ? 6 : 5);
 }
 
-template <int PT, int CT, int WM, int WN, bool SIMPLE>
-__global__ __launch_bounds__(256, pw_min_blocks(PT, CT, SIMPLE)) void pw_kernel(PwArgs a) {
+// DW (with SIMPLE): the single source is read through a 3x3 depthwise conv + BN + activation (YR_X_DW3, PwDwRow):
+// nine tap quads are fetched per activation quad and reduced in the stage; the depthwise weights, scale and shift of
+// ALL k live in dynamic LDS (11 * kp floats, loaded once per workgroup).
+template <int PT, int CT, int WM, int WN, bool SIMPLE, bool DW = false>
+__global__ __launch_bounds__(256, DW ? 3 : pw_min_blocks(PT, CT, SIMPLE)) void pw_kernel(PwArgs a) {
+    static_assert(!DW || SIMPLE, "a depthwise-folded source is a single source");
     constexpr int BM = 16 * PT * WM;
     constexpr int BN = 16 * CT * WN;
     constexpr int A_PASSES = BM / PW_RPP;
@@ -64,13 +68,23 @@ __global__ __launch_bounds__(256, pw_min_blocks(PT, CT, SIMPLE)) void pw_kernel(
     // loader mapping: quad kq of row lr (+64 per pass)
     const int lr = tid / PW_KQ, kq = tid % PW_KQ;
     constexpr int MODE = SIMPLE ? 2 : 0;
-    const bool gated = SIMPLE && a.gate != nullptr;
-    PwRow<MODE> row[A_PASSES];
+    constexpr int TAPS = DW ? 9 : 1;
+    const bool gated = SIMPLE && !DW && a.gate != nullptr;
+    typename std::conditional<DW, PwDwRow, PwRow<MODE>>::type row[A_PASSES];
     pw_unroll<A_PASSES>([&](auto P) __attribute__((always_inline)) {
         constexpr int p = decltype(P)::value;
         row[p].init(a, m0 + lr + p * PW_RPP);
-        if (SIMPLE && !gated) row[p].grow = a.wt;  // ungated: the gate load becomes a (cached, ignored) weight quad
+        if constexpr (SIMPLE && !DW)
+            if (!gated) row[p].grow = a.wt;  // ungated: the gate load becomes a (cached, ignored) weight quad
     });
+    extern __shared__ __attribute__((aligned(16))) float dwl[];  // DW: [9][kp] weights | [kp] scale | [kp] shift
+    if constexpr (DW) {
+        for (int i = tid * 4; i < 11 * kp; i += 256 * 4) {
+            const float* src = i < 9 * kp ? a.dw_w + i : (i < 10 * kp ? a.dw_scale + (i - 9 * kp) : a.dw_shift + (i - 10 * kp));
+            *reinterpret_cast<float4*>(dwl + i) = *reinterpret_cast<const float4*>(src);
+        }
+        __syncthreads();
+    }
     const float* brow[B_PASSES];
     pw_unroll<B_PASSES>([&](auto P) __attribute__((always_inline)) {
         constexpr int p = decltype(P)::value;
@@ -94,7 +108,7 @@ __global__ __launch_bounds__(256, pw_min_blocks(PT, CT, SIMPLE)) void pw_kernel(
         // Touching the loaded registers inside fetch() would put the s_waitcnt - a full L2/HBM round trip - in
         // front of the MFMAs of every k chunk.
         struct Regs {
-            float4 ra[A_PASSES], rg[A_PASSES], rb[B_PASSES];
+            float4 ra[A_PASSES][TAPS], rg[A_PASSES], rb[B_PASSES];
             int cv[A_PASSES];  // valid channels in the fetched quad (<= 0: none)
         };
         auto fetch = [&](int k0, Regs& R) __attribute__((always_inline)) {
@@ -102,7 +116,8 @@ __global__ __launch_bounds__(256, pw_min_blocks(PT, CT, SIMPLE)) void pw_kernel(
             const int k = kraw < kp ? kraw : kp - 4;
             pw_unroll<A_PASSES>([&](auto P) __attribute__((always_inline)) {
                 constexpr int p = decltype(P)::value;
-                row[p].template issue<POOLS>(a, kraw, kp, R.ra[p], R.rg[p], R.cv[p]);
+                if constexpr (DW) row[p].issue(a, kraw, kp, R.ra[p], R.cv[p]);
+                else row[p].template issue<POOLS>(a, kraw, kp, R.ra[p][0], R.rg[p], R.cv[p]);
             });
             pw_unroll<B_PASSES>([&](auto P) __attribute__((always_inline)) {
                 constexpr int p = decltype(P)::value;
@@ -114,11 +129,17 @@ __global__ __launch_bounds__(256, pw_min_blocks(PT, CT, SIMPLE)) void pw_kernel(
         // barrier.  With DEPTH 2 two chunks of global loads are in flight per wave; the loop body is two steps on
         // alternating register sets and every fetch is unconditional, so the compiler counts the outstanding loads
         // exactly and a step waits only for ITS set.  A dead step (odd chunk count) stages zeros and skips the MFMAs.
-        constexpr int DEPTH = (PT * CT <= PW_PF2_MAX_TILES) ? 2 : 1;
+        constexpr int DEPTH = (!DW && PT * CT <= PW_PF2_MAX_TILES) ? 2 : 1;  // (nine tap quads per activation quad: one set only)
         auto step = [&](int k0, Regs& R, bool live) __attribute__((always_inline)) {
             pw_unroll<A_PASSES>([&](auto P) __attribute__((always_inline)) {
                 constexpr int p = decltype(P)::value;
-                const float4 v = gated ? pw_finish<2>(R.ra[p], R.rg[p], R.cv[p]) : pw_finish<1>(R.ra[p], R.rg[p], R.cv[p]);
+                float4 v;
+                if constexpr (DW) {
+                    const int kraw = k0 + kq * 4;
+                    v = row[p].finish(a, R.ra[p], R.cv[p], dwl, kp, kraw < kp ? kraw : kp - 4);
+                } else {
+                    v = gated ? pw_finish<2>(R.ra[p][0], R.rg[p], R.cv[p]) : pw_finish<1>(R.ra[p][0], R.rg[p], R.cv[p]);
+                }
                 *reinterpret_cast<float4*>(As + (lr + p * PW_RPP) * PW_LDS_LD + kq * 4) = v;
             });
             pw_unroll<B_PASSES>([&](auto P) __attribute__((always_inline)) {
@@ -197,6 +218,20 @@ template <int PT, int CT, int WM, int WN>
 static int launch_cfg(const PwArgs& a, hipStream_t s) {
     constexpr int BM = 16 * PT * WM, BN = 16 * CT * WN;
     dim3 grid((unsigned)((a.M + BM - 1) / BM) * (unsigned)((a.N + BN - 1) / BN));
+    if (a.dw_w != nullptr) {  // depthwise-folded source: built for the 64-row shapes with 3..8 cout tiles
+        if constexpr (PT == 1 && WM == 4 && CT >= 3) {
+            static char dnm[48];
+            static const int dnm_len = snprintf(dnm, sizeof(dnm), "pw_kernel<%d,%d,%d,%d,dw>", PT, CT, WM, WN);
+            (void)dnm_len;
+            yr_note_kernel(dnm);
+            hipLaunchKernelGGL((pw_kernel<PT, CT, WM, WN, true, true>), grid, dim3(256), (size_t)11 * a.S.kp * sizeof(float), s, a);
+            YR_LAUNCH_CHECK();
+            return YR_OK;
+        } else {
+            yr_set_error("pointwise: no depthwise-folded kernel for tile shape %dx%d", BM, BN);
+            return YR_ERR_ARG;
+        }
+    }
     const bool simple = a.S.n == 1 && a.S.s[0].xform == YR_X_IDENTITY;
     static char nm[2][48];
     static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "pw_kernel<%d,%d,%d,%d,0>", PT, CT, WM, WN) +
@@ -210,6 +245,9 @@ static int launch_cfg(const PwArgs& a, hipStream_t s) {
 }
 
 int yr_pw_launch_lds(int shape, const PwArgs& a, hipStream_t s) {
+    if (a.dw_w != nullptr && (shape < 9 || shape > 13)) {  // any other request: the narrowest built shape that covers N
+        shape = a.N <= 48 ? 9 : a.N <= 64 ? 10 : a.N <= 80 ? 11 : a.N <= 96 ? 12 : 13;
+    }
     switch (shape) {
         case 0: return launch_cfg<4, 1, 4, 1>(a, s);
         case 1: return launch_cfg<2, 2, 4, 1>(a, s);

@@ -39,6 +39,11 @@ struct PwArgs {
     int out_ld, res_ld, gate_ld, pre_ld;
     int act;
     int pool;             // 1: the output is MaxPooling2D(2)(conv output); H, W, M stay the CONV's (pre-pool) dims
+    // YR_X_DW3 source (null dw_w: none): S.s[0] is the depthwise INPUT [B][Hi][Wi][ld]; H, W are its OUTPUT dims
+    const float* dw_w;      // [9][S.kp] depthwise weights, tap-major (ky, kx)
+    const float* dw_scale;  // [S.kp] folded BN of the depthwise stage
+    const float* dw_shift;  // [S.kp]
+    int dw_stride, dw_act, dw_pad_t, dw_pad_l;
 };
 
 // GEMM row -> conv pixel.  Plain: identity.  Pooled output: rows are walked in 2x2-quad-major order, so the four
@@ -130,7 +135,8 @@ __device__ __forceinline__ void pw_finish_quad(const PwArgs& a, const f32x4& acc
 }
 
 // One output row (pixel) of the activation operand: where its channels come from.
-// MODE 0: generic gather (upsample / maxpool / concat sources), 1: one identity source, 2: identity + SE gate.
+// MODE 0: generic gather (upsample / maxpool / concat sources), 1: one identity source, 2: identity + SE gate
+// (MODE 3, the depthwise-folded source, is PwDwRow below).
 // The per-source row pointers are four named members, not an array: after unrolling, LLVM folds a select between
 // loads of two array slots into ONE load with a selected address, which pins the array in scratch memory and puts
 // a scratch round trip in front of every activation load.
@@ -229,6 +235,67 @@ struct PwRow {
             }
         }
         cv = (valid && kraw < kp) ? cvalid : 0;
+    }
+};
+
+// MODE 3: the row's channels are the output of a 3x3 depthwise conv (TF 'SAME', stride 1/2) + BN + activation over
+// S.s[0] (YR_X_DW3).  issue() fetches the nine taps of a channel quad (clamped addresses, unconditional); finish()
+// reproduces dw_kernel's arithmetic exactly - taps in (ky, kx) order as one fma chain from 0, padding taps contribute
+// fma(0, w, acc) = acc, then fma(acc, scale, shift) and the activation - so the operand is bit-identical to what a
+// DEPTHWISE op would have written.  Weights, scale and shift are read from LDS (`dwl`: [9][kp] | [kp] | [kp]).
+struct PwDwRow {
+    const float* img;   // the image's depthwise input
+    int off[9];         // element offset of each (clamped) tap pixel
+    unsigned mask;      // bit t: tap t lies inside the input
+    bool valid;
+
+    __device__ __forceinline__ void init(const PwArgs& a, int m) {
+        valid = m < a.M;
+        const int mm = valid ? m : 0;
+        const DSrc& d = a.S.s[0];
+        const int hw = a.H * a.W;
+        const int b = mm / hw, rem = mm - b * hw;
+        const int y = rem / a.W, x = rem - y * a.W;
+        img = d.ptr + (size_t)b * d.h * d.w * d.ld;
+        const int iy0 = y * a.dw_stride - a.dw_pad_t, ix0 = x * a.dw_stride - a.dw_pad_l;
+        mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+            const bool in = iy >= 0 && iy < d.h && ix >= 0 && ix < d.w;
+            mask |= (in ? 1u : 0u) << t;
+            const int cy = iy < 0 ? 0 : (iy >= d.h ? d.h - 1 : iy), cx = ix < 0 ? 0 : (ix >= d.w ? d.w - 1 : ix);
+            off[t] = (cy * d.w + cx) * d.ld;
+        }
+    }
+
+    __device__ __forceinline__ void issue(const PwArgs& a, int kraw, int kp, float4 (&v)[9], int& cv) const {
+        const int k = kraw < kp ? kraw : kp - 4;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[t] = *reinterpret_cast<const float4*>(img + off[t] + k);
+        cv = (valid && kraw < kp) ? a.S.s[0].c - k : 0;
+    }
+
+    // kq4: the quad's k offset inside the LDS weight block (= the clamped k of issue())
+    __device__ __forceinline__ float4 finish(const PwArgs& a, const float4 (&v)[9], int cv, const float* dwl, int kp, int k) const {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4 w = *reinterpret_cast<const float4*>(dwl + t * kp + k);
+            const bool in = (mask >> t) & 1u;
+            const float4 e = make_float4(in ? v[t].x : 0.f, in ? v[t].y : 0.f, in ? v[t].z : 0.f, in ? v[t].w : 0.f);
+            acc = make_float4(__builtin_fmaf(e.x, w.x, acc.x), __builtin_fmaf(e.y, w.y, acc.y),
+                              __builtin_fmaf(e.z, w.z, acc.z), __builtin_fmaf(e.w, w.w, acc.w));
+        }
+        const float4 sc = *reinterpret_cast<const float4*>(dwl + 9 * kp + k);
+        const float4 sh = *reinterpret_cast<const float4*>(dwl + 10 * kp + k);
+        float4 r = yr_apply_act4(make_float4(__builtin_fmaf(acc.x, sc.x, sh.x), __builtin_fmaf(acc.y, sc.y, sh.y),
+                                             __builtin_fmaf(acc.z, sc.z, sh.z), __builtin_fmaf(acc.w, sc.w, sh.w)), a.dw_act);
+        r.x = cv > 0 ? r.x : 0.f;
+        r.y = cv > 1 ? r.y : 0.f;
+        r.z = cv > 2 ? r.z : 0.f;
+        r.w = cv > 3 ? r.w : 0.f;
+        return r;
     }
 };
 

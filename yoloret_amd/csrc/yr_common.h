@@ -167,6 +167,11 @@ static inline int yr_make_srcset(const yr_op& op, DSrcSet* S) {
         if (s.xform == YR_X_UP2) { eh *= 2; ew *= 2; }
         else if (s.xform == YR_X_MAXPOOL2) { eh /= 2; ew /= 2; }
         else if (s.xform == YR_X_MAXPOOL4) { eh /= 4; ew /= 4; }
+        else if (s.xform == YR_X_DW3) {  // POINTWISE only (checked there): read through a 3x3 depthwise conv, TF 'SAME'
+            const int st = op.se_reduced & 0xff;
+            if (op.nsrc != 1 || (st != 1 && st != 2)) { yr_set_error("dw3 source: must be the only source, stride 1 or 2"); return YR_ERR_ARG; }
+            eh = (eh + st - 1) / st; ew = (ew + st - 1) / st;
+        }
         else if (s.xform != YR_X_IDENTITY) { yr_set_error("bad xform %d", s.xform); return YR_ERR_ARG; }
         if (eh != op.h || ew != op.w) { yr_set_error("src %d dims %dx%d (xform %d) do not give %dx%d", i, s.h, s.w, s.xform, op.h, op.w); return YR_ERR_ARG; }
         if (s.ld % 4 != 0 || s.ld < yr_round_up(s.c, 4)) { yr_set_error("src %d: ld=%d must be a multiple of 4 and >= round_up(c=%d,4)", i, s.ld, s.c); return YR_ERR_ARG; }
