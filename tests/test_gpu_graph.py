@@ -229,3 +229,58 @@ def test_small_batch_plan(dev, model_name):
     assert len(m._handles) == 2
     rows = m.profile(xt[:1], iters=2)
     assert len(rows) == len(m.plan_for(1).ops) and all(r['ms'] > 0 for r in rows)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json's other configurations at the resolutions they are quoted on (fp32 here; the bf16 / fp16 forms of
+# c3 and c5 are in tests/test_gpu_narrow.py).  Reference for the expected logits: the oracle's torch-CPU graph
+# (oracle/torch_ref.py, itself checked against the NumPy restatement in tests/test_golden.py).
+@pytest.mark.parametrize('name,size,b', [('mobilenetv2x14', 512, 2),        # c4's model (model.py:192-203)
+                                         ('efficientnetb0', 416, 1),        # SE EfficientNet-B0 (efficientnet.py:611-710)
+                                         ('efficientnetb0-lite', 416, 1),   # c3's model
+                                         ('efficientnetb3', 640, 1),        # the reference's EfficientNet-B3 (model.py:205-217)
+                                         ('efficientnetb3-lite', 640, 1)])  # c5's model
+def test_full_resolution_configs(dev, name, size, b):
+    from oracle import torch_ref
+    m, P = _build(name, (size, size), 20)
+    x = params.synthetic_images(b, size, size)
+    ref = torch_ref.TorchReference(P, name, 3, 20)(x)
+    m.set_weights(P.values)
+    ys = m(torch.from_numpy(x).to(dev))
+    torch.cuda.synchronize()
+    worst = 0.0
+    for i, (y, r) in enumerate(zip(ys, ref)):
+        worst = max(worst, assert_close(y.cpu().numpy().reshape(r.shape), r, 1e-4, '%s@%d y%d' % (name, size, i + 1)))
+    print('%s@%d: max scaled logit error vs the torch-CPU oracle %.2e' % (name, size, worst))
+
+
+def test_c2_batch64_properties(dev):
+    """BASELINE config 2 at its full batch (64 images, the plan and tile table the bench runs).  The oracle cannot run
+    64 images at 416 in seconds, so: (i) sampled images must equal their own batch-1 run through the SAME plan bit for
+    bit (size-independent property: batching == the reference applied per image), (ii) two sampled images
+    are checked against the NumPy oracle at the 1e-4 bar, (iii) the oracle's post-processing of the GPU's own logits
+    must equal the GPU's detections exactly for the sampled images."""
+    from yoloret_amd.yolo3.model import yolo_eval_packed, unpack_detections
+    b, hw = 64, (416, 416)
+    m, P = _build('mobilenetv2x75', hw, 20)
+    m.small_batch = 0
+    x = params.synthetic_images(b, *hw)
+    sample = [0, 37, 63]
+    ref = om.yolov3_body(P, x[sample[:2]], 'mobilenetv2x75', 3, 20)
+    m.set_weights(P.values)
+    xd = torch.from_numpy(x).to(dev)
+    ys = [y.clone() for y in m(xd)]
+    for j, i in enumerate(sample):
+        one = m(xd[i:i + 1].contiguous())
+        for a, full in zip(one, ys):
+            assert torch.equal(a[0], full[i]), 'image %d differs between the batch-64 and the batch-1 run' % i
+        if j < 2:
+            for y, r in zip(ys, ref):
+                assert_close(y[i].cpu().numpy(), r[j], 1e-4, 'B=64 image %d' % i)
+    det, cnt = yolo_eval_packed(ys, ANCHORS, 3, 20, hw, 20, 0.2, 0.5)
+    res = unpack_detections(det, cnt)
+    assert len(res) == b
+    for i in sample:
+        gb, gs, gc = [t.cpu().numpy() for t in res[i]]
+        ob, os_, oc, _ = cpost.yolo_eval([y[i].cpu().numpy() for y in ys], ANCHORS, 3, 20, hw, 20, 0.2, 0.5)
+        assert np.array_equal(gb, ob) and np.array_equal(gs, os_) and np.array_equal(gc, oc)
