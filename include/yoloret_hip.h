@@ -7,8 +7,13 @@
  * kernels it replaces.  INTEGRATION.md shows the ctypes binding.
  *
  * Conventions
- *   - all tensors NHWC float32; `ld` = channel stride in floats (>= channels,
- *     multiple of 4 unless stated); every device pointer 16-byte aligned.
+ *   - all tensors NHWC.  Element type (yr_dtype): float32, or - activations between the ops of a
+ *     reduced-precision plan (BASELINE.json configs 3 and 5) - bfloat16 / float16.  Images in, the
+ *     three logit outputs, BatchNorm scale/shift, depthwise weights, SE vectors and everything
+ *     behind the logits (decode, NMS) are float32 in every plan; all accumulation is float32.
+ *   - `ld` = channel stride in ELEMENTS (>= channels; a multiple of 4 for float32 tensors and of 8
+ *     for 16-bit tensors unless stated, i.e. every pixel row is 16-byte aligned); every device
+ *     pointer 16-byte aligned.
  *   - every function returns 0 on success, a negative yr_status otherwise, and
  *     never throws; the message is available from yr_last_error().
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it
@@ -26,7 +31,7 @@
 extern "C" {
 #endif
 
-#define YR_ABI_VERSION 1
+#define YR_ABI_VERSION 2
 #define YR_MAX_SRC 4
 
 typedef enum {
@@ -35,6 +40,11 @@ typedef enum {
     YR_ERR_HIP = -2,     /* a HIP runtime call failed */
     YR_ERR_STATE = -3    /* e.g. weights not loaded */
 } yr_status;
+
+/* Element type of an activation tensor / of the POINTWISE weight matrix.  The 16-bit types are storage formats:
+ * every kernel converts to float32 on load (bf16: exact widening) and rounds to nearest-even on store; only the
+ * POINTWISE GEMM consumes them natively (v_mfma_f32_16x16x32_bf16 / _f16, float32 accumulate). */
+typedef enum { YR_F32 = 0, YR_BF16 = 1, YR_F16 = 2 } yr_dtype;
 
 typedef enum { YR_ACT_NONE = 0, YR_ACT_RELU6 = 1, YR_ACT_SWISH = 2, YR_ACT_SIGMOID = 3, YR_ACT_LEAKY = 4 } yr_act;
 
@@ -64,12 +74,14 @@ typedef enum {
  * consumer's dims follow from xform.  In plan ops `ptr` is unused and `buf`
  * indexes the plan's buffer table; in yr_op_* calls `ptr` is the device pointer. */
 typedef struct {
-    const float* ptr;
+    const void* ptr;
     int32_t buf;
     int32_t h, w;
     int32_t c;       /* channels taken from this source */
-    int32_t ld;      /* channel stride of the source buffer */
+    int32_t ld;      /* channel stride of the source buffer, in elements */
     int32_t xform;   /* yr_xform */
+    int32_t dtype;   /* yr_dtype of the source buffer: must equal the op's `dtype`, except for sources that are float32
+                        in every plan (the image of STEM / STEMBLOCK, a YR_X_UP2_ADD source, the pooled vector of SE_FC) */
 } yr_src;
 
 typedef enum {
@@ -109,15 +121,20 @@ typedef struct {
     int32_t k, stride;    /* DEPTHWISE / STEM kernel size and stride */
     int32_t nsrc;
     int32_t se_reduced;   /* SE_FC: hidden width */
+    int32_t dtype;        /* yr_dtype the op works in: element type of its sources, residual and (POINTWISE) `wgt`;
+                             16-bit types: every op kind except MBCONV */
+    int32_t out_dtype;    /* yr_dtype of `out`: equal to `dtype`, or YR_F32 from a 16-bit POINTWISE op (logit outputs,
+                             the low-resolution partial sums of a hoisted conv); SE_MEAN / SE_FC always write float32 */
     yr_src src[YR_MAX_SRC];
     /* output */
-    float* out;  int32_t out_buf;  int32_t out_ld;
-    /* optional residual added after BN (same shape as output) */
-    const float* res;  int32_t res_buf;  int32_t res_ld;
-    /* optional SE gate [B, gate_ld] multiplied onto the (single) source on load */
+    void* out;  int32_t out_buf;  int32_t out_ld;
+    /* optional residual added after BN (same shape as output, element type `dtype`) */
+    const void* res;  int32_t res_buf;  int32_t res_ld;
+    /* optional SE gate [B, gate_ld] (float32) multiplied onto the (single) source on load */
     const float* gate;  int32_t gate_buf;  int32_t gate_ld;
-    /* parameters (device pointers, or float offsets into the blob when in a plan):
-     *   POINTWISE: wgt = Wt[cout][kp] (kp = sum of round_up(src.c,4), zero padded),
+    /* parameters (device pointers, or float offsets into the blob when in a plan); float32 unless stated:
+     *   POINTWISE: wgt = Wt[cout][kp] of element type `dtype` (kp = sum of round_up(src.c, V), V = 4 for float32 and 8
+     *              for the 16-bit types, zero padded; in the blob a 16-bit matrix occupies cout*kp/2 floats),
      *              scale/shift [cout] (folded BN and/or bias)
      *   DEPTHWISE: wgt = [k*k][round_up(c,4)] ; scale/shift [round_up(c,4)]
      *   STEM:      wgt = [27][round_up(cout,4)] ; scale/shift [round_up(cout,4)]
@@ -135,20 +152,23 @@ typedef struct {
     const float* b2;     int64_t b2_off;
 } yr_op;
 
-/* Buffer table entry of a plan: per-image size in floats and either an arena
- * offset (per-image floats; the runtime multiplies by batch) or an external
- * slot (0 = input images, 1..3 = y1..y3). */
+/* Buffer table entry of a plan: per-image size in BYTES and either an arena
+ * offset (per-image bytes, a multiple of 16; the runtime multiplies by batch) or an
+ * external slot (0 = input images, 1..3 = y1..y3; always float32). */
 typedef struct {
-    int64_t elems_per_image;
+    int64_t bytes_per_image;
     int64_t arena_off_per_image;   /* -1 for external buffers */
     int32_t external_slot;         /* -1 for arena buffers */
-    int32_t pad_;
+    int32_t dtype;                 /* yr_dtype of the buffer's elements */
 } yr_buf;
 
 typedef struct yr_handle yr_handle;
 
 const char* yr_last_error(void);
 int yr_abi_version(void);
+/* sizeof(yr_src) / sizeof(yr_op) / sizeof(yr_buf) for which = 0 / 1 / 2 (else 0): lets a binding that restates the
+ * structs (ctypes, cgo, JNA ...) verify its layout against the library's at load time. */
+int yr_abi_sizeof(int which);
 
 /* ---- whole-graph runtime: replaces tf.keras.Model.__call__ on the graph built by
  * yolov3_body (model.py:170-342; called at yolo.py:152, map.py:111). */

@@ -4,6 +4,9 @@ Test infrastructure only (see ``oracle/__init__.py``).  Follows, function by
 function, /root/reference/code/yolo3/model.py, .../efficientnet.py and the
 third-party ``tf.keras.applications.MobileNetV2`` graph.
 All tensors NHWC; ``P`` is a parameter provider (``oracle.params.ParamStore``).
+``P.store(x)`` marks where a fused op of the product writes its result to memory: the identity for
+the float32 oracle, a rounding to bfloat16 / float16 for ``oracle.params.QuantStore`` (the emulation the
+16-bit configs are measured against; the reference itself has no reduced-precision mode).
 
 Layer names: MobileNetV2 layers use the Keras names (``Conv1``, ``bn_Conv1``,
 ``expanded_conv_*``, ``block_{b}_{expand,depthwise,project}[_BN]``); layers the
@@ -58,7 +61,7 @@ def mobilenet_v2(P, x, alpha, last_block=15):
     acts = {}
     first = _make_divisible(32 * alpha, 8)
     x = nn.conv2d(x, P.conv('Conv1', 3, 3, first), stride=2, padding='same')
-    x = nn.relu6(_bn(P, 'bn_Conv1', x))
+    x = P.store(nn.relu6(_bn(P, 'bn_Conv1', x)))
     acts['Conv1_relu'] = x
     for b, (f, s, t) in enumerate(MBV2_BLOCKS[:last_block + 1]):
         prefix = 'expanded_conv_' if b == 0 else 'block_%d_' % b
@@ -67,14 +70,16 @@ def mobilenet_v2(P, x, alpha, last_block=15):
         inp = x
         if b > 0:
             x = _conv1x1(P, prefix + 'expand', x, t * cin)
-            x = nn.relu6(_bn(P, prefix + 'expand_BN', x))
+            x = P.store(nn.relu6(_bn(P, prefix + 'expand_BN', x)))
         x = nn.depthwise(x, P.dw(prefix + 'depthwise', 3, x.shape[-1]), stride=s, padding='same')
-        x = nn.relu6(_bn(P, prefix + 'depthwise_BN', x))
+        x = P.store(nn.relu6(_bn(P, prefix + 'depthwise_BN', x)))
         x = _conv1x1(P, prefix + 'project', x, cout)
         x = _bn(P, prefix + 'project_BN', x)
         if cin == cout and s == 1:
-            x = inp + x
+            x = P.store(inp + x)
             acts['block_%d_add' % b] = x
+        else:
+            x = P.store(x)
         acts['block_%d_out' % b] = x
     return acts
 
@@ -119,7 +124,7 @@ def se_block(P, name, x, input_filters, se_ratio):
     s = nn.mean_hw(x)
     s = nn.swish(_conv1x1(P, name + '_se_reduce', s, reduced, bias=True))
     s = nn.sigmoid(_conv1x1(P, name + '_se_expand', s, x.shape[-1], bias=True))
-    return s * x
+    return P.store(s * x)
 
 
 def mbconv_block(P, name, x, a, lite=False):
@@ -129,16 +134,16 @@ def mbconv_block(P, name, x, a, lite=False):
     inp = x
     filters = a.input_filters * a.expand_ratio
     if a.expand_ratio != 1:
-        x = act(_bn(P, name + '_expand_BN', _conv1x1(P, name + '_expand', x, filters)))
+        x = P.store(act(_bn(P, name + '_expand_BN', _conv1x1(P, name + '_expand', x, filters))))
     x = nn.depthwise(x, P.dw(name + '_dw', a.kernel_size, x.shape[-1]), stride=a.strides[0], padding='same')
-    x = act(_bn(P, name + '_dw_BN', x))
+    x = P.store(act(_bn(P, name + '_dw_BN', x)))
     has_se = (not lite) and a.se_ratio is not None and 0 < a.se_ratio <= 1
     if has_se:
         x = se_block(P, name, x, a.input_filters, a.se_ratio)
     x = _bn(P, name + '_project_BN', _conv1x1(P, name + '_project', x, a.output_filters))
     if a.id_skip and all(s == 1 for s in a.strides) and a.input_filters == a.output_filters:
         x = x + inp
-    return x
+    return P.store(x)
 
 
 def efficientnet(P, x, width, depth, lite=False, last_stage=6):
@@ -147,7 +152,7 @@ def efficientnet(P, x, width, depth, lite=False, last_stage=6):
     act = nn.relu6 if lite else nn.swish
     stem = round_filters(32, width)
     x = nn.conv2d(x, P.conv('stem_conv', 3, 3, stem), stride=2, padding='same')
-    x = act(_bn(P, 'stem_BN', x))
+    x = P.store(act(_bn(P, 'stem_BN', x)))
     acts = {}
     for si, (r, k, s, e, i, o, se) in enumerate(EFFNET_STAGES[:last_stage], start=1):
         a = BlockArgs(kernel_size=k, num_repeat=round_repeats(r, depth),
@@ -166,20 +171,20 @@ def efficientnet(P, x, width, depth, lite=False, last_stage=6):
 def mobilenet_separable_conv2d(P, name, x, filters, kernel_size):
     """model.py:14-30 (live use: RFCR, k=5, bias-free, SAME)."""
     x = nn.depthwise(x, P.dw(name + '_dw', kernel_size, x.shape[-1]), 1, 'same')
-    x = nn.relu6(_bn(P, name + '_dw_BN', x))
+    x = P.store(nn.relu6(_bn(P, name + '_dw_BN', x)))
     x = _conv1x1(P, name + '_pw', x, filters)
-    return nn.relu6(_bn(P, name + '_pw_BN', x))
+    return P.store(nn.relu6(_bn(P, name + '_pw_BN', x)))
 
 
 def rfcr_module(P, inp_arr):
     """model.py:146-168."""
-    b1c = _conv1x1(P, 'rfcr_b1c', inp_arr[0], 48)
-    b2c = _conv1x1(P, 'rfcr_b2c', inp_arr[1], 48)
-    b3c = _conv1x1(P, 'rfcr_b3c', inp_arr[2], 48)
-    b4c = _conv1x1(P, 'rfcr_b4c', inp_arr[3], 48)
+    b1c = P.store(_conv1x1(P, 'rfcr_b1c', inp_arr[0], 48))
+    b2c = P.store(_conv1x1(P, 'rfcr_b2c', inp_arr[1], 48))
+    b3c = P.store(_conv1x1(P, 'rfcr_b3c', inp_arr[2], 48))
+    b4c = P.store(_conv1x1(P, 'rfcr_b4c', inp_arr[3], 48))
     a = P.alpha('rfcr_wsum').astype(b1c.dtype)
     # model.py:134 - left-to-right sum
-    bc = a[0] * nn.upsample2(b1c) + a[1] * b2c + a[2] * nn.maxpool(b3c, 2) + a[3] * b4c
+    bc = P.store(a[0] * nn.upsample2(b1c) + a[1] * b2c + a[2] * nn.maxpool(b3c, 2) + a[3] * b4c)
     bc = mobilenet_separable_conv2d(P, 'rfcr_sep', bc, 96, 5)
     b1 = nn.concat([inp_arr[0], nn.maxpool(bc, 2)])
     b2 = nn.concat([inp_arr[1], bc])
@@ -189,7 +194,7 @@ def rfcr_module(P, inp_arr):
 
 def make_last_layers_efficientnet_lite(P, name, x, input_filters, out_filters):
     """model.py:91-115: 1x1->F +BN+ReLU6 -> MBConv(k3,s1,e1,se.25,F->O) ; y = 1x1 O->O."""
-    x = nn.relu6(_bn(P, name + '_conv_BN', _conv1x1(P, name + '_conv', x, input_filters)))
+    x = P.store(nn.relu6(_bn(P, name + '_conv_BN', _conv1x1(P, name + '_conv', x, input_filters))))
     a = BlockArgs(kernel_size=3, num_repeat=1, input_filters=input_filters, output_filters=out_filters,
                   expand_ratio=1, id_skip=True, strides=[1, 1], se_ratio=0.25)
     x = mbconv_block(P, name + '_mb', x, a)
@@ -198,7 +203,7 @@ def make_last_layers_efficientnet_lite(P, name, x, input_filters, out_filters):
 
 
 def _cbr(P, name, bn_name, x, filters):
-    return nn.relu6(_bn(P, bn_name, _conv1x1(P, name, x, filters)))
+    return P.store(nn.relu6(_bn(P, bn_name, _conv1x1(P, name, x, filters))))
 
 
 def backbone_taps(P, x, model_name):

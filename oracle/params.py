@@ -74,6 +74,42 @@ class ParamStore:
     def alpha(self, name, n=4):
         return self._get(name + '/alpha', (n,), lambda r: r.uniform(0.5, 1.5, (n,)))
 
+    @staticmethod
+    def store(x):
+        """Where a fused op writes its result to memory (oracle/model.py): float32 keeps the value as it is."""
+        return x
+
+
+def round16(a, dtype):
+    """float32 -> nearest-even bfloat16 / float16 -> float32 (NumPy restatement of the storage rounding)."""
+    a = np.ascontiguousarray(a, np.float32)
+    if dtype in ('f16', 'float16'):
+        return a.astype(np.float16).astype(np.float32)
+    assert dtype in ('bf16', 'bfloat16'), dtype
+    u = a.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7fff + ((u >> 16) & 1)) >> 16) << 16
+    return (r & 0xffffffff).astype(np.uint32).view(np.float32).reshape(a.shape)
+
+
+class QuantStore(ParamStore):
+    """Emulation of a 16-bit storage plan (BASELINE.json configs 3 / 5) on the float32 NumPy oracle: the SAME
+    parameters as ParamStore(seed, recipe) (``values`` stays float32 - it is what the product is given), but
+    activations are rounded to `dtype` wherever a fused op stores them and the 1x1-convolution kernels (the MFMA
+    operands; not the SE FCs, which stay float32) are rounded once.  Arithmetic in between is float32."""
+
+    def __init__(self, seed=1234, recipe='conditioned', dtype='bf16'):
+        super().__init__(seed, recipe)
+        self.dtype = dtype
+
+    def store(self, x):
+        return round16(x, self.dtype) if x.dtype == np.float32 else x
+
+    def conv(self, name, k, cin, cout):
+        w = super().conv(name, k, cin, cout)
+        if k == 1 and not name.endswith(('_se_reduce', '_se_expand')):
+            return round16(w, self.dtype)
+        return w
+
 
 def synthetic_images(batch, h, w, seed=20240416):
     """Uniform [0,1) NHWC float32, the range tf.io.decode_image(dtype=float32)

@@ -1,0 +1,523 @@
+"""The 16-bit (bfloat16 / float16 storage) forms of the fused ops and of the whole graph - BASELINE.json configs 3
+("bf16 pointwise on MFMA, fp32 decode/NMS") and 5 ("fp16 + fused RFCR upsample-concat-conv").
+
+The reference has no reduced-precision mode (build-defined), so the bars are:
+  * per op: inputs and weights exactly representable in the 16-bit type; the result must equal the float64 value of
+    the same expression rounded ONCE to the 16-bit type, up to half an ulp of that type plus float32 accumulation
+    noise (i.e. the kernels compute in float32 and round only at the store);
+  * whole graph: measured against the float32 oracle, the HIP path must be no less accurate than a NumPy emulation of
+    the same storage format (oracle.params.QuantStore: float32 arithmetic, activations rounded to the 16-bit type at
+    the fused-op boundaries, 1x1-conv weights rounded once) - x1.5 slack - and the detections are compared with the
+    float32 oracle's (agreement reported and bounded).  SURVEY.md H3: "bf16/fp16 configs cannot meet 1e-4: report
+    error vs fp32 and detection agreement instead".
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn
+from tests.util import round_up
+
+pytestmark = pytest.mark.gpu
+
+REL = {'bf16': 2.0 ** -8, 'f16': 2.0 ** -11}     # half an ulp, relative (normal range)
+TINY = {'bf16': 1e-30, 'f16': 2.0 ** -25}        # half an ulp in the subnormal range of float16
+DTYPES = ['bf16', 'f16']
+
+
+def _rt():
+    from yoloret_amd import runtime as rt
+    return rt
+
+
+def q16(a, dt):
+    """float32 array rounded to the 16-bit type and widened back."""
+    rt = _rt()
+    a = np.ascontiguousarray(a, np.float32)
+    return rt.from_bits16(rt.to_bits16(a, dt), dt).reshape(a.shape)
+
+
+def to_dev16(a, dev, dt, ld=None, poison=True):
+    """[..., C] float32 (values representable in dt) -> device tensor [..., ld] of the 16-bit type; pad channels NaN."""
+    rt = _rt()
+    a = np.asarray(a, np.float32)
+    c = a.shape[-1]
+    ld = round_up(c, 8) if ld is None else ld
+    if ld != c:
+        p = np.full(a.shape[:-1] + (ld,), np.nan if poison else 0.0, np.float32)
+        p[..., :c] = a
+        a = p
+    bits = rt.to_bits16(a, dt).reshape(a.shape)
+    t = torch.from_numpy(bits.view(np.int16)).to(dev)
+    return t.view(rt.TORCH_DTYPE[rt.dtype_id(dt)])
+
+
+def from_dev16(t, dt, c=None):
+    rt = _rt()
+    a = rt.from_bits16(t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16), dt).reshape(tuple(t.shape))
+    return a if c is None else a[..., :c]
+
+
+def assert_rounded_once(got, ref64, dt, what, slack=2e-5):
+    """|got - ref| <= half ulp_dt(ref) (x1.02) + slack*max(1,|ref|): one rounding of a float32-accurate value."""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref64, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert np.isfinite(got).all(), '%s: non-finite values' % what
+    tol = 1.02 * REL[dt] * np.abs(ref) + TINY[dt] + slack * np.maximum(1.0, np.abs(ref))
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), '%s: %d of %d beyond half an ulp; worst |d|/tol = %.2f' % (
+        what, bad.sum(), bad.size, float((np.abs(got - ref) / tol).max()))
+
+
+def _dev_vec(a, dev):
+    return torch.from_numpy(np.asarray(a, np.float32).ravel().copy()).to(dev)
+
+
+def _act(x, act):
+    return {'none': lambda v: v, 'relu6': nn.relu6, 'swish': nn.swish, 'sigmoid': nn.sigmoid, 'leaky': nn.leaky_relu}[act](x)
+
+
+def _xform(x, xf):
+    return {'identity': lambda v: v, 'up2': nn.upsample2, 'maxpool2': lambda v: nn.maxpool(v, 2),
+            'maxpool4': lambda v: nn.maxpool(v, 4)}[xf](x)
+
+
+def _src_dims(h, w, xf):
+    return {'identity': (h, w), 'up2': (h // 2, w // 2), 'maxpool2': (h * 2, w * 2), 'maxpool4': (h * 4, w * 4)}[xf]
+
+
+def run_pointwise16(dev, dt, rng, b, h, w, segs, cout, act='none', bn=True, residual=False, gate=False, out_f32=False,
+                    dense_out=False, pool=False, pre=False, cfg=0):
+    """One 16-bit POINTWISE op through yr_op_run against float64 NumPy on the same (exactly representable) operands.
+    h, w: the conv's resolution (pool=True: the output is its 2x2 max)."""
+    rt = _rt()
+    did = rt.dtype_id(dt)
+    srcs_np, srcs_dev = [], []
+    for c, xf in segs:
+        sh, sw = _src_dims(h, w, xf)
+        a = q16(rng.standard_normal((b, sh, sw, c)), dt)
+        srcs_np.append(a)
+        srcs_dev.append(to_dev16(a, dev, dt))
+    cin = sum(c for c, _ in segs)
+    wk = q16(rng.standard_normal((cin, cout)) * np.sqrt(2.0 / cin), dt)
+    kp = sum(round_up(c, 8) for c, _ in segs)
+    wt = np.zeros((cout, kp), np.float32)
+    d = kb = 0
+    for c, _ in segs:
+        wt[:, kb:kb + c] = wk[d:d + c].T
+        d += c
+        kb += round_up(c, 8)
+    x = nn.concat([_xform(a, xf) for a, (_, xf) in zip(srcs_np, segs)]).astype(np.float64)
+    keep = []
+    op = rt.new_op(rt.OP_POINTWISE, act)
+    op.dtype, op.out_dtype = did, (0 if out_f32 else did)
+    if gate:
+        gate_np = rng.uniform(0.1, 1.0, (b, 1, 1, cin)).astype(np.float32)
+        # the kernel forms x*gate in float32 and rounds the product to the operand type (efficientnet.py:435 is a tensor)
+        x = q16((x.astype(np.float32) * gate_np), dt).astype(np.float64)
+        g = np.full((b, round_up(cin, 8)), np.nan, np.float32)
+        g[:, :cin] = gate_np.reshape(b, cin)
+        gd = torch.from_numpy(g).to(dev)
+        keep.append(gd)
+        op.gate, op.gate_ld = gd.data_ptr(), gd.shape[1]
+    ref = x.reshape(-1, cin).dot(wk.astype(np.float64)).reshape(b, h, w, cout)
+    nsrc = len(segs)
+    for i, (t, (c, xf)) in enumerate(zip(srcs_dev, segs)):
+        op.src[i] = rt.make_src(t, c=c, xform=xf)
+    if pre:   # the hoisted share of a concat conv: float32 [B, h/2, w/2, cout], added before BatchNorm
+        p_np = rng.standard_normal((b, h // 2, w // 2, cout)).astype(np.float32)
+        ref = ref + nn.upsample2(p_np).astype(np.float64)
+        ldp = round_up(cout, 4)
+        pp = np.full((b, h // 2, w // 2, ldp), np.nan, np.float32)
+        pp[..., :cout] = p_np
+        pd = torch.from_numpy(pp).to(dev)
+        keep.append(pd)
+        op.src[nsrc] = rt.make_src(pd, c=cout, xform='up2_add')
+        nsrc += 1
+    if bn:
+        scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        shift = rng.normal(0, 0.3, cout).astype(np.float32)
+        ref = ref * scale + shift
+        keep += [_dev_vec(scale, dev), _dev_vec(shift, dev)]
+        op.scale, op.shift = keep[-2].data_ptr(), keep[-1].data_ptr()
+    ref = _act(ref, act)
+    if residual:
+        res_np = q16(rng.standard_normal((b, h, w, cout)), dt)
+        ref = ref + res_np
+        r = to_dev16(res_np, dev, dt)
+        keep.append(r)
+        op.res, op.res_ld = r.data_ptr(), r.shape[3]
+    oh, ow = h, w
+    if pool:
+        ref = nn.maxpool(ref, 2)
+        oh, ow = h // 2, w // 2
+        op.stride = 2
+    wd = torch.from_numpy(rt.to_bits16(wt, dt).view(np.int16).reshape(wt.shape)).to(dev)
+    keep.append(wd)
+    op.wgt = wd.data_ptr()
+    op.h, op.w, op.cin, op.cout, op.nsrc = oh, ow, cin, cout, nsrc
+    if out_f32:
+        out_ld = cout if dense_out else round_up(cout, 4)
+        out = torch.full((b, oh, ow, out_ld), float('nan'), dtype=torch.float32, device=dev)
+    else:
+        out_ld = round_up(cout, 8)
+        out = torch.full((b, oh, ow, out_ld), float('nan'), dtype=rt.TORCH_DTYPE[did], device=dev)
+    op.out, op.out_ld = out.data_ptr(), out_ld
+    op.k = cfg
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    if out_f32:
+        got = out.cpu().numpy()[..., :cout]
+        err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+        assert np.isfinite(got).all() and err.max() <= 2e-5, 'pointwise16 f32 out %s: %.3e' % (segs, err.max())
+    else:
+        got = from_dev16(out, dt, cout)
+        assert_rounded_once(got, ref, dt, 'pointwise16 %s %s cfg %d' % (dt, segs, cfg))
+    return got
+
+
+PW16 = [
+    # (h, w, segs, cout, act, bn, residual, gate, out_f32, dense_out, pool, pre)
+    (13, 13, [(16, 'identity')], 96, 'relu6', True, False, False, False, False, False, False),
+    (13, 11, [(24, 'identity')], 16, 'none', True, False, False, False, False, False, False),
+    (7, 9, [(144, 'identity')], 24, 'none', True, True, False, False, False, False, False),
+    (13, 13, [(720, 'identity')], 120, 'none', True, True, False, False, False, False, False),
+    (26, 26, [(72, 'identity')], 432, 'swish', True, False, False, False, False, False, False),
+    (13, 13, [(120, 'identity'), (96, 'maxpool2')], 512, 'relu6', True, False, False, False, False, False, False),
+    (26, 26, [(256, 'up2'), (72, 'identity'), (96, 'identity')], 256, 'relu6', True, False, False, False, False, False, False),
+    (12, 12, [(128, 'up2'), (24, 'identity'), (96, 'up2')], 128, 'relu6', True, False, False, False, False, False, False),
+    (13, 13, [(128, 'maxpool2'), (75, 'identity')], 256, 'relu6', True, False, False, False, False, False, False),
+    (13, 13, [(512, 'identity')], 75, 'none', True, False, True, False, False, False, False),        # SE-gated project
+    (13, 13, [(75, 'identity')], 75, 'none', False, False, False, True, True, False, False),          # y conv: dense fp32 logits
+    (26, 26, [(24, 'maxpool4')], 48, 'none', False, False, False, False, False, False, False),         # rfcr_b4c
+    (5, 5, [(75, 'identity')], 255, 'swish', True, False, False, True, True, False, False),
+    (8, 8, [(37, 'identity'), (22, 'up2')], 50, 'leaky', True, True, False, False, False, False, False),
+    (1, 1, [(128, 'identity')], 32, 'sigmoid', True, False, False, False, False, False, False),
+    (12, 12, [(128, 'identity')], 128, 'relu6', True, False, False, False, False, True, False),        # pooled output (bu*_down_conv)
+    (14, 10, [(48, 'identity'), (96, 'identity')], 203, 'relu6', True, False, False, False, False, True, False),
+    (12, 12, [(72, 'identity'), (96, 'identity')], 256, 'relu6', True, False, False, False, False, False, True),   # hoisted: up2_add
+    (6, 6, [(256, 'identity')], 75, 'none', False, False, False, True, False, False, False),         # the _lowres half: fp32 out, padded
+]
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('case', PW16, ids=[str(i) for i in range(len(PW16))])
+def test_pointwise16(dev, dt, case):
+    h, w, segs, cout, act, bn, residual, gate, out_f32, dense, pool, pre = case
+    rng = np.random.default_rng(zlib.crc32(str(case).encode()))
+    run_pointwise16(dev, dt, rng, 3, h, w, segs, cout, act, bn, residual, gate, out_f32, dense, pool, pre)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('ci', [0, 3, 6, 9, 10, 15, 17])
+def test_pointwise16_tile_shapes_are_bit_identical(dev, dt, ci):
+    """Every tile shape runs the same MFMA sequence per output: the autotuner may swap them freely."""
+    h, w, segs, cout, act, bn, residual, gate, out_f32, dense, pool, pre = PW16[ci]
+    outs = []
+    n = 10
+    for cfg in range(0, n + 1):
+        rng = np.random.default_rng(zlib.crc32(str(PW16[ci]).encode()))
+        outs.append(run_pointwise16(dev, dt, rng, 2, h, w, segs, cout, act, bn, residual, gate, out_f32, dense, pool, pre, cfg=cfg))
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('k,s,h,w,c,act', [(3, 1, 13, 13, 96, 'relu6'), (3, 2, 15, 17, 144, 'relu6'), (5, 1, 9, 12, 40, 'swish'),
+                                           (5, 2, 14, 14, 75, 'swish'), (3, 1, 5, 7, 10, 'none'), (3, 2, 32, 32, 32, 'relu6')])
+def test_depthwise16(dev, dt, k, s, h, w, c, act):
+    rt = _rt()
+    did = rt.dtype_id(dt)
+    rng = np.random.default_rng(k * 1000 + s * 100 + c)
+    b = 2
+    x = q16(rng.standard_normal((b, h, w, c)), dt)
+    wk = (rng.standard_normal((k, k, c)) * np.sqrt(2.0 / (k * k))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    shift = rng.normal(0, 0.3, c).astype(np.float32)
+    ref = _act(nn.depthwise(x.astype(np.float64), wk.astype(np.float64), s, 'same') * scale + shift, act)
+    ldc = round_up(c, 4)
+    wp = np.zeros((k * k, ldc), np.float32)
+    wp[:, :c] = wk.reshape(k * k, c)
+    pad = lambda v: np.concatenate([v, np.zeros(ldc - c, np.float32)])
+    xd = to_dev16(x, dev, dt)
+    ho, wo = -(-h // s), -(-w // s)
+    out = torch.full((b, ho, wo, round_up(c, 8)), float('nan'), dtype=rt.TORCH_DTYPE[did], device=dev)
+    keep = [_dev_vec(wp, dev), _dev_vec(pad(scale), dev), _dev_vec(pad(shift), dev)]
+    op = rt.new_op(rt.OP_DEPTHWISE, act)
+    op.dtype = op.out_dtype = did
+    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc = ho, wo, c, c, k, s, 1
+    op.src[0] = rt.make_src(xd, c=c)
+    op.wgt, op.scale, op.shift = [t.data_ptr() for t in keep]
+    op.out, op.out_ld = out.data_ptr(), out.shape[3]
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    assert_rounded_once(from_dev16(out, dt, c), ref, dt, 'depthwise16 k%d s%d' % (k, s))
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('cout,act', [(24, 'relu6'), (32, 'swish'), (40, 'swish')])
+def test_stem16(dev, dt, cout, act):
+    """float32 image in, 16-bit map out."""
+    rt = _rt()
+    did = rt.dtype_id(dt)
+    rng = np.random.default_rng(cout)
+    b, h, w = 2, 37, 50
+    x = rng.random((b, h, w, 3), dtype=np.float32)
+    wk = (rng.standard_normal((3, 3, 3, cout)) * np.sqrt(2.0 / 27)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.3, cout).astype(np.float32)
+    ref = _act(nn.conv2d(x.astype(np.float64), wk.astype(np.float64), 2, 'same') * scale + shift, act)
+    ldw = round_up(cout, 4)
+    wp = np.zeros((27, ldw), np.float32)
+    wp[:, :cout] = wk.reshape(27, cout)
+    xd = torch.from_numpy(x).to(dev)
+    ho, wo = (h + 1) // 2, (w + 1) // 2
+    out = torch.full((b, ho, wo, round_up(cout, 8)), float('nan'), dtype=rt.TORCH_DTYPE[did], device=dev)
+    keep = [_dev_vec(wp, dev), _dev_vec(scale, dev), _dev_vec(shift, dev)]
+    op = rt.new_op(rt.OP_STEM, act)
+    op.dtype = op.out_dtype = did
+    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc = ho, wo, 3, cout, 3, 2, 1
+    op.src[0] = rt.make_src(xd, c=3)
+    op.wgt, op.scale, op.shift = [t.data_ptr() for t in keep]
+    op.out, op.out_ld = out.data_ptr(), out.shape[3]
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    assert_rounded_once(from_dev16(out, dt, cout), ref, dt, 'stem16 %d' % cout)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_weighted_sum_and_gather16(dev, dt):
+    """WSUM over four gathered 16-bit sources (reference add order, one rounding) and the materialising GATHER
+    (exact: a copy / maximum of 16-bit values)."""
+    rt = _rt()
+    did = rt.dtype_id(dt)
+    rng = np.random.default_rng(5)
+    b, h, w, c = 2, 12, 12, 48
+    srcs = [('up2', q16(rng.standard_normal((b, h // 2, w // 2, c)), dt)), ('identity', q16(rng.standard_normal((b, h, w, c)), dt)),
+            ('maxpool2', q16(rng.standard_normal((b, 2 * h, 2 * w, c)), dt)), ('maxpool4', q16(rng.standard_normal((b, 4 * h, 4 * w, c)), dt))]
+    alpha = rng.uniform(0.5, 1.5, 4).astype(np.float32)
+    xs = [_xform(a, xf) for xf, a in srcs]
+    ref = sum(np.float64(alpha[i]) * xs[i].astype(np.float64) for i in range(4))
+    devs = [to_dev16(a, dev, dt) for _, a in srcs]
+    out = torch.full((b, h, w, round_up(c, 8)), float('nan'), dtype=rt.TORCH_DTYPE[did], device=dev)
+    ad = _dev_vec(alpha, dev)
+    op = rt.new_op(rt.OP_WSUM)
+    op.dtype = op.out_dtype = did
+    op.h, op.w, op.cin, op.cout, op.nsrc = h, w, c, c, 4
+    for i, ((xf, _), t) in enumerate(zip(srcs, devs)):
+        op.src[i] = rt.make_src(t, c=c, xform=xf)
+    op.wgt = ad.data_ptr()
+    op.out, op.out_ld = out.data_ptr(), out.shape[3]
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    assert_rounded_once(from_dev16(out, dt, c), ref, dt, 'wsum16')
+    # gather: concat of three sources with ragged widths
+    gs = [('up2', q16(rng.standard_normal((b, h // 2, w // 2, 37)), dt)), ('identity', q16(rng.standard_normal((b, h, w, 22)), dt)),
+          ('maxpool2', q16(rng.standard_normal((b, 2 * h, 2 * w, 75)), dt))]
+    refg = nn.concat([_xform(a, xf) for xf, a in gs])
+    gd = [to_dev16(a, dev, dt) for _, a in gs]
+    ctot = refg.shape[-1]
+    outg = torch.zeros((b, h, w, round_up(ctot, 8)), dtype=rt.TORCH_DTYPE[did], device=dev)
+    op = rt.new_op(rt.OP_GATHER)
+    op.dtype = op.out_dtype = did
+    op.h, op.w, op.cin, op.cout, op.nsrc = h, w, ctot, ctot, 3
+    for i, ((xf, a), t) in enumerate(zip(gs, gd)):
+        op.src[i] = rt.make_src(t, c=a.shape[-1], xform=xf)
+    op.out, op.out_ld = outg.data_ptr(), outg.shape[3]
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    assert np.array_equal(from_dev16(outg, dt, ctot), refg)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('h,w,c,r,merged', [(13, 13, 75, 18, True), (7, 5, 480, 20, True), (26, 26, 144, 6, False)])
+def test_squeeze_excite16(dev, dt, h, w, c, r, merged):
+    """SE on a 16-bit map: float32 mean of the widened values, float32 FCs, float32 gate (efficientnet.py:406-434)."""
+    rt = _rt()
+    did = rt.dtype_id(dt)
+    rng = np.random.default_rng(h * 100 + c)
+    b = 3
+    x = q16(rng.standard_normal((b, h, w, c)), dt)
+    w1 = (rng.standard_normal((c, r)) * np.sqrt(1.0 / c)).astype(np.float32)
+    b1 = rng.normal(0, 0.1, r).astype(np.float32)
+    w2 = (rng.standard_normal((r, c)) * np.sqrt(1.0 / r)).astype(np.float32)
+    b2 = rng.normal(0, 0.1, c).astype(np.float32)
+    mean = x.astype(np.float64).mean(axis=(1, 2))
+    hid = nn.swish(mean.dot(w1.astype(np.float64)) + b1)
+    ref = nn.sigmoid(hid.dot(w2.astype(np.float64)) + b2)
+    ldc = round_up(c, 4)
+    w1t = np.zeros((r, ldc), np.float32); w1t[:, :c] = w1.T
+    w2p = np.zeros((r, ldc), np.float32); w2p[:, :c] = w2
+    b2p = np.zeros(ldc, np.float32); b2p[:c] = b2
+    keep = [_dev_vec(w1t, dev), _dev_vec(b1, dev), _dev_vec(w2p, dev), _dev_vec(b2p, dev)]
+    xd = to_dev16(x, dev, dt)
+    ldg = round_up(c, 8)
+    gate = torch.full((b, ldg), float('nan'), dtype=torch.float32, device=dev)
+    src = rt.make_src(xd, c=c)
+    if not merged:
+        mean_d = torch.full((b, 1, 1, ldc), float('nan'), dtype=torch.float32, device=dev)
+        op = rt.new_op(rt.OP_SE_MEAN)
+        op.dtype, op.out_dtype = did, 0
+        op.h = op.w = 1
+        op.cin = op.cout = c
+        op.nsrc = 1
+        op.src[0] = src
+        op.out, op.out_ld = mean_d.data_ptr(), ldc
+        rt.run_op(op, b)
+        got_mean = mean_d.cpu().numpy().reshape(b, ldc)[:, :c]
+        assert np.abs(got_mean - mean).max() <= 2e-6 * max(1.0, np.abs(mean).max())
+        src = rt.make_src(mean_d, c=c)
+    op = rt.new_op(rt.OP_SE_FC)
+    op.dtype, op.out_dtype = did, 0
+    op.h = op.w = 1
+    op.cin = op.cout = c
+    op.se_reduced = r
+    op.nsrc = 1
+    op.src[0] = src
+    op.wgt, op.b1, op.wgt2, op.b2 = [t.data_ptr() for t in keep]
+    op.out, op.out_ld = gate.data_ptr(), ldg
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    g = gate.cpu().numpy()
+    assert np.abs(g[:, :c] - ref).max() <= 2e-5
+    assert (g[:, c:] == 0).all()
+
+
+def test_dtype_mismatches_are_refused(dev):
+    rt = _rt()
+    x = torch.zeros((1, 4, 4, 16), dtype=torch.bfloat16, device=dev)
+    out = torch.zeros((1, 4, 4, 16), dtype=torch.float16, device=dev)
+    wgt = torch.zeros((16, 16), dtype=torch.bfloat16, device=dev)
+    op = rt.new_op(rt.OP_POINTWISE)
+    op.dtype, op.out_dtype = rt.DTYPE['bf16'], rt.DTYPE['f16']
+    op.h = op.w = 4
+    op.cin = op.cout = 16
+    op.nsrc = 1
+    op.src[0] = rt.make_src(x)
+    op.wgt = wgt.data_ptr()
+    op.out, op.out_ld = out.data_ptr(), 16
+    with pytest.raises(rt.YoloretHipError, match='out_dtype'):
+        rt.run_op(op, 1)
+    op.out_dtype = rt.DTYPE['bf16']
+    op.src[0].dtype = rt.DTYPE['f32']
+    with pytest.raises(rt.YoloretHipError, match='dtype'):
+        rt.run_op(op, 1)
+
+
+# ------------------------------------------------------------------------------------------------ whole graph
+def _graph16(dev, model_name, hw, b, dt, recipe='conditioned', seed=1234):
+    """-> (model, x, fp32 oracle logits, emulated-16-bit oracle logits, HIP logits)."""
+    from oracle import model as om, params
+    from yoloret_amd import layers as L
+    from yoloret_amd.yolo3.model import yolov3_body
+    L.set_global_policy({'bf16': 'mixed_bfloat16', 'f16': 'mixed_float16'}[dt])
+    try:
+        m = yolov3_body(L.Input(shape=[hw[0], hw[1], 3]), model_name, 3, num_classes=20)
+    finally:
+        L.set_global_policy('float32')
+    assert m.plan.dtype == _rt().dtype_id(dt)
+    P = params.ParamStore(seed, recipe)
+    x = params.synthetic_images(b, hw[0], hw[1])
+    ref = om.yolov3_body(P, x, model_name, 3, 20)
+    emu = om.yolov3_body(params.QuantStore(seed, recipe, dt), x, model_name, 3, 20)
+    m.set_weights(P.values)
+    ys = m(torch.from_numpy(x).to(dev))
+    torch.cuda.synchronize()
+    assert all(y.dtype == torch.float32 for y in ys)          # logits leave the graph as float32
+    return m, x, ref, emu, [y.cpu().numpy() for y in ys]
+
+
+def _errs(a, ref):
+    e = np.abs(a.astype(np.float64) - ref) / np.maximum(1.0, np.abs(ref))
+    return float(e.max()), float(e.mean())
+
+
+def _check_vs_emulation(ref, emu, got, what):
+    worst = 0.0
+    for i, (r, e, g) in enumerate(zip(ref, emu, got)):
+        assert g.shape == r.shape and np.isfinite(g).all()
+        gm, ga = _errs(g, r)
+        em, ea = _errs(e, r)
+        print('%s y%d  scaled error vs the fp32 oracle (max / mean):  HIP %.2e / %.2e   NumPy emulation %.2e / %.2e'
+              % (what, i + 1, gm, ga, em, ea))
+        assert ga <= 1.5 * ea + 1e-6, '%s y%d: mean error %.3e vs emulation %.3e' % (what, i + 1, ga, ea)
+        assert gm <= 2.0 * em + 1e-5, '%s y%d: max error %.3e vs emulation %.3e' % (what, i + 1, gm, em)
+        worst = max(worst, gm)
+    return worst
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('model_name,hw', [('mobilenetv2x75', (64, 64)), ('mobilenetv2x14', (64, 96)), ('efficientnetb0', (96, 64)),
+                                           ('efficientnetb3', (64, 64)), ('efficientnetb0-lite', (64, 64)), ('mobilenetv2x75', (352, 352))])
+def test_logits16_small(dev, dt, model_name, hw):
+    _, _, ref, emu, got = _graph16(dev, model_name, hw, 2, dt)
+    _check_vs_emulation(ref, emu, got, '%s@%dx%d %s' % (model_name, hw[0], hw[1], dt))
+
+
+def _detection_agreement(ys_a, ys_b, hw, thr=0.2):
+    """(class, box index) picks of the oracle's post-processing on two sets of logits: |A & B|, |A|, |B|."""
+    from oracle import cpost
+    from tests.util import ANCHORS
+    inter = na = nb = 0
+    for i in range(ys_a[0].shape[0]):
+        _, _, ca, ia = cpost.yolo_eval([y[i] for y in ys_a], ANCHORS, 3, 20, hw, 20, thr, 0.5)
+        _, _, cb, ib = cpost.yolo_eval([y[i] for y in ys_b], ANCHORS, 3, 20, hw, 20, thr, 0.5)
+        sa, sb = set(zip(ca.tolist(), ia.tolist())), set(zip(cb.tolist(), ib.tolist()))
+        inter += len(sa & sb); na += len(sa); nb += len(sb)
+    return inter, na, nb
+
+
+@pytest.mark.parametrize('model_name,size,dt', [('efficientnetb0', 416, 'bf16'),         # config 3 (reference-faithful SE + Swish)
+                                                ('efficientnetb0-lite', 416, 'bf16'),    # config 3, build-defined lite form
+                                                ('efficientnetb3', 640, 'f16'),          # config 5
+                                                ('efficientnetb3-lite', 640, 'f16'),
+                                                ('mobilenetv2x75', 416, 'bf16'), ('mobilenetv2x75', 416, 'f16')])
+def test_baseline_configs_16bit(dev, model_name, size, dt):
+    """BASELINE.json configs 3 and 5 at their resolution: logits against the float32 oracle and against the NumPy
+    emulation of the storage format, detections (GPU post-processing == the oracle's on the same logits, bit for bit;
+    agreement of the picks with the float32 oracle's reported)."""
+    from oracle import cpost
+    from tests.util import ANCHORS
+    from yoloret_amd.yolo3.model import yolo_eval
+    b, hw = 1, (size, size)
+    m, x, ref, emu, got = _graph16(dev, model_name, hw, b, dt)
+    worst = _check_vs_emulation(ref, emu, got, '%s@%d %s' % (model_name, size, dt))
+    ys = [torch.from_numpy(g).to(dev) for g in got]
+    res = yolo_eval(ys, ANCHORS, 3, 20, hw, max_boxes=20, score_threshold=0.2, iou_threshold=0.5)
+    gb, gs, gc = [t.cpu().numpy() for t in res]
+    ob, os_, oc, _ = cpost.yolo_eval([g[0] for g in got], ANCHORS, 3, 20, hw, 20, 0.2, 0.5)
+    assert np.array_equal(gb, ob) and np.array_equal(gs, os_) and np.array_equal(gc, oc)   # decode / NMS are float32: bit-exact
+    inter, na, nb = _detection_agreement(got, ref, hw)
+    inter_e, ne, _ = _detection_agreement(emu, ref, hw)
+    print('%s@%d %s: max scaled logit error %.2e; detections HIP %d, fp32 oracle %d, common %d (%.1f %%); NumPy emulation: common %d of %d'
+          % (model_name, size, dt, worst, na, nb, inter, 100.0 * inter / max(nb, 1), inter_e, ne))
+    # the 16-bit path may flip decisions that sit within its logit noise of a threshold - no more of them than the
+    # emulation of the same format does (+ slack for the small counts)
+    assert nb > 0 and inter >= 0.8 * min(inter_e, nb) - 2
+
+
+def test_policy_and_dtype_plumbing(dev):
+    """set_global_policy / Model(dtype=...) / YOLORET_DTYPE select the plan's element type; float32 stays the default;
+    the 16-bit plan halves the arena and the pointwise weights."""
+    from yoloret_amd import layers as L
+    from yoloret_amd.engine import Model
+    from yoloret_amd.yolo3.model import yolov3_body
+    rt = _rt()
+    m32 = yolov3_body(L.Input(shape=[96, 96, 3]), 'efficientnetb0', 3, num_classes=20)
+    assert m32.plan.dtype == 0 and all(o.dtype == 0 for o in m32.plan.ops)
+    L.set_global_policy('mixed_float16')
+    try:
+        m16 = yolov3_body(L.Input(shape=[96, 96, 3]), 'efficientnetb0', 3, num_classes=20)
+    finally:
+        L.set_global_policy('float32')
+    assert m16.plan.dtype == rt.DTYPE['f16']
+    assert m16.plan.arena_bytes_per_image < 0.6 * m32.plan.arena_bytes_per_image
+    assert m16.plan.blob_floats < 0.75 * m32.plan.blob_floats
+    assert all(b.dtype == 0 for b in m16.plan.bufs if b.external_slot >= 0)
+    with pytest.raises(ValueError):
+        L.set_global_policy('int8')
+    with pytest.raises(ValueError):
+        Model(m32.inputs, m32.outputs, dtype='float64')

@@ -53,7 +53,7 @@ def test_plan_structure_and_accounting():
     assert sum(o.kind == rt.OP_MBLANE for o in fused.ops) == 6 and fused.ops[0].kind == rt.OP_STEMBLOCK  # block_1..6
     assert abs(fused.algorithmic_bytes_per_image() - p.algorithmic_bytes_per_image()) < 1  # accounting is fusion-invariant
     assert fused.total_macs() == p.total_macs()
-    assert fused.arena_elems_per_image < p.arena_elems_per_image
+    assert fused.arena_bytes_per_image < p.arena_bytes_per_image
 
 
 def test_fold_depthwise_plan_keeps_the_accounting():
@@ -72,7 +72,7 @@ def test_fold_depthwise_plan_keeps_the_accounting():
     assert sum(o.kind == rt.OP_DEPTHWISE for o in p.ops) == sum(o.kind == rt.OP_DEPTHWISE for o in base.ops) - 9
     assert p.total_macs() == base.total_macs()
     assert abs(p.algorithmic_bytes_per_image() - base.algorithmic_bytes_per_image()) < 1
-    assert p.arena_elems_per_image <= base.arena_elems_per_image
+    assert p.arena_bytes_per_image <= base.arena_bytes_per_image
     assert np.isfinite(p.build_blob(synthetic_weights(fm, 1, 'survey'))).all()
     b13 = next(o for o in folded if o.name == 'block_13_project')
     assert b13.se_reduced == (2 | (rt.ACT['relu6'] << 8)) and (b13.srcs[0].buf.h, b13.h) == (26, 13)
@@ -186,9 +186,12 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
         assert hasattr(L, sym), 'libyoloret_hip.so does not export %s' % sym
     assert declared == set(rt.EXPORTS)
     L.yr_abi_version.restype = ctypes.c_int
-    assert L.yr_abi_version() == 1
-    # struct layouts agree with the header's field order (spot check on sizes)
-    assert ctypes.sizeof(rt.YrSrc) == 32 and ctypes.sizeof(rt.YrBuf) == 24
+    assert L.yr_abi_version() == 2
+    # struct layouts agree with the header's (the library reports its own sizeof)
+    for which, st in enumerate((rt.YrSrc, rt.YrOp, rt.YrBuf)):
+        assert L.yr_abi_sizeof(which) == ctypes.sizeof(st), st.__name__
+    assert ctypes.sizeof(rt.YrSrc) == 40 and ctypes.sizeof(rt.YrBuf) == 24
+    rt.lib()   # the binding's own load-time checks
 
 
 def test_product_does_not_import_the_oracle():

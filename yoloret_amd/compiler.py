@@ -24,11 +24,13 @@ def round_up(v, m):
 
 
 class Buf:
-    def __init__(self, bid, h, w, c, ld, external_slot=-1, name=''):
+    def __init__(self, bid, h, w, c, ld, external_slot=-1, name='', dtype=0):
         self.id, self.h, self.w, self.c, self.ld = bid, h, w, c, ld
         self.external_slot = external_slot
         self.name = name
+        self.dtype = dtype            # yr_dtype of the elements (rt.DTYPE)
         self.elems = h * w * ld
+        self.bytes = self.elems * rt.ESIZE[dtype]
         self.first_def = None
         self.last_use = -1
         self.offset = -1
@@ -63,15 +65,17 @@ class OpRec:
         self.out = None
         self.res = None
         self.gate = None
-        self.params = {}      # role -> numpy builder fn(weights) -> array
+        self.params = {}      # role -> (shape, numpy builder fn(weights) -> float32 array[, yr_dtype it is stored as])
         self.offsets = {}     # role -> float offset in blob
         self.macs = 0
+        self.dtype = 0        # yr_dtype the op works in (sources, residual, pointwise weights)
         self.__dict__.update(kw)
 
 
 class Plan:
-    def __init__(self, ops, bufs, inputs, outputs, param_shapes, input_shape):
+    def __init__(self, ops, bufs, inputs, outputs, param_shapes, input_shape, dtype=0):
         self.ops, self.bufs = ops, bufs
+        self.dtype = dtype            # yr_dtype of the activations between ops (images, logits and SE vectors: float32)
         self.input_buf, self.output_bufs = inputs, outputs
         self.param_shapes = param_shapes
         self.input_shape = input_shape
@@ -97,7 +101,7 @@ class Plan:
         for i, b in enumerate(self.bufs):
             b.id = i
 
-    # -- arena: first-fit with liveness reuse (offsets in floats per image, multiples of 4)
+    # -- arena: first-fit with liveness reuse (offsets in BYTES per image, multiples of 16)
     def _assign_arena(self):
         arena = [b for b in self.bufs if b.external_slot < 0]
         for b in arena:
@@ -107,7 +111,7 @@ class Plan:
         total = 0
         for b in sorted(arena, key=lambda x: x.first_def):
             live = [l for l in live if l[2] >= b.first_def]  # a buffer read by op i may not be overwritten by op i
-            size = round_up(b.elems, 4)
+            size = round_up(b.bytes, 16)
             off = 0
             for lo, ls, _ in sorted(live):
                 if off + size <= lo:
@@ -116,25 +120,34 @@ class Plan:
             b.offset = off
             live.append((off, size, b.last_use))
             total = max(total, off + size)
-        self.arena_elems_per_image = total
+        self.arena_bytes_per_image = total
 
     def _assign_blob_offsets(self):
         off = 0
         self.blob_layout = []
         for op in self.ops:
-            for role, (shape, _fn) in op.params.items():
+            for role, prm in op.params.items():
+                shape, dt = prm[0], (prm[2] if len(prm) > 2 else 0)
                 n = int(np.prod(shape))
                 op.offsets[role] = off
-                self.blob_layout.append((op, role, off, shape))
-                off += round_up(n, 4)
+                self.blob_layout.append((op, role, off, shape, dt))
+                off += round_up((n * rt.ESIZE[dt] + 3) // 4, 4)   # the blob is addressed in floats; a 16-bit matrix takes n/2
         self.blob_floats = max(off, 4)
 
     def build_blob(self, weights):
+        """The flat parameter blob in op order.  float32 everywhere except the pointwise weight matrices of a 16-bit
+        plan, which are rounded (to nearest even) to that type here, once, and stored packed two per float slot."""
         blob = np.zeros(self.blob_floats, np.float32)
-        for op, role, off, shape in self.blob_layout:
+        for op, role, off, shape, dt in self.blob_layout:
             arr = np.asarray(op.params[role][1](weights), np.float32)
             assert tuple(arr.shape) == tuple(shape), (op.name, role, arr.shape, shape)
-            blob[off:off + arr.size] = arr.ravel()
+            if dt == 0:
+                blob[off:off + arr.size] = arr.ravel()
+            else:
+                bits = rt.to_bits16(arr.ravel(), dt)
+                if bits.size % 2:
+                    bits = np.concatenate([bits, np.zeros(1, np.uint16)])
+                blob[off:off + bits.size // 2] = bits.view(np.float32)
         return blob
 
     def c_arrays(self):
@@ -144,11 +157,13 @@ class Plan:
             o.kind, o.act = r.kind, rt.ACT[r.act]
             o.h, o.w, o.cin, o.cout, o.k, o.stride = r.h, r.w, r.cin, r.cout, r.k, r.stride
             o.nsrc, o.se_reduced = len(r.srcs), r.se_reduced
+            o.dtype, o.out_dtype = r.dtype, r.out.dtype
             for j, s in enumerate(r.srcs):
                 o.src[j].ptr = None
                 o.src[j].buf = s.buf.id
                 o.src[j].h, o.src[j].w, o.src[j].c, o.src[j].ld = s.buf.h, s.buf.w, s.c, s.buf.ld
                 o.src[j].xform = rt.XFORM[s.xform]
+                o.src[j].dtype = s.buf.dtype
             o.out_buf, o.out_ld = r.out.id, r.out.ld
             o.res_buf, o.res_ld = (r.res.id, r.res.ld) if r.res is not None else (-1, 0)
             o.gate_buf, o.gate_ld = (r.gate.id, r.gate.ld) if r.gate is not None else (-1, 0)
@@ -159,9 +174,10 @@ class Plan:
         bufs = (rt.YrBuf * len(self.bufs))()
         for i, b in enumerate(self.bufs):
             assert b.id == i
-            bufs[i].elems_per_image = b.elems
+            bufs[i].bytes_per_image = b.bytes
             bufs[i].arena_off_per_image = b.offset if b.external_slot < 0 else -1
             bufs[i].external_slot = b.external_slot
+            bufs[i].dtype = b.dtype
         return ops, bufs
 
     # -- reporting
@@ -214,17 +230,17 @@ class Plan:
                 elems += getattr(op, 'merged_mean', 0)
             return elems
 
-        return [elems_of(op) * 4 for op in self.ops]
+        return [elems_of(op) * rt.ESIZE[self.dtype] for op in self.ops]
 
     def hbm_bytes_per_op(self):
         """What each op actually has to move through HBM per image when intermediates of fused ops
         stay on chip (reads of every source + writes of the output, fp32)."""
         out = []
         for op in self.ops:
-            rd = sum(s.buf.h * s.buf.w * s.c for s in op.srcs)
+            rd = sum(s.buf.h * s.buf.w * s.c * rt.ESIZE[s.buf.dtype] for s in op.srcs)
             if op.kind == rt.OP_POINTWISE and op.res is not None:
-                rd += op.h * op.w * op.cout
-            out.append((rd + op.out.h * op.out.w * op.out.c) * 4)
+                rd += op.h * op.w * op.cout * rt.ESIZE[op.res.dtype]
+            out.append(rd + op.out.h * op.out.w * op.out.c * rt.ESIZE[op.out.dtype])
         return out
 
     def algorithmic_bytes_per_image(self):
@@ -269,25 +285,27 @@ def hoist_upsampled_sources(ops, bufs):
         if not ok:
             out.append(op)
             continue
-        pads = [round_up(s.c, 4) for s in op.srcs]
+        V = rt.VEC[op.dtype]
+        pads = [round_up(s.c, V) for s in op.srcs]
         base = [sum(pads[:i]) for i in range(len(pads))]
         lo_cols = [(base[i], pads[i]) for i, s in enumerate(op.srcs) if s.xform == 'up2']
         hi_cols = [(base[i], pads[i]) for i, s in enumerate(op.srcs) if s.xform != 'up2']
-        wshape, wfn = op.params['wgt']
+        wshape, wfn = op.params['wgt'][:2]
         h_lo, w_lo = lo[0].buf.h, lo[0].buf.w
-        p = Buf(len(bufs), h_lo, w_lo, op.cout, round_up(op.cout, 4), name=op.name + '_lowres')
+        # (float32 in every plan: a pre-BatchNorm partial sum, rounding it to 16 bits would cost the conv its accuracy)
+        p = Buf(len(bufs), h_lo, w_lo, op.cout, round_up(op.cout, 4), name=op.name + '_lowres', dtype=0)
         bufs.append(p)
 
         def cols(sel, wfn=wfn):
             return lambda wd: np.ascontiguousarray(np.concatenate([wfn(wd)[:, b:b + n] for b, n in sel], axis=1))
         low = OpRec(rt.OP_POINTWISE, op.name + '_lowres', act='none', h=h_lo, w=w_lo, cin=sum(s.c for s in lo),
-                    cout=op.cout, srcs=[Seg(s.buf, s.c, 'identity') for s in lo], out=p, macs=0)
-        low.params = {'wgt': ((op.cout, sum(n for _, n in lo_cols)), cols(lo_cols))}
+                    cout=op.cout, srcs=[Seg(s.buf, s.c, 'identity') for s in lo], out=p, macs=0, dtype=op.dtype)
+        low.params = {'wgt': ((op.cout, sum(n for _, n in lo_cols)), cols(lo_cols), op.dtype)}
         low.accounted_in = op.name     # its traffic and MACs are part of `op` in the conv-granular accounting
         top = OpRec(rt.OP_POINTWISE, op.name, act=op.act, h=op.h, w=op.w, cin=sum(s.c for s in hi), cout=op.cout,
-                    srcs=hi + [Seg(p, op.cout, 'up2_add')], out=op.out, res=op.res, macs=op.macs)
+                    srcs=hi + [Seg(p, op.cout, 'up2_add')], out=op.out, res=op.res, macs=op.macs, dtype=op.dtype)
         top.params = dict(op.params)
-        top.params['wgt'] = ((op.cout, sum(n for _, n in hi_cols)), cols(hi_cols))
+        top.params['wgt'] = ((op.cout, sum(n for _, n in hi_cols)), cols(hi_cols), op.dtype)
         top.accounting_srcs = list(op.srcs)   # SURVEY 8(d) charges the conv its original (concatenated) input
         out += [low, top]
     return out
@@ -342,7 +360,7 @@ def pool_into_producers(ops, bufs, output_buf_ids):
                 or not rd or any(s is None or s.xform != 'maxpool2' for _, s in rd) or op.h % 2 or op.w % 2
                 or any(s.xform == 'up2_add' for s in op.srcs) or getattr(op, 'stride', 0) == 2):
             continue
-        q = Buf(len(bufs), op.h // 2, op.w // 2, op.out.c, op.out.ld, name=op.out.name + '_pooled')
+        q = Buf(len(bufs), op.h // 2, op.w // 2, op.out.c, op.out.ld, name=op.out.name + '_pooled', dtype=op.out.dtype)
         bufs.append(q)
         op.accounting_hw = q.accounting_hw = (op.h, op.w)   # SURVEY 8(d) charges the conv its full-resolution output
         op.out, op.h, op.w, op.stride = q, op.h // 2, op.w // 2, 2
@@ -376,7 +394,7 @@ def fold_depthwise_into_project(ops, output_buf_ids):
     while i < len(ops):
         d = ops[i]
         p = ops[i + 1] if i + 1 < len(ops) else None
-        if (p is not None and d.kind == rt.OP_DEPTHWISE and d.k == 3 and d.stride in (1, 2)
+        if (p is not None and d.kind == rt.OP_DEPTHWISE and d.dtype == 0 and d.k == 3 and d.stride in (1, 2)
                 and len(d.srcs) == 1 and d.srcs[0].xform == 'identity' and d.srcs[0].c == d.srcs[0].buf.c
                 and p.kind == rt.OP_POINTWISE and len(p.srcs) == 1 and p.srcs[0].buf is d.out
                 and p.srcs[0].xform == 'identity' and p.gate is None and not getattr(p, 'stride', 0)
@@ -549,8 +567,10 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True):
 
 
 class Compiler:
-    def __init__(self, inputs, outputs, fuse=True):
+    def __init__(self, inputs, outputs, fuse=True, dtype=0):
         self.fuse = fuse
+        self.dtype = rt.dtype_id(dtype)   # element type of the activations between ops
+        self.V = rt.VEC[self.dtype]
         self.inputs = inputs
         self.outputs = list(outputs)
         self.bufs = []
@@ -593,12 +613,17 @@ class Compiler:
                 return None
         return n
 
-    def _new_buf(self, h, w, c, ld=None, external_slot=-1, name=''):
-        b = Buf(len(self.bufs), h, w, c, round_up(c, 4) if ld is None else ld, external_slot, name)
+    def _new_buf(self, h, w, c, ld=None, external_slot=-1, name='', dtype=None):
+        """Arena buffers hold the plan's activation type unless told otherwise; external ones (images, logits) and
+        the SE vectors are float32 in every plan."""
+        if dtype is None:
+            dtype = self.dtype if external_slot < 0 else 0
+        b = Buf(len(self.bufs), h, w, c, round_up(c, rt.VEC[dtype]) if ld is None else ld, external_slot, name, dtype)
         self.bufs.append(b)
         return b
 
     def _emit(self, op):
+        op.dtype = self.dtype
         idx = len(self.ops)
         self.ops.append(op)
         op.out.first_def = idx if op.out.first_def is None else op.out.first_def
@@ -704,10 +729,11 @@ class Compiler:
             latency = self.fuse == 'latency'
             if MERGE_SE_MEAN and not latency:
                 ops = merge_se_mean(ops)
-            ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency)
-            if FOLD_DW and not latency:
+            if self.dtype == 0:   # the fused block / network-entry kernels are float32
+                ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency)
+            if FOLD_DW and not latency and self.dtype == 0:
                 ops = fold_depthwise_into_project(ops, set(b.id for b in outs))
-        return Plan(ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape)
+        return Plan(ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape, self.dtype)
 
     def _lower_conv2d(self, n, done):
         x = n.inputs[0]
@@ -757,18 +783,19 @@ class Compiler:
         hh, ww = last.shape[0], last.shape[1]
         op = OpRec(rt.OP_POINTWISE, n.name, act=act, h=hh, w=ww, cin=cin, cout=cout, srcs=segs, out=out,
                    res=res, gate=v.gate, macs=hh * ww * cin * cout)
-        kp = sum(round_up(sg.c, 4) for sg in segs)
+        V = self.V
+        kp = sum(round_up(sg.c, V) for sg in segs)
 
-        def wfn(wd, kname=kname, segs=[sg.c for sg in segs], kp=kp, cout=cout):
+        def wfn(wd, kname=kname, segs=[sg.c for sg in segs], kp=kp, cout=cout, V=V):
             wk = wd[kname].reshape(-1, cout)  # [cin, cout]
             o = np.zeros((cout, kp), np.float32)
             d = kb = 0
             for c_ in segs:
                 o[:, kb:kb + c_] = wk[d:d + c_].T
                 d += c_
-                kb += round_up(c_, 4)
+                kb += round_up(c_, V)
             return o
-        op.params = {'wgt': ((cout, kp), wfn)}
+        op.params = {'wgt': ((cout, kp), wfn, self.dtype)}
         if bn is not None or bias is not None:
             sc, sh = self._bn_fold(bn, bias, cout)
             op.params['scale'] = ((cout,), sc)
@@ -805,7 +832,7 @@ class Compiler:
             return False
         src = self._plain(x)
         ldc = round_up(c, 4)
-        out = self._new_buf(1, 1, c, name=n.name + ':gate')
+        out = self._new_buf(1, 1, c, ld=round_up(c, self.V), name=n.name + ':gate', dtype=0)   # float32; ld covers the consumer's k-space
         op = OpRec(rt.OP_SE_FC, n.name, h=1, w=1, cin=c, cout=c, se_reduced=r, srcs=[src], out=out,
                    macs=2 * c * r)
         k1, b1, k2, b2 = n.name + '/kernel', n.name + '/bias', c2.name + '/kernel', c2.name + '/bias'
@@ -857,7 +884,7 @@ class Compiler:
         x = n.inputs[0]
         src = self._plain(x)
         c = x.shape[2]
-        out = self._new_buf(1, 1, c, name=n.name)
+        out = self._new_buf(1, 1, c, name=n.name, dtype=0)
         self._emit(OpRec(rt.OP_SE_MEAN, n.name, h=1, w=1, cin=c, cout=c, srcs=[src], out=out))
         done.add(id(n))
         self.values[id(n.output)] = Value([Seg(out, c)])
@@ -935,5 +962,5 @@ class Compiler:
         raise NotImplementedError('Add %s does not follow a fused 1x1 convolution' % n.name)
 
 
-def compile_graph(inputs, outputs, fuse=True):
-    return Compiler(inputs, outputs, fuse).compile()
+def compile_graph(inputs, outputs, fuse=True, dtype=0):
+    return Compiler(inputs, outputs, fuse, dtype).compile()

@@ -12,12 +12,15 @@
 // default was measured to fetch each input row ~3x from HBM - profiles/r01_pmc_fetch.txt).
 #include "yr_common.h"
 
+// T: element type of the input and output maps (float32, or bf16 / f16 storage: widened on load, rounded to nearest
+// on store; the accumulation, BatchNorm and activation are float32 either way).  Weights, scale, shift: float32.
+template <class T>
 struct DwArgs {
-    const float* in;     // [B][Hi][Wi][ld_in]
+    const T* in;         // [B][Hi][Wi][ld_in]
     const float* w;      // [K*K][ld_w] (channel-fastest)
     const float* scale;  // [C]
     const float* shift;  // [C]
-    float* out;          // [B][Ho][Wo][ld_out]
+    T* out;              // [B][Ho][Wo][ld_out]
     int B, Hi, Wi, Ho, Wo, C4;  // C4 = ceil(C/4)
     int ld_in, ld_w, ld_out;
     int pad_t, pad_l;
@@ -32,8 +35,8 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
                        __builtin_fmaf(a.z, b.z, c.z), __builtin_fmaf(a.w, b.w, c.w));
 }
 
-template <int K, int S, int XT, int YT>
-__global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
+template <int K, int S, int XT, int YT, class T>
+__global__ __launch_bounds__(256) void dw_kernel(DwArgs<T> a) {
     const long long gid = (long long)yr_xcd_swizzle(blockIdx.x, a.nblocks) * 256 + threadIdx.x;
     if (gid >= a.total) return;
     const int cq = (int)(gid % a.C4);
@@ -59,13 +62,12 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
     for (int r = 0; r < ROWS; ++r) {
         const int iy = iy0 + r;
         if (iy < 0 || iy >= a.Hi) continue;  // zero padding row
-        const float* rowp = a.in + ((size_t)(b * a.Hi + iy) * a.Wi) * a.ld_in + c;
+        const T* rowp = a.in + ((size_t)(b * a.Hi + iy) * a.Wi) * a.ld_in + c;
         float4 col[COLS];
 #pragma unroll
         for (int j = 0; j < COLS; ++j) {
             const int ix = ix0 + j;
-            col[j] = (ix >= 0 && ix < a.Wi) ? *reinterpret_cast<const float4*>(rowp + (size_t)ix * a.ld_in)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            col[j] = (ix >= 0 && ix < a.Wi) ? yr_ld4<T>(rowp + (size_t)ix * a.ld_in) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         // input row r feeds output row j through kernel row ky = r - j*S
 #pragma unroll
@@ -85,47 +87,50 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
 #pragma unroll
     for (int j = 0; j < YT; ++j) {
         if (y0 + j >= a.Ho) continue;
-        float* op = a.out + ((size_t)(b * a.Ho + y0 + j) * a.Wo + x0) * a.ld_out + c;
+        T* op = a.out + ((size_t)(b * a.Ho + y0 + j) * a.Wo + x0) * a.ld_out + c;
 #pragma unroll
         for (int i = 0; i < XT; ++i) {
             if (x0 + i < a.Wo) {
                 float4 v = yr_apply_act4(fma4(acc[j][i], sc, sh), a.act);
-                *reinterpret_cast<float4*>(op + (size_t)i * a.ld_out) = v;
+                yr_st4<T>(op + (size_t)i * a.ld_out, v);
             }
         }
     }
 }
 
-template <int K, int S, int XT, int YT>
-static int launch_dw(DwArgs a, hipStream_t s) {
+template <int K, int S, int XT, int YT, class T>
+static int launch_dw(DwArgs<T> a, hipStream_t s) {
     a.xstrips = (a.Wo + XT - 1) / XT;
     a.ystrips = (a.Ho + YT - 1) / YT;
     a.total = (long long)a.B * a.ystrips * a.xstrips * a.C4;
     const long long blocks = (a.total + 255) / 256;
     YR_REQUIRE(blocks < (1ll << 31), "depthwise: grid too large");
     a.nblocks = (unsigned)blocks;
-    static char nm[32];
-    static const int nm_len = snprintf(nm, sizeof(nm), "dw_kernel<%d,%d,%d,%d>", K, S, XT, YT);
+    static char nm[40];
+    static const int nm_len = snprintf(nm, sizeof(nm), "dw_kernel<%d,%d,%d,%d,%s>", K, S, XT, YT, yr_dtype_name(yr_elem<T>::dtype));
     (void)nm_len;
     yr_note_kernel(nm);
-    hipLaunchKernelGGL((dw_kernel<K, S, XT, YT>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((dw_kernel<K, S, XT, YT, T>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
 }
 
-int yr_launch_depthwise(const yr_op& op, int batch, hipStream_t s) {
+template <class T>
+static int launch_depthwise_t(const yr_op& op, int batch, hipStream_t s) {
+    constexpr int V = yr_elem<T>::vec;
     YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY, "depthwise: needs one identity source");
+    YR_REQUIRE(op.src[0].dtype == op.dtype && op.out_dtype == op.dtype, "depthwise: source and output must have the op's dtype");
     const yr_src& in = op.src[0];
     YR_REQUIRE(op.k == 3 || op.k == 5, "depthwise: kernel size %d unsupported", op.k);
     YR_REQUIRE(op.stride == 1 || op.stride == 2, "depthwise: stride %d unsupported", op.stride);
     YR_REQUIRE(in.c == op.cout && op.cin == op.cout, "depthwise: channel mismatch");
-    YR_REQUIRE(in.ld % 4 == 0 && op.out_ld % 4 == 0 && in.ld >= yr_round_up(in.c, 4) && op.out_ld >= yr_round_up(in.c, 4),
-               "depthwise: ld must be a multiple of 4 and cover round_up(c,4)");
+    YR_REQUIRE(in.ld % V == 0 && op.out_ld % V == 0 && in.ld >= yr_round_up(in.c, 4) && op.out_ld >= yr_round_up(in.c, 4),
+               "depthwise: ld must be a multiple of %d and cover round_up(c,4)", V);
     YR_REQUIRE(in.ptr && op.out && op.wgt && op.scale && op.shift, "depthwise: null pointer");
     YR_REQUIRE(((uintptr_t)in.ptr | (uintptr_t)op.out | (uintptr_t)op.wgt | (uintptr_t)op.scale | (uintptr_t)op.shift) % 16 == 0,
                "depthwise: pointers must be 16-byte aligned");
-    DwArgs a;
-    a.in = in.ptr; a.w = op.wgt; a.scale = op.scale; a.shift = op.shift; a.out = op.out;
+    DwArgs<T> a;
+    a.in = (const T*)in.ptr; a.w = op.wgt; a.scale = op.scale; a.shift = op.shift; a.out = (T*)op.out;
     a.B = batch; a.Hi = in.h; a.Wi = in.w;
     a.Ho = (in.h + op.stride - 1) / op.stride;
     a.Wo = (in.w + op.stride - 1) / op.stride;
@@ -141,8 +146,10 @@ int yr_launch_depthwise(const yr_op& op, int batch, hipStream_t s) {
     const bool big = (long long)batch * a.Ho * a.Wo * a.C4 >= (1ll << 21);
     // stride 1: 4x1 patches beat 4x2, 2x1, 2x2, 8x1 and 13x1 on every 13/26/52 map of the flagship (tools/dw_probe.py):
     // the neighbouring rows' re-reads hit L2, and the shorter patch keeps more loads in flight per CU
-    if (op.k == 3 && op.stride == 1) return launch_dw<3, 1, 4, 1>(a, s);
-    if (op.k == 3 && op.stride == 2) return big ? launch_dw<3, 2, 2, 2>(a, s) : launch_dw<3, 2, 2, 1>(a, s);
-    if (op.k == 5 && op.stride == 1) return launch_dw<5, 1, 4, 1>(a, s);
-    return launch_dw<5, 2, 2, 1>(a, s);
+    if (op.k == 3 && op.stride == 1) return launch_dw<3, 1, 4, 1, T>(a, s);
+    if (op.k == 3 && op.stride == 2) return big ? launch_dw<3, 2, 2, 2, T>(a, s) : launch_dw<3, 2, 2, 1, T>(a, s);
+    if (op.k == 5 && op.stride == 1) return launch_dw<5, 1, 4, 1, T>(a, s);
+    return launch_dw<5, 2, 2, 1, T>(a, s);
 }
+
+int yr_launch_depthwise(const yr_op& op, int batch, hipStream_t s) { return YR_BY_DTYPE(op.dtype, launch_depthwise_t, op, batch, s); }

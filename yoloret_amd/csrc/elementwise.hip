@@ -9,8 +9,9 @@
 #include "yr_common.h"
 
 // ------------------------------------------------------------------ SE mean
+template <class T>
 struct MeanArgs {
-    const float* in;  // [B][HW][ld]
+    const T* in;      // [B][HW][ld]   (T: float32 or 16-bit storage; the sum and the mean are float32)
     float* out;       // [B][ld_out]
     int HW, C4, ld, ld_out, C;
     float inv;        // unused (division keeps reduce_mean's sum/count form)
@@ -19,17 +20,18 @@ struct MeanArgs {
 // grid (ceil(C4/16), B); block 1024 = 64 pixel lanes x 16 channel quads.  Fixed summation
 // order => run-to-run deterministic.
 #define SE_MEAN_PL 64
-__global__ __launch_bounds__(1024) void se_mean_kernel(MeanArgs a) {
+template <class T>
+__global__ __launch_bounds__(1024) void se_mean_kernel(MeanArgs<T> a) {
     __shared__ float4 part[SE_MEAN_PL][16];
     const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int cq = blockIdx.x * 16 + q;
     const int b = blockIdx.y;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cq < a.C4) {
-        const float* p = a.in + (size_t)b * a.HW * a.ld + cq * 4;
+        const T* p = a.in + (size_t)b * a.HW * a.ld + cq * 4;
 #pragma unroll 4
         for (int i = pl; i < a.HW; i += SE_MEAN_PL) {
-            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)i * a.ld);
+            const float4 v = yr_ld4<T>(p + (size_t)i * a.ld);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     }
@@ -61,23 +63,30 @@ __global__ __launch_bounds__(1024) void se_mean_kernel(MeanArgs a) {
     }
 }
 
-int yr_launch_se_mean(const yr_op& op, int batch, hipStream_t s) {
+template <class T>
+static int launch_se_mean_t(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY, "se_mean: needs one identity source");
     const yr_src& in = op.src[0];
-    YR_REQUIRE(in.ptr && op.out && in.ld % 4 == 0 && op.out_ld % 4 == 0 && op.out_ld >= yr_round_up(in.c, 4),
+    YR_REQUIRE(in.dtype == op.dtype && op.out_dtype == YR_F32, "se_mean: the source has the op's dtype, the pooled vector is float32");
+    YR_REQUIRE(in.ptr && op.out && in.ld % yr_elem<T>::vec == 0 && op.out_ld % 4 == 0 && op.out_ld >= yr_round_up(in.c, 4),
                "se_mean: bad pointers / strides");
-    MeanArgs a;
-    a.in = in.ptr; a.out = op.out; a.HW = in.h * in.w; a.C = in.c; a.C4 = (in.c + 3) / 4;
+    MeanArgs<T> a;
+    a.in = (const T*)in.ptr; a.out = (float*)op.out; a.HW = in.h * in.w; a.C = in.c; a.C4 = (in.c + 3) / 4;
     a.ld = in.ld; a.ld_out = op.out_ld; a.inv = 0.f;
-    yr_note_kernel("se_mean_kernel");
-    hipLaunchKernelGGL(se_mean_kernel, dim3((a.C4 + 15) / 16, batch), dim3(1024), 0, s, a);
+    static char nm[32];
+    static const int nm_len = snprintf(nm, sizeof(nm), "se_mean_kernel<%s>", yr_dtype_name(yr_elem<T>::dtype));
+    (void)nm_len;
+    yr_note_kernel(nm);
+    hipLaunchKernelGGL(se_mean_kernel<T>, dim3((a.C4 + 15) / 16, batch), dim3(1024), 0, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
 }
+int yr_launch_se_mean(const yr_op& op, int batch, hipStream_t s) { return YR_BY_DTYPE(op.dtype, launch_se_mean_t, op, batch, s); }
 
 // ------------------------------------------------------------------ SE FCs
+template <class T>
 struct FcArgs {
-    const float* map;   // HW > 1: the full map [B][HW][ld_map] whose spatial mean is the FC input (SE_MEAN merged in)
+    const T* map;       // HW > 1: the full map [B][HW][ld_map] (element type T) whose spatial mean is the FC input (SE_MEAN merged in)
     int HW, ld_map;
     const float* mean;  // [B][ld_mean]
     const float* w1t;   // [R][ldc]   (transposed Keras kernel: hidden j, channel c)
@@ -93,7 +102,8 @@ struct FcArgs {
 //   fc2: thread (jg, c): partial sum over j = jg, jg+JS, ... of hid[j]*W2[j][c] (coalesced across c),
 //        combined through LDS in a fixed order (deterministic).
 #define SE_FC_THREADS 1024
-__global__ __launch_bounds__(SE_FC_THREADS) void se_fc_kernel(FcArgs a) {
+template <class T>
+__global__ __launch_bounds__(SE_FC_THREADS) void se_fc_kernel(FcArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* mean = sm;                 // [ldc]
     float* hid = sm + a.ldc;          // [R]
@@ -112,10 +122,10 @@ __global__ __launch_bounds__(SE_FC_THREADS) void se_fc_kernel(FcArgs a) {
             const int cq = q0 + (tid & (c4p - 1)), pl = tid / c4p;
             float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (cq < C4) {
-                const float* p = a.map + (size_t)b * a.HW * a.ld_map + cq * 4;
+                const T* p = a.map + (size_t)b * a.HW * a.ld_map + cq * 4;
 #pragma unroll 8
                 for (int i = pl; i < a.HW; i += PL) {
-                    const float4 v = *reinterpret_cast<const float4*>(p + (size_t)i * a.ld_map);
+                    const float4 v = yr_ld4<T>(p + (size_t)i * a.ld_map);
                     s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
                 }
             }
@@ -176,35 +186,48 @@ __global__ __launch_bounds__(SE_FC_THREADS) void se_fc_kernel(FcArgs a) {
     }
 }
 
-int yr_launch_se_fc(const yr_op& op, int batch, hipStream_t s) {
+template <class T>
+static int launch_se_fc_t(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(op.nsrc == 1, "se_fc: needs one source (the pooled vector)");
     const yr_src& in = op.src[0];
     YR_REQUIRE(in.ptr && op.out && op.wgt && op.wgt2 && op.b1 && op.b2, "se_fc: null pointer");
     YR_REQUIRE(op.se_reduced >= 1 && in.c == op.cout, "se_fc: bad widths");
-    FcArgs a;
-    a.map = in.ptr; a.HW = in.h * in.w; a.ld_map = in.ld;   // h*w > 1: the pooled vector is computed here (SE_MEAN merged)
-    YR_REQUIRE(a.HW == 1 || (in.ld % 4 == 0 && ((uintptr_t)in.ptr % 16) == 0), "se_fc: the map to pool must be float4-addressable");
-    a.mean = in.ptr; a.w1t = op.wgt; a.b1 = op.b1; a.w2 = op.wgt2; a.b2 = op.b2; a.gate = op.out;
+    YR_REQUIRE(op.out_dtype == YR_F32, "se_fc: the gate is float32");
+    FcArgs<T> a;
+    a.map = (const T*)in.ptr; a.HW = in.h * in.w; a.ld_map = in.ld;   // h*w > 1: the pooled vector is computed here (SE_MEAN merged)
+    YR_REQUIRE(a.HW == 1 ? in.dtype == YR_F32 : in.dtype == op.dtype, "se_fc: a pooled vector is float32, a map to pool has the op's dtype");
+    YR_REQUIRE(a.HW == 1 || (in.ld % yr_elem<T>::vec == 0 && ((uintptr_t)in.ptr % 16) == 0), "se_fc: the map to pool must be 16-byte addressable per pixel");
+    a.mean = (const float*)in.ptr; a.w1t = op.wgt; a.b1 = op.b1; a.w2 = op.wgt2; a.b2 = op.b2; a.gate = (float*)op.out;
     a.C = in.c; a.R = op.se_reduced; a.ldc = yr_round_up(in.c, 4); a.ld_mean = in.ld; a.ld_gate = op.out_ld;
     YR_REQUIRE(op.out_ld >= a.ldc, "se_fc: gate ld too small");
     const size_t lds = (size_t)((a.ldc + a.R + SE_FC_THREADS + 3) & ~3) * sizeof(float) + (a.HW > 1 ? SE_FC_THREADS * sizeof(float4) : 0);
     YR_REQUIRE(lds <= 64 * 1024, "se_fc: widths too large for LDS");
-    yr_note_kernel("se_fc_kernel");
-    hipLaunchKernelGGL(se_fc_kernel, dim3(batch), dim3(SE_FC_THREADS), lds, s, a);
+    static char nm[32];
+    static const int nm_len = snprintf(nm, sizeof(nm), "se_fc_kernel<%s>", yr_dtype_name(yr_elem<T>::dtype));
+    (void)nm_len;
+    yr_note_kernel(nm);
+    hipLaunchKernelGGL(se_fc_kernel<T>, dim3(batch), dim3(SE_FC_THREADS), lds, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
 }
+int yr_launch_se_fc(const yr_op& op, int batch, hipStream_t s) {
+    // a pooled vector (h*w == 1) is float32 whatever the plan's dtype: one instantiation serves it
+    if (op.nsrc == 1 && op.src[0].h * op.src[0].w == 1) return launch_se_fc_t<float>(op, batch, s);
+    return YR_BY_DTYPE(op.dtype, launch_se_fc_t, op, batch, s);
+}
 
 // ------------------------------------------------------------------ WeightedSum
+template <class T>
 struct WsumArgs {
     DSrc s[4];
     const float* alpha;  // [4]
-    float* out;
+    T* out;
     int H, W, C4, ld_out;
     long long total;
 };
 
-__global__ __launch_bounds__(256) void wsum_kernel(WsumArgs a) {
+template <class T>
+__global__ __launch_bounds__(256) void wsum_kernel(WsumArgs<T> a) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= a.total) return;
     const int cq = (int)(gid % a.C4);
@@ -214,47 +237,55 @@ __global__ __launch_bounds__(256) void wsum_kernel(WsumArgs a) {
     const int y = (int)(t % a.H);
     const int b = (int)(t / a.H);
     const float a0 = a.alpha[0], a1 = a.alpha[1], a2 = a.alpha[2], a3 = a.alpha[3];
-    const float4 v0 = yr_load_src_quad(a.s[0], b, y, x, cq * 4);
-    const float4 v1 = yr_load_src_quad(a.s[1], b, y, x, cq * 4);
-    const float4 v2 = yr_load_src_quad(a.s[2], b, y, x, cq * 4);
-    const float4 v3 = yr_load_src_quad(a.s[3], b, y, x, cq * 4);
+    const float4 v0 = yr_load_src_quad<T>(a.s[0], b, y, x, cq * 4);
+    const float4 v1 = yr_load_src_quad<T>(a.s[1], b, y, x, cq * 4);
+    const float4 v2 = yr_load_src_quad<T>(a.s[2], b, y, x, cq * 4);
+    const float4 v3 = yr_load_src_quad<T>(a.s[3], b, y, x, cq * 4);
     // reference order (model.py:134): a0*m0 + a1*m1 + a2*m2 + a3*m3, left to right, no contraction
     float4 r;
     r.x = a0 * v0.x + a1 * v1.x + a2 * v2.x + a3 * v3.x;
     r.y = a0 * v0.y + a1 * v1.y + a2 * v2.y + a3 * v3.y;
     r.z = a0 * v0.z + a1 * v1.z + a2 * v2.z + a3 * v3.z;
     r.w = a0 * v0.w + a1 * v1.w + a2 * v2.w + a3 * v3.w;
-    *reinterpret_cast<float4*>(a.out + ((size_t)(b * a.H + y) * a.W + x) * a.ld_out + cq * 4) = r;
+    yr_st4<T>(a.out + ((size_t)(b * a.H + y) * a.W + x) * a.ld_out + cq * 4, r);
 }
 
-int yr_launch_wsum(const yr_op& op, int batch, hipStream_t s) {
+template <class T>
+static int launch_wsum_t(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(op.nsrc == 4, "wsum: needs exactly 4 sources");
+    YR_REQUIRE(op.out_dtype == op.dtype, "wsum: the output has the op's dtype");
     DSrcSet S;
     for (int i = 0; i < op.nsrc && i < YR_MAX_SRC; ++i) YR_REQUIRE(op.src[i].xform != YR_X_DW3, "dw3 sources are a POINTWISE feature");
     int rc = yr_make_srcset(op, &S);
     if (rc) return rc;
     for (int i = 0; i < 4; ++i) YR_REQUIRE(op.src[i].c == op.cout, "wsum: source %d has %d channels, expected %d", i, op.src[i].c, op.cout);
-    YR_REQUIRE(op.wgt && op.out && op.out_ld % 4 == 0 && op.out_ld >= yr_round_up(op.cout, 4), "wsum: bad out/alpha");
-    WsumArgs a;
+    YR_REQUIRE(op.wgt && op.out && op.out_ld % yr_elem<T>::vec == 0 && op.out_ld >= yr_round_up(op.cout, 4), "wsum: bad out/alpha");
+    WsumArgs<T> a;
     for (int i = 0; i < 4; ++i) a.s[i] = S.s[i];
-    a.alpha = op.wgt; a.out = op.out; a.H = op.h; a.W = op.w; a.C4 = (op.cout + 3) / 4; a.ld_out = op.out_ld;
+    a.alpha = op.wgt; a.out = (T*)op.out; a.H = op.h; a.W = op.w; a.C4 = (op.cout + 3) / 4; a.ld_out = op.out_ld;
     a.total = (long long)batch * op.h * op.w * a.C4;
-    yr_note_kernel("wsum_kernel");
-    hipLaunchKernelGGL(wsum_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, s, a);
+    static char nm[32];
+    static const int nm_len = snprintf(nm, sizeof(nm), "wsum_kernel<%s>", yr_dtype_name(yr_elem<T>::dtype));
+    (void)nm_len;
+    yr_note_kernel(nm);
+    hipLaunchKernelGGL(wsum_kernel<T>, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
 }
+int yr_launch_wsum(const yr_op& op, int batch, hipStream_t s) { return YR_BY_DTYPE(op.dtype, launch_wsum_t, op, batch, s); }
 
 // ------------------------------------------------------------------ gather (materialise)
+template <class T>
 struct GatherArgs {
     DSrcSet S;
     int dense_base[YR_MAX_SRC];  // start of each segment in the dense concat output
-    float* out;
+    T* out;
     int H, W, KQ, ld_out;
     long long total;
 };
 
-__global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
+template <class T>
+__global__ __launch_bounds__(256) void gather_kernel(GatherArgs<T> a) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= a.total) return;
     const int kq = (int)(gid % a.KQ);
@@ -273,15 +304,17 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     if (si == 2) { s = a.S.s[2]; db = a.dense_base[2]; }
     if (si == 3) { s = a.S.s[3]; db = a.dense_base[3]; }
     const int kk = k - s.kbase;
-    const float4 v = yr_load_src_quad(s, b, y, x, kk);
-    float* op = a.out + ((size_t)(b * a.H + y) * a.W + x) * a.ld_out + db + kk;
+    const float4 v = yr_load_src_quad<T>(s, b, y, x, kk);
+    T* op = a.out + ((size_t)(b * a.H + y) * a.W + x) * a.ld_out + db + kk;
     const float vv[4] = {v.x, v.y, v.z, v.w};
     for (int j = 0; j < 4; ++j)
-        if (kk + j < s.c) op[j] = vv[j];
+        if (kk + j < s.c) yr_st1<T>(op + j, vv[j]);
 }
 
-int yr_launch_gather(const yr_op& op, int batch, hipStream_t s) {
-    GatherArgs a;
+template <class T>
+static int launch_gather_t(const yr_op& op, int batch, hipStream_t s) {
+    GatherArgs<T> a;
+    YR_REQUIRE(op.out_dtype == op.dtype, "gather: the output has the op's dtype");
     for (int i = 0; i < op.nsrc && i < YR_MAX_SRC; ++i) YR_REQUIRE(op.src[i].xform != YR_X_DW3, "dw3 sources are a POINTWISE feature");
     int rc = yr_make_srcset(op, &a.S);
     if (rc) return rc;
@@ -291,10 +324,14 @@ int yr_launch_gather(const yr_op& op, int batch, hipStream_t s) {
         if (i < op.nsrc) dense += op.src[i].c;
     }
     YR_REQUIRE(dense == op.cout && op.out && op.out_ld >= dense, "gather: cout %d != sum of sources %d (or bad out)", op.cout, dense);
-    a.out = op.out; a.H = op.h; a.W = op.w; a.KQ = a.S.kp / 4; a.ld_out = op.out_ld;
+    a.out = (T*)op.out; a.H = op.h; a.W = op.w; a.KQ = a.S.kp / 4; a.ld_out = op.out_ld;
     a.total = (long long)batch * op.h * op.w * a.KQ;
-    yr_note_kernel("gather_kernel");
-    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, s, a);
+    static char nm[32];
+    static const int nm_len = snprintf(nm, sizeof(nm), "gather_kernel<%s>", yr_dtype_name(yr_elem<T>::dtype));
+    (void)nm_len;
+    yr_note_kernel(nm);
+    hipLaunchKernelGGL(gather_kernel<T>, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
 }
+int yr_launch_gather(const yr_op& op, int batch, hipStream_t s) { return YR_BY_DTYPE(op.dtype, launch_gather_t, op, batch, s); }

@@ -322,7 +322,8 @@ int yr_launch_mbconv(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(in.ld % 4 == 0 && in.c == op.cin && in.ld >= yr_round_up(in.c, 4), "mbconv: bad input stride");
     YR_REQUIRE(((uintptr_t)in.ptr | (uintptr_t)op.wgt | (uintptr_t)op.wgt2 | (uintptr_t)op.b1) % 16 == 0, "mbconv: pointers must be 16-byte aligned");
     MbArgs a;
-    a.x = in.ptr; a.out = op.out;
+    YR_REQUIRE(op.dtype == YR_F32 && op.out_dtype == YR_F32 && in.dtype == YR_F32, "mbconv: float32 only");
+    a.x = (const float*)in.ptr; a.out = (float*)op.out;
     a.has_expand = op.wgt != nullptr;
     a.Cin = in.c; a.Cexp = a.has_expand ? op.se_reduced : in.c; a.Cout = op.cout;
     YR_REQUIRE(a.Cexp >= 1 && (a.has_expand || op.se_reduced == in.c), "mbconv: bad expanded width");

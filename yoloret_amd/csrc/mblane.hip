@@ -314,7 +314,8 @@ int yr_launch_mblane(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(((uintptr_t)in.ptr) % 16 == 0 && ((uintptr_t)op.out) % 8 == 0, "mblane: pointers must be 16-byte aligned");
     YR_REQUIRE(op.se_reduced >= 1 && op.cout >= 1 && op.out_ld >= op.cout, "mblane: bad widths");
     MlArgs a;
-    a.x = in.ptr; a.out = op.out;
+    YR_REQUIRE(op.dtype == YR_F32 && op.out_dtype == YR_F32 && in.dtype == YR_F32, "mblane: float32 only");
+    a.x = (const float*)in.ptr; a.out = (float*)op.out;
     a.we = op.wgt; a.wd = op.wgt2; a.wp = op.b1; a.bp = op.b2;
     a.Cin = in.c; a.Cout = op.cout;
     a.npairs = yr_round_up((op.se_reduced + 1) / 2, ML_CH);

@@ -159,11 +159,15 @@ int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
     PwArgs a;
     yr_op op = op_in;
     a.pre = nullptr; a.pre_ld = 0;
+    YR_REQUIRE(yr_dtype_ok(op.dtype) && (op.out_dtype == op.dtype || op.out_dtype == YR_F32),
+               "pointwise: dtype %d / out_dtype %d unsupported (the output has the op's dtype or is float32)", op.dtype, op.out_dtype);
+    const bool narrow = op.dtype != YR_F32;
+    const int V = yr_vec_of(op.dtype);
     if (op.nsrc >= 2 && op.src[op.nsrc - 1].xform == YR_X_UP2_ADD) {  // not a k-space source: see yr_xform
         const yr_src& p = op.src[op.nsrc - 1];
-        YR_REQUIRE(p.ptr && p.c == op.cout && p.ld >= op.cout && p.h * 2 == op.h && p.w * 2 == op.w,
-                   "pointwise: the up2_add source must be [B,%d,%d,cout=%d]", op.h / 2, op.w / 2, op.cout);
-        a.pre = p.ptr; a.pre_ld = p.ld;
+        YR_REQUIRE(p.ptr && p.c == op.cout && p.ld >= op.cout && p.h * 2 == op.h && p.w * 2 == op.w && p.dtype == YR_F32,
+                   "pointwise: the up2_add source must be float32 [B,%d,%d,cout=%d]", op.h / 2, op.w / 2, op.cout);
+        a.pre = (const float*)p.ptr; a.pre_ld = p.ld;
         op.nsrc -= 1;
     }
     for (int i = 0; i < op.nsrc; ++i)
@@ -184,6 +188,7 @@ int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
     a.dw_w = a.dw_scale = a.dw_shift = nullptr;
     a.dw_stride = a.dw_act = a.dw_pad_t = a.dw_pad_l = 0;
     const bool dw = op.src[0].xform == YR_X_DW3;
+    YR_REQUIRE(!(dw && narrow), "pointwise: a dw3 source is a float32 feature");
     if (dw) {
         const yr_src& e = op.src[0];
         YR_REQUIRE(a.pre == nullptr && !a.pool && op.gate == nullptr, "pointwise: a dw3 source takes no up2_add / pooled output / SE gate");
@@ -205,12 +210,18 @@ int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
     YR_REQUIRE(op.out_ld >= op.cout, "pointwise: out_ld %d < cout %d", op.out_ld, op.cout);
     YR_REQUIRE(((uintptr_t)op.wgt % 16) == 0, "pointwise: weights must be 16-byte aligned");
     if ((op.out_ld & 3) == 0) YR_REQUIRE(((uintptr_t)op.out % 16) == 0, "pointwise: out must be 16-byte aligned");
+    if (op.out_dtype != YR_F32)
+        YR_REQUIRE(op.out_ld % 8 == 0 && op.out_ld >= yr_round_up(op.cout, 8), "pointwise: a 16-bit output needs out_ld %% 8 == 0 and >= round_up(cout,8)");
+    if (narrow && op.res)
+        YR_REQUIRE(op.res_ld % 8 == 0 && op.res_ld >= yr_round_up(op.cout, 8) && ((uintptr_t)op.res % 16) == 0,
+                   "pointwise: a 16-bit residual needs res_ld %% 8 == 0, >= round_up(cout,8) and a 16-byte aligned pointer");
     if (op.gate) {
         YR_REQUIRE(op.nsrc == 1 && op.gate_ld % 4 == 0 && op.gate_ld >= a.S.kp, "pointwise: SE gate needs a single source and gate_ld >= kp");
         YR_REQUIRE(((uintptr_t)op.gate % 16) == 0, "pointwise: gate must be 16-byte aligned");
     }
-    YR_REQUIRE(a.S.kp >= 4, "pointwise: no input channels");
-    a.wt = op.wgt; a.scale = op.scale; a.shift = op.shift; a.res = op.res; a.gate = op.gate; a.out = op.out;
+    YR_REQUIRE(a.S.kp >= V, "pointwise: no input channels");
+    a.wt = op.wgt; a.scale = op.scale; a.shift = op.shift; a.res = (const float*)op.res; a.gate = op.gate; a.out = (float*)op.out;
+    a.out_f32 = op.out_dtype == YR_F32;
     a.H = op.h; a.W = op.w; a.N = op.cout;
     const long long M = (long long)batch * op.h * op.w;
     YR_REQUIRE(M > 0 && M < (1ll << 31), "pointwise: pixel count %lld out of range", M);
@@ -233,6 +244,7 @@ int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
                                {128, 32, launch_direct<2, 2>}, {128, 48, launch_direct<2, 3>}, {128, 64, launch_direct<2, 4>},
                                {128, 80, launch_direct<2, 5>}, {128, 96, launch_direct<2, 6>},
                                {256, 32, launch_direct<4, 2>}, {256, 48, launch_direct<4, 3>}, {256, 64, launch_direct<4, 4>}};
+    if (narrow) return yr_pw_launch_h(op.dtype, op.k - 1, a, s);   // bf16 / f16: pointwise_h.hip (its own tile table)
     constexpr int NLDS = 14;  // the first NLDS entries are the LDS-staged kernel (the heuristic below only ranks those)
     constexpr int NCFG = sizeof(cfgs) / sizeof(cfgs[0]);
     const int N = op.cout;
@@ -268,5 +280,5 @@ int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
     return best->fn(a, s);
 }
 
-// number of tile shapes yr_launch_pointwise can be forced to through op.k (1-based)
-int yr_pointwise_num_cfgs() { return 29; }
+// number of tile shapes yr_launch_pointwise can be forced to through op.k (1-based) for ops of this dtype
+int yr_pointwise_num_cfgs(int dtype) { return dtype == YR_F32 ? 29 : yr_pwh_num_cfgs(); }

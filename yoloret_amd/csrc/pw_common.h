@@ -44,6 +44,9 @@ struct PwArgs {
     const float* dw_scale;  // [S.kp] folded BN of the depthwise stage
     const float* dw_shift;  // [S.kp]
     int dw_stride, dw_act, dw_pad_t, dw_pad_l;
+    // 16-bit ops (pointwise_h.hip; the float32 kernels ignore it): sources, weights and residual are bf16 / f16 behind the
+    // type-erased pointers above; out_f32 = 1: `out` is float32 all the same (logit outputs, hoisted partial sums)
+    int out_f32;
 };
 
 // GEMM row -> conv pixel.  Plain: identity.  Pooled output: rows are walked in 2x2-quad-major order, so the four
@@ -312,3 +315,6 @@ __device__ __forceinline__ float4 pw_finish(float4 v, const float4& gt, int cval
 // LDS-staged kernel, tile shape index 0..13: (BM x BN) = 256x16, 128x32, 128x48, 128x64, 128x80, 128x96, 128x128,
 // 64x16, 64x32, 64x48, 64x64, 64x80, 64x96, 64x128
 int yr_pw_launch_lds(int shape, const PwArgs& a, hipStream_t s);
+// 16-bit kernel (pointwise_h.hip): cfg = tile shape index 0..yr_pwh_num_cfgs()-1, or -1 for its heuristic
+int yr_pw_launch_h(int dtype, int cfg, const PwArgs& a, hipStream_t s);
+int yr_pwh_num_cfgs();

@@ -25,6 +25,9 @@ void yr_note_kernel(const char* name) { g_kernel = name; }
 
 extern "C" const char* yr_last_error(void) { return g_err; }
 extern "C" int yr_abi_version(void) { return YR_ABI_VERSION; }
+extern "C" int yr_abi_sizeof(int which) {
+    return which == 0 ? (int)sizeof(yr_src) : which == 1 ? (int)sizeof(yr_op) : which == 2 ? (int)sizeof(yr_buf) : 0;
+}
 
 static int dispatch(const yr_op& op, int batch, hipStream_t s) {
     switch (op.kind) {
@@ -50,7 +53,7 @@ extern "C" int yr_op_run(const yr_op* op, int batch, void* stream) {
 struct yr_handle {
     std::vector<yr_op> ops;
     std::vector<yr_buf> bufs;
-    int64_t arena_per_image = 0;  // floats
+    int64_t arena_per_image = 0;  // bytes
     float* weights = nullptr;
     size_t n_weights = 0;
     std::map<int, std::vector<int>> tuned;  // batch -> per-op pointwise tile choice (1-based, 0 = heuristic)
@@ -65,28 +68,29 @@ extern "C" int yr_create(const yr_op* ops, int n_ops, const yr_buf* bufs, int n_
     if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
     for (const yr_buf& b : h->bufs) {
         if (b.external_slot < 0) {
-            if (b.arena_off_per_image < 0 || b.arena_off_per_image % 4 != 0 || b.elems_per_image <= 0) {
+            if (b.arena_off_per_image < 0 || b.arena_off_per_image % 16 != 0 || b.bytes_per_image <= 0 || !yr_dtype_ok(b.dtype)) {
                 delete h;
-                yr_set_error("yr_create: arena buffer with bad offset/size");
+                yr_set_error("yr_create: arena buffer with bad offset/size/dtype");
                 return YR_ERR_ARG;
             }
-            const int64_t end = b.arena_off_per_image + b.elems_per_image;
+            const int64_t end = b.arena_off_per_image + b.bytes_per_image;
             if (end > h->arena_per_image) h->arena_per_image = end;
-        } else if (b.external_slot > 3) {
+        } else if (b.external_slot > 3 || b.dtype != YR_F32) {
             delete h;
-            yr_set_error("yr_create: external slot %d out of range", b.external_slot);
+            yr_set_error("yr_create: external slot %d out of range (or not float32)", b.external_slot);
             return YR_ERR_ARG;
         }
     }
     auto buf_ok = [&](int32_t b) { return b >= 0 && b < n_bufs; };
     for (const yr_op& op : h->ops) {
         bool ok = buf_ok(op.out_buf) && op.nsrc >= 1 && op.nsrc <= YR_MAX_SRC;
-        for (int i = 0; ok && i < op.nsrc; ++i) ok = buf_ok(op.src[i].buf);
+        for (int i = 0; ok && i < op.nsrc; ++i) ok = buf_ok(op.src[i].buf) && op.src[i].dtype == h->bufs[op.src[i].buf].dtype;
+        if (ok) ok = op.out_dtype == h->bufs[op.out_buf].dtype;
         if (ok && op.res_buf >= 0) ok = buf_ok(op.res_buf);
         if (ok && op.gate_buf >= 0) ok = buf_ok(op.gate_buf);
         if (!ok) {
             delete h;
-            yr_set_error("yr_create: op references a buffer outside the table");
+            yr_set_error("yr_create: op references a buffer outside the table, or with a dtype other than the buffer's");
             return YR_ERR_ARG;
         }
     }
@@ -111,7 +115,7 @@ extern "C" int yr_load_weights(yr_handle* h, const float* host_blob, size_t n_fl
 
 extern "C" size_t yr_workspace_bytes(const yr_handle* h, int batch) {
     if (!h || batch <= 0) return 0;
-    return (size_t)h->arena_per_image * (size_t)batch * sizeof(float);
+    return (size_t)h->arena_per_image * (size_t)batch;
 }
 
 extern "C" int yr_plan_num_launches(const yr_handle* h) { return h ? (int)h->ops.size() : 0; }
@@ -126,9 +130,9 @@ extern "C" int yr_get_tuning(const yr_handle* h, int batch, int32_t* cfg, int n)
 
 extern "C" int yr_set_tuning(yr_handle* h, int batch, const int32_t* cfg, int n) {
     YR_REQUIRE(h && cfg && batch > 0 && n == (int)h->ops.size(), "yr_set_tuning: bad arguments (n must equal yr_plan_num_launches)");
-    const int ncfg = yr_pointwise_num_cfgs();
     std::vector<int> t(n, 0);
     for (int i = 0; i < n; ++i) {
+        const int ncfg = yr_pointwise_num_cfgs(h->ops[i].dtype);
         YR_REQUIRE(cfg[i] >= 0 && cfg[i] <= ncfg && (cfg[i] == 0 || h->ops[i].kind == YR_OP_POINTWISE),
                    "yr_set_tuning: entry %d = %d is not a valid tile shape for that op", i, cfg[i]);
         t[i] = cfg[i];
@@ -137,9 +141,9 @@ extern "C" int yr_set_tuning(yr_handle* h, int batch, const int32_t* cfg, int n)
     return YR_OK;
 }
 
-static int resolve_op(const yr_handle* h, size_t i, int batch, float* const ext[4], float* ws, yr_op* out) {
+static int resolve_op(const yr_handle* h, size_t i, int batch, float* const ext[4], char* ws, yr_op* out) {
     yr_op op = h->ops[i];
-    auto bufptr = [&](int32_t b) -> float* {
+    auto bufptr = [&](int32_t b) -> void* {
         const yr_buf& d = h->bufs[b];
         if (d.external_slot >= 0) return ext[d.external_slot];
         return ws + (size_t)d.arena_off_per_image * (size_t)batch;
@@ -148,7 +152,7 @@ static int resolve_op(const yr_handle* h, size_t i, int batch, float* const ext[
     for (int k = 0; k < op.nsrc; ++k) op.src[k].ptr = bufptr(op.src[k].buf);
     op.out = bufptr(op.out_buf);
     op.res = op.res_buf >= 0 ? bufptr(op.res_buf) : nullptr;
-    op.gate = op.gate_buf >= 0 ? bufptr(op.gate_buf) : nullptr;
+    op.gate = op.gate_buf >= 0 ? (const float*)bufptr(op.gate_buf) : nullptr;
     op.wgt = wptr(op.wgt_off); op.scale = wptr(op.scale_off); op.shift = wptr(op.shift_off);
     op.wgt2 = wptr(op.wgt2_off); op.b1 = wptr(op.b1_off); op.b2 = wptr(op.b2_off);
     if (op.out == nullptr) { yr_set_error("op %zu writes a null external buffer", i); return YR_ERR_ARG; }
@@ -185,7 +189,7 @@ extern "C" int yr_forward(yr_handle* h, const float* images, int batch, float* y
     hipStream_t s = (hipStream_t)stream;
     for (size_t i = 0; i < h->ops.size(); ++i) {
         yr_op op;
-        rc = resolve_op(h, i, batch, ext, static_cast<float*>(workspace), &op);
+        rc = resolve_op(h, i, batch, ext, static_cast<char*>(workspace), &op);
         if (rc == YR_OK) rc = dispatch(op, batch, s);
         if (rc != YR_OK) return fail_op(i, h->ops[i].kind, rc);
     }
@@ -211,7 +215,7 @@ extern "C" int yr_forward_profile(yr_handle* h, const float* images, int batch, 
         YR_CHECK_HIP(hipEventRecord(ev[0], s));
         for (size_t i = 0; i < n; ++i) {
             yr_op op;
-            rc = resolve_op(h, i, batch, ext, static_cast<float*>(workspace), &op);
+            rc = resolve_op(h, i, batch, ext, static_cast<char*>(workspace), &op);
             if (rc == YR_OK) rc = dispatch(op, batch, s);
             if (rc != YR_OK) { rc = fail_op(i, h->ops[i].kind, rc); break; }
             if (kernel_names) kernel_names[i] = g_kernel;
@@ -249,11 +253,11 @@ extern "C" int yr_autotune(yr_handle* h, const float* images, int batch, float* 
     YR_CHECK_HIP(hipEventCreate(&e0));
     YR_CHECK_HIP(hipEventCreate(&e1));
     std::vector<int> best(h->ops.size(), 0);
-    const int ncfg = yr_pointwise_num_cfgs();
     for (size_t i = 0; i < h->ops.size() && rc == YR_OK; ++i) {
         if (h->ops[i].kind != YR_OP_POINTWISE) continue;
+        const int ncfg = yr_pointwise_num_cfgs(h->ops[i].dtype);
         yr_op op;
-        rc = resolve_op(h, i, batch, ext, static_cast<float*>(workspace), &op);
+        rc = resolve_op(h, i, batch, ext, static_cast<char*>(workspace), &op);
         if (rc) break;
         auto time_cfg = [&](int c, float* ms) -> int {
             op.k = c;
@@ -272,7 +276,7 @@ extern "C" int yr_autotune(yr_handle* h, const float* images, int batch, float* 
         yr_op prev;
         bool have_prev = false;
         if (i > 0) {
-            rc = resolve_op(h, i - 1, batch, ext, static_cast<float*>(workspace), &prev);
+            rc = resolve_op(h, i - 1, batch, ext, static_cast<char*>(workspace), &prev);
             if (rc) break;
             if (h->ops[i - 1].kind == YR_OP_POINTWISE) prev.k = best[i - 1];
             have_prev = true;

@@ -13,17 +13,19 @@
 #define ST_IH (2 * ST_TH + 1)
 #define ST_IW (2 * ST_TW + 1)
 
+// T: element type of the OUTPUT map (the image, the weights and all arithmetic are float32).
+template <class T>
 struct StemArgs {
     const float* in;     // [B][Hi][Wi][3] dense
     const float* w;      // [27][ldw]  (tap-major: (ky*3+kx)*3+ci), zero padded to ldw
     const float* scale;  // [ldw]
     const float* shift;  // [ldw]
-    float* out;          // [B][Ho][Wo][ld_out]
+    T* out;              // [B][Ho][Wo][ld_out]
     int B, Hi, Wi, Ho, Wo, ldw, ld_out, pad_t, pad_l, act, tiles_x, tiles_y;
 };
 
-template <int CQ>  // cout quads held per lane
-__global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
+template <int CQ, class T>  // cout quads held per lane
+__global__ __launch_bounds__(256) void stem_kernel(StemArgs<T> a) {
     __shared__ float tile[ST_IH * ST_IW * 3];
     __shared__ __attribute__((aligned(16))) float wl[27 * CQ * 4];
     __shared__ __attribute__((aligned(16))) float otile[256 * CQ * 4];
@@ -88,34 +90,35 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
         const int p = i / CQ, q = i - p * CQ;
         const int oy = ty0 + p / ST_TW, ox = tx0 + (p % ST_TW);
         if (oy < a.Ho && ox < a.Wo)
-            *reinterpret_cast<float4*>(a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.ld_out + q * 4) =
-                *reinterpret_cast<const float4*>(otile + i * 4);
+            yr_st4<T>(a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.ld_out + q * 4, *reinterpret_cast<const float4*>(otile + i * 4));
     }
 }
 
-template <int CQ>
-static int launch_stem(const StemArgs& a, hipStream_t s) {
-    static char nm[24];
-    static const int nm_len = snprintf(nm, sizeof(nm), "stem_kernel<%d>", CQ);
+template <int CQ, class T>
+static int launch_stem(const StemArgs<T>& a, hipStream_t s) {
+    static char nm[32];
+    static const int nm_len = snprintf(nm, sizeof(nm), "stem_kernel<%d,%s>", CQ, yr_dtype_name(yr_elem<T>::dtype));
     (void)nm_len;
     yr_note_kernel(nm);
-    hipLaunchKernelGGL(stem_kernel<CQ>, dim3((unsigned)(a.B * a.tiles_x * a.tiles_y)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((stem_kernel<CQ, T>), dim3((unsigned)(a.B * a.tiles_x * a.tiles_y)), dim3(256), 0, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
 }
 
-int yr_launch_stem(const yr_op& op, int batch, hipStream_t s) {
-    YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY && op.src[0].c == 3 && op.src[0].ld == 3,
-               "stem: needs one dense 3-channel source");
+template <class T>
+static int launch_stem_t(const yr_op& op, int batch, hipStream_t s) {
+    YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY && op.src[0].c == 3 && op.src[0].ld == 3 && op.src[0].dtype == YR_F32,
+               "stem: needs one dense 3-channel float32 source");
+    YR_REQUIRE(op.out_dtype == op.dtype, "stem: the output has the op's dtype");
     YR_REQUIRE(op.k == 3 && op.stride == 2, "stem: only 3x3 stride 2 is supported");
     const yr_src& in = op.src[0];
-    StemArgs a;
-    a.in = in.ptr; a.w = op.wgt; a.scale = op.scale; a.shift = op.shift; a.out = op.out;
+    StemArgs<T> a;
+    a.in = (const float*)in.ptr; a.w = op.wgt; a.scale = op.scale; a.shift = op.shift; a.out = (T*)op.out;
     YR_REQUIRE(a.in && a.w && a.scale && a.shift && a.out, "stem: null pointer");
     a.B = batch; a.Hi = in.h; a.Wi = in.w; a.Ho = (in.h + 1) / 2; a.Wo = (in.w + 1) / 2;
     YR_REQUIRE(a.Ho == op.h && a.Wo == op.w, "stem: output dims mismatch");
     a.ldw = yr_round_up(op.cout, 4); a.ld_out = op.out_ld;
-    YR_REQUIRE(op.out_ld % 4 == 0 && op.out_ld >= a.ldw, "stem: out_ld must be a multiple of 4 and >= round_up(cout,4)");
+    YR_REQUIRE(op.out_ld % yr_elem<T>::vec == 0 && op.out_ld >= a.ldw, "stem: out_ld must be a multiple of %d and >= round_up(cout,4)", yr_elem<T>::vec);
     const int pth = (a.Ho - 1) * 2 + 3 - in.h, ptw = (a.Wo - 1) * 2 + 3 - in.w;
     a.pad_t = (pth > 0 ? pth : 0) / 2; a.pad_l = (ptw > 0 ? ptw : 0) / 2;
     a.act = op.act;
@@ -124,14 +127,16 @@ int yr_launch_stem(const yr_op& op, int batch, hipStream_t s) {
     const int cq = a.ldw / 4;
     // the kernel holds exactly ldw/4 cout quads per lane (no guards in the unrolled FMA block)
     switch (cq) {
-        case 2: return launch_stem<2>(a, s);
-        case 4: return launch_stem<4>(a, s);
-        case 6: return launch_stem<6>(a, s);      // MobileNetV2 x0.75 (24)
-        case 8: return launch_stem<8>(a, s);      // EfficientNet-B0 (32)
-        case 10: return launch_stem<10>(a, s);    // EfficientNet-B3 (40)
-        case 12: return launch_stem<12>(a, s);    // MobileNetV2 x1.4 (48), EfficientNet-B4
-        case 14: return launch_stem<14>(a, s);
-        case 16: return launch_stem<16>(a, s);
+        case 2: return launch_stem<2, T>(a, s);
+        case 4: return launch_stem<4, T>(a, s);
+        case 6: return launch_stem<6, T>(a, s);      // MobileNetV2 x0.75 (24)
+        case 8: return launch_stem<8, T>(a, s);      // EfficientNet-B0 (32)
+        case 10: return launch_stem<10, T>(a, s);    // EfficientNet-B3 (40)
+        case 12: return launch_stem<12, T>(a, s);    // MobileNetV2 x1.4 (48), EfficientNet-B4
+        case 14: return launch_stem<14, T>(a, s);
+        case 16: return launch_stem<16, T>(a, s);
         default: yr_set_error("stem: %d output channels: only multiples of 8 up to 64 are supported", op.cout); return YR_ERR_ARG;
     }
 }
+
+int yr_launch_stem(const yr_op& op, int batch, hipStream_t s) { return YR_BY_DTYPE(op.dtype, launch_stem_t, op, batch, s); }

@@ -184,7 +184,8 @@ int yr_launch_stemblock(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(op.k == 3 && op.stride == 2, "stemblock: the stem is 3x3 stride 2");
     const yr_src& in = op.src[0];
     SbArgs a;
-    a.in = in.ptr; a.out = op.out;
+    YR_REQUIRE(op.dtype == YR_F32 && op.out_dtype == YR_F32 && in.dtype == YR_F32, "stemblock: float32 only");
+    a.in = (const float*)in.ptr; a.out = (float*)op.out;
     YR_REQUIRE(op.se_reduced >= 1 && op.cout >= 1, "stemblock: bad widths (C1=%d, Cout=%d)", op.se_reduced, op.cout);
     const int c1p = yr_round_up(op.se_reduced, 4), cop = yr_round_up(op.cout, 8);
     YR_REQUIRE(in.ptr && op.out && op.wgt && op.wgt2 && op.b1 && op.b2, "stemblock: null pointer");

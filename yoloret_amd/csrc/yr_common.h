@@ -41,9 +41,13 @@ int yr_launch_gather(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_mbconv(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_stemblock(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_mblane(const yr_op& op, int batch, hipStream_t s);
-int yr_pointwise_num_cfgs();
+int yr_pointwise_num_cfgs(int dtype);
 
 static inline int yr_round_up(int v, int m) { return (v + m - 1) / m * m; }
+// channels per 16 bytes of a tensor of this yr_dtype: the granule of `ld` and of the pointwise k-space
+static inline int yr_vec_of(int dtype) { return dtype == YR_F32 ? 4 : 8; }
+static inline const char* yr_dtype_name(int dtype) { return dtype == YR_BF16 ? "bf16" : dtype == YR_F16 ? "f16" : "f32"; }
+static inline bool yr_dtype_ok(int dtype) { return dtype == YR_F32 || dtype == YR_BF16 || dtype == YR_F16; }
 
 #ifdef __HIPCC__
 // ---------------------------------------------------------------- device side
@@ -86,6 +90,49 @@ __device__ __forceinline__ float4 yr_max4(float4 a, float4 b) {
     return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
 }
 
+// ---- element types.  float32, or the 16-bit STORAGE types of a reduced-precision plan: kernels widen to float32 on
+// load (exact) and round to nearest-even on store (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32); arithmetic stays float32
+// everywhere except the pointwise GEMM's MFMA operands.
+typedef __bf16 yr_bf16;
+typedef _Float16 yr_f16;
+template <class T> struct yr_elem;
+template <> struct yr_elem<float> { static constexpr int dtype = YR_F32, vec = 4; };
+template <> struct yr_elem<yr_bf16> { static constexpr int dtype = YR_BF16, vec = 8; };
+template <> struct yr_elem<yr_f16> { static constexpr int dtype = YR_F16, vec = 8; };
+
+// four consecutive channels at p (float32: 16 bytes, 16-byte aligned; 16-bit: 8 bytes, 8-byte aligned) <-> float4
+template <class T>
+__device__ __forceinline__ float4 yr_ld4(const T* p) {
+    if constexpr (sizeof(T) == 4) {
+        return *reinterpret_cast<const float4*>(p);
+    } else {
+        typedef T t4 __attribute__((ext_vector_type(4)));
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 v = __builtin_convertvector(*reinterpret_cast<const t4*>(p), f4);
+        return make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+template <class T>
+__device__ __forceinline__ void yr_st4(T* p, float4 v) {
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(p) = v;
+    } else {
+        typedef T t4 __attribute__((ext_vector_type(4)));
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<t4*>(p) = __builtin_convertvector((f4){v.x, v.y, v.z, v.w}, t4);
+    }
+}
+template <class T> __device__ __forceinline__ float yr_ld1(const T* p) { return (float)*p; }
+template <class T> __device__ __forceinline__ void yr_st1(T* p, float v) { *p = (T)v; }
+
+// Dispatch a launcher template over the op's element type: YR_BY_DTYPE(op.dtype, launch_x, args...) calls
+// launch_x<float|yr_bf16|yr_f16>(args...).
+#define YR_BY_DTYPE(dt, fn, ...)                                             \
+    ((dt) == YR_F32 ? fn<float>(__VA_ARGS__)                                 \
+     : (dt) == YR_BF16 ? fn<yr_bf16>(__VA_ARGS__)                            \
+     : (dt) == YR_F16 ? fn<yr_f16>(__VA_ARGS__)                              \
+                      : (yr_set_error("unknown dtype %d", (int)(dt)), (int)YR_ERR_ARG))
+
 // XCD-aware block order (cdna_hip_programming.md T1): hardware block b runs on XCD b % 8, each XCD has
 // its own L2.  Map hardware ids so that every XCD walks a CONTIGUOUS range of logical blocks; logical
 // neighbours (adjacent rows of a depthwise map, the cout tiles of one pixel tile) then share an L2.
@@ -96,7 +143,8 @@ __device__ __forceinline__ unsigned yr_xcd_swizzle(unsigned bid, unsigned nb) {
     return x * q + (x < r ? x : r) + i;
 }
 
-// Device view of one concatenated source segment (see yr_src).
+// Device view of one concatenated source segment (see yr_src).  `ptr` is type-erased: the kernel template knows the
+// element type (all k-space sources of an op share it).
 struct DSrc {
     const float* ptr;
     int h, w;      // source spatial dims
@@ -114,19 +162,21 @@ struct DSrcSet {
 
 // Loads channels [kk, kk+4) of segment `s` for consumer pixel (b,y,x); lanes beyond
 // the segment's channel count are returned as 0 (never multiplied through).
+template <class T = float>
 __device__ __forceinline__ float4 yr_load_src_quad(const DSrc& s, int b, int y, int x, int kk) {
     float4 v;
+    const T* sp = reinterpret_cast<const T*>(s.ptr);
     if (s.xform == YR_X_IDENTITY) {
-        v = *reinterpret_cast<const float4*>(s.ptr + ((size_t)(b * s.h + y) * s.w + x) * s.ld + kk);
+        v = yr_ld4<T>(sp + ((size_t)(b * s.h + y) * s.w + x) * s.ld + kk);
     } else if (s.xform == YR_X_UP2) {
-        v = *reinterpret_cast<const float4*>(s.ptr + ((size_t)(b * s.h + (y >> 1)) * s.w + (x >> 1)) * s.ld + kk);
+        v = yr_ld4<T>(sp + ((size_t)(b * s.h + (y >> 1)) * s.w + (x >> 1)) * s.ld + kk);
     } else {
         const int p = (s.xform == YR_X_MAXPOOL2) ? 2 : 4;
-        const float* base = s.ptr + ((size_t)(b * s.h + y * p) * s.w + x * p) * s.ld + kk;
-        v = *reinterpret_cast<const float4*>(base);
+        const T* base = sp + ((size_t)(b * s.h + y * p) * s.w + x * p) * s.ld + kk;
+        v = yr_ld4<T>(base);
         for (int dy = 0; dy < p; ++dy)
             for (int dx = 0; dx < p; ++dx)
-                v = yr_max4(v, *reinterpret_cast<const float4*>(base + ((size_t)dy * s.w + dx) * s.ld));
+                v = yr_max4(v, yr_ld4<T>(base + ((size_t)dy * s.w + dx) * s.ld));
     }
     const int rem = s.c - kk;
     if (rem < 4) {
@@ -138,6 +188,7 @@ __device__ __forceinline__ float4 yr_load_src_quad(const DSrc& s, int b, int y, 
 }
 
 // k in the padded k-space -> (segment, offset); returns zero quad when k >= kp.
+template <class T = float>
 __device__ __forceinline__ float4 yr_load_cat_quad(const DSrcSet& S, int b, int y, int x, int k) {
     if (k >= S.kp) return make_float4(0.f, 0.f, 0.f, 0.f);
     int si = 0;
@@ -149,7 +200,7 @@ __device__ __forceinline__ float4 yr_load_cat_quad(const DSrcSet& S, int b, int 
     if (si == 1) s = S.s[1];
     if (si == 2) s = S.s[2];
     if (si == 3) s = S.s[3];
-    return yr_load_src_quad(s, b, y, x, k - s.kbase);
+    return yr_load_src_quad<T>(s, b, y, x, k - s.kbase);
 }
 #endif
 
@@ -157,6 +208,8 @@ __device__ __forceinline__ float4 yr_load_cat_quad(const DSrcSet& S, int b, int 
 #ifdef __HIPCC__
 static inline int yr_make_srcset(const yr_op& op, DSrcSet* S) {
     if (op.nsrc < 1 || op.nsrc > YR_MAX_SRC) { yr_set_error("nsrc=%d out of range", op.nsrc); return YR_ERR_ARG; }
+    if (!yr_dtype_ok(op.dtype)) { yr_set_error("unknown dtype %d", op.dtype); return YR_ERR_ARG; }
+    const int V = yr_vec_of(op.dtype);   // channels per 16 bytes: the granule of ld and of the k-space segments
     int k = 0;
     S->n = op.nsrc;
     for (int i = 0; i < YR_MAX_SRC; ++i) {
@@ -174,10 +227,11 @@ static inline int yr_make_srcset(const yr_op& op, DSrcSet* S) {
         }
         else if (s.xform != YR_X_IDENTITY) { yr_set_error("bad xform %d", s.xform); return YR_ERR_ARG; }
         if (eh != op.h || ew != op.w) { yr_set_error("src %d dims %dx%d (xform %d) do not give %dx%d", i, s.h, s.w, s.xform, op.h, op.w); return YR_ERR_ARG; }
-        if (s.ld % 4 != 0 || s.ld < yr_round_up(s.c, 4)) { yr_set_error("src %d: ld=%d must be a multiple of 4 and >= round_up(c=%d,4)", i, s.ld, s.c); return YR_ERR_ARG; }
+        if (s.dtype != op.dtype) { yr_set_error("src %d has dtype %d, the op works in dtype %d", i, s.dtype, op.dtype); return YR_ERR_ARG; }
+        if (s.ld % V != 0 || s.ld < yr_round_up(s.c, V)) { yr_set_error("src %d: ld=%d must be a multiple of %d and >= round_up(c=%d,%d)", i, s.ld, V, s.c, V); return YR_ERR_ARG; }
         if (((uintptr_t)s.ptr) % 16 != 0 || s.ptr == nullptr) { yr_set_error("src %d pointer null or not 16-byte aligned", i); return YR_ERR_ARG; }
-        d.ptr = s.ptr; d.h = s.h; d.w = s.w; d.c = s.c; d.ld = s.ld; d.xform = s.xform; d.kbase = k;
-        k += yr_round_up(s.c, 4);
+        d.ptr = (const float*)s.ptr; d.h = s.h; d.w = s.w; d.c = s.c; d.ld = s.ld; d.xform = s.xform; d.kbase = k;
+        k += yr_round_up(s.c, V);
     }
     S->kp = k;
     return YR_OK;

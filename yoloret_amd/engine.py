@@ -17,13 +17,21 @@ from .compiler import compile_graph
 
 
 class Model:
-    def __init__(self, inputs, outputs, name=None, fuse=None):
+    def __init__(self, inputs, outputs, name=None, fuse=None, dtype=None):
+        """dtype: element type of the activations BETWEEN the fused ops and of the 1x1-conv weights - 'float32'
+        (default), 'bfloat16' or 'float16' (BASELINE.json configs 3 / 5).  None takes the global policy
+        (yoloret_amd.layers.set_global_policy, the counterpart of tf.keras.mixed_precision.set_global_policy).
+        Images in, logits out, BatchNorm, depthwise weights, SE vectors and all accumulation stay float32."""
         if fuse is None:
             fuse = os.environ.get('YOLORET_FUSE', '1') != '0'
+        if dtype is None:
+            from .layers import global_policy_dtype
+            dtype = global_policy_dtype()
+        self.dtype = rt.dtype_id(dtype)
         self.inputs = inputs if isinstance(inputs, (list, tuple)) else [inputs]
         self.outputs = list(outputs)
         self.name = name
-        self.plan = compile_graph(self.inputs[0], self.outputs, fuse)
+        self.plan = compile_graph(self.inputs[0], self.outputs, fuse, self.dtype)
         # batches of up to SMALL_BATCH images run a second plan without block fusion (compiler.py: 'latency');
         # compiled on first use, same parameters, its own weight blob / handle / tile table
         self.small_batch = int(os.environ.get('YOLORET_SMALL_BATCH', '4')) if fuse is True else 0
@@ -88,7 +96,7 @@ class Model:
     def plan_for(self, batch):
         v = self.variant(batch)
         if v not in self._plans:
-            self._plans[v] = compile_graph(self.inputs[0], self.outputs, v)
+            self._plans[v] = compile_graph(self.inputs[0], self.outputs, v, self.dtype)
         return self._plans[v]
 
     def _blob_of(self, variant):
@@ -114,7 +122,7 @@ class Model:
         return idx, h
 
     def workspace_bytes(self, batch):
-        return self.plan_for(batch).arena_elems_per_image * batch * 4
+        return self.plan_for(batch).arena_bytes_per_image * batch
 
     def __call__(self, x, out=None):
         h, w, c = self.plan.input_shape
@@ -157,7 +165,7 @@ class Model:
     # (tune once, deploy many; also keeps profiler runs free of the tuner's trial launches)
     def _tune_key(self, b):
         import zlib
-        sig = zlib.crc32(' '.join('%s:%d:%d:%d' % (o.name, o.kind, o.cin, o.cout) for o in self.plan_for(b).ops).encode())
+        sig = zlib.crc32(' '.join('%s:%d:%d:%d:%d' % (o.name, o.kind, o.cin, o.cout, o.dtype) for o in self.plan_for(b).ops).encode())
         return '%08x:%d' % (sig, b)
 
     def _load_tuning(self, hd, b):

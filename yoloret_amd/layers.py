@@ -10,8 +10,31 @@ Every layer owns named parameters (``<name>/kernel`` ...) with Keras layouts
 (SURVEY.md A.5), so a weight dict keyed by those names fully specifies a model.
 """
 import itertools
+import os
 
 _uid = itertools.count()
+
+# ---- compute policy: the counterpart of tf.keras.mixed_precision.set_global_policy for models built afterwards.
+# 'float32' (default; also YOLORET_DTYPE), 'mixed_bfloat16', 'mixed_float16': activations between the fused ops and
+# the 1x1-conv weights are stored in the 16-bit type, variables / BatchNorm / accumulation / logits stay float32.
+_POLICIES = {'float32': 'float32', 'mixed_bfloat16': 'bfloat16', 'mixed_float16': 'float16',
+             'bfloat16': 'bfloat16', 'float16': 'float16', 'bf16': 'bfloat16', 'f16': 'float16', 'f32': 'float32'}
+_policy = [None]
+
+
+def set_global_policy(name):
+    if name not in _POLICIES:
+        raise ValueError('unknown policy %r (float32, mixed_bfloat16, mixed_float16)' % (name,))
+    _policy[0] = _POLICIES[name]
+
+
+def global_policy_dtype():
+    if _policy[0] is not None:
+        return _policy[0]
+    env = os.environ.get('YOLORET_DTYPE', 'float32')
+    if env not in _POLICIES:
+        raise ValueError('YOLORET_DTYPE=%r (float32, bfloat16, float16)' % (env,))
+    return _POLICIES[env]
 
 
 class Tensor:

@@ -18,19 +18,56 @@ ACT = {'none': 0, None: 0, 'relu6': 1, 'swish': 2, 'sigmoid': 3, 'leaky': 4}
 XFORM = {'identity': 0, 'up2': 1, 'maxpool2': 2, 'maxpool4': 3, 'up2_add': 4, 'dw3': 5}
 OP_STEM, OP_POINTWISE, OP_DEPTHWISE, OP_SE_MEAN, OP_SE_FC, OP_WSUM, OP_GATHER, OP_MBCONV = 1, 2, 3, 4, 5, 6, 7, 8
 OP_STEMBLOCK, OP_MBLANE = 9, 10
+# yr_dtype: element type of activation tensors / pointwise weights (include/yoloret_hip.h)
+DTYPE = {'f32': 0, 'float32': 0, None: 0, 'bf16': 1, 'bfloat16': 1, 'f16': 2, 'float16': 2}
+DTYPE_NAME = {0: 'f32', 1: 'bf16', 2: 'f16'}
+ESIZE = {0: 4, 1: 2, 2: 2}
+VEC = {0: 4, 1: 8, 2: 8}          # channels per 16 bytes: granule of `ld` and of the pointwise k-space
+TORCH_DTYPE = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
+
+
+def dtype_id(d):
+    """'f32' | 'bf16' | 'f16' | 'float32' | 'bfloat16' | 'float16' | torch dtype | yr_dtype int -> yr_dtype int."""
+    if isinstance(d, int):
+        if d in DTYPE_NAME:
+            return d
+    elif isinstance(d, torch.dtype):
+        for k, v in TORCH_DTYPE.items():
+            if v == d:
+                return k
+    elif d in DTYPE:
+        return DTYPE[d]
+    raise ValueError('unsupported dtype %r (float32, bfloat16, float16)' % (d,))
+
+
+def to_bits16(a, dtype):
+    """float32 array -> uint16 bit patterns of the 16-bit type, round to nearest even (what the kernels' stores do)."""
+    a = np.ascontiguousarray(a, np.float32)
+    if dtype_id(dtype) == 2:
+        return a.astype(np.float16).view(np.uint16)
+    u = a.view(np.uint32).astype(np.uint64)
+    return (((u + 0x7fff + ((u >> 16) & 1)) >> 16) & 0xffff).astype(np.uint16)
+
+
+def from_bits16(b, dtype):
+    b = np.ascontiguousarray(b, np.uint16)
+    if dtype_id(dtype) == 2:
+        return b.view(np.float16).astype(np.float32)
+    return (b.astype(np.uint32) << 16).view(np.float32)
 OP_NAMES = {1: 'stem', 2: 'pointwise', 3: 'depthwise', 4: 'se_mean', 5: 'se_fc', 6: 'wsum', 7: 'gather', 8: 'mbconv',
             9: 'stemblock', 10: 'mblane'}
 
 
 class YrSrc(ctypes.Structure):
     _fields_ = [('ptr', ctypes.c_void_p), ('buf', ctypes.c_int32), ('h', ctypes.c_int32), ('w', ctypes.c_int32),
-                ('c', ctypes.c_int32), ('ld', ctypes.c_int32), ('xform', ctypes.c_int32)]
+                ('c', ctypes.c_int32), ('ld', ctypes.c_int32), ('xform', ctypes.c_int32), ('dtype', ctypes.c_int32)]
 
 
 class YrOp(ctypes.Structure):
     _fields_ = [('kind', ctypes.c_int32), ('act', ctypes.c_int32), ('h', ctypes.c_int32), ('w', ctypes.c_int32),
                 ('cin', ctypes.c_int32), ('cout', ctypes.c_int32), ('k', ctypes.c_int32), ('stride', ctypes.c_int32),
                 ('nsrc', ctypes.c_int32), ('se_reduced', ctypes.c_int32),
+                ('dtype', ctypes.c_int32), ('out_dtype', ctypes.c_int32),
                 ('src', YrSrc * YR_MAX_SRC),
                 ('out', ctypes.c_void_p), ('out_buf', ctypes.c_int32), ('out_ld', ctypes.c_int32),
                 ('res', ctypes.c_void_p), ('res_buf', ctypes.c_int32), ('res_ld', ctypes.c_int32),
@@ -44,11 +81,11 @@ class YrOp(ctypes.Structure):
 
 
 class YrBuf(ctypes.Structure):
-    _fields_ = [('elems_per_image', ctypes.c_int64), ('arena_off_per_image', ctypes.c_int64),
-                ('external_slot', ctypes.c_int32), ('pad_', ctypes.c_int32)]
+    _fields_ = [('bytes_per_image', ctypes.c_int64), ('arena_off_per_image', ctypes.c_int64),
+                ('external_slot', ctypes.c_int32), ('dtype', ctypes.c_int32)]
 
 
-EXPORTS = ['yr_last_error', 'yr_abi_version', 'yr_create', 'yr_destroy', 'yr_load_weights', 'yr_workspace_bytes',
+EXPORTS = ['yr_last_error', 'yr_abi_version', 'yr_abi_sizeof', 'yr_create', 'yr_destroy', 'yr_load_weights', 'yr_workspace_bytes',
            'yr_forward', 'yr_forward_profile', 'yr_autotune', 'yr_get_tuning', 'yr_set_tuning', 'yr_plan_num_launches', 'yr_op_run', 'yr_decode', 'yr_decode_zoom', 'yr_yolo_head', 'yr_correct_boxes',
            'yr_nms', 'yr_pack_detections', 'yr_letterbox']
 
@@ -98,8 +135,13 @@ def lib():
         L.yr_pack_detections.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3
         L.yr_letterbox.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_void_p]
-        if L.yr_abi_version() != 1:
+        if L.yr_abi_version() != 2:
             raise YoloretHipError('libyoloret_hip.so ABI version mismatch')
+        L.yr_abi_sizeof.argtypes = [ctypes.c_int]
+        for which, st in enumerate((YrSrc, YrOp, YrBuf)):
+            if L.yr_abi_sizeof(which) != ctypes.sizeof(st):
+                raise YoloretHipError('struct %s: %d bytes here, %d in libyoloret_hip.so'
+                                      % (st.__name__, ctypes.sizeof(st), L.yr_abi_sizeof(which)))
         _lib = L
     return _lib
 
@@ -123,8 +165,9 @@ def _require_cuda_f32(t, name):
 
 
 def make_src(t, c=None, xform='identity', ld=None):
-    """yr_src for a [B,H,W,ld] tensor of which `c` channels are taken."""
+    """yr_src for a [B,H,W,ld] tensor (float32 / bfloat16 / float16) of which `c` channels are taken."""
     s = YrSrc()
+    s.dtype = dtype_id(t.dtype)
     s.ptr = t.data_ptr()
     s.buf = -1
     s.h, s.w = t.shape[1], t.shape[2]
