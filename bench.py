@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy peak 6290
 FP32_PEAK_TFLOPS = 157.3  # fp32 vector == fp32 MFMA peak
+MFMA16_PEAK_TFLOPS = 2500.0  # dense bf16 / f16 MFMA peak (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -38,6 +39,9 @@ def parse():
     ap.add_argument('--model', default='mobilenetv2x75')
     ap.add_argument('--size', type=int, default=416)
     ap.add_argument('--classes', type=int, default=20)
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f16'],
+                    help='element type of the activations between fused ops and of the 1x1-conv weights (BASELINE configs 3 / 5 '
+                         'run bf16 / f16; the headline config 2 is f32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline sample')
     ap.add_argument('--profile-iters', type=int, default=3)
@@ -47,6 +51,22 @@ def parse():
     ap.add_argument('--no-latency', action='store_true',
                     help='skip the batch-1 p50 loop (use under rocprofv3 so that every launch is a batch-%d launch)' % 64)
     return ap.parse_args()
+
+
+def canon_symbol(name):
+    """Kernel symbol in one spelling: no spaces, bools as 1/0, element types as f32/bf16/f16."""
+    name = name.replace(' ', '').replace('true', '1').replace('false', '0')
+    return name.replace('__bf16', 'bf16').replace('_Float16', 'f16').replace('float', 'f32')
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
 
 
 def usable_cores():
@@ -86,7 +106,7 @@ def cpu_baseline(model_name, size, classes, anchors, seconds):
         dt = time.perf_counter() - t0
         if dt >= seconds or n >= 4096:
             break
-    return {'value': round(n / dt, 2), 'unit': 'img/s', 'cores': cores, 'kind': 'port',
+    return {'value': round(n / dt, 2), 'unit': 'img/s', 'cores': cores, 'cpu': cpu_model(), 'kind': 'port',
             'sample': '%d images (batches of %d) of the same %s@%d workload through oracle/torch_ref.py '
                       '(torch-CPU/oneDNN fp32) + oracle C decode/NMS, %.1f s' % (n, b, model_name, size, dt)}
 
@@ -124,6 +144,7 @@ def main():
     from yoloret_amd.yolo3.utils import get_anchors
 
     anchors = get_anchors('model_data/yolo_anchors.txt')
+    L.set_global_policy({'f32': 'float32', 'bf16': 'mixed_bfloat16', 'f16': 'mixed_float16'}[a.dtype])
     model = yolov3_body(L.Input(shape=[a.size, a.size, 3]), a.model, 3, num_classes=a.classes)
     model.set_weights(W.synthetic_weights(model, 1234, 'survey'))
     pipe = DetectionPipeline(model, anchors, a.classes, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5)
@@ -211,56 +232,104 @@ def main():
         dom = max(by, key=lambda k: by[k]['ms'])
         d = by[dom]
         avg_ms = d['ms'] / d['launches']
-        # The dominant kernel against the roofline that bounds it.  For a fused block kernel (mblane / stemblock)
-        # the bytes that still cross HBM are the block's input + output only, so it is bound by the fp32 pipe
-        # (packed FMA and fp32 MFMA share the 157.3 TFLOP/s dense peak); an unfused conv is bound by HBM.
+        # The dominant kernel against the roofline that bounds it.  Bytes = what the op must move through HBM (its
+        # sources + its output; for a fused block kernel that is the block's input + output only).  Arithmetic peak:
+        # the 16-bit pointwise GEMM runs on bf16/f16 MFMA (2.5 PFLOP/s dense), everything else is float32 (fp32 MFMA
+        # and packed fp32 FMA share the 157.3 TFLOP/s dense peak).
+        peak_tf = MFMA16_PEAK_TFLOPS if dom.startswith('pwh_kernel') else FP32_PEAK_TFLOPS
         gbs = d['hbm'] / d['launches'] / (avg_ms * 1e-3) / 1e9
         tfl = 2.0 * d['macs'] / (d['ms'] * 1e-3) / 1e12
-        if tfl / FP32_PEAK_TFLOPS > gbs / HBM_PEAK_GBS:
+        if tfl / peak_tf > gbs / HBM_PEAK_GBS:
             roofline = {'bound': 'mfma', 'kernel': dom, 'launches_per_step': d['launches'], 'avg_launch_ms': round(avg_ms, 4),
-                        'achieved': round(tfl, 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(tfl / FP32_PEAK_TFLOPS, 4), 'traffic': None,
+                        'achieved': round(tfl, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
+                        'frac': round(tfl / peak_tf, 4), 'traffic': None,
                         'flops_per_launch': int(2.0 * d['macs'] / d['launches']), 'hbm_gbs': round(gbs, 1)}
         else:
             roofline = {'bound': 'hbm', 'kernel': dom, 'launches_per_step': d['launches'], 'avg_launch_ms': round(avg_ms, 4),
                         'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None, 'tflops': round(tfl, 2)}
+        roofline['bytes_per_launch'] = int(d['hbm'] / d['launches'])   # the `achieved` GB/s = this / avg_launch_ms
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
         # (profiles/rNN_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KiB, see tools/rocpd_summary.py); None if absent
+        pmc_step_bytes = None
         try:
             import glob
-            tfile = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))[-1]
-            # rocprof prints template bools as true/false; the launchers name shapes without them (pw: as 1/0)
-            table = {}
-            for key, val in json.load(open(tfile)).items():
-                key = key.replace(' ', '')
-                if key.startswith('pw'):
-                    key = key.replace(',true>', ',1>').replace(',false>', ',0>')
-                table[key.replace(',true>', '>').replace(',false>', '>')] = val
-            tr = table.get(dom)
-            if tr and a.batch == 64 and a.model == 'mobilenetv2x75' and a.size == 416:
+            tag = '' if (a.model, a.size, a.batch, a.dtype) == ('mobilenetv2x75', 416, 64, 'f32') else \
+                '_%s_%d_b%d_%s' % (a.model.replace('-', ''), a.size, a.batch, a.dtype)
+            tfile = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_traffic%s.json' % tag)))[-1]
+            # rocprof prints the full template argument list (bools as true/false, types by their C++ names); the
+            # launchers name a kernel by its leading arguments: compare canonical forms, the launcher's as a prefix
+            table = {canon_symbol(k): v for k, v in json.load(open(tfile)).items()}
+
+            def lookup(sym):
+                want = canon_symbol(sym)
+                tr = table.get(want)
+                if tr is None and want.endswith('>'):
+                    hits = [v for k, v in table.items() if k.startswith(want[:-1] + ',')]
+                    tr = hits[0] if len(hits) == 1 else None
+                return tr
+            tr = lookup(dom)
+            if tr:
                 roofline['traffic'] = tr['traffic_bytes']
                 roofline['traffic_source'] = os.path.relpath(tfile, ROOT)
                 roofline['alg_bytes_per_launch'] = int(d['bytes'] / d['launches'])   # conv-granular
-                roofline['min_hbm_bytes_per_launch'] = int(d['hbm'] / d['launches'])  # fused: block in + out
+            # the whole step's measured traffic: sum over symbols of (PMC bytes per launch x launches per step)
+            tot, miss = 0.0, []
+            for sym, v in by.items():
+                names = ['nms_lazy_kernel<256>', 'nms_lazy_kernel<1024>'] if sym.startswith('nms_lazy') else [sym]
+                for nme in names:
+                    t = lookup(nme)
+                    if t:
+                        tot += t['traffic_bytes'] * v['launches']
+                    elif nme != 'nms_lazy_kernel<1024>':
+                        miss.append(nme)
+            if not miss:
+                pmc_step_bytes = tot
         except (IndexError, OSError, ValueError):
             pass
         per_gpu = value / world
-        step_gbs = per_gpu * alg_img / 1e9
-        roofline_step = {'bound': 'hbm', 'achieved': round(step_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(step_gbs / HBM_PEAK_GBS, 4), 'alg_bytes_per_image': int(alg_img),
+        step_s = b / per_gpu
+        alg_gbs = per_gpu * alg_img / 1e9
+        moved_min = sum(r.get('hbm_bytes', r['bytes']) for r in rows)     # per step: every op's sources + output
+        fp32_roof = FP32_PEAK_TFLOPS * 1e12 / flops_img                   # img/s if the float32 pipe were the only limit
+        # `achieved` / `frac` follow SURVEY.md 8(d)'s agreed accounting: conv-granular ALGORITHMIC bytes (a fused kernel is
+        # credited the bytes of the convolutions it replaces) - a measure of work done per second, NOT of bandwidth used.
+        # What actually crosses HBM is `moved_*`: the plan's minimum (each launched op's inputs + output) and, when the
+        # committed PMC passes cover this configuration, the measured FETCH/WRITE traffic.
+        roofline_step = {'bound': 'hbm', 'achieved': round(alg_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(alg_gbs / HBM_PEAK_GBS, 4),
+                         'accounting': 'conv-granular algorithmic bytes (SURVEY 8d): credited work, not moved bytes',
+                         'alg_bytes_per_image': int(alg_img), 'alg_gbs': round(alg_gbs, 1),
+                         'moved_bytes_per_image_plan': int(moved_min / b),
+                         'moved_gbs_plan': round(moved_min / step_s / 1e9, 1),
+                         'frac_hbm_moved_plan': round(moved_min / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                         'moved_bytes_per_image_pmc': int(pmc_step_bytes / b) if pmc_step_bytes else None,
+                         'moved_gbs_pmc': round(pmc_step_bytes / step_s / 1e9, 1) if pmc_step_bytes else None,
+                         'frac_hbm_moved_pmc': round(pmc_step_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4) if pmc_step_bytes else None,
                          'tflops': round(per_gpu * flops_img / 1e12, 2),
                          'frac_fp32_peak': round(per_gpu * flops_img / 1e12 / FP32_PEAK_TFLOPS, 4),
+                         'fp32_roofline_img_s': round(fp32_roof, 0),
+                         'hbm_roofline_img_s': round(HBM_PEAK_GBS * 1e9 / alg_img, 0),
                          'sum_kernel_ms': round(sum(r['ms'] for r in rows), 3),
                          'launches_per_step': len(rows)}
         if a.per_op:
+            # `moved`: the op's own sources + output (what must cross HBM); `credited`: the conv-granular accounting
+            # of SURVEY 8(d), where a fused / hoisted op carries the bytes and MACs of the convolutions it stands for
+            # (a `_lowres` half is listed with the conv it was split from: its credited columns are 0 by design)
+            sys.stderr.write('%-26s %-30s %9s %12s %10s %12s %10s %8s\n' % ('op', 'kernel', 'ms', 'moved MB', 'moved GB/s',
+                                                                              'credited MB', 'cred GB/s', 'TF'))
             for r in sorted(rows, key=lambda r: -r['ms']):
-                gbs = r['bytes'] / (r['ms'] * 1e-3) / 1e9 if r['ms'] > 0 else 0
+                mv = r.get('hbm_bytes', r['bytes'])
+                g1 = mv / (r['ms'] * 1e-3) / 1e9 if r['ms'] > 0 else 0
+                g2 = r['bytes'] / (r['ms'] * 1e-3) / 1e9 if r['ms'] > 0 else 0
                 tf = 2.0 * r['macs'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0
-                sys.stderr.write('%-24s %-22s %8.4f ms %8.1f GB/s %7.2f TF\n' % (r['name'], r['kernel'], r['ms'], gbs, tf))
+                sys.stderr.write('%-26s %-30s %9.4f %12.2f %10.1f %12.2f %10.1f %8.2f\n'
+                                 % (r['name'], r['kernel'], r['ms'], mv / 1e6, g1, r['bytes'] / 1e6, g2, tf))
             for k, v in sorted(by.items(), key=lambda kv: -kv[1]['ms']):
-                sys.stderr.write('SYMBOL %-24s n=%3d total %8.4f ms  %8.1f GB/s\n'
-                                 % (k, v['launches'], v['ms'], v['bytes'] / (v['ms'] * 1e-3) / 1e9 if v['ms'] else 0))
+                sys.stderr.write('SYMBOL %-30s n=%3d total %8.4f ms  moved %8.1f GB/s  credited %8.1f GB/s  %7.2f TF\n'
+                                 % (k, v['launches'], v['ms'], v['hbm'] / (v['ms'] * 1e-3) / 1e9 if v['ms'] else 0,
+                                    v['bytes'] / (v['ms'] * 1e-3) / 1e9 if v['ms'] else 0,
+                                    2.0 * v['macs'] / (v['ms'] * 1e-3) / 1e12 if v['ms'] else 0))
         # ---- p50 per-image latency at B=1 (the second half of BASELINE.json's metric)
         p50 = None
         if world == 1 and not a.no_latency:
@@ -299,15 +368,44 @@ def main():
                 sys.stderr.write('hip graph replay failed: %s\n' % (e,))
             finally:
                 pipe.enable_graph(False)
+        # ---- SURVEY.md 8(d) "incl. H2D": the same step fed from host memory the sane way - pinned uint8 batch over
+        # PCIe (a quarter of the float32 bytes), /255 + letterbox on the GPU (yr_letterbox_batch), then the step.
+        # Reported next to `value`, never as `value` (the boundary of the headline is a resident batch).
+        incl_h2d = None
+        if world == 1 and not a.no_latency:
+            from yoloret_amd import runtime as rt
+            u8 = (x * 255.0).round().clamp(0, 255).to(torch.uint8).cpu().pin_memory()
+            dbuf = torch.empty(u8.shape, dtype=torch.uint8, device=dev)
+
+            def step_h2d():
+                dbuf.copy_(u8, non_blocking=True)
+                rt.letterbox(dbuf, (a.size, a.size), out=x)
+                return step()
+            for _ in range(3):
+                step_h2d()
+            sync()
+            t1 = time.perf_counter()
+            nh = 20
+            for _ in range(nh):
+                step_h2d()
+            sync()
+            dth = (time.perf_counter() - t1) / nh
+            incl_h2d = {'img_s': round(b / dth, 1), 'ms_per_step': round(dth * 1e3, 4),
+                        'host_bytes_per_image': int(u8[0].numel()),
+                        'path': 'pinned uint8 [B,H,W,3] -> hipMemcpyAsync H2D -> yr_letterbox_batch (u8/255, letterbox) -> step; '
+                                'copy, conversion and step serialised on one stream'}
         out = {'metric': 'images/sec (+ p50 per-image ms) MobileNetV2-0.75x @416, 1/2/4/8 MI355X',
                'value': round(value, 1), 'unit': 'img/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
                'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
-               'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': '%s @%d, batch %d per GPU, fp32, random weights (SURVEY 8(d) recipe), C=%d: '
-                                      'forward + decode + per-class NMS + pack%s'
-                                      % (a.model, a.size, b, a.classes, ' + all-gather of detections' if world > 1 else ''),
+               'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+               'config': {'workload': '%s @%d, batch %d per GPU, %s, random weights (SURVEY 8(d) recipe; parity tests run the '
+                                      'variance-preserving recipe, see DESIGN.md 5), C=%d: forward + decode + per-class NMS + pack%s'
+                                      % (a.model, a.size, b,
+                                         {'f32': 'fp32', 'bf16': 'bf16 activations + 1x1 weights on bf16 MFMA (fp32 accumulate, logits, decode, NMS)',
+                                          'f16': 'fp16 activations + 1x1 weights on f16 MFMA (fp32 accumulate, logits, decode, NMS)'}[a.dtype],
+                                         a.classes, ' + all-gather of detections' if world > 1 else ''),
                           'global_batch': b * world, 'parallelism': 'dp%d (image-sharded)' % world},
-               'p50_ms_b1': p50, 'roofline': roofline, 'roofline_step': roofline_step}
+               'p50_ms_b1': p50, 'roofline': roofline, 'roofline_step': roofline_step, 'incl_h2d': incl_h2d}
         if p50 is not None:
             out['p50_ms_b1_detail'] = {'eager_launches': p50_eager, 'hip_graph_replay': p50_graph}
         if world == 1 and not a.no_cpu_baseline:

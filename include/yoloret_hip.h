@@ -136,7 +136,7 @@ typedef struct {
      *   POINTWISE: wgt = Wt[cout][kp] of element type `dtype` (kp = sum of round_up(src.c, V), V = 4 for float32 and 8
      *              for the 16-bit types, zero padded; in the blob a 16-bit matrix occupies cout*kp/2 floats),
      *              scale/shift [cout] (folded BN and/or bias)
-     *   DEPTHWISE: wgt = [k*k][round_up(c,4)] ; scale/shift [round_up(c,4)]
+     *   DEPTHWISE: wgt = [k*k][round_up(c,V)] ; scale/shift [round_up(c,V)]  (V as above: 4 for float32 ops, 8 for 16-bit ops)
      *   STEM:      wgt = [27][round_up(cout,4)] ; scale/shift [round_up(cout,4)]
      *   SE_FC:     wgt = W1t[reduced][ldc], b1 [reduced], wgt2 = W2[reduced][ldc], b2 [ldc], ldc = round_up(c,4)
      *   WSUM:      wgt = alpha[4]
@@ -208,6 +208,9 @@ int yr_op_run(const yr_op* op, int batch, void* stream);
  * letterboxed float32 [H,W,3] network input.  Replaces tf.io.decode_image(dtype=float32)'s /255
  * (yolo.py:106) + letterbox_image (utils.py:67-83: bilinear half-pixel resize, zero pad). */
 int yr_letterbox(const unsigned char* src_u8, int ih, int iw, float* dst, int H, int W, void* stream);
+/* The same for a batch of EQUALLY sized decoded images [B,ih,iw,3] -> [B,H,W,3] in one launch: the ingestion path of a
+ * resident batch (uint8 over PCIe is a quarter of the float32 bytes; SURVEY.md 8(d) "incl. H2D"). */
+int yr_letterbox_batch(const unsigned char* src_u8, int batch, int ih, int iw, float* dst, int H, int W, void* stream);
 
 /* ---- decode: replaces yolo_head + yolo_correct_boxes + yolo_boxes_and_scores
  * (model.py:344-428) for the three scales at once, per image.

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import nn
-from tests.util import assert_close, from_dev, round_up, to_dev
+from tests.util import assert_close, assert_rounded_once, from_dev, from_dev16, q16, round_up, to_dev, to_dev16
 
 pytestmark = pytest.mark.gpu
 
@@ -38,13 +38,18 @@ def _pairs(rows, scale, shift, e2):
     return np.ascontiguousarray(full.reshape(-1, e2 // 2, 2).transpose(1, 0, 2))
 
 
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('case', CASES, ids=[str(i) for i in range(len(CASES))])
-def test_mblane(dev, case):
+def test_mblane(dev, case, dt):
+    """dt: element type of the block's input and output (16-bit: the block computes in float32 from registers and
+    rounds once at the store; the residual is the 16-bit input widened)."""
     from yoloret_amd import runtime as rt
     h, w, cin, cexp, cout, s, residual, act = case
     rng = np.random.default_rng(zlib.crc32(str(case).encode()))
     b = 2
     x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
+    if dt != 'f32':
+        x = q16(x, dt)
     we = (rng.standard_normal((cin, cexp)) * np.sqrt(2.0 / cin)).astype(np.float32)
     se, he = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
     t = _act((nn.pointwise(x, we) * se + he).astype(np.float32), act)
@@ -66,18 +71,24 @@ def test_mblane(dev, case):
     pb[0, :cout], pb[1, :cout] = sp, hp
     keep = [torch.from_numpy(np.ascontiguousarray(a).ravel()).to(dev)
             for a in (_pairs(wep, se, he, e2), _pairs(wd.reshape(9, cexp), sd, hd, e2), wpp, pb)]
-    xd = to_dev(x, dev)
+    xd = to_dev(x, dev) if dt == 'f32' else to_dev16(x, dev, dt)
     op = rt.new_op(rt.OP_MBLANE, act)
+    op.dtype = op.out_dtype = rt.dtype_id(dt)
     op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc, op.se_reduced = ref.shape[1], ref.shape[2], cin, cout, 3, s, 1, cexp
     op.src[0] = rt.make_src(xd, c=cin)
     op.wgt, op.wgt2, op.b1, op.b2 = [k.data_ptr() for k in keep]
     if residual:
         op.res, op.res_ld = xd.data_ptr(), xd.shape[3]
-    out = torch.full((b, ref.shape[1], ref.shape[2], ldo), float('nan'), dtype=torch.float32, device=dev)
+    if dt != 'f32':
+        ldo = round_up(cout, 8)
+    out = torch.full((b, ref.shape[1], ref.shape[2], ldo), float('nan'), dtype=rt.TORCH_DTYPE[rt.dtype_id(dt)], device=dev)
     op.out, op.out_ld = out.data_ptr(), ldo
     rt.run_op(op, b)
     torch.cuda.synchronize()
-    assert_close(from_dev(out, cout), ref, 5e-5, 'mblane %s' % (case,))
+    if dt == 'f32':
+        assert_close(from_dev(out, cout), ref, 5e-5, 'mblane %s' % (case,))
+    else:
+        assert_rounded_once(from_dev16(out, dt, cout), ref, dt, 'mblane %s %s' % (dt, case), slack=5e-5)
 
 
 def test_mblane_rejects_unsupported_widths(dev):

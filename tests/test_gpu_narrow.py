@@ -18,58 +18,16 @@ import pytest
 import torch
 
 from oracle import nn
-from tests.util import round_up
+from tests.util import assert_rounded_once, from_dev16, q16, round_up, to_dev16
 
 pytestmark = pytest.mark.gpu
 
-REL = {'bf16': 2.0 ** -8, 'f16': 2.0 ** -11}     # half an ulp, relative (normal range)
-TINY = {'bf16': 1e-30, 'f16': 2.0 ** -25}        # half an ulp in the subnormal range of float16
 DTYPES = ['bf16', 'f16']
 
 
 def _rt():
     from yoloret_amd import runtime as rt
     return rt
-
-
-def q16(a, dt):
-    """float32 array rounded to the 16-bit type and widened back."""
-    rt = _rt()
-    a = np.ascontiguousarray(a, np.float32)
-    return rt.from_bits16(rt.to_bits16(a, dt), dt).reshape(a.shape)
-
-
-def to_dev16(a, dev, dt, ld=None, poison=True):
-    """[..., C] float32 (values representable in dt) -> device tensor [..., ld] of the 16-bit type; pad channels NaN."""
-    rt = _rt()
-    a = np.asarray(a, np.float32)
-    c = a.shape[-1]
-    ld = round_up(c, 8) if ld is None else ld
-    if ld != c:
-        p = np.full(a.shape[:-1] + (ld,), np.nan if poison else 0.0, np.float32)
-        p[..., :c] = a
-        a = p
-    bits = rt.to_bits16(a, dt).reshape(a.shape)
-    t = torch.from_numpy(bits.view(np.int16)).to(dev)
-    return t.view(rt.TORCH_DTYPE[rt.dtype_id(dt)])
-
-
-def from_dev16(t, dt, c=None):
-    rt = _rt()
-    a = rt.from_bits16(t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16), dt).reshape(tuple(t.shape))
-    return a if c is None else a[..., :c]
-
-
-def assert_rounded_once(got, ref64, dt, what, slack=2e-5):
-    """|got - ref| <= half ulp_dt(ref) (x1.02) + slack*max(1,|ref|): one rounding of a float32-accurate value."""
-    got = np.asarray(got, np.float64)
-    ref = np.asarray(ref64, np.float64)
-    assert got.shape == ref.shape, (what, got.shape, ref.shape)
-    assert np.isfinite(got).all(), '%s: non-finite values' % what
-    tol = 1.02 * REL[dt] * np.abs(ref) + TINY[dt] + slack * np.maximum(1.0, np.abs(ref))
-    bad = np.abs(got - ref) > tol
-    assert not bad.any(), '%s: %d of %d beyond half an ulp; worst |d|/tol = %.2f' % (
-        what, bad.sum(), bad.size, float((np.abs(got - ref) / tol).max()))
 
 
 def _dev_vec(a, dev):
@@ -238,7 +196,7 @@ def test_depthwise16(dev, dt, k, s, h, w, c, act):
     scale = rng.uniform(0.5, 1.5, c).astype(np.float32)
     shift = rng.normal(0, 0.3, c).astype(np.float32)
     ref = _act(nn.depthwise(x.astype(np.float64), wk.astype(np.float64), s, 'same') * scale + shift, act)
-    ldc = round_up(c, 4)
+    ldc = round_up(c, 8)
     wp = np.zeros((k * k, ldc), np.float32)
     wp[:, :c] = wk.reshape(k * k, c)
     pad = lambda v: np.concatenate([v, np.zeros(ldc - c, np.float32)])

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import nn
-from tests.util import assert_close, from_dev, round_up
+from tests.util import assert_close, assert_rounded_once, from_dev, from_dev16, round_up
 
 pytestmark = pytest.mark.gpu
 
@@ -25,8 +25,10 @@ CASES = [((64, 64), 24, 16, 'relu6'), ((416, 416), 24, 16, 'relu6'), ((32, 96), 
          ((30, 22), 32, 16, 'swish'), ((50, 34), 40, 24, 'relu6')]
 
 
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('hw,c1,cout,act', CASES)
-def test_stemblock(dev, hw, c1, cout, act):
+def test_stemblock(dev, hw, c1, cout, act, dt):
+    """dt: element type of the OUTPUT map (the image is float32 in every plan)."""
     from yoloret_amd import runtime as rt
     rng = np.random.default_rng(zlib.crc32(str((hw, c1, cout)).encode()))
     b = 2
@@ -54,12 +56,18 @@ def test_stemblock(dev, hw, c1, cout, act):
     keep = [_vec(per_pair(ws.reshape(27, c1), ss, hs), dev), _vec(per_pair(wd.reshape(9, c1), sd, hd), dev),
             _vec(wpp, dev), _vec(pb, dev)]
     xd = torch.from_numpy(x).to(dev)
-    out = torch.full((b, ref.shape[1], ref.shape[2], ldo), float('nan'), dtype=torch.float32, device=dev)
+    if dt != 'f32':
+        ldo = round_up(cout, 8)
+    out = torch.full((b, ref.shape[1], ref.shape[2], ldo), float('nan'), dtype=rt.TORCH_DTYPE[rt.dtype_id(dt)], device=dev)
     op = rt.new_op(rt.OP_STEMBLOCK, act)
+    op.dtype = op.out_dtype = rt.dtype_id(dt)
     op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc, op.se_reduced = ref.shape[1], ref.shape[2], 3, cout, 3, 2, 1, c1
     op.src[0] = rt.make_src(xd, c=3, ld=3)
     op.wgt, op.wgt2, op.b1, op.b2 = [k.data_ptr() for k in keep]
     op.out, op.out_ld = out.data_ptr(), ldo
     rt.run_op(op, b)
     torch.cuda.synchronize()
-    assert_close(from_dev(out, cout), ref, 3e-5, 'stemblock')
+    if dt == 'f32':
+        assert_close(from_dev(out, cout), ref, 3e-5, 'stemblock')
+    else:
+        assert_rounded_once(from_dev16(out, dt, cout), ref, dt, 'stemblock %s' % dt, slack=3e-5)

@@ -58,8 +58,10 @@ def test_yolo_facade_end_to_end(dev):
     # ... and the logits themselves track the oracle's on this (ill-conditioned, 'survey') recipe loosely
     for g, r in zip(gl, ys):
         assert np.abs(g[0].cpu().numpy().reshape(r.shape[1:]) - r[0]).max() < 5e-2
-    with pytest.raises(NotImplementedError):
-        y.detect_image(_png(img), draw=True)
+    drawn = y.detect_image(_png(img))             # the reference's default (draw=True): the annotated PIL image
+    assert drawn.size == (100, 75) and drawn.mode == 'RGB'
+    if len(boxes):
+        assert np.any(np.asarray(drawn) != img)   # something was drawn
 
 
 def test_yolomodel_batch_of_images(dev):

@@ -414,10 +414,13 @@ def fold_depthwise_into_project(ops, output_buf_ids):
     return out
 
 
-def fuse_inverted_residuals(ops, output_buf_ids, blocks=True):
+def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0):
     """Peephole over the lowered op list: [POINTWISE expand+act ->] DEPTHWISE 3x3+act -> POINTWISE
     project (+residual == block input) becomes one MBCONV op whose expanded tensors never reach HBM.
-    blocks=False (the small-batch plan) keeps only the network-entry fusion (stem + first block)."""
+    blocks=False (the small-batch plan) keeps only the network-entry fusion (stem + first block).
+    16-bit plans (dtype != 0): the lane-per-pixel kernels (stemblock, mblane) take 16-bit inputs / outputs - they
+    compute in float32 from registers, so only their loads and stores change; the MFMA block kernel (mbconv.hip) is
+    float32 only and is not selected."""
     max_cin = FUSE_MAX_CIN if blocks else 0
     readers = {}
     for op in ops:
@@ -457,7 +460,7 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True):
                 c1, cout = e.cout, p.cout
                 c1p, cop = round_up(c1, 4), round_up(cout, 8)
                 m = OpRec(rt.OP_STEMBLOCK, e.name + '_block0', act=e.act, h=p.h, w=p.w, cin=3, cout=cout, k=3, stride=2,
-                          se_reduced=c1, srcs=[e.srcs[0]], out=p.out, macs=e.macs + d.macs + p.macs)
+                          se_reduced=c1, srcs=[e.srcs[0]], out=p.out, macs=e.macs + d.macs + p.macs, dtype=dtype)
                 m.fused = [e, d, p]
 
                 def per_pair(prm, taps, c1p=c1p):
@@ -490,11 +493,11 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True):
         d = ops[j] if j < len(ops) else None
         if (d is not None and d.kind == rt.OP_DEPTHWISE and d.k == 3 and plain1(d) and private(d.out)
                 and (exp is None or (d.srcs[0].buf is exp.out and d.act == exp.act)) and d.act in ('relu6', 'swish')
-                and d.srcs[0].buf.ld == round_up(d.cin, 4) and j + 1 < len(ops)):
+                and d.srcs[0].buf.ld == round_up(d.cin, rt.VEC[dtype]) and j + 1 < len(ops)):
             p = ops[j + 1]
             block_in = exp.srcs[0] if exp is not None else d.srcs[0]
             lane = lane_ok(exp, block_in, p)
-            if (p.kind == rt.OP_POINTWISE and plain1(p) and p.srcs[0].buf is d.out and p.act == 'none'
+            if ((lane or dtype == 0) and p.kind == rt.OP_POINTWISE and plain1(p) and p.srcs[0].buf is d.out and p.act == 'none'
                     and 'scale' in p.params and p.cout <= 224 and block_in.buf.ld % 4 == 0
                     and (exp is not None or FUSE_NO_EXPAND) and block_in.c <= max_cin
                     and p.h * p.w >= (FUSE_LANE_MIN_PIXELS if lane else FUSE_MIN_PIXELS)
@@ -509,7 +512,7 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True):
         lde, ldo = round_up(cexp, 4), round_up(cout, 4)
         m = OpRec(rt.OP_MBCONV, (exp or dw).name.rsplit('_', 1)[0] + '_mbconv', act=dw.act, h=proj.h, w=proj.w,
                   cin=block_in.c, cout=cout, k=3, stride=dw.stride, se_reduced=cexp, srcs=[block_in], out=proj.out,
-                  res=proj.res, macs=(exp.macs if exp else 0) + dw.macs + proj.macs)
+                  res=proj.res, macs=(exp.macs if exp else 0) + dw.macs + proj.macs, dtype=dtype)
         m.fused = [o for o in (exp, dw, proj) if o is not None]
 
         def padded(fn, n, ld):
@@ -729,8 +732,7 @@ class Compiler:
             latency = self.fuse == 'latency'
             if MERGE_SE_MEAN and not latency:
                 ops = merge_se_mean(ops)
-            if self.dtype == 0:   # the fused block / network-entry kernels are float32
-                ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency)
+            ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency, dtype=self.dtype)
             if FOLD_DW and not latency and self.dtype == 0:
                 ops = fold_depthwise_into_project(ops, set(b.id for b in outs))
         return Plan(ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape, self.dtype)
@@ -866,7 +868,7 @@ class Compiler:
         bn, act, last = self._absorb_bn_act(n.output)
         src = self._plain(x)
         out = self._out_buf_for(last, n.name)
-        ldc = round_up(c, 4)
+        ldc = round_up(c, self.V)
         op = OpRec(rt.OP_DEPTHWISE, n.name, act=act, h=last.shape[0], w=last.shape[1], cin=c, cout=c, k=k,
                    stride=s, srcs=[src], out=out, macs=last.shape[0] * last.shape[1] * k * k * c)
         kname = n.name + '/depthwise_kernel'

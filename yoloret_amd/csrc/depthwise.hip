@@ -1,5 +1,5 @@
 // Depthwise k x k convolution (k in {3,5}, stride in {1,2}, TF 'SAME' padding) with fused
-// BatchNorm scale/shift + ReLU6/Swish, NHWC, 4 channels (one float4) per lane.  Replaces TF's
+// BatchNorm scale/shift + ReLU6/Swish, NHWC, 16 bytes of channels per lane (4 float32 / 8 bf16 or f16).  Replaces TF's
 // DepthwiseConv2dNative + FusedBatchNormV3 + Relu6/Swish used by MobileNetV2's *_depthwise
 // layers [3P], reference code/yolo3/model.py:20-24 (RFCR 5x5) and
 // code/yolo3/efficientnet.py:501-510 (MBConv).
@@ -21,7 +21,7 @@ struct DwArgs {
     const float* scale;  // [C]
     const float* shift;  // [C]
     T* out;              // [B][Ho][Wo][ld_out]
-    int B, Hi, Wi, Ho, Wo, C4;  // C4 = ceil(C/4)
+    int B, Hi, Wi, Ho, Wo, C4;  // C4 = ceil(C / channels per lane)
     int ld_in, ld_w, ld_out;
     int pad_t, pad_l;
     int act;
@@ -35,8 +35,34 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
                        __builtin_fmaf(a.z, b.z, c.z), __builtin_fmaf(a.w, b.w, c.w));
 }
 
+// One 16-byte load = Q quads of channels (float32: 1, 16-bit: 2 - the same bytes in flight per lane, half the lanes:
+// with 8-byte loads the 16-bit form took exactly as long as float32, the kernel is bound by loads issued, not bytes).
+template <class T, int Q>
+__device__ __forceinline__ void dw_load(const T* p, float4 (&v)[Q]) {
+    if constexpr (Q == 1) {
+        v[0] = *reinterpret_cast<const float4*>(p);
+    } else {
+        typedef T t8 __attribute__((ext_vector_type(8)));
+        typedef float f8 __attribute__((ext_vector_type(8)));
+        const f8 x = __builtin_convertvector(*reinterpret_cast<const t8*>(p), f8);
+        v[0] = make_float4(x[0], x[1], x[2], x[3]);
+        v[1] = make_float4(x[4], x[5], x[6], x[7]);
+    }
+}
+template <class T, int Q>
+__device__ __forceinline__ void dw_store(T* p, const float4 (&v)[Q]) {
+    if constexpr (Q == 1) {
+        *reinterpret_cast<float4*>(p) = v[0];
+    } else {
+        typedef T t8 __attribute__((ext_vector_type(8)));
+        typedef float f8 __attribute__((ext_vector_type(8)));
+        *reinterpret_cast<t8*>(p) = __builtin_convertvector((f8){v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w}, t8);
+    }
+}
+
 template <int K, int S, int XT, int YT, class T>
 __global__ __launch_bounds__(256) void dw_kernel(DwArgs<T> a) {
+    constexpr int Q = yr_elem<T>::vec / 4;   // channel quads per lane
     const long long gid = (long long)yr_xcd_swizzle(blockIdx.x, a.nblocks) * 256 + threadIdx.x;
     if (gid >= a.total) return;
     const int cq = (int)(gid % a.C4);
@@ -45,16 +71,18 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs<T> a) {
     t /= a.xstrips;
     const int ys = (int)(t % a.ystrips);
     const int b = (int)(t / a.ystrips);
-    const int c = cq * 4;
+    const int c = cq * 4 * Q;
     const int x0 = xs * XT, y0 = ys * YT;
     constexpr int COLS = (XT - 1) * S + K;
     constexpr int ROWS = (YT - 1) * S + K;
 
-    float4 acc[YT][XT];
+    float4 acc[YT][XT][Q];
 #pragma unroll
     for (int j = 0; j < YT; ++j)
 #pragma unroll
-        for (int i = 0; i < XT; ++i) acc[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < XT; ++i)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) acc[j][i][q] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     const int iy0 = y0 * S - a.pad_t;
     const int ix0 = x0 * S - a.pad_l;
@@ -63,11 +91,16 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs<T> a) {
         const int iy = iy0 + r;
         if (iy < 0 || iy >= a.Hi) continue;  // zero padding row
         const T* rowp = a.in + ((size_t)(b * a.Hi + iy) * a.Wi) * a.ld_in + c;
-        float4 col[COLS];
+        float4 col[COLS][Q];
 #pragma unroll
         for (int j = 0; j < COLS; ++j) {
             const int ix = ix0 + j;
-            col[j] = (ix >= 0 && ix < a.Wi) ? yr_ld4<T>(rowp + (size_t)ix * a.ld_in) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ix >= 0 && ix < a.Wi) {
+                dw_load<T, Q>(rowp + (size_t)ix * a.ld_in, col[j]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) col[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         // input row r feeds output row j through kernel row ky = r - j*S
 #pragma unroll
@@ -76,14 +109,21 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs<T> a) {
             if (ky < 0 || ky >= K) continue;
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
-                const float4 wv = *reinterpret_cast<const float4*>(a.w + (size_t)(ky * K + kx) * a.ld_w + c);
 #pragma unroll
-                for (int i = 0; i < XT; ++i) acc[j][i] = fma4(col[i * S + kx], wv, acc[j][i]);
+                for (int q = 0; q < Q; ++q) {
+                    const float4 wv = *reinterpret_cast<const float4*>(a.w + (size_t)(ky * K + kx) * a.ld_w + c + 4 * q);
+#pragma unroll
+                    for (int i = 0; i < XT; ++i) acc[j][i][q] = fma4(col[i * S + kx][q], wv, acc[j][i][q]);
+                }
             }
         }
     }
-    const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
-    const float4 sh = *reinterpret_cast<const float4*>(a.shift + c);
+    float4 sc[Q], sh[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        sc[q] = *reinterpret_cast<const float4*>(a.scale + c + 4 * q);
+        sh[q] = *reinterpret_cast<const float4*>(a.shift + c + 4 * q);
+    }
 #pragma unroll
     for (int j = 0; j < YT; ++j) {
         if (y0 + j >= a.Ho) continue;
@@ -91,8 +131,10 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs<T> a) {
 #pragma unroll
         for (int i = 0; i < XT; ++i) {
             if (x0 + i < a.Wo) {
-                float4 v = yr_apply_act4(fma4(acc[j][i], sc, sh), a.act);
-                yr_st4<T>(op + (size_t)i * a.ld_out, v);
+                float4 v[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) v[q] = yr_apply_act4(fma4(acc[j][i][q], sc[q], sh[q]), a.act);
+                dw_store<T, Q>(op + (size_t)i * a.ld_out, v);
             }
         }
     }
@@ -124,8 +166,8 @@ static int launch_depthwise_t(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(op.k == 3 || op.k == 5, "depthwise: kernel size %d unsupported", op.k);
     YR_REQUIRE(op.stride == 1 || op.stride == 2, "depthwise: stride %d unsupported", op.stride);
     YR_REQUIRE(in.c == op.cout && op.cin == op.cout, "depthwise: channel mismatch");
-    YR_REQUIRE(in.ld % V == 0 && op.out_ld % V == 0 && in.ld >= yr_round_up(in.c, 4) && op.out_ld >= yr_round_up(in.c, 4),
-               "depthwise: ld must be a multiple of %d and cover round_up(c,4)", V);
+    YR_REQUIRE(in.ld % V == 0 && op.out_ld % V == 0 && in.ld >= yr_round_up(in.c, V) && op.out_ld >= yr_round_up(in.c, V),
+               "depthwise: ld must be a multiple of %d and cover round_up(c,%d)", V, V);
     YR_REQUIRE(in.ptr && op.out && op.wgt && op.scale && op.shift, "depthwise: null pointer");
     YR_REQUIRE(((uintptr_t)in.ptr | (uintptr_t)op.out | (uintptr_t)op.wgt | (uintptr_t)op.scale | (uintptr_t)op.shift) % 16 == 0,
                "depthwise: pointers must be 16-byte aligned");
@@ -135,8 +177,8 @@ static int launch_depthwise_t(const yr_op& op, int batch, hipStream_t s) {
     a.Ho = (in.h + op.stride - 1) / op.stride;
     a.Wo = (in.w + op.stride - 1) / op.stride;
     YR_REQUIRE(a.Ho == op.h && a.Wo == op.w, "depthwise: output dims %dx%d != SAME(%dx%d / %d)", op.h, op.w, in.h, in.w, op.stride);
-    a.C4 = (in.c + 3) / 4;
-    a.ld_in = in.ld; a.ld_w = yr_round_up(in.c, 4); a.ld_out = op.out_ld;
+    a.C4 = (in.c + V - 1) / V;                    // lanes per pixel: V channels (16 bytes) each
+    a.ld_in = in.ld; a.ld_w = yr_round_up(in.c, V); a.ld_out = op.out_ld;   // weights / scale / shift: [..][round_up(c, V)]
     // TF 'SAME': pad_total = max((out-1)*s + k - in, 0); before = total/2 (extra goes bottom/right)
     const int pth = (a.Ho - 1) * op.stride + op.k - in.h, ptw = (a.Wo - 1) * op.stride + op.k - in.w;
     a.pad_t = (pth > 0 ? pth : 0) / 2;

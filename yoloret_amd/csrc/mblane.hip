@@ -23,8 +23,11 @@
 typedef const float __attribute__((address_space(4))) * kptr;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// T: element type of the block input and output (float32, or bf16 / f16 storage: widened on load - the pixel's
+// channels then live in float32 registers as before - and rounded once at the store).  Weights: float32.
+template <class T>
 struct MlArgs {
-    const float* x; float* out;
+    const T* x; T* out;
     const float* we;   // expand     [P][CINP x 2 | scale 2 | shift 2]
     const float* wd;   // depthwise  [P][9 x 2    | scale 2 | shift 2]
     const float* wp;   // project    [2P][COP]
@@ -55,16 +58,16 @@ __device__ __forceinline__ v2f ml_expand(const float4 (&x)[CQ], kptr w, int act)
     return ml_act<RELU6>(ml_fma(a0, (v2f){w[8 * CQ], w[8 * CQ + 1]}, (v2f){w[8 * CQ + 2], w[8 * CQ + 3]}), act);
 }
 
-template <int CQ>
-__device__ __forceinline__ void ml_load_x(float4 (&x)[CQ], const MlArgs& a, int b, int hy, int hx, bool inside) {
+template <int CQ, class T>
+__device__ __forceinline__ void ml_load_x(float4 (&x)[CQ], const MlArgs<T>& a, int b, int hy, int hx, bool inside) {
 #pragma unroll
     for (int q = 0; q < CQ; ++q) x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (inside) {
-        const float* xp = a.x + ((size_t)(b * a.Hi + hy) * a.Wi + hx) * a.ld_in;
+        const T* xp = a.x + ((size_t)(b * a.Hi + hy) * a.Wi + hx) * a.ld_in;
 #pragma unroll
         for (int q = 0; q < CQ; ++q) {
             if (q * 4 < a.Cin) {
-                float4 v = *reinterpret_cast<const float4*>(xp + q * 4);
+                float4 v = yr_ld4<T>(xp + q * 4);
                 const int rem = a.Cin - q * 4;  // pad lanes of the source may hold anything
                 if (rem < 4) { v.w = 0.f; if (rem < 3) v.z = 0.f; if (rem < 2) v.y = 0.f; }
                 x[q] = v;
@@ -131,9 +134,9 @@ __device__ __forceinline__ void ml_dw_project(const v2f* e, kptr w, kptr pw, v2f
 }
 
 // ------------------------------------------------------------------------------------------ stride 1
-template <int CQ, int COP, bool RELU6>
-__global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s1_kernel(MlArgs a) {
-    constexpr int T = 14, WE = 8 * CQ + 4;
+template <int CQ, int COP, bool RELU6, class T>
+__global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s1_kernel(MlArgs<T> a) {
+    constexpr int TL = 14, WE = 8 * CQ + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     v2f* Es = reinterpret_cast<v2f*>(lds);  // [2][ML_CH][256]
     const int tid = threadIdx.x;
@@ -141,13 +144,13 @@ __global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s1_ke
     const int tpi = a.tiles_x * a.tiles_y;
     const int b = t / tpi, r = t - b * tpi;
     const int ty = r / a.tiles_x;
-    const int oy0 = ty * T, ox0 = (r - ty * a.tiles_x) * T;
+    const int oy0 = ty * TL, ox0 = (r - ty * a.tiles_x) * TL;
     const int ey = tid >> 4, ex = tid & 15;
     const int hy = oy0 - 1 + ey, hx = ox0 - 1 + ex;  // stride 1, 3x3 SAME: pad 1
     const bool inside = hy >= 0 && hy < a.Hi && hx >= 0 && hx < a.Wi;
-    const bool is_out = inside && ey >= 1 && ey <= T && ex >= 1 && ex <= T;
+    const bool is_out = inside && ey >= 1 && ey <= TL && ex >= 1 && ex <= TL;
     float4 x[CQ];
-    ml_load_x<CQ>(x, a, b, hy, hx, inside);
+    ml_load_x<CQ, T>(x, a, b, hy, hx, inside);
     v2f o[COP / 2];
 #pragma unroll
     for (int n = 0; n < COP / 2; ++n) o[n] = (v2f){0.f, 0.f};
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s1_ke
     }
     if (is_out && hy < a.Ho && hx < a.Wo) {
         const kptr bp = (kptr)a.bp;
-        float* op = a.out + ((size_t)(b * a.Ho + hy) * a.Wo + hx) * a.ld_out;
+        T* op = a.out + ((size_t)(b * a.Ho + hy) * a.Wo + hx) * a.ld_out;
 #pragma unroll
         for (int n = 0; n < COP / 2; ++n) o[n] = ml_fma(o[n], (v2f){bp[2 * n], bp[2 * n + 1]}, (v2f){bp[COP + 2 * n], bp[COP + 2 * n + 1]});
 #pragma unroll
@@ -181,20 +184,20 @@ __global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s1_ke
             float4 v = make_float4(o[n / 2].x, o[n / 2].y, o[n / 2 + 1].x, o[n / 2 + 1].y);
             if (a.has_res && n / 4 < CQ) { const float4 rx = x[n / 4 < CQ ? n / 4 : 0]; v.x += rx.x; v.y += rx.y; v.z += rx.z; v.w += rx.w; }
             if (n + 3 < a.Cout && (a.ld_out & 3) == 0) {
-                *reinterpret_cast<float4*>(op + n) = v;
+                yr_st4<T>(op + n, v);
             } else {
-                if (n < a.Cout) op[n] = v.x;
-                if (n + 1 < a.Cout) op[n + 1] = v.y;
-                if (n + 2 < a.Cout) op[n + 2] = v.z;
-                if (n + 3 < a.Cout) op[n + 3] = v.w;
+                if (n < a.Cout) yr_st1<T>(op + n, v.x);
+                if (n + 1 < a.Cout) yr_st1<T>(op + n + 1, v.y);
+                if (n + 2 < a.Cout) yr_st1<T>(op + n + 2, v.z);
+                if (n + 3 < a.Cout) yr_st1<T>(op + n + 3, v.w);
             }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------ stride 2
-template <int CQ, int COP, bool RELU6>
-__global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s2_kernel(MlArgs a) {
+template <int CQ, int COP, bool RELU6, class T>
+__global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s2_kernel(MlArgs<T> a) {
     constexpr int TH = 7, TW = 8, IH = 2 * TH + 1, IW = 2 * TW + 1, WE = 8 * CQ + 4;
     static_assert(IH * IW <= 256 && COP % 8 == 0, "tile / width assumptions");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s2_ke
     const int hy = 2 * oy0 - a.pad_t + ey, hx = 2 * ox0 - a.pad_l + ex;
     const bool inside = tid < IH * IW && hy >= 0 && hy < a.Hi && hx >= 0 && hx < a.Wi;
     float4 x[CQ];
-    ml_load_x<CQ>(x, a, b, hy, hx, inside);
+    ml_load_x<CQ, T>(x, a, b, hy, hx, inside);
     // depthwise/project phase: lane = output pixel, wave = which quarter of each chunk's pairs
     const int py = lane >> 3, px = lane & 7;
     const int gy = oy0 + py, gx = ox0 + px;
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s2_ke
     if (is_out) {
         constexpr int NQ = COP / 8;  // pairs per thread: this thread finishes channels [wave*COP/4, (wave+1)*COP/4)
         const kptr bp = (kptr)a.bp;
-        float* op = a.out + ((size_t)(b * a.Ho + gy) * a.Wo + gx) * a.ld_out;
+        T* op = a.out + ((size_t)(b * a.Ho + gy) * a.Wo + gx) * a.ld_out;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int n2 = wave * NQ + i;
@@ -256,44 +259,44 @@ __global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s2_ke
             for (int w = 1; w < 4; ++w) s += red[(w * (COP / 2) + n2) * 64 + lane];
             // wave is uniform, so these are still scalar loads
             s = ml_fma(s, (v2f){bp[2 * n2], bp[2 * n2 + 1]}, (v2f){bp[COP + 2 * n2], bp[COP + 2 * n2 + 1]});
-            if (2 * n2 + 1 < a.Cout) *reinterpret_cast<v2f*>(op + 2 * n2) = s;
-            else if (2 * n2 < a.Cout) op[2 * n2] = s.x;
+            if (2 * n2 + 1 < a.Cout) yr_st2<T>(op + 2 * n2, s.x, s.y);
+            else if (2 * n2 < a.Cout) yr_st1<T>(op + 2 * n2, s.x);
         }
     }
 }
 
-template <int S, int CQ, int COP>
-static int launch_ml(const MlArgs& a, int batch, hipStream_t s) {
+template <int S, int CQ, int COP, class T>
+static int launch_ml(const MlArgs<T>& a, int batch, hipStream_t s) {
     constexpr size_t es = (size_t)2 * ML_CH * 256 * sizeof(v2f), red = (size_t)4 * (COP / 2) * 64 * sizeof(v2f);
     constexpr size_t lds = (S == 2 && red > es) ? red : es;  // stride 2 reuses Es as the cross-wave reduction buffer
-    static char nm[48];
-    static const int nm_len = snprintf(nm, sizeof(nm), "mblane_s%d_kernel<%d,%d>", S, CQ, COP);
+    static char nm[56];
+    static const int nm_len = snprintf(nm, sizeof(nm), "mblane_s%d_kernel<%d,%d,%s>", S, CQ, COP, yr_dtype_name(yr_elem<T>::dtype));
     (void)nm_len;
     yr_note_kernel(nm);
     const dim3 grid((unsigned)(batch * a.tiles_x * a.tiles_y));
     if (S == 1) {
-        if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((mblane_s1_kernel<CQ, COP, true>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((mblane_s1_kernel<CQ, COP, false>), grid, dim3(256), lds, s, a);
+        if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((mblane_s1_kernel<CQ, COP, true, T>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((mblane_s1_kernel<CQ, COP, false, T>), grid, dim3(256), lds, s, a);
     } else {
-        if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((mblane_s2_kernel<CQ, COP, true>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((mblane_s2_kernel<CQ, COP, false>), grid, dim3(256), lds, s, a);
+        if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((mblane_s2_kernel<CQ, COP, true, T>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((mblane_s2_kernel<CQ, COP, false, T>), grid, dim3(256), lds, s, a);
     }
     YR_LAUNCH_CHECK();
     return YR_OK;
 }
 
-template <int S>
-static int launch_ml_widths(const MlArgs& a, int cq, int cop, int batch, hipStream_t s) {
+template <int S, class T>
+static int launch_ml_widths(const MlArgs<T>& a, int cq, int cop, int batch, hipStream_t s) {
     switch (cq * 100 + cop) {
-        case 416: return launch_ml<S, 4, 16>(a, batch, s);
-        case 424: return launch_ml<S, 4, 24>(a, batch, s);
-        case 624: return launch_ml<S, 6, 24>(a, batch, s);
-        case 632: return launch_ml<S, 6, 32>(a, batch, s);
-        case 640: return launch_ml<S, 6, 40>(a, batch, s);
-        case 832: return launch_ml<S, 8, 32>(a, batch, s);
-        case 840: return launch_ml<S, 8, 40>(a, batch, s);
-        case 648: return launch_ml<S, 6, 48>(a, batch, s);
-        case 848: return launch_ml<S, 8, 48>(a, batch, s);
+        case 416: return launch_ml<S, 4, 16, T>(a, batch, s);
+        case 424: return launch_ml<S, 4, 24, T>(a, batch, s);
+        case 624: return launch_ml<S, 6, 24, T>(a, batch, s);
+        case 632: return launch_ml<S, 6, 32, T>(a, batch, s);
+        case 640: return launch_ml<S, 6, 40, T>(a, batch, s);
+        case 832: return launch_ml<S, 8, 32, T>(a, batch, s);
+        case 840: return launch_ml<S, 8, 40, T>(a, batch, s);
+        case 648: return launch_ml<S, 6, 48, T>(a, batch, s);
+        case 848: return launch_ml<S, 8, 48, T>(a, batch, s);
         default: yr_set_error("mblane: widths Cin=%d Cout=%d unsupported", a.Cin, a.Cout); return YR_ERR_ARG;
     }
 }
@@ -305,17 +308,19 @@ static int launch_ml_widths(const MlArgs& a, int cq, int cop, int batch, hipStre
 //   wgt  = expand     [P][CINP x 2 (input channel major) | BN scale 2 | BN shift 2]
 //   wgt2 = depthwise  [P][9 taps x 2 | BN scale 2 | BN shift 2]
 //   b1   = project    W[2P][COP] (expanded-channel major);   b2 = project BN scale [COP] ++ shift [COP].
-int yr_launch_mblane(const yr_op& op, int batch, hipStream_t s) {
+template <class T>
+static int launch_mblane_t(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY, "mblane: needs one identity source");
     const yr_src& in = op.src[0];
     YR_REQUIRE(op.k == 3 && (op.stride == 1 || op.stride == 2), "mblane: only 3x3 stride 1|2 is fused");
     YR_REQUIRE(in.ptr && op.out && op.wgt && op.wgt2 && op.b1 && op.b2, "mblane: null pointer");
-    YR_REQUIRE(in.ld % 4 == 0 && in.c == op.cin && in.ld >= yr_round_up(in.c, 4), "mblane: bad input stride");
+    YR_REQUIRE(in.ld % yr_elem<T>::vec == 0 && op.out_ld % yr_elem<T>::vec == 0 && in.c == op.cin && in.ld >= yr_round_up(in.c, 4),
+               "mblane: channel strides must be multiples of %d", yr_elem<T>::vec);
     YR_REQUIRE(((uintptr_t)in.ptr) % 16 == 0 && ((uintptr_t)op.out) % 8 == 0, "mblane: pointers must be 16-byte aligned");
     YR_REQUIRE(op.se_reduced >= 1 && op.cout >= 1 && op.out_ld >= op.cout, "mblane: bad widths");
-    MlArgs a;
-    YR_REQUIRE(op.dtype == YR_F32 && op.out_dtype == YR_F32 && in.dtype == YR_F32, "mblane: float32 only");
-    a.x = (const float*)in.ptr; a.out = (float*)op.out;
+    MlArgs<T> a;
+    YR_REQUIRE(op.out_dtype == op.dtype && in.dtype == op.dtype, "mblane: input and output have the op's dtype");
+    a.x = (const T*)in.ptr; a.out = (T*)op.out;
     a.we = op.wgt; a.wd = op.wgt2; a.wp = op.b1; a.bp = op.b2;
     a.Cin = in.c; a.Cout = op.cout;
     a.npairs = yr_round_up((op.se_reduced + 1) / 2, ML_CH);
@@ -330,9 +335,11 @@ int yr_launch_mblane(const yr_op& op, int batch, hipStream_t s) {
     const int cq = yr_round_up(in.c, 4) / 4, cop = yr_round_up(op.cout, 8);
     if (op.stride == 1) {
         a.tiles_x = (a.Wo + 13) / 14; a.tiles_y = (a.Ho + 13) / 14;
-        return launch_ml_widths<1>(a, cq, cop, batch, s);
+        return launch_ml_widths<1, T>(a, cq, cop, batch, s);
     }
     YR_REQUIRE(a.ld_out % 2 == 0, "mblane: stride-2 stores need an even output channel stride");
     a.tiles_x = (a.Wo + 7) / 8; a.tiles_y = (a.Ho + 6) / 7;
-    return launch_ml_widths<2>(a, cq, cop, batch, s);
+    return launch_ml_widths<2, T>(a, cq, cop, batch, s);
 }
+
+int yr_launch_mblane(const yr_op& op, int batch, hipStream_t s) { return YR_BY_DTYPE(op.dtype, launch_mblane_t, op, batch, s); }

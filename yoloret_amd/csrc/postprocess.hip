@@ -440,7 +440,11 @@ extern "C" int yr_nms(const float* boxes, const float* scores, int batch, int n,
     YR_REQUIRE(batch > 0 && n > 0 && num_classes > 0 && max_boxes > 0, "nms: bad sizes");
     YR_REQUIRE(((uintptr_t)boxes % 16) == 0, "nms: boxes must be 16-byte aligned");
     const size_t lds_limit = 150 * 1024;
-    static bool attr_set = false;
+    // the > 64 KB dynamic-LDS opt-in is a per-device function attribute: remember it per device
+    static bool attr_set_dev[64] = {false};
+    int cur_dev = 0;
+    YR_CHECK_HIP(hipGetDevice(&cur_dev));
+    bool& attr_set = attr_set_dev[cur_dev & 63];
     if (!attr_set) {
         YR_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
         YR_CHECK_HIP(hipFuncSetAttribute((const void*)nms_lazy_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));

@@ -12,9 +12,12 @@ struct LbArgs {
     float sy, sx;              // ih/nh, iw/nw  (CalculateResizeScale)
 };
 
+// grid.y = image index of a batch of equally sized sources (yr_letterbox_batch); 0 for a single image
 __global__ __launch_bounds__(256) void letterbox_kernel(LbArgs a) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     if (gid >= a.H * a.W) return;
+    a.src += (size_t)blockIdx.y * a.ih * a.iw * 3;
+    a.dst += (size_t)blockIdx.y * a.H * a.W * 3;
     const int y = gid / a.W, x = gid - y * a.W;
     float* o = a.dst + (size_t)gid * 3;
     const int ry = y - a.dy, rx = x - a.dx;
@@ -39,8 +42,8 @@ __global__ __launch_bounds__(256) void letterbox_kernel(LbArgs a) {
     }
 }
 
-extern "C" int yr_letterbox(const unsigned char* src_u8, int ih, int iw, float* dst, int H, int W, void* stream) {
-    YR_REQUIRE(src_u8 && dst && ih > 0 && iw > 0 && H > 0 && W > 0, "letterbox: bad arguments");
+extern "C" int yr_letterbox_batch(const unsigned char* src_u8, int batch, int ih, int iw, float* dst, int H, int W, void* stream) {
+    YR_REQUIRE(src_u8 && dst && batch > 0 && batch < 65536 && ih > 0 && iw > 0 && H > 0 && W > 0, "letterbox: bad arguments");
     LbArgs a;
     a.src = src_u8; a.dst = dst; a.ih = ih; a.iw = iw; a.H = H; a.W = W;
     // utils.py:76-79: nh/nw in float64 then truncated; offsets by floor division
@@ -49,7 +52,11 @@ extern "C" int yr_letterbox(const unsigned char* src_u8, int ih, int iw, float* 
     YR_REQUIRE(a.nh > 0 && a.nw > 0, "letterbox: image collapses to zero size");
     a.dy = (H - a.nh) / 2; a.dx = (W - a.nw) / 2;
     a.sy = (float)ih / (float)a.nh; a.sx = (float)iw / (float)a.nw;
-    hipLaunchKernelGGL(letterbox_kernel, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(letterbox_kernel, dim3((H * W + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
+}
+
+extern "C" int yr_letterbox(const unsigned char* src_u8, int ih, int iw, float* dst, int H, int W, void* stream) {
+    return yr_letterbox_batch(src_u8, 1, ih, iw, dst, H, W, stream);
 }

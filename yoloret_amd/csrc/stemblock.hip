@@ -31,9 +31,11 @@ typedef const float __attribute__((address_space(4))) * kptr;  // uniform reads 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load at a dword-aligned address
 
+// T: element type of the OUTPUT map (image, weights and arithmetic: float32; one rounding at the store).
+template <class T>
 struct SbArgs {
     const float* in;   // [B][Hi][Wi][3]
-    float* out;        // [B][Ho][Wo][ld_out]   (Ho = ceil(Hi/2))
+    T* out;            // [B][Ho][Wo][ld_out]   (Ho = ceil(Hi/2))
     const float* ws;   // stem       [CP][SB_WS]
     const float* wd;   // depthwise  [CP][SB_WD]
     const float* wp;   // project    [2*CP][COP]
@@ -49,8 +51,8 @@ __device__ __forceinline__ v2f sb_act(v2f v, int act) {
     return (v2f){yr_apply_act(v.x, act), yr_apply_act(v.y, act)};
 }
 
-template <int CP, int COP, bool RELU6>
-__global__ __launch_bounds__(256, 4) void stemblock_kernel(SbArgs a) {
+template <int CP, int COP, bool RELU6, class T>
+__global__ __launch_bounds__(256, 4) void stemblock_kernel(SbArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     v2f* Es = reinterpret_cast<v2f*>(lds);                       // [CP][256]
     const int tid = threadIdx.x;
@@ -140,35 +142,35 @@ __global__ __launch_bounds__(256, 4) void stemblock_kernel(SbArgs a) {
         }
         if (gy < a.Ho && gx < a.Wo) {
             const kptr bp = (kptr)a.bp;
-            float* op = a.out + (((size_t)b * a.Ho + gy) * a.Wo + gx) * a.ld_out;
+            T* op = a.out + (((size_t)b * a.Ho + gy) * a.Wo + gx) * a.ld_out;
 #pragma unroll
             for (int n = 0; n < COP / 2; ++n) o[n] = sb_fma(o[n], (v2f){bp[2 * n], bp[2 * n + 1]}, (v2f){bp[COP + 2 * n], bp[COP + 2 * n + 1]});
 #pragma unroll
             for (int n = 0; n < COP; n += 4) {
                 if (n + 3 < a.Cout && (a.ld_out & 3) == 0) {
-                    *reinterpret_cast<float4*>(op + n) = make_float4(o[n / 2].x, o[n / 2].y, o[n / 2 + 1].x, o[n / 2 + 1].y);
+                    yr_st4<T>(op + n, make_float4(o[n / 2].x, o[n / 2].y, o[n / 2 + 1].x, o[n / 2 + 1].y));
                 } else {
-                    if (n < a.Cout) op[n] = o[n / 2].x;
-                    if (n + 1 < a.Cout) op[n + 1] = o[n / 2].y;
-                    if (n + 2 < a.Cout) op[n + 2] = o[n / 2 + 1].x;
-                    if (n + 3 < a.Cout) op[n + 3] = o[n / 2 + 1].y;
+                    if (n < a.Cout) yr_st1<T>(op + n, o[n / 2].x);
+                    if (n + 1 < a.Cout) yr_st1<T>(op + n + 1, o[n / 2].y);
+                    if (n + 2 < a.Cout) yr_st1<T>(op + n + 2, o[n / 2 + 1].x);
+                    if (n + 3 < a.Cout) yr_st1<T>(op + n + 3, o[n / 2 + 1].y);
                 }
             }
         }
     }
 }
 
-template <int CP, int COP>
-static int launch_sb(const SbArgs& a, int batch, hipStream_t s) {
+template <int CP, int COP, class T>
+static int launch_sb(const SbArgs<T>& a, int batch, hipStream_t s) {
     constexpr size_t lds = (size_t)CP * 256 * 2 * sizeof(float);
     static_assert(lds <= 64 * 1024, "stemblock LDS tile too large");
-    static char nm[40];
-    static const int nm_len = snprintf(nm, sizeof(nm), "stemblock_kernel<%d,%d>", CP, COP);
+    static char nm[48];
+    static const int nm_len = snprintf(nm, sizeof(nm), "stemblock_kernel<%d,%d,%s>", CP, COP, yr_dtype_name(yr_elem<T>::dtype));
     (void)nm_len;
     yr_note_kernel(nm);
     const dim3 grid((unsigned)(batch * a.tiles_x * a.tiles_y));
-    if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((stemblock_kernel<CP, COP, true>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((stemblock_kernel<CP, COP, false>), grid, dim3(256), lds, s, a);
+    if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((stemblock_kernel<CP, COP, true, T>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((stemblock_kernel<CP, COP, false, T>), grid, dim3(256), lds, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
 }
@@ -178,14 +180,15 @@ static int launch_sb(const SbArgs& a, int batch, hipStream_t s) {
 //   wgt  = stem, per channel pair:      [CP][27 taps (ky,kx,ci) x 2 | BN scale 2 | BN shift 2]   (58 floats per pair)
 //   wgt2 = depthwise, per channel pair: [CP][ 9 taps (ky,kx)    x 2 | BN scale 2 | BN shift 2]   (22 floats per pair)
 //   b1   = project W[2*CP][COP] (input-channel major);  b2 = project BN scale [COP] ++ shift [COP].
-int yr_launch_stemblock(const yr_op& op, int batch, hipStream_t s) {
-    YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY && op.src[0].c == 3 && op.src[0].ld == 3,
-               "stemblock: needs one dense 3-channel source");
+template <class T>
+static int launch_stemblock_t(const yr_op& op, int batch, hipStream_t s) {
+    YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY && op.src[0].c == 3 && op.src[0].ld == 3 && op.src[0].dtype == YR_F32,
+               "stemblock: needs one dense 3-channel float32 source");
     YR_REQUIRE(op.k == 3 && op.stride == 2, "stemblock: the stem is 3x3 stride 2");
     const yr_src& in = op.src[0];
-    SbArgs a;
-    YR_REQUIRE(op.dtype == YR_F32 && op.out_dtype == YR_F32 && in.dtype == YR_F32, "stemblock: float32 only");
-    a.in = (const float*)in.ptr; a.out = (float*)op.out;
+    SbArgs<T> a;
+    YR_REQUIRE(op.out_dtype == op.dtype && op.out_ld % (yr_elem<T>::vec == 8 ? 8 : 1) == 0, "stemblock: the output has the op's dtype (16-bit: out_ld %% 8 == 0)");
+    a.in = (const float*)in.ptr; a.out = (T*)op.out;
     YR_REQUIRE(op.se_reduced >= 1 && op.cout >= 1, "stemblock: bad widths (C1=%d, Cout=%d)", op.se_reduced, op.cout);
     const int c1p = yr_round_up(op.se_reduced, 4), cop = yr_round_up(op.cout, 8);
     YR_REQUIRE(in.ptr && op.out && op.wgt && op.wgt2 && op.b1 && op.b2, "stemblock: null pointer");
@@ -199,12 +202,14 @@ int yr_launch_stemblock(const yr_op& op, int batch, hipStream_t s) {
     a.act = op.act;
     a.tiles_x = (a.Wo + SB_T - 1) / SB_T; a.tiles_y = (a.Ho + SB_T - 1) / SB_T;
     switch (c1p / 2 * 100 + cop) {
-        case 1216: return launch_sb<12, 16>(a, batch, s);
-        case 1616: return launch_sb<16, 16>(a, batch, s);
-        case 1624: return launch_sb<16, 24>(a, batch, s);
-        case 2024: return launch_sb<20, 24>(a, batch, s);
-        case 2416: return launch_sb<24, 16>(a, batch, s);
-        case 2424: return launch_sb<24, 24>(a, batch, s);
+        case 1216: return launch_sb<12, 16, T>(a, batch, s);
+        case 1616: return launch_sb<16, 16, T>(a, batch, s);
+        case 1624: return launch_sb<16, 24, T>(a, batch, s);
+        case 2024: return launch_sb<20, 24, T>(a, batch, s);
+        case 2416: return launch_sb<24, 16, T>(a, batch, s);
+        case 2424: return launch_sb<24, 24, T>(a, batch, s);
         default: yr_set_error("stemblock: widths C1=%d Cout=%d unsupported", op.se_reduced, op.cout); return YR_ERR_ARG;
     }
 }
+
+int yr_launch_stemblock(const yr_op& op, int batch, hipStream_t s) { return YR_BY_DTYPE(op.dtype, launch_stemblock_t, op, batch, s); }

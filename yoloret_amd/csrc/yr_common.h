@@ -122,6 +122,13 @@ __device__ __forceinline__ void yr_st4(T* p, float4 v) {
         *reinterpret_cast<t4*>(p) = __builtin_convertvector((f4){v.x, v.y, v.z, v.w}, t4);
     }
 }
+// two consecutive channels (float32: 8 bytes; 16-bit: 4 bytes)
+template <class T>
+__device__ __forceinline__ void yr_st2(T* p, float x, float y) {
+    typedef T t2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<t2*>(p) = __builtin_convertvector((f2){x, y}, t2);
+}
 template <class T> __device__ __forceinline__ float yr_ld1(const T* p) { return (float)*p; }
 template <class T> __device__ __forceinline__ void yr_st1(T* p, float v) { *p = (T)v; }
 

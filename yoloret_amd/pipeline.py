@@ -52,6 +52,18 @@ class DetectionPipeline:
     def postprocess(self, ys, image_hw):
         b, dev = ys[0].shape[0], ys[0].device
         v = self._buffers(b, dev)
+        for i, y in enumerate(ys[:self.num_scales]):   # the kernels size their grids from input_hw, not from the tensors
+            g = (self.input_hw[0] // (32 >> i), self.input_hw[1] // (32 >> i))
+            if (y.dtype != torch.float32 or not y.is_contiguous() or y.device != dev or y.shape[0] != b
+                    or tuple(y.shape[1:3]) != g or y[0].numel() != g[0] * g[1] * self.num_anchors * (self.num_classes + 5)):
+                raise ValueError('postprocess: y%d %s does not match input %s, %d anchors, %d classes'
+                                 % (i + 1, tuple(y.shape), self.input_hw, self.num_anchors, self.num_classes))
+        if tuple(image_hw.shape) != (b, 2) or image_hw.dtype != torch.int32 or image_hw.device != dev:
+            raise ValueError('postprocess: image_hw must be int32 [B,2] on the logits\' device')
+        with torch.cuda.device(dev):
+            return self._postprocess(ys, image_hw, b, dev, v)
+
+    def _postprocess(self, ys, image_hw, b, dev, v):
         L, s = rt.lib(), rt.stream_ptr(dev)
         yp = [rt._ptr(ys[i]) if i < self.num_scales else None for i in range(3)]
         rt.check(L.yr_decode(yp[0], yp[1], yp[2], b, self.input_hw[0], self.input_hw[1], self.num_anchors,

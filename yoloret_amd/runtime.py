@@ -87,7 +87,7 @@ class YrBuf(ctypes.Structure):
 
 EXPORTS = ['yr_last_error', 'yr_abi_version', 'yr_abi_sizeof', 'yr_create', 'yr_destroy', 'yr_load_weights', 'yr_workspace_bytes',
            'yr_forward', 'yr_forward_profile', 'yr_autotune', 'yr_get_tuning', 'yr_set_tuning', 'yr_plan_num_launches', 'yr_op_run', 'yr_decode', 'yr_decode_zoom', 'yr_yolo_head', 'yr_correct_boxes',
-           'yr_nms', 'yr_pack_detections', 'yr_letterbox']
+           'yr_nms', 'yr_pack_detections', 'yr_letterbox', 'yr_letterbox_batch']
 
 _lib = None
 
@@ -135,6 +135,8 @@ def lib():
         L.yr_pack_detections.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3
         L.yr_letterbox.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_void_p]
+        L.yr_letterbox_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         if L.yr_abi_version() != 2:
             raise YoloretHipError('libyoloret_hip.so ABI version mismatch')
         L.yr_abi_sizeof.argtypes = [ctypes.c_int]
@@ -177,8 +179,10 @@ def make_src(t, c=None, xform='identity', ld=None):
     return s
 
 
-def run_op(op, batch):
-    check(lib().yr_op_run(ctypes.byref(op), int(batch), stream_ptr()))
+def run_op(op, batch, device=None):
+    """One fused op on `device` (default: the current device) - the tensors behind its pointers must live there."""
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        check(lib().yr_op_run(ctypes.byref(op), int(batch), stream_ptr(device)))
 
 
 def new_op(kind, act='none'):
@@ -205,8 +209,30 @@ ZOOM_RATIO = (224 * 224) / (416 * 416)     # utils.py:7: the central_crop fracti
 def decode(ys, anchors, num_classes, image_hw, input_hw, num_scales=3, zoom_ys=None):
     """ys: list of [B,G,G,A*(C+5)] (or [B,G,G,A,C+5]) logits -> boxes [B,N,4], scores [B,C,N].
     zoom_ys: the logits of the zoom-in TTA pass (model.py:408-417) -> boxes [B,2N,4], scores [B,C,2N]."""
+    if len(ys) < num_scales:
+        raise ValueError('decode: %d logit tensors for %d scales' % (len(ys), num_scales))
+    anchors = np.ascontiguousarray(np.asarray(anchors, np.float32).reshape(-1, 2))
+    if anchors.shape[0] % 3 or anchors.shape[0] == 0:
+        raise ValueError('decode: the anchor list must hold 3 scales x A anchors')
+    a_ = anchors.shape[0] // 3
+    in_h_, in_w_ = int(input_hw[0]), int(input_hw[1])
     for i, y in enumerate(ys[:num_scales]):
         _require_cuda_f32(y, 'y%d' % (i + 1))
+        # the kernel derives the grids from input_hw and the strides, not from the tensors: the shapes must agree,
+        # otherwise it would read past the end of y
+        gh, gw = in_h_ // (32 >> i), in_w_ // (32 >> i)
+        if y.dim() < 3 or tuple(y.shape[1:3]) != (gh, gw) or y[0].numel() != gh * gw * a_ * (num_classes + 5) \
+                or y.shape[0] != ys[0].shape[0] or y.device != ys[0].device:
+            raise ValueError('y%d has shape %s, expected [B=%d,%d,%d,%d*(%d+5)] for input %dx%d'
+                             % (i + 1, tuple(y.shape), ys[0].shape[0], gh, gw, a_, num_classes, in_h_, in_w_))
+    if not (isinstance(image_hw, torch.Tensor) and image_hw.dtype == torch.int32 and image_hw.is_contiguous()
+            and image_hw.device == ys[0].device and tuple(image_hw.shape) == (ys[0].shape[0], 2)):
+        raise ValueError('image_hw must be a contiguous int32 [B,2] tensor on the logits\' device (image_hw_tensor)')
+    with torch.cuda.device(ys[0].device):
+        return _decode(ys, anchors, num_classes, image_hw, input_hw, num_scales, zoom_ys)
+
+
+def _decode(ys, anchors, num_classes, image_hw, input_hw, num_scales, zoom_ys):
     if zoom_ys is not None:
         for i, (y, z) in enumerate(zip(ys[:num_scales], zoom_ys[:num_scales])):
             _require_cuda_f32(z, 'zoom y%d' % (i + 1))
@@ -224,7 +250,7 @@ def decode(ys, anchors, num_classes, image_hw, input_hw, num_scales=3, zoom_ys=N
         zp = [_ptr(zoom_ys[i]) if i < num_scales else None for i in range(3)]
         check(lib().yr_decode_zoom(yp[0], yp[1], yp[2], zp[0], zp[1], zp[2], ZOOM_MUL, ZOOM_ADD, b, in_h, in_w, a,
                                    num_classes, num_scales, anchors.ctypes.data_as(ctypes.c_void_p), _ptr(image_hw),
-                                   _ptr(boxes), _ptr(scores), stream_ptr()))
+                                   _ptr(boxes), _ptr(scores), stream_ptr(dev)))
         return boxes, scores
     b = ys[0].shape[0]
     anchors = np.ascontiguousarray(np.asarray(anchors, np.float32).reshape(-1, 2))
@@ -237,7 +263,7 @@ def decode(ys, anchors, num_classes, image_hw, input_hw, num_scales=3, zoom_ys=N
     yp = [_ptr(ys[i]) if i < num_scales else None for i in range(3)]
     check(lib().yr_decode(yp[0], yp[1], yp[2], b, in_h, in_w, a, num_classes, num_scales,
                           anchors.ctypes.data_as(ctypes.c_void_p), _ptr(image_hw), _ptr(boxes), _ptr(scores),
-                          stream_ptr()))
+                          stream_ptr(dev)))
     return boxes, scores
 
 
@@ -245,11 +271,14 @@ def nms(boxes, scores, max_boxes=20, score_threshold=.6, iou_threshold=.5):
     """boxes [B,N,4], scores [B,C,N] -> idx [B,C,max] int32 (-1 padded), count [B,C] int32."""
     _require_cuda_f32(boxes, 'boxes')
     _require_cuda_f32(scores, 'scores')
+    if scores.dim() != 3 or tuple(boxes.shape) != (scores.shape[0], scores.shape[2], 4) or boxes.device != scores.device:
+        raise ValueError('nms: boxes %s / scores %s, expected [B,N,4] / [B,C,N] on one device' % (tuple(boxes.shape), tuple(scores.shape)))
     b, c, n = scores.shape
     idx = torch.empty((b, c, max_boxes), dtype=torch.int32, device=boxes.device)
     cnt = torch.empty((b, c), dtype=torch.int32, device=boxes.device)
-    check(lib().yr_nms(_ptr(boxes), _ptr(scores), b, n, c, int(max_boxes), float(score_threshold),
-                       float(iou_threshold), _ptr(idx), _ptr(cnt), stream_ptr()))
+    with torch.cuda.device(boxes.device):
+        check(lib().yr_nms(_ptr(boxes), _ptr(scores), b, n, c, int(max_boxes), float(score_threshold),
+                           float(iou_threshold), _ptr(idx), _ptr(cnt), stream_ptr(boxes.device)))
     return idx, cnt
 
 
@@ -259,8 +288,9 @@ def pack_detections(boxes, scores, idx, cnt):
     max_boxes = idx.shape[2]
     det = torch.empty((b, c * max_boxes, 6), dtype=torch.int32, device=boxes.device)
     det_count = torch.empty((b,), dtype=torch.int32, device=boxes.device)
-    check(lib().yr_pack_detections(_ptr(boxes), _ptr(scores), _ptr(idx), _ptr(cnt), b, n, c, max_boxes,
-                                   _ptr(det), _ptr(det_count), stream_ptr()))
+    with torch.cuda.device(boxes.device):
+        check(lib().yr_pack_detections(_ptr(boxes), _ptr(scores), _ptr(idx), _ptr(cnt), b, n, c, max_boxes,
+                                       _ptr(det), _ptr(det_count), stream_ptr(boxes.device)))
     return det, det_count
 
 
@@ -279,9 +309,10 @@ def yolo_head(feats, anchors, input_hw, with_scores=False):
     conf = torch.empty((b, gh, gw, a, 1), dtype=torch.float32, device=dev)
     probs = torch.empty((b, gh, gw, a, c), dtype=torch.float32, device=dev)
     scores = torch.empty_like(probs) if with_scores else None
-    check(lib().yr_yolo_head(_ptr(feats), b, gh, gw, a, c, anchors.ctypes.data_as(ctypes.c_void_p),
-                             int(input_hw[0]), int(input_hw[1]), _ptr(xy), _ptr(wh), _ptr(conf), _ptr(probs),
-                             _ptr(scores), stream_ptr()))
+    with torch.cuda.device(dev):
+        check(lib().yr_yolo_head(_ptr(feats), b, gh, gw, a, c, anchors.ctypes.data_as(ctypes.c_void_p),
+                                 int(input_hw[0]), int(input_hw[1]), _ptr(xy), _ptr(wh), _ptr(conf), _ptr(probs),
+                                 _ptr(scores), stream_ptr(dev)))
     return (xy, wh, conf, probs, scores) if with_scores else (xy, wh, conf, probs)
 
 
@@ -291,21 +322,30 @@ def correct_boxes(box_xy, box_wh, input_hw, image_hw):
     b = box_xy.shape[0]
     n = box_xy[0].numel() // 2
     boxes = torch.empty(tuple(box_xy.shape[:-1]) + (4,), dtype=torch.float32, device=box_xy.device)
-    check(lib().yr_correct_boxes(_ptr(box_xy), _ptr(box_wh), b, n, int(input_hw[0]), int(input_hw[1]),
-                                 _ptr(image_hw), _ptr(boxes), stream_ptr()))
+    if box_wh.shape != box_xy.shape or box_wh.device != box_xy.device:
+        raise ValueError('correct_boxes: box_xy %s and box_wh %s differ' % (tuple(box_xy.shape), tuple(box_wh.shape)))
+    with torch.cuda.device(box_xy.device):
+        check(lib().yr_correct_boxes(_ptr(box_xy), _ptr(box_wh), b, n, int(input_hw[0]), int(input_hw[1]),
+                                     _ptr(image_hw), _ptr(boxes), stream_ptr(box_xy.device)))
     return boxes
 
 
 def letterbox(image_u8, input_hw, out=None):
-    """image_u8: uint8 CUDA tensor [ih,iw,3] -> float32 [H,W,3] letterboxed network input."""
+    """image_u8: uint8 CUDA tensor [ih,iw,3] -> float32 [H,W,3] letterboxed network input; a batch of equally sized
+    images [B,ih,iw,3] -> [B,H,W,3] in one launch."""
     if not (isinstance(image_u8, torch.Tensor) and image_u8.is_cuda and image_u8.dtype == torch.uint8
-            and image_u8.dim() == 3 and image_u8.shape[2] == 3 and image_u8.is_contiguous()):
-        raise ValueError('image must be a contiguous uint8 CUDA tensor [h,w,3]')
+            and image_u8.dim() in (3, 4) and image_u8.shape[-1] == 3 and image_u8.is_contiguous()):
+        raise ValueError('image must be a contiguous uint8 CUDA tensor [h,w,3] or [B,h,w,3]')
     h, w = int(input_hw[0]), int(input_hw[1])
+    batched = image_u8.dim() == 4
+    shape = ((image_u8.shape[0],) if batched else ()) + (h, w, 3)
     if out is None:
-        out = torch.empty((h, w, 3), dtype=torch.float32, device=image_u8.device)
-    check(lib().yr_letterbox(_ptr(image_u8), image_u8.shape[0], image_u8.shape[1], _ptr(out), h, w,
-                             stream_ptr(image_u8.device)))
+        out = torch.empty(shape, dtype=torch.float32, device=image_u8.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != image_u8.device:
+        raise ValueError('out must be a contiguous float32 tensor %s on the image\'s device' % (shape,))
+    with torch.cuda.device(image_u8.device):
+        check(lib().yr_letterbox_batch(_ptr(image_u8), image_u8.shape[0] if batched else 1, image_u8.shape[-3],
+                                       image_u8.shape[-2], _ptr(out), h, w, stream_ptr(image_u8.device)))
     return out
 
 

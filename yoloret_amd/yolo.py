@@ -10,8 +10,9 @@ Differences that follow from the platform, not from taste:
     /255, bilinear letterbox resize and zero padding run in the HIP letterbox kernel;
   * ``YoloModel`` also accepts a batch: a list of encoded images -> a list of per-image results
     (the reference is batch-1 only, yolo.py:84); a single image returns exactly the reference's triple;
-  * drawing (yolo.py:276-313) needs a font file the reference does not ship and is out of scope:
-    ``detect_image(..., draw=True)`` raises NotImplementedError; the export_* / video paths are not mirrored.
+  * ``detect_image(..., draw=True)`` (the reference's default, yolo.py:276-313) returns the annotated PIL image; the
+    font file the reference loads is not shipped with it, so PIL's built-in font stands in when it is absent.
+    The export_* / video paths are not mirrored.
 """
 import colorsys
 import io
@@ -170,6 +171,40 @@ class YOLO(object):
             out_classes = out_classes.cpu().numpy()
         self.last_seconds = timer() - start
         if draw:
-            raise NotImplementedError('drawing needs font/FiraMono-Medium.otf, which the reference does not ship '
-                                      '(yolo.py:278-280); call detect_image(image, draw=False)')
+            if isinstance(image, (bytes, bytearray)):
+                import io
+                image = io.BytesIO(image_data)
+            elif hasattr(image, 'seek'):
+                image.seek(0)
+            return self._draw(image, out_boxes, out_scores, out_classes)
         return out_boxes, out_scores, out_classes
+
+    def _draw(self, image, boxes, scores, classes):
+        """The annotated PIL image of yolo.py:276-313: one frame per detection in the class colour, 'name score' label
+        above the box (inside it when there is no room).  The reference loads font/FiraMono-Medium.otf, which it does
+        not ship; that file is used when present, PIL's built-in font otherwise."""
+        from PIL import Image, ImageDraw, ImageFont
+        img = Image.open(image).convert('RGB')
+        size = int(np.floor(3e-2 * img.size[1] + 0.5))
+        try:
+            font = ImageFont.truetype('font/FiraMono-Medium.otf', size=size)
+        except OSError:
+            font = ImageFont.load_default()
+        pen = ImageDraw.Draw(img)
+        width = max(1, (img.size[0] + img.size[1]) // 300)
+        for i in reversed(range(len(classes))):
+            c = classes[i]
+            if self.with_classes:
+                c = self.class_names.index(c.decode('utf-8') if isinstance(c, bytes) else str(c))
+            c = int(c)
+            text = '%s %.2f' % (self.class_names[c], float(scores[i]))
+            top, left, bottom, right = [int(v) for v in boxes[i]]
+            x0, y0, x1, y1 = pen.textbbox((0, 0), text, font=font)
+            tw, th = x1 - x0, y1 - y0
+            ty = top - th if top - th >= 0 else top + 1
+            for t in range(width):
+                if right - t >= left + t and bottom - t >= top + t:
+                    pen.rectangle([left + t, top + t, right - t, bottom - t], outline=self.colors[c])
+            pen.rectangle([left, ty, left + tw, ty + th], fill=self.colors[c])
+            pen.text((left, ty), text, fill=(0, 0, 0), font=font)
+        return img
