@@ -128,6 +128,46 @@ def non_max_suppression(boxes, scores, max_output_size, iou_threshold, score_thr
     return np.asarray(picked, np.int32)
 
 
+def nms_decision_margin(boxes, scores, max_output_size, iou_threshold, score_threshold):
+    """``non_max_suppression`` plus the smallest MARGIN of any decision that shaped its result: the
+    score gap between a popped candidate and the runner-up (ordering), the distance of an evaluated IoU from the IoU
+    threshold, the distance of a score from the score threshold.  Only candidates that were reachable count: when the
+    loop ends with max_output_size picks, boxes scoring below the last pick can neither be picked nor change a pick,
+    whatever side of a threshold they are on.  Two runs whose scores / IoUs differ by less than the margin take the
+    same decisions and return the same picks; a disagreement on a problem whose margin exceeds the numerical noise of
+    its inputs is a real error.  -> (picks int32, margin float)."""
+    boxes = np.asarray(boxes, np.float32)
+    key = np.asarray(scores, np.float32).copy()
+    thr = float(F(score_threshold))
+    alive = key > F(score_threshold)
+    picked, order_margin, iou_steps = [], np.inf, []
+    while len(picked) < max_output_size and alive.any():
+        masked = np.where(alive, key, -np.inf)
+        i = int(np.argmax(masked))
+        masked[i] = -np.inf
+        runner = float(masked.max())
+        if np.isfinite(runner):
+            order_margin = min(order_margin, float(key[i]) - runner)   # 0 for exact ties (broken by index in every run)
+        picked.append(i)
+        alive[i] = False
+        idx = np.nonzero(alive)[0]
+        if idx.size:
+            iou = iou_one_to_many(boxes[i], boxes[idx])
+            iou_steps.append((key[idx].copy(), np.abs(iou.astype(np.float64) - float(F(iou_threshold)))))
+            alive[idx[iou > F(iou_threshold)]] = False
+    # candidates that could have been reached: everything when the list ran dry, else those scoring >= the last pick
+    floor = float(key[picked[-1]]) if len(picked) >= max_output_size else -np.inf
+    margin = order_margin
+    reach = key >= floor
+    if reach.any():
+        margin = min(margin, float(np.min(np.abs(key[reach].astype(np.float64) - thr))))
+    for sc, d in iou_steps:
+        m = sc >= floor
+        if m.any():
+            margin = min(margin, float(d[m].min()))
+    return np.asarray(picked, np.int32), margin
+
+
 def nms_bruteforce(boxes, scores, max_output_size, iou_threshold, score_threshold):
     """Line-by-line form of the TF kernel's loop (pop best; test against the
     already-selected, most recent first).  O(N*K) Python; small cases only -

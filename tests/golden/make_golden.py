@@ -9,6 +9,11 @@ What the fixtures are (data only - inputs and expected outputs):
                          tf_padding=True), loaded with the oracle's seeded weights.  This is the only
                          executable cross-check available for the third-party part of the graph
                          (tf.keras.applications.MobileNetV2 is not in /root/reference; TensorFlow is absent).
+  backbone_effnet_hf.npz The same for the EfficientNet-B0 / -B3 backbone (SE + Swish MBConv, reference
+                         code/yolo3/efficientnet.py:406-536,611-710): ends of stages 2/3/5/6 from `transformers`'
+                         EfficientNetModel with the oracle's weights.  Pins the oracle's reading of efficientnet.py
+                         (block order, SE width, padding, BN epsilon, repeats/width rounding) against a second,
+                         unrelated implementation of the published architecture.
   detector_tiny.npz      End-to-end logits + detections of the NumPy oracle for a 64x64 MobileNetV2x0.75
                          detector (labelled: oracle = this repo's CPU restatement, NOT TensorFlow).
   nms_cases.npz          Boxes/scores with ties / degenerate boxes and the line-by-line TF-loop picks.
@@ -66,7 +71,70 @@ def hf_mobilenetv2_taps(P, x, alpha):
     return {b: hs[b - 1].permute(0, 2, 3, 1).numpy() for b in (2, 5, 12, 15)}
 
 
+def hf_efficientnet_taps(P, x, width, depth):
+    """Ends of stages 2/3/5/6 (the taps of reference code/yolo3/model.py:213-216) from the `transformers` EfficientNet
+    port - an implementation of the published architecture that shares nothing with oracle/model.py or with the
+    reference's efficientnet.py - fed with the oracle's parameters.  Input sizes must keep every stride-2 layer's
+    input even: the port pads stride-2 convs Keras-applications style, which equals TF 'SAME' only then."""
+    import math
+    import torch
+    from transformers import EfficientNetConfig, EfficientNetModel
+    cfg = EfficientNetConfig(width_coefficient=width, depth_coefficient=depth, hidden_dim=om.round_filters(1280, width),
+                             batch_norm_eps=1e-3, hidden_act='swish')
+    m = EfficientNetModel(cfg).eval()
+    sd = m.state_dict()
+
+    def conv(dst, name, dw=False):
+        if dw:
+            k = P.values[name + '/depthwise_kernel']            # [k,k,C]
+            sd[dst + '.weight'] = torch.from_numpy(k).permute(2, 0, 1).unsqueeze(1).contiguous()
+        else:
+            k = P.values[name + '/kernel']                      # HWIO
+            sd[dst + '.weight'] = torch.from_numpy(k).permute(3, 2, 0, 1).contiguous()
+        if name + '/bias' in P.values and not dw:
+            sd[dst + '.bias'] = torch.from_numpy(P.values[name + '/bias'])
+
+    def bn(dst, name):
+        sd[dst + '.weight'] = torch.from_numpy(P.values[name + '/gamma'])
+        sd[dst + '.bias'] = torch.from_numpy(P.values[name + '/beta'])
+        sd[dst + '.running_mean'] = torch.from_numpy(P.values[name + '/moving_mean'])
+        sd[dst + '.running_var'] = torch.from_numpy(P.values[name + '/moving_variance'])
+
+    conv('embeddings.convolution', 'stem_conv'); bn('embeddings.batchnorm', 'stem_BN')
+    blk, ends = 0, {}
+    for si, (r, k, s_, e, i, o, se) in enumerate(om.EFFNET_STAGES[:6], start=1):
+        for rep in range(int(math.ceil(depth * r))):
+            name, dst = 'stage%d_block%d' % (si, rep), 'encoder.blocks.%d' % blk
+            if e != 1:
+                conv(dst + '.expansion.expand_conv', name + '_expand'); bn(dst + '.expansion.expand_bn', name + '_expand_BN')
+            conv(dst + '.depthwise_conv.depthwise_conv', name + '_dw', True); bn(dst + '.depthwise_conv.depthwise_norm', name + '_dw_BN')
+            conv(dst + '.squeeze_excite.reduce', name + '_se_reduce'); conv(dst + '.squeeze_excite.expand', name + '_se_expand')
+            conv(dst + '.projection.project_conv', name + '_project'); bn(dst + '.projection.project_bn', name + '_project_BN')
+            blk += 1
+        ends[si] = blk     # hidden_states[blk] = output of the stage's last block
+    missing = [k for k in m.state_dict() if k not in sd]
+    assert not missing
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        hs = m(torch.from_numpy(x).permute(0, 3, 1, 2), output_hidden_states=True).hidden_states
+    return {si: hs[ends[si]].permute(0, 2, 3, 1).numpy() for si in (2, 3, 5, 6)}
+
+
 def main():
+    out = {}
+    for key, tag in (('efficientnet-b0', 'b0'), ('efficientnet-b3', 'b3')):
+        width, depth = om.EFFNET_COEFFS[key]
+        P = params.ParamStore(1234)
+        x = params.synthetic_images(2, 64, 96, seed=7)
+        acts = om.efficientnet(P, x, width, depth)      # creates the seeded parameters
+        hf = hf_efficientnet_taps(P, x, width, depth)
+        for si in (2, 3, 5, 6):
+            d = float(np.abs(hf[si] - acts['stage%d' % si]).max())
+            print('EfficientNet-%s stage%d: HF port vs oracle max |diff| = %.2e  shape %s' % (tag.upper(), si, d, hf[si].shape))
+            assert d < 1e-4
+            out['%s_stage%d' % (tag, si)] = hf[si].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, 'backbone_effnet_hf.npz'), **out)
+
     out = {}
     for alpha, tag in ((0.75, 'x75'), (1.4, 'x14')):
         P = params.ParamStore(1234)

@@ -69,3 +69,19 @@ def test_hip_path_reproduces_detector_fixture(dev):
     idx, cnt = rt.nms(zb.contiguous(), zs.contiguous(), 20, 0.2, 0.5)
     picks = np.load(os.path.join(G, 'nms_cases.npz'))['picks']
     assert idx[0, 0, :int(cnt[0, 0])].cpu().tolist() == picks.tolist()
+
+
+def test_oracle_efficientnet_matches_independent_port():
+    """EfficientNet-B0 / -B3 stage ends (the detection taps) of the oracle against the activations an unrelated
+    implementation of the published architecture (`transformers` EfficientNetModel) produced from the same weights
+    (tests/golden/make_golden.py: hf_efficientnet_taps)."""
+    z = np.load(os.path.join(G, 'backbone_effnet_hf.npz'))
+    for key, tag in (('efficientnet-b0', 'b0'), ('efficientnet-b3', 'b3')):
+        width, depth = om.EFFNET_COEFFS[key]
+        P = params.ParamStore(1234)
+        x = params.synthetic_images(2, 64, 96, seed=7)
+        acts = om.efficientnet(P, x, width, depth)
+        for si in (2, 3, 5, 6):
+            ref = z['%s_stage%d' % (tag, si)]
+            assert acts['stage%d' % si].shape == ref.shape
+            assert np.abs(acts['stage%d' % si] - ref).max() < 1e-5
