@@ -174,6 +174,20 @@ int yr_abi_sizeof(int which);
  * yolov3_body (model.py:170-342; called at yolo.py:152, map.py:111). */
 int yr_create(const yr_op* ops, int n_ops, const yr_buf* bufs, int n_bufs, yr_handle** out);
 void yr_destroy(yr_handle* h);
+/* ---- the same from ONE self-contained byte blob (yoloret_amd: Model.save_plan(); layout below): op list, buffer
+ * table, parameter blob and the autotuned tile tables of a compiled model.  A host without the Python graph compiler
+ * (C, C++, Go/cgo, JNI ...) instantiates "MobileNetV2x0.75 @416, bf16" from a file with this one call: the handle
+ * comes back with its weights on the device and its tile tables installed.  Replaces yolov3_body + load_weights
+ * (model.py:170-342, yolo.py:82-87) for deployments.  All fields little-endian:
+ *   char magic[8] = "YRPLAN\0\0"; u32 abi (= YR_ABI_VERSION); u32 n_ops; u32 n_bufs; u32 sizeof(yr_op);
+ *   u32 sizeof(yr_buf); u32 n_tables; u64 n_weight_floats; i32 in_h, in_w; i32 out_hwc[3][3] (y1, y2, y3: h, w, c);
+ *   i32 reserved[3];   -- 96 bytes
+ *   yr_op ops[n_ops] (pointer fields zero); yr_buf bufs[n_bufs]; float weights[n_weight_floats];
+ *   n_tables x { i32 batch; i32 cfg[n_ops]; }   (yr_set_tuning tables) */
+int yr_create_from_blob(const void* blob, size_t bytes, yr_handle** out);
+/* Input / output geometry of a handle made by yr_create_from_blob (YR_ERR_STATE for other handles):
+ * in_hw[2] = network input (h, w); out_hwc[9] = (h, w, c) of y1, y2, y3 (c = A*(C+5), dense). */
+int yr_plan_io_dims(const yr_handle* h, int32_t* in_hw, int32_t* out_hwc);
 /* Copies the flat fp32 parameter blob (host) to the device; owned by the handle.
  * Replaces tf.keras.Model.load_weights (yolo.py:87) once weights are in blob order. */
 int yr_load_weights(yr_handle* h, const float* host_blob, size_t n_floats);

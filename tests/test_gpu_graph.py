@@ -309,3 +309,51 @@ def test_c2_batch64_properties(dev):
         gb, gs, gc = [t.cpu().numpy() for t in res[i]]
         ob, os_, oc, _ = cpost.yolo_eval([y[i].cpu().numpy() for y in ys], ANCHORS, 3, 20, hw, 20, 0.2, 0.5)
         assert np.array_equal(gb, ob) and np.array_equal(gs, os_) and np.array_equal(gc, oc)
+
+
+def test_plan_blob_round_trip(dev, tmp_path):
+    """Model.save_plan() -> yr_create_from_blob in a fresh process that never imports the graph compiler: same
+    logits bit for bit, tile tables included (the recipe a non-Python host follows)."""
+    import subprocess
+    import sys
+    from yoloret_amd import runtime as rt
+    m, P = _build('mobilenetv2x75', (96, 96), 20)
+    x = params.synthetic_images(3, 96, 96)
+    om.yolov3_body(P, x[:1], 'mobilenetv2x75', 3, 20)
+    m.set_weights(P.values)
+    want = [y.cpu().numpy() for y in m(torch.from_numpy(x).to(dev))]      # autotunes batch 3
+    blob_path, x_path, out_path = tmp_path / 'model.yrplan', tmp_path / 'x.npy', tmp_path / 'out.npz'
+    data = m.save_plan(str(blob_path))
+    np.save(x_path, x)
+    import struct
+    n_tables = struct.unpack_from('<I', data, 8 + 5 * 4)[0]
+    assert data[:8] == rt.PLAN_MAGIC and n_tables == 1
+    code = ('import sys, numpy as np, torch\n'
+            'from yoloret_amd import runtime as rt\n'
+            'h = rt.PlanHandle(open(sys.argv[1], "rb").read())\n'
+            'assert h.input_hw == (96, 96) and [c for _, _, c in h.output_hwc] == [75, 75, 75]\n'
+            'ys = h(torch.from_numpy(np.load(sys.argv[2])).cuda())\n'
+            'torch.cuda.synchronize()\n'
+            'assert "yoloret_amd.compiler" not in sys.modules and "yoloret_amd.engine" not in sys.modules\n'
+            'np.savez(sys.argv[3], *[y.cpu().numpy() for y in ys])\n')
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, '-c', code, str(blob_path), str(x_path), str(out_path)], cwd=root)
+    z = np.load(out_path)
+    for i, w in enumerate(want):
+        assert np.array_equal(z['arr_%d' % i], w)
+    # a 16-bit plan travels the same way
+    from yoloret_amd import layers as L
+    from yoloret_amd.yolo3.model import yolov3_body
+    L.set_global_policy('mixed_bfloat16')
+    try:
+        m16 = yolov3_body(L.Input(shape=[96, 96, 3]), 'efficientnetb0', 3, num_classes=20)
+    finally:
+        L.set_global_policy('float32')
+    from yoloret_amd.weights import synthetic_weights
+    m16.set_weights(synthetic_weights(m16, 3, 'conditioned'))
+    xd = torch.from_numpy(x).to(dev)
+    want16 = [y.cpu().numpy() for y in m16(xd)]
+    h = rt.PlanHandle(m16.save_plan())
+    for a, w in zip(h(xd), want16):
+        assert np.array_equal(a.cpu().numpy(), w)

@@ -132,3 +132,28 @@ def test_yolomodel_zoom_in_tta(dev):
     assert np.array_equal(classes.cpu().numpy(), oc) and len(oc) > 0
     plain = ym.call([_png(img)])   # the default path still runs on the same object afterwards
     assert plain[0].dtype == torch.int32 and plain[0].shape[1] == 4
+
+
+def test_yolo_facade_loads_keras_h5(dev, tmp_path):
+    """YOLO({'model': 'x.h5'}) - the reference's own way of restoring a detector (yolo.py:87) - gives the same
+    detections as the parameters the checkpoint was written from."""
+    import subprocess
+    from tests.test_h5 import CONDA, MBV2_NAMED, ROOT, _has_h5py, _layers_json
+    if not _has_h5py():
+        pytest.skip('needs the conda interpreter with h5py to WRITE the checkpoint (the product reads it itself)')
+    import os
+    from yoloret_amd.yolo import YOLO
+    from yoloret_amd.yolo3.enums import BACKBONE
+    flags = {'input_size': (96, 96), 'backbone': BACKBONE.MOBILENETV2x75, 'score': 0.2, 'nms': 0.5}
+    a = YOLO(dict(flags, model='synthetic:7'))
+    m = a.yolo_model.model
+    np.savez(tmp_path / 'w.npz', **m.get_weights())
+    _layers_json(m, tmp_path / 'layers.json', MBV2_NAMED)
+    subprocess.check_call([CONDA, os.path.join(ROOT, 'tools', 'make_keras_h5.py'), str(tmp_path / 'w.npz'),
+                           str(tmp_path / 'layers.json'), str(tmp_path / 'ckpt.h5'), '--gap-every', '7'])
+    b = YOLO(dict(flags, model=str(tmp_path / 'ckpt.h5')))
+    img = np.random.default_rng(3).integers(0, 256, (80, 120, 3), dtype=np.uint8)
+    ra, rb = a.detect_image(_png(img), draw=False), b.detect_image(_png(img), draw=False)
+    assert len(ra[0]) > 0
+    for x, y in zip(ra, rb):
+        assert np.array_equal(x, y)

@@ -226,3 +226,25 @@ def test_central_crop_matches_tf_rule():
     assert abs(rt.ZOOM_RATIO - 0.2899) < 1e-4 and abs(rt.ZOOM_MUL - 224 / 416) < 1e-7
     with pytest.raises(ValueError):
         central_crop(img, 0.0)
+
+
+def test_serialised_plan_is_validated():
+    """yr_create_from_blob refuses anything that is not a plan of this ABI (no GPU needed: the checks come first)."""
+    from yoloret_amd import layers as L, runtime as rt, weights as W
+    from yoloret_amd.yolo3.model import yolov3_body
+    m = yolov3_body(L.Input(shape=[64, 64, 3]), 'mobilenetv2x75', 3, num_classes=20)
+    m.set_weights(W.synthetic_weights(m, 1, 'conditioned'))
+    data = m.save_plan()
+    assert data[:8] == rt.PLAN_MAGIC and len(data) > 96
+    lib = rt.lib()
+    h = ctypes.c_void_p()
+
+    def load(b):
+        buf = (ctypes.c_char * len(b)).from_buffer_copy(b)
+        return lib.yr_create_from_blob(buf, len(b), ctypes.byref(h))
+    assert load(b'NOTAPLAN' + data[8:]) == -1 and b'magic' in lib.yr_last_error()
+    assert load(data[:-4]) == -1 and b'bytes' in lib.yr_last_error()
+    bad_abi = bytearray(data)
+    bad_abi[8] = 1
+    assert load(bytes(bad_abi)) == -1 and b'ABI' in lib.yr_last_error()
+    assert load(data[:50]) == -1

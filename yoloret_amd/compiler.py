@@ -580,6 +580,7 @@ class Compiler:
         self.ops = []
         self.values = {}       # Tensor -> Value
         self.param_shapes = {}
+        self.layer_seq = {}    # layer name -> creation sequence number (layers with parameters, reachable from the outputs)
         self.consumers = {}
 
     # ---------------------------------------------------------------- graph utilities
@@ -703,6 +704,8 @@ class Compiler:
         order = self._topo()
         for n in order:
             self.param_shapes.update(n.params)
+            if n.params:
+                self.layer_seq[n.name] = n.seq
         x = self.inputs
         h, w, c = x.shape
         in_buf = self._new_buf(h, w, c, ld=c, external_slot=0, name='images')
@@ -735,7 +738,9 @@ class Compiler:
             ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency, dtype=self.dtype)
             if FOLD_DW and not latency and self.dtype == 0:
                 ops = fold_depthwise_into_project(ops, set(b.id for b in outs))
-        return Plan(ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape, self.dtype)
+        plan = Plan(ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape, self.dtype)
+        plan.layer_seq = dict(self.layer_seq)
+        return plan
 
     def _lower_conv2d(self, n, done):
         x = n.inputs[0]

@@ -58,6 +58,8 @@ struct yr_handle {
     size_t n_weights = 0;
     std::map<int, std::vector<int>> tuned;  // batch -> per-op pointwise tile choice (1-based, 0 = heuristic)
     int device = 0;
+    int32_t in_hw[2] = {0, 0};              // yr_create_from_blob only
+    int32_t out_hwc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 extern "C" int yr_create(const yr_op* ops, int n_ops, const yr_buf* bufs, int n_bufs, yr_handle** out) {
@@ -95,6 +97,71 @@ extern "C" int yr_create(const yr_op* ops, int n_ops, const yr_buf* bufs, int n_
         }
     }
     *out = h;
+    return YR_OK;
+}
+
+// Header of a serialised plan (include/yoloret_hip.h: yr_create_from_blob).
+struct yr_blob_header {
+    char magic[8];
+    uint32_t abi, n_ops, n_bufs, sizeof_op, sizeof_buf, n_tables;
+    uint64_t n_weight_floats;
+    int32_t in_h, in_w;
+    int32_t out_hwc[9];
+    int32_t reserved[3];
+};
+static_assert(sizeof(yr_blob_header) == 96, "serialised plan header is 96 bytes");
+
+extern "C" int yr_create_from_blob(const void* blob, size_t bytes, yr_handle** out) {
+    YR_REQUIRE(blob && out && bytes >= sizeof(yr_blob_header), "yr_create_from_blob: bad arguments");
+    yr_blob_header hd;
+    memcpy(&hd, blob, sizeof(hd));
+    YR_REQUIRE(memcmp(hd.magic, "YRPLAN\0\0", 8) == 0, "yr_create_from_blob: not a serialised plan (bad magic)");
+    YR_REQUIRE(hd.abi == YR_ABI_VERSION && hd.sizeof_op == sizeof(yr_op) && hd.sizeof_buf == sizeof(yr_buf),
+               "yr_create_from_blob: plan written for ABI %u (yr_op %u bytes, yr_buf %u bytes); this library is ABI %d (%zu, %zu)",
+               hd.abi, hd.sizeof_op, hd.sizeof_buf, YR_ABI_VERSION, sizeof(yr_op), sizeof(yr_buf));
+    const size_t need = sizeof(hd) + (size_t)hd.n_ops * sizeof(yr_op) + (size_t)hd.n_bufs * sizeof(yr_buf) +
+                        (size_t)hd.n_weight_floats * sizeof(float) + (size_t)hd.n_tables * (1 + (size_t)hd.n_ops) * sizeof(int32_t);
+    YR_REQUIRE(hd.n_ops > 0 && hd.n_bufs > 0 && hd.n_weight_floats > 0 && bytes == need,
+               "yr_create_from_blob: %zu bytes, the header describes %zu", bytes, need);
+    const char* p = static_cast<const char*>(blob) + sizeof(hd);
+    std::vector<yr_op> ops(hd.n_ops);
+    std::vector<yr_buf> bufs(hd.n_bufs);
+    memcpy(ops.data(), p, ops.size() * sizeof(yr_op));
+    p += ops.size() * sizeof(yr_op);
+    memcpy(bufs.data(), p, bufs.size() * sizeof(yr_buf));
+    p += bufs.size() * sizeof(yr_buf);
+    for (yr_op& op : ops) {   // a file must not smuggle pointers in
+        for (int i = 0; i < YR_MAX_SRC; ++i) op.src[i].ptr = nullptr;
+        op.out = nullptr; op.res = nullptr; op.gate = nullptr;
+        op.wgt = op.scale = op.shift = op.wgt2 = op.b1 = op.b2 = nullptr;
+        const int64_t offs[6] = {op.wgt_off, op.scale_off, op.shift_off, op.wgt2_off, op.b1_off, op.b2_off};
+        for (int64_t o : offs) YR_REQUIRE(o < (int64_t)hd.n_weight_floats, "yr_create_from_blob: parameter offset outside the weight blob");
+    }
+    yr_handle* h = nullptr;
+    int rc = yr_create(ops.data(), (int)ops.size(), bufs.data(), (int)bufs.size(), &h);
+    if (rc) return rc;
+    std::vector<float> w(hd.n_weight_floats);
+    memcpy(w.data(), p, w.size() * sizeof(float));
+    p += w.size() * sizeof(float);
+    rc = yr_load_weights(h, w.data(), w.size());
+    for (uint32_t t = 0; rc == YR_OK && t < hd.n_tables; ++t) {
+        std::vector<int32_t> tab(1 + hd.n_ops);
+        memcpy(tab.data(), p, tab.size() * sizeof(int32_t));
+        p += tab.size() * sizeof(int32_t);
+        rc = yr_set_tuning(h, tab[0], tab.data() + 1, (int)hd.n_ops);
+    }
+    if (rc) { yr_destroy(h); return rc; }
+    h->in_hw[0] = hd.in_h; h->in_hw[1] = hd.in_w;
+    memcpy(h->out_hwc, hd.out_hwc, sizeof(h->out_hwc));
+    *out = h;
+    return YR_OK;
+}
+
+extern "C" int yr_plan_io_dims(const yr_handle* h, int32_t* in_hw, int32_t* out_hwc) {
+    YR_REQUIRE(h && in_hw && out_hwc, "yr_plan_io_dims: null argument");
+    if (h->in_hw[0] == 0) { yr_set_error("yr_plan_io_dims: the handle was not created from a serialised plan"); return YR_ERR_STATE; }
+    memcpy(in_hw, h->in_hw, sizeof(h->in_hw));
+    memcpy(out_hwc, h->out_hwc, sizeof(h->out_hwc));
     return YR_OK;
 }
 

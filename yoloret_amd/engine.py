@@ -76,12 +76,41 @@ class Model:
         return dict(self._weights) if self._weights is not None else None
 
     def load_weights(self, path):
-        """Loads an ``.npz`` written by ``save_weights`` (name -> array).  Keras HDF5
-        checkpoints (reference code/yolo.py:87) need the offline converter - SURVEY.md 8(f)-2."""
-        if str(path).endswith('.h5'):
-            raise NotImplementedError('Keras HDF5 import is not available (no h5py); convert to .npz')
+        """reference code/yolo.py:87 ``self.model.load_weights(self.model_path)``: a Keras weights-only HDF5 checkpoint
+        (``*.h5`` / ``*.hdf5`` / ``*.keras.h5``; read by yoloret_amd.h5lite, layers matched as yoloret_amd.keras_h5
+        describes), or an ``.npz`` written by ``save_weights`` (parameter name -> array)."""
+        with open(path, 'rb') as f:
+            magic = f.read(8)
+        if magic == b'\x89HDF\r\n\x1a\n':
+            from .keras_h5 import load_keras_h5
+            self.set_weights(load_keras_h5(self, path))
+            return
         with np.load(path) as z:
             self.set_weights({k: z[k] for k in z.files})
+
+    def save_plan(self, path=None, batch=None):
+        """The compiled model as ONE self-contained byte blob for yr_create_from_blob (include/yoloret_hip.h): fused
+        op list, buffer table, parameter blob and every tile table autotuned so far.  A host without this Python
+        package instantiates the model from the file.  batch: which plan variant (None: the
+        throughput plan).  Returns the bytes; also written to `path` when given."""
+        variant = 'throughput' if batch is None else self.variant(batch)
+        plan = self._plans.get(variant) or self.plan_for(batch)
+        blob = self._blob_of(variant)
+        ops, bufs = plan.c_arrays()
+        tuning = {}
+        for (idx, v), h in self._handles.items():
+            if v != variant:
+                continue
+            for (i2, b) in self._tuned:
+                if i2 == idx and self.variant(b) == variant:
+                    arr = (ctypes.c_int32 * len(plan.ops))()
+                    if rt.lib().yr_get_tuning(h, b, arr, len(plan.ops)) == 0:
+                        tuning[b] = list(arr)
+        data = rt.pack_plan(ops, bufs, blob, plan.input_shape[:2], [(ob.h, ob.w, ob.c) for ob in plan.output_bufs], tuning)
+        if path is not None:
+            with open(path, 'wb') as f:
+                f.write(data)
+        return data
 
     def save_weights(self, path):
         if self._weights is None:

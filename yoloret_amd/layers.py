@@ -55,7 +55,8 @@ class Node:
         self.inputs = list(inputs)
         self.attrs = dict(attrs or {})
         self.params = dict(params or {})   # param name -> shape
-        self.name = name or ('%s_%d' % (op, next(_uid)))
+        self.seq = next(_uid)              # creation order (what Keras' automatic layer names are numbered by)
+        self.name = name or ('%s_%d' % (op, self.seq))
         self.output = Tensor(output_shape, self, self.name + ':0')
 
 

@@ -85,7 +85,7 @@ class YrBuf(ctypes.Structure):
                 ('external_slot', ctypes.c_int32), ('dtype', ctypes.c_int32)]
 
 
-EXPORTS = ['yr_last_error', 'yr_abi_version', 'yr_abi_sizeof', 'yr_create', 'yr_destroy', 'yr_load_weights', 'yr_workspace_bytes',
+EXPORTS = ['yr_last_error', 'yr_abi_version', 'yr_abi_sizeof', 'yr_create', 'yr_create_from_blob', 'yr_plan_io_dims', 'yr_destroy', 'yr_load_weights', 'yr_workspace_bytes',
            'yr_forward', 'yr_forward_profile', 'yr_autotune', 'yr_get_tuning', 'yr_set_tuning', 'yr_plan_num_launches', 'yr_op_run', 'yr_decode', 'yr_decode_zoom', 'yr_yolo_head', 'yr_correct_boxes',
            'yr_nms', 'yr_pack_detections', 'yr_letterbox', 'yr_letterbox_batch']
 
@@ -110,6 +110,8 @@ def lib():
         L.yr_workspace_bytes.restype = ctypes.c_size_t
         L.yr_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.yr_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.yr_create_from_blob.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.yr_plan_io_dims.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.yr_destroy.argtypes = [ctypes.c_void_p]
         L.yr_destroy.restype = None
         L.yr_load_weights.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
@@ -360,3 +362,68 @@ def image_hw_tensor(image_shape, batch, device):
     if t.shape[0] != batch:
         raise ValueError('image_shape must be (h,w) or one (h,w) per image')
     return t.contiguous()
+
+
+# ----------------------------------------------------------------------------- serialised plans
+PLAN_MAGIC = b'YRPLAN\0\0'
+
+
+def pack_plan(ops, bufs, weights, in_hw, out_hwc, tuning=None):
+    """ctypes YrOp / YrBuf arrays + float32 parameter blob (+ {batch: [cfg per op]}) -> the byte blob
+    yr_create_from_blob reads (layout: include/yoloret_hip.h)."""
+    import struct
+    tuning = tuning or {}
+    weights = np.ascontiguousarray(weights, np.float32)
+    head = PLAN_MAGIC + struct.pack('<6IQ2i9i3i', 2, len(ops), len(bufs), ctypes.sizeof(YrOp), ctypes.sizeof(YrBuf),
+                                    len(tuning), weights.size, int(in_hw[0]), int(in_hw[1]),
+                                    *[int(v) for hwc in out_hwc for v in hwc], 0, 0, 0)
+    assert len(head) == 96
+    parts = [head, bytes(ops), bytes(bufs), weights.tobytes()]
+    for batch in sorted(tuning):
+        tab = np.asarray([batch] + list(tuning[batch]), np.int32)
+        assert tab.size == 1 + len(ops)
+        parts.append(tab.tobytes())
+    return b''.join(parts)
+
+
+class PlanHandle:
+    """A model instantiated from a serialised plan through yr_create_from_blob - nothing of the graph compiler is
+    involved (what a C / C++ / cgo / JNI host does; this class is the ctypes rendition of INTEGRATION.md's recipe).
+    __call__(images [B,H,W,3] float32 CUDA) -> [y1, y2, y3] raw logits [B,G,G,A*(C+5)]."""
+
+    def __init__(self, blob, device=None):
+        blob = bytes(blob) if not isinstance(blob, (bytes, bytearray)) else blob
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self._h = ctypes.c_void_p()
+        buf = (ctypes.c_char * len(blob)).from_buffer_copy(blob)
+        with torch.cuda.device(self.device):
+            check(lib().yr_create_from_blob(buf, len(blob), ctypes.byref(self._h)))
+        in_hw = (ctypes.c_int32 * 2)()
+        out = (ctypes.c_int32 * 9)()
+        check(lib().yr_plan_io_dims(self._h, in_hw, out))
+        self.input_hw = (in_hw[0], in_hw[1])
+        self.output_hwc = [tuple(out[3 * i:3 * i + 3]) for i in range(3)]
+        self._ws = None
+
+    def __call__(self, x):
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                and tuple(x.shape[1:]) == self.input_hw + (3,)):
+            raise ValueError('input must be a float32 CUDA tensor [B,%d,%d,3]' % self.input_hw)
+        x = x.contiguous()
+        b = x.shape[0]
+        L = lib()
+        with torch.cuda.device(x.device):
+            need = L.yr_workspace_bytes(self._h, b)
+            if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+                self._ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+            ys = [torch.empty((b,) + hwc, dtype=torch.float32, device=x.device) for hwc in self.output_hwc]
+            check(L.yr_forward(self._h, _ptr(x), b, _ptr(ys[0]), _ptr(ys[1]), _ptr(ys[2]), _ptr(self._ws),
+                               self._ws.numel(), stream_ptr(x.device)))
+        return ys
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().yr_destroy(self._h)
+        except Exception:
+            pass
