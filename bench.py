@@ -147,15 +147,23 @@ def main():
     L.set_global_policy({'f32': 'float32', 'bf16': 'mixed_bfloat16', 'f16': 'mixed_float16'}[a.dtype])
     model = yolov3_body(L.Input(shape=[a.size, a.size, 3]), a.model, 3, num_classes=a.classes)
     model.set_weights(W.synthetic_weights(model, 1234, 'survey'))
-    pipe = DetectionPipeline(model, anchors, a.classes, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5)
+    pipe = DetectionPipeline(model, anchors, a.classes, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5,
+                             record_slots=2 if use_dist else 1)
     gather = DetectionGatherer(always=a.force_dist)
     b = a.batch
     x = torch.from_numpy(W.synthetic_images(b, a.size, a.size, seed=20240416 + rank)).to(dev)
     image_hw = torch.tensor([[a.size, a.size]] * b, dtype=torch.int32, device=dev)
 
+    pending = [None]
+
     def step():
+        # N > 1: the all-gather of step i's records runs on a second stream while step i+1's forward is enqueued; its
+        # handle is waited for one step later (the final sync() covers the last one).  Every step still contains
+        # exactly one collective.
         det, cnt = pipe(x, image_hw)
-        return gather(det, cnt, pipe.record)
+        h = gather.start(det, cnt, pipe.record)
+        prev, pending[0] = pending[0], h
+        return prev.wait() if prev is not None else None
 
     def sync():
         torch.cuda.synchronize(dev)

@@ -340,8 +340,8 @@ def test_plan_blob_round_trip(dev, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call([sys.executable, '-c', code, str(blob_path), str(x_path), str(out_path)], cwd=root)
     z = np.load(out_path)
-    for i, w in enumerate(want):
-        assert np.array_equal(z['arr_%d' % i], w)
+    for i, w in enumerate(want):     # the C-ABI's logits are [B,G,G,A*(C+5)]; Model.__call__ views them as [B,G,G,A,C+5]
+        assert np.array_equal(z['arr_%d' % i].reshape(w.shape), w)
     # a 16-bit plan travels the same way
     from yoloret_amd import layers as L
     from yoloret_amd.yolo3.model import yolov3_body
@@ -356,4 +356,4 @@ def test_plan_blob_round_trip(dev, tmp_path):
     want16 = [y.cpu().numpy() for y in m16(xd)]
     h = rt.PlanHandle(m16.save_plan())
     for a, w in zip(h(xd), want16):
-        assert np.array_equal(a.cpu().numpy(), w)
+        assert np.array_equal(a.cpu().numpy().reshape(w.shape), w)

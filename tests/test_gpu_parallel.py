@@ -1,0 +1,72 @@
+"""The N>1 exchange on real hardware with ONE rank: an RCCL ('nccl' backend) process group of world size 1, the
+all-gather of the detection records issued for real (DetectionGatherer(always=True)) - plain and overlapped on the
+second stream with double-buffered records.  The driver's GPU test run thereby loads librccl and checks
+the gathered bytes; the world-size-2 logic is covered on CPU by tests/test_parallel_gloo.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om
+from oracle import params
+from tests.util import ANCHORS
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_single_rank_rccl_all_gather_of_detections(dev):
+    import torch.distributed as dist
+    from yoloret_amd import layers as L
+    from yoloret_amd.parallel import DetectionGatherer
+    from yoloret_amd.pipeline import DetectionPipeline
+    from yoloret_amd.weights import synthetic_weights
+    from yoloret_amd.yolo3.model import yolov3_body
+    assert not dist.is_initialized()
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % _free_port(), rank=0, world_size=1,
+                            device_id=dev)
+    try:
+        m = yolov3_body(L.Input(shape=[96, 96, 3]), 'mobilenetv2x75', 3, num_classes=20)
+        m.set_weights(synthetic_weights(m, 5, 'survey'))
+        pipe = DetectionPipeline(m, ANCHORS, 20, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5, record_slots=2)
+        g = DetectionGatherer(always=True)
+        assert g.world == 1 and g.always
+        b = 4
+        xs = [torch.from_numpy(params.synthetic_images(b, 96, 96, seed=s)).to(dev) for s in (1, 2, 3)]
+        hw = torch.tensor([[96, 96]] * b, dtype=torch.int32, device=dev)
+        # reference: every batch on its own, no collective
+        want = []
+        for x in xs:
+            det, cnt = pipe(x, hw)
+            torch.cuda.synchronize()
+            want.append((det.cpu().numpy().copy(), cnt.cpu().numpy().copy()))
+        assert sum(int(c.sum()) for _, c in want) > 0 and not np.array_equal(want[0][0], want[1][0])
+        # plain collective
+        det, cnt = pipe(xs[0], hw)
+        ad, ac = g(det, cnt, pipe.record)
+        torch.cuda.synchronize()
+        assert np.array_equal(ad.cpu().numpy(), want[0][0]) and np.array_equal(ac.cpu().numpy(), want[0][1])
+        # overlapped: step i's records travel while step i+1 runs; each handle is waited for one step late
+        handles, got = [], []
+        for x in xs:
+            det, cnt = pipe(x, hw)
+            handles.append(g.start(det, cnt, pipe.record))
+            if len(handles) >= 2:
+                d, c = handles[-2].wait()
+                got.append((d.clone(), c.clone()))
+        d, c = handles[-1].wait()
+        got.append((d.clone(), c.clone()))
+        torch.cuda.synchronize()
+        for (d, c), (wd, wc) in zip(got, want):
+            assert np.array_equal(d.cpu().numpy(), wd) and np.array_equal(c.cpu().numpy(), wc)
+    finally:
+        dist.destroy_process_group()

@@ -47,6 +47,11 @@ def _worker(rank, world, port, q, use_record):
     g = DetectionGatherer()
     for _ in range(2):  # second call reuses the preallocated buffers
         all_det, all_cnt = g(d, c, record)
+    # the overlapped form: two gathers in flight, results live in alternating buffers until the second start() after them
+    h1 = g.start(d, c, record)
+    h2 = g.start(d, c, record)
+    (d1, c1), (d2, c2) = h1.wait(), h2.wait()
+    assert d1.data_ptr() != d2.data_ptr() and torch.equal(d1, all_det) and torch.equal(d2, all_det) and torch.equal(c1, c2)
     q.put((rank, all_det.numpy().copy(), all_cnt.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()

@@ -20,23 +20,52 @@ def shard_range(global_batch, rank, world_size):
     return rank * per, (rank + 1) * per
 
 
+class GatherHandle:
+    """One all-gather in flight (DetectionGatherer.start).  wait() makes the CURRENT stream wait for it and returns
+    (all_det [W*b,S,6], all_cnt [W*b]) - views of one of the gatherer's two result buffers, valid until the second
+    start() after this one."""
+
+    def __init__(self, work, event, out, world, b, s, six, ready=None):
+        self._work, self._event, self._out = work, event, out
+        self._dims = (world, b, s, six)
+        self._ready = ready              # single rank without a collective: the local (det, det_count) as they are
+
+    def wait(self):
+        if self._ready is not None:
+            return self._ready
+        if self._work is not None:
+            self._work.wait()            # the current stream waits for the collective (no host block on GPU backends)
+            self._work = None
+        if self._event is not None:
+            torch.cuda.current_stream(self._out.device).wait_event(self._event)
+            self._event = None
+        world, b, s, six = self._dims
+        words = b * s * six + b
+        out = self._out.view(world, words)
+        return out[:, :b * s * six].reshape(world * b, s, six), out[:, b * s * six:].reshape(world * b)
+
+
 class DetectionGatherer:
-    """Preallocated all-gather of (det, det_count); result rows are in global image order."""
+    """Preallocated all-gather of (det, det_count); result rows are in global image order.
+
+    __call__ is the plain form (the result is ready for whatever is enqueued next on the current stream).
+    start() / GatherHandle.wait() is the overlapped form of SURVEY.md 8(e): the collective is issued on a SECOND stream
+    behind an event recorded after the step's pack kernel, so the next batch's forward runs while the records travel
+    over xGMI; the caller waits for step i's handle after having enqueued step i+1.  Both the send side (the
+    pipeline's record buffer, DetectionPipeline(record_slots=2)) and the result side are double buffered, so a step
+    never overwrites bytes a collective in flight still reads or a consumer still holds."""
 
     def __init__(self, group=None, always=False):
         """always=True issues the collective even for a 1-rank group (exercises RCCL on a single GPU)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.always = always and dist.is_initialized()
-        self._out = None
+        self._out = [None, None]
+        self._slot = 0
         self._send = None
+        self._stream = None
 
-    def __call__(self, det, det_count, record=None):
-        """det int32 [b, S, 6], det_count int32 [b] (local shard) -> ([W*b, S, 6], [W*b]).
-        `record`: the flat buffer both are views of (DetectionPipeline.record) - sent as is;
-        without it the two tensors are first staged into one message."""
-        if self.world == 1 and not self.always:
-            return det, det_count
+    def _message(self, det, det_count, record):
         b, s, six = det.shape
         words = b * s * six + b
         if record is None or record.numel() != words:
@@ -45,10 +74,39 @@ class DetectionGatherer:
             self._send[:b * s * six].copy_(det.reshape(-1))
             self._send[b * s * six:].copy_(det_count)
             record = self._send
-        if self._out is None or self._out.numel() != self.world * words or self._out.device != det.device:
-            self._out = torch.empty(self.world * words, dtype=torch.int32, device=det.device)
-        dist.all_gather_into_tensor(self._out, record, group=self.group)
-        out = self._out.view(self.world, words)
-        all_det = out[:, :b * s * six].reshape(self.world * b, s, six)
-        all_cnt = out[:, b * s * six:].reshape(self.world * b)
-        return all_det, all_cnt
+        return record, words
+
+    def start(self, det, det_count, record=None, overlap=True):
+        """det int32 [b, S, 6], det_count int32 [b] (local shard); `record`: the flat buffer both are views of
+        (DetectionPipeline.record) - sent as is; without it the two tensors are first staged into one message."""
+        b, s, six = det.shape
+        if self.world == 1 and not self.always:
+            return GatherHandle(None, None, det, 1, b, s, six, ready=(det, det_count))
+        record, words = self._message(det, det_count, record)
+        slot = self._slot
+        self._slot ^= 1
+        out = self._out[slot]
+        if out is None or out.numel() != self.world * words or out.device != det.device:
+            out = self._out[slot] = torch.empty(self.world * words, dtype=torch.int32, device=det.device)
+        if not (overlap and det.is_cuda):
+            dist.all_gather_into_tensor(out, record, group=self.group)
+            return GatherHandle(None, None, out, self.world, b, s, six)
+        if self._stream is None or self._stream.device != det.device:
+            self._stream = torch.cuda.Stream(device=det.device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(det.device))          # after the step's pack kernel
+        with torch.cuda.stream(self._stream):
+            self._stream.wait_event(ready)
+            record.record_stream(self._stream)
+            out.record_stream(self._stream)
+            work = dist.all_gather_into_tensor(out, record, group=self.group, async_op=True)
+            work.wait()                                              # orders the side stream behind the collective
+            done = torch.cuda.Event()
+            done.record(self._stream)
+        return GatherHandle(None, done, out, self.world, b, s, six)
+
+    def __call__(self, det, det_count, record=None):
+        """det int32 [b, S, 6], det_count int32 [b] (local shard) -> ([W*b, S, 6], [W*b])."""
+        if self.world == 1 and not self.always:
+            return det, det_count
+        return self.start(det, det_count, record, overlap=False).wait()

@@ -15,7 +15,9 @@ from . import runtime as rt
 
 class DetectionPipeline:
     def __init__(self, model, anchors, num_classes, num_scales=3, max_boxes=20, score_threshold=.2,
-                 iou_threshold=.5):
+                 iou_threshold=.5, record_slots=1):
+        """record_slots=2: successive calls alternate between two output record buffers, so the records of step i stay
+        intact while step i+1 runs (the overlapped all-gather of yoloret_amd.parallel reads them meanwhile)."""
         self.model = model
         self.anchors = np.ascontiguousarray(np.asarray(anchors, np.float32).reshape(-1, 2))
         self.num_classes, self.num_scales = int(num_classes), int(num_scales)
@@ -23,6 +25,8 @@ class DetectionPipeline:
         self.input_hw = tuple(model.plan.input_shape[:2])
         self.num_anchors = self.anchors.shape[0] // 3
         self.n = rt.num_boxes(self.input_hw[0], self.input_hw[1], self.num_anchors, self.num_scales)
+        self.record_slots = int(record_slots)
+        self._turn = 0
         self._bufs = {}
 
     def _buffers(self, b, dev):
@@ -37,11 +41,12 @@ class DetectionPipeline:
                 scores=torch.empty((b, c, n), dtype=f32, device=dev),
                 idx=torch.empty((b, c, mb), dtype=i32, device=dev),
                 cnt=torch.empty((b, c), dtype=i32, device=dev),
-                record=torch.empty(b * c * mb * 6 + b, dtype=i32, device=dev))
+                records=[torch.empty(b * c * mb * 6 + b, dtype=i32, device=dev) for _ in range(self.record_slots)])
             # det and det_count are views of ONE buffer so the multi-GPU exchange is a single
             # all-gather without staging copies
-            v['det'] = v['record'][:b * c * mb * 6].view(b, c * mb, 6)
-            v['det_count'] = v['record'][b * c * mb * 6:]
+            v['dets'] = [r[:b * c * mb * 6].view(b, c * mb, 6) for r in v['records']]
+            v['det_counts'] = [r[b * c * mb * 6:] for r in v['records']]
+            v['record'], v['det'], v['det_count'] = v['records'][0], v['dets'][0], v['det_counts'][0]
             self._bufs = {key: v}  # keep one batch shape resident
         return v
 
@@ -65,6 +70,9 @@ class DetectionPipeline:
 
     def _postprocess(self, ys, image_hw, b, dev, v):
         L, s = rt.lib(), rt.stream_ptr(dev)
+        slot = self._turn % self.record_slots
+        self._turn += 1
+        v['record'], v['det'], v['det_count'] = v['records'][slot], v['dets'][slot], v['det_counts'][slot]
         yp = [rt._ptr(ys[i]) if i < self.num_scales else None for i in range(3)]
         rt.check(L.yr_decode(yp[0], yp[1], yp[2], b, self.input_hw[0], self.input_hw[1], self.num_anchors,
                              self.num_classes, self.num_scales, self.anchors.ctypes.data_as(ctypes.c_void_p),
