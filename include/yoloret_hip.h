@@ -101,6 +101,13 @@ typedef enum {
                             wgt2 = depthwise [CP][ 9 taps (ky,kx)    x 2 | BN scale 2 | BN shift 2],
                             b1   = project W[2*CP][COP] (input-channel major), b2 = project BN scale[COP] ++ shift[COP].
                             Built for (CP,COP) in {(12,16),(16,16),(16,24),(20,24),(24,16),(24,24)}; others: YR_ERR_ARG */
+    YR_OP_MBH = 11,      /* the MBCONV block on 16-bit activations, both 1x1 convs on bf16 / f16 MFMA, depthwise K = 3 | 5 from an
+                            LDS tile (dtype must be YR_BF16 / YR_F16; cin, cout <= 128).  se_reduced = Cexp; k = K, optionally
+                            | th << 8 | tw << 16 to force the output tile.  CexpP = round_up(Cexp,32), KP = round_up(cin,32),
+                            zero padded: wgt = expand Wt[CexpP][KP] (16-bit); wgt2 = [K*K + 4][CexpP] float32: depthwise taps |
+                            depthwise BN scale | shift | expand BN scale | shift;
+                            b1 = project Wt[cout][CexpP] (16-bit); b2 = project BN scale ++ shift, [round_up(cout,8)] each;
+                            res (optional) = the block input (stride 1, cin == cout) */
     YR_OP_MBLANE = 10    /* the MBCONV block (same layers, same op fields) in the lane-per-pixel formulation for narrow
                             block inputs (Cin <= 32): packed-fp32 FMA with scalar-register weights instead of MFMA.
                             se_reduced = Cexp; parameters packed per expanded-channel PAIR, P = round_up(ceil(Cexp/2),8),

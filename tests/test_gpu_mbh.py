@@ -1,0 +1,113 @@
+"""Fused inverted-residual block on 16-bit MFMA (YR_OP_MBH: expand 1x1 + BN + act -> depthwise KxK s1|s2 + BN + act ->
+project 1x1 + BN (+ residual), 16-bit in / out) against the three oracle ops composed in float64, through yr_op_run.
+
+Rounding model of the kernel (what the reference below restates): input, expand and project weights are 16-bit values;
+the expanded tensor stays float32 on chip; the depthwise result is rounded ONCE to the 16-bit type (it is the MFMA
+operand of the projection); the block output is rounded once at the store.  A depthwise value that sits on a rounding
+boundary may round the other way in float32 than in the float64 reference - one operand ulp in one of Cexp products -
+hence the extra slack (one ulp of a value up to 6 times a projection weight) on top of the output's own half ulp."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn
+from tests.util import assert_rounded_once, from_dev16, q16, round_up, to_dev16
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (h, w, cin, cexp, cout, k, stride, residual, act, forced tile (th, tw) or None)
+    (16, 16, 16, 96, 24, 3, 2, False, 'relu6', None),      # MobileNetV2 block_1 shape
+    (104, 104, 16, 96, 24, 3, 2, False, 'relu6', None),    # ... at a size with many tiles
+    (26, 26, 24, 144, 24, 3, 1, True, 'relu6', None),      # block_2 (+add)
+    (52, 52, 24, 144, 32, 3, 2, False, 'relu6', None),     # block_3
+    (30, 44, 32, 192, 32, 3, 1, True, 'relu6', None),      # block_4/5, ragged tiles
+    (26, 26, 48, 288, 48, 3, 1, True, 'relu6', None),      # block_7..9: two k-steps of the expand GEMM
+    (26, 26, 72, 432, 72, 3, 1, True, 'relu6', None),      # block_11/12: three k-steps (weights not hoisted)
+    (26, 26, 72, 432, 120, 3, 2, False, 'relu6', None),    # block_13
+    (13, 13, 120, 720, 120, 3, 1, True, 'relu6', None),    # block_14/15: four k-steps, four cout pairs
+    (9, 7, 24, 144, 32, 3, 2, False, 'relu6', None),       # odd size, stride 2
+    (15, 17, 40, 240, 40, 5, 1, True, 'relu6', None),      # EfficientNet-lite stage 3 (k5)
+    (16, 16, 24, 144, 40, 5, 2, False, 'relu6', None),     # ... its stride-2 entry block
+    (13, 13, 80, 480, 112, 5, 1, False, 'relu6', None),    # stage 5 entry (k5, cin != cout)
+    (8, 8, 16, 100, 20, 3, 1, False, 'relu6', None),       # expanded width not a multiple of 32, cout not of 8
+    (21, 9, 14, 50, 14, 3, 1, True, 'relu6', None),        # cin / cout with pad lanes (NaN-filled)
+    (26, 26, 24, 144, 24, 3, 1, True, 'relu6', (13, 13)),  # forced large tile (3 pixel tiles per wave)
+    (26, 26, 48, 288, 48, 3, 1, True, 'relu6', (7, 9)),    # forced odd tile
+    (20, 20, 32, 192, 48, 3, 1, False, 'swish', None),     # generic activation path
+]
+
+
+def _act(t, act):
+    return {'relu6': nn.relu6, 'swish': nn.swish}[act](t)
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+@pytest.mark.parametrize('case', CASES, ids=[str(i) for i in range(len(CASES))])
+def test_mbh(dev, case, dt):
+    from yoloret_amd import runtime as rt
+    h, w, cin, cexp, cout, k, s, residual, act, tile = case
+    rng = np.random.default_rng(zlib.crc32(str(case).encode()))
+    b = 2
+    x = q16(rng.standard_normal((b, h, w, cin)), dt)
+    we = q16(rng.standard_normal((cin, cexp)) * np.sqrt(2.0 / cin), dt)
+    se, he = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
+    t = _act(nn.pointwise(x.astype(np.float64), we.astype(np.float64)) * se + he, act)
+    wd = (rng.standard_normal((k, k, cexp)) * np.sqrt(2.0 / (k * k))).astype(np.float32)
+    sd, hd = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
+    t = _act(nn.depthwise(t, wd.astype(np.float64), s, 'same') * sd + hd, act)
+    t = q16(t.astype(np.float32), dt).astype(np.float64)            # the projection's MFMA operand
+    wp = q16(rng.standard_normal((cexp, cout)) * np.sqrt(1.0 / cexp), dt)
+    sp, hp = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.3, cout).astype(np.float32)
+    ref = nn.pointwise(t, wp.astype(np.float64)) * sp + hp
+    if residual:
+        ref = ref + x
+    cexp_p, kp, ldo = round_up(cexp, 32), round_up(cin, 32), round_up(cout, 8)
+    wet = np.zeros((cexp_p, kp), np.float32); wet[:cexp, :cin] = we.T
+    dwp = np.zeros((k * k + 4, cexp_p), np.float32)      # depthwise taps | dw BN scale | shift | expand BN scale | shift
+    dwp[:k * k, :cexp], dwp[k * k, :cexp], dwp[k * k + 1, :cexp] = wd.reshape(k * k, cexp), sd, hd
+    dwp[k * k + 2, :cexp], dwp[k * k + 3, :cexp] = se, he
+    wpt = np.zeros((cout, cexp_p), np.float32); wpt[:, :cexp] = wp.T
+    pb = np.zeros((2, ldo), np.float32); pb[0, :cout], pb[1, :cout] = sp, hp
+
+    def dev16(a):
+        return torch.from_numpy(rt.to_bits16(a, dt).view(np.int16).reshape(a.shape)).to(dev)
+
+    def dev32(a):
+        return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    keep = [dev16(wet), dev32(dwp), dev16(wpt), dev32(pb)]
+    xd = to_dev16(x, dev, dt)
+    did = rt.dtype_id(dt)
+    op = rt.new_op(rt.OP_MBH, act)
+    op.dtype = op.out_dtype = did
+    ho, wo = ref.shape[1], ref.shape[2]
+    op.h, op.w, op.cin, op.cout, op.stride, op.nsrc, op.se_reduced = ho, wo, cin, cout, s, 1, cexp
+    op.k = k | ((tile[0] << 8) | (tile[1] << 16) if tile else 0)
+    op.src[0] = rt.make_src(xd, c=cin)
+    op.wgt, op.wgt2, op.b1, op.b2 = [t_.data_ptr() for t_ in keep]
+    if residual:
+        op.res, op.res_ld = xd.data_ptr(), xd.shape[3]
+    out = torch.full((b, ho, wo, ldo), float('nan'), dtype=rt.TORCH_DTYPE[did], device=dev)
+    op.out, op.out_ld = out.data_ptr(), ldo
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    assert_rounded_once(from_dev16(out, dt, cout), ref, dt, 'mbh %s %s' % (dt, case), slack={'bf16': 4e-3, 'f16': 5e-4}[dt])
+
+
+def test_mbh_rejects_what_it_is_not_built_for(dev):
+    from yoloret_amd import runtime as rt
+    x = torch.zeros((1, 8, 8, 160), dtype=torch.bfloat16, device=dev)
+    out = torch.zeros((1, 8, 8, 160), dtype=torch.bfloat16, device=dev)
+    op = rt.new_op(rt.OP_MBH, 'relu6')
+    op.dtype = op.out_dtype = rt.DTYPE['bf16']
+    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc, op.se_reduced = 8, 8, 160, 160, 3, 1, 1, 960
+    op.src[0] = rt.make_src(x, c=160)
+    op.wgt = op.wgt2 = op.b1 = op.b2 = x.data_ptr()
+    op.out, op.out_ld = out.data_ptr(), 160
+    with pytest.raises(rt.YoloretHipError, match='widths out of range'):
+        rt.run_op(op, 1)
+    op.dtype = op.out_dtype = 0
+    with pytest.raises(rt.YoloretHipError, match='16-bit'):
+        rt.run_op(op, 1)

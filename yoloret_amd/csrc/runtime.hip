@@ -41,6 +41,7 @@ static int dispatch(const yr_op& op, int batch, hipStream_t s) {
         case YR_OP_MBCONV: return yr_launch_mbconv(op, batch, s);
         case YR_OP_STEMBLOCK: return yr_launch_stemblock(op, batch, s);
         case YR_OP_MBLANE: return yr_launch_mblane(op, batch, s);
+        case YR_OP_MBH: return yr_launch_mbh(op, batch, s);
         default: yr_set_error("unknown op kind %d", op.kind); return YR_ERR_ARG;
     }
 }
