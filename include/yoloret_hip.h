@@ -209,13 +209,13 @@ int yr_forward(yr_handle* h, const float* images, int batch, float* y1, float* y
 int yr_forward_profile(yr_handle* h, const float* images, int batch, float* y1, float* y2, float* y3,
                        void* workspace, size_t workspace_bytes, void* stream, int iters,
                        float* ms_per_op, const char** kernel_names);
-/* Per-op tile autotuning for `batch` images: times every pointwise tile shape on every pointwise op and
- * remembers the fastest for later yr_forward calls with the same batch (numerics do not depend on the
+/* Per-op tile autotuning for `batch` images: times every pointwise tile shape on every pointwise op (and a list of
+ * output tiles on every MBH op) and remembers the fastest for later yr_forward calls with the same batch (numerics do not depend on the
  * shape).  Runs the forward once first; synchronises the stream. */
 int yr_autotune(yr_handle* h, const float* images, int batch, float* y1, float* y2, float* y3,
                 void* workspace, size_t workspace_bytes, void* stream, int iters);
-/* The autotuned table for `batch`: one int per plan op (0 = heuristic / not a pointwise op, else the 1-based tile
- * shape).  yr_get_tuning returns YR_ERR_STATE if that batch has not been tuned; yr_set_tuning installs a table
+/* The autotuned table for `batch`: one int per plan op - POINTWISE: 0 = heuristic, else the 1-based tile shape;
+ * MBH: 0 = heuristic, else the output tile as th << 8 | tw << 16; every other op kind: 0.  yr_get_tuning returns YR_ERR_STATE if that batch has not been tuned; yr_set_tuning installs a table
  * saved from an earlier run (tune once, deploy many: n must equal yr_plan_num_launches). */
 int yr_get_tuning(const yr_handle* h, int batch, int32_t* cfg_per_op, int n);
 int yr_set_tuning(yr_handle* h, int batch, const int32_t* cfg_per_op, int n);

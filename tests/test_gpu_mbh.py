@@ -34,8 +34,9 @@ CASES = [
     (13, 13, 80, 480, 112, 5, 1, False, 'relu6', None),    # stage 5 entry (k5, cin != cout)
     (8, 8, 16, 100, 20, 3, 1, False, 'relu6', None),       # expanded width not a multiple of 32, cout not of 8
     (21, 9, 14, 50, 14, 3, 1, True, 'relu6', None),        # cin / cout with pad lanes (NaN-filled)
-    (26, 26, 24, 144, 24, 3, 1, True, 'relu6', (13, 13)),  # forced large tile (3 pixel tiles per wave)
-    (26, 26, 48, 288, 48, 3, 1, True, 'relu6', (7, 9)),    # forced odd tile
+    (26, 26, 24, 144, 24, 3, 1, True, 'relu6', (13, 12)),  # forced large tile (two pixel groups per wave)
+    (26, 26, 48, 288, 48, 3, 1, True, 'relu6', (7, 8)),    # forced odd tile (14 runs: ragged groups)
+    (13, 13, 120, 720, 120, 3, 1, True, 'relu6', (3, 4)),  # tiny tile: a single partial group
     (20, 20, 32, 192, 48, 3, 1, False, 'swish', None),     # generic activation path
 ]
 

@@ -264,6 +264,11 @@ MBLANE_WIDTHS = {(4, 16), (4, 24), (6, 24), (6, 32), (6, 40), (6, 48), (8, 32), 
 STEMBLOCK_WIDTHS ={(12, 16), (16, 16), (16, 24), (20, 24), (24, 16), (24, 24)}  # (C1p/2, round_up(cout,8)) built in stemblock.hip
 
 
+FUSE_MBH = os.environ.get('YOLORET_FUSE_MBH', '1') != '0'   # 16-bit plans: inverted-residual blocks on the MFMA block kernel (mbh.hip)
+MBH_LANE_MIN_PIXELS = int(os.environ.get('YOLORET_MBH_LANE_MIN_PIXELS', '10000'))
+MBH_ACTS = ('relu6',) if os.environ.get('YOLORET_MBH_SWISH', '0') == '0' else ('relu6', 'swish')
+
+
 HOIST_UPSAMPLE = os.environ.get('YOLORET_HOIST', '1') != '0'
 
 
@@ -491,6 +496,60 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0):
                 and private(e.out) and 'scale' in e.params and not (e.h == 1 and e.w == 1) and j + 1 < len(ops)):
             exp, j = e, j + 1
         d = ops[j] if j < len(ops) else None
+        # 16-bit plans: the MFMA block kernel (mbh.hip) takes every expand -> depthwise 3x3 | 5x5 -> project block with up
+        # to 128 input / output channels, whatever the map size (measured: it beats the unfused chain on every
+        # MobileNetV2 block at batch 64 and the float32 lane kernels where both apply)
+        mbh = None
+        if (FUSE_MBH and dtype != 0 and blocks and exp is not None and d is not None and d.kind == rt.OP_DEPTHWISE and d.k in (3, 5)
+                and d.stride in (1, 2) and plain1(d) and private(d.out) and d.srcs[0].buf is exp.out and d.act == exp.act
+                and d.act in MBH_ACTS and j + 1 < len(ops)):
+            p = ops[j + 1]
+            bi = exp.srcs[0]
+            if (p.kind == rt.OP_POINTWISE and plain1(p) and p.srcs[0].buf is d.out and p.act == 'none' and 'scale' in p.params
+                    and p.out.dtype == dtype and bi.c <= 128 and p.cout <= 128 and bi.xform == 'identity' and bi.buf.dtype == dtype
+                    and (p.res is None or (p.res is bi.buf and d.stride == 1 and p.cout == bi.c))):
+                mbh = (d, p)
+                # measured (tools/mbh_probe.py, batch 64): only on the first, stride-2 block (16 -> 96 -> 24 channels,
+                # 208 x 208 -> 104 x 104) the float32 lane-per-pixel kernel is still ahead (0.223 vs 0.253 ms: its 17 x 17
+                # halo tile leaves two workgroups per CU); from block_2 on (0.205 vs 0.138 ms) everything goes to mbh
+                if lane_ok(exp, bi, p) and d.k == 3 and d.stride == 2 and p.h * p.w >= MBH_LANE_MIN_PIXELS:
+                    mbh = None
+        if mbh is not None:
+            d, p = mbh
+            bi = exp.srcs[0]
+            cin, cexp, cout, kk = bi.c, d.cin, p.cout, d.k * d.k
+            cexp_p, kp, ldo = round_up(cexp, 32), round_up(cin, 32), round_up(cout, 8)
+            m = OpRec(rt.OP_MBH, exp.name.rsplit('_', 1)[0] + '_mbh', act=d.act, h=p.h, w=p.w, cin=cin, cout=cout, k=d.k,
+                      stride=d.stride, se_reduced=cexp, srcs=[bi], out=p.out, res=p.res, macs=exp.macs + d.macs + p.macs, dtype=dtype)
+            m.fused = [exp, d, p]
+            ep, dp, pp = exp.params, d.params, p.params
+
+            def expand_wt(wd, ep=ep, cexp=cexp, cin=cin, cexp_p=cexp_p, kp=kp):
+                o = np.zeros((cexp_p, kp), np.float32)
+                o[:cexp, :cin] = ep['wgt'][1](wd)[:, :cin]            # pointwise layout Wt[cexp][k-space], one source
+                return o
+
+            def chunk_params(wd, ep=ep, dp=dp, cexp=cexp, cexp_p=cexp_p, kk=kk):
+                o = np.zeros((kk + 4, cexp_p), np.float32)            # taps | dw scale | dw shift | expand scale | expand shift
+                o[:kk, :cexp] = dp['wgt'][1](wd)[:, :cexp]
+                o[kk, :cexp], o[kk + 1, :cexp] = dp['scale'][1](wd)[:cexp], dp['shift'][1](wd)[:cexp]
+                o[kk + 2, :cexp], o[kk + 3, :cexp] = ep['scale'][1](wd)[:cexp], ep['shift'][1](wd)[:cexp]
+                return o
+
+            def project_wt(wd, pp=pp, cexp=cexp, cexp_p=cexp_p, cout=cout):
+                o = np.zeros((cout, cexp_p), np.float32)
+                o[:, :cexp] = pp['wgt'][1](wd)[:, :cexp]
+                return o
+
+            def project_bn(wd, pp=pp, cout=cout, ldo=ldo):
+                o = np.zeros((2, ldo), np.float32)
+                o[0, :cout], o[1, :cout] = pp['scale'][1](wd)[:cout], pp['shift'][1](wd)[:cout]
+                return o.ravel()
+            m.params = {'wgt': ((cexp_p, kp), expand_wt, dtype), 'wgt2': ((kk + 4, cexp_p), chunk_params),
+                        'b1': ((cout, cexp_p), project_wt, dtype), 'b2': ((2 * ldo,), project_bn)}
+            out.append(m)
+            i = j + 2
+            continue
         if (d is not None and d.kind == rt.OP_DEPTHWISE and d.k == 3 and plain1(d) and private(d.out)
                 and (exp is None or (d.srcs[0].buf is exp.out and d.act == exp.act)) and d.act in ('relu6', 'swish')
                 and d.srcs[0].buf.ld == round_up(d.cin, rt.VEC[dtype]) and j + 1 < len(ops)):

@@ -14,7 +14,11 @@
 //                   (read from HBM once; also the residual source);
 //   Es [PH][32+4]   the current 32-channel chunk of the EXPANDED halo tile, float32 (zero outside the image: TF pads
 //                   the expanded tensor, not the input);
-//   Ps [2][..]      the chunk's depthwise weights and the expand / depthwise BN parameters, double buffered.
+//   Ps [2][..]      the chunk's depthwise weights and the expand / depthwise BN parameters, double buffered;
+//   Ws [2][32][KP+8] the chunk's expand weights, 16-bit, double buffered.  Both are fetched one chunk ahead into
+//                   registers and stored behind the depthwise phase, so no chunk starts by waiting for L2 (the first
+//                   version read the weight fragments from global memory where they were used: 4-5 us per chunk on
+//                   the 13x13 blocks, whose four k-steps each waited for a round trip).
 // Per chunk of 32 expanded channels (two barriers):
 //   expand : Es[p][32] = act(BN(Xs[p][:] . We))         MFMA, 16-pixel tiles of the halo round-robin over the waves
 //   dw+proj: every lane computes the KxK depthwise result of (its output pixel, 8 channels) in float32 - exactly the
@@ -57,16 +61,29 @@ __device__ __forceinline__ float mbh_act(float v, int act) {
     return yr_apply_act(v, act);
 }
 
-// CP: cout tile pairs (Cout <= 32*CP); MTO: 16-pixel output tiles per wave (th*tw <= 64*MTO)
-template <class T, int K, int S, int CP, int MTO, bool RELU6>
-__global__ __launch_bounds__(256, 2) void mbh_kernel(MbhArgs a) {
-    constexpr int CT = 2 * CP, KK = K * K;
+// CP: cout tile pairs (Cout <= 32*CP); NG: groups of 32 output pixels per wave (th*tw <= 128*NG)
+//
+// Output pixels are enumerated in RUNS of 4 along x (tw % 4 == 0); 8 runs = one group = 32 pixels = two 16-pixel MFMA
+// tiles; groups go round-robin over the 4 waves.  In the depthwise phase a lane owns (run rl = lane>>3, channel quad
+// cq = lane&7): 4 horizontally adjacent outputs x 4 channels, register blocked like depthwise.hip - an input row of
+// 3S+K positions is read once for the 4 outputs, the K*K tap weights of the lane's channels stay in registers for the
+// whole chunk.  (The first version gave every lane one pixel x 8 channels, the projection's MFMA operand layout, and
+// re-read all K*K taps and their weights from LDS per output: PMC showed the LDS pipe 69 % busy, 30 % of it bank
+// conflicts, and half of the reads were weights.)  The 16-bit results go to a wave-private LDS patch Ds[32][32] and
+// come back as B-operand fragments - same wave, program order, no workgroup barrier.
+template <class T, int K, int S, int CP, int NG, bool RELU6>
+__global__ __launch_bounds__(256, (CP * NG <= 1 ? 3 : 2)) void mbh_kernel(MbhArgs a) {
+    constexpr int CT = 2 * CP, KK = K * K, MTO = 2 * NG;
     constexpr int PSZ = (KK + 4) * MBH_EC;              // floats per parameter buffer: dw taps | sd | hd | se | he
+    constexpr int COLS = 3 * S + K;                     // input positions per row feeding a run of 4 outputs
+    constexpr int LDD = MBH_EC + 8;                     // Ds row stride in elements (80 bytes: conflict-free b128 rows)
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    const int ldx = a.KP + 8;                           // Xs row stride in elements (16-byte aligned, conflict-free)
+    const int ldx = a.KP + 8;                           // Xs / Ws row stride in elements (16-byte aligned, conflict-free)
     T* Xs = reinterpret_cast<T*>(lds_raw);
     float* Es = reinterpret_cast<float*>(lds_raw + (((size_t)a.PH * ldx * sizeof(T) + 15) & ~(size_t)15));
     float* Ps = Es + (size_t)a.PH * MBH_LDE;
+    T* Ws = reinterpret_cast<T*>(Ps + 2 * PSZ);         // [2][32][ldx]: expand weights of the current / next chunk
+    T* Ds = Ws + (size_t)2 * 32 * ldx;                  // [4 waves][32][LDD]: depthwise results on their way to the MFMA
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
     const int tpi = a.tiles_x * a.tiles_y;
@@ -78,6 +95,8 @@ __global__ __launch_bounds__(256, 2) void mbh_kernel(MbhArgs a) {
     const T* xin = reinterpret_cast<const T*>(a.x) + (size_t)b * a.Hi * a.Wi * a.ld_in;
     const T* we = reinterpret_cast<const T*>(a.we);
     const T* wp = reinterpret_cast<const T*>(a.wp);
+    // block-uniform: the halo tile lies inside the image (no zero padding to apply anywhere)
+    const bool all_inside = iy0 >= 0 && ix0 >= 0 && iy0 + a.ih <= a.Hi && ix0 + a.iw <= a.Wi;
 
     // ---- 1. input halo tile -> LDS (zero outside the image and beyond Cin; pad channels of the source may hold anything).
     //      Loads are issued in batches before the first LDS store of the batch (one HBM round trip per batch).
@@ -85,6 +104,7 @@ __global__ __launch_bounds__(256, 2) void mbh_kernel(MbhArgs a) {
         const int nq = a.KP >> 3;                       // 16-byte vectors per pixel row
         const int cq = (a.Cin + 7) >> 3;                // ... of which hold real channels
         const int total = a.PH * nq;
+        const bool ragged = (a.Cin & 7) != 0;
         constexpr int XB = 4;
         for (int base = 0; base < total; base += 256 * XB) {
             mbh_u4 v[XB];
@@ -95,11 +115,13 @@ __global__ __launch_bounds__(256, 2) void mbh_kernel(MbhArgs a) {
                 const int hy = p / a.iw, hx = p - hy * a.iw;
                 const int iy = iy0 + hy, ix = ix0 + hx;
                 v[u] = (mbh_u4){0u, 0u, 0u, 0u};
-                if (idx < total && q < cq && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
+                if (idx < total && q < cq && (all_inside || (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi))) {
                     v[u] = *reinterpret_cast<const mbh_u4*>(xin + ((size_t)iy * a.Wi + ix) * a.ld_in + q * 8);
-                    const int cv = a.Cin - q * 8;       // real channels in this vector
+                    if (ragged) {
+                        const int cv = a.Cin - q * 8;   // real channels in this vector
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) v[u][d] = cv >= 2 * d + 2 ? v[u][d] : (cv == 2 * d + 1 ? (v[u][d] & 0xffffu) : 0u);
+                        for (int d = 0; d < 4; ++d) v[u][d] = cv >= 2 * d + 2 ? v[u][d] : (cv == 2 * d + 1 ? (v[u][d] & 0xffffu) : 0u);
+                    }
                 }
             }
 #pragma unroll
@@ -120,9 +142,7 @@ __global__ __launch_bounds__(256, 2) void mbh_kernel(MbhArgs a) {
             const int i = tid + u * 256;
             const int rr = i / MBH_EC, ch = i - rr * MBH_EC;
             pv[u] = 0.f;
-            if (i < PSZ) {
-                pv[u] = a.prm[(size_t)rr * a.CexpP + e0 + ch];
-            }
+            if (i < PSZ) pv[u] = a.prm[(size_t)rr * a.CexpP + e0 + ch];
         }
     };
     auto store_params = [&](float* dst, const float (&pv)[NPV]) __attribute__((always_inline)) {
@@ -130,10 +150,32 @@ __global__ __launch_bounds__(256, 2) void mbh_kernel(MbhArgs a) {
         for (int u = 0; u < NPV; ++u)
             if (tid + u * 256 < PSZ) dst[tid + u * 256] = pv[u];
     };
+    // expand weights of one chunk: 32 rows x KP/8 16-byte vectors, at most 2 per thread (KP <= 128)
+    const int wq = a.KP >> 3, wtotal = 32 * wq;
+    auto load_w = [&](int e0, mbh_u4 (&wv)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 256;
+            const int rr = i / wq, q = i - rr * wq;
+            wv[u] = (mbh_u4){0u, 0u, 0u, 0u};
+            if (i < wtotal) wv[u] = *reinterpret_cast<const mbh_u4*>(we + (size_t)(e0 + rr) * a.KP + q * 8);
+        }
+    };
+    auto store_w = [&](T* dst, const mbh_u4 (&wv)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 256;
+            const int rr = i / wq, q = i - rr * wq;
+            if (i < wtotal) *reinterpret_cast<mbh_u4*>(dst + (size_t)rr * ldx + q * 8) = wv[u];
+        }
+    };
     {
         float pv[NPV];
+        mbh_u4 wv[2];
         load_params(0, pv);
+        load_w(0, wv);
         store_params(Ps, pv);
+        store_w(Ws, wv);
     }
 
     mbh_f4 acc_o[CT][MTO];
@@ -149,27 +191,55 @@ __global__ __launch_bounds__(256, 2) void mbh_kernel(MbhArgs a) {
         const int n = (c >> 1) * 32 + 8 * (li >> 2) + 4 * (c & 1) + (li & 3);
         wprow[c] = wp + (size_t)(n < a.Cout ? n : 0) * a.CexpP + 8 * g;
     }
-    const int nmt_h = (a.PH + 15) >> 4, nmt_o = (a.OPX + 15) >> 4;
+    const int nmt_h = (a.PH + 15) >> 4;
     const int nks = a.KP >> 5;                          // k-steps of the expand GEMM
-    const bool hoist = a.KP <= 64;                      // the chunk's expand-weight fragments fit registers: load once per wave
-    __syncthreads();                                    // Xs and Ps[0] visible
+    const bool hoist = a.KP <= 64;                      // the chunk's expand-weight fragments fit registers: read once per wave
+    // which of this lane's halo pixels (expand tile slot j: pixel (wave + 4j)*16 + li) lie inside the image
+    unsigned inside_bits = 0;
+    if (!all_inside) {
+        for (int j = 0, mt = wave; mt < nmt_h; ++j, mt += 4) {
+            const int p = mt * 16 + li;
+            const int hy = p / a.iw, hx = p - hy * a.iw;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            inside_bits |= (p < a.PH && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi ? 1u : 0u) << j;
+        }
+    }
+    // depthwise-phase geometry of this lane: run rl of each of the wave's groups, channel quad cq
+    const int cq4 = (lane & 7) * 4, rl = lane >> 3;
+    const int nrx = a.tw >> 2, nruns = a.th * nrx, ngroups = (nruns + 7) >> 3;
+    int es_off[NG];                                     // float offset of the run's window origin in Es (+ channel quad)
+#pragma unroll
+    for (int m = 0; m < NG; ++m) {
+        const int run = (wave + 4 * m) * 8 + rl;
+        const int rc = run < nruns ? run : nruns - 1;
+        const int oy = rc / nrx, ox = (rc - oy * nrx) * 4;
+        es_off[m] = ((oy * S) * a.iw + ox * S) * MBH_LDE + cq4;
+    }
+    T* Dw = Ds + (size_t)wave * 32 * LDD;
+    __syncthreads();                                    // Xs, Ps[0], Ws[0] visible
 
     const int nchunks = a.CexpP >> 5;
     for (int ci = 0; ci < nchunks; ++ci) {
         const int e0 = ci * MBH_EC;
         const float* Pc = Ps + (ci & 1) * PSZ;
-        // prefetches: this chunk's projection fragments, the next chunk's parameters (stored behind the dw phase)
+        // prefetches: this chunk's projection fragments; the next chunk's parameters and expand weights (stored to
+        // their other LDS buffers behind the depthwise phase)
         mbh_u4 wpf[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) wpf[c] = *reinterpret_cast<const mbh_u4*>(wprow[c] + e0);
         float pnext[NPV];
+        mbh_u4 wnext[2];
         const bool more = ci + 1 < nchunks;
-        if (more) load_params(e0 + MBH_EC, pnext);
+        if (more) {
+            load_params(e0 + MBH_EC, pnext);
+            load_w(e0 + MBH_EC, wnext);
+        }
+        const T* Wc = Ws + (size_t)(ci & 1) * 32 * ldx;
 
         // ---- 2. expand GEMM over this wave's 16-pixel halo tiles -> Es
         {
-            const T* wer0 = we + (size_t)(e0 + li) * a.KP + 8 * g;          // tile 0: expanded channel e0 + li
-            const T* wer1 = wer0 + (size_t)16 * a.KP;                       // tile 1: e0 + 16 + li
+            const T* wer0 = Wc + (size_t)li * ldx + 8 * g;                  // tile 0: expanded channel e0 + li (LDS)
+            const T* wer1 = wer0 + (size_t)16 * ldx;                        // tile 1: e0 + 16 + li
             mbh_u4 wh0[2], wh1[2];
             if (hoist) {
                 wh0[0] = *reinterpret_cast<const mbh_u4*>(wer0);
@@ -184,7 +254,8 @@ __global__ __launch_bounds__(256, 2) void mbh_kernel(MbhArgs a) {
             const mbh_f4 sc1 = *reinterpret_cast<const mbh_f4*>(Pc + (KK + 2) * MBH_EC + 16 + 4 * g);
             const mbh_f4 sh0 = *reinterpret_cast<const mbh_f4*>(Pc + (KK + 3) * MBH_EC + 4 * g);
             const mbh_f4 sh1 = *reinterpret_cast<const mbh_f4*>(Pc + (KK + 3) * MBH_EC + 16 + 4 * g);
-            for (int mt = wave; mt < nmt_h; mt += 4) {
+            unsigned bits = inside_bits;
+            for (int mt = wave; mt < nmt_h; mt += 4, bits >>= 1) {
                 const int p = mt * 16 + li;
                 const int pc = p < a.PH ? p : a.PH - 1;
                 const T* xr = Xs + (size_t)pc * ldx + 8 * g;
@@ -207,16 +278,14 @@ __global__ __launch_bounds__(256, 2) void mbh_kernel(MbhArgs a) {
                         e1acc = mbh_mfma<T>(w1, xf, e1acc);
                     }
                 }
-                if (p < a.PH) {
-                    const int hy = p / a.iw, hx = p - hy * a.iw;
-                    const int iy = iy0 + hy, ix = ix0 + hx;
-                    const bool inside = iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
-                    mbh_f4 v0, v1;
+                mbh_f4 v0 = __builtin_elementwise_fma(e0acc, sc0, sh0), v1 = __builtin_elementwise_fma(e1acc, sc1, sh1);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        v0[q] = inside ? mbh_act<RELU6>(__builtin_fmaf(e0acc[q], sc0[q], sh0[q]), a.act) : 0.f;
-                        v1[q] = inside ? mbh_act<RELU6>(__builtin_fmaf(e1acc[q], sc1[q], sh1[q]), a.act) : 0.f;
-                    }
+                for (int q = 0; q < 4; ++q) { v0[q] = mbh_act<RELU6>(v0[q], a.act); v1[q] = mbh_act<RELU6>(v1[q], a.act); }
+                if (!all_inside && !(bits & 1u)) {      // TF pads the EXPANDED tensor with zeros
+                    v0 = (mbh_f4){0.f, 0.f, 0.f, 0.f};
+                    v1 = v0;
+                }
+                if (p < a.PH) {
                     *reinterpret_cast<mbh_f4*>(Es + (size_t)p * MBH_LDE + 4 * g) = v0;
                     *reinterpret_cast<mbh_f4*>(Es + (size_t)p * MBH_LDE + 16 + 4 * g) = v1;
                 }
@@ -224,58 +293,76 @@ __global__ __launch_bounds__(256, 2) void mbh_kernel(MbhArgs a) {
         }
         __syncthreads();   // (A) the expanded chunk is complete
 
-        // ---- 3. depthwise KxK straight into the projection's B-operand fragment (8 channels per lane) + MFMA
+        // ---- 3. depthwise KxK, 4 outputs x 4 channels per lane -> Ds (16-bit) -> B-operand fragments -> projection MFMA
         {
-            const float* pw = Pc + 8 * g;               // this lane's 8 channels of every parameter row
-            const mbh_f4 sd0 = *reinterpret_cast<const mbh_f4*>(pw + KK * MBH_EC), sd1 = *reinterpret_cast<const mbh_f4*>(pw + KK * MBH_EC + 4);
-            const mbh_f4 hd0 = *reinterpret_cast<const mbh_f4*>(pw + (KK + 1) * MBH_EC), hd1 = *reinterpret_cast<const mbh_f4*>(pw + (KK + 1) * MBH_EC + 4);
+            mbh_f4 wk[K == 3 ? KK : 1];
+            if constexpr (K == 3) {
 #pragma unroll
-            for (int m = 0; m < MTO; ++m) {
-                const int mt = wave + 4 * m;
-                if (mt < nmt_o) {
-                    const int o = mt * 16 + li;
-                    const int oc = o < a.OPX ? o : a.OPX - 1;
-                    const int oy = oc / a.tw, ox = oc - oy * a.tw;
-                    const float* base = Es + (size_t)((oy * S) * a.iw + ox * S) * MBH_LDE + 8 * g;
-                    mbh_f4 d0 = (mbh_f4){0.f, 0.f, 0.f, 0.f}, d1 = (mbh_f4){0.f, 0.f, 0.f, 0.f};
+                for (int tp = 0; tp < KK; ++tp) wk[tp] = *reinterpret_cast<const mbh_f4*>(Pc + tp * MBH_EC + cq4);
+            }
+            const mbh_f4 sd = *reinterpret_cast<const mbh_f4*>(Pc + KK * MBH_EC + cq4);
+            const mbh_f4 hd = *reinterpret_cast<const mbh_f4*>(Pc + (KK + 1) * MBH_EC + cq4);
 #pragma unroll
-                    for (int ky = 0; ky < K; ++ky)
+            for (int m = 0; m < NG; ++m) {
+                if (wave + 4 * m < ngroups) {           // wave-uniform
+                    const float* base = Es + es_off[m];
+                    mbh_f4 acc[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = (mbh_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ky = 0; ky < K; ++ky) {
+                        const float* rowp = base + (size_t)(ky * a.iw) * MBH_LDE;
+                        mbh_f4 col[COLS];
+#pragma unroll
+                        for (int j = 0; j < COLS; ++j) col[j] = *reinterpret_cast<const mbh_f4*>(rowp + j * MBH_LDE);
 #pragma unroll
                         for (int kx = 0; kx < K; ++kx) {
-                            const float* ep = base + (size_t)(ky * a.iw + kx) * MBH_LDE;
-                            const mbh_f4 v0 = *reinterpret_cast<const mbh_f4*>(ep), v1 = *reinterpret_cast<const mbh_f4*>(ep + 4);
-                            const mbh_f4 w0 = *reinterpret_cast<const mbh_f4*>(pw + (ky * K + kx) * MBH_EC);
-                            const mbh_f4 w1 = *reinterpret_cast<const mbh_f4*>(pw + (ky * K + kx) * MBH_EC + 4);
-                            d0 = __builtin_elementwise_fma(v0, w0, d0);
-                            d1 = __builtin_elementwise_fma(v1, w1, d1);
+                            mbh_f4 w;
+                            if constexpr (K == 3) w = wk[ky * K + kx];
+                            else w = *reinterpret_cast<const mbh_f4*>(Pc + (ky * K + kx) * MBH_EC + cq4);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[i] = __builtin_elementwise_fma(col[i * S + kx], w, acc[i]);
                         }
-                    d0 = __builtin_elementwise_fma(d0, sd0, hd0);
-                    d1 = __builtin_elementwise_fma(d1, sd1, hd1);
-                    mbh_f8 dv;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        dv[q] = mbh_act<RELU6>(d0[q], a.act);
-                        dv[4 + q] = mbh_act<RELU6>(d1[q], a.act);
                     }
-                    const mbh_u4 df = __builtin_bit_cast(mbh_u4, __builtin_convertvector(dv, mbh_v8<T>));
+                    typedef T t4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-                    for (int c = 0; c < CT; ++c) acc_o[c][m] = mbh_mfma<T>(wpf[c], df, acc_o[c][m]);
+                    for (int i = 0; i < 4; ++i) {
+                        mbh_f4 d = __builtin_elementwise_fma(acc[i], sd, hd);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) d[q] = mbh_act<RELU6>(d[q], a.act);
+                        *reinterpret_cast<t4*>(Dw + (size_t)(rl * 4 + i) * LDD + cq4) = __builtin_convertvector(d, t4);
+                    }
+                    // same wave, program order: the patch is complete before its fragments are read (the fence keeps the
+                    // compiler from moving the reads up; LDS executes a wave's accesses in order)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const mbh_u4 df = *reinterpret_cast<const mbh_u4*>(Dw + (size_t)(tt * 16 + li) * LDD + 8 * g);
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) acc_o[c][2 * m + tt] = mbh_mfma<T>(wpf[c], df, acc_o[c][2 * m + tt]);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();    // the fragments are read before the next group overwrites the patch
                 }
             }
         }
-        if (more) store_params(Ps + ((ci + 1) & 1) * PSZ, pnext);
-        __syncthreads();   // (B) Es may be rewritten; the next chunk's parameters are visible
+        if (more) {
+            store_params(Ps + ((ci + 1) & 1) * PSZ, pnext);
+            store_w(Ws + (size_t)((ci + 1) & 1) * 32 * ldx, wnext);
+        }
+        __syncthreads();   // (B) Es may be rewritten; the next chunk's parameters and expand weights are visible
     }
 
-    // ---- 4. epilogue: project BN (+ the block input at the centre tap, from Xs) -> 16-byte stores
+    // ---- 4. epilogue: project BN (+ the block input at the centre tap, from Xs) -> 16-byte stores.
+    //      Tile 2m+tt, lane li: run (wave+4m)*8 + 4tt + (li>>2), pixel li&3 of the run.
     T* outp = reinterpret_cast<T*>(a.out) + (size_t)b * a.Ho * a.Wo * a.ld_out;
 #pragma unroll
-    for (int m = 0; m < MTO; ++m) {
-        const int mt = wave + 4 * m;
-        if (mt >= nmt_o) continue;
-        const int o = mt * 16 + li;
-        if (o >= a.OPX) continue;
-        const int oy = o / a.tw, ox = o - oy * a.tw;
+    for (int mm = 0; mm < MTO; ++mm) {
+        const int run = (wave + 4 * (mm >> 1)) * 8 + 4 * (mm & 1) + (li >> 2);
+        if (run >= nruns) continue;
+        const int oy = run / nrx, ox = (run - oy * nrx) * 4 + (li & 3);
         const int gy = oy0 + oy, gx = ox0 + ox;
         if (gy >= a.Ho || gx >= a.Wo) continue;
         T* op = outp + ((size_t)gy * a.Wo + gx) * a.ld_out;
@@ -288,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void mbh_kernel(MbhArgs a) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int nn = n + q < a.Cout ? n + q : a.Cout - 1;
-                const float acc = q < 4 ? acc_o[2 * c][m][q] : acc_o[2 * c + 1][m][q - 4];
+                const float acc = q < 4 ? acc_o[2 * c][mm][q] : acc_o[2 * c + 1][mm][q - 4];
                 v[q] = __builtin_fmaf(acc, a.sp[nn], a.hp[nn]);
             }
             if (a.has_res) {
@@ -303,10 +390,11 @@ __global__ __launch_bounds__(256, 2) void mbh_kernel(MbhArgs a) {
 
 // ------------------------------------------------------------------------------------------ host side
 static size_t mbh_lds_bytes(int ph, int kp, int k) {
-    return (((size_t)ph * (kp + 8) * 2 + 15) & ~(size_t)15) + (size_t)ph * MBH_LDE * 4 + (size_t)2 * (k * k + 4) * MBH_EC * 4;
+    return (((size_t)ph * (kp + 8) * 2 + 15) & ~(size_t)15) + (size_t)ph * MBH_LDE * 4 + (size_t)2 * (k * k + 4) * MBH_EC * 4 +
+           (size_t)2 * 32 * (kp + 8) * 2 + (size_t)4 * 32 * (MBH_EC + 8) * 2;
 }
 
-template <class T, int K, int S, int CP, int MTO>
+template <class T, int K, int S, int CP, int NG>
 static int launch_mbh(const MbhArgs& a, int batch, hipStream_t s) {
     const size_t lds = mbh_lds_bytes(a.PH, a.KP, K);
     YR_REQUIRE(lds <= 160 * 1024, "mbh: LDS tile of %zu bytes does not fit", lds);
@@ -314,61 +402,64 @@ static int launch_mbh(const MbhArgs& a, int batch, hipStream_t s) {
     int dev = 0;
     YR_CHECK_HIP(hipGetDevice(&dev));
     if (!attr_dev[dev & 63]) {
-        YR_CHECK_HIP(hipFuncSetAttribute((const void*)mbh_kernel<T, K, S, CP, MTO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        YR_CHECK_HIP(hipFuncSetAttribute((const void*)mbh_kernel<T, K, S, CP, MTO, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        YR_CHECK_HIP(hipFuncSetAttribute((const void*)mbh_kernel<T, K, S, CP, NG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        YR_CHECK_HIP(hipFuncSetAttribute((const void*)mbh_kernel<T, K, S, CP, NG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_dev[dev & 63] = true;
     }
     static char nm[56];
-    static const int nm_len = snprintf(nm, sizeof(nm), "mbh_kernel<%s,%d,%d,%d,%d>", yr_dtype_name(yr_elem<T>::dtype), K, S, CP, MTO);
+    static const int nm_len = snprintf(nm, sizeof(nm), "mbh_kernel<%s,%d,%d,%d,%d>", yr_dtype_name(yr_elem<T>::dtype), K, S, CP, NG);
     (void)nm_len;
     yr_note_kernel(nm);
     const dim3 grid((unsigned)(batch * a.tiles_x * a.tiles_y));
-    if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((mbh_kernel<T, K, S, CP, MTO, true>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((mbh_kernel<T, K, S, CP, MTO, false>), grid, dim3(256), lds, s, a);
+    if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((mbh_kernel<T, K, S, CP, NG, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((mbh_kernel<T, K, S, CP, NG, false>), grid, dim3(256), lds, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
 }
 
 template <class T, int K, int S>
-static int launch_mbh_shape(const MbhArgs& a, int cp, int mto, int batch, hipStream_t s) {
-    switch (cp * 10 + mto) {
+static int launch_mbh_shape(const MbhArgs& a, int cp, int ng, int batch, hipStream_t s) {
+    switch (cp * 10 + ng) {
         case 11: return launch_mbh<T, K, S, 1, 1>(a, batch, s);
-        case 13: return launch_mbh<T, K, S, 1, 3>(a, batch, s);
+        case 12: return launch_mbh<T, K, S, 1, 2>(a, batch, s);
         case 21: return launch_mbh<T, K, S, 2, 1>(a, batch, s);
-        case 23: return launch_mbh<T, K, S, 2, 3>(a, batch, s);
+        case 22: return launch_mbh<T, K, S, 2, 2>(a, batch, s);
         case 41: return launch_mbh<T, K, S, 4, 1>(a, batch, s);
-        case 43: return launch_mbh<T, K, S, 4, 3>(a, batch, s);
-        default: yr_set_error("mbh: no kernel for %d cout pairs x %d pixel tiles per wave", cp, mto); return YR_ERR_ARG;
+        default: yr_set_error("mbh: no kernel for %d cout pairs x %d pixel groups per wave", cp, ng); return YR_ERR_ARG;
     }
 }
 
-// Output tile th x tw for a map of ho x wo: few wasted pixels in ragged edge tiles, a small halo-to-output ratio (the
-// expand GEMM and its epilogue run on halo pixels), an LDS footprint that leaves >= 2 workgroups per CU, and enough
-// workgroups to fill 256 CUs.  op.k may force a choice: k = K | th << 8 | tw << 16.
-static void mbh_pick_tile(int ho, int wo, int batch, int k, int s, int kp, int* th_out, int* tw_out) {
+// Output tile th x tw for a map of ho x wo (tw a multiple of 4: outputs are processed in runs of 4 along x; at most
+// 128 outputs per group slot, i.e. 128 for NG = 1, 256 for NG = 2): few wasted pixels in ragged edge tiles, a small
+// halo-to-output ratio (the expand GEMM and its epilogue run on halo pixels), whole groups of 8 runs for the four waves,
+// an LDS footprint that leaves several workgroups per CU, and enough workgroups to fill 256 CUs.  The constants were
+// fitted to tools/mbh_probe.py on the MobileNetV2 block shapes.  op.k may force a choice: k = K | th << 8 | tw << 16.
+static void mbh_pick_tile(int ho, int wo, int batch, int k, int s, int kp, int cp, int* th_out, int* tw_out) {
     double best = 1e30;
     *th_out = 8; *tw_out = 8;
-    for (int th = 4; th <= 16; ++th)
-        for (int tw = 4; tw <= 16; ++tw) {
-            const int opx = th * tw;
-            if (opx > 192 || (opx > 64 && opx < 100)) continue;     // MTO = 1 (<= 64 outputs) or 3 (<= 192)
+    const int max_groups = cp >= 4 ? 4 : 8;                       // NG <= 1 for 4 cout pairs (accumulator registers)
+    for (int th = 2; th <= 16; ++th)
+        for (int tw = 4; tw <= 32; tw += 4) {
+            const int runs = th * (tw / 4), groups = (runs + 7) / 8;
+            if (groups > max_groups) continue;
             const int ih = (th - 1) * s + k, iw = (tw - 1) * s + k, ph = ih * iw;
             const size_t lds = mbh_lds_bytes(ph, kp, k);
-            if (lds > 76 * 1024) continue;                            // two workgroups per CU
+            if (lds > 78 * 1024) continue;                            // at least two workgroups per CU
             const int ty = (ho + th - 1) / th, tx = (wo + tw - 1) / tw;
             const double blocks = (double)batch * ty * tx;
-            const int nmt_h = (ph + 15) / 16, nmt_o = (opx + 15) / 16;
-            // work per block in MFMA-tile units: expand on the halo (rounded to whole tiles over 4 waves) + dw/project
-            const double per_block = ((nmt_h + 3) / 4) * 1.0 + ((nmt_o + 3) / 4) * 1.6;
-            const int per_cu = lds <= 50 * 1024 ? 3 : 2;
+            const int nmt_h = (ph + 15) / 16;
+            // work per block: expand on the halo (whole MFMA tiles over 4 waves) + depthwise/project (whole groups over 4 waves)
+            const double per_block = ((nmt_h + 3) / 4) * 1.0 + ((groups + 3) / 4) * 3.0 + 1.5;
+            const int per_cu = lds <= 31 * 1024 ? 5 : lds <= 39 * 1024 ? 4 : lds <= 52 * 1024 ? 3 : 2;
             const double rounds = blocks / (256.0 * per_cu);
-            const double cost = per_block * (rounds < 1.0 ? 1.0 : rounds) * (per_cu == 3 ? 1.0 : 1.15);
+            const double occ = per_cu >= 4 ? 1.0 : per_cu == 3 ? 1.08 : 1.25;
+            const double cost = per_block * (rounds < 1.0 ? 1.0 : rounds) * occ;
             if (cost < best) { best = cost; *th_out = th; *tw_out = tw; }
         }
 }
 
 // op fields (YR_OP_MBH): src[0] = block input (16-bit, ld % 8 == 0); cin; se_reduced = expanded width Cexp; cout <= 128;
-// k = K (3 | 5), optionally | th << 8 | tw << 16 to force the output tile; stride 1 | 2; act = expand / depthwise
+// k = K (3 | 5), optionally | th << 8 | tw << 16 to force the output tile (tw % 4 == 0); stride 1 | 2; act = expand / depthwise
 // activation; res (optional) = the block input itself (stride 1, cin == cout).  With CexpP = round_up(Cexp, 32),
 // KP = round_up(cin, 32), everything zero padded:
 //   wgt  = expand Wt[CexpP][KP] (16-bit, in the blob: CexpP*KP/2 floats);
@@ -400,19 +491,21 @@ static int launch_mbh_t(const yr_op& op, int batch, hipStream_t s) {
     a.has_res = op.res != nullptr;
     if (a.has_res) YR_REQUIRE(op.res == in.ptr && op.stride == 1 && in.c == op.cout, "mbh: the residual must be the block input (stride 1, cin == cout)");
     a.act = op.act;
+    const int cp = op.cout <= 32 ? 1 : (op.cout <= 64 ? 2 : 4);
     if (fth && ftw) { a.th = fth; a.tw = ftw; }
-    else mbh_pick_tile(a.Ho, a.Wo, batch, K, op.stride, a.KP, &a.th, &a.tw);
+    else mbh_pick_tile(a.Ho, a.Wo, batch, K, op.stride, a.KP, cp, &a.th, &a.tw);
     a.OPX = a.th * a.tw;
-    YR_REQUIRE(a.OPX >= 1 && a.OPX <= 192, "mbh: output tile %dx%d out of range (<= 192 pixels)", a.th, a.tw);
+    const int groups = (a.th * (a.tw / 4) + 7) / 8;
+    YR_REQUIRE(a.tw % 4 == 0 && a.th >= 1 && groups >= 1 && groups <= (cp >= 4 ? 4 : 8),
+               "mbh: output tile %dx%d unsupported (tw %% 4 == 0, at most %d pixels)", a.th, a.tw, cp >= 4 ? 128 : 256);
     a.ih = (a.th - 1) * op.stride + K; a.iw = (a.tw - 1) * op.stride + K; a.PH = a.ih * a.iw;
     a.tiles_x = (a.Wo + a.tw - 1) / a.tw; a.tiles_y = (a.Ho + a.th - 1) / a.th;
     YR_REQUIRE((long long)batch * a.tiles_x * a.tiles_y < (1ll << 31), "mbh: grid too large");
-    const int cp = op.cout <= 32 ? 1 : (op.cout <= 64 ? 2 : 4);
-    const int mto = a.OPX <= 64 ? 1 : 3;
-    if (K == 3 && op.stride == 1) return launch_mbh_shape<T, 3, 1>(a, cp, mto, batch, s);
-    if (K == 3 && op.stride == 2) return launch_mbh_shape<T, 3, 2>(a, cp, mto, batch, s);
-    if (K == 5 && op.stride == 1) return launch_mbh_shape<T, 5, 1>(a, cp, mto, batch, s);
-    return launch_mbh_shape<T, 5, 2>(a, cp, mto, batch, s);
+    const int ng = groups <= 4 ? 1 : 2;
+    if (K == 3 && op.stride == 1) return launch_mbh_shape<T, 3, 1>(a, cp, ng, batch, s);
+    if (K == 3 && op.stride == 2) return launch_mbh_shape<T, 3, 2>(a, cp, ng, batch, s);
+    if (K == 5 && op.stride == 1) return launch_mbh_shape<T, 5, 1>(a, cp, ng, batch, s);
+    return launch_mbh_shape<T, 5, 2>(a, cp, ng, batch, s);
 }
 
 int yr_launch_mbh(const yr_op& op, int batch, hipStream_t s) {

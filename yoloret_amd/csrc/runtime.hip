@@ -201,8 +201,9 @@ extern "C" int yr_set_tuning(yr_handle* h, int batch, const int32_t* cfg, int n)
     std::vector<int> t(n, 0);
     for (int i = 0; i < n; ++i) {
         const int ncfg = yr_pointwise_num_cfgs(h->ops[i].dtype);
-        YR_REQUIRE(cfg[i] >= 0 && cfg[i] <= ncfg && (cfg[i] == 0 || h->ops[i].kind == YR_OP_POINTWISE),
-                   "yr_set_tuning: entry %d = %d is not a valid tile shape for that op", i, cfg[i]);
+        const bool pw_ok = cfg[i] >= 0 && cfg[i] <= ncfg && (cfg[i] == 0 || h->ops[i].kind == YR_OP_POINTWISE);
+        const bool mbh_ok = h->ops[i].kind == YR_OP_MBH && cfg[i] >= 0 && (cfg[i] & 0xff) == 0 && cfg[i] < (1 << 24);   // th << 8 | tw << 16
+        YR_REQUIRE(pw_ok || mbh_ok, "yr_set_tuning: entry %d = %d is not a valid tile shape for that op", i, cfg[i]);
         t[i] = cfg[i];
     }
     h->tuned[batch] = t;
@@ -227,6 +228,9 @@ static int resolve_op(const yr_handle* h, size_t i, int batch, float* const ext[
     if (op.kind == YR_OP_POINTWISE) {
         auto it = h->tuned.find(batch);
         op.k = it != h->tuned.end() ? it->second[i] : 0;
+    } else if (op.kind == YR_OP_MBH) {   // the tuned output tile (th << 8 | tw << 16) rides in the upper bytes of k
+        auto it = h->tuned.find(batch);
+        if (it != h->tuned.end()) op.k = (op.k & 0xff) | it->second[i];
     }
     *out = op;
     return YR_OK;
@@ -322,6 +326,33 @@ extern "C" int yr_autotune(yr_handle* h, const float* images, int batch, float* 
     YR_CHECK_HIP(hipEventCreate(&e1));
     std::vector<int> best(h->ops.size(), 0);
     for (size_t i = 0; i < h->ops.size() && rc == YR_OK; ++i) {
+        if (h->ops[i].kind == YR_OP_MBH) {
+            // fused 16-bit block: time a fixed list of output tiles (runs of 4 along x: tw % 4 == 0); tiles the op
+            // cannot take (too many pixels for its accumulators, LDS footprint) are refused by the launcher and skipped
+            static const int tiles[][2] = {{4, 8}, {8, 4}, {7, 4}, {7, 8}, {8, 8}, {13, 4}, {4, 16}, {8, 16}, {7, 16}, {13, 8},
+                                           {16, 8}, {13, 16}, {8, 12}, {7, 12}, {13, 12}, {16, 12}, {16, 16}, {4, 12}, {6, 8}};
+            yr_op op;
+            rc = resolve_op(h, i, batch, ext, static_cast<char*>(workspace), &op);
+            if (rc) break;
+            const int kk = op.k & 0xff;
+            float best_ms = 1e30f;
+            int best_cfg = 0;
+            for (int pass = 0; pass < 2; ++pass)                 // two passes, minimum: one noisy sample must not decide
+                for (int c = -1; c < (int)(sizeof(tiles) / sizeof(tiles[0])); ++c) {
+                    const int cfg = c < 0 ? 0 : (tiles[c][0] << 8) | (tiles[c][1] << 16);
+                    op.k = kk | cfg;
+                    if (dispatch(op, batch, s) != YR_OK) continue;          // warm-up / validity
+                    YR_CHECK_HIP(hipEventRecord(e0, s));
+                    for (int it = 0; it < iters; ++it) (void)dispatch(op, batch, s);
+                    YR_CHECK_HIP(hipEventRecord(e1, s));
+                    YR_CHECK_HIP(hipEventSynchronize(e1));
+                    float ms = 0.f;
+                    YR_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+                    if (ms < best_ms * 0.98f) { best_ms = ms; best_cfg = cfg; }
+                }
+            best[i] = best_cfg;
+            continue;
+        }
         if (h->ops[i].kind != YR_OP_POINTWISE) continue;
         const int ncfg = yr_pointwise_num_cfgs(h->ops[i].dtype);
         yr_op op;
