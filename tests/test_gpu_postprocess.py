@@ -190,3 +190,33 @@ def test_decode_zoom_tta_bit_exact(dev, hw, c, image_shapes):
     assert np.array_equal(bx.cpu().numpy(), boxes[0, :n0]) and np.array_equal(sc.cpu().numpy(), scores[0, :, :n0].T)
     with pytest.raises(ValueError):
         rt.decode(yd, ANCHORS, c, ihw, hw, zoom_ys=[zd[0], zd[0], zd[2]])
+
+
+@pytest.mark.parametrize('kind', ['uniform', 'dense_top', 'duplicates', 'ties', 'one_bin'])
+def test_nms_with_more_candidates_than_the_first_pass_list(dev, kind):
+    """More candidates above the score threshold than the first launch's list holds (5200): it keeps the highest-scoring
+    ones (histogram cut) and must still return exactly the oracle's picks - falling back to the full-capacity launch
+    when the kept list runs dry before max_boxes picks (heavy suppression) or when scores pile up in one histogram bin."""
+    rt = _rt()
+    rng = np.random.default_rng({'uniform': 1, 'dense_top': 2, 'duplicates': 3, 'ties': 4, 'one_bin': 5}[kind])
+    n, c, b = 10647, 3, 2
+    boxes = np.stack([_random_boxes(rng, n) for _ in range(b)])
+    scores = (0.2 + 0.8 * rng.random((b, c, n))).astype(np.float32)          # every box is a candidate
+    if kind == 'dense_top':
+        scores = (1.0 - 1e-3 * rng.random((b, c, n))).astype(np.float32)     # all within the top two bins
+    elif kind == 'duplicates':                                                # a few distinct boxes: everything suppressed
+        proto = _random_boxes(rng, 7, degenerate=False)
+        boxes = np.stack([proto[rng.integers(0, 7, n)] for _ in range(b)])
+    elif kind == 'ties':
+        scores = (np.round(scores * 64) / 64).astype(np.float32)
+    elif kind == 'one_bin':
+        scores = np.full((b, c, n), 0.75, np.float32)                        # one value: index order decides
+    idx, cnt = rt.nms(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), 20, 0.2, 0.5)
+    torch.cuda.synchronize()
+    idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
+    for i in range(b):
+        for k in range(c):
+            ref = cpost.nms(boxes[i], scores[i, k], 20, 0.5, 0.2)
+            assert cnt[i, k] == len(ref), (kind, i, k, cnt[i, k], len(ref))
+            assert np.array_equal(idx[i, k, :len(ref)], ref), (kind, i, k)
+            assert (idx[i, k, len(ref):] == -1).all()
