@@ -87,9 +87,14 @@ typedef struct {
 typedef enum {
     YR_OP_STEM = 1,      /* Conv2D 3x3 s2 Cin=3 + BN + act            (MobileNetV2 Conv1 [3P]; efficientnet.py:636-645) */
     YR_OP_POINTWISE = 2, /* Conv2D 1x1 (+bias)(+BN)(+act)(+residual)  (model.py:25-30,98-114,152-155,243-251; efficientnet.py:485-496,517-533) */
-    YR_OP_DEPTHWISE = 3, /* DepthwiseConv2D k3/k5 s1/s2 SAME + BN + act (model.py:20-24; efficientnet.py:501-510) */
+    YR_OP_DEPTHWISE = 3, /* DepthwiseConv2D k3/k5 s1/s2 SAME + BN + act (model.py:20-24; efficientnet.py:501-510).  With `gate` set (SE
+                            form; needs 256 % ceil(c / V) == 0): the kernel ALSO writes per-workgroup channel sums of its output to
+                            gate = float32 [B][se_reduced rows][gate_ld] - the squeeze of squeeze-excite (efficientnet.py:417) as an
+                            epilogue; an SE_FC op with k = H*W adds the rows up instead of re-reading the map */
     YR_OP_SE_MEAN = 4,   /* Mean over H,W                              (efficientnet.py:391-403,417) */
-    YR_OP_SE_FC = 5,     /* 1x1+bias -> Swish -> 1x1+bias -> sigmoid   (efficientnet.py:419-434) */
+    YR_OP_SE_FC = 5,     /* 1x1+bias -> Swish -> 1x1+bias -> sigmoid   (efficientnet.py:419-434).  Source: the pooled vector (h*w == 1,
+                            float32), or a map to pool first (SE_MEAN merged in), or - k > 0 - float32 rows of partial channel
+                            sums [B][h*w][ld] to add up and divide by k (the depthwise SE form above) */
     YR_OP_WSUM = 6,      /* WeightedSum of 4 gathered sources          (model.py:117-137,157) */
     YR_OP_GATHER = 7,    /* materialise upsample/maxpool/concat        (standalone K5; testing / unfused use) */
     YR_OP_MBCONV = 8,    /* fused inverted-residual block: expand 1x1+BN+act -> DW3x3+BN+act -> project 1x1+BN (+residual)

@@ -479,3 +479,77 @@ def test_policy_and_dtype_plumbing(dev):
         L.set_global_policy('int8')
     with pytest.raises(ValueError):
         Model(m32.inputs, m32.outputs, dtype='float64')
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('k,s,h,w,c,r', [(3, 1, 13, 13, 512, 128), (3, 1, 26, 26, 256, 64), (3, 1, 52, 52, 128, 32), (5, 1, 13, 9, 64, 4),
+                                         (3, 2, 27, 26, 128, 8), (5, 2, 14, 14, 256, 16)])
+def test_depthwise_se_form(dev, dt, k, s, h, w, c, r):
+    """The squeeze of squeeze-excite as an epilogue of the depthwise conv (efficientnet.py:417 after :501-510): the SE
+    form writes the same map as the plain op, bit for bit, plus per-workgroup channel sums; SE_FC (k = pixel count) on
+    those rows gives the oracle's gate.  All three element types (float32: the head blocks of the headline config)."""
+    rt = _rt()
+    did = rt.dtype_id(dt)
+    V = rt.VEC[did]
+    rng = np.random.default_rng(k * 100 + c + r)
+    b = 3
+    x = rng.standard_normal((b, h, w, c)).astype(np.float32)
+    if dt != 'f32':
+        x = q16(x, dt)
+    wk = (rng.standard_normal((k, k, c)) * np.sqrt(2.0 / (k * k))).astype(np.float32)
+    scale, shift = rng.uniform(0.5, 1.5, c).astype(np.float32), rng.normal(0, 0.3, c).astype(np.float32)
+    ldc = round_up(c, V)
+    wp = np.zeros((k * k, ldc), np.float32); wp[:, :c] = wk.reshape(k * k, c)
+    pad = lambda v: np.concatenate([v, np.zeros(ldc - c, np.float32)])
+    tdt = rt.TORCH_DTYPE[did]
+    xd = torch.from_numpy(x).to(dev) if dt == 'f32' else to_dev16(x, dev, dt)
+    ho, wo = -(-h // s), -(-w // s)
+    keep = [_dev_vec(wp, dev), _dev_vec(pad(scale), dev), _dev_vec(pad(shift), dev)]
+
+    def dw(gate=None, rows=0):
+        out = torch.full((b, ho, wo, ldc), float('nan'), dtype=tdt, device=dev)
+        op = rt.new_op(rt.OP_DEPTHWISE, 'swish')
+        op.dtype = op.out_dtype = did
+        op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc = ho, wo, c, c, k, s, 1
+        op.src[0] = rt.make_src(xd, c=c)
+        op.wgt, op.scale, op.shift = [t.data_ptr() for t in keep]
+        op.out, op.out_ld = out.data_ptr(), ldc
+        if gate is not None:
+            op.gate, op.gate_ld, op.se_reduced = gate.data_ptr(), gate.shape[2], rows
+        rt.run_op(op, b)
+        torch.cuda.synchronize()
+        return out
+    plain = dw()
+    c4 = (c + V - 1) // V
+    xt = 4 if s == 1 else 2
+    rows = (ho * ((wo + xt - 1) // xt) * c4 + 255) // 256
+    part = torch.full((b, rows, ldc), float('nan'), dtype=torch.float32, device=dev)
+    fused = dw(part, rows)
+    assert torch.equal(plain.view(torch.int16 if dt != 'f32' else torch.int32), fused.view(torch.int16 if dt != 'f32' else torch.int32))
+    stored = plain.float().cpu().numpy()[..., :c].astype(np.float64)       # the mean is that of the stored values
+    sums = part.cpu().numpy()[..., :c].astype(np.float64).sum(axis=1)
+    assert np.abs(sums - stored.sum(axis=(1, 2))).max() <= 2e-5 * max(1.0, np.abs(stored).sum(axis=(1, 2)).max())
+    # SE_FC on the rows
+    w1 = (rng.standard_normal((c, r)) * np.sqrt(1.0 / c)).astype(np.float32)
+    b1 = rng.normal(0, 0.1, r).astype(np.float32)
+    w2 = (rng.standard_normal((r, c)) * np.sqrt(1.0 / r)).astype(np.float32)
+    b2 = rng.normal(0, 0.1, c).astype(np.float32)
+    mean = stored.mean(axis=(1, 2))
+    ref = nn.sigmoid(nn.swish(mean.dot(w1.astype(np.float64)) + b1).dot(w2.astype(np.float64)) + b2)
+    l4 = round_up(c, 4)
+    w1t = np.zeros((r, l4), np.float32); w1t[:, :c] = w1.T
+    w2p = np.zeros((r, l4), np.float32); w2p[:, :c] = w2
+    b2p = np.zeros(l4, np.float32); b2p[:c] = b2
+    k2 = [_dev_vec(w1t, dev), _dev_vec(b1, dev), _dev_vec(w2p, dev), _dev_vec(b2p, dev)]
+    gate = torch.full((b, ldc), float('nan'), dtype=torch.float32, device=dev)
+    op = rt.new_op(rt.OP_SE_FC)
+    op.dtype, op.out_dtype = did, 0
+    op.h = op.w = 1
+    op.cin = op.cout = c
+    op.se_reduced, op.nsrc, op.k = r, 1, ho * wo
+    op.src[0] = rt.make_src(part.view(b, rows, 1, ldc), c=c)
+    op.wgt, op.b1, op.wgt2, op.b2 = [t.data_ptr() for t in k2]
+    op.out, op.out_ld = gate.data_ptr(), ldc
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    assert np.abs(gate.cpu().numpy()[:, :c] - ref).max() <= 2e-5

@@ -97,6 +97,8 @@ class Plan:
             for b in (op.res, op.gate):
                 if b is not None:
                     b.last_use = max(b.last_use, i)
+                    if b is op.gate and op.kind == rt.OP_DEPTHWISE and b.first_def is None:
+                        b.first_def = i          # SE form: the depthwise op WRITES its per-workgroup channel sums there
         self.bufs = [b for b in self.bufs if b.first_def is not None]
         for i, b in enumerate(self.bufs):
             b.id = i
@@ -341,6 +343,38 @@ def merge_se_mean(ops):
             fc.merged_mean = op.cout     # the accounting still charges the mean its C outputs
             drop.add(id(op))
     return [op for op in ops if id(op) not in drop]
+
+
+SE_PARTIALS = os.environ.get('YOLORET_SE_PARTIALS', '1') != '0'
+
+
+def se_partials_from_depthwise(ops, bufs):
+    """the squeeze of squeeze-excite (tf.reduce_mean over H, W; efficientnet.py:417) as an epilogue of
+    the depthwise conv that produces the map.  The SE_FC op with the merged mean re-reads the whole map for it (one
+    workgroup per image: 54 MB per launch on the 52x52 head block); here every workgroup of the depthwise kernel adds up
+    the outputs it has just computed, per channel, in a fixed order, and writes one float32 row; SE_FC adds the rows up
+    and divides by the pixel count.  Needs all channel vectors of a pixel strip inside one workgroup: 256 % C4 == 0."""
+    producer = {}
+    for op in ops:
+        producer[id(op.out)] = op
+    for fc in ops:
+        if fc.kind != rt.OP_SE_FC or not getattr(fc, 'merged_mean', 0) or len(fc.srcs) != 1:
+            continue
+        d = producer.get(id(fc.srcs[0].buf))
+        if d is None or d.kind != rt.OP_DEPTHWISE or d.gate is not None or d.k not in (3, 5) or d.stride not in (1, 2):
+            continue
+        v = rt.VEC[d.dtype]
+        c4 = (d.cout + v - 1) // v
+        if c4 > 256 or 256 % c4:
+            continue
+        xt = 4 if d.stride == 1 else 2
+        rows = (d.h * ((d.w + xt - 1) // xt) * c4 + 255) // 256          # == dw_se_blocks() in depthwise.hip
+        part = Buf(len(bufs), rows, 1, d.cout, round_up(d.cout, v), name=d.name + ':se_sums', dtype=0)
+        bufs.append(part)
+        d.gate, d.se_reduced = part, rows
+        fc.srcs = [Seg(part, d.cout, 'identity')]
+        fc.k = d.h * d.w                                                 # what the summed rows are divided by
+    return ops
 
 
 POOL_IN_PRODUCER = os.environ.get('YOLORET_POOL_FUSE', '1') != '0'
@@ -794,6 +828,8 @@ class Compiler:
             latency = self.fuse == 'latency'
             if MERGE_SE_MEAN and not latency:
                 ops = merge_se_mean(ops)
+                if SE_PARTIALS:
+                    ops = se_partials_from_depthwise(ops, self.bufs)
             ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency, dtype=self.dtype)
             if FOLD_DW and not latency and self.dtype == 0:
                 ops = fold_depthwise_into_project(ops, set(b.id for b in outs))

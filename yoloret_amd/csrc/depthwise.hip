@@ -26,8 +26,13 @@ struct DwArgs {
     int pad_t, pad_l;
     int act;
     int xstrips, ystrips;  // ceil(Wo / XT), ceil(Ho / YT)
-    long long total;       // B*ystrips*xstrips*C4
+    long long total;       // B*ystrips*xstrips*C4  (SE form: per image)
     unsigned nblocks;
+    // SE form (squeeze-excite squeeze fused in, efficientnet.py:417): grid = (workgroups per image, B); every workgroup
+    // also writes the sums of ITS outputs per channel to part[b][blockIdx.x][..] (float32, fixed order: deterministic);
+    // the SE_FC op adds the workgroups' rows up instead of re-reading the whole map.  Needs 256 % C4 == 0.
+    float* part;
+    int ld_part;
 };
 
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
@@ -60,17 +65,24 @@ __device__ __forceinline__ void dw_store(T* p, const float4 (&v)[Q]) {
     }
 }
 
-template <int K, int S, int XT, int YT, class T>
+template <int K, int S, int XT, int YT, class T, bool SE = false>
 __global__ __launch_bounds__(256) void dw_kernel(DwArgs<T> a) {
     constexpr int Q = yr_elem<T>::vec / 4;   // channel quads per lane
-    const long long gid = (long long)yr_xcd_swizzle(blockIdx.x, a.nblocks) * 256 + threadIdx.x;
-    if (gid >= a.total) return;
+    __shared__ float4 red[SE ? 256 * Q : 1];
+    // SE: grid (workgroups per image, B), walked in XCD-contiguous order like the plain form (adjacent strips share input rows)
+    const unsigned lin = SE ? yr_xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y) : 0u;
+    const unsigned se_b = SE ? lin / gridDim.x : 0u, se_blk = SE ? lin - se_b * gridDim.x : 0u;
+    long long gid = SE ? (long long)se_blk * 256 + threadIdx.x
+                       : (long long)yr_xcd_swizzle(blockIdx.x, a.nblocks) * 256 + threadIdx.x;
+    const bool live = gid < a.total;
+    if (!SE && !live) return;
+    if (!live) gid = a.total - 1;            // SE: idle lanes of an image's last workgroup still take part in the reduction
     const int cq = (int)(gid % a.C4);
     long long t = gid / a.C4;
     const int xs = (int)(t % a.xstrips);
     t /= a.xstrips;
     const int ys = (int)(t % a.ystrips);
-    const int b = (int)(t / a.ystrips);
+    const int b = SE ? (int)se_b : (int)(t / a.ystrips);
     const int c = cq * 4 * Q;
     const int x0 = xs * XT, y0 = ys * YT;
     constexpr int COLS = (XT - 1) * S + K;
@@ -124,6 +136,9 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs<T> a) {
         sc[q] = *reinterpret_cast<const float4*>(a.scale + c + 4 * q);
         sh[q] = *reinterpret_cast<const float4*>(a.shift + c + 4 * q);
     }
+    float4 psum[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) psum[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < YT; ++j) {
         if (y0 + j >= a.Ho) continue;
@@ -134,10 +149,61 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs<T> a) {
                 float4 v[Q];
 #pragma unroll
                 for (int q = 0; q < Q; ++q) v[q] = yr_apply_act4(fma4(acc[j][i][q], sc[q], sh[q]), a.act);
-                dw_store<T, Q>(op + (size_t)i * a.ld_out, v);
+                if (!SE || live) dw_store<T, Q>(op + (size_t)i * a.ld_out, v);
+                if constexpr (SE) {
+                    if constexpr (Q == 2) {   // the mean is that of the STORED (rounded) values
+                        typedef T t8 __attribute__((ext_vector_type(8)));
+                        typedef float f8 __attribute__((ext_vector_type(8)));
+                        const f8 rv = __builtin_convertvector(__builtin_convertvector((f8){v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w}, t8), f8);
+                        v[0] = make_float4(rv[0], rv[1], rv[2], rv[3]);
+                        v[1] = make_float4(rv[4], rv[5], rv[6], rv[7]);
+                    }
+                    if (live) {
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) { psum[q].x += v[q].x; psum[q].y += v[q].y; psum[q].z += v[q].z; psum[q].w += v[q].w; }
+                    }
+                }
             }
         }
     }
+    if constexpr (SE) {
+        // lanes l, l + C4, l + 2*C4 ... of the workgroup hold the same channel quad (256 % C4 == 0): add them in index order
+#pragma unroll
+        for (int q = 0; q < Q; ++q) red[threadIdx.x * Q + q] = psum[q];
+        __syncthreads();
+        if ((int)threadIdx.x < a.C4) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                float4 s = red[threadIdx.x * Q + q];
+                for (int l = threadIdx.x + a.C4; l < 256; l += a.C4) {
+                    const float4 v = red[l * Q + q];
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+                *reinterpret_cast<float4*>(a.part + ((size_t)b * gridDim.x + se_blk) * a.ld_part + (threadIdx.x * Q + q) * 4) = s;
+            }
+        }
+    }
+}
+
+// workgroups per image of the SE form (the compiler sizes the partial-sum buffer with the same formula)
+static inline int dw_se_blocks(int ho, int wo, int c4, int xt) { return (int)(((long long)ho * ((wo + xt - 1) / xt) * c4 + 255) / 256); }
+
+template <int K, int S, int XT, class T>
+static int launch_dw_se(DwArgs<T> a, int expect_blocks, hipStream_t s) {
+    a.xstrips = (a.Wo + XT - 1) / XT;
+    a.ystrips = a.Ho;
+    a.total = (long long)a.ystrips * a.xstrips * a.C4;
+    const int blocks = dw_se_blocks(a.Ho, a.Wo, a.C4, XT);
+    YR_REQUIRE(blocks == expect_blocks && 256 % a.C4 == 0, "depthwise: the SE partial-sum buffer must hold %d rows per image (has %d); 256 %% C4 == 0 required",
+               blocks, expect_blocks);
+    a.nblocks = (unsigned)blocks;
+    static char nm[48];
+    static const int nm_len = snprintf(nm, sizeof(nm), "dw_kernel<%d,%d,%d,1,%s,se>", K, S, XT, yr_dtype_name(yr_elem<T>::dtype));
+    (void)nm_len;
+    yr_note_kernel(nm);
+    hipLaunchKernelGGL((dw_kernel<K, S, XT, 1, T, true>), dim3((unsigned)blocks, a.B), dim3(256), 0, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
 }
 
 template <int K, int S, int XT, int YT, class T>
@@ -184,6 +250,16 @@ static int launch_depthwise_t(const yr_op& op, int batch, hipStream_t s) {
     a.pad_t = (pth > 0 ? pth : 0) / 2;
     a.pad_l = (ptw > 0 ? ptw : 0) / 2;
     a.act = op.act;
+    a.part = nullptr; a.ld_part = 0;
+    if (op.gate) {   // SE form: `gate` is an OUTPUT here - float32 [B][workgroups per image][gate_ld] channel sums
+        YR_REQUIRE(op.gate_ld % 4 == 0 && op.gate_ld >= yr_round_up(in.c, V) && ((uintptr_t)op.gate % 16) == 0, "depthwise: bad SE partial-sum buffer");
+        a.part = const_cast<float*>(op.gate); a.ld_part = op.gate_ld;
+        const int rows = op.se_reduced;     // rows per image the buffer was sized for
+        if (op.k == 3 && op.stride == 1) return launch_dw_se<3, 1, 4, T>(a, rows, s);
+        if (op.k == 3 && op.stride == 2) return launch_dw_se<3, 2, 2, T>(a, rows, s);
+        if (op.k == 5 && op.stride == 1) return launch_dw_se<5, 1, 4, T>(a, rows, s);
+        return launch_dw_se<5, 2, 2, T>(a, rows, s);
+    }
     // small maps (13x13, 26x26) keep 1-row patches so the grid still fills the chip
     const bool big = (long long)batch * a.Ho * a.Wo * a.C4 >= (1ll << 21);
     // stride 1: 4x1 patches beat 4x2, 2x1, 2x2, 8x1 and 13x1 on every 13/26/52 map of the flagship (tools/dw_probe.py):

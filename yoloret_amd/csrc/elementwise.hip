@@ -88,6 +88,9 @@ template <class T>
 struct FcArgs {
     const T* map;       // HW > 1: the full map [B][HW][ld_map] (element type T) whose spatial mean is the FC input (SE_MEAN merged in)
     int HW, ld_map;
+    int pool;           // 1: `map` rows are added up and divided by `count` first; 0: `mean` is the pooled vector already
+    float count;        // what the pooled sums are divided by: HW, or the true pixel count when `map` holds per-workgroup
+                        // partial sums written by the SE form of the depthwise kernel
     const float* mean;  // [B][ld_mean]
     const float* w1t;   // [R][ldc]   (transposed Keras kernel: hidden j, channel c)
     const float* b1;    // [R]
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(SE_FC_THREADS) void se_fc_kernel(FcArgs<T> a) {
     float* hid = sm + a.ldc;          // [R]
     float* part = hid + a.R;          // [SE_FC_THREADS]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (a.HW > 1) {
+    if (a.pool) {
         // tf.reduce_mean over H,W first (the SE_MEAN op merged into this launch).  All channel quads at once:
         // C4P = next power of two >= C4 quads x (1024 / C4P) pixel lanes, then one fixed-order combine over the
         // pixel lanes (deterministic; the summation grouping differs from se_mean_kernel's by fp32 rounding only).
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(SE_FC_THREADS) void se_fc_kernel(FcArgs<T> a) {
                     const float4 v = red[i * c4p + tid];
                     t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
                 }
-                const float n = (float)a.HW;
+                const float n = a.count;
                 const int c = cq * 4;
                 mean[c] = t.x / n;
                 if (c + 1 < a.ldc) mean[c + 1] = c + 1 < a.C ? t.y / n : 0.f;
@@ -195,12 +198,14 @@ static int launch_se_fc_t(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(op.out_dtype == YR_F32, "se_fc: the gate is float32");
     FcArgs<T> a;
     a.map = (const T*)in.ptr; a.HW = in.h * in.w; a.ld_map = in.ld;   // h*w > 1: the pooled vector is computed here (SE_MEAN merged)
-    YR_REQUIRE(a.HW == 1 ? in.dtype == YR_F32 : in.dtype == op.dtype, "se_fc: a pooled vector is float32, a map to pool has the op's dtype");
-    YR_REQUIRE(a.HW == 1 || (in.ld % yr_elem<T>::vec == 0 && ((uintptr_t)in.ptr % 16) == 0), "se_fc: the map to pool must be 16-byte addressable per pixel");
+    a.count = op.k > 0 ? (float)op.k : (float)a.HW;                   // k: pixel count when the rows are partial sums, not pixels
+    a.pool = (a.HW > 1 || op.k > 0) ? 1 : 0;
+    YR_REQUIRE((a.HW == 1 || op.k > 0) ? in.dtype == YR_F32 : in.dtype == op.dtype, "se_fc: a pooled vector / partial sums are float32, a map to pool has the op's dtype");
+    YR_REQUIRE((a.HW == 1 && op.k <= 0) || (in.ld % yr_elem<T>::vec == 0 && ((uintptr_t)in.ptr % 16) == 0), "se_fc: the map to pool must be 16-byte addressable per pixel");
     a.mean = (const float*)in.ptr; a.w1t = op.wgt; a.b1 = op.b1; a.w2 = op.wgt2; a.b2 = op.b2; a.gate = (float*)op.out;
     a.C = in.c; a.R = op.se_reduced; a.ldc = yr_round_up(in.c, 4); a.ld_mean = in.ld; a.ld_gate = op.out_ld;
     YR_REQUIRE(op.out_ld >= a.ldc, "se_fc: gate ld too small");
-    const size_t lds = (size_t)((a.ldc + a.R + SE_FC_THREADS + 3) & ~3) * sizeof(float) + (a.HW > 1 ? SE_FC_THREADS * sizeof(float4) : 0);
+    const size_t lds = (size_t)((a.ldc + a.R + SE_FC_THREADS + 3) & ~3) * sizeof(float) + (a.pool ? SE_FC_THREADS * sizeof(float4) : 0);
     YR_REQUIRE(lds <= 64 * 1024, "se_fc: widths too large for LDS");
     static char nm[32];
     static const int nm_len = snprintf(nm, sizeof(nm), "se_fc_kernel<%s>", yr_dtype_name(yr_elem<T>::dtype));
@@ -211,8 +216,8 @@ static int launch_se_fc_t(const yr_op& op, int batch, hipStream_t s) {
     return YR_OK;
 }
 int yr_launch_se_fc(const yr_op& op, int batch, hipStream_t s) {
-    // a pooled vector (h*w == 1) is float32 whatever the plan's dtype: one instantiation serves it
-    if (op.nsrc == 1 && op.src[0].h * op.src[0].w == 1) return launch_se_fc_t<float>(op, batch, s);
+    // a pooled vector (h*w == 1) and per-workgroup partial sums (k > 0) are float32 whatever the plan's dtype
+    if (op.nsrc == 1 && (op.src[0].h * op.src[0].w == 1 || op.k > 0)) return launch_se_fc_t<float>(op, batch, s);
     return YR_BY_DTYPE(op.dtype, launch_se_fc_t, op, batch, s);
 }
 
