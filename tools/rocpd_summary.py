@@ -8,13 +8,72 @@ import sqlite3
 import sys
 
 
+import re
+
+
+def demangle_simple(m):
+    """'_Z10mbh_kernelIDF16bLi3ELi2ELi4ELi1ELb1EEv7MbhArgs' -> 'mbh_kernel<bf16,3,2,4,1,1>': the template arguments this
+    library's kernels take (element types, ints, bools).  rocprofv3's own demangler garbles __bf16 / _Float16 arguments
+    ('mbh_kernel<bool _Accum, int, ELi, E, 1, 1, true>'), so the symbol table's mangled names are decoded here."""
+    r = re.match(r'^_Z(\d+)', m)
+    if not r:
+        return None
+    n = int(r.group(1))
+    pos = r.end() + n
+    name = m[r.end():pos]
+    if pos >= len(m) or m[pos] != 'I':
+        return name
+    pos += 1
+    args = []
+    while pos < len(m) and m[pos] != 'E':
+        if m.startswith('DF16b', pos):
+            args.append('bf16'); pos += 5
+        elif m.startswith('DF16_', pos):
+            args.append('f16'); pos += 5
+        elif m[pos] == 'f':
+            args.append('f32'); pos += 1
+        elif m[pos] == 'L':
+            q = re.match(r'L([ib])(n?)(\d+)E', m[pos:])
+            if not q:
+                return None
+            args.append(('-' if q.group(2) else '') + q.group(3)); pos += q.end()
+        else:
+            return None
+    return '%s<%s>' % (name, ','.join(args))
+
+
+_pretty = {}
+
+
+def load_symbols(c):
+    """display name -> decoded name for the kernels whose display name rocprofv3 garbled."""
+    try:
+        rows = c.execute('select kernel_name, display_name from rocpd_info_kernel_symbol').fetchall()
+    except sqlite3.Error:
+        return
+    for mangled, disp in rows:
+        d = demangle_simple(mangled.replace('.kd', ''))
+        if d and ('_Accum' in disp or disp.startswith('_Z')):
+            _pretty[disp] = d
+            _pretty[disp.split('(')[0].replace('void ', '')] = d
+
+
 def short(name):
-    name = name.replace('(MbArgs)', '').replace('(PwArgs)', '').replace('(DwArgs)', '')
-    return name.split('(')[0].replace('void ', '')[:64]
+    if name in _pretty:
+        return _pretty[name]
+    base = name.split('(')[0].replace('void ', '')
+    if base in _pretty:
+        return _pretty[base]
+    if base.startswith('_Z'):
+        d = demangle_simple(base)
+        if d:
+            return d
+    return base[:64]
 
 
 def stats(db):
     c = sqlite3.connect(db)
+    load_symbols(c)
     rows = c.execute('select name, count(*), sum(duration), avg(duration), min(duration), max(duration) '
                      'from kernels group by name order by sum(duration) desc').fetchall()
     total = sum(r[2] for r in rows) or 1
@@ -25,6 +84,7 @@ def stats(db):
 
 def pmc(db):
     c = sqlite3.connect(db)
+    load_symbols(c)
     cols = [r[1] for r in c.execute("pragma table_info('counters_collection')")]
     rows = c.execute('select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection '
                      'group by kernel_name, counter_name order by sum(value) desc').fetchall() \
@@ -49,6 +109,7 @@ def traffic(fetch_db, write_db):
     out = {}
     for db, key in ((fetch_db, 'FETCH_SIZE'), (write_db, 'WRITE_SIZE')):
         c = sqlite3.connect(db)
+        load_symbols(c)
         for n, k, a in c.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name=? "
                                  "group by kernel_name", (key,)):
             d = out.setdefault(short(n).replace(', ', ','), {})

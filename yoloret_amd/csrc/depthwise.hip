@@ -198,7 +198,7 @@ static int launch_dw_se(DwArgs<T> a, int expect_blocks, hipStream_t s) {
                blocks, expect_blocks);
     a.nblocks = (unsigned)blocks;
     static char nm[48];
-    static const int nm_len = snprintf(nm, sizeof(nm), "dw_kernel<%d,%d,%d,1,%s,se>", K, S, XT, yr_dtype_name(yr_elem<T>::dtype));
+    static const int nm_len = snprintf(nm, sizeof(nm), "dw_kernel<%d,%d,%d,1,%s,1>", K, S, XT, yr_dtype_name(yr_elem<T>::dtype));
     (void)nm_len;
     yr_note_kernel(nm);
     hipLaunchKernelGGL((dw_kernel<K, S, XT, 1, T, true>), dim3((unsigned)blocks, a.B), dim3(256), 0, s, a);
@@ -215,7 +215,7 @@ static int launch_dw(DwArgs<T> a, hipStream_t s) {
     YR_REQUIRE(blocks < (1ll << 31), "depthwise: grid too large");
     a.nblocks = (unsigned)blocks;
     static char nm[40];
-    static const int nm_len = snprintf(nm, sizeof(nm), "dw_kernel<%d,%d,%d,%d,%s>", K, S, XT, YT, yr_dtype_name(yr_elem<T>::dtype));
+    static const int nm_len = snprintf(nm, sizeof(nm), "dw_kernel<%d,%d,%d,%d,%s,0>", K, S, XT, YT, yr_dtype_name(yr_elem<T>::dtype));
     (void)nm_len;
     yr_note_kernel(nm);
     hipLaunchKernelGGL((dw_kernel<K, S, XT, YT, T>), dim3((unsigned)blocks), dim3(256), 0, s, a);

@@ -269,10 +269,12 @@ template <int S, int CQ, int COP, class T>
 static int launch_ml(const MlArgs<T>& a, int batch, hipStream_t s) {
     constexpr size_t es = (size_t)2 * ML_CH * 256 * sizeof(v2f), red = (size_t)4 * (COP / 2) * 64 * sizeof(v2f);
     constexpr size_t lds = (S == 2 && red > es) ? red : es;  // stride 2 reuses Es as the cross-wave reduction buffer
-    static char nm[56];
-    static const int nm_len = snprintf(nm, sizeof(nm), "mblane_s%d_kernel<%d,%d,%s>", S, CQ, COP, yr_dtype_name(yr_elem<T>::dtype));
+    // (named as rocprof prints the symbol - template arguments in order - so that profiles can be joined by name)
+    static char nm[2][56];
+    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "mblane_s%d_kernel<%d,%d,0,%s>", S, CQ, COP, yr_dtype_name(yr_elem<T>::dtype)) +
+                              snprintf(nm[1], sizeof(nm[1]), "mblane_s%d_kernel<%d,%d,1,%s>", S, CQ, COP, yr_dtype_name(yr_elem<T>::dtype));
     (void)nm_len;
-    yr_note_kernel(nm);
+    yr_note_kernel(nm[a.act == YR_ACT_RELU6 ? 1 : 0]);
     const dim3 grid((unsigned)(batch * a.tiles_x * a.tiles_y));
     if (S == 1) {
         if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((mblane_s1_kernel<CQ, COP, true, T>), grid, dim3(256), lds, s, a);

@@ -164,10 +164,11 @@ template <int CP, int COP, class T>
 static int launch_sb(const SbArgs<T>& a, int batch, hipStream_t s) {
     constexpr size_t lds = (size_t)CP * 256 * 2 * sizeof(float);
     static_assert(lds <= 64 * 1024, "stemblock LDS tile too large");
-    static char nm[48];
-    static const int nm_len = snprintf(nm, sizeof(nm), "stemblock_kernel<%d,%d,%s>", CP, COP, yr_dtype_name(yr_elem<T>::dtype));
+    static char nm[2][48];
+    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "stemblock_kernel<%d,%d,0,%s>", CP, COP, yr_dtype_name(yr_elem<T>::dtype)) +
+                              snprintf(nm[1], sizeof(nm[1]), "stemblock_kernel<%d,%d,1,%s>", CP, COP, yr_dtype_name(yr_elem<T>::dtype));
     (void)nm_len;
-    yr_note_kernel(nm);
+    yr_note_kernel(nm[a.act == YR_ACT_RELU6 ? 1 : 0]);
     const dim3 grid((unsigned)(batch * a.tiles_x * a.tiles_y));
     if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((stemblock_kernel<CP, COP, true, T>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((stemblock_kernel<CP, COP, false, T>), grid, dim3(256), lds, s, a);
