@@ -17,48 +17,68 @@ import re
 from .. import layers as L
 from ..layers import Mean, Swish  # re-exported: efficientnet.py:327-331, :391-403
 
-GlobalParams = collections.namedtuple('GlobalParams', [
-    'batch_norm_momentum', 'batch_norm_epsilon', 'dropout_rate', 'data_format', 'num_classes',
-    'width_coefficient', 'depth_coefficient', 'depth_divisor', 'min_depth', 'drop_connect_rate'])
-GlobalParams.__new__.__defaults__ = (None,) * len(GlobalParams._fields)
+# The reference's two configuration records (efficientnet.py:110-130): field names are API (callers pass them as
+# keyword arguments and use ._replace), every field defaults to None.
+_GLOBAL_FIELDS = ('batch_norm_momentum batch_norm_epsilon dropout_rate data_format num_classes width_coefficient '
+                  'depth_coefficient depth_divisor min_depth drop_connect_rate').split()
+_BLOCK_FIELDS = 'kernel_size num_repeat input_filters output_filters expand_ratio id_skip strides se_ratio'.split()
+GlobalParams = collections.namedtuple('GlobalParams', _GLOBAL_FIELDS, defaults=(None,) * len(_GLOBAL_FIELDS))
+BlockArgs = collections.namedtuple('BlockArgs', _BLOCK_FIELDS, defaults=(None,) * len(_BLOCK_FIELDS))
 
-BlockArgs = collections.namedtuple('BlockArgs', [
-    'kernel_size', 'num_repeat', 'input_filters', 'output_filters', 'expand_ratio', 'id_skip',
-    'strides', 'se_ratio'])
-BlockArgs.__new__.__defaults__ = (None,) * len(BlockArgs._fields)
+# Block-string notation (efficientnet.py:133-200), e.g. 'r2_k5_s22_e6_i24_o40_se0.25[_noskip]':
+# token prefix -> (BlockArgs field, parser, formatter); 's' holds the two stride digits.
+_TOKENS = collections.OrderedDict([
+    ('r', ('num_repeat', int, '%d')), ('k', ('kernel_size', int, '%d')),
+    ('s', ('strides', lambda v: [int(ch) for ch in v], None)), ('e', ('expand_ratio', int, '%s')),
+    ('i', ('input_filters', int, '%d')), ('o', ('output_filters', int, '%d')), ('se', ('se_ratio', float, '%s'))])
+_TOKEN_RE = re.compile(r'^(se|[a-z])(\d.*)$')
+
+# Stage table of the B0 baseline network (efficientnet.py:208-216) as rows of
+# (repeats, kernel, stride, expand ratio, input filters, output filters); every stage has se_ratio 0.25.
+_B0_STAGES = ((1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
+              (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320))
+
+# Compound-scaling coefficients (efficientnet.py:231-244): name -> (width, depth, resolution, dropout)
+_SCALING = {0: (1.0, 1.0, 224, 0.2), 1: (1.0, 1.1, 240, 0.2), 2: (1.1, 1.2, 260, 0.3), 3: (1.2, 1.4, 300, 0.3),
+            4: (1.4, 1.8, 380, 0.4), 5: (1.6, 2.2, 456, 0.4), 6: (1.8, 2.6, 528, 0.5), 7: (2.0, 3.1, 600, 0.5)}
 
 
 class BlockDecoder(object):
-    """Block-string notation (efficientnet.py:133-200)."""
+    """String <-> BlockArgs (efficientnet.py:133-200), driven by the _TOKENS table."""
 
     def _decode_block_string(self, block_string):
-        assert isinstance(block_string, str)
-        options = {}
-        for op in block_string.split('_'):
-            splits = re.split(r'(\d.*)', op)
-            if len(splits) >= 2:
-                key, value = splits[:2]
-                options[key] = value
-        if 's' not in options or len(options['s']) != 2:
+        if not isinstance(block_string, str):
+            raise AssertionError('block string expected')
+        fields = {}
+        for tok in block_string.split('_'):
+            m = _TOKEN_RE.match(tok)
+            if m and m.group(1) in _TOKENS:
+                name, parse, _ = _TOKENS[m.group(1)]
+                fields[name] = (m.group(2), parse)
+        if 'strides' not in fields or len(fields['strides'][0]) != 2:
             raise ValueError('Strides options should be a pair of integers.')
-        return BlockArgs(kernel_size=int(options['k']), num_repeat=int(options['r']),
-                         input_filters=int(options['i']), output_filters=int(options['o']),
-                         expand_ratio=int(options['e']), id_skip=('noskip' not in block_string),
-                         se_ratio=float(options['se']) if 'se' in options else None,
-                         strides=[int(options['s'][0]), int(options['s'][1])])
+        values = {name: parse(raw) for name, (raw, parse) in fields.items()}
+        values.setdefault('se_ratio', None)
+        return BlockArgs(id_skip='noskip' not in block_string, **values)
 
     def _encode_block_string(self, block):
-        args = ['r%d' % block.num_repeat, 'k%d' % block.kernel_size,
-                's%d%d' % (block.strides[0], block.strides[1]), 'e%s' % block.expand_ratio,
-                'i%d' % block.input_filters, 'o%d' % block.output_filters]
-        if block.se_ratio is not None and 0 < block.se_ratio <= 1:
-            args.append('se%s' % block.se_ratio)
+        parts = []
+        for prefix, (name, _, fmt) in _TOKENS.items():
+            value = getattr(block, name)
+            if prefix == 's':
+                parts.append('s%d%d' % tuple(value[:2]))
+            elif prefix == 'se':
+                if value is not None and 0 < value <= 1:
+                    parts.append('se%s' % value)
+            else:
+                parts.append(prefix + fmt % value)
         if block.id_skip is False:
-            args.append('noskip')
-        return '_'.join(args)
+            parts.append('noskip')
+        return '_'.join(parts)
 
     def decode(self, string_list):
-        assert isinstance(string_list, list)
+        if not isinstance(string_list, list):
+            raise AssertionError('a list of block strings expected')
         return [self._decode_block_string(s) for s in string_list]
 
     def encode(self, blocks_args):
@@ -66,65 +86,55 @@ class BlockDecoder(object):
 
 
 def efficientnet(width_coefficient=None, depth_coefficient=None, dropout_rate=0.2, drop_connect_rate=0.2):
-    """Stage table + global params (efficientnet.py:203-228)."""
-    blocks_args = [
-        'r1_k3_s11_e1_i32_o16_se0.25', 'r2_k3_s22_e6_i16_o24_se0.25', 'r2_k5_s22_e6_i24_o40_se0.25',
-        'r3_k3_s22_e6_i40_o80_se0.25', 'r3_k5_s11_e6_i80_o112_se0.25', 'r4_k5_s22_e6_i112_o192_se0.25',
-        'r1_k3_s11_e6_i192_o320_se0.25']
+    """(list of BlockArgs, GlobalParams) of the baseline network scaled by the two coefficients
+    (efficientnet.py:203-228)."""
+    stages = [BlockArgs(kernel_size=k, num_repeat=r, input_filters=i, output_filters=o, expand_ratio=e, id_skip=True,
+                        strides=[s, s], se_ratio=0.25) for r, k, s, e, i, o in _B0_STAGES]
     global_params = GlobalParams(batch_norm_momentum=0.99, batch_norm_epsilon=1e-3, dropout_rate=dropout_rate,
-                                 drop_connect_rate=drop_connect_rate, data_format='channels_last',
-                                 num_classes=1000, width_coefficient=width_coefficient,
-                                 depth_coefficient=depth_coefficient, depth_divisor=8, min_depth=None)
-    return BlockDecoder().decode(blocks_args), global_params
+                                 drop_connect_rate=drop_connect_rate, data_format='channels_last', num_classes=1000,
+                                 width_coefficient=width_coefficient, depth_coefficient=depth_coefficient,
+                                 depth_divisor=8, min_depth=None)
+    return stages, global_params
 
 
 def efficientnet_params(model_name):
-    """(width, depth, resolution, dropout) per model name (efficientnet.py:231-244)."""
-    params_dict = {
-        'efficientnet-b0': (1.0, 1.0, 224, 0.2), 'efficientnet-b1': (1.0, 1.1, 240, 0.2),
-        'efficientnet-b2': (1.1, 1.2, 260, 0.3), 'efficientnet-b3': (1.2, 1.4, 300, 0.3),
-        'efficientnet-b4': (1.4, 1.8, 380, 0.4), 'efficientnet-b5': (1.6, 2.2, 456, 0.4),
-        'efficientnet-b6': (1.8, 2.6, 528, 0.5), 'efficientnet-b7': (2.0, 3.1, 600, 0.5)}
-    return params_dict[model_name]
+    """'efficientnet-b<n>' -> (width, depth, resolution, dropout) (efficientnet.py:231-244); KeyError otherwise."""
+    m = re.match(r'^efficientnet-b([0-7])$', model_name)
+    if not m:
+        raise KeyError(model_name)
+    return _SCALING[int(m.group(1))]
 
 
 def get_model_params(model_name, override_params=None):
-    """efficientnet.py:247-267.  Unlike the reference this does not mutate (or print)
-    the caller's dict; 'drop_rate' is still accepted and ignored, and unknown keys
-    still raise ValueError (from namedtuple._replace)."""
-    if model_name.startswith('efficientnet'):
-        width_coefficient, depth_coefficient, input_shape, dropout_rate = efficientnet_params(model_name)
-        blocks_args, global_params = efficientnet(width_coefficient, depth_coefficient, dropout_rate)
-    else:
+    """efficientnet.py:247-267.  Unlike the reference this does not mutate (or print) the caller's dict; 'drop_rate'
+    is still accepted and ignored, and unknown keys still raise ValueError (from namedtuple._replace)."""
+    if not model_name.startswith('efficientnet'):
         raise NotImplementedError('model name is not pre-defined: %s' % model_name)
-    override_params = dict(override_params or {})
-    override_params.pop('drop_rate', None)
-    if override_params:
-        global_params = global_params._replace(**override_params)
-    return blocks_args, global_params, input_shape
+    width, depth, resolution, dropout = efficientnet_params(model_name)
+    blocks_args, global_params = efficientnet(width, depth, dropout)
+    overrides = {k: v for k, v in (override_params or {}).items() if k != 'drop_rate'}
+    if overrides:
+        global_params = global_params._replace(**overrides)
+    return blocks_args, global_params, resolution
 
 
 def round_filters(filters, global_params):
-    """efficientnet.py:364-380."""
-    multiplier = global_params.width_coefficient
-    divisor = global_params.depth_divisor
-    min_depth = global_params.min_depth
-    if not multiplier:
+    """Channel count scaled by the width coefficient, to a multiple of depth_divisor, never more than 10 % below the
+    scaled value (efficientnet.py:364-380)."""
+    width = global_params.width_coefficient
+    if not width:
         return filters
-    filters *= multiplier
-    min_depth = min_depth or divisor
-    new_filters = max(min_depth, int(filters + divisor / 2) // divisor * divisor)
-    if new_filters < 0.9 * filters:
-        new_filters += divisor
-    return int(new_filters)
+    divisor = global_params.depth_divisor
+    scaled = filters * width
+    floor = global_params.min_depth or divisor
+    rounded = max(floor, int(scaled + divisor / 2) // divisor * divisor)
+    return int(rounded + divisor if rounded < 0.9 * scaled else rounded)
 
 
 def round_repeats(repeats, global_params):
-    """efficientnet.py:383-388."""
-    multiplier = global_params.depth_coefficient
-    if not multiplier:
-        return repeats
-    return int(math.ceil(multiplier * repeats))
+    """Block repeats scaled by the depth coefficient, rounded up (efficientnet.py:383-388)."""
+    depth = global_params.depth_coefficient
+    return int(math.ceil(depth * repeats)) if depth else repeats
 
 
 def _require_channels_last(global_params):

@@ -6,6 +6,8 @@ rule (detections of a class sorted by score; a detection is a true positive if i
 box of that class in the same image has IoU > threshold - computed with the VOC "+1 pixel" convention - and has
 not been claimed yet), same AP definition (area under the monotone precision envelope), classes without any
 detection score AP 0, mAP = mean over classes.  It is host-side NumPy: the device work is the model call.
+One deliberate difference: detections with EQUAL scores are ranked in input order (a stable sort) - the reference's
+`np.argsort(-confidence)` leaves their order to NumPy's unstable default, so its AP can vary between runs on ties.
 
 The TFRecord branch of the reference (map.py:33-53) needs TensorFlow's proto parser and is not provided.
 """
