@@ -113,7 +113,7 @@ typedef enum {
                             depthwise BN scale | shift | expand BN scale | shift;
                             b1 = project Wt[cout][CexpP] (16-bit); b2 = project BN scale ++ shift, [round_up(cout,8)] each;
                             res (optional) = the block input (stride 1, cin == cout) */
-    YR_OP_MBLANE = 10    /* the MBCONV block (same layers, same op fields) in the lane-per-pixel formulation for narrow
+    YR_OP_MBLANE = 10,   /* the MBCONV block (same layers, same op fields) in the lane-per-pixel formulation for narrow
                             block inputs (Cin <= 32): packed-fp32 FMA with scalar-register weights instead of MFMA.
                             se_reduced = Cexp; parameters packed per expanded-channel PAIR, P = round_up(ceil(Cexp/2),8),
                             CINP = round_up(Cin,4), COP = round_up(cout,8), zero padded; scale/shift unused:
@@ -121,6 +121,14 @@ typedef enum {
                             wgt2 = depthwise [P][9 taps (ky,kx) x 2 | BN scale 2 | BN shift 2],
                             b1   = project W[2P][COP] (expanded-channel major), b2 = project BN scale[COP] ++ shift[COP].
                             Built for (CINP/4,COP) in {(4,16),(4,24),(6,24),(6,32),(6,40),(6,48),(8,32),(8,40),(8,48)} */
+    YR_OP_MBX = 12       /* the first two thirds of an MBConv block WITH squeeze-excite (efficientnet.py:406-536), 16-bit
+                            activations: expand 1x1 + BN + act (bf16 / f16 MFMA) -> depthwise K = 3 | 5, stride 1 | 2 + BN +
+                            act, the expanded input of the depthwise conv staying in LDS; the depthwise map is stored and
+                            the squeeze (tf.reduce_mean over H, W, efficientnet.py:417) leaves as per-tile channel sums.
+                            src[0] = block input (cin <= 128); cout = Cexp = width of the stored map; wgt, wgt2, k as MBH;
+                            gate (optional) = OUTPUT float32 [B][se_reduced][gate_ld] sums of the STORED values, one row
+                            per output tile, unused rows zeroed (se_reduced = rows >= tiles per image: the buffer is sized
+                            for the smallest tile the host may pick, 4 x 8, or 4 x 4 on maps under 1000 pixels); SE_FC (k = H*W) adds the rows up; the projection stays a POINTWISE op */
 } yr_op_kind;
 
 /* One fused operation.  Weight-like fields are float offsets into the weight
@@ -215,12 +223,12 @@ int yr_forward_profile(yr_handle* h, const float* images, int batch, float* y1, 
                        void* workspace, size_t workspace_bytes, void* stream, int iters,
                        float* ms_per_op, const char** kernel_names);
 /* Per-op tile autotuning for `batch` images: times every pointwise tile shape on every pointwise op (and a list of
- * output tiles on every MBH op) and remembers the fastest for later yr_forward calls with the same batch (numerics do not depend on the
+ * output tiles on every MBH / MBX op) and remembers the fastest for later yr_forward calls with the same batch (numerics do not depend on the
  * shape).  Runs the forward once first; synchronises the stream. */
 int yr_autotune(yr_handle* h, const float* images, int batch, float* y1, float* y2, float* y3,
                 void* workspace, size_t workspace_bytes, void* stream, int iters);
 /* The autotuned table for `batch`: one int per plan op - POINTWISE: 0 = heuristic, else the 1-based tile shape;
- * MBH: 0 = heuristic, else the output tile as th << 8 | tw << 16; every other op kind: 0.  yr_get_tuning returns YR_ERR_STATE if that batch has not been tuned; yr_set_tuning installs a table
+ * MBH, MBX: 0 = heuristic, else the output tile as th << 8 | tw << 16; every other op kind: 0.  yr_get_tuning returns YR_ERR_STATE if that batch has not been tuned; yr_set_tuning installs a table
  * saved from an earlier run (tune once, deploy many: n must equal yr_plan_num_launches). */
 int yr_get_tuning(const yr_handle* h, int batch, int32_t* cfg_per_op, int n);
 int yr_set_tuning(yr_handle* h, int batch, const int32_t* cfg_per_op, int n);

@@ -112,3 +112,90 @@ def test_mbh_rejects_what_it_is_not_built_for(dev):
     op.dtype = op.out_dtype = 0
     with pytest.raises(rt.YoloretHipError, match='16-bit'):
         rt.run_op(op, 1)
+
+
+MBX_CASES = [
+    # (h, w, cin, cexp, k, stride, act, forced tile or None)   - EfficientNet MBConv blocks with squeeze-excite
+    (52, 52, 16, 96, 3, 2, 'swish', None),       # B0 stage 2 entry (expanded width: 3 chunks)
+    (26, 26, 24, 144, 3, 1, 'swish', None),      # stage 2 (144 = 4.5 chunks: masked tail)
+    (30, 22, 24, 144, 5, 2, 'swish', None),      # stage 3 entry (k5 s2), ragged tiles
+    (26, 26, 40, 240, 5, 1, 'swish', None),      # stage 3
+    (13, 13, 80, 480, 3, 1, 'swish', None),      # stage 4
+    (13, 13, 112, 672, 5, 1, 'swish', None),     # stage 5: four k-steps of the expand GEMM
+    (14, 14, 112, 672, 5, 2, 'swish', None),     # stage 6 entry
+    (26, 26, 32, 192, 3, 1, 'relu6', (13, 12)),  # two pixel groups per wave
+    (9, 11, 14, 52, 3, 1, 'swish', (4, 8)),      # pad lanes in the input (NaN-filled), width not a multiple of 8
+    (20, 20, 48, 288, 5, 1, 'swish', (8, 16)),
+]
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+@pytest.mark.parametrize('with_sums', [True, False])
+@pytest.mark.parametrize('case', MBX_CASES, ids=[str(i) for i in range(len(MBX_CASES))])
+def test_mbx(dev, case, with_sums, dt):
+    """YR_OP_MBX: expand 1x1 + BN + act -> depthwise + BN + act, the depthwise map stored once (16-bit) and its per-tile
+    channel sums (the squeeze of squeeze-excite) written beside it."""
+    from yoloret_amd import runtime as rt
+    h, w, cin, cexp, k, s, act, tile = case
+    rng = np.random.default_rng(zlib.crc32(str(case).encode()))
+    b = 2
+    x = q16(rng.standard_normal((b, h, w, cin)), dt)
+    we = q16(rng.standard_normal((cin, cexp)) * np.sqrt(2.0 / cin), dt)
+    se, he = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
+    t = _act(nn.pointwise(x.astype(np.float64), we.astype(np.float64)) * se + he, act)
+    wd = (rng.standard_normal((k, k, cexp)) * np.sqrt(2.0 / (k * k))).astype(np.float32)
+    sd, hd = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
+    ref = _act(nn.depthwise(t, wd.astype(np.float64), s, 'same') * sd + hd, act)
+    cexp_p, kp, ldo = round_up(cexp, 32), round_up(cin, 32), round_up(cexp, 8)
+    wet = np.zeros((cexp_p, kp), np.float32); wet[:cexp, :cin] = we.T
+    dwp = np.zeros((k * k + 4, cexp_p), np.float32)
+    dwp[:k * k, :cexp], dwp[k * k, :cexp], dwp[k * k + 1, :cexp] = wd.reshape(k * k, cexp), sd, hd
+    dwp[k * k + 2, :cexp], dwp[k * k + 3, :cexp] = se, he
+    keep = [torch.from_numpy(rt.to_bits16(wet, dt).view(np.int16).reshape(wet.shape)).to(dev), torch.from_numpy(dwp).to(dev)]
+    xd = to_dev16(x, dev, dt)
+    did = rt.dtype_id(dt)
+    ho, wo = ref.shape[1], ref.shape[2]
+    rows = ((ho + 3) // 4) * ((wo + 7) // 8)
+    op = rt.new_op(rt.OP_MBX, act)
+    op.dtype = op.out_dtype = did
+    op.h, op.w, op.cin, op.cout, op.stride, op.nsrc = ho, wo, cin, cexp, s, 1
+    op.k = k | ((tile[0] << 8) | (tile[1] << 16) if tile else 0)
+    op.src[0] = rt.make_src(xd, c=cin)
+    op.wgt, op.wgt2 = keep[0].data_ptr(), keep[1].data_ptr()
+    out = torch.full((b, ho, wo, ldo), float('nan'), dtype=rt.TORCH_DTYPE[did], device=dev)
+    op.out, op.out_ld = out.data_ptr(), ldo
+    part = torch.full((b, rows, ldo), float('nan'), dtype=torch.float32, device=dev)
+    if with_sums:
+        op.gate, op.gate_ld, op.se_reduced = part.data_ptr(), ldo, rows
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    got = from_dev16(out, dt, cexp)
+    # hardware exp2 / reciprocal in the swish (about 1e-6 relative) on top of the half ulp of the one rounding
+    assert_rounded_once(got, ref, dt, 'mbx %s %s' % (dt, case), slack=5e-5)
+    if ldo > cexp:
+        assert np.all(from_dev16(out, dt, ldo)[..., cexp:] == 0), 'pad channels of the stored map are zero'
+    if with_sums:
+        p = part.cpu().numpy()
+        assert np.all(np.isfinite(p)), 'every row of the partial-sum buffer is written (unused rows zeroed)'
+        sums = p.astype(np.float64).sum(axis=1)[:, :cexp]
+        want = got.astype(np.float64).sum(axis=(1, 2))               # sums of the STORED values
+        np.testing.assert_allclose(sums, want, rtol=2e-5, atol=2e-4 * np.sqrt(ho * wo))
+    else:
+        assert torch.isnan(part).all()
+
+
+def test_mbx_rejects_a_short_sum_buffer(dev):
+    from yoloret_amd import runtime as rt
+    x = torch.zeros((1, 26, 26, 24), dtype=torch.bfloat16, device=dev)
+    out = torch.zeros((1, 26, 26, 144), dtype=torch.bfloat16, device=dev)
+    part = torch.zeros((1, 4, 144), dtype=torch.float32, device=dev)
+    op = rt.new_op(rt.OP_MBX, 'swish')
+    op.dtype = op.out_dtype = rt.DTYPE['bf16']
+    op.h, op.w, op.cin, op.cout, op.stride, op.nsrc = 26, 26, 24, 144, 1, 1
+    op.k = 3 | (4 << 8) | (8 << 16)
+    op.src[0] = rt.make_src(x, c=24)
+    op.wgt = op.wgt2 = x.data_ptr()
+    op.out, op.out_ld = out.data_ptr(), 144
+    op.gate, op.gate_ld, op.se_reduced = part.data_ptr(), 144, 4
+    with pytest.raises(rt.YoloretHipError, match='exceed the 4 rows'):
+        rt.run_op(op, 1)

@@ -97,7 +97,7 @@ class Plan:
             for b in (op.res, op.gate):
                 if b is not None:
                     b.last_use = max(b.last_use, i)
-                    if b is op.gate and op.kind == rt.OP_DEPTHWISE and b.first_def is None:
+                    if b is op.gate and op.kind in (rt.OP_DEPTHWISE, rt.OP_MBX) and b.first_def is None:
                         b.first_def = i          # SE form: the depthwise op WRITES its per-workgroup channel sums there
         self.bufs = [b for b in self.bufs if b.first_def is not None]
         for i, b in enumerate(self.bufs):
@@ -268,6 +268,7 @@ STEMBLOCK_WIDTHS ={(12, 16), (16, 16), (16, 24), (20, 24), (24, 16), (24, 24)}  
 
 FUSE_MBH = os.environ.get('YOLORET_FUSE_MBH', '1') != '0'   # 16-bit plans: inverted-residual blocks on the MFMA block kernel (mbh.hip)
 MBH_LANE_MIN_PIXELS = int(os.environ.get('YOLORET_MBH_LANE_MIN_PIXELS', '10000'))
+FUSE_MBX = os.environ.get('YOLORET_FUSE_MBX', '1') != '0'   # 16-bit plans: expand + depthwise of squeeze-excite MBConv blocks in one kernel
 MBH_ACTS = ('relu6',) if os.environ.get('YOLORET_MBH_SWISH', '0') == '0' else ('relu6', 'swish')
 
 
@@ -453,13 +454,15 @@ def fold_depthwise_into_project(ops, output_buf_ids):
     return out
 
 
-def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0):
+def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None):
     """Peephole over the lowered op list: [POINTWISE expand+act ->] DEPTHWISE 3x3+act -> POINTWISE
     project (+residual == block input) becomes one MBCONV op whose expanded tensors never reach HBM.
     blocks=False (the small-batch plan) keeps only the network-entry fusion (stem + first block).
     16-bit plans (dtype != 0): the lane-per-pixel kernels (stemblock, mblane) take 16-bit inputs / outputs - they
     compute in float32 from registers, so only their loads and stores change; the MFMA block kernel (mbconv.hip) is
-    float32 only and is not selected."""
+    float32 only and is not selected.  Blocks with squeeze-excite (the projection needs the gate of the complete depthwise
+    map) get their first two thirds fused instead: POINTWISE expand -> DEPTHWISE becomes one MBX op that stores the
+    depthwise map and the per-tile channel sums the SE_FC op finishes the squeeze from."""
     max_cin = FUSE_MAX_CIN if blocks else 0
     readers = {}
     for op in ops:
@@ -548,6 +551,49 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0):
                 # halo tile leaves two workgroups per CU); from block_2 on (0.205 vs 0.138 ms) everything goes to mbh
                 if lane_ok(exp, bi, p) and d.k == 3 and d.stride == 2 and p.h * p.w >= MBH_LANE_MIN_PIXELS:
                     mbh = None
+        mbx = None
+        if (FUSE_MBX and mbh is None and bufs is not None and dtype != 0 and blocks and exp is not None and d is not None
+                and d.kind == rt.OP_DEPTHWISE and d.k in (3, 5) and d.stride in (1, 2) and len(d.srcs) == 1
+                and d.srcs[0].xform == 'identity' and d.srcs[0].buf is exp.out and d.act == exp.act and d.out.dtype == dtype
+                and exp.srcs[0].buf.dtype == dtype and exp.srcs[0].c <= 128 and d.out.external_slot < 0 and d.out.id not in output_buf_ids):
+            # the squeeze of this depthwise map: an SE_FC op reading it (merged mean) or the partial sums it already writes
+            mbx = next((o for o in ops if o.kind == rt.OP_SE_FC and getattr(o, 'merged_mean', 0) and len(o.srcs) == 1
+                        and (o.srcs[0].buf is d.out or (d.gate is not None and o.srcs[0].buf is d.gate))), None)
+        if mbx is not None:
+            fc, bi = mbx, exp.srcs[0]
+            cin, cexp, kk = bi.c, d.cin, d.k * d.k
+            cexp_p, kp = round_up(cexp, 32), round_up(cin, 32)
+            # partial-sum rows: enough for a 4 x 8 output tile (4 x 4 on small maps, where wide blocks need small tiles)
+            rows = ((d.h + 3) // 4) * ((d.w + 7) // 8 if d.h * d.w > 1000 else (d.w + 3) // 4)
+            part = d.gate
+            if part is None:
+                part = Buf(len(bufs), rows, 1, cexp, round_up(cexp, rt.VEC[dtype]), name=d.name + ':se_sums', dtype=0)
+                bufs.append(part)
+                fc.srcs = [Seg(part, cexp, 'identity')]
+                fc.k = d.h * d.w
+            else:
+                part.h, part.elems = rows, rows * part.w * part.ld
+                part.bytes = part.elems * rt.ESIZE[part.dtype]
+            m = OpRec(rt.OP_MBX, exp.name.rsplit('_', 1)[0] + '_mbx', act=d.act, h=d.h, w=d.w, cin=cin, cout=cexp, k=d.k,
+                      stride=d.stride, se_reduced=rows, srcs=[bi], out=d.out, gate=part, macs=exp.macs + d.macs, dtype=dtype)
+            m.fused = [exp, d]
+            ep, dp = exp.params, d.params
+
+            def expand_wt(wd, ep=ep, cexp=cexp, cin=cin, cexp_p=cexp_p, kp=kp):
+                o = np.zeros((cexp_p, kp), np.float32)
+                o[:cexp, :cin] = ep['wgt'][1](wd)[:, :cin]            # pointwise layout Wt[cexp][k-space], one source
+                return o
+
+            def chunk_params(wd, ep=ep, dp=dp, cexp=cexp, cexp_p=cexp_p, kk=kk):
+                o = np.zeros((kk + 4, cexp_p), np.float32)            # taps | dw scale | dw shift | expand scale | expand shift
+                o[:kk, :cexp] = dp['wgt'][1](wd)[:, :cexp]
+                o[kk, :cexp], o[kk + 1, :cexp] = dp['scale'][1](wd)[:cexp], dp['shift'][1](wd)[:cexp]
+                o[kk + 2, :cexp], o[kk + 3, :cexp] = ep['scale'][1](wd)[:cexp], ep['shift'][1](wd)[:cexp]
+                return o
+            m.params = {'wgt': ((cexp_p, kp), expand_wt, dtype), 'wgt2': ((kk + 4, cexp_p), chunk_params)}
+            out.append(m)
+            i = j + 1
+            continue
         if mbh is not None:
             d, p = mbh
             bi = exp.srcs[0]
@@ -830,7 +876,7 @@ class Compiler:
                 ops = merge_se_mean(ops)
                 if SE_PARTIALS:
                     ops = se_partials_from_depthwise(ops, self.bufs)
-            ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency, dtype=self.dtype)
+            ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency, dtype=self.dtype, bufs=self.bufs)
             if FOLD_DW and not latency and self.dtype == 0:
                 ops = fold_depthwise_into_project(ops, set(b.id for b in outs))
         plan = Plan(ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape, self.dtype)

@@ -45,6 +45,8 @@ struct MbhArgs {
     int Hi, Wi, Ho, Wo, Cin, CexpP, Cout, ld_in, ld_out, KP;
     int pad_t, pad_l, th, tw, tiles_x, tiles_y, ih, iw, PH, OPX;
     int has_res, act;
+    // MODE 1 (expand + depthwise only): per-tile channel sums of the stored outputs, float32 [B][rows_cap][ld_part]
+    float* part; int ld_part, rows_cap;
 };
 
 template <class T>
@@ -55,10 +57,15 @@ __device__ __forceinline__ mbh_f4 mbh_mfma(mbh_u4 w, mbh_u4 x, mbh_f4 acc) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mbh_v8<_Float16>, w), __builtin_bit_cast(mbh_v8<_Float16>, x), acc, 0, 0, 0);
 }
 
-template <bool RELU6>
+// ACT 0: relu6; 1: swish; 2: whatever op.act says.  The results are rounded to a 16-bit type right away (8 or 11
+// significant bits), so swish uses the hardware exp2 / reciprocal (about 1 ulp of float32 each) instead of the pinned
+// float32 expf and the IEEE division of the float32 plans (28 instructions per element, and the EfficientNet blocks
+// apply it to 6x the block's input twice).
+template <int ACT>
 __device__ __forceinline__ float mbh_act(float v, int act) {
-    if (RELU6) return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f);   // clamp in one instruction (== min(max(v,0),6) for finite v)
-    return yr_apply_act(v, act);
+    if constexpr (ACT == 0) return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f);   // clamp in one instruction (== min(max(v,0),6) for finite v)
+    else if constexpr (ACT == 1) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
+    else return yr_apply_act(v, act);
 }
 
 // CP: cout tile pairs (Cout <= 32*CP); NG: groups of 32 output pixels per wave (th*tw <= 128*NG)
@@ -71,8 +78,14 @@ __device__ __forceinline__ float mbh_act(float v, int act) {
 // re-read all K*K taps and their weights from LDS per output: PMC showed the LDS pipe 69 % busy, 30 % of it bank
 // conflicts, and half of the reads were weights.)  The 16-bit results go to a wave-private LDS patch Ds[32][32] and
 // come back as B-operand fragments - same wave, program order, no workgroup barrier.
-template <class T, int K, int S, int CP, int NG, bool RELU6>
-__global__ __launch_bounds__(256, (CP * NG <= 1 ? 3 : 2)) void mbh_kernel(MbhArgs a) {
+//
+// MODE 0: the whole block.  MODE 1 (YR_OP_MBX; MBConv blocks WITH squeeze-excite, efficientnet.py:406-536, whose
+// projection needs the gate computed from the complete depthwise map): expand + depthwise only - the depthwise results
+// are stored (16-bit) and every workgroup also writes the per-channel sums of what it stored to its row of `part`
+// (the squeeze, tf.reduce_mean over H, W at efficientnet.py:417, finished by SE_FC); the expanded INPUT of the depthwise
+// conv - half of the chain's traffic - still never reaches HBM.
+template <class T, int K, int S, int CP, int NG, int ACT, int MODE>
+__global__ __launch_bounds__(256, (MODE == 1 || CP * NG <= 1 ? 3 : 2)) void mbh_kernel(MbhArgs a) {
     constexpr int CT = 2 * CP, KK = K * K, MTO = 2 * NG;
     constexpr int PSZ = (KK + 4) * MBH_EC;              // floats per parameter buffer: dw taps | sd | hd | se | he
     constexpr int COLS = 3 * S + K;                     // input positions per row feeding a run of 4 outputs
@@ -84,6 +97,7 @@ __global__ __launch_bounds__(256, (CP * NG <= 1 ? 3 : 2)) void mbh_kernel(MbhArg
     float* Ps = Es + (size_t)a.PH * MBH_LDE;
     T* Ws = reinterpret_cast<T*>(Ps + 2 * PSZ);         // [2][32][ldx]: expand weights of the current / next chunk
     T* Ds = Ws + (size_t)2 * 32 * ldx;                  // [4 waves][32][LDD]: depthwise results on their way to the MFMA
+    float* Sw = reinterpret_cast<float*>(Ds);           // MODE 1 instead: [4 waves][32] channel sums of the current chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
     const int tpi = a.tiles_x * a.tiles_y;
@@ -98,6 +112,16 @@ __global__ __launch_bounds__(256, (CP * NG <= 1 ? 3 : 2)) void mbh_kernel(MbhArg
     // block-uniform: the halo tile lies inside the image (no zero padding to apply anywhere)
     const bool all_inside = iy0 >= 0 && ix0 >= 0 && iy0 + a.ih <= a.Hi && ix0 + a.iw <= a.Wi;
 
+    if constexpr (MODE == 1) {
+        // rows of `part` no tile owns (the buffer is sized for the smallest tile the host may choose): zero, shared out
+        // over the image's workgroups
+        if (a.part != nullptr && a.rows_cap > tpi) {
+            const int extra = a.rows_cap - tpi, per = (extra + tpi - 1) / tpi;
+            const int r0 = tpi + r * per, r1 = r0 + per < a.rows_cap ? r0 + per : a.rows_cap;
+            float* pz = a.part + (size_t)b * a.rows_cap * a.ld_part;
+            for (int i = r0 * a.ld_part + tid; i < r1 * a.ld_part; i += 256) pz[i] = 0.f;
+        }
+    }
     // ---- 1. input halo tile -> LDS (zero outside the image and beyond Cin; pad channels of the source may hold anything).
     //      Loads are issued in batches before the first LDS store of the batch (one HBM round trip per batch).
     {
@@ -189,7 +213,7 @@ __global__ __launch_bounds__(256, (CP * NG <= 1 ? 3 : 2)) void mbh_kernel(MbhArg
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int n = (c >> 1) * 32 + 8 * (li >> 2) + 4 * (c & 1) + (li & 3);
-        wprow[c] = wp + (size_t)(n < a.Cout ? n : 0) * a.CexpP + 8 * g;
+        wprow[c] = MODE == 0 ? wp + (size_t)(n < a.Cout ? n : 0) * a.CexpP + 8 * g : nullptr;
     }
     const int nmt_h = (a.PH + 15) >> 4;
     const int nks = a.KP >> 5;                          // k-steps of the expand GEMM
@@ -208,13 +232,21 @@ __global__ __launch_bounds__(256, (CP * NG <= 1 ? 3 : 2)) void mbh_kernel(MbhArg
     const int cq4 = (lane & 7) * 4, rl = lane >> 3;
     const int nrx = a.tw >> 2, nruns = a.th * nrx, ngroups = (nruns + 7) >> 3;
     int es_off[NG];                                     // float offset of the run's window origin in Es (+ channel quad)
+    unsigned out_off[NG];                               // MODE 1: element offset of the run's first output pixel (+ channel quad) in the image
+    unsigned out_ok[NG];                                // MODE 1: which of the run's 4 pixels exist
 #pragma unroll
     for (int m = 0; m < NG; ++m) {
         const int run = (wave + 4 * m) * 8 + rl;
         const int rc = run < nruns ? run : nruns - 1;
         const int oy = rc / nrx, ox = (rc - oy * nrx) * 4;
         es_off[m] = ((oy * S) * a.iw + ox * S) * MBH_LDE + cq4;
+        const int gy = oy0 + oy, gx = ox0 + ox;
+        out_off[m] = (unsigned)((gy * a.Wo + gx) * a.ld_out + cq4);
+        out_ok[m] = 0u;
+        if (MODE == 1 && run < nruns && gy < a.Ho)
+            for (int i = 0; i < 4; ++i) out_ok[m] |= (gx + i < a.Wo ? 1u : 0u) << i;
     }
+    T* outp = reinterpret_cast<T*>(a.out) + (size_t)b * a.Ho * a.Wo * a.ld_out;
     T* Dw = Ds + (size_t)wave * 32 * LDD;
     __syncthreads();                                    // Xs, Ps[0], Ws[0] visible
 
@@ -225,8 +257,10 @@ __global__ __launch_bounds__(256, (CP * NG <= 1 ? 3 : 2)) void mbh_kernel(MbhArg
         // prefetches: this chunk's projection fragments; the next chunk's parameters and expand weights (stored to
         // their other LDS buffers behind the depthwise phase)
         mbh_u4 wpf[CT];
+        if constexpr (MODE == 0) {
 #pragma unroll
-        for (int c = 0; c < CT; ++c) wpf[c] = *reinterpret_cast<const mbh_u4*>(wprow[c] + e0);
+            for (int c = 0; c < CT; ++c) wpf[c] = *reinterpret_cast<const mbh_u4*>(wprow[c] + e0);
+        }
         float pnext[NPV];
         mbh_u4 wnext[2];
         const bool more = ci + 1 < nchunks;
@@ -280,7 +314,7 @@ __global__ __launch_bounds__(256, (CP * NG <= 1 ? 3 : 2)) void mbh_kernel(MbhArg
                 }
                 mbh_f4 v0 = __builtin_elementwise_fma(e0acc, sc0, sh0), v1 = __builtin_elementwise_fma(e1acc, sc1, sh1);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { v0[q] = mbh_act<RELU6>(v0[q], a.act); v1[q] = mbh_act<RELU6>(v1[q], a.act); }
+                for (int q = 0; q < 4; ++q) { v0[q] = mbh_act<ACT>(v0[q], a.act); v1[q] = mbh_act<ACT>(v1[q], a.act); }
                 if (!all_inside && !(bits & 1u)) {      // TF pads the EXPANDED tensor with zeros
                     v0 = (mbh_f4){0.f, 0.f, 0.f, 0.f};
                     v1 = v0;
@@ -302,6 +336,7 @@ __global__ __launch_bounds__(256, (CP * NG <= 1 ? 3 : 2)) void mbh_kernel(MbhArg
             }
             const mbh_f4 sd = *reinterpret_cast<const mbh_f4*>(Pc + KK * MBH_EC + cq4);
             const mbh_f4 hd = *reinterpret_cast<const mbh_f4*>(Pc + (KK + 1) * MBH_EC + cq4);
+            mbh_f4 psum = (mbh_f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int m = 0; m < NG; ++m) {
                 if (wave + 4 * m < ngroups) {           // wave-uniform
@@ -309,7 +344,9 @@ __global__ __launch_bounds__(256, (CP * NG <= 1 ? 3 : 2)) void mbh_kernel(MbhArg
                     mbh_f4 acc[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[i] = (mbh_f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+                    // (MODE 1, K = 5: a real loop over the rows.  Fully unrolled and without the projection's fences the
+                    // scheduler finishes pixel 0's 25 taps first and keeps every operand and weight for pixels 1..3 - in scratch.)
+#pragma unroll (MODE == 1 && K == 5 ? 1 : K)
                     for (int ky = 0; ky < K; ++ky) {
                         const float* rowp = base + (size_t)(ky * a.iw) * MBH_LDE;
                         mbh_f4 col[COLS];
@@ -325,26 +362,64 @@ __global__ __launch_bounds__(256, (CP * NG <= 1 ? 3 : 2)) void mbh_kernel(MbhArg
                         }
                     }
                     typedef T t4 __attribute__((ext_vector_type(4)));
+                    if constexpr (MODE == 1) {
+                        // the depthwise map itself is the output: 8-byte stores (8 lanes = 64 contiguous bytes of a pixel);
+                        // the sums are those of the STORED (rounded) values, like depthwise.hip's SE form
+                        const bool ch_ok = e0 + cq4 < a.ld_out;
+                        // every value and the sums first, the conditional stores last: anything used only behind a branch is
+                        // sunk there by the compiler - with the stores interleaved, the FMA chains of pixels 1..3 moved behind
+                        // pixel 0's branch and all K * COLS operands and K * K weights stayed alive (in scratch) until then
+                        t4 dr[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        mbh_f4 d = __builtin_elementwise_fma(acc[i], sd, hd);
+                        for (int i = 0; i < 4; ++i) {
+                            mbh_f4 d = __builtin_elementwise_fma(acc[i], sd, hd);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) d[q] = mbh_act<RELU6>(d[q], a.act);
-                        *reinterpret_cast<t4*>(Dw + (size_t)(rl * 4 + i) * LDD + cq4) = __builtin_convertvector(d, t4);
+                            for (int q = 0; q < 4; ++q) d[q] = mbh_act<ACT>(d[q], a.act);
+                            dr[i] = __builtin_convertvector(d, t4);
+                            const mbh_f4 back = __builtin_convertvector(dr[i], mbh_f4);
+                            const float keep = ch_ok && ((out_ok[m] >> i) & 1u) ? 1.0f : 0.0f;
+                            psum += back * keep;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (ch_ok && ((out_ok[m] >> i) & 1u))
+                                *reinterpret_cast<t4*>(outp + (out_off[m] + (unsigned)(i * a.ld_out + e0))) = dr[i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            mbh_f4 d = __builtin_elementwise_fma(acc[i], sd, hd);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) d[q] = mbh_act<ACT>(d[q], a.act);
+                            *reinterpret_cast<t4*>(Dw + (size_t)(rl * 4 + i) * LDD + cq4) = __builtin_convertvector(d, t4);
+                        }
+                        // same wave, program order: the patch is complete before its fragments are read (the fence keeps the
+                        // compiler from moving the reads up; LDS executes a wave's accesses in order)
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) {
+                            const mbh_u4 df = *reinterpret_cast<const mbh_u4*>(Dw + (size_t)(tt * 16 + li) * LDD + 8 * g);
+#pragma unroll
+                            for (int c = 0; c < CT; ++c) acc_o[c][2 * m + tt] = mbh_mfma<T>(wpf[c], df, acc_o[c][2 * m + tt]);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();    // the fragments are read before the next group overwrites the patch
                     }
-                    // same wave, program order: the patch is complete before its fragments are read (the fence keeps the
-                    // compiler from moving the reads up; LDS executes a wave's accesses in order)
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+            if constexpr (MODE == 1) {
+                if (a.part != nullptr) {
+                    // lanes l, l+8, ... l+56 hold the same channel quad: add them in a fixed butterfly order, then the waves
 #pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        const mbh_u4 df = *reinterpret_cast<const mbh_u4*>(Dw + (size_t)(tt * 16 + li) * LDD + 8 * g);
-#pragma unroll
-                        for (int c = 0; c < CT; ++c) acc_o[c][2 * m + tt] = mbh_mfma<T>(wpf[c], df, acc_o[c][2 * m + tt]);
+                    for (int q = 0; q < 4; ++q) {
+                        float v = psum[q];
+                        v += __shfl_xor(v, 8);
+                        v += __shfl_xor(v, 16);
+                        v += __shfl_xor(v, 32);
+                        psum[q] = v;
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();    // the fragments are read before the next group overwrites the patch
+                    if (lane < 8) *reinterpret_cast<mbh_f4*>(Sw + wave * MBH_EC + cq4) = psum;
                 }
             }
         }
@@ -353,11 +428,17 @@ __global__ __launch_bounds__(256, (CP * NG <= 1 ? 3 : 2)) void mbh_kernel(MbhArg
             store_w(Ws + (size_t)((ci + 1) & 1) * 32 * ldx, wnext);
         }
         __syncthreads();   // (B) Es may be rewritten; the next chunk's parameters and expand weights are visible
+        if constexpr (MODE == 1) {
+            // this chunk's 32 channel sums of the tile: waves added in index order (Sw is next written behind barrier (A))
+            if (a.part != nullptr && tid < MBH_EC && e0 + tid < a.ld_part)
+                a.part[((size_t)b * a.rows_cap + r) * a.ld_part + e0 + tid] =
+                    ((Sw[tid] + Sw[MBH_EC + tid]) + Sw[2 * MBH_EC + tid]) + Sw[3 * MBH_EC + tid];
+        }
     }
+    if constexpr (MODE == 1) return;
 
     // ---- 4. epilogue: project BN (+ the block input at the centre tap, from Xs) -> 16-byte stores.
     //      Tile 2m+tt, lane li: run (wave+4m)*8 + 4tt + (li>>2), pixel li&3 of the run.
-    T* outp = reinterpret_cast<T*>(a.out) + (size_t)b * a.Ho * a.Wo * a.ld_out;
 #pragma unroll
     for (int mm = 0; mm < MTO; ++mm) {
         const int run = (wave + 4 * (mm >> 1)) * 8 + 4 * (mm & 1) + (li >> 2);
@@ -389,30 +470,33 @@ __global__ __launch_bounds__(256, (CP * NG <= 1 ? 3 : 2)) void mbh_kernel(MbhArg
 }
 
 // ------------------------------------------------------------------------------------------ host side
-static size_t mbh_lds_bytes(int ph, int kp, int k) {
+static size_t mbh_lds_bytes(int ph, int kp, int k, int mode) {
     return (((size_t)ph * (kp + 8) * 2 + 15) & ~(size_t)15) + (size_t)ph * MBH_LDE * 4 + (size_t)2 * (k * k + 4) * MBH_EC * 4 +
-           (size_t)2 * 32 * (kp + 8) * 2 + (size_t)4 * 32 * (MBH_EC + 8) * 2;
+           (size_t)2 * 32 * (kp + 8) * 2 + (mode == 0 ? (size_t)4 * 32 * (MBH_EC + 8) * 2 : (size_t)4 * MBH_EC * 4);
 }
 
-template <class T, int K, int S, int CP, int NG>
+template <class T, int K, int S, int CP, int NG, int MODE>
 static int launch_mbh(const MbhArgs& a, int batch, hipStream_t s) {
-    const size_t lds = mbh_lds_bytes(a.PH, a.KP, K);
+    const size_t lds = mbh_lds_bytes(a.PH, a.KP, K, MODE);
     YR_REQUIRE(lds <= 160 * 1024, "mbh: LDS tile of %zu bytes does not fit", lds);
     static bool attr_dev[64] = {false};
     int dev = 0;
     YR_CHECK_HIP(hipGetDevice(&dev));
     if (!attr_dev[dev & 63]) {
-        YR_CHECK_HIP(hipFuncSetAttribute((const void*)mbh_kernel<T, K, S, CP, NG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        YR_CHECK_HIP(hipFuncSetAttribute((const void*)mbh_kernel<T, K, S, CP, NG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        YR_CHECK_HIP(hipFuncSetAttribute((const void*)mbh_kernel<T, K, S, CP, NG, 0, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        YR_CHECK_HIP(hipFuncSetAttribute((const void*)mbh_kernel<T, K, S, CP, NG, 1, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        YR_CHECK_HIP(hipFuncSetAttribute((const void*)mbh_kernel<T, K, S, CP, NG, 2, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_dev[dev & 63] = true;
     }
     static char nm[56];
-    static const int nm_len = snprintf(nm, sizeof(nm), "mbh_kernel<%s,%d,%d,%d,%d>", yr_dtype_name(yr_elem<T>::dtype), K, S, CP, NG);
+    static const int nm_len = MODE == 0 ? snprintf(nm, sizeof(nm), "mbh_kernel<%s,%d,%d,%d,%d>", yr_dtype_name(yr_elem<T>::dtype), K, S, CP, NG)
+                                        : snprintf(nm, sizeof(nm), "mbh_kernel<%s,%d,%d,x,%d>", yr_dtype_name(yr_elem<T>::dtype), K, S, NG);
     (void)nm_len;
     yr_note_kernel(nm);
     const dim3 grid((unsigned)(batch * a.tiles_x * a.tiles_y));
-    if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((mbh_kernel<T, K, S, CP, NG, true>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((mbh_kernel<T, K, S, CP, NG, false>), grid, dim3(256), lds, s, a);
+    if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((mbh_kernel<T, K, S, CP, NG, 0, MODE>), grid, dim3(256), lds, s, a);
+    else if (a.act == YR_ACT_SWISH) hipLaunchKernelGGL((mbh_kernel<T, K, S, CP, NG, 1, MODE>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((mbh_kernel<T, K, S, CP, NG, 2, MODE>), grid, dim3(256), lds, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
 }
@@ -420,11 +504,13 @@ static int launch_mbh(const MbhArgs& a, int batch, hipStream_t s) {
 template <class T, int K, int S>
 static int launch_mbh_shape(const MbhArgs& a, int cp, int ng, int batch, hipStream_t s) {
     switch (cp * 10 + ng) {
-        case 11: return launch_mbh<T, K, S, 1, 1>(a, batch, s);
-        case 12: return launch_mbh<T, K, S, 1, 2>(a, batch, s);
-        case 21: return launch_mbh<T, K, S, 2, 1>(a, batch, s);
-        case 22: return launch_mbh<T, K, S, 2, 2>(a, batch, s);
-        case 41: return launch_mbh<T, K, S, 4, 1>(a, batch, s);
+        case 1: return launch_mbh<T, K, S, 1, 1, 1>(a, batch, s);      // cp == 0: expand + depthwise only (MODE 1)
+        case 2: return launch_mbh<T, K, S, 1, 2, 1>(a, batch, s);
+        case 11: return launch_mbh<T, K, S, 1, 1, 0>(a, batch, s);
+        case 12: return launch_mbh<T, K, S, 1, 2, 0>(a, batch, s);
+        case 21: return launch_mbh<T, K, S, 2, 1, 0>(a, batch, s);
+        case 22: return launch_mbh<T, K, S, 2, 2, 0>(a, batch, s);
+        case 41: return launch_mbh<T, K, S, 4, 1, 0>(a, batch, s);
         default: yr_set_error("mbh: no kernel for %d cout pairs x %d pixel groups per wave", cp, ng); return YR_ERR_ARG;
     }
 }
@@ -434,22 +520,26 @@ static int launch_mbh_shape(const MbhArgs& a, int cp, int ng, int batch, hipStre
 // halo-to-output ratio (the expand GEMM and its epilogue run on halo pixels), whole groups of 8 runs for the four waves,
 // an LDS footprint that leaves several workgroups per CU, and enough workgroups to fill 256 CUs.  The constants were
 // fitted to tools/mbh_probe.py on the MobileNetV2 block shapes.  op.k may force a choice: k = K | th << 8 | tw << 16.
-static void mbh_pick_tile(int ho, int wo, int batch, int k, int s, int kp, int cp, int* th_out, int* tw_out) {
+// cp == 0: the expand + depthwise form; max_tiles > 0 bounds the tiles per image (rows of its partial-sum buffer).
+static void mbh_pick_tile(int ho, int wo, int batch, int k, int s, int kp, int cp, int max_tiles, int* th_out, int* tw_out) {
     double best = 1e30;
     *th_out = 8; *tw_out = 8;
     const int max_groups = cp >= 4 ? 4 : 8;                       // NG <= 1 for 4 cout pairs (accumulator registers)
+    // at least two workgroups per CU if any tile allows it (wide 5x5 stride-2 blocks do not: one workgroup per CU then)
+    for (size_t lds_cap = 78 * 1024; best == 1e30 && lds_cap <= 160 * 1024; lds_cap += 82 * 1024)
     for (int th = 2; th <= 16; ++th)
         for (int tw = 4; tw <= 32; tw += 4) {
             const int runs = th * (tw / 4), groups = (runs + 7) / 8;
             if (groups > max_groups) continue;
             const int ih = (th - 1) * s + k, iw = (tw - 1) * s + k, ph = ih * iw;
-            const size_t lds = mbh_lds_bytes(ph, kp, k);
-            if (lds > 78 * 1024) continue;                            // at least two workgroups per CU
+            const size_t lds = mbh_lds_bytes(ph, kp, k, cp == 0);
+            if (lds > lds_cap) continue;
             const int ty = (ho + th - 1) / th, tx = (wo + tw - 1) / tw;
+            if (max_tiles > 0 && ty * tx > max_tiles) continue;
             const double blocks = (double)batch * ty * tx;
             const int nmt_h = (ph + 15) / 16;
             // work per block: expand on the halo (whole MFMA tiles over 4 waves) + depthwise/project (whole groups over 4 waves)
-            const double per_block = ((nmt_h + 3) / 4) * 1.0 + ((groups + 3) / 4) * 3.0 + 1.5;
+            const double per_block = ((nmt_h + 3) / 4) * 1.0 + ((groups + 3) / 4) * (cp == 0 ? 2.0 : 3.0) * (k == 5 ? 2.0 : 1.0) + 1.5;
             const int per_cu = lds <= 31 * 1024 ? 5 : lds <= 39 * 1024 ? 4 : lds <= 52 * 1024 ? 3 : 2;
             const double rounds = blocks / (256.0 * per_cu);
             const double occ = per_cu >= 4 ? 1.0 : per_cu == 3 ? 1.08 : 1.25;
@@ -465,24 +555,42 @@ static void mbh_pick_tile(int ho, int wo, int batch, int k, int s, int kp, int c
 //   wgt  = expand Wt[CexpP][KP] (16-bit, in the blob: CexpP*KP/2 floats);
 //   wgt2 = [K*K + 4][CexpP] float32: depthwise taps | depthwise BN scale | shift | expand BN scale | shift;
 //   b1   = project Wt[cout][CexpP] (16-bit); b2 = project BN scale [round_up(cout,8)] ++ shift [round_up(cout,8)].
+// YR_OP_MBX (expand + depthwise, the first two thirds of the block): cout = Cexp = the width of the stored depthwise map;
+// wgt, wgt2 as above; no b1 / b2 / res; gate (optional) = OUTPUT, float32 [B][se_reduced][gate_ld] per-tile channel sums
+// (se_reduced = rows of the buffer >= tiles per image; the rows no tile owns are zeroed).
 template <class T>
 static int launch_mbh_t(const yr_op& op, int batch, hipStream_t s) {
+    const bool full = op.kind == YR_OP_MBH;
     YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY, "mbh: needs one identity source");
     const yr_src& in = op.src[0];
     const int K = op.k & 0xff, fth = (op.k >> 8) & 0xff, ftw = (op.k >> 16) & 0xff;
     YR_REQUIRE((K == 3 || K == 5) && (op.stride == 1 || op.stride == 2), "mbh: depthwise %dx%d stride %d is not fused", K, K, op.stride);
-    YR_REQUIRE(in.ptr && op.out && op.wgt && op.wgt2 && op.b1 && op.b2, "mbh: null pointer");
+    YR_REQUIRE(in.ptr && op.out && op.wgt && op.wgt2 && (!full || (op.b1 && op.b2)), "mbh: null pointer");
     YR_REQUIRE(in.dtype == op.dtype && op.out_dtype == op.dtype, "mbh: input and output have the op's 16-bit dtype");
     YR_REQUIRE(in.ld % 8 == 0 && op.out_ld % 8 == 0 && in.c == op.cin && in.ld >= yr_round_up(in.c, 8) && op.out_ld >= yr_round_up(op.cout, 8),
                "mbh: channel strides must be multiples of 8 and cover round_up(c,8)");
     YR_REQUIRE(((uintptr_t)in.ptr | (uintptr_t)op.out | (uintptr_t)op.wgt | (uintptr_t)op.b1 | (uintptr_t)op.wgt2) % 16 == 0, "mbh: pointers must be 16-byte aligned");
-    YR_REQUIRE(op.se_reduced >= 1 && op.cout >= 1 && op.cout <= 128 && op.cin >= 1 && op.cin <= 128, "mbh: widths out of range (cin, cout <= 128)");
+    YR_REQUIRE(op.cout >= 1 && op.cin >= 1 && op.cin <= 128, "mbh: widths out of range (cin <= 128)");
     MbhArgs a;
     a.x = in.ptr; a.out = op.out;
     a.Cin = in.c; a.Cout = op.cout;
-    a.CexpP = yr_round_up(op.se_reduced, 32); a.KP = yr_round_up(in.c, 32);
+    a.KP = yr_round_up(in.c, 32);
     a.we = op.wgt; a.prm = op.wgt2;
-    a.wp = op.b1; a.sp = op.b2; a.hp = op.b2 + yr_round_up(op.cout, 8);
+    a.part = nullptr; a.ld_part = 0; a.rows_cap = 0;
+    if (full) {
+        YR_REQUIRE(op.se_reduced >= 1 && op.cout <= 128, "mbh: widths out of range (cout <= 128)");
+        a.CexpP = yr_round_up(op.se_reduced, 32);
+        a.wp = op.b1; a.sp = op.b2; a.hp = op.b2 + yr_round_up(op.cout, 8);
+    } else {
+        a.CexpP = yr_round_up(op.cout, 32);
+        a.wp = nullptr; a.sp = nullptr; a.hp = nullptr;
+        YR_REQUIRE(op.res == nullptr, "mbx: no residual in the expand + depthwise form");
+        if (op.gate) {
+            YR_REQUIRE(op.gate_ld % 4 == 0 && op.gate_ld >= op.cout && op.gate_ld <= a.CexpP && op.se_reduced >= 1 && ((uintptr_t)op.gate % 16) == 0,
+                       "mbx: bad partial-sum buffer (ld %d for %d channels, %d rows)", op.gate_ld, op.cout, op.se_reduced);
+            a.part = const_cast<float*>(op.gate); a.ld_part = op.gate_ld; a.rows_cap = op.se_reduced;
+        }
+    }
     a.Hi = in.h; a.Wi = in.w; a.Ho = (in.h + op.stride - 1) / op.stride; a.Wo = (in.w + op.stride - 1) / op.stride;
     YR_REQUIRE(a.Ho == op.h && a.Wo == op.w, "mbh: output dims mismatch");
     a.ld_in = in.ld; a.ld_out = op.out_ld;
@@ -491,16 +599,18 @@ static int launch_mbh_t(const yr_op& op, int batch, hipStream_t s) {
     a.has_res = op.res != nullptr;
     if (a.has_res) YR_REQUIRE(op.res == in.ptr && op.stride == 1 && in.c == op.cout, "mbh: the residual must be the block input (stride 1, cin == cout)");
     a.act = op.act;
-    const int cp = op.cout <= 32 ? 1 : (op.cout <= 64 ? 2 : 4);
+    const int cp = !full ? 0 : op.cout <= 32 ? 1 : (op.cout <= 64 ? 2 : 4);
     if (fth && ftw) { a.th = fth; a.tw = ftw; }
-    else mbh_pick_tile(a.Ho, a.Wo, batch, K, op.stride, a.KP, cp, &a.th, &a.tw);
+    else mbh_pick_tile(a.Ho, a.Wo, batch, K, op.stride, a.KP, cp, a.rows_cap, &a.th, &a.tw);
     a.OPX = a.th * a.tw;
     const int groups = (a.th * (a.tw / 4) + 7) / 8;
     YR_REQUIRE(a.tw % 4 == 0 && a.th >= 1 && groups >= 1 && groups <= (cp >= 4 ? 4 : 8),
                "mbh: output tile %dx%d unsupported (tw %% 4 == 0, at most %d pixels)", a.th, a.tw, cp >= 4 ? 128 : 256);
     a.ih = (a.th - 1) * op.stride + K; a.iw = (a.tw - 1) * op.stride + K; a.PH = a.ih * a.iw;
     a.tiles_x = (a.Wo + a.tw - 1) / a.tw; a.tiles_y = (a.Ho + a.th - 1) / a.th;
-    YR_REQUIRE((long long)batch * a.tiles_x * a.tiles_y < (1ll << 31), "mbh: grid too large");
+    YR_REQUIRE((long long)batch * a.tiles_x * a.tiles_y < (1ll << 31) && (long long)a.Ho * a.Wo * a.ld_out < (1ll << 31), "mbh: grid or image too large");
+    YR_REQUIRE(a.part == nullptr || a.tiles_x * a.tiles_y <= a.rows_cap, "mbx: %d tiles per image exceed the %d rows of the partial-sum buffer",
+               a.tiles_x * a.tiles_y, a.rows_cap);
     const int ng = groups <= 4 ? 1 : 2;
     if (K == 3 && op.stride == 1) return launch_mbh_shape<T, 3, 1>(a, cp, ng, batch, s);
     if (K == 3 && op.stride == 2) return launch_mbh_shape<T, 3, 2>(a, cp, ng, batch, s);

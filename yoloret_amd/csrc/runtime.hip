@@ -41,7 +41,7 @@ static int dispatch(const yr_op& op, int batch, hipStream_t s) {
         case YR_OP_MBCONV: return yr_launch_mbconv(op, batch, s);
         case YR_OP_STEMBLOCK: return yr_launch_stemblock(op, batch, s);
         case YR_OP_MBLANE: return yr_launch_mblane(op, batch, s);
-        case YR_OP_MBH: return yr_launch_mbh(op, batch, s);
+        case YR_OP_MBH: case YR_OP_MBX: return yr_launch_mbh(op, batch, s);
         default: yr_set_error("unknown op kind %d", op.kind); return YR_ERR_ARG;
     }
 }
@@ -202,7 +202,7 @@ extern "C" int yr_set_tuning(yr_handle* h, int batch, const int32_t* cfg, int n)
     for (int i = 0; i < n; ++i) {
         const int ncfg = yr_pointwise_num_cfgs(h->ops[i].dtype);
         const bool pw_ok = cfg[i] >= 0 && cfg[i] <= ncfg && (cfg[i] == 0 || h->ops[i].kind == YR_OP_POINTWISE);
-        const bool mbh_ok = h->ops[i].kind == YR_OP_MBH && cfg[i] >= 0 && (cfg[i] & 0xff) == 0 && cfg[i] < (1 << 24);   // th << 8 | tw << 16
+        const bool mbh_ok = (h->ops[i].kind == YR_OP_MBH || h->ops[i].kind == YR_OP_MBX) && cfg[i] >= 0 && (cfg[i] & 0xff) == 0 && cfg[i] < (1 << 24);   // th << 8 | tw << 16
         YR_REQUIRE(pw_ok || mbh_ok, "yr_set_tuning: entry %d = %d is not a valid tile shape for that op", i, cfg[i]);
         t[i] = cfg[i];
     }
@@ -228,7 +228,7 @@ static int resolve_op(const yr_handle* h, size_t i, int batch, float* const ext[
     if (op.kind == YR_OP_POINTWISE) {
         auto it = h->tuned.find(batch);
         op.k = it != h->tuned.end() ? it->second[i] : 0;
-    } else if (op.kind == YR_OP_MBH) {   // the tuned output tile (th << 8 | tw << 16) rides in the upper bytes of k
+    } else if (op.kind == YR_OP_MBH || op.kind == YR_OP_MBX) {   // the tuned output tile (th << 8 | tw << 16) rides in the upper bytes of k
         auto it = h->tuned.find(batch);
         if (it != h->tuned.end()) op.k = (op.k & 0xff) | it->second[i];
     }
@@ -326,7 +326,7 @@ extern "C" int yr_autotune(yr_handle* h, const float* images, int batch, float* 
     YR_CHECK_HIP(hipEventCreate(&e1));
     std::vector<int> best(h->ops.size(), 0);
     for (size_t i = 0; i < h->ops.size() && rc == YR_OK; ++i) {
-        if (h->ops[i].kind == YR_OP_MBH) {
+        if (h->ops[i].kind == YR_OP_MBH || h->ops[i].kind == YR_OP_MBX) {
             // fused 16-bit block: time a fixed list of output tiles (runs of 4 along x: tw % 4 == 0); tiles the op
             // cannot take (too many pixels for its accumulators, LDS footprint) are refused by the launcher and skipped
             static const int tiles[][2] = {{4, 8}, {8, 4}, {7, 4}, {7, 8}, {8, 8}, {13, 4}, {4, 16}, {8, 16}, {7, 16}, {13, 8},
