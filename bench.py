@@ -228,7 +228,7 @@ def main():
         post_ms /= reps
         rows = prof + [
             dict(name='decode', kind='decode', kernel='decode_kernel', ms=post_ms[0], macs=0, bytes=alg_dec * b),
-            dict(name='nms', kind='nms', kernel='nms_lazy_kernel<256>(+<1024> overflow pass)' if n_boxes * 6 + 16 + 320 <= 150 * 1024 else 'nms_kernel',
+            dict(name='nms', kind='nms', kernel=('nms_band_kernel<%s>(+nms_lazy_kernel<1024> overflow pass)' % ('256,44' if n_boxes <= 11264 else '512,50' if n_boxes <= 25600 else '1024,38')) if n_boxes * 6 + 16 + 320 <= 150 * 1024 else 'nms_kernel',
                  ms=post_ms[1], macs=0,
                  bytes=(a.classes * n_boxes * 4 + n_boxes * 16) * b),
             dict(name='pack', kind='pack', kernel='pack_kernel', ms=post_ms[2], macs=0, bytes=0)]
@@ -284,7 +284,7 @@ def main():
             # the whole step's measured traffic: sum over symbols of (PMC bytes per launch x launches per step)
             tot, miss = 0.0, []
             for sym, v in by.items():
-                names = ['nms_lazy_kernel<256>', 'nms_lazy_kernel<1024>'] if sym.startswith('nms_lazy') else [sym]
+                names = [sym.split('(')[0], 'nms_lazy_kernel<1024>'] if sym.startswith('nms_band') else [sym]
                 for nme in names:
                     t = lookup(nme)
                     if t:

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs<T> a) {
             if (x0 + i < a.Wo) {
                 float4 v[Q];
 #pragma unroll
-                for (int q = 0; q < Q; ++q) v[q] = yr_apply_act4(fma4(acc[j][i][q], sc[q], sh[q]), a.act);
+                for (int q = 0; q < Q; ++q) v[q] = yr_apply_act4_t<T>(fma4(acc[j][i][q], sc[q], sh[q]), a.act);
                 if (!SE || live) dw_store<T, Q>(op + (size_t)i * a.ld_out, v);
                 if constexpr (SE) {
                     if constexpr (Q == 2) {   // the mean is that of the STORED (rounded) values

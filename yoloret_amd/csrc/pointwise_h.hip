@@ -180,7 +180,10 @@ __device__ __forceinline__ void pwh_finish_oct(const PwArgs& a, const f32x4& lo,
         for (int r = 0; r < 8; ++r) v[r] += q[r];
     }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = yr_apply_act(__builtin_fmaf(v[r], sc[r], sh[r]), a.act);
+    for (int r = 0; r < 8; ++r) {
+        const float t = __builtin_fmaf(v[r], sc[r], sh[r]);
+        v[r] = a.out_f32 ? yr_apply_act(t, a.act) : yr_apply_act_t<T>(t, a.act);   // (uniform; float32 outputs keep the pinned path)
+    }
     if (a.res) {  // uniform; the residual has the op's 16-bit type and a pitch that is a multiple of 8
         const pwh_f8 t = pwh_widen<T>(*reinterpret_cast<const pwh_u4*>(reinterpret_cast<const T*>(a.res) + (size_t)ml * a.res_ld + nld));
 #pragma unroll

@@ -7,6 +7,7 @@
 // (library built with -ffp-contract=off) and exp() pinned to yr_expf, so that the results
 // are bit-identical to the C oracle (oracle/csrc/yr_oracle.c) on identical logits.
 #include "yr_common.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------ letterbox inverse terms
 struct Letterbox {
@@ -510,6 +511,171 @@ __global__ __launch_bounds__(T) void nms_lazy_kernel(NmsLazyArgs L) {
     for (int i = nsel + tid; i < a.max_boxes; i += T) oi[i] = -1;
 }
 
+// Band-wise lazy greedy NMS: the first launch of yr_nms.  Greedy NMS pops candidates in descending (score, then
+// ascending index) order and tests each only against the boxes selected so far, so only the top of the order ever
+// matters - typically a few more entries than max_boxes.  One workgroup of T lanes per (image, class):
+//   1. every lane reads its <= SR scores ONCE into registers; candidates (score > thr) go into a 2048-bin histogram
+//      of the scores (linear in [thr, 1], monotone in the score) in LDS;
+//   2. a BAND is the widest run of bins below the previous band that holds <= 64 (then 128, ... T) candidates (found
+//      from a block-wide scan of the histogram).  Its candidates are compacted from the registers (one per lane), every lane fetches
+//      its box and computes the rank of its entry among the band's by (score desc, index asc) - T broadcast reads,
+//      no sort, no barrier - and scatters (box, index) to that rank;
+//   3. wave 0 walks the ranked band: entry r is selected unless its IoU with an already selected box exceeds the
+//      threshold (lanes = selected boxes, __any) - a single wave, no workgroup barrier per step;
+//   4. bands repeat, downwards, until max_boxes are selected or the candidates run out.
+// Exact: a higher bin means a strictly higher score, so band after band in rank order IS the global descending order,
+// ties included (equal scores share a bin).  The kernel this replaces as the first pass (nms_lazy_kernel<256>, still
+// the second pass) built and insertion-sorted a list of up to 5200 candidates and found every pick by a block-wide
+// arg-max with three barriers: ~100 us per problem, latency-bound; this one is ~10 us.  A problem whose next bin alone
+// holds more than a band's capacity (a mass of equal scores) is flagged (count = -1) for the second pass.
+template <int T, int SR>
+#ifndef NMS_BAND_WPE
+#define NMS_BAND_WPE 5
+#endif
+__global__ __launch_bounds__(T, (T <= 256 ? NMS_BAND_WPE : 4)) void nms_band_kernel(NmsArgs a) {   // (second argument: waves per SIMD)
+    constexpr int NB = 2048, BPT = NB / T;   // bins per lane; lane t owns the descending bins NB-1-(t*BPT+j)
+    static_assert(NB % T == 0, "bins divide over the lanes");
+    extern __shared__ float4 nms_lds[];
+    float4* selb = nms_lds;                  // [max_boxes] selected boxes
+    __shared__ unsigned hist[NB];
+    __shared__ int cum[T];                   // candidates in the bins of lanes 0..t (inclusive)
+    __shared__ __attribute__((aligned(16))) float ks[T];   // the band: scores, box indices (compacted, unordered)
+    __shared__ __attribute__((aligned(16))) int ki[T];
+    __shared__ float4 sbox[T];               // ... ranked: boxes, box indices
+    __shared__ int sidx[T];
+    __shared__ int wtot[T / 64];
+    __shared__ int cnt, lo_s, nsel_s;
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* sc = a.scores + ((size_t)b * a.C + c) * a.N;
+    const float4* bx = reinterpret_cast<const float4*>(a.boxes) + (size_t)b * a.N;
+    int32_t* oi = a.out_idx + ((size_t)b * a.C + c) * a.max_boxes;
+    const float thr = a.score_thr;
+    const float scale = (float)NB / (1.0f - thr);
+    auto bin_of = [&](float v) { const int q = (int)((v - thr) * scale); return q < 0 ? 0 : (q > NB - 1 ? NB - 1 : q); };
+
+    float sreg[SR];
+#pragma unroll
+    for (int u = 0; u < SR; ++u) {
+        const int i = u * T + tid;
+        const float v = sc[i < a.N ? i : a.N - 1];   // (clamped, unconditional: all SR loads in flight at once - written
+        sreg[u] = i < a.N ? v : thr;                 //  as a branch per load they ran one HBM round trip after the other)
+                                                     // thr itself is not a candidate
+    }
+    for (int i = tid; i < NB; i += T) hist[i] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SR; ++u) {
+        if (sreg[u] > thr) atomicAdd(&hist[bin_of(sreg[u])], 1u);
+        if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (keeps the unrolled bodies from piling up their temporaries)
+    }
+    __syncthreads();
+    // inclusive scan over the lanes of the per-lane bin sums (descending bins)
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) mine += (int)hist[NB - 1 - (tid * BPT + j)];
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wtot[w];
+    incl += before;
+    cum[tid] = incl;
+    __syncthreads();
+    const int total = cum[T - 1];
+
+    int hi = NB, base = 0, nsel = 0;         // bins >= hi are done; they held `base` candidates
+    // band capacity: 64 entries first (max_boxes picks rarely need more than a few dozen pops, and ranking costs
+    // capacity^2 LDS reads), doubling per band up to one entry per lane
+    for (int bcap = 64 < T ? 64 : T; base < total; bcap = 2 * bcap < T ? 2 * bcap : T) {   // (workgroup-uniform)
+        if (tid == 0) { lo_s = NB; cnt = 0; }
+        __syncthreads();
+        {   // the lowest bin lo < hi with (candidates in bins [lo, hi)) <= bcap
+            int s = tid ? cum[tid - 1] : 0, mylo = NB;
+#pragma unroll
+            for (int j = 0; j < BPT; ++j) {
+                const int bin = NB - 1 - (tid * BPT + j);
+                s += (int)hist[bin];
+                if (bin < hi && s - base <= bcap) mylo = bin;
+            }
+            if (mylo < NB) atomicMin(&lo_s, mylo);
+        }
+        __syncthreads();
+        const int lo = lo_s;
+        if (lo >= NB) {                      // the next bin alone overflows a band: the second pass redoes the problem
+            if (tid == 0) a.out_count[(size_t)b * a.C + c] = -1;
+            return;
+        }
+        {   // compact the band from the registers: per-lane count, wave scan, ONE LDS atomic per wave, then the writes
+            static_assert(SR <= 64, "one mask bit per score register");
+            unsigned long long km = 0ull;
+#pragma unroll
+            for (int u = 0; u < SR; ++u) {
+                const float v = sreg[u];
+                bool keep = v > thr;
+                if (keep) { const int q = bin_of(v); keep = q >= lo && q < hi; }
+                km |= (unsigned long long)(keep ? 1 : 0) << u;
+                if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            const int mycnt = __popcll(km);
+            int incl2 = mycnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl2, o);
+                if (lane >= o) incl2 += v;
+            }
+            int wbase = 0;
+            if (lane == 63 && incl2 > 0) wbase = atomicAdd(&cnt, incl2);
+            wbase = __shfl(wbase, 63);
+            int pos = wbase + incl2 - mycnt;
+#pragma unroll
+            for (int u = 0; u < SR; ++u)
+                if ((km >> u) & 1ull) { ks[pos] = sreg[u]; ki[pos] = u * T + tid; ++pos; }
+        }
+        __syncthreads();
+        const int n = cnt;                   // 1 <= n <= T
+        if (tid < n) {
+            const float s = ks[tid];
+            const int i = ki[tid];
+            const float4 box = bx[i];        // (in flight while the rank is counted)
+            int rank = 0;
+            for (int j = 0; j < n; j += 4) { // LDS broadcast reads, four entries at a time (entries >= n are stale: masked)
+                const float4 s4 = *reinterpret_cast<const float4*>(ks + j);
+                const int4 i4 = *reinterpret_cast<const int4*>(ki + j);
+                rank += (s4.x > s || (s4.x == s && i4.x < i)) ? 1 : 0;
+                rank += (j + 1 < n && (s4.y > s || (s4.y == s && i4.y < i))) ? 1 : 0;
+                rank += (j + 2 < n && (s4.z > s || (s4.z == s && i4.z < i))) ? 1 : 0;
+                rank += (j + 3 < n && (s4.w > s || (s4.w == s && i4.w < i))) ? 1 : 0;
+            }
+            sbox[rank] = box; sidx[rank] = i;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int r = 0; r < n && nsel < a.max_boxes; ++r) {
+                const float4 pb = sbox[r];
+                bool sup = false;
+                for (int j = lane; j < nsel; j += 64) sup = sup || (yr_iou(pb, selb[j]) > a.iou_thr);
+                if (!__any(sup)) {
+                    if (lane == 0) { oi[nsel] = sidx[r]; selb[nsel] = pb; }
+                    ++nsel;
+                }
+            }
+            if (lane == 0) nsel_s = nsel;
+        }
+        __syncthreads();
+        nsel = nsel_s;
+        if (nsel >= a.max_boxes) break;
+        base += n;
+        hi = lo;
+    }
+    if (tid == 0) a.out_count[(size_t)b * a.C + c] = nsel;
+    for (int i = nsel + tid; i < a.max_boxes; i += T) oi[i] = -1;
+}
+
 extern "C" int yr_nms(const float* boxes, const float* scores, int batch, int n, int num_classes, int max_boxes,
                       float score_thr, float iou_thr, int32_t* out_idx, int32_t* out_count, void* stream) {
     YR_REQUIRE(boxes && scores && out_idx && out_count, "nms: null pointer");
@@ -535,11 +701,22 @@ extern "C" int yr_nms(const float* boxes, const float* scores, int batch, int n,
     const size_t lds_full = sel_bytes + (size_t)n * 6 + 16;
     hipStream_t st = (hipStream_t)stream;
     if (n < 65536 && lds_full <= lds_limit) {
-        // pass 1: capped lists for every problem; pass 2: full-capacity lists, only where pass 1 overflowed
-        L.cap = n < NMS_CAP1 ? n : NMS_CAP1;
-        L.only_overflow = 0;
-        hipLaunchKernelGGL(nms_lazy_kernel<256>, dim3(num_classes, batch), dim3(256), sel_bytes + (size_t)L.cap * 6 + 16, st, L);
-        if (L.cap < n) {
+        // pass 1: band-wise lists for every problem (scores in registers: the lane count follows n); pass 2: full-capacity
+        // sorted lists, only where pass 1 met a bin with more candidates than a band holds
+        static const bool band_on = [] { const char* e = getenv("YOLORET_NMS_BAND"); return !(e && e[0] == '0'); }();   // (A/B switch)
+        const bool band_ok = band_on && score_thr < 1.0f && score_thr > -1e30f;   // a finite linear histogram range [thr, 1]
+        if (band_ok && n <= 256 * 44) {
+            hipLaunchKernelGGL((nms_band_kernel<256, 44>), dim3(num_classes, batch), dim3(256), sel_bytes, st, a);
+        } else if (band_ok && n <= 512 * 50) {
+            hipLaunchKernelGGL((nms_band_kernel<512, 50>), dim3(num_classes, batch), dim3(512), sel_bytes, st, a);
+        } else if (band_ok) {
+            hipLaunchKernelGGL((nms_band_kernel<1024, 38>), dim3(num_classes, batch), dim3(1024), sel_bytes, st, a);   // n <= 38400
+        } else {
+            L.cap = n < NMS_CAP1 ? n : NMS_CAP1;
+            L.only_overflow = 0;
+            hipLaunchKernelGGL(nms_lazy_kernel<256>, dim3(num_classes, batch), dim3(256), sel_bytes + (size_t)L.cap * 6 + 16, st, L);
+        }
+        if (band_ok || L.cap < n) {
             L.cap = n;
             L.only_overflow = 1;
             hipLaunchKernelGGL(nms_lazy_kernel<1024>, dim3(num_classes, batch), dim3(1024), lds_full, st, L);

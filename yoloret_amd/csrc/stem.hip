@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs<T> a) {
         const float4 sh = *reinterpret_cast<const float4*>(a.shift + q * 4);
         float4 v = make_float4(__builtin_fmaf(acc[q].x, sc.x, sh.x), __builtin_fmaf(acc[q].y, sc.y, sh.y),
                                __builtin_fmaf(acc[q].z, sc.z, sh.z), __builtin_fmaf(acc[q].w, sc.w, sh.w));
-        *reinterpret_cast<float4*>(otile + (tid * CQ + q) * 4) = yr_apply_act4(v, a.act);
+        *reinterpret_cast<float4*>(otile + (tid * CQ + q) * 4) = yr_apply_act4_t<T>(v, a.act);
     }
     __syncthreads();
     for (int i = tid; i < 256 * CQ; i += 256) {
