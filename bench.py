@@ -402,6 +402,27 @@ def main():
                         'host_bytes_per_image': int(u8[0].numel()),
                         'path': 'pinned uint8 [B,H,W,3] -> hipMemcpyAsync H2D -> yr_letterbox_batch (u8/255, letterbox) -> step; '
                                 'copy, conversion and step serialised on one stream'}
+            # the same with the copy of batch i+1 on its own stream behind step i (yoloret_amd.pipeline.HostFeeder)
+            from yoloret_amd.pipeline import HostFeeder
+            feeder = HostFeeder(tuple(u8.shape), (a.size, a.size), dev, slots=2)
+
+            def step_fed():
+                feeder.submit(u8)
+                feeder.take(out=x)
+                return step()
+            feeder.submit(u8)
+            for _ in range(3):
+                step_fed()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(nh):
+                step_fed()
+            sync()
+            dtf = (time.perf_counter() - t1) / nh
+            feeder.take(out=x)
+            sync()
+            incl_h2d['overlapped'] = {'img_s': round(b / dtf, 1), 'ms_per_step': round(dtf * 1e3, 4),
+                                      'path': 'HostFeeder: the H2D copy of batch i+1 on a second stream while batch i computes (two device buffers)'}
         out = {'metric': 'images/sec (+ p50 per-image ms) MobileNetV2-0.75x @416, 1/2/4/8 MI355X',
                'value': round(value, 1), 'unit': 'img/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
                'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',

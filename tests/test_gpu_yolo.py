@@ -196,3 +196,34 @@ def test_map_callback_through_the_hip_model(dev, tmp_path):
         assert (aps[c] > 0.9) if c in seen else (aps[c] == 0), (c, aps[c])
     logs = cb.on_train_end({})
     assert abs(logs['mAP'] - sum(want.values()) / 20.0) < 1e-12 and cb.seconds_per_image > 0
+
+
+def test_host_feeder_overlaps_copies_without_changing_the_input(dev):
+    """HostFeeder: batches submitted from pinned host memory come out of take() as exactly the letterboxed input the
+    synchronous path produces, in order, with up to `slots` copies in flight; misuse is refused."""
+    from yoloret_amd import runtime as rt
+    from yoloret_amd.pipeline import HostFeeder
+    rng = np.random.default_rng(11)
+    shape = (4, 60, 90, 3)
+    batches = [torch.from_numpy(rng.integers(0, 256, shape, dtype=np.uint8)).pin_memory() for _ in range(5)]
+    want = [rt.letterbox(b.to(dev), (96, 96)).cpu() for b in batches]
+    f = HostFeeder(shape, (96, 96), dev, slots=2)
+    out = torch.empty((4, 96, 96, 3), dtype=torch.float32, device=dev)
+    f.submit(batches[0])
+    got = []
+    for i in range(5):
+        if i + 1 < 5:
+            f.submit(batches[i + 1])                 # the next copy is enqueued before this batch is consumed
+        x = f.take(out=out if i % 2 else None)
+        got.append(x.cpu())                          # (synchronises; the next take() may overwrite `out`)
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+    with pytest.raises(RuntimeError, match='nothing was submitted'):
+        f.take()
+    f.submit(batches[0]); f.submit(batches[1])
+    with pytest.raises(RuntimeError, match='not taken yet'):
+        f.submit(batches[2])
+    with pytest.raises(ValueError, match='pinned'):
+        HostFeeder(shape, (96, 96), dev).submit(torch.zeros(shape, dtype=torch.uint8))
+    with pytest.raises(ValueError, match='uint8 host tensor'):
+        HostFeeder(shape, (96, 96), dev).submit(torch.zeros((4, 60, 90, 3), dtype=torch.float32).pin_memory())

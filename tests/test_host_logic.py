@@ -100,14 +100,49 @@ def test_plan_variants(monkeypatch):
     assert _model().variant(1) == 'throughput'
 
 
-def test_arena_has_no_overlapping_live_buffers():
-    p = _model('efficientnetb0', 64).plan
+@pytest.mark.parametrize('policy', ['float32', 'mixed_bfloat16'])
+def test_arena_has_no_overlapping_live_buffers(policy):
+    from yoloret_amd import layers as L
+    L.set_global_policy(policy)
+    try:
+        p = _model('efficientnetb0', 64).plan
+    finally:
+        L.set_global_policy('float32')
     arena = [b for b in p.bufs if b.external_slot < 0]
     for i, a in enumerate(arena):
         for b in arena[i + 1:]:
             overlap_t = not (a.last_use < b.first_def or b.last_use < a.first_def)
-            overlap_m = not (a.offset + a.elems <= b.offset or b.offset + b.elems <= a.offset)
+            overlap_m = not (a.offset + a.bytes <= b.offset or b.offset + b.bytes <= a.offset)   # offsets are bytes per image
             assert not (overlap_t and overlap_m), (a.name, b.name)
+
+
+def test_squeeze_excite_blocks_of_a_16_bit_plan_fuse_expand_and_depthwise():
+    """16-bit EfficientNet plan: every MBConv block with squeeze-excite and an expand conv of at most 128 inputs becomes
+    MBX (expand + depthwise, per-tile channel sums out) -> SE_FC reading those sums -> gated projection; parameters,
+    MACs and the conv-granular byte accounting are those of the unfused float32 plan."""
+    from yoloret_amd import layers as L, runtime as rt
+    f32 = _model('efficientnetb0', 416, 80).plan
+    L.set_global_policy('mixed_bfloat16')
+    try:
+        p = _model('efficientnetb0', 416, 80).plan
+    finally:
+        L.set_global_policy('float32')
+    ops = p.ops
+    mbx = [i for i, o in enumerate(ops) if o.kind == rt.OP_MBX]
+    assert len(mbx) == 11 and [ops[i].name for i in mbx][:2] == ['stage2_block0_mbx', 'stage2_block1_mbx']
+    for i in mbx:
+        m, fc, proj = ops[i], ops[i + 1], ops[i + 2]
+        assert fc.kind == rt.OP_SE_FC and proj.kind == rt.OP_POINTWISE
+        assert m.gate is not None and m.gate.dtype == 0 and fc.srcs[0].buf is m.gate and fc.k == m.h * m.w
+        rows = ((m.h + 3) // 4) * ((m.w + 7) // 8 if m.h * m.w > 1000 else (m.w + 3) // 4)
+        assert m.se_reduced == rows == m.gate.h and m.gate.ld >= m.cout and m.out.dtype == rt.DTYPE['bf16']
+        assert proj.srcs[0].buf is m.out and proj.gate is fc.out and m.srcs[0].c <= 128
+        assert m.params['wgt'][0] == ((m.cout + 31) // 32 * 32, (m.cin + 31) // 32 * 32) and m.params['wgt'][2] == rt.DTYPE['bf16']
+        assert m.params['wgt2'][0] == (m.k * m.k + 4, (m.cout + 31) // 32 * 32)
+    # the 13x13 blocks with 192 inputs stay unfused
+    assert sum(1 for o in ops if o.kind == rt.OP_DEPTHWISE and o.name.startswith('stage6_block')) == 3
+    assert p.param_shapes == f32.param_shapes and p.total_macs() == f32.total_macs()
+    assert abs(2 * p.algorithmic_bytes_per_image() - f32.algorithmic_bytes_per_image()) < 1
 
 
 @pytest.mark.parametrize('name', ['mobilenetv2x75', 'mobilenetv2x14', 'efficientnetb0', 'efficientnetb3', 'efficientnetb0-lite'])

@@ -269,7 +269,7 @@ STEMBLOCK_WIDTHS ={(12, 16), (16, 16), (16, 24), (20, 24), (24, 16), (24, 24)}  
 FUSE_MBH = os.environ.get('YOLORET_FUSE_MBH', '1') != '0'   # 16-bit plans: inverted-residual blocks on the MFMA block kernel (mbh.hip)
 MBH_LANE_MIN_PIXELS = int(os.environ.get('YOLORET_MBH_LANE_MIN_PIXELS', '10000'))
 FUSE_MBX = os.environ.get('YOLORET_FUSE_MBX', '1') != '0'   # 16-bit plans: expand + depthwise of squeeze-excite MBConv blocks in one kernel
-MBH_ACTS = ('relu6',) if os.environ.get('YOLORET_MBH_SWISH', '0') == '0' else ('relu6', 'swish')
+MBH_ACTS = ('relu6', 'swish')   # (swish in the fused 16-bit kernels: hardware exp2 / rcp, no register spills)
 
 
 HOIST_UPSAMPLE = os.environ.get('YOLORET_HOIST', '1') != '0'

@@ -127,3 +127,58 @@ class DetectionPipeline:
             hws.copy_(image_hw)
         graph.replay()
         return out
+
+
+class HostFeeder:
+    """Batches of decoded images from host memory, the copy hidden behind the previous step.
+
+    The reference hands `YoloModel` encoded bytes one image at a time (code/yolo.py:105-112, 152); a serving loop
+    decodes on the host and owns a batch of equally sized uint8 images [B,ih,iw,3] in PINNED memory.  `submit()` puts
+    the host-to-device copy of that batch on the feeder's own HIP stream into one of `slots` device buffers;
+    `take()` - on the caller's (compute) stream - waits for that copy only, converts (u8/255 + letterbox,
+    yr_letterbox_batch) into the network input and releases the buffer.  With two slots the PCIe transfer of batch i+1
+    runs while batch i computes; a quarter of the float32 bytes cross the bus."""
+
+    def __init__(self, batch_shape, input_hw, device, slots=2):
+        if len(batch_shape) != 4 or batch_shape[3] != 3 or slots < 1:
+            raise ValueError('HostFeeder: batch_shape must be (B, ih, iw, 3), slots >= 1')
+        self.device = torch.device(device)
+        self.input_hw = (int(input_hw[0]), int(input_hw[1]))
+        self.batch_shape = tuple(int(v) for v in batch_shape)
+        self.copy_stream = torch.cuda.Stream(self.device)
+        self.dbuf = [torch.empty(self.batch_shape, dtype=torch.uint8, device=self.device) for _ in range(slots)]
+        self.copied = [torch.cuda.Event() for _ in range(slots)]
+        self.released = [None] * slots
+        self._head = self._tail = 0          # batches submitted / taken
+
+    def submit(self, images_u8):
+        """Enqueue the copy of one pinned host batch; returns immediately.  At most `slots` batches may be in flight."""
+        if (not isinstance(images_u8, torch.Tensor) or images_u8.is_cuda or images_u8.dtype != torch.uint8
+                or tuple(images_u8.shape) != self.batch_shape or not images_u8.is_contiguous()):
+            raise ValueError('HostFeeder.submit: a contiguous uint8 host tensor %s is expected' % (self.batch_shape,))
+        if not images_u8.is_pinned():
+            raise ValueError('HostFeeder.submit: the host batch must be pinned (tensor.pin_memory()): a pageable copy blocks the host')
+        if self._head - self._tail >= len(self.dbuf):
+            raise RuntimeError('HostFeeder.submit: all %d buffers hold batches that were not taken yet' % len(self.dbuf))
+        s = self._head % len(self.dbuf)
+        with torch.cuda.stream(self.copy_stream):
+            if self.released[s] is not None:
+                self.copy_stream.wait_event(self.released[s])    # the conversion that read this buffer last
+            self.dbuf[s].copy_(images_u8, non_blocking=True)
+            self.copied[s].record(self.copy_stream)
+        self._head += 1
+
+    def take(self, out=None):
+        """The oldest submitted batch as the float32 network input [B,H,W,3] (written into `out` if given), enqueued on
+        the current stream of the feeder's device."""
+        if self._tail >= self._head:
+            raise RuntimeError('HostFeeder.take: nothing was submitted')
+        s = self._tail % len(self.dbuf)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(self.copied[s])
+        x = rt.letterbox(self.dbuf[s], self.input_hw, out=out)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.released[s] = ev
+        self._tail += 1
+        return x
