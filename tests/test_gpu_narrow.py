@@ -483,7 +483,10 @@ def test_policy_and_dtype_plumbing(dev):
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('k,s,h,w,c,r', [(3, 1, 13, 13, 512, 128), (3, 1, 26, 26, 256, 64), (3, 1, 52, 52, 128, 32), (5, 1, 13, 9, 64, 4),
-                                         (3, 2, 27, 26, 128, 8), (5, 2, 14, 14, 256, 16)])
+                                         (3, 2, 27, 26, 128, 8), (5, 2, 14, 14, 256, 16),
+                                         # channel-vector counts that do not divide 256 (several workgroups share a row):
+                                         (3, 1, 40, 36, 40, 10), (5, 1, 20, 20, 816, 34), (5, 2, 21, 20, 1392, 58), (3, 1, 9, 7, 100, 6),
+                                         (3, 1, 13, 13, 1152, 48)])
 def test_depthwise_se_form(dev, dt, k, s, h, w, c, r):
     """The squeeze of squeeze-excite as an epilogue of the depthwise conv (efficientnet.py:417 after :501-510): the SE
     form writes the same map as the plain op, bit for bit, plus per-workgroup channel sums; SE_FC (k = pixel count) on
@@ -520,9 +523,12 @@ def test_depthwise_se_form(dev, dt, k, s, h, w, c, r):
         torch.cuda.synchronize()
         return out
     plain = dw()
+    from yoloret_amd.compiler import dw_se_geometry
     c4 = (c + V - 1) // V
     xt = 4 if s == 1 else 2
-    rows = (ho * ((wo + xt - 1) // xt) * c4 + 255) // 256
+    rows = dw_se_geometry(ho * ((wo + xt - 1) // xt), c4)[2]
+    if c4 <= 256 and 256 % c4 == 0:
+        assert rows == (ho * ((wo + xt - 1) // xt) * c4 + 255) // 256
     part = torch.full((b, rows, ldc), float('nan'), dtype=torch.float32, device=dev)
     fused = dw(part, rows)
     assert torch.equal(plain.view(torch.int16 if dt != 'f32' else torch.int32), fused.view(torch.int16 if dt != 'f32' else torch.int32))

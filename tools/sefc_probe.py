@@ -11,16 +11,31 @@ dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 
 
+COLD = os.environ.get('SEFC_COLD', '0') != '0'   # 1: a 1.5 GB fill between launches (caches cold, as inside a real step)
+junk = torch.empty(3 * 2 ** 27, dtype=torch.float32, device=dev) if COLD else None
+
+
 def timed(op, n=50):
     rt.run_op(op, B)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
+    if not COLD:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            rt.run_op(op, B)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3
+    tot = 0.0
+    for _ in range(10):
+        junk.fill_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         rt.run_op(op, B)
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
+        e1.record()
+        torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1)
+    return tot / 10 * 1e3
 
 
 for name, rows, c, r, px in [('td1/bu1 13x13', 11, 384, 16, 169), ('td2/bu2 26x26', 43, 192, 8, 676), ('td3/bu3 52x52', 169, 96, 4, 2704),

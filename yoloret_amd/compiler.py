@@ -349,12 +349,23 @@ def merge_se_mean(ops):
 SE_PARTIALS = os.environ.get('YOLORET_SE_PARTIALS', '1') != '0'
 
 
+def dw_se_geometry(strips, c4):
+    """== dw_se_geometry() in depthwise.hip: (channel vectors per workgroup, workgroups per strip group, rows of the
+    partial-sum buffer) of the squeeze-excite form of the depthwise kernel."""
+    cw = c4
+    if c4 > 256 or 256 % c4:
+        cw = 1
+        while cw < c4 and cw < 32:
+            cw <<= 1
+    return cw, (c4 + cw - 1) // cw, (strips + 256 // cw - 1) // (256 // cw)
+
+
 def se_partials_from_depthwise(ops, bufs):
     """the squeeze of squeeze-excite (tf.reduce_mean over H, W; efficientnet.py:417) as an epilogue of
     the depthwise conv that produces the map.  The SE_FC op with the merged mean re-reads the whole map for it (one
     workgroup per image: 54 MB per launch on the 52x52 head block); here every workgroup of the depthwise kernel adds up
     the outputs it has just computed, per channel, in a fixed order, and writes one float32 row; SE_FC adds the rows up
-    and divides by the pixel count.  Needs all channel vectors of a pixel strip inside one workgroup: 256 % C4 == 0."""
+    and divides by the pixel count."""
     producer = {}
     for op in ops:
         producer[id(op.out)] = op
@@ -366,10 +377,8 @@ def se_partials_from_depthwise(ops, bufs):
             continue
         v = rt.VEC[d.dtype]
         c4 = (d.cout + v - 1) // v
-        if c4 > 256 or 256 % c4:
-            continue
         xt = 4 if d.stride == 1 else 2
-        rows = (d.h * ((d.w + xt - 1) // xt) * c4 + 255) // 256          # == dw_se_blocks() in depthwise.hip
+        rows = dw_se_geometry(d.h * ((d.w + xt - 1) // xt), c4)[2]
         part = Buf(len(bufs), rows, 1, d.cout, round_up(d.cout, v), name=d.name + ':se_sums', dtype=0)
         bufs.append(part)
         d.gate, d.se_reduced = part, rows

@@ -30,9 +30,11 @@ struct DwArgs {
     unsigned nblocks;
     // SE form (squeeze-excite squeeze fused in, efficientnet.py:417): grid = (workgroups per image, B); every workgroup
     // also writes the sums of ITS outputs per channel to part[b][blockIdx.x][..] (float32, fixed order: deterministic);
-    // the SE_FC op adds the workgroups' rows up instead of re-reading the whole map.  Needs 256 % C4 == 0.
+    // the SE_FC op adds the rows up instead of re-reading the whole map.  A workgroup's 256 lanes are `cw` channel vectors
+    // x 256/cw pixel strips (dw_se_geometry): cw = C4 when that divides 256, else a power of two - `ncb` workgroups then
+    // share a group of strips and each writes its own channels of that group's row.
     float* part;
-    int ld_part;
+    int ld_part, cw, ncb;
 };
 
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
@@ -72,11 +74,22 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs<T> a) {
     // SE: grid (workgroups per image, B), walked in XCD-contiguous order like the plain form (adjacent strips share input rows)
     const unsigned lin = SE ? yr_xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y) : 0u;
     const unsigned se_b = SE ? lin / gridDim.x : 0u, se_blk = SE ? lin - se_b * gridDim.x : 0u;
-    long long gid = SE ? (long long)se_blk * 256 + threadIdx.x
-                       : (long long)yr_xcd_swizzle(blockIdx.x, a.nblocks) * 256 + threadIdx.x;
-    const bool live = gid < a.total;
+    long long gid = SE ? 0ll : (long long)yr_xcd_swizzle(blockIdx.x, a.nblocks) * 256 + threadIdx.x;
+    bool live = gid < a.total;
+    unsigned se_row = 0u;                    // SE: the row of `part` this workgroup's strips belong to
+    if constexpr (SE) {
+        const int cvl = (int)threadIdx.x % a.cw, sl = (int)threadIdx.x / a.cw;
+        const unsigned cb = se_blk % (unsigned)a.ncb;
+        se_row = se_blk / (unsigned)a.ncb;
+        const long long strips = (long long)a.ystrips * a.xstrips;
+        long long strip = (long long)se_row * (256 / a.cw) + sl;
+        int cv = (int)cb * a.cw + cvl;
+        live = strip < strips && cv < a.C4;
+        if (strip >= strips) strip = strips - 1;   // idle lanes compute a valid location (no store, no sum) and take part
+        if (cv >= a.C4) cv = a.C4 - 1;             // in the reduction
+        gid = strip * a.C4 + cv;
+    }
     if (!SE && !live) return;
-    if (!live) gid = a.total - 1;            // SE: idle lanes of an image's last workgroup still take part in the reduction
     const int cq = (int)(gid % a.C4);
     long long t = gid / a.C4;
     const int xs = (int)(t % a.xstrips);
@@ -167,35 +180,49 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs<T> a) {
         }
     }
     if constexpr (SE) {
-        // lanes l, l + C4, l + 2*C4 ... of the workgroup hold the same channel quad (256 % C4 == 0): add them in index order
+        // lanes l, l + cw, l + 2*cw ... of the workgroup hold the same channel vector: add them in index order
 #pragma unroll
         for (int q = 0; q < Q; ++q) red[threadIdx.x * Q + q] = psum[q];
         __syncthreads();
-        if ((int)threadIdx.x < a.C4) {
+        const int cv = (int)(se_blk % (unsigned)a.ncb) * a.cw + (int)threadIdx.x;
+        if ((int)threadIdx.x < a.cw && cv < a.C4) {
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 float4 s = red[threadIdx.x * Q + q];
-                for (int l = threadIdx.x + a.C4; l < 256; l += a.C4) {
+                for (int l = threadIdx.x + a.cw; l < 256; l += a.cw) {
                     const float4 v = red[l * Q + q];
                     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
                 }
-                *reinterpret_cast<float4*>(a.part + ((size_t)b * gridDim.x + se_blk) * a.ld_part + (threadIdx.x * Q + q) * 4) = s;
+                *reinterpret_cast<float4*>(a.part + ((size_t)b * (gridDim.x / a.ncb) + se_row) * a.ld_part + (cv * Q + q) * 4) = s;
             }
         }
     }
 }
 
-// workgroups per image of the SE form (the compiler sizes the partial-sum buffer with the same formula)
-static inline int dw_se_blocks(int ho, int wo, int c4, int xt) { return (int)(((long long)ho * ((wo + xt - 1) / xt) * c4 + 255) / 256); }
+// SE form geometry (the compiler sizes the partial-sum buffer with the same formula, compiler.dw_se_geometry): `strips`
+// pixel strips per image, C4 channel vectors -> cw lanes of a workgroup span channels, ncb workgroups cover C4, rows =
+// groups of 256/cw strips = rows of the partial-sum buffer.
+static inline void dw_se_geometry(long long strips, int c4, int* cw, int* ncb, int* rows) {
+    int w = c4;
+    if (c4 > 256 || 256 % c4 != 0) {
+        w = 1;
+        while (w < c4 && w < 32) w <<= 1;
+    }
+    *cw = w;
+    *ncb = (c4 + w - 1) / w;
+    *rows = (int)((strips + 256 / w - 1) / (256 / w));
+}
 
 template <int K, int S, int XT, class T>
-static int launch_dw_se(DwArgs<T> a, int expect_blocks, hipStream_t s) {
+static int launch_dw_se(DwArgs<T> a, int expect_rows, hipStream_t s) {
     a.xstrips = (a.Wo + XT - 1) / XT;
     a.ystrips = a.Ho;
     a.total = (long long)a.ystrips * a.xstrips * a.C4;
-    const int blocks = dw_se_blocks(a.Ho, a.Wo, a.C4, XT);
-    YR_REQUIRE(blocks == expect_blocks && 256 % a.C4 == 0, "depthwise: the SE partial-sum buffer must hold %d rows per image (has %d); 256 %% C4 == 0 required",
-               blocks, expect_blocks);
+    int rows = 0;
+    dw_se_geometry((long long)a.ystrips * a.xstrips, a.C4, &a.cw, &a.ncb, &rows);
+    YR_REQUIRE(rows == expect_rows, "depthwise: the SE partial-sum buffer must hold %d rows per image (has %d)", rows, expect_rows);
+    const long long blocks = (long long)rows * a.ncb;
+    YR_REQUIRE(blocks * a.B < (1ll << 31), "depthwise: grid too large");
     a.nblocks = (unsigned)blocks;
     static char nm[48];
     static const int nm_len = snprintf(nm, sizeof(nm), "dw_kernel<%d,%d,%d,1,%s,1>", K, S, XT, yr_dtype_name(yr_elem<T>::dtype));
@@ -250,7 +277,7 @@ static int launch_depthwise_t(const yr_op& op, int batch, hipStream_t s) {
     a.pad_t = (pth > 0 ? pth : 0) / 2;
     a.pad_l = (ptw > 0 ? ptw : 0) / 2;
     a.act = op.act;
-    a.part = nullptr; a.ld_part = 0;
+    a.part = nullptr; a.ld_part = 0; a.cw = 1; a.ncb = 1;
     if (op.gate) {   // SE form: `gate` is an OUTPUT here - float32 [B][workgroups per image][gate_ld] channel sums
         YR_REQUIRE(op.gate_ld % 4 == 0 && op.gate_ld >= yr_round_up(in.c, V) && ((uintptr_t)op.gate % 16) == 0, "depthwise: bad SE partial-sum buffer");
         a.part = const_cast<float*>(op.gate); a.ld_part = op.gate_ld;

@@ -112,6 +112,16 @@ __global__ __launch_bounds__(SE_FC_THREADS) void se_fc_kernel(FcArgs<T> a) {
     float* hid = sm + a.ldc;          // [R]
     float* part = hid + a.R;          // [SE_FC_THREADS]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // The kernel is three dependent round trips (pooled input, W1, W2) on 64 workgroups: touch one float of every 64-byte
+    // line of both weight matrices and the biases NOW, so that they travel from HBM while the pooling below waits for its
+    // own loads; the FC loops then find them in L2.  (`warm` is consumed by a never-true test at the end.)
+    float warm = 0.f;
+    {
+        const int nw = a.R * a.ldc;
+        for (int i = tid * 16; i < nw; i += SE_FC_THREADS * 16) warm += a.w1t[i] + a.w2[i];
+        if (tid * 16 < a.R) warm += a.b1[tid * 16];
+        if (tid * 16 < a.ldc) warm += a.b2[tid * 16];
+    }
     if (a.pool) {
         // tf.reduce_mean over H,W first (the SE_MEAN op merged into this launch).  All channel quads at once:
         // C4P = next power of two >= C4 quads x (1024 / C4P) pixel lanes, then one fixed-order combine over the
@@ -183,6 +193,7 @@ __global__ __launch_bounds__(SE_FC_THREADS) void se_fc_kernel(FcArgs<T> a) {
                 for (int g = 1; g < js; ++g) t += part[g * cp + tid];
                 v = yr_sigmoid(t + a.b2[c]);
             }
+            if (warm == 1.2345678e-30f) v = 0.f;   // (keeps the warming loads alive; weights never add up to this)
             a.gate[(size_t)b * a.ld_gate + c] = v;
         }
         __syncthreads();
