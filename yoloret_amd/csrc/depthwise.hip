@@ -11,6 +11,7 @@
 // (which share K-S input rows) are processed on the same XCD and hit its L2 (the round-robin
 // default was measured to fetch each input row ~3x from HBM - profiles/r01_pmc_fetch.txt).
 #include "yr_common.h"
+#include <cstdlib>
 
 // T: element type of the input and output maps (float32, or bf16 / f16 storage: widened on load, rounded to nearest
 // on store; the accumulation, BatchNorm and activation are float32 either way).  Weights, scale, shift: float32.
@@ -287,6 +288,18 @@ static int launch_depthwise_t(const yr_op& op, int batch, hipStream_t s) {
         if (op.k == 5 && op.stride == 1) return launch_dw_se<5, 1, 4, T>(a, rows, s);
         return launch_dw_se<5, 2, 2, T>(a, rows, s);
     }
+#ifdef YR_DW_EXPERIMENT   // tools/dw5_probe.py: patch shapes of the 5x5 stride-1 form (XT*10 + YT in YR_DW_FORCE)
+    if (op.k == 5 && op.stride == 1) {
+        const char* e = getenv("YR_DW_FORCE");
+        const int f = e ? atoi(e) : 0;
+        if (f == 42) return launch_dw<5, 1, 4, 2, T>(a, s);
+        if (f == 22) return launch_dw<5, 1, 2, 2, T>(a, s);
+        if (f == 21) return launch_dw<5, 1, 2, 1, T>(a, s);
+        if (f == 81) return launch_dw<5, 1, 8, 1, T>(a, s);
+        if (f == 44) return launch_dw<5, 1, 4, 4, T>(a, s);
+        if (f == 24) return launch_dw<5, 1, 2, 4, T>(a, s);
+    }
+#endif
     // small maps (13x13, 26x26) keep 1-row patches so the grid still fills the chip
     const bool big = (long long)batch * a.Ho * a.Wo * a.C4 >= (1ll << 21);
     // stride 1: 4x1 patches beat 4x2, 2x1, 2x2, 8x1 and 13x1 on every 13/26/52 map of the flagship (tools/dw_probe.py):
