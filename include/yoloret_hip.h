@@ -102,8 +102,8 @@ typedef enum {
     YR_OP_STEMBLOCK = 9, /* fused network entry: stem Conv2D 3x3 s2 (Cin=3)+BN+act -> DW3x3 s1+BN+act -> project 1x1+BN
                             (MobileNetV2 Conv1 + expanded_conv block [3P]); se_reduced = stem width C1.  Parameters are packed
                             per channel PAIR (CP = round_up(C1,4)/2, COP = round_up(cout,8), zero padded; scale/shift unused):
-                            wgt  = stem      [CP][27 taps (ky,kx,ci) x 2 | BN scale 2 | BN shift 2],
-                            wgt2 = depthwise [CP][ 9 taps (ky,kx)    x 2 | BN scale 2 | BN shift 2],
+                            wgt  = stem      [CP][27 taps (ky,kx,ci) x 2, times the BN scale | 1 1 | BN shift 2],
+                            wgt2 = depthwise [CP][ 9 taps (ky,kx)    x 2, times the BN scale | 1 1 | BN shift 2],
                             b1   = project W[2*CP][COP] (input-channel major), b2 = project BN scale[COP] ++ shift[COP].
                             Built for (CP,COP) in {(12,16),(16,16),(16,24),(20,24),(24,16),(24,24)}; others: YR_ERR_ARG */
     YR_OP_MBH = 11,      /* the MBCONV block on 16-bit activations, both 1x1 convs on bf16 / f16 MFMA, depthwise K = 3 | 5 from an
@@ -117,8 +117,8 @@ typedef enum {
                             block inputs (Cin <= 32): packed-fp32 FMA with scalar-register weights instead of MFMA.
                             se_reduced = Cexp; parameters packed per expanded-channel PAIR, P = round_up(ceil(Cexp/2),8),
                             CINP = round_up(Cin,4), COP = round_up(cout,8), zero padded; scale/shift unused:
-                            wgt  = expand    [P][CINP x 2 (input-channel major) | BN scale 2 | BN shift 2],
-                            wgt2 = depthwise [P][9 taps (ky,kx) x 2 | BN scale 2 | BN shift 2],
+                            wgt  = expand    [P][CINP x 2 (input-channel major), times the BN scale | 1 1 | BN shift 2],
+                            wgt2 = depthwise [P][9 taps (ky,kx) x 2, times the BN scale | 1 1 | BN shift 2],
                             b1   = project W[2P][COP] (expanded-channel major), b2 = project BN scale[COP] ++ shift[COP].
                             Built for (CINP/4,COP) in {(4,16),(4,24),(6,24),(6,32),(6,40),(6,48),(8,32),(8,40),(8,48)} */
     YR_OP_MBX = 12       /* the first two thirds of an MBConv block WITH squeeze-excite (efficientnet.py:406-536), 16-bit

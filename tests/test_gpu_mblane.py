@@ -34,7 +34,7 @@ def _act(t, act):
 def _pairs(rows, scale, shift, e2):
     cexp = rows.shape[1]
     full = np.zeros((rows.shape[0] + 2, e2), np.float32)
-    full[:-2, :cexp], full[-2, :cexp], full[-1, :cexp] = rows, scale, shift
+    full[:-2, :cexp], full[-2, :cexp], full[-1, :cexp] = (rows * scale[None]).astype(np.float32), 1.0, shift   # BN scale folded (yoloret_hip.h)
     return np.ascontiguousarray(full.reshape(-1, e2 // 2, 2).transpose(1, 0, 2))
 
 

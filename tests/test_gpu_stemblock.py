@@ -45,9 +45,9 @@ def test_stemblock(dev, hw, c1, cout, act, dt):
     ref = (nn.pointwise(t, wp) * sp + hp).astype(np.float32)
     c1p, ldo, cop = round_up(c1, 4), round_up(cout, 4), round_up(cout, 8)
 
-    def per_pair(w, scale, shift):    # [taps][c1] + BN -> [c1p/2][taps x 2 | scale 2 | shift 2]  (include/yoloret_hip.h)
+    def per_pair(w, scale, shift):    # [taps][c1] + BN -> [c1p/2][taps x 2, times the scale | 1 1 | shift 2]  (include/yoloret_hip.h)
         rows = np.zeros((w.shape[0] + 2, c1p), np.float32)
-        rows[:-2, :c1], rows[-2, :c1], rows[-1, :c1] = w, scale, shift
+        rows[:-2, :c1], rows[-2, :c1], rows[-1, :c1] = (w * scale[None]).astype(np.float32), 1.0, shift   # BN scale folded into the taps
         return np.ascontiguousarray(rows.reshape(-1, c1p // 2, 2).transpose(1, 0, 2))
     wpp = np.zeros((c1p, cop), np.float32)
     wpp[:c1, :cout] = wp

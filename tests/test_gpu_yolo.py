@@ -227,3 +227,26 @@ def test_host_feeder_overlaps_copies_without_changing_the_input(dev):
         HostFeeder(shape, (96, 96), dev).submit(torch.zeros(shape, dtype=torch.uint8))
     with pytest.raises(ValueError, match='uint8 host tensor'):
         HostFeeder(shape, (96, 96), dev).submit(torch.zeros((4, 60, 90, 3), dtype=torch.float32).pin_memory())
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs')
+def test_second_device_gives_the_first_device_s_result(dev):
+    """Every wrapper takes its device and stream from its tensors, not from the process's current device: the same model
+    on cuda:1 (while cuda:0 stays current) returns what cuda:0 returns, through the facade and through the raw wrappers."""
+    from yoloret_amd import runtime as rt
+    from yoloret_amd.yolo import YOLO
+    from yoloret_amd.yolo3.enums import BACKBONE
+    flags = {'model': 'synthetic:7', 'input_size': (96, 96), 'backbone': BACKBONE.MOBILENETV2x75, 'score': 0.2, 'nms': 0.5}
+    img = _png(np.random.default_rng(5).integers(0, 256, (70, 110, 3), dtype=np.uint8))
+    torch.cuda.set_device(0)
+    a = YOLO(dict(flags, device='cuda:0')).detect_image(img, draw=False)
+    b = YOLO(dict(flags, device='cuda:1')).detect_image(img, draw=False)
+    assert torch.cuda.current_device() == 0
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    rng = np.random.default_rng(6)
+    boxes = torch.from_numpy(rng.uniform(0, 90, (2, 300, 4)).astype(np.float32))
+    scores = torch.from_numpy(rng.random((2, 5, 300), dtype=np.float32))
+    r0 = [t.cpu() for t in rt.nms(boxes.to('cuda:0'), scores.to('cuda:0'), 20, 0.3, 0.5)]
+    r1 = [t.cpu() for t in rt.nms(boxes.to('cuda:1'), scores.to('cuda:1'), 20, 0.3, 0.5)]
+    assert all(torch.equal(p, q) for p, q in zip(r0, r1))

@@ -45,6 +45,23 @@ __global__ __launch_bounds__(256) void k_pkfma(float* out, int iters) {
     for (int i = 0; i < NACC; ++i) s += acc[i].x + acc[i].y;
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// the lane kernels' form: one operand a wave-uniform SGPR pair (weights), the other a VGPR broadcast to both halves
+template <int NACC>
+__global__ __launch_bounds__(256) void k_pkfma_sgpr(float* out, int iters, float w0, float w1) {
+    v2f acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = (v2f){0.f, (float)i};
+    float x = threadIdx.x * 1e-3f;
+    v2f b = {w0, w1};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_elementwise_fma((v2f){x, x}, b, acc[i]);
+        asm volatile("" : "+v"(x));
+        asm volatile("" : "+s"(b));
+    }
+    float s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i].x + acc[i].y;
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
 template <typename F>
 static float timeit(F f) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -61,6 +78,10 @@ int main() {
         printf("mfma32x32x2 f32  blocks %4d: %.1f TF\n", blocks, 2.0 * 2048 * 4 * iters * blocks * 4 / ms / 1e9);
         ms = timeit([&] { k_pkfma<16><<<blocks, 256>>>(out, iters); });
         printf("v_pk_fma_f32     blocks %4d: %.1f TF\n", blocks, 2.0 * 128 * 16 * iters * blocks * 4 / ms / 1e9);
+        ms = timeit([&] { k_pkfma_sgpr<16><<<blocks, 256>>>(out, iters, 1.0f, 1.0001f); });
+        printf("v_pk_fma_f32 (SGPR pair x broadcast VGPR) blocks %4d: %.1f TF\n", blocks, 2.0 * 128 * 16 * iters * blocks * 4 / ms / 1e9);
+        ms = timeit([&] { k_pkfma_sgpr<2><<<blocks, 256>>>(out, iters * 8, 1.0f, 1.0001f); });
+        printf("v_pk_fma_f32 (SGPR form, 2 chains as in mblane) blocks %4d: %.1f TF\n", blocks, 2.0 * 128 * 2 * iters * 8 * blocks * 4 / ms / 1e9);
     }
     return 0;
 }

@@ -515,10 +515,12 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                 m.fused = [e, d, p]
 
                 def per_pair(prm, taps, c1p=c1p):
-                    """[taps][c1p] weights + scale/shift [c1p]  ->  [c1p/2][taps x 2 | scale 2 | shift 2]"""
+                    """[taps][c1p] weights + scale/shift [c1p]  ->  [c1p/2][taps x 2, times the scale | 1 1 | shift 2]
+                    (the kernel adds the shift to the sum of products: one float32 rounding of w * scale per weight)"""
                     def f(wd):
-                        w = prm['wgt'][1](wd).reshape(taps, -1)[:, :c1p]
-                        rows = np.concatenate([w, pad_to(prm['scale'][1], c1p, c1p)(wd)[None],
+                        sc = pad_to(prm['scale'][1], c1p, c1p)(wd)
+                        w = (prm['wgt'][1](wd).reshape(taps, -1)[:, :c1p] * sc[None]).astype(np.float32)
+                        rows = np.concatenate([w, np.ones((1, c1p), np.float32),
                                                pad_to(prm['shift'][1], c1p, c1p)(wd)[None]])     # [taps+2][c1p]
                         return np.ascontiguousarray(rows.reshape(taps + 2, c1p // 2, 2).transpose(1, 0, 2)).reshape(c1p // 2, -1)
                     return ((c1p // 2, (taps + 2) * 2), f)
@@ -677,9 +679,11 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
             e2 = 2 * npair
 
             def pairs(rows, scale, shift, e2=e2, cexp=cexp):
-                """rows [K][>=cexp] + BN [>=cexp]  ->  [P][K x 2 | scale 2 | shift 2]"""
+                """rows [K][>=cexp] + BN [>=cexp]  ->  [P][K x 2, times the BN scale | 1 1 | shift 2]  (the kernels add
+                the shift to the sum of products; the scale slot stays in the layout)"""
                 full = np.zeros((rows.shape[0] + 2, e2), np.float32)
-                full[:-2, :cexp], full[-2, :cexp], full[-1, :cexp] = rows[:, :cexp], scale[:cexp], shift[:cexp]
+                full[:-2, :cexp] = (rows[:, :cexp] * scale[None, :cexp]).astype(np.float32)
+                full[-2, :cexp], full[-1, :cexp] = 1.0, shift[:cexp]
                 return np.ascontiguousarray(full.reshape(-1, e2 // 2, 2).transpose(1, 0, 2)).reshape(e2 // 2, -1)
             ep, dwp, pp_ = exp.params, dw.params, proj.params
 

@@ -43,19 +43,28 @@ __device__ __forceinline__ v2f ml_act(v2f v, int act) {
     return (v2f){yr_apply_act(v.x, act), yr_apply_act(v.y, act)};
 }
 
-// expand one channel pair for this lane's pixel: act(BN(sum_k x[k] * W[k][pair]))
+// expand one channel pair for this lane's pixel: act(sum_k x[k] * W'[k][pair] + shift), W' = W * BN scale (folded by the
+// host: the packed rows keep their scale slot, holding 1).  `hi` is the lane's upper clamp: 6 inside the image, 0 outside
+// - TF pads the EXPANDED tensor with zeros for the depthwise, and min(max(v, 0), 0) is that zero for free.  (With the BN
+// multiply-add, two moves of the shift into VGPRs and two selects this loop was 25 VALU instructions for 16 useful ones
+// on block_1, and it runs on every lane of the 15 x 17 halo: 72 % of that kernel's instructions.)
 template <int CQ, bool RELU6>
-__device__ __forceinline__ v2f ml_expand(const float4 (&x)[CQ], kptr w, int act) {
-    v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f};  // two chains
+__device__ __forceinline__ v2f ml_expand(const float4 (&x)[CQ], kptr w, int act, float hi) {
+    // FOUR independent accumulator chains: a dependent v_pk_fma_f32 issues only every ~13th slot (tools/peak.hip: two
+    // chains per wave cap at 89 TF however many waves are resident, sixteen reach 128 TF), and this loop is most of the kernel
+    v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
         a0 = ml_fma((v2f){x[q].x, x[q].x}, (v2f){w[8 * q + 0], w[8 * q + 1]}, a0);
         a1 = ml_fma((v2f){x[q].y, x[q].y}, (v2f){w[8 * q + 2], w[8 * q + 3]}, a1);
-        a0 = ml_fma((v2f){x[q].z, x[q].z}, (v2f){w[8 * q + 4], w[8 * q + 5]}, a0);
-        a1 = ml_fma((v2f){x[q].w, x[q].w}, (v2f){w[8 * q + 6], w[8 * q + 7]}, a1);
+        a2 = ml_fma((v2f){x[q].z, x[q].z}, (v2f){w[8 * q + 4], w[8 * q + 5]}, a2);
+        a3 = ml_fma((v2f){x[q].w, x[q].w}, (v2f){w[8 * q + 6], w[8 * q + 7]}, a3);
     }
-    a0 += a1;
-    return ml_act<RELU6>(ml_fma(a0, (v2f){w[8 * CQ], w[8 * CQ + 1]}, (v2f){w[8 * CQ + 2], w[8 * CQ + 3]}), act);
+    a0 = (a0 + a1) + (a2 + a3);
+    a0 += (v2f){w[8 * CQ + 2], w[8 * CQ + 3]};
+    if (RELU6) return (v2f){__builtin_amdgcn_fmed3f(a0.x, 0.f, hi), __builtin_amdgcn_fmed3f(a0.y, 0.f, hi)};
+    const v2f v = {yr_apply_act(a0.x, act), yr_apply_act(a0.y, act)};
+    return hi > 0.f ? v : (v2f){0.f, 0.f};
 }
 
 template <int CQ, class T>
@@ -115,11 +124,17 @@ __device__ __forceinline__ void ml_dw_project(const v2f* e, kptr w, kptr pw, v2f
     else if constexpr (NR == 5) asm volatile("" : ML_PIN_EV, "+s"(wa), "+s"(wb), "+s"(wc), "+s"(r0[0]), "+s"(r0[1]), "+s"(r0[2]), "+s"(r0[3]), "+s"(r0[4]));
     else asm volatile("" : ML_PIN_EV, "+s"(wa), "+s"(wb), "+s"(wc), "+s"(r0[0]), "+s"(r0[1]), "+s"(r0[2]), "+s"(r0[3]), "+s"(r0[4]), "+s"(r0[5]));
 #undef ML_PIN_EV
-    v2f d = {0.f, 0.f};
+    v2f d = {0.f, 0.f}, d1 = {0.f, 0.f}, d2 = {0.f, 0.f};   // one chain per tap row (see ml_expand)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) d = ml_fma(ev[k], (v2f){wa[2 * k], wa[2 * k + 1]}, d);
-    d = ml_fma(ev[8], (v2f){wb[0], wb[1]}, d);
-    d = ml_act<RELU6>(ml_fma(d, (v2f){wb[2], wb[3]}, wc), act);
+    for (int k = 0; k < 3; ++k) {
+        d = ml_fma(ev[k], (v2f){wa[2 * k], wa[2 * k + 1]}, d);
+        d1 = ml_fma(ev[3 + k], (v2f){wa[6 + 2 * k], wa[7 + 2 * k]}, d1);
+    }
+    d2 = ml_fma(ev[6], (v2f){wa[12], wa[13]}, d2);
+    d2 = ml_fma(ev[7], (v2f){wa[14], wa[15]}, d2);
+    d2 = ml_fma(ev[8], (v2f){wb[0], wb[1]}, d2);
+    d = (d + d1) + d2;
+    d = ml_act<RELU6>(d + wc, act);          // (BN scale folded into the taps by the host; wb[2..3] hold 1)
 #pragma unroll
     for (int n = 0; n < COP / 2; ++n) o[n] = ml_fma((v2f){d.x, d.x}, (v2f){r0[n / 4][(2 * n) % 8], r0[n / 4][(2 * n) % 8 + 1]}, o[n]);
     if constexpr (!BOTH) {  // wide projections: the second row is loaded (one burst, one wait) once the first is consumed
@@ -151,6 +166,7 @@ __global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s1_ke
     const bool is_out = inside && ey >= 1 && ey <= TL && ex >= 1 && ex <= TL;
     float4 x[CQ];
     ml_load_x<CQ, T>(x, a, b, hy, hx, inside);
+    const float hi = inside ? 6.f : 0.f;     // (relu6's upper clamp; 0 = the expanded tensor's zero padding)
     v2f o[COP / 2];
 #pragma unroll
     for (int n = 0; n < COP / 2; ++n) o[n] = (v2f){0.f, 0.f};
@@ -160,9 +176,7 @@ __global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s1_ke
         v2f* buf = Es + ((p0 / ML_CH) & 1) * (ML_CH * 256);
 #pragma unroll 1
         for (int j = 0; j < ML_CH; ++j) {
-            v2f e = ml_expand<CQ, RELU6>(x, we + (p0 + j) * WE, a.act);
-            if (!inside) e = (v2f){0.f, 0.f};  // TF pads the EXPANDED tensor with zeros for the depthwise
-            buf[j * 256 + tid] = e;
+            buf[j * 256 + tid] = ml_expand<CQ, RELU6>(x, we + (p0 + j) * WE, a.act, hi);
         }
         __syncthreads();  // also orders this chunk's writes after the readers of the same buffer two chunks back
         if (is_out) {
@@ -214,6 +228,7 @@ __global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s2_ke
     const bool inside = tid < IH * IW && hy >= 0 && hy < a.Hi && hx >= 0 && hx < a.Wi;
     float4 x[CQ];
     ml_load_x<CQ, T>(x, a, b, hy, hx, inside);
+    const float hi = inside ? 6.f : 0.f;
     // depthwise/project phase: lane = output pixel, wave = which quarter of each chunk's pairs
     const int py = lane >> 3, px = lane & 7;
     const int gy = oy0 + py, gx = ox0 + px;
@@ -227,9 +242,7 @@ __global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s2_ke
         v2f* buf = Es + ((p0 / ML_CH) & 1) * (ML_CH * 256);
 #pragma unroll 1
         for (int j = 0; j < ML_CH; ++j) {
-            v2f e = ml_expand<CQ, RELU6>(x, we + (p0 + j) * WE, a.act);
-            if (!inside) e = (v2f){0.f, 0.f};
-            buf[j * 256 + tid] = e;
+            buf[j * 256 + tid] = ml_expand<CQ, RELU6>(x, we + (p0 + j) * WE, a.act, hi);
         }
         __syncthreads();
         if (is_out) {
@@ -307,8 +320,8 @@ static int launch_ml_widths(const MlArgs<T>& a, int cq, int cop, int batch, hipS
 // act = expand/DW activation; res (optional) must be the block input itself.  Parameters are packed per
 // expanded-channel PAIR, P = round_up(ceil(Cexp/2), 8) pairs, CINP = round_up(Cin,4), COP = round_up(Cout,8),
 // zero padded (a zero pair contributes act(0) * 0 = 0):
-//   wgt  = expand     [P][CINP x 2 (input channel major) | BN scale 2 | BN shift 2]
-//   wgt2 = depthwise  [P][9 taps x 2 | BN scale 2 | BN shift 2]
+//   wgt  = expand     [P][CINP x 2 (input channel major), times the BN scale | 1 1 | BN shift 2]
+//   wgt2 = depthwise  [P][9 taps x 2, times the BN scale | 1 1 | BN shift 2]
 //   b1   = project    W[2P][COP] (expanded-channel major);   b2 = project BN scale [COP] ++ shift [COP].
 template <class T>
 static int launch_mblane_t(const yr_op& op, int batch, hipStream_t s) {

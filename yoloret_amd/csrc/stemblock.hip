@@ -24,8 +24,8 @@
 
 #define SB_T 14             // output tile edge
 #define SB_E (SB_T + 2)     // stem-output halo tile edge (== 16: one halo pixel per lane of 256)
-#define SB_WS 58            // stem floats per channel pair:      27 taps x 2 | scale 2 | shift 2
-#define SB_WD 22            // depthwise floats per channel pair:  9 taps x 2 | scale 2 | shift 2
+#define SB_WS 58            // stem floats per channel pair:      27 taps x 2 (times the BN scale) | 1 1 | shift 2
+#define SB_WD 22            // depthwise floats per channel pair:  9 taps x 2 (times the BN scale) | 1 1 | shift 2
 
 typedef const float __attribute__((address_space(4))) * kptr;  // uniform reads of this become s_load
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -95,17 +95,31 @@ __global__ __launch_bounds__(256, 4) void stemblock_kernel(SbArgs<T> a) {
                 }
         }
         const kptr ws = (kptr)a.ws;
+        const float hi = valid ? 6.f : 0.f;
 #pragma unroll 1
         for (int p = 0; p < CP; ++p) {
             const kptr w = ws + p * SB_WS;
-            v2f acc = {0.f, 0.f}, acc2 = {0.f, 0.f};  // two chains (taps 0-13 | 14-26) for issue-level parallelism
+            // four chains (taps k = c mod 4): a dependent v_pk_fma_f32 issues only every ~13th slot - two chains per wave cap
+            // at 89 TF of the pipe's 128 (tools/peak.hip)
+            v2f acc = {0.f, 0.f}, acc2 = {0.f, 0.f}, acc3 = {0.f, 0.f}, acc4 = {0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 14; ++k) acc = sb_fma((v2f){in[k], in[k]}, (v2f){w[2 * k], w[2 * k + 1]}, acc);
-#pragma unroll
-            for (int k = 14; k < 27; ++k) acc2 = sb_fma((v2f){in[k], in[k]}, (v2f){w[2 * k], w[2 * k + 1]}, acc2);
-            acc += acc2;
-            acc = sb_act<RELU6>(sb_fma(acc, (v2f){w[54], w[55]}, (v2f){w[56], w[57]}), a.act);
-            if (!valid) acc = (v2f){0.f, 0.f};
+            for (int k = 0; k < 24; k += 4) {
+                acc = sb_fma((v2f){in[k], in[k]}, (v2f){w[2 * k], w[2 * k + 1]}, acc);
+                acc2 = sb_fma((v2f){in[k + 1], in[k + 1]}, (v2f){w[2 * k + 2], w[2 * k + 3]}, acc2);
+                acc3 = sb_fma((v2f){in[k + 2], in[k + 2]}, (v2f){w[2 * k + 4], w[2 * k + 5]}, acc3);
+                acc4 = sb_fma((v2f){in[k + 3], in[k + 3]}, (v2f){w[2 * k + 6], w[2 * k + 7]}, acc4);
+            }
+            acc = sb_fma((v2f){in[24], in[24]}, (v2f){w[48], w[49]}, acc);
+            acc2 = sb_fma((v2f){in[25], in[25]}, (v2f){w[50], w[51]}, acc2);
+            acc3 = sb_fma((v2f){in[26], in[26]}, (v2f){w[52], w[53]}, acc3);
+            acc = (acc + acc2) + (acc3 + acc4);
+            acc += (v2f){w[56], w[57]};          // BN shift; the scale is folded into the taps by the host (w[54..55] hold 1)
+            if (RELU6) {                         // upper clamp 0 outside the map = the depthwise's zero padding, for free
+                acc = (v2f){__builtin_amdgcn_fmed3f(acc.x, 0.f, hi), __builtin_amdgcn_fmed3f(acc.y, 0.f, hi)};
+            } else {
+                acc = sb_act<false>(acc, a.act);
+                if (!valid) acc = (v2f){0.f, 0.f};
+            }
             Es[p * 256 + tid] = acc;
         }
     }
@@ -126,15 +140,16 @@ __global__ __launch_bounds__(256, 4) void stemblock_kernel(SbArgs<T> a) {
             const kptr w = wd + p * SB_WD;
             const kptr pw = wp + p * 2 * COP;
             const v2f* e = e0 + p * 256;
-            v2f d = {0.f, 0.f};
+            v2f dr[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};    // one chain per tap row
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
+                for (int ky = 0; ky < 3; ++ky) {
                     const int k = ky * 3 + kx;
-                    d = sb_fma(e[ky * SB_E + kx], (v2f){w[2 * k], w[2 * k + 1]}, d);
+                    dr[ky] = sb_fma(e[ky * SB_E + kx], (v2f){w[2 * k], w[2 * k + 1]}, dr[ky]);
                 }
-            d = sb_act<RELU6>(sb_fma(d, (v2f){w[18], w[19]}, (v2f){w[20], w[21]}), a.act);
+            v2f d = (dr[0] + dr[1]) + dr[2];
+            d = sb_act<RELU6>(d + (v2f){w[20], w[21]}, a.act);   // (scale folded into the taps; w[18..19] hold 1)
 #pragma unroll
             for (int n = 0; n < COP / 2; ++n) o[n] = sb_fma((v2f){d.x, d.x}, (v2f){pw[2 * n], pw[2 * n + 1]}, o[n]);
 #pragma unroll
@@ -178,8 +193,8 @@ static int launch_sb(const SbArgs<T>& a, int batch, hipStream_t s) {
 
 // op fields: src[0] = dense 3-channel image; cin = 3; se_reduced = C1 (stem width); cout; k = 3; stride = 2;
 // act = stem/DW activation.  With CP = round_up(C1,4)/2 channel pairs, COP = round_up(cout,8), all zero padded:
-//   wgt  = stem, per channel pair:      [CP][27 taps (ky,kx,ci) x 2 | BN scale 2 | BN shift 2]   (58 floats per pair)
-//   wgt2 = depthwise, per channel pair: [CP][ 9 taps (ky,kx)    x 2 | BN scale 2 | BN shift 2]   (22 floats per pair)
+//   wgt  = stem, per channel pair:      [CP][27 taps (ky,kx,ci) x 2, times the BN scale | 1 1 | BN shift 2]   (58 floats per pair)
+//   wgt2 = depthwise, per channel pair: [CP][ 9 taps (ky,kx)    x 2, times the BN scale | 1 1 | BN shift 2]   (22 floats per pair)
 //   b1   = project W[2*CP][COP] (input-channel major);  b2 = project BN scale [COP] ++ shift [COP].
 template <class T>
 static int launch_stemblock_t(const yr_op& op, int batch, hipStream_t s) {
