@@ -85,11 +85,13 @@ typedef struct {
 } yr_src;
 
 typedef enum {
-    YR_OP_STEM = 1,      /* Conv2D 3x3 s2 Cin=3 + BN + act            (MobileNetV2 Conv1 [3P]; efficientnet.py:636-645) */
+    YR_OP_STEM = 1,      /* Conv2D 3x3 s2 Cin=3 + BN + act            (MobileNetV2 Conv1 [3P]; efficientnet.py:636-645).  Optional
+                            wgt2 = the same parameters packed per channel PAIR, [round_up(cout,4)/2][27 taps x 2, times the BN
+                            scale | 1 1 | BN shift 2] (STEMBLOCK's stem layout): selects the scalar-operand kernel */
     YR_OP_POINTWISE = 2, /* Conv2D 1x1 (+bias)(+BN)(+act)(+residual)  (model.py:25-30,98-114,152-155,243-251; efficientnet.py:485-496,517-533) */
     YR_OP_DEPTHWISE = 3, /* DepthwiseConv2D k3/k5 s1/s2 SAME + BN + act (model.py:20-24; efficientnet.py:501-510).  With `gate` set (SE
-                            form; needs 256 % ceil(c / V) == 0): the kernel ALSO writes per-workgroup channel sums of its output to
-                            gate = float32 [B][se_reduced rows][gate_ld] - the squeeze of squeeze-excite (efficientnet.py:417) as an
+                            form): the kernel ALSO writes per-workgroup channel sums of its output to
+                            gate = float32 [B][se_reduced rows][gate_ld] (rows: compiler.dw_se_geometry == depthwise.hip) - the squeeze of squeeze-excite (efficientnet.py:417) as an
                             epilogue; an SE_FC op with k = H*W adds the rows up instead of re-reading the map */
     YR_OP_SE_MEAN = 4,   /* Mean over H,W                              (efficientnet.py:391-403,417) */
     YR_OP_SE_FC = 5,     /* 1x1+bias -> Swish -> 1x1+bias -> sigmoid   (efficientnet.py:419-434).  Source: the pooled vector (h*w == 1,

@@ -215,9 +215,10 @@ def test_depthwise16(dev, dt, k, s, h, w, c, act):
     assert_rounded_once(from_dev16(out, dt, c), ref, dt, 'depthwise16 k%d s%d' % (k, s))
 
 
+@pytest.mark.parametrize('pairs', [False, True])
 @pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('cout,act', [(24, 'relu6'), (32, 'swish'), (40, 'swish')])
-def test_stem16(dev, dt, cout, act):
+def test_stem16(dev, dt, cout, act, pairs):
     """float32 image in, 16-bit map out."""
     rt = _rt()
     did = rt.dtype_id(dt)
@@ -240,6 +241,10 @@ def test_stem16(dev, dt, cout, act):
     op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc = ho, wo, 3, cout, 3, 2, 1
     op.src[0] = rt.make_src(xd, c=3)
     op.wgt, op.scale, op.shift = [t.data_ptr() for t in keep]
+    if pairs:
+        from tests.test_gpu_ops import _stem_pairs
+        keep.append(_dev_vec(_stem_pairs(wp, scale, shift, ldw), dev))
+        op.wgt2 = keep[-1].data_ptr()
     op.out, op.out_ld = out.data_ptr(), out.shape[3]
     rt.run_op(op, b)
     torch.cuda.synchronize()

@@ -181,8 +181,17 @@ def test_depthwise(dev, k, s, h, w, c, act):
     assert_close(from_dev(out, c), ref, TOL, 'depthwise')
 
 
-@pytest.mark.parametrize('hw,cout,act', [((64, 64), 24, 'relu6'), ((32, 96), 40, 'swish'), ((30, 22), 48, 'relu6')])
-def test_stem(dev, hw, cout, act):
+def _stem_pairs(wd, scale, shift, ldw):
+    """[27][ldw] + BN -> [ldw/2][27 taps x 2, times the scale | 1 1 | shift 2]: the pair-packed form (include/yoloret_hip.h)"""
+    sc, sh = np.zeros(ldw, np.float32), np.zeros(ldw, np.float32)
+    sc[:scale.size], sh[:shift.size] = scale, shift
+    rows = np.concatenate([(wd * sc[None]).astype(np.float32), np.ones((1, ldw), np.float32), sh[None]])
+    return np.ascontiguousarray(rows.reshape(29, ldw // 2, 2).transpose(1, 0, 2)).reshape(ldw // 2, 58)
+
+
+@pytest.mark.parametrize('pairs', [False, True])
+@pytest.mark.parametrize('hw,cout,act', [((64, 64), 24, 'relu6'), ((32, 96), 40, 'swish'), ((30, 22), 48, 'relu6'), ((41, 67), 32, 'swish')])
+def test_stem(dev, hw, cout, act, pairs):
     rt = _rt()
     rng = np.random.default_rng(cout)
     b = 2
@@ -202,6 +211,9 @@ def test_stem(dev, hw, cout, act):
     op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc = ho, wo, 3, cout, 3, 2, 1
     op.src[0] = rt.make_src(xd, c=3, ld=3)
     op.wgt, op.scale, op.shift = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
+    if pairs:   # the scalar-operand kernel
+        keep.append(_dev_vec(_stem_pairs(wd, scale, shift, ldw), dev))
+        op.wgt2 = keep[-1].data_ptr()
     op.out, op.out_ld = out.data_ptr(), ldw
     rt.run_op(op, b)
     torch.cuda.synchronize()

@@ -917,7 +917,12 @@ class Compiler:
                 o[:, :cout] = wd[kname].reshape(27, cout)  # (ky,kx,ci) major == HWIO flattening
                 return o
             sc, sh = self._bn_fold(bn, bias, cout, ldw)
-            op.params = {'wgt': ((27, ldw), wfn), 'scale': ((ldw,), sc), 'shift': ((ldw,), sh)}
+
+            def wpair(wd, wfn=wfn, sc=sc, sh=sh, ldw=ldw):
+                """[27][ldw] + BN -> [ldw/2][27 taps x 2, times the BN scale | 1 1 | shift 2] (stemblock's stem layout)"""
+                rows = np.concatenate([(wfn(wd) * sc(wd)[None]).astype(np.float32), np.ones((1, ldw), np.float32), sh(wd)[None]])
+                return np.ascontiguousarray(rows.reshape(29, ldw // 2, 2).transpose(1, 0, 2)).reshape(ldw // 2, 58)
+            op.params = {'wgt': ((27, ldw), wfn), 'scale': ((ldw,), sc), 'shift': ((ldw,), sh), 'wgt2': ((ldw // 2, 58), wpair)}
             self._emit(op)
             self._finish(n, bn, last, out, done)
             return

@@ -20,6 +20,7 @@ struct StemArgs {
     const float* w;      // [27][ldw]  (tap-major: (ky*3+kx)*3+ci), zero padded to ldw
     const float* scale;  // [ldw]
     const float* shift;  // [ldw]
+    const float* wpair;  // optional [ldw/2][58]: per channel PAIR 27 taps x 2 (times the BN scale) | 1 1 | BN shift 2 (stemblock's layout)
     T* out;              // [B][Ho][Wo][ld_out]
     int B, Hi, Wi, Ho, Wo, ldw, ld_out, pad_t, pad_l, act, tiles_x, tiles_y;
 };
@@ -94,11 +95,91 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs<T> a) {
     }
 }
 
+// The same tile with the weights as SCALAR operands (the network-entry kernel's scheme, stemblock.hip): one channel pair per
+// rolled iteration, its 58 packed floats through s_load, 27 v_pk_fma_f32 in four accumulator chains (a dependent packed FMA
+// issues only every ~13th slot: tools/peak.hip), BN shift added, activation, 8-byte store into the LDS output tile.  The
+// LDS-weight form above costs 27 x Cout/4 broadcast ds_read_b128 and 27 x Cout scalar FMAs per pixel and is bound by
+// the LDS pipe (EfficientNet-B0 @416, 128 images: 0.32 ms at 24 TFLOP/s); this one issues half the VALU instructions and
+// no weight reads from LDS.  Used when the op carries the pair-packed weights (wgt2).
+typedef const float __attribute__((address_space(4))) * st_kptr;
+typedef float st_v2f __attribute__((ext_vector_type(2)));
+template <int CQ, class T>
+__global__ __launch_bounds__(256) void stem_pair_kernel(StemArgs<T> a) {
+    constexpr int OS = CQ * 4 + 2;            // output-tile pixel stride in floats: 8-byte stores of a half wave hit 64 banks once
+    __shared__ float tile[ST_IH * ST_IW * 3];
+    __shared__ __attribute__((aligned(8))) float otile[256 * OS];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x;
+    const int b = t / (a.tiles_x * a.tiles_y);
+    const int r = t - b * a.tiles_x * a.tiles_y;
+    const int ty0 = (r / a.tiles_x) * ST_TH, tx0 = (r % a.tiles_x) * ST_TW;
+    const int iy0 = ty0 * 2 - a.pad_t, ix0 = tx0 * 2 - a.pad_l;
+    constexpr int NLD = (ST_IH * ST_IW * 3 + 255) / 256;
+    float stage[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int i = tid + u * 256;
+        const int ry = i / (ST_IW * 3), rc = i - ry * (ST_IW * 3);
+        const int iy = iy0 + ry, ixc = ix0 * 3 + rc;
+        stage[u] = 0.f;
+        if (i < ST_IH * ST_IW * 3 && iy >= 0 && iy < a.Hi && ixc >= 0 && ixc < a.Wi * 3)
+            stage[u] = a.in[((size_t)b * a.Hi + iy) * a.Wi * 3 + ixc];
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u)
+        if (tid + u * 256 < ST_IH * ST_IW * 3) tile[tid + u * 256] = stage[u];
+    __syncthreads();
+    const int py = tid / ST_TW, px = tid - py * ST_TW;
+    float in[27];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) in[ky * 9 + j] = tile[(py * 2 + ky) * (ST_IW * 3) + px * 6 + j];
+    const st_kptr ws = (st_kptr)a.wpair;
+#pragma unroll 1
+    for (int p = 0; p < 2 * CQ; ++p) {
+        const st_kptr w = ws + p * 58;
+        st_v2f c0 = {0.f, 0.f}, c1 = {0.f, 0.f}, c2 = {0.f, 0.f}, c3 = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 24; k += 4) {
+            c0 = __builtin_elementwise_fma((st_v2f){in[k], in[k]}, (st_v2f){w[2 * k], w[2 * k + 1]}, c0);
+            c1 = __builtin_elementwise_fma((st_v2f){in[k + 1], in[k + 1]}, (st_v2f){w[2 * k + 2], w[2 * k + 3]}, c1);
+            c2 = __builtin_elementwise_fma((st_v2f){in[k + 2], in[k + 2]}, (st_v2f){w[2 * k + 4], w[2 * k + 5]}, c2);
+            c3 = __builtin_elementwise_fma((st_v2f){in[k + 3], in[k + 3]}, (st_v2f){w[2 * k + 6], w[2 * k + 7]}, c3);
+        }
+        c0 = __builtin_elementwise_fma((st_v2f){in[24], in[24]}, (st_v2f){w[48], w[49]}, c0);
+        c1 = __builtin_elementwise_fma((st_v2f){in[25], in[25]}, (st_v2f){w[50], w[51]}, c1);
+        c2 = __builtin_elementwise_fma((st_v2f){in[26], in[26]}, (st_v2f){w[52], w[53]}, c2);
+        c0 = (c0 + c1) + (c2 + c3);
+        c0 += (st_v2f){w[56], w[57]};
+        c0 = (st_v2f){yr_apply_act_t<T>(c0.x, a.act), yr_apply_act_t<T>(c0.y, a.act)};
+        *reinterpret_cast<st_v2f*>(otile + tid * OS + 2 * p) = c0;
+    }
+    __syncthreads();
+    for (int i = tid; i < 256 * CQ; i += 256) {
+        const int p = i / CQ, q = i - p * CQ;
+        const int oy = ty0 + p / ST_TW, ox = tx0 + (p % ST_TW);
+        if (oy < a.Ho && ox < a.Wo) {
+            const float* o = otile + p * OS + q * 4;
+            yr_st4<T>(a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.ld_out + q * 4, make_float4(o[0], o[1], o[2], o[3]));
+        }
+    }
+}
+
 template <int CQ, class T>
 static int launch_stem(const StemArgs<T>& a, hipStream_t s) {
     static char nm[32];
     static const int nm_len = snprintf(nm, sizeof(nm), "stem_kernel<%d,%s>", CQ, yr_dtype_name(yr_elem<T>::dtype));
     (void)nm_len;
+    static char nmp[40];
+    static const int nmp_len = snprintf(nmp, sizeof(nmp), "stem_pair_kernel<%d,%s>", CQ, yr_dtype_name(yr_elem<T>::dtype));
+    (void)nmp_len;
+    if (a.wpair) {
+        yr_note_kernel(nmp);
+        hipLaunchKernelGGL((stem_pair_kernel<CQ, T>), dim3((unsigned)(a.B * a.tiles_x * a.tiles_y)), dim3(256), 0, s, a);
+        YR_LAUNCH_CHECK();
+        return YR_OK;
+    }
     yr_note_kernel(nm);
     hipLaunchKernelGGL((stem_kernel<CQ, T>), dim3((unsigned)(a.B * a.tiles_x * a.tiles_y)), dim3(256), 0, s, a);
     YR_LAUNCH_CHECK();
@@ -113,7 +194,7 @@ static int launch_stem_t(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(op.k == 3 && op.stride == 2, "stem: only 3x3 stride 2 is supported");
     const yr_src& in = op.src[0];
     StemArgs<T> a;
-    a.in = (const float*)in.ptr; a.w = op.wgt; a.scale = op.scale; a.shift = op.shift; a.out = (T*)op.out;
+    a.in = (const float*)in.ptr; a.w = op.wgt; a.scale = op.scale; a.shift = op.shift; a.wpair = op.wgt2; a.out = (T*)op.out;
     YR_REQUIRE(a.in && a.w && a.scale && a.shift && a.out, "stem: null pointer");
     a.B = batch; a.Hi = in.h; a.Wi = in.w; a.Ho = (in.h + 1) / 2; a.Wo = (in.w + 1) / 2;
     YR_REQUIRE(a.Ho == op.h && a.Wo == op.w, "stem: output dims mismatch");
