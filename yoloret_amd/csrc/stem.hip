@@ -105,9 +105,11 @@ typedef const float __attribute__((address_space(4))) * st_kptr;
 typedef float st_v2f __attribute__((ext_vector_type(2)));
 template <int CQ, class T>
 __global__ __launch_bounds__(256) void stem_pair_kernel(StemArgs<T> a) {
-    constexpr int OS = CQ * 4 + 2;            // output-tile pixel stride in floats: 8-byte stores of a half wave hit 64 banks once
+    // output tile in LDS in the OUTPUT type (a 16-bit plan: half the bytes, five workgroups per CU instead of three);
+    // pixel stride: an odd number of pair slots, so the pair stores of a half wave spread over all banks
+    constexpr int OS = CQ * 4 + 2;
     __shared__ float tile[ST_IH * ST_IW * 3];
-    __shared__ __attribute__((aligned(8))) float otile[256 * OS];
+    __shared__ __attribute__((aligned(8))) T otile[256 * OS];
     const int tid = threadIdx.x;
     const int t = blockIdx.x;
     const int b = t / (a.tiles_x * a.tiles_y);
@@ -153,15 +155,19 @@ __global__ __launch_bounds__(256) void stem_pair_kernel(StemArgs<T> a) {
         c0 = (c0 + c1) + (c2 + c3);
         c0 += (st_v2f){w[56], w[57]};
         c0 = (st_v2f){yr_apply_act_t<T>(c0.x, a.act), yr_apply_act_t<T>(c0.y, a.act)};
-        *reinterpret_cast<st_v2f*>(otile + tid * OS + 2 * p) = c0;
+        yr_st2<T>(otile + tid * OS + 2 * p, c0.x, c0.y);
     }
     __syncthreads();
     for (int i = tid; i < 256 * CQ; i += 256) {
         const int p = i / CQ, q = i - p * CQ;
         const int oy = ty0 + p / ST_TW, ox = tx0 + (p % ST_TW);
-        if (oy < a.Ho && ox < a.Wo) {
-            const float* o = otile + p * OS + q * 4;
-            yr_st4<T>(a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.ld_out + q * 4, make_float4(o[0], o[1], o[2], o[3]));
+        if (oy < a.Ho && ox < a.Wo) {   // (already rounded: a copy of 4 elements)
+            const T* o = otile + p * OS + q * 4;
+            T* g = a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.ld_out + q * 4;
+            typedef T t2 __attribute__((ext_vector_type(2)));
+            typedef T t4 __attribute__((ext_vector_type(4)));
+            const t2 lo = *reinterpret_cast<const t2*>(o), hi2 = *reinterpret_cast<const t2*>(o + 2);   // (LDS rows are pair aligned)
+            *reinterpret_cast<t4*>(g) = (t4){lo[0], lo[1], hi2[0], hi2[1]};
         }
     }
 }
