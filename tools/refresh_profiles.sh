@@ -12,11 +12,11 @@ db() { ls $O/$1/*.db 2>/dev/null | head -1; }
 # ---------------------------------------------------------------- headline: config 2 (MobileNetV2x0.75 @416, batch 64, fp32)
 export YOLORET_TUNE_CACHE=$R/$O/tuned.json   # the first run tunes and saves; the profiled runs reuse the table (no trial launches)
 python bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats -d $O/prof_stats -o stats -- python bench.py --no-cpu-baseline --no-latency > $O/bench_under_rocprof.json 2> $O/rocprof_stats.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o stats -- python bench.py --no-cpu-baseline --no-latency > $O/bench_under_rocprof.json 2> $O/rocprof_stats.err
 B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-latency --profile-iters 0"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_fetch -o pmc -- $B > /dev/null 2> $O/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_write -o pmc -- $B > /dev/null 2> $O/pmc_write.err
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SMEM -d $O/prof_sq -o pmc -- $B > /dev/null 2> $O/pmc_sq.err
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_fetch -o pmc -- $B > /dev/null 2> $O/pmc_fetch.err
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_write -o pmc -- $B > /dev/null 2> $O/pmc_write.err
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SMEM -d $O/prof_sq -o pmc -- $B > /dev/null 2> $O/pmc_sq.err
 python bench.py --per-op --no-cpu-baseline --no-latency > $O/bench_perop.json 2> $O/perop.txt
 python tools/rocpd_summary.py stats "$(db prof_stats)" > $O/kernel_stats.txt
 python tools/rocpd_summary.py pmc "$(db prof_fetch)" > $O/pmc_fetch.txt
@@ -28,11 +28,11 @@ rm -rf $O/prof_stats $O/prof_fetch $O/prof_write $O/prof_sq
 # ---------------------------------------------------------------- the same model with 16-bit activations (bf16 MFMA)
 export YOLORET_TUNE_CACHE=$R/$O/tuned_bf16.json
 python bench.py --dtype bf16 --no-cpu-baseline --per-op > $O/bench_c2_bf16.json 2> $O/perop_c2_bf16.txt
-rocprofv3 --kernel-trace --stats -d $O/prof_stats16 -o stats -- python bench.py --dtype bf16 --no-cpu-baseline --no-latency > /dev/null 2> $O/rocprof_stats16.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_stats16 -o stats -- python bench.py --dtype bf16 --no-cpu-baseline --no-latency > /dev/null 2> $O/rocprof_stats16.err
 B16="python bench.py --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-latency --profile-iters 0"
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA -d $O/prof_sq16 -o pmc -- $B16 > /dev/null 2> $O/pmc_sq16.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_fetch16 -o pmc -- $B16 > /dev/null 2> $O/pmc_fetch16.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_write16 -o pmc -- $B16 > /dev/null 2> $O/pmc_write16.err
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA -d $O/prof_sq16 -o pmc -- $B16 > /dev/null 2> $O/pmc_sq16.err
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_fetch16 -o pmc -- $B16 > /dev/null 2> $O/pmc_fetch16.err
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_write16 -o pmc -- $B16 > /dev/null 2> $O/pmc_write16.err
 python tools/rocpd_summary.py stats "$(db prof_stats16)" > $O/kernel_stats_c2_bf16.txt
 python tools/rocpd_summary.py pmc "$(db prof_sq16)" > $O/pmc_sq_c2_bf16.txt
 python tools/rocpd_summary.py traffic "$(db prof_fetch16)" "$(db prof_write16)" > $O/traffic_c2_bf16.json
