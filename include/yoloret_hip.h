@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define YR_ABI_VERSION 2
+#define YR_ABI_VERSION 3   /* 3: op kind MBX, pair-packed STEM weights, BN scale folded into the packed taps of STEMBLOCK / MBLANE */
 #define YR_MAX_SRC 4
 
 typedef enum {

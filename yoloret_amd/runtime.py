@@ -85,6 +85,7 @@ class YrBuf(ctypes.Structure):
                 ('external_slot', ctypes.c_int32), ('dtype', ctypes.c_int32)]
 
 
+ABI_VERSION = 3   # == YR_ABI_VERSION of include/yoloret_hip.h
 EXPORTS = ['yr_last_error', 'yr_abi_version', 'yr_abi_sizeof', 'yr_create', 'yr_create_from_blob', 'yr_plan_io_dims', 'yr_destroy', 'yr_load_weights', 'yr_workspace_bytes',
            'yr_forward', 'yr_forward_profile', 'yr_autotune', 'yr_get_tuning', 'yr_set_tuning', 'yr_plan_num_launches', 'yr_op_run', 'yr_decode', 'yr_decode_zoom', 'yr_yolo_head', 'yr_correct_boxes',
            'yr_nms', 'yr_pack_detections', 'yr_letterbox', 'yr_letterbox_batch']
@@ -139,7 +140,7 @@ def lib():
                                    ctypes.c_int, ctypes.c_void_p]
         L.yr_letterbox_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-        if L.yr_abi_version() != 2:
+        if L.yr_abi_version() != ABI_VERSION:
             raise YoloretHipError('libyoloret_hip.so ABI version mismatch')
         L.yr_abi_sizeof.argtypes = [ctypes.c_int]
         for which, st in enumerate((YrSrc, YrOp, YrBuf)):
@@ -374,7 +375,7 @@ def pack_plan(ops, bufs, weights, in_hw, out_hwc, tuning=None):
     import struct
     tuning = tuning or {}
     weights = np.ascontiguousarray(weights, np.float32)
-    head = PLAN_MAGIC + struct.pack('<6IQ2i9i3i', 2, len(ops), len(bufs), ctypes.sizeof(YrOp), ctypes.sizeof(YrBuf),
+    head = PLAN_MAGIC + struct.pack('<6IQ2i9i3i', ABI_VERSION, len(ops), len(bufs), ctypes.sizeof(YrOp), ctypes.sizeof(YrBuf),
                                     len(tuning), weights.size, int(in_hw[0]), int(in_hw[1]),
                                     *[int(v) for hwc in out_hwc for v in hwc], 0, 0, 0)
     assert len(head) == 96
