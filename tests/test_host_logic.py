@@ -90,7 +90,9 @@ def test_plan_variants(monkeypatch):
     assert thr is m.plan and lat is not thr and m.plan_for(3) is lat
     kinds = [o.kind for o in lat.ops]
     assert rt.OP_MBLANE not in kinds and rt.OP_MBCONV not in kinds and kinds[0] == rt.OP_STEMBLOCK
-    assert kinds.count(rt.OP_SE_MEAN) == 6 and kinds.count(rt.OP_DEPTHWISE) == 22
+    # the squeeze of every SE block rides on its depthwise kernel as partial sums (no SE_MEAN launches, no merged pooling)
+    assert kinds.count(rt.OP_SE_MEAN) == 0 and kinds.count(rt.OP_DEPTHWISE) == 22 and kinds.count(rt.OP_SE_FC) == 6
+    assert sum(1 for o in lat.ops if o.kind == rt.OP_DEPTHWISE and o.gate is not None) == 6
     assert lat.param_shapes == thr.param_shapes and lat.total_macs() == thr.total_macs()
     assert abs(lat.algorithmic_bytes_per_image() - thr.algorithmic_bytes_per_image()) < 1
     assert [(b.h, b.w, b.c) for b in lat.output_bufs] == [(b.h, b.w, b.c) for b in thr.output_bufs]

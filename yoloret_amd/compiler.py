@@ -322,10 +322,13 @@ def hoist_upsampled_sources(ops, bufs):
 MERGE_SE_MEAN = os.environ.get('YOLORET_MERGE_SE_MEAN', '1') != '0'
 
 
-def merge_se_mean(ops):
+def merge_se_mean(ops, only_after_depthwise=False):
     """SE's reduce_mean and its FC pair are two latency-bound launches of one workgroup per image; when the mean
     feeds nothing but the FCs the SE_FC op takes the full map as its source and pools it itself (a fixed summation
-    order of its own): six launches fewer per MBV2 step."""
+    order of its own): six launches fewer per MBV2 step.  only_after_depthwise (the small-batch plan): merge only where
+    se_partials_from_depthwise will then turn the pooling into partial sums of the depthwise kernel - a merged launch
+    that pools a whole map in one workgroup is what that plan avoids."""
+    producer = {id(op.out): op for op in ops}
     readers = {}
     for op in ops:
         for s in op.srcs:
@@ -338,6 +341,10 @@ def merge_se_mean(ops):
         if op.kind != rt.OP_SE_MEAN or op.out.external_slot >= 0:
             continue
         rd = readers.get(id(op.out), [])
+        if only_after_depthwise:
+            d = producer.get(id(op.srcs[0].buf))
+            if d is None or d.kind != rt.OP_DEPTHWISE or d.gate is not None or d.k not in (3, 5) or d.stride not in (1, 2):
+                continue
         if len(rd) == 1 and rd[0].kind == rt.OP_SE_FC and len(rd[0].srcs) == 1 and rd[0].srcs[0].buf is op.out:
             fc = rd[0]
             fc.srcs = [Seg(op.srcs[0].buf, op.srcs[0].c, 'identity')]
@@ -882,11 +889,12 @@ class Compiler:
                 ops = pool_into_producers(ops, self.bufs, set(b.id for b in outs))
             # fuse == 'latency': the plan for batches of a few images.  A fused inverted-residual block is ONE long
             # workgroup chain (block_4 at batch 1: 14 workgroups x 60 us) where its three unfused launches take 10 us
-            # each, and the merged SE launch pools 2704 pixels in one workgroup: at batch <= 4 the unfused plan is
-            # 20 % faster end to end (0.92 -> 0.73 ms at batch 1), from batch 8 on the fused one wins.
+            # each, and a merged SE launch pools 2704 pixels in one workgroup: at batch <= 4 the unfused plan is
+            # 20 % faster end to end (0.92 -> 0.73 ms at batch 1), from batch 8 on the fused one wins.  The squeeze as
+            # partial sums of the depthwise kernel has no such workgroup: it is kept (one launch fewer per SE block).
             latency = self.fuse == 'latency'
-            if MERGE_SE_MEAN and not latency:
-                ops = merge_se_mean(ops)
+            if MERGE_SE_MEAN and (not latency or SE_PARTIALS):
+                ops = merge_se_mean(ops, only_after_depthwise=latency)
                 if SE_PARTIALS:
                     ops = se_partials_from_depthwise(ops, self.bufs)
             ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency, dtype=self.dtype, bufs=self.bufs)
