@@ -332,6 +332,124 @@ __global__ __launch_bounds__(256) void pwh_kernel(PwArgs a) {
     }
 }
 
+// Small-K form (k space of at most 32*NCH channels, one identity source, optional SE gate): the projections of the
+// high-resolution blocks - [millions of pixels] x [32..128 channels] -> [16..48 couts].  In pwh_kernel a wave fetches its
+// PT pixel tiles, multiplies and leaves: with a single 32-deep chunk there is nothing to pipeline INSIDE a tile set, so
+// every workgroup's life is one exposed HBM round trip (EfficientNet-B0 stage 1 projection, 128 x 208 x 208 pixels:
+// 0.29 ms at 1.85 TB/s).  Here a workgroup keeps the weight fragments of its cout tile in registers and WALKS a contiguous
+// range of pixel tiles; the next tile's activations (and gate rows) are in flight while the current tile is multiplied
+// and stored.  Same MFMA sequence per output as pwh_kernel: bit-identical results.
+template <class T, int PT, int CP, int NCH, int MODE>
+__global__ __launch_bounds__(256) void pwhp_kernel(PwArgs a, int tiles_per_wg) {
+    static_assert(MODE == 1 || MODE == 2, "one identity source");
+    constexpr int BM = 64 * PT, BN = 32 * CP, CT = 2 * CP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int n0 = (int)blockIdx.y * BN;
+    const int kp = a.S.kp;
+    const int kl = g * 8;
+    const int ntm = (a.M + BM - 1) / BM;
+    const int t_begin = (int)blockIdx.x * tiles_per_wg;
+    const int t_end = t_begin + tiles_per_wg < ntm ? t_begin + tiles_per_wg : ntm;
+    if (t_begin >= t_end) return;
+
+    pwh_u4 wf[NCH][CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int n = n0 + (t >> 1) * 32 + 8 * (li >> 2) + 4 * (t & 1) + (li & 3);
+        const T* brow = reinterpret_cast<const T*>(a.wt) + (size_t)(n < a.N ? n : 0) * kp;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int kraw = ch * 32 + kl;
+            wf[ch][t] = *reinterpret_cast<const pwh_u4*>(brow + (kraw < kp ? kraw : kp - 8));
+        }
+    }
+    float sc[CP][8], sh[CP][8];
+#pragma unroll
+    for (int c = 0; c < CP; ++c)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int n = n0 + c * 32 + g * 8 + r;
+            const int nc = n < a.N ? n : a.N - 1;
+            sc[c][r] = a.scale ? a.scale[nc] : 1.f;
+            sh[c][r] = a.shift ? a.shift[nc] : 0.f;
+        }
+
+    struct Tile {
+        pwh_u4 x[NCH][PT];
+        float4 g0[MODE == 2 ? NCH : 1][MODE == 2 ? PT : 1], g1[MODE == 2 ? NCH : 1][MODE == 2 ? PT : 1];
+        int cv[NCH][PT];
+    };
+    auto fetch = [&](int mt, Tile& X) __attribute__((always_inline)) {
+        const int m0 = mt * BM + wave * 16 * PT;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            PwhRow<MODE, T> row;
+            row.init(a, m0 + p * 16 + li);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+                row.template issue<false>(a, ch * 32 + kl, kp, X.x[ch][p], X.g0[MODE == 2 ? ch : 0][MODE == 2 ? p : 0],
+                                          X.g1[MODE == 2 ? ch : 0][MODE == 2 ? p : 0], X.cv[ch][p]);
+        }
+    };
+    const bool need_mask = MODE != 1 || (a.S.s[0].c & 7) != 0 || (kp & 31) != 0 || kp < 32 * NCH;
+    auto compute = [&](int mt, const Tile& X) __attribute__((always_inline)) {
+        f32x4 acc[CT][PT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) acc[t][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            pwh_u4 xf[PT];
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+                xf[p] = need_mask ? pwh_finish<MODE, T>(X.x[ch][p], X.g0[MODE == 2 ? ch : 0][MODE == 2 ? p : 0],
+                                                        X.g1[MODE == 2 ? ch : 0][MODE == 2 ? p : 0], X.cv[ch][p]) : X.x[ch][p];
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+#pragma unroll
+                for (int p = 0; p < PT; ++p) acc[t][p] = pwh_mfma<T>(wf[ch][t], xf[p], acc[t][p]);
+        }
+        const int m0 = mt * BM + wave * 16 * PT;
+#pragma unroll
+        for (int c = 0; c < CP; ++c)
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+                pwh_finish_oct<T>(a, acc[2 * c][p], acc[2 * c + 1][p], sc[c], sh[c], m0 + p * 16 + li, n0 + c * 32 + g * 8, li);
+    };
+    Tile A, B;
+    fetch(t_begin, A);
+    for (int mt = t_begin; mt < t_end; mt += 2) {   // ping-pong: static register sets
+        if (mt + 1 < t_end) fetch(mt + 1, B);
+        compute(mt, A);
+        if (mt + 1 < t_end) {
+            if (mt + 2 < t_end) fetch(mt + 2, A);
+            compute(mt + 1, B);
+        }
+    }
+}
+
+template <class T, int PT, int CP, int NCH>
+static int launch_hp(const PwArgs& a, int mode, hipStream_t s) {
+    constexpr int BM = 64 * PT, BN = 32 * CP;
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+    // about 8 workgroups per CU in flight and at least 4 tiles per workgroup (the first tile's fetch is exposed)
+    int per = (ntm + 2047) / 2048;
+    if (per < 4) per = 4;
+    const int wgs = (ntm + per - 1) / per;
+    static char nm[2][48];
+    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "pwhp_kernel<%s,%d,%d,%d,1>", yr_dtype_name(yr_elem<T>::dtype), PT, CP, NCH) +
+                              snprintf(nm[1], sizeof(nm[1]), "pwhp_kernel<%s,%d,%d,%d,2>", yr_dtype_name(yr_elem<T>::dtype), PT, CP, NCH);
+    (void)nm_len;
+    yr_note_kernel(nm[mode - 1]);
+    const dim3 grid((unsigned)wgs, (unsigned)ntn);
+    if (mode == 1) hipLaunchKernelGGL((pwhp_kernel<T, PT, CP, NCH, 1>), grid, dim3(256), 0, s, a, per);
+    else hipLaunchKernelGGL((pwhp_kernel<T, PT, CP, NCH, 2>), grid, dim3(256), 0, s, a, per);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
 template <class T, int PT, int CP>
 static int launch_h(const PwArgs& a, hipStream_t s) {
     constexpr int BM = 64 * PT, BN = 32 * CP;
@@ -356,7 +474,23 @@ struct PwhCfg { int bm, bn; };
 static const PwhCfg pwh_cfgs[] = {{64, 32}, {64, 64}, {64, 96}, {64, 128},
                                   {128, 32}, {128, 64}, {128, 96}, {128, 128}, {256, 32}, {256, 64}};
 constexpr int PWH_NCFG = sizeof(pwh_cfgs) / sizeof(pwh_cfgs[0]);
-int yr_pwh_num_cfgs() { return PWH_NCFG; }
+// + the small-K walking form (pwhp_kernel) in four shapes; where it does not apply (more than 128 k, gathered sources)
+// these indices run the plain kernel of the same tile shape, so every index is valid for every op
+constexpr int PWH_NWALK = 4;
+int yr_pwh_num_cfgs() { return PWH_NCFG + PWH_NWALK; }
+
+template <class T, int PT, int CP>
+static int launch_h(const PwArgs& a, hipStream_t s);
+
+template <class T, int PT, int CP>
+static int launch_walk(const PwArgs& a, hipStream_t s) {
+    const int mode = (a.S.n == 1 && a.S.s[0].xform == YR_X_IDENTITY) ? (a.gate ? 2 : 1) : 0;
+    const int nch = (a.S.kp + 31) >> 5;
+    if (mode == 0 || nch > 4 || a.dw_w != nullptr) return launch_h<T, PT, CP>(a, s);
+    if (nch <= 1) return launch_hp<T, PT, CP, 1>(a, mode, s);
+    if (nch <= 2) return launch_hp<T, PT, CP, 2>(a, mode, s);
+    return launch_hp<T, PT, CP, 4>(a, mode, s);
+}
 
 template <class T>
 static int launch_h_cfg(int cfg, const PwArgs& a, hipStream_t s) {
@@ -371,6 +505,10 @@ static int launch_h_cfg(int cfg, const PwArgs& a, hipStream_t s) {
         case 7: return launch_h<T, 2, 4>(a, s);
         case 8: return launch_h<T, 4, 1>(a, s);
         case 9: return launch_h<T, 4, 2>(a, s);
+        case 10: return launch_walk<T, 1, 1>(a, s);
+        case 11: return launch_walk<T, 2, 1>(a, s);
+        case 12: return launch_walk<T, 1, 2>(a, s);
+        case 13: return launch_walk<T, 2, 2>(a, s);
         default: yr_set_error("pointwise: 16-bit tile shape %d out of range", cfg); return YR_ERR_ARG;
     }
 }
@@ -378,7 +516,7 @@ static int launch_h_cfg(int cfg, const PwArgs& a, hipStream_t s) {
 // 16-bit ops: a filled PwArgs (yr_launch_pointwise did the argument checks that do not depend on the element type);
 // cfg = op.k - 1 (autotuned tile shape) or -1: heuristic.
 int yr_pw_launch_h(int dtype, int cfg, const PwArgs& a, hipStream_t s) {
-    if (cfg < 0 || cfg >= PWH_NCFG) {
+    if (cfg < 0 || cfg >= PWH_NCFG + PWH_NWALK) {
         // heuristic: the widest cout tile that still yields ~2 workgroups per CU, 128-row tiles when pixels abound
         const double Md = (double)a.M;
         double best = 1e30;
