@@ -418,15 +418,12 @@ __global__ __launch_bounds__(256) void pwhp_kernel(PwArgs a, int tiles_per_wg) {
             for (int p = 0; p < PT; ++p)
                 pwh_finish_oct<T>(a, acc[2 * c][p], acc[2 * c + 1][p], sc[c], sh[c], m0 + p * 16 + li, n0 + c * 32 + g * 8, li);
     };
-    Tile A, B;
-    fetch(t_begin, A);
-    for (int mt = t_begin; mt < t_end; mt += 2) {   // ping-pong: static register sets
-        if (mt + 1 < t_end) fetch(mt + 1, B);
-        compute(mt, A);
-        if (mt + 1 < t_end) {
-            if (mt + 2 < t_end) fetch(mt + 2, A);
-            compute(mt + 1, B);
-        }
+    Tile cur, nxt;
+    fetch(t_begin, cur);
+    for (int mt = t_begin; mt < t_end; ++mt) {
+        if (mt + 1 < t_end) fetch(mt + 1, nxt);   // (uniform) the next tile's loads are in flight during this tile's MFMAs and stores
+        compute(mt, cur);
+        cur = nxt;                                // register moves: cheaper than a second copy of the multiply + epilogue code
     }
 }
 
