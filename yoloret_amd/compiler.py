@@ -359,11 +359,9 @@ SE_PARTIALS = os.environ.get('YOLORET_SE_PARTIALS', '1') != '0'
 def dw_se_geometry(strips, c4):
     """== dw_se_geometry() in depthwise.hip: (channel vectors per workgroup, workgroups per strip group, rows of the
     partial-sum buffer) of the squeeze-excite form of the depthwise kernel."""
-    cw = c4
-    if c4 > 256 or 256 % c4:
-        cw = 1
-        while cw < c4 and cw < 32:
-            cw <<= 1
+    cw = 32
+    if c4 <= 256 and (256 // c4) * c4 * ((c4 + 31) // 32) * 32 >= c4 * 256:
+        cw = c4        # all channel vectors of a strip in one workgroup keeps at least as many lanes busy as 32-vector blocks
     return cw, (c4 + cw - 1) // cw, (strips + 256 // cw - 1) // (256 // cw)
 
 

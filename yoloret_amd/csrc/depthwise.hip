@@ -32,7 +32,7 @@ struct DwArgs {
     // SE form (squeeze-excite squeeze fused in, efficientnet.py:417): grid = (workgroups per image, B); every workgroup
     // also writes the sums of ITS outputs per channel to part[b][blockIdx.x][..] (float32, fixed order: deterministic);
     // the SE_FC op adds the rows up instead of re-reading the whole map.  A workgroup's 256 lanes are `cw` channel vectors
-    // x 256/cw pixel strips (dw_se_geometry): cw = C4 when that divides 256, else a power of two - `ncb` workgroups then
+    // x 256/cw pixel strips (dw_se_geometry): cw = C4 (all channels of a strip in one workgroup) or 32 - `ncb` workgroups then
     // share a group of strips and each writes its own channels of that group's row.
     float* part;
     int ld_part, cw, ncb;
@@ -80,12 +80,13 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs<T> a) {
     unsigned se_row = 0u;                    // SE: the row of `part` this workgroup's strips belong to
     if constexpr (SE) {
         const int cvl = (int)threadIdx.x % a.cw, sl = (int)threadIdx.x / a.cw;
+        const int spb = 256 / a.cw;              // whole strips per workgroup (cw need not divide 256: the last lanes idle)
         const unsigned cb = se_blk % (unsigned)a.ncb;
         se_row = se_blk / (unsigned)a.ncb;
         const long long strips = (long long)a.ystrips * a.xstrips;
-        long long strip = (long long)se_row * (256 / a.cw) + sl;
+        long long strip = (long long)se_row * spb + (sl < spb ? sl : spb - 1);
         int cv = (int)cb * a.cw + cvl;
-        live = strip < strips && cv < a.C4;
+        live = sl < spb && strip < strips && cv < a.C4;
         if (strip >= strips) strip = strips - 1;   // idle lanes compute a valid location (no store, no sum) and take part
         if (cv >= a.C4) cv = a.C4 - 1;             // in the reduction
         gid = strip * a.C4 + cv;
@@ -204,10 +205,12 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs<T> a) {
 // pixel strips per image, C4 channel vectors -> cw lanes of a workgroup span channels, ncb workgroups cover C4, rows =
 // groups of 256/cw strips = rows of the partial-sum buffer.
 static inline void dw_se_geometry(long long strips, int c4, int* cw, int* ncb, int* rows) {
-    int w = c4;
-    if (c4 > 256 || 256 % c4 != 0) {
-        w = 1;
-        while (w < c4 && w < 32) w <<= 1;
+    // (a) all channel vectors of a strip in one workgroup (cw = C4, 256/C4 whole strips, the remaining lanes idle) or
+    // (b) 32-vector blocks, several workgroups per strip group: whichever keeps more of the 256 lanes busy
+    int w = 32;
+    if (c4 <= 256) {
+        const int busy_a = (256 / c4) * c4 * ((c4 + 31) / 32) * 32;   // compared as busy_a / 256 vs c4 / (ncb_b * 32)
+        if (busy_a >= c4 * 256) w = c4;
     }
     *cw = w;
     *ncb = (c4 + w - 1) / w;
