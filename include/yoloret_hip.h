@@ -107,7 +107,10 @@ typedef enum {
                             wgt  = stem      [CP][27 taps (ky,kx,ci) x 2, times the BN scale | 1 1 | BN shift 2],
                             wgt2 = depthwise [CP][ 9 taps (ky,kx)    x 2, times the BN scale | 1 1 | BN shift 2],
                             b1   = project W[2*CP][COP] (input-channel major), b2 = project BN scale[COP] ++ shift[COP].
-                            Built for (CP,COP) in {(12,16),(16,16),(16,24),(20,24),(24,16),(24,24)}; others: YR_ERR_ARG */
+                            Built for (CP,COP) in {(12,16),(16,16),(16,24),(20,24),(24,16),(24,24)}; others: YR_ERR_ARG.
+                            Without b1 (no projection; cout == C1, CP in {16,20,24}): stem + depthwise only - the depthwise
+                            map is stored and, if `gate` is set, gate = OUTPUT float32 [B][ceil(h/14)*ceil(w/14)][gate_ld]
+                            per-tile channel sums of the stored values (the squeeze of the first SE block) */
     YR_OP_MBH = 11,      /* the MBCONV block on 16-bit activations, both 1x1 convs on bf16 / f16 MFMA, depthwise K = 3 | 5 from an
                             LDS tile (dtype must be YR_BF16 / YR_F16; cin, cout <= 128).  se_reduced = Cexp; k = K, optionally
                             | th << 8 | tw << 16 to force the output tile.  CexpP = round_up(Cexp,32), KP = round_up(cin,32),

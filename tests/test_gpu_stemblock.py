@@ -71,3 +71,59 @@ def test_stemblock(dev, hw, c1, cout, act, dt):
         assert_close(from_dev(out, cout), ref, 3e-5, 'stemblock')
     else:
         assert_rounded_once(from_dev16(out, dt, cout), ref, dt, 'stemblock %s' % dt, slack=3e-5)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('with_sums', [True, False])
+@pytest.mark.parametrize('hw,c1,act', [((64, 64), 32, 'swish'), ((62, 90), 40, 'swish'), ((30, 22), 48, 'relu6'), ((416, 416), 32, 'swish')])
+def test_stem_plus_depthwise(dev, hw, c1, act, with_sums, dt):
+    """YR_OP_STEMBLOCK without a projection (the entry of the squeeze-excite EfficientNets, efficientnet.py:636-645 + the
+    first block's depthwise conv): the depthwise map, one rounding at the store, plus the per-tile channel sums of the
+    STORED values (the squeeze), every row of the sum buffer written."""
+    from yoloret_amd import runtime as rt
+    rng = np.random.default_rng(zlib.crc32(str((hw, c1)).encode()))
+    b = 2
+    x = rng.random((b, hw[0], hw[1], 3), dtype=np.float32)
+    actf = {'relu6': nn.relu6, 'swish': nn.swish}[act]
+    ws = (rng.standard_normal((3, 3, 3, c1)) * np.sqrt(2.0 / 27)).astype(np.float32)
+    ss, hs = rng.uniform(0.5, 1.5, c1).astype(np.float32), rng.normal(0, 0.3, c1).astype(np.float32)
+    wd = (rng.standard_normal((3, 3, c1)) * np.sqrt(2.0 / 9)).astype(np.float32)
+    sd, hd = rng.uniform(0.5, 1.5, c1).astype(np.float32), rng.normal(0, 0.3, c1).astype(np.float32)
+    t = actf(nn.conv2d(x.astype(np.float64), ws.astype(np.float64), 2, 'same') * ss + hs)
+    ref = actf(nn.depthwise(t, wd.astype(np.float64), 1, 'same') * sd + hd)
+    c1p = round_up(c1, 4)
+
+    def per_pair(w, scale, shift):
+        rows = np.zeros((w.shape[0] + 2, c1p), np.float32)
+        rows[:-2, :c1], rows[-2, :c1], rows[-1, :c1] = (w * scale[None]).astype(np.float32), 1.0, shift
+        return np.ascontiguousarray(rows.reshape(-1, c1p // 2, 2).transpose(1, 0, 2))
+    keep = [_vec(per_pair(ws.reshape(27, c1), ss, hs), dev), _vec(per_pair(wd.reshape(9, c1), sd, hd), dev)]
+    xd = torch.from_numpy(x).to(dev)
+    did = rt.dtype_id(dt)
+    ho, wo = ref.shape[1], ref.shape[2]
+    ldo = round_up(c1, 8)
+    out = torch.full((b, ho, wo, ldo), float('nan'), dtype=rt.TORCH_DTYPE[did], device=dev)
+    rows = ((ho + 13) // 14) * ((wo + 13) // 14)
+    part = torch.full((b, rows, ldo), float('nan'), dtype=torch.float32, device=dev)
+    op = rt.new_op(rt.OP_STEMBLOCK, act)
+    op.dtype = op.out_dtype = did
+    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc, op.se_reduced = ho, wo, 3, c1, 3, 2, 1, c1
+    op.src[0] = rt.make_src(xd, c=3, ld=3)
+    op.wgt, op.wgt2 = keep[0].data_ptr(), keep[1].data_ptr()
+    op.out, op.out_ld = out.data_ptr(), ldo
+    if with_sums:
+        op.gate, op.gate_ld = part.data_ptr(), ldo
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    got = from_dev(out, c1) if dt == 'f32' else from_dev16(out, dt, c1)
+    if dt == 'f32':
+        assert_close(got, ref.astype(np.float32), 3e-5, 'stem+dw')
+    else:
+        assert_rounded_once(got, ref, dt, 'stem+dw %s' % dt, slack=5e-5)
+    if with_sums:
+        p = part.cpu().numpy()[..., :c1]
+        assert np.isfinite(p).all(), 'every row of the sum buffer is written'
+        want = np.asarray(got, np.float64).sum(axis=(1, 2))
+        np.testing.assert_allclose(p.astype(np.float64).sum(axis=1), want, rtol=2e-5, atol=2e-4 * np.sqrt(ho * wo))
+    else:
+        assert torch.isnan(part).all()

@@ -97,7 +97,7 @@ class Plan:
             for b in (op.res, op.gate):
                 if b is not None:
                     b.last_use = max(b.last_use, i)
-                    if b is op.gate and op.kind in (rt.OP_DEPTHWISE, rt.OP_MBX) and b.first_def is None:
+                    if b is op.gate and op.kind in (rt.OP_DEPTHWISE, rt.OP_MBX, rt.OP_STEMBLOCK) and b.first_def is None:
                         b.first_def = i          # SE form: the depthwise op WRITES its per-workgroup channel sums there
         self.bufs = [b for b in self.bufs if b.first_def is not None]
         for i, b in enumerate(self.bufs):
@@ -268,6 +268,7 @@ STEMBLOCK_WIDTHS ={(12, 16), (16, 16), (16, 24), (20, 24), (24, 16), (24, 24)}  
 
 FUSE_MBH = os.environ.get('YOLORET_FUSE_MBH', '1') != '0'   # 16-bit plans: inverted-residual blocks on the MFMA block kernel (mbh.hip)
 MBH_LANE_MIN_PIXELS = int(os.environ.get('YOLORET_MBH_LANE_MIN_PIXELS', '10000'))
+FUSE_STEMDW = os.environ.get('YOLORET_FUSE_STEMDW', '1') != '0'   # stem + first depthwise of the SE EfficientNets in one kernel
 FUSE_MBX = os.environ.get('YOLORET_FUSE_MBX', '1') != '0'   # 16-bit plans: expand + depthwise of squeeze-excite MBConv blocks in one kernel
 MBH_ACTS = ('relu6', 'swish')   # (swish in the fused 16-bit kernels: hardware exp2 / rcp, no register spills)
 
@@ -542,6 +543,48 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                     [pad_to(pp2['scale'][1], cout, cop)(wd), pad_to(pp2['shift'][1], cout, cop)(wd)]))
                 out.append(m)
                 i += 3
+                continue
+        # ---- network entry of the squeeze-excite EfficientNets: STEM -> DEPTHWISE 3x3 s1 whose map feeds an SE block (the
+        # projection waits for the gate): stem + depthwise as one kernel, the depthwise map and its per-tile channel sums out.
+        # 16-bit plans only: measured (B0 @416, 128 images) 0.53 vs 0.23 + 0.34 ms with bf16 maps - the kernel is bound by its
+        # two swish passes, the 708 MB it no longer moves buy 7 % - and 0.77 vs 0.36 + 0.39 ms in float32 (pinned expf)
+        if (FUSE_STEM and FUSE_STEMDW and dtype != 0 and blocks and bufs is not None and e.kind == rt.OP_STEM and private(e.out) and i + 1 < len(ops)
+                and e.act in ('relu6', 'swish') and round_up(e.cout, 4) // 2 in (16, 20, 24)):
+            d = ops[i + 1]
+            fc = None
+            if (d.kind == rt.OP_DEPTHWISE and d.k == 3 and d.stride == 1 and len(d.srcs) == 1 and d.srcs[0].xform == 'identity'
+                    and d.srcs[0].buf is e.out and d.act == e.act and d.out.external_slot < 0 and d.out.id not in output_buf_ids
+                    and d.out.ld % 4 == 0):
+                fc = next((o for o in ops if o.kind == rt.OP_SE_FC and getattr(o, 'merged_mean', 0) and len(o.srcs) == 1
+                           and (o.srcs[0].buf is d.out or (d.gate is not None and o.srcs[0].buf is d.gate))), None)
+            if fc is not None:
+                c1 = e.cout
+                c1p = round_up(c1, 4)
+                rows = ((d.h + 13) // 14) * ((d.w + 13) // 14)           # one row per 14 x 14 output tile (stemblock.hip)
+                part = d.gate
+                if part is None:
+                    part = Buf(len(bufs), rows, 1, c1, round_up(c1, 4), name=d.name + ':se_sums', dtype=0)
+                    bufs.append(part)
+                    fc.srcs = [Seg(part, c1, 'identity')]
+                    fc.k = d.h * d.w
+                else:
+                    part.h, part.elems = rows, rows * part.w * part.ld
+                    part.bytes = part.elems * rt.ESIZE[part.dtype]
+                m = OpRec(rt.OP_STEMBLOCK, e.name + '_dw', act=e.act, h=d.h, w=d.w, cin=3, cout=c1, k=3, stride=2,
+                          se_reduced=c1, srcs=[e.srcs[0]], out=d.out, gate=part, macs=e.macs + d.macs, dtype=dtype)
+                m.fused = [e, d]
+
+                def per_pair2(prm, taps, c1p=c1p):
+                    def f(wd):
+                        sc = pad_to(prm['scale'][1], c1p, c1p)(wd)
+                        w = (prm['wgt'][1](wd).reshape(taps, -1)[:, :c1p] * sc[None]).astype(np.float32)
+                        rows_ = np.concatenate([w, np.ones((1, c1p), np.float32), pad_to(prm['shift'][1], c1p, c1p)(wd)[None]])
+                        return np.ascontiguousarray(rows_.reshape(taps + 2, c1p // 2, 2).transpose(1, 0, 2)).reshape(c1p // 2, -1)
+                    return ((c1p // 2, (taps + 2) * 2), f)
+                m.params['wgt'] = per_pair2(e.params, 27)
+                m.params['wgt2'] = per_pair2(d.params, 9)
+                out.append(m)
+                i += 2
                 continue
         exp = dw = proj = None
         j = i

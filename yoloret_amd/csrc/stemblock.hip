@@ -41,14 +41,17 @@ struct SbArgs {
     const float* wp;   // project    [2*CP][COP]
     const float* bp;   // project    scale [COP] ++ shift [COP]
     int Hi, Wi, Ho, Wo, Cout, ld_out, pad_t, pad_l, act, tiles_x, tiles_y;
+    // COP == 0 (stem + depthwise only, the entry of the squeeze-excite EfficientNets): per-tile channel sums of the stored
+    // depthwise map, float32 [B][tiles_y * tiles_x][ld_part] (the squeeze; SE_FC adds the rows up), or null
+    float* part; int ld_part;
 };
 
 __device__ __forceinline__ v2f sb_fma(v2f x, v2f y, v2f z) { return __builtin_elementwise_fma(x, y, z); }
 
-template <bool RELU6>
+template <bool RELU6, class T = float>
 __device__ __forceinline__ v2f sb_act(v2f v, int act) {
     if (RELU6) return (v2f){fminf(fmaxf(v.x, 0.f), 6.f), fminf(fmaxf(v.y, 0.f), 6.f)};
-    return (v2f){yr_apply_act(v.x, act), yr_apply_act(v.y, act)};
+    return (v2f){yr_apply_act_t<T>(v.x, act), yr_apply_act_t<T>(v.y, act)};   // (16-bit maps: hardware exp2 / rcp swish)
 }
 
 template <int CP, int COP, bool RELU6, class T>
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256, 4) void stemblock_kernel(SbArgs<T> a) {
             if (RELU6) {                         // upper clamp 0 outside the map = the depthwise's zero padding, for free
                 acc = (v2f){__builtin_amdgcn_fmed3f(acc.x, 0.f, hi), __builtin_amdgcn_fmed3f(acc.y, 0.f, hi)};
             } else {
-                acc = sb_act<false>(acc, a.act);
+                acc = sb_act<false, T>(acc, a.act);
                 if (!valid) acc = (v2f){0.f, 0.f};
             }
             Es[p * 256 + tid] = acc;
@@ -125,11 +128,67 @@ __global__ __launch_bounds__(256, 4) void stemblock_kernel(SbArgs<T> a) {
     }
     __syncthreads();
 
+    if constexpr (COP == 0) {
+        // ---- phase 2, no projection: the depthwise map itself is the output (2*CP channels per lane, contiguous), and the
+        // tile's per-channel sums of the STORED values go to its row of `part` (wave butterfly, then the four waves in order)
+        const int py = tid / SB_T, px = tid - py * SB_T;
+        const int gy = oy0 + py, gx = ox0 + px;
+        const bool live = tid < SB_T * SB_T && gy < a.Ho && gx < a.Wo;
+        const kptr wd = (kptr)a.wd;
+        const v2f* e0 = Es + (tid < SB_T * SB_T ? py * SB_E + px : 0);
+        v2f dres[CP];
+#pragma unroll
+        for (int p = 0; p < CP; ++p) {
+            const kptr w = wd + p * SB_WD;
+            const v2f* e = e0 + p * 256;
+            v2f dr[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int k = ky * 3 + kx;
+                    dr[ky] = sb_fma(e[ky * SB_E + kx], (v2f){w[2 * k], w[2 * k + 1]}, dr[ky]);
+                }
+            v2f d = (dr[0] + dr[1]) + dr[2];
+            d = sb_act<RELU6, T>(d + (v2f){w[20], w[21]}, a.act);
+            // what is stored (one rounding), widened again: the squeeze is the mean of the stored map
+            dres[p] = (v2f){(float)(T)d.x, (float)(T)d.y};
+        }
+        if (live) {
+            T* op = a.out + (((size_t)b * a.Ho + gy) * a.Wo + gx) * a.ld_out;
+#pragma unroll
+            for (int p = 0; p < CP; p += 2) {   // 4 channels per store (CP is even)
+                if (2 * p + 3 < a.Cout) {
+                    yr_st4<T>(op + 2 * p, make_float4(dres[p].x, dres[p].y, dres[p + 1].x, dres[p + 1].y));
+                } else {
+                    if (2 * p < a.Cout) yr_st1<T>(op + 2 * p, dres[p].x);
+                    if (2 * p + 1 < a.Cout) yr_st1<T>(op + 2 * p + 1, dres[p].y);
+                    if (2 * p + 2 < a.Cout) yr_st1<T>(op + 2 * p + 2, dres[p + 1].x);
+                }
+            }
+        }
+        if (a.part != nullptr) {
+            __syncthreads();                  // every reader of Es is done: its first floats become the wave sums
+            float* ws4 = lds;                 // [4 waves][2 * CP]
+            const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+            for (int p = 0; p < CP; ++p) {
+                v2f v = live ? dres[p] : (v2f){0.f, 0.f};
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); }
+                if (lane == 0) { ws4[wave * 2 * CP + 2 * p] = v.x; ws4[wave * 2 * CP + 2 * p + 1] = v.y; }
+            }
+            __syncthreads();
+            if (tid < 2 * CP && tid < a.ld_part)
+                a.part[((size_t)b * tpi + r) * a.ld_part + tid] = ((ws4[tid] + ws4[2 * CP + tid]) + ws4[4 * CP + tid]) + ws4[6 * CP + tid];
+        }
+        return;
+    }
     // ---- phase 2: lane = output pixel; depthwise 3x3 + BN + act in registers, projected immediately
     if (tid < SB_T * SB_T) {
         const int py = tid / SB_T, px = tid - py * SB_T;
         const int gy = oy0 + py, gx = ox0 + px;
-        v2f o[COP / 2];
+        v2f o[COP > 0 ? COP / 2 : 1];
 #pragma unroll
         for (int n = 0; n < COP / 2; ++n) o[n] = (v2f){0.f, 0.f};
         const kptr wd = (kptr)a.wd;
@@ -177,7 +236,7 @@ __global__ __launch_bounds__(256, 4) void stemblock_kernel(SbArgs<T> a) {
 
 template <int CP, int COP, class T>
 static int launch_sb(const SbArgs<T>& a, int batch, hipStream_t s) {
-    constexpr size_t lds = (size_t)CP * 256 * 2 * sizeof(float);
+    constexpr size_t lds = (size_t)CP * 256 * 2 * sizeof(float);   // (COP == 0: its head doubles as the [4][2*CP] wave sums)
     static_assert(lds <= 64 * 1024, "stemblock LDS tile too large");
     static char nm[2][48];
     static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "stemblock_kernel<%d,%d,0,%s>", CP, COP, yr_dtype_name(yr_elem<T>::dtype)) +
@@ -207,8 +266,10 @@ static int launch_stemblock_t(const yr_op& op, int batch, hipStream_t s) {
     a.in = (const float*)in.ptr; a.out = (T*)op.out;
     YR_REQUIRE(op.se_reduced >= 1 && op.cout >= 1, "stemblock: bad widths (C1=%d, Cout=%d)", op.se_reduced, op.cout);
     const int c1p = yr_round_up(op.se_reduced, 4), cop = yr_round_up(op.cout, 8);
-    YR_REQUIRE(in.ptr && op.out && op.wgt && op.wgt2 && op.b1 && op.b2, "stemblock: null pointer");
+    const bool noproj = op.b1 == nullptr;   // stem + depthwise only (cout == C1): the depthwise map and its squeeze sums leave
+    YR_REQUIRE(in.ptr && op.out && op.wgt && op.wgt2 && (noproj || op.b2), "stemblock: null pointer");
     a.ws = op.wgt; a.wd = op.wgt2; a.wp = op.b1; a.bp = op.b2;
+    a.part = nullptr; a.ld_part = 0;
     a.Cout = op.cout;
     a.Hi = in.h; a.Wi = in.w; a.Ho = (in.h + 1) / 2; a.Wo = (in.w + 1) / 2;
     YR_REQUIRE(a.Ho == op.h && a.Wo == op.w && op.out_ld >= op.cout, "stemblock: output dims mismatch");
@@ -217,6 +278,19 @@ static int launch_stemblock_t(const yr_op& op, int batch, hipStream_t s) {
     a.pad_t = (pth > 0 ? pth : 0) / 2; a.pad_l = (ptw > 0 ? ptw : 0) / 2;
     a.act = op.act;
     a.tiles_x = (a.Wo + SB_T - 1) / SB_T; a.tiles_y = (a.Ho + SB_T - 1) / SB_T;
+    if (noproj) {
+        YR_REQUIRE(op.cout == op.se_reduced && op.out_ld % 4 == 0, "stemblock: without a projection the output is the depthwise map (cout == C1, out_ld %% 4 == 0)");
+        if (op.gate) {   // OUTPUT: per-tile channel sums
+            YR_REQUIRE(op.gate_ld >= op.cout && ((uintptr_t)op.gate % 4) == 0, "stemblock: bad squeeze-sum buffer");
+            a.part = const_cast<float*>(op.gate); a.ld_part = op.gate_ld;
+        }
+        switch (c1p / 2) {
+            case 16: return launch_sb<16, 0, T>(a, batch, s);    // EfficientNet-B0 / B1 (32)
+            case 20: return launch_sb<20, 0, T>(a, batch, s);    // B3 (40)
+            case 24: return launch_sb<24, 0, T>(a, batch, s);    // B4 / B5 (48)
+            default: yr_set_error("stemblock: stem width C1=%d unsupported without a projection", op.se_reduced); return YR_ERR_ARG;
+        }
+    }
     switch (c1p / 2 * 100 + cop) {
         case 1216: return launch_sb<12, 16, T>(a, batch, s);
         case 1616: return launch_sb<16, 16, T>(a, batch, s);
