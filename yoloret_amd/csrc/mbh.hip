@@ -14,8 +14,11 @@
 //                   (read from HBM once; also the residual source);
 //   Es [PH][32+4]   the current 32-channel chunk of the EXPANDED halo tile, float32 (zero outside the image: TF pads
 //                   the expanded tensor, not the input);
-//   Ps [2][..]      the chunk's depthwise weights and the expand / depthwise BN parameters, double buffered;
-//   Ws [2][32][KP+8] the chunk's expand weights, 16-bit, double buffered.  Both are fetched one chunk ahead into
+//   Ps [..]         the chunk's depthwise weights and the expand / depthwise BN parameters;
+//   Ws [32][KP+8]   the chunk's expand weights, 16-bit.  Both are SINGLE buffers rewritten in the phase that does not read
+//                   them (expand weights + expand BN behind barrier (A), depthwise rows behind barrier (B)): 12 KB less than
+//                   double buffers for a 112-channel 5x5 block - the difference between one and two workgroups per CU.
+//                   Both are fetched one chunk ahead into
 //                   registers and stored behind the depthwise phase, so no chunk starts by waiting for L2 (the first
 //                   version read the weight fragments from global memory where they were used: 4-5 us per chunk on
 //                   the 13x13 blocks, whose four k-steps each waited for a round trip).
@@ -94,9 +97,10 @@ __global__ __launch_bounds__(256, (MODE == 1 || CP * NG <= 1 ? 3 : 2)) void mbh_
     const int ldx = a.KP + 8;                           // Xs / Ws row stride in elements (16-byte aligned, conflict-free)
     T* Xs = reinterpret_cast<T*>(lds_raw);
     float* Es = reinterpret_cast<float*>(lds_raw + (((size_t)a.PH * ldx * sizeof(T) + 15) & ~(size_t)15));
+    constexpr int PDZ = (KK + 2) * MBH_EC;              // ... of which the depthwise phase reads the first PDZ, the expand phase the rest
     float* Ps = Es + (size_t)a.PH * MBH_LDE;
-    T* Ws = reinterpret_cast<T*>(Ps + 2 * PSZ);         // [2][32][ldx]: expand weights of the current / next chunk
-    T* Ds = Ws + (size_t)2 * 32 * ldx;                  // [4 waves][32][LDD]: depthwise results on their way to the MFMA
+    T* Ws = reinterpret_cast<T*>(Ps + PSZ);             // [32][ldx]: expand weights of the current chunk
+    T* Ds = Ws + (size_t)32 * ldx;                      // [4 waves][32][LDD]: depthwise results on their way to the MFMA
     float* Sw = reinterpret_cast<float*>(Ds);           // MODE 1 instead: [4 waves][32] channel sums of the current chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
@@ -169,10 +173,13 @@ __global__ __launch_bounds__(256, (MODE == 1 || CP * NG <= 1 ? 3 : 2)) void mbh_
             if (i < PSZ) pv[u] = a.prm[(size_t)rr * a.CexpP + e0 + ch];
         }
     };
-    auto store_params = [&](float* dst, const float (&pv)[NPV]) __attribute__((always_inline)) {
+    // lo..hi: the depthwise rows [0, PDZ) or the expand rows [PDZ, PSZ) - they are rewritten at different points of a chunk
+    auto store_params = [&](float* dst, const float (&pv)[NPV], int lo, int hi) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < NPV; ++u)
-            if (tid + u * 256 < PSZ) dst[tid + u * 256] = pv[u];
+        for (int u = 0; u < NPV; ++u) {
+            const int i = tid + u * 256;
+            if (i >= lo && i < hi) dst[i] = pv[u];
+        }
     };
     // expand weights of one chunk: 32 rows x KP/8 16-byte vectors, at most 2 per thread (KP <= 128)
     const int wq = a.KP >> 3, wtotal = 32 * wq;
@@ -193,12 +200,12 @@ __global__ __launch_bounds__(256, (MODE == 1 || CP * NG <= 1 ? 3 : 2)) void mbh_
             if (i < wtotal) *reinterpret_cast<mbh_u4*>(dst + (size_t)rr * ldx + q * 8) = wv[u];
         }
     };
+    float pcur[NPV];                                    // the current chunk's parameters (its depthwise rows are stored at the chunk's top)
     {
-        float pv[NPV];
         mbh_u4 wv[2];
-        load_params(0, pv);
+        load_params(0, pcur);
         load_w(0, wv);
-        store_params(Ps, pv);
+        store_params(Ps, pcur, PDZ, PSZ);
         store_w(Ws, wv);
     }
 
@@ -253,9 +260,10 @@ __global__ __launch_bounds__(256, (MODE == 1 || CP * NG <= 1 ? 3 : 2)) void mbh_
     const int nchunks = a.CexpP >> 5;
     for (int ci = 0; ci < nchunks; ++ci) {
         const int e0 = ci * MBH_EC;
-        const float* Pc = Ps + (ci & 1) * PSZ;
-        // prefetches: this chunk's projection fragments; the next chunk's parameters and expand weights (stored to
-        // their other LDS buffers behind the depthwise phase)
+        const float* Pc = Ps;
+        store_params(Ps, pcur, 0, PDZ);    // this chunk's depthwise rows: every wave is past barrier (B) of the previous chunk
+        // prefetches: this chunk's projection fragments; the next chunk's parameters and expand weights (into registers; the
+        // expand rows / weights are stored behind this chunk's depthwise phase, the depthwise rows at the next chunk's top)
         mbh_u4 wpf[CT];
         if constexpr (MODE == 0) {
 #pragma unroll
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(256, (MODE == 1 || CP * NG <= 1 ? 3 : 2)) void mbh_
             load_params(e0 + MBH_EC, pnext);
             load_w(e0 + MBH_EC, wnext);
         }
-        const T* Wc = Ws + (size_t)(ci & 1) * 32 * ldx;
+        const T* Wc = Ws;
 
         // ---- 2. expand GEMM over this wave's 16-pixel halo tiles -> Es
         {
@@ -424,8 +432,10 @@ __global__ __launch_bounds__(256, (MODE == 1 || CP * NG <= 1 ? 3 : 2)) void mbh_
             }
         }
         if (more) {
-            store_params(Ps + ((ci + 1) & 1) * PSZ, pnext);
-            store_w(Ws + (size_t)((ci + 1) & 1) * 32 * ldx, wnext);
+            store_params(Ps, pnext, PDZ, PSZ);   // the next chunk's expand BN rows and weights: every wave is past barrier (A)
+            store_w(Ws, wnext);
+#pragma unroll
+            for (int u = 0; u < NPV; ++u) pcur[u] = pnext[u];
         }
         __syncthreads();   // (B) Es may be rewritten; the next chunk's parameters and expand weights are visible
         if constexpr (MODE == 1) {
@@ -471,8 +481,8 @@ __global__ __launch_bounds__(256, (MODE == 1 || CP * NG <= 1 ? 3 : 2)) void mbh_
 
 // ------------------------------------------------------------------------------------------ host side
 static size_t mbh_lds_bytes(int ph, int kp, int k, int mode) {
-    return (((size_t)ph * (kp + 8) * 2 + 15) & ~(size_t)15) + (size_t)ph * MBH_LDE * 4 + (size_t)2 * (k * k + 4) * MBH_EC * 4 +
-           (size_t)2 * 32 * (kp + 8) * 2 + (mode == 0 ? (size_t)4 * 32 * (MBH_EC + 8) * 2 : (size_t)4 * MBH_EC * 4);
+    return (((size_t)ph * (kp + 8) * 2 + 15) & ~(size_t)15) + (size_t)ph * MBH_LDE * 4 + (size_t)(k * k + 4) * MBH_EC * 4 +
+           (size_t)32 * (kp + 8) * 2 + (mode == 0 ? (size_t)4 * 32 * (MBH_EC + 8) * 2 : (size_t)4 * MBH_EC * 4);
 }
 
 template <class T, int K, int S, int CP, int NG, int MODE>
