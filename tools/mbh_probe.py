@@ -17,7 +17,7 @@ BLOCKS = [  # name, h(in), cin, cexp, cout, k, s, res
     ('block_14', 13, 120, 720, 120, 3, 1, 1),
     # EfficientNet-lite0 @416 blocks (5x5 depthwise)
     ('l_s3b0', 104, 24, 144, 40, 5, 2, 0), ('l_s3b1', 52, 40, 240, 40, 5, 1, 1), ('l_s5b0', 26, 80, 480, 112, 5, 1, 0),
-    ('l_s5b1', 26, 112, 672, 112, 5, 1, 1),
+    ('l_s5b1', 26, 112, 672, 112, 5, 1, 1), ('l3_s2b0', 320, 24, 144, 32, 3, 2, 0), ('l3_s3b0', 160, 32, 192, 48, 5, 2, 0),
     # EfficientNet-B0 @416 squeeze-excite blocks: expand + depthwise (cout 0 = MBX, swish)
     ('x_s2b0', 208, 16, 96, 0, 3, 2, 0), ('x_s2b1', 104, 24, 144, 0, 3, 1, 0), ('x_s3b0', 104, 24, 144, 0, 5, 2, 0),
     ('x_s3b1', 52, 40, 240, 0, 5, 1, 0), ('x_s4b0', 52, 40, 240, 0, 3, 2, 0), ('x_s4b1', 26, 80, 480, 0, 3, 1, 0),

@@ -268,6 +268,7 @@ STEMBLOCK_WIDTHS ={(12, 16), (16, 16), (16, 24), (20, 24), (24, 16), (24, 24)}  
 
 FUSE_MBH = os.environ.get('YOLORET_FUSE_MBH', '1') != '0'   # 16-bit plans: inverted-residual blocks on the MFMA block kernel (mbh.hip)
 MBH_LANE_MIN_PIXELS = int(os.environ.get('YOLORET_MBH_LANE_MIN_PIXELS', '10000'))
+MBH_LANE_MAX_CIN = int(os.environ.get('YOLORET_MBH_LANE_MAX_CIN', '16'))
 FUSE_STEMDW = os.environ.get('YOLORET_FUSE_STEMDW', '1') != '0'   # stem + first depthwise of the SE EfficientNets in one kernel
 FUSE_MBX = os.environ.get('YOLORET_FUSE_MBX', '1') != '0'   # 16-bit plans: expand + depthwise of squeeze-excite MBConv blocks in one kernel
 MBH_ACTS = ('relu6', 'swish')   # (swish in the fused 16-bit kernels: hardware exp2 / rcp, no register spills)
@@ -607,8 +608,10 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                 mbh = (d, p)
                 # measured (tools/mbh_probe.py, batch 64): only on the first, stride-2 block (16 -> 96 -> 24 channels,
                 # 208 x 208 -> 104 x 104) the float32 lane-per-pixel kernel is still ahead (0.223 vs 0.253 ms: its 17 x 17
-                # halo tile leaves two workgroups per CU); from block_2 on (0.205 vs 0.138 ms) everything goes to mbh
-                if lane_ok(exp, bi, p) and d.k == 3 and d.stride == 2 and p.h * p.w >= MBH_LANE_MIN_PIXELS:
+                # halo tile leaves two workgroups per CU); from block_2 on (0.205 vs 0.138 ms) everything goes to mbh.  With 24
+                # block inputs the lane kernel loses there too (EfficientNet-lite3 stage 2 entry, 320 x 320 -> 160 x 160, 32 images:
+                # 0.48 vs 0.41 ms): only blocks of at most 16 inputs stay on it
+                if lane_ok(exp, bi, p) and d.k == 3 and d.stride == 2 and p.h * p.w >= MBH_LANE_MIN_PIXELS and bi.c <= MBH_LANE_MAX_CIN:
                     mbh = None
         mbx = None
         if (FUSE_MBX and mbh is None and bufs is not None and dtype != 0 and blocks and exp is not None and d is not None
