@@ -428,13 +428,16 @@ def pool_into_producers(ops, bufs, output_buf_ids):
 # Off by default (measured, MBV2x0.75@416 batch 64): the folded projection equals depthwise + projection on the 26x26
 # blocks (0.046 vs 0.048 ms, 0.0735 vs 0.075 ms) and loses on the 13x13 ones (0.081 vs 0.056 ms): a 64-row tile per
 # workgroup leaves the depthwise arithmetic to 2-3 workgroups per CU where dw_kernel spreads it over 8 waves per SIMD.
-# 21.4k vs 21.9k img/s end to end.  Kept (bit-identical, tested) for maps with more pixels per layer.
-FOLD_DW = os.environ.get('YOLORET_FOLD_DW', '0') != '0'
+# 21.4k vs 21.9k img/s end to end.  On maps of 32 x 32 and more it wins (MobileNetV2 x1.4 @512, batch 64: block_4/5 at
+# 64 x 64: 0.233 vs 0.193 + 0.118 ms; block_7..9 at 32 x 32: 0.14 vs 0.16 ms; 8.70k -> 8.98k img/s): folded by default
+# where the projection's map has at least FOLD_DW_MIN_PIXELS pixels.  YOLORET_FOLD_DW = 0: never, 1: every eligible block.
+FOLD_DW = os.environ.get('YOLORET_FOLD_DW', 'auto')
+FOLD_DW_MIN_PIXELS = int(os.environ.get('YOLORET_FOLD_DW_MIN_PIXELS', '1024'))
 FOLD_DW_MAX_COUT = int(os.environ.get('YOLORET_FOLD_DW_MAX_COUT', '128'))   # one cout tile: the depthwise work is done once
 FOLD_DW_MAX_C = 1088                                                       # 11 * round_up(C,4) floats of LDS <= 48 KB
 
 
-def fold_depthwise_into_project(ops, output_buf_ids):
+def fold_depthwise_into_project(ops, output_buf_ids, min_pixels=0):
     """DEPTHWISE 3x3 (+BN+act) whose only reader is a plain POINTWISE projection: the projection reads the
     depthwise INPUT through xform 'dw3' and computes the depthwise stage in its loader (pointwise_lds.hip, PwDwRow),
     bit-identically; the depthwise output - as wide as the expand output - never reaches HBM.  Only where the
@@ -455,7 +458,8 @@ def fold_depthwise_into_project(ops, output_buf_ids):
                 and p.kind == rt.OP_POINTWISE and len(p.srcs) == 1 and p.srcs[0].buf is d.out
                 and p.srcs[0].xform == 'identity' and p.gate is None and not getattr(p, 'stride', 0)
                 and readers.get(d.out.id, 0) == 1 and d.out.id not in output_buf_ids
-                and p.cout <= FOLD_DW_MAX_COUT and d.cout <= FOLD_DW_MAX_C and 'scale' in p.params):
+                and p.cout <= FOLD_DW_MAX_COUT and d.cout <= FOLD_DW_MAX_C and 'scale' in p.params
+                and p.h * p.w >= min_pixels):
             f = OpRec(rt.OP_POINTWISE, p.name, act=p.act, h=p.h, w=p.w, cin=p.cin, cout=p.cout,
                       srcs=[Seg(d.srcs[0].buf, d.srcs[0].c, 'dw3')], out=p.out, res=p.res,
                       se_reduced=d.stride | (rt.ACT[d.act] << 8), macs=p.macs + d.macs)
@@ -942,8 +946,9 @@ class Compiler:
                 if SE_PARTIALS:
                     ops = se_partials_from_depthwise(ops, self.bufs)
             ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency, dtype=self.dtype, bufs=self.bufs)
-            if FOLD_DW and not latency and self.dtype == 0:
-                ops = fold_depthwise_into_project(ops, set(b.id for b in outs))
+            fold = FOLD_DW if isinstance(FOLD_DW, str) else ('1' if FOLD_DW else '0')   # (tests assign booleans)
+            if fold != '0' and not latency and self.dtype == 0:
+                ops = fold_depthwise_into_project(ops, set(b.id for b in outs), 0 if fold == '1' else FOLD_DW_MIN_PIXELS)
         plan = Plan(ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape, self.dtype)
         plan.layer_seq = dict(self.layer_seq)
         return plan
