@@ -185,7 +185,13 @@ def test_pointwise16_tile_shapes_are_bit_identical(dev, dt, ci):
 
 @pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('k,s,h,w,c,act', [(3, 1, 13, 13, 96, 'relu6'), (3, 2, 15, 17, 144, 'relu6'), (5, 1, 9, 12, 40, 'swish'),
-                                           (5, 2, 14, 14, 75, 'swish'), (3, 1, 5, 7, 10, 'none'), (3, 2, 32, 32, 32, 'relu6')])
+                                           (5, 2, 14, 14, 75, 'swish'), (3, 1, 5, 7, 10, 'none'), (3, 2, 32, 32, 32, 'relu6'),
+                                           # 5x5 stride 1 with 64 channels or more: the LDS-tiled form (depthwise_lds.hip) - one tile with
+                                           # two bands, tiles of 8 columns in four bands, ragged tiles, a channel tail, a map smaller than the
+                                           # kernel, wider than one 32-column tile
+                                           (5, 1, 13, 13, 200, 'relu6'), (5, 1, 20, 20, 72, 'swish'), (5, 1, 40, 40, 136, 'relu6'),
+                                           (5, 1, 7, 45, 64, 'none'), (5, 1, 37, 9, 100, 'swish'), (5, 1, 3, 3, 64, 'relu6'),
+                                           (5, 1, 26, 26, 96, 'leaky')])
 def test_depthwise16(dev, dt, k, s, h, w, c, act):
     rt = _rt()
     did = rt.dtype_id(dt)

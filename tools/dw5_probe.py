@@ -18,17 +18,26 @@ for name, b, h, c in [('B3 stage5 40x40', 32, 40, 816), ('B3 stage6 20x20', 32, 
     out = torch.empty_like(x)
     w = torch.randn((25, ldc), device=dev)
     sc, sh = torch.ones(ldc, device=dev), torch.zeros(ldc, device=dev)
-    op = rt.new_op(rt.OP_DEPTHWISE, 'swish')
+    op = rt.new_op(rt.OP_DEPTHWISE, sys.argv[2] if len(sys.argv) > 2 else 'swish')
     op.dtype = op.out_dtype = did
     op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc = h, h, c, c, 5, 1, 1
     op.src[0] = rt.make_src(x, c=c)
     op.wgt, op.scale, op.shift = w.data_ptr(), sc.data_ptr(), sh.data_ptr()
     op.out, op.out_ld = out.data_ptr(), ldc
     res = []
-    for f in ('', '42', '22', '21', '81', '44', '24'):
-        os.environ['YR_DW_FORCE'] = f
+    ref = None
+    for f in ('lds', '', 'lds1', 'lds2'):
+        os.environ['YOLORET_DW_LDS'] = '1' if f.startswith('lds') else '0'
+        os.environ['YR_DWL_DBG'] = f[3:] if f.startswith('lds') and len(f) > 3 else '0'
+        os.environ['YR_DW_FORCE'] = '' if f.startswith('lds') else f
+        out.zero_()
         rt.run_op(op, b)
         torch.cuda.synchronize()
+        if f == 'lds':
+            lds_out = out.clone()
+        elif f == '':
+            same = torch.equal(lds_out.view(torch.int16), out.view(torch.int16))
+            res.append('bit-identical' if same else 'DIFFERENT (max %.3g)' % (lds_out.float() - out.float()).abs().max().item())
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20):

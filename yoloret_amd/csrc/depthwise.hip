@@ -291,6 +291,18 @@ static int launch_depthwise_t(const yr_op& op, int batch, hipStream_t s) {
         if (op.k == 5 && op.stride == 1) return launch_dw_se<5, 1, 4, T>(a, rows, s);
         return launch_dw_se<5, 2, 2, T>(a, rows, s);
     }
+    // 16-bit 5x5 stride 1 on maps with at least one 64-channel chunk: the LDS-tiled form (depthwise_lds.hip, bit-identical
+    // results; YOLORET_DW_LDS=0 keeps this kernel for A/B runs)
+    if constexpr (sizeof(T) == 2) {
+#ifdef YR_DW_EXPERIMENT
+        const bool lds_form = !(getenv("YOLORET_DW_LDS") && atoi(getenv("YOLORET_DW_LDS")) == 0);   // re-read per launch
+#else
+        static const bool lds_form = !(getenv("YOLORET_DW_LDS") && atoi(getenv("YOLORET_DW_LDS")) == 0);
+#endif
+        if (lds_form && op.k == 5 && op.stride == 1 && in.c >= 64)
+            return yr_launch_depthwise_lds5(op.dtype, in.ptr, op.wgt, op.scale, op.shift, op.out, batch, in.h, in.w, a.C4, a.ld_in, a.ld_w, a.ld_out,
+                                            a.pad_t, a.pad_l, a.act, s);
+    }
 #ifdef YR_DW_EXPERIMENT   // tools/dw5_probe.py: patch shapes of the 5x5 stride-1 form (XT*10 + YT in YR_DW_FORCE)
     if (op.k == 5 && op.stride == 1) {
         const char* e = getenv("YR_DW_FORCE");

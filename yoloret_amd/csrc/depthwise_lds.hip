@@ -1,0 +1,246 @@
+// Depthwise 5x5 stride-1 convolution on 16-bit maps, LDS-tiled: the form for the wide EfficientNet stages whose blocks the
+// fused kernels do not take (more than 128 block inputs: efficientnet.py:501-510 with kernel_size 5).  Same arithmetic as
+// dw_kernel<5,1,..> - float32 accumulation in (ky, kx) order, BatchNorm, activation, one rounding on store - so the two
+// forms are bit-identical; only the data movement differs:
+//
+//   dw_kernel: lane = 4 outputs x 8 channels straight from global memory.  Every input element is fetched and widened by
+//   ten lanes, the 25 x 8 float32 tap weights are re-fetched per lane (more load instructions than the data itself), and
+//   at 134-154 VGPRs three waves per SIMD cannot hide five dependent round trips: 1.1-1.4 TB/s (profiles/r02_perop_c5*).
+//
+//   here: one workgroup = 64 channels x a TW x TH output tile.  The halo tile is fetched ONCE with independent 16-byte
+//   loads (all in flight together) and parked in LDS transposed to [row][channel pair][x]; a lane owns ONE channel pair
+//   (2 x 25 taps = 50 VGPRs, fetched once) and a strip of 4 output columns and slides down its band of rows with a ring
+//   of 5 x 4 float2 accumulators: per input row 4 ds_read_b64, 16 conversions and 100 packed FMAs on 20 independent
+//   chains (the packed-FMA issue limit of tools/peak.hip does not bite).  Row pitch TWp = TW + 6 = 2 (mod 4) words makes
+//   both the transposing writes (8 channel groups x 8 pixels of a wave -> 64 distinct banks) and the b64 reads (32 pairs x
+//   pitch: 32 distinct even banks) conflict-free.
+#include "yr_common.h"
+#include <cstdlib>
+
+struct DwlArgs {
+    const void* in;      // [B][H][W][ld_in] 16-bit
+    const float* w;      // [25][ld_w]
+    const float* scale;
+    const float* shift;
+    void* out;           // [B][H][W][ld_out]
+    int B, H, W, C8;     // C8 = ceil(C / 8): 16-byte channel vectors per pixel
+    int ld_in, ld_w, ld_out;
+    int pad_t, pad_l, act;
+    int tw, twp, th;     // output tile, LDS row pitch in words
+    int nstrip, nband, band_rows;
+    int ntx, nty, ncc;   // tiles along x / y, 64-channel chunks
+    int step_r, step_j;  // 32 = step_r * (tw + 4) + step_j
+    int stage_u;         // 16-byte loads per lane and staging round (the halo tile's loads spread evenly over the rounds)
+    unsigned nblocks;
+    int dbg;             // YR_DW_EXPERIMENT builds: 1 = no compute phase, 2 = no global loads while staging
+};
+
+typedef float dwl_f2 __attribute__((ext_vector_type(2)));
+
+template <class T>
+__device__ __forceinline__ dwl_f2 dwl_widen(unsigned v) {
+    typedef T t2 __attribute__((ext_vector_type(2)));
+    return __builtin_convertvector(__builtin_bit_cast(t2, v), dwl_f2);
+}
+
+// ACT: 0 ReLU6, 1 swish (the fast form of 16-bit stores, yr_apply_act_t), 2 whatever a.act says (a switch per value)
+template <int ACT, class T>
+__device__ __forceinline__ float dwl_act(float v, int act) {
+    if constexpr (ACT == 0) return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f);
+    else if constexpr (ACT == 1) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
+    else return yr_apply_act_t<T>(v, act);
+}
+
+constexpr int DWL_STAGE_U = 10;   // 16-byte loads in flight per lane while staging: the usual tile (up to 320 halo pixels) in ONE round trip
+
+template <class T, int ACT>
+__global__ __launch_bounds__(256) void dwl5_kernel(DwlArgs a) {
+    extern __shared__ unsigned dwl_tile[];   // [th + 4][32][twp]
+    const unsigned lin = yr_xcd_swizzle(blockIdx.x, a.nblocks);
+    // spatially adjacent tiles of one channel chunk are consecutive: their halos meet in one XCD's L2
+    const int tx = (int)(lin % (unsigned)a.ntx);
+    unsigned t = lin / (unsigned)a.ntx;
+    const int ty = (int)(t % (unsigned)a.nty);
+    t /= (unsigned)a.nty;
+    const int cc = (int)(t % (unsigned)a.ncc);
+    const int b = (int)(t / (unsigned)a.ncc);
+    const int x0 = tx * a.tw, y0 = ty * a.th;
+    const int rows_here = min(a.th, a.H - y0);
+    const int tid = (int)threadIdx.x;
+
+    // ---- compute-phase identity (needed first: the tap weights are fetched before the tile so that they are in flight too)
+    const int cp = tid & 31;
+    const int sb = tid >> 5;
+    const int strip = sb % a.nstrip, band = sb / a.nstrip;
+    const int cfirst = cc * 64 + cp * 2;
+    const bool chan_ok = cfirst < a.C8 * 8;
+    const int cl = chan_ok ? cfirst : 0;
+    dwl_f2 w[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) w[k] = *reinterpret_cast<const dwl_f2*>(a.w + (size_t)k * a.ld_w + cl);
+    const dwl_f2 sc = *reinterpret_cast<const dwl_f2*>(a.scale + cl);
+    const dwl_f2 sh = *reinterpret_cast<const dwl_f2*>(a.shift + cl);
+
+    // ---- stage the halo tile: thread = (channel vector cv, pixel slot); pixels walk the tile row-major in steps of 32
+    {
+        const int cv = tid & 7, slot = tid >> 3;
+        const int cols = a.tw + 4;
+        const int npix = (rows_here + 4) * cols;
+        const bool cv_ok = cc * 8 + cv < a.C8;
+        const T* base = reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * a.ld_in + (size_t)(cv_ok ? cc * 8 + cv : 0) * 8;
+        int r = slot / cols, j = slot - r * cols;
+        for (int p0 = slot; p0 < npix; p0 += 32 * a.stage_u) {
+            uint4 v[DWL_STAGE_U];
+            int woff[DWL_STAGE_U];
+            unsigned okm = 0u;
+#pragma unroll
+            for (int u = 0; u < DWL_STAGE_U; ++u) {
+                woff[u] = -1;
+                if (u < a.stage_u) {   // uniform
+                const int iy = y0 - a.pad_t + r, ix = x0 - a.pad_l + j;
+                const bool ok = cv_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && p0 + 32 * u < npix;
+                const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
+#ifdef YR_DW_EXPERIMENT
+                v[u] = a.dbg == 2 ? make_uint4(cy, cx, 0u, 0u) : *reinterpret_cast<const uint4*>(base + ((size_t)cy * a.W + cx) * a.ld_in);
+#else
+                v[u] = *reinterpret_cast<const uint4*>(base + ((size_t)cy * a.W + cx) * a.ld_in);
+#endif
+                okm |= ok ? 1u << u : 0u;
+                woff[u] = p0 + 32 * u < npix ? (r * 32 + cv * 4) * a.twp + j : -1;
+                j += a.step_j; r += a.step_r;          // 32 pixels on, row-major
+                if (j >= cols) { j -= cols; ++r; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < DWL_STAGE_U; ++u) {
+                if (u < a.stage_u && woff[u] >= 0) {
+                    const bool ok = (okm >> u) & 1u;
+                    unsigned* d = dwl_tile + woff[u];
+                    d[0] = ok ? v[u].x : 0u; d[a.twp] = ok ? v[u].y : 0u; d[2 * a.twp] = ok ? v[u].z : 0u; d[3 * a.twp] = ok ? v[u].w : 0u;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- slide down the band: input row rr of the band feeds output rows rr - ky
+    const int yb0 = band * a.band_rows;
+    int nrows = min(a.band_rows, rows_here - yb0);
+    if (band >= a.nband || !chan_ok) nrows = 0;
+#ifdef YR_DW_EXPERIMENT
+    if (a.dbg == 1) nrows = 0;
+#endif
+    const int nin = nrows > 0 ? nrows + 4 : 0;
+    const int xo = x0 + strip * 4;
+    T* orow = reinterpret_cast<T*>(a.out) + (((size_t)b * a.H + y0 + yb0) * a.W + xo) * a.ld_out + cl;
+    const unsigned* trow = dwl_tile + (yb0 * 32 + cp) * a.twp + strip * 4;
+    const int tpitch = 32 * a.twp;
+    dwl_f2 acc[5][4];
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[s][i] = (dwl_f2){0.f, 0.f};
+    for (int rr0 = 0; rr0 < nin; rr0 += 5) {
+#pragma unroll
+        for (int ph = 0; ph < 5; ++ph) {
+            const int rr = rr0 + ph;
+            if (rr < nin) {
+                const uint2* p = reinterpret_cast<const uint2*>(trow + rr * tpitch);
+                const uint2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                dwl_f2 col[8];
+                col[0] = dwl_widen<T>(q0.x); col[1] = dwl_widen<T>(q0.y);
+                col[2] = dwl_widen<T>(q1.x); col[3] = dwl_widen<T>(q1.y);
+                col[4] = dwl_widen<T>(q2.x); col[5] = dwl_widen<T>(q2.y);
+                col[6] = dwl_widen<T>(q3.x); col[7] = dwl_widen<T>(q3.y);
+#pragma unroll
+                for (int ky = 0; ky < 5; ++ky) {
+                    const int s = (ph - ky + 5) % 5;
+                    if (rr - ky >= 0 && rr - ky < nrows) {   // an output row of this band (the bands of a wave agree except at the tile's last rows)
+#pragma unroll
+                        for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[s][i] = __builtin_elementwise_fma(col[i + kx], w[ky * 5 + kx], acc[s][i]);
+                    }
+                }
+                constexpr int DONE[5] = {1, 2, 3, 4, 0};   // (ph + 1) % 5: the slot of output row rr - 4
+                const int sd = DONE[ph];
+                if (rr >= 4) {
+                    T* op = orow + (size_t)(rr - 4) * a.W * a.ld_out;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const dwl_f2 y = __builtin_elementwise_fma(acc[sd][i], sc, sh);
+                        if (xo + i < a.W) yr_st2<T>(op + (size_t)i * a.ld_out, dwl_act<ACT, T>(y.x, a.act), dwl_act<ACT, T>(y.y, a.act));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[sd][i] = (dwl_f2){0.f, 0.f};
+            }
+        }
+    }
+}
+
+// Tile geometry.  A workgroup's 256 lanes are 32 channel pairs x 8 (strip, band) slots: tw / 4 column strips x as many row
+// bands as still fit.  Among the tile widths, take the one with the least lane-time: workgroups x (rows a lane walks + the
+// 4 extra input rows of its band + its share of staging the halo tile), the tile height being what a third of a CU's LDS
+// holds.  40x40 -> 8 x 20 tiles in 4 bands of 5 rows, 20x20 -> 8 x 20, 13x13 -> 16 x 13 in 2 bands.
+static void dwl_geometry(int H, int W, DwlArgs* a) {
+    float best = 0.f;
+    for (int tw = 4; tw <= 32; tw += 4) {
+        const int nstrip = tw / 4, twp = tw + 6;
+        const int ntx = (W + tw - 1) / tw;
+        const int row_bytes = 32 * twp * 4;
+        int th = 48 * 1024 / row_bytes - 4;
+        if (th > H) th = H;
+        if (th < 4) th = 4;
+        const int nty = (H + th - 1) / th;
+        th = (H + nty - 1) / nty;
+        int nband = 8 / nstrip;
+        if (nband > th) nband = th;
+        const int band_rows = (th + nband - 1) / nband;
+        nband = (th + band_rows - 1) / band_rows;
+        const float cost = (float)(ntx * nty) * ((float)band_rows + 0.64f + 0.00375f * (float)((tw + 4) * (th + 4)));
+        if (best == 0.f || cost < best) {
+            best = cost;
+            a->ntx = ntx; a->tw = tw; a->twp = twp; a->nstrip = nstrip;
+            a->nty = nty; a->th = th; a->nband = nband; a->band_rows = band_rows;
+        }
+    }
+}
+
+template <class T>
+static int launch_dwl5_t(DwlArgs a, hipStream_t s) {
+    dwl_geometry(a.H, a.W, &a);
+    a.ncc = (a.C8 + 7) / 8;
+    a.step_r = 32 / (a.tw + 4); a.step_j = 32 % (a.tw + 4);
+    {
+        const int items = ((a.th + 4) * (a.tw + 4) + 31) / 32, rounds = (items + DWL_STAGE_U - 1) / DWL_STAGE_U;
+        a.stage_u = (items + rounds - 1) / rounds;
+    }
+    const long long blocks = (long long)a.B * a.ncc * a.nty * a.ntx;
+    YR_REQUIRE(blocks < (1ll << 31), "depthwise: grid too large");
+    a.nblocks = (unsigned)blocks;
+    a.dbg = getenv("YR_DWL_DBG") ? atoi(getenv("YR_DWL_DBG")) : 0;
+    const size_t lds = (size_t)(a.th + 4) * 32 * a.twp * 4;
+    static char nm[40];
+    static const int nm_len = snprintf(nm, sizeof(nm), "dwl5_kernel<%s>", yr_dtype_name(yr_elem<T>::dtype));
+    (void)nm_len;
+    yr_note_kernel(nm);
+    if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((dwl5_kernel<T, 0>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    else if (a.act == YR_ACT_SWISH) hipLaunchKernelGGL((dwl5_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((dwl5_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
+int yr_launch_depthwise_lds5(int dtype, const void* in, const float* w, const float* scale, const float* shift, void* out, int B, int H, int W,
+                             int C8, int ld_in, int ld_w, int ld_out, int pad_t, int pad_l, int act, hipStream_t s) {
+    DwlArgs a;
+    a.in = in; a.w = w; a.scale = scale; a.shift = shift; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.C8 = C8;
+    a.ld_in = ld_in; a.ld_w = ld_w; a.ld_out = ld_out;
+    a.pad_t = pad_t; a.pad_l = pad_l; a.act = act;
+    if (dtype == YR_BF16) return launch_dwl5_t<yr_bf16>(a, s);
+    if (dtype == YR_F16) return launch_dwl5_t<yr_f16>(a, s);
+    yr_set_error("depthwise (LDS form): 16-bit maps only");
+    return YR_ERR_ARG;
+}
