@@ -497,7 +497,7 @@ def test_policy_and_dtype_plumbing(dev):
                                          (3, 2, 27, 26, 128, 8), (5, 2, 14, 14, 256, 16),
                                          # channel-vector counts that do not divide 256 (several workgroups share a row):
                                          (3, 1, 40, 36, 40, 10), (5, 1, 20, 20, 816, 34), (5, 2, 21, 20, 1392, 58), (3, 1, 9, 7, 100, 6),
-                                         (3, 1, 13, 13, 1152, 48)])
+                                         (3, 1, 13, 13, 1152, 48), (5, 1, 40, 40, 136, 8), (5, 1, 26, 26, 100, 8), (5, 1, 70, 37, 64, 4)])
 def test_depthwise_se_form(dev, dt, k, s, h, w, c, r):
     """The squeeze of squeeze-excite as an epilogue of the depthwise conv (efficientnet.py:417 after :501-510): the SE
     form writes the same map as the plain op, bit for bit, plus per-workgroup channel sums; SE_FC (k = pixel count) on
@@ -534,12 +534,15 @@ def test_depthwise_se_form(dev, dt, k, s, h, w, c, r):
         torch.cuda.synchronize()
         return out
     plain = dw()
-    from yoloret_amd.compiler import dw_se_geometry
+    from yoloret_amd.compiler import dw_se_geometry, dwl_geometry, DW_LDS
     c4 = (c + V - 1) // V
     xt = 4 if s == 1 else 2
     rows = dw_se_geometry(ho * ((wo + xt - 1) // xt), c4)[2]
     if c4 <= 256 and 256 % c4 == 0:
         assert rows == (ho * ((wo + xt - 1) // xt) * c4 + 255) // 256
+    if DW_LDS and dt != 'f32' and k == 5 and s == 1 and c >= 64:     # the LDS-tiled form: one row per tile
+        ntx, nty = dwl_geometry(ho, wo)
+        rows = ntx * nty
     part = torch.full((b, rows, ldc), float('nan'), dtype=torch.float32, device=dev)
     fused = dw(part, rows)
     assert torch.equal(plain.view(torch.int16 if dt != 'f32' else torch.int32), fused.view(torch.int16 if dt != 'f32' else torch.int32))

@@ -367,6 +367,32 @@ def dw_se_geometry(strips, c4):
     return cw, (c4 + cw - 1) // cw, (strips + 256 // cw - 1) // (256 // cw)
 
 
+DW_LDS = os.environ.get('YOLORET_DW_LDS', '1') != '0'
+
+
+def dwl_geometry(h, w):
+    """== dwl_geometry() in depthwise_lds.hip (integer arithmetic, the same choice): (tiles along x, tiles along y) of the
+    LDS-tiled 5x5 stride-1 depthwise form; its squeeze-excite variant writes one row of channel sums per tile."""
+    best = None
+    for tw in range(4, 33, 4):
+        nstrip, twp = tw // 4, tw + 6
+        ntx = (w + tw - 1) // tw
+        th = max(4, min(h, 48 * 1024 // (32 * twp * 4) - 4))
+        nty = (h + th - 1) // th
+        th = (h + nty - 1) // nty
+        nband = min(8 // nstrip, th)
+        band_rows = (th + nband - 1) // nband
+        cost = ntx * nty * (8000 * band_rows + 5120 + 30 * (tw + 4) * (th + 4))
+        if best is None or cost < best[0]:
+            best = (cost, ntx, nty)
+    return best[1], best[2]
+
+
+def dw_uses_lds_form(d):
+    """launch_depthwise_t's choice (depthwise.hip): 16-bit 5x5 stride 1 with at least one 64-channel chunk."""
+    return DW_LDS and d.dtype != 0 and d.k == 5 and d.stride == 1 and d.cout >= 64
+
+
 def se_partials_from_depthwise(ops, bufs):
     """the squeeze of squeeze-excite (tf.reduce_mean over H, W; efficientnet.py:417) as an epilogue of
     the depthwise conv that produces the map.  The SE_FC op with the merged mean re-reads the whole map for it (one
@@ -386,6 +412,9 @@ def se_partials_from_depthwise(ops, bufs):
         c4 = (d.cout + v - 1) // v
         xt = 4 if d.stride == 1 else 2
         rows = dw_se_geometry(d.h * ((d.w + xt - 1) // xt), c4)[2]
+        if dw_uses_lds_form(d):
+            ntx, nty = dwl_geometry(d.h, d.w)
+            rows = ntx * nty
         part = Buf(len(bufs), rows, 1, d.cout, round_up(d.cout, v), name=d.name + ':se_sums', dtype=0)
         bufs.append(part)
         d.gate, d.se_reduced = part, rows

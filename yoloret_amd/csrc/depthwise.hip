@@ -282,17 +282,10 @@ static int launch_depthwise_t(const yr_op& op, int batch, hipStream_t s) {
     a.pad_l = (ptw > 0 ? ptw : 0) / 2;
     a.act = op.act;
     a.part = nullptr; a.ld_part = 0; a.cw = 1; a.ncb = 1;
-    if (op.gate) {   // SE form: `gate` is an OUTPUT here - float32 [B][workgroups per image][gate_ld] channel sums
-        YR_REQUIRE(op.gate_ld % 4 == 0 && op.gate_ld >= yr_round_up(in.c, V) && ((uintptr_t)op.gate % 16) == 0, "depthwise: bad SE partial-sum buffer");
-        a.part = const_cast<float*>(op.gate); a.ld_part = op.gate_ld;
-        const int rows = op.se_reduced;     // rows per image the buffer was sized for
-        if (op.k == 3 && op.stride == 1) return launch_dw_se<3, 1, 4, T>(a, rows, s);
-        if (op.k == 3 && op.stride == 2) return launch_dw_se<3, 2, 2, T>(a, rows, s);
-        if (op.k == 5 && op.stride == 1) return launch_dw_se<5, 1, 4, T>(a, rows, s);
-        return launch_dw_se<5, 2, 2, T>(a, rows, s);
-    }
+    if (op.gate) YR_REQUIRE(op.gate_ld % 4 == 0 && op.gate_ld >= yr_round_up(in.c, V) && ((uintptr_t)op.gate % 16) == 0, "depthwise: bad SE partial-sum buffer");
     // 16-bit 5x5 stride 1 on maps with at least one 64-channel chunk: the LDS-tiled form (depthwise_lds.hip, bit-identical
-    // results; YOLORET_DW_LDS=0 keeps this kernel for A/B runs)
+    // maps; its SE rows are its tiles - compiler.se_partials_from_depthwise sizes the buffer for whichever form
+    // YOLORET_DW_LDS selects, 0 keeps this kernel for A/B runs)
     if constexpr (sizeof(T) == 2) {
 #ifdef YR_DW_EXPERIMENT
         const bool lds_form = !(getenv("YOLORET_DW_LDS") && atoi(getenv("YOLORET_DW_LDS")) == 0);   // re-read per launch
@@ -301,7 +294,15 @@ static int launch_depthwise_t(const yr_op& op, int batch, hipStream_t s) {
 #endif
         if (lds_form && op.k == 5 && op.stride == 1 && in.c >= 64)
             return yr_launch_depthwise_lds5(op.dtype, in.ptr, op.wgt, op.scale, op.shift, op.out, batch, in.h, in.w, a.C4, a.ld_in, a.ld_w, a.ld_out,
-                                            a.pad_t, a.pad_l, a.act, s);
+                                            a.pad_t, a.pad_l, a.act, const_cast<float*>(op.gate), op.gate_ld, op.se_reduced, s);
+    }
+    if (op.gate) {   // SE form: `gate` is an OUTPUT here - float32 [B][workgroups per image][gate_ld] channel sums
+        a.part = const_cast<float*>(op.gate); a.ld_part = op.gate_ld;
+        const int rows = op.se_reduced;     // rows per image the buffer was sized for
+        if (op.k == 3 && op.stride == 1) return launch_dw_se<3, 1, 4, T>(a, rows, s);
+        if (op.k == 3 && op.stride == 2) return launch_dw_se<3, 2, 2, T>(a, rows, s);
+        if (op.k == 5 && op.stride == 1) return launch_dw_se<5, 1, 4, T>(a, rows, s);
+        return launch_dw_se<5, 2, 2, T>(a, rows, s);
     }
 #ifdef YR_DW_EXPERIMENT   // tools/dw5_probe.py: patch shapes of the 5x5 stride-1 form (XT*10 + YT in YR_DW_FORCE)
     if (op.k == 5 && op.stride == 1) {

@@ -32,6 +32,8 @@ struct DwlArgs {
     int step_r, step_j;  // 32 = step_r * (tw + 4) + step_j
     int stage_u;         // 16-byte loads per lane and staging round (the halo tile's loads spread evenly over the rounds)
     unsigned nblocks;
+    float* part;         // squeeze-excite form: [B][ntx * nty][ld_part] float32 channel sums of what each tile stored, or null
+    int ld_part;
     int dbg;             // YR_DW_EXPERIMENT builds: 1 = no compute phase, 2 = no global loads while staging
 };
 
@@ -53,7 +55,7 @@ __device__ __forceinline__ float dwl_act(float v, int act) {
 
 constexpr int DWL_STAGE_U = 10;   // 16-byte loads in flight per lane while staging: the usual tile (up to 320 halo pixels) in ONE round trip
 
-template <class T, int ACT>
+template <class T, int ACT, bool SE>
 __global__ __launch_bounds__(256) void dwl5_kernel(DwlArgs a) {
     extern __shared__ unsigned dwl_tile[];   // [th + 4][32][twp]
     const unsigned lin = yr_xcd_swizzle(blockIdx.x, a.nblocks);
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(256) void dwl5_kernel(DwlArgs a) {
     T* orow = reinterpret_cast<T*>(a.out) + (((size_t)b * a.H + y0 + yb0) * a.W + xo) * a.ld_out + cl;
     const unsigned* trow = dwl_tile + (yb0 * 32 + cp) * a.twp + strip * 4;
     const int tpitch = 32 * a.twp;
+    dwl_f2 psum = (dwl_f2){0.f, 0.f};   // SE: what this lane stored, per channel (rounded values, fixed order)
     dwl_f2 acc[5][4];
 #pragma unroll
     for (int s = 0; s < 5; ++s)
@@ -169,12 +172,30 @@ __global__ __launch_bounds__(256) void dwl5_kernel(DwlArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const dwl_f2 y = __builtin_elementwise_fma(acc[sd][i], sc, sh);
-                        if (xo + i < a.W) yr_st2<T>(op + (size_t)i * a.ld_out, dwl_act<ACT, T>(y.x, a.act), dwl_act<ACT, T>(y.y, a.act));
+                        if (xo + i < a.W) {
+                            typedef T t2 __attribute__((ext_vector_type(2)));
+                            const t2 r = __builtin_convertvector((dwl_f2){dwl_act<ACT, T>(y.x, a.act), dwl_act<ACT, T>(y.y, a.act)}, t2);
+                            *reinterpret_cast<t2*>(op + (size_t)i * a.ld_out) = r;
+                            if constexpr (SE) psum += __builtin_convertvector(r, dwl_f2);
+                        }
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[sd][i] = (dwl_f2){0.f, 0.f};
             }
+        }
+    }
+    if constexpr (SE) {
+        // the 8 (strip, band) slots of a channel pair are added in slot order by the first wave: one row of `part` per tile
+        dwl_f2* red = reinterpret_cast<dwl_f2*>(dwl_tile);
+        __syncthreads();   // every wave is done with the tile
+        red[tid] = psum;
+        __syncthreads();
+        if (tid < 32 && chan_ok) {
+            dwl_f2 sum = red[tid];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) sum += red[k * 32 + tid];
+            *reinterpret_cast<dwl_f2*>(a.part + ((size_t)b * (a.ntx * a.nty) + ty * a.ntx + tx) * a.ld_part + cfirst) = sum;
         }
     }
 }
@@ -184,7 +205,7 @@ __global__ __launch_bounds__(256) void dwl5_kernel(DwlArgs a) {
 // 4 extra input rows of its band + its share of staging the halo tile), the tile height being what a third of a CU's LDS
 // holds.  40x40 -> 8 x 20 tiles in 4 bands of 5 rows, 20x20 -> 8 x 20, 13x13 -> 16 x 13 in 2 bands.
 static void dwl_geometry(int H, int W, DwlArgs* a) {
-    float best = 0.f;
+    long long best = 0;
     for (int tw = 4; tw <= 32; tw += 4) {
         const int nstrip = tw / 4, twp = tw + 6;
         const int ntx = (W + tw - 1) / tw;
@@ -198,8 +219,9 @@ static void dwl_geometry(int H, int W, DwlArgs* a) {
         if (nband > th) nband = th;
         const int band_rows = (th + nband - 1) / nband;
         nband = (th + band_rows - 1) / band_rows;
-        const float cost = (float)(ntx * nty) * ((float)band_rows + 0.64f + 0.00375f * (float)((tw + 4) * (th + 4)));
-        if (best == 0.f || cost < best) {
+        // in 1/8000 of the time of one output row of a lane (integers: compiler.dwl_geometry must pick the same tile)
+        const long long cost = (long long)(ntx * nty) * (8000 * band_rows + 5120 + 30 * (tw + 4) * (th + 4));
+        if (best == 0 || cost < best) {
             best = cost;
             a->ntx = ntx; a->tw = tw; a->twp = twp; a->nstrip = nstrip;
             a->nty = nty; a->th = th; a->nband = nband; a->band_rows = band_rows;
@@ -207,9 +229,10 @@ static void dwl_geometry(int H, int W, DwlArgs* a) {
     }
 }
 
-template <class T>
-static int launch_dwl5_t(DwlArgs a, hipStream_t s) {
+template <class T, bool SE>
+static int launch_dwl5_t(DwlArgs a, int expect_rows, hipStream_t s) {
     dwl_geometry(a.H, a.W, &a);
+    if (SE) YR_REQUIRE(a.ntx * a.nty == expect_rows, "depthwise (LDS form): the SE partial-sum buffer must hold %d rows per image (has %d)", a.ntx * a.nty, expect_rows);
     a.ncc = (a.C8 + 7) / 8;
     a.step_r = 32 / (a.tw + 4); a.step_j = 32 % (a.tw + 4);
     {
@@ -222,25 +245,27 @@ static int launch_dwl5_t(DwlArgs a, hipStream_t s) {
     a.dbg = getenv("YR_DWL_DBG") ? atoi(getenv("YR_DWL_DBG")) : 0;
     const size_t lds = (size_t)(a.th + 4) * 32 * a.twp * 4;
     static char nm[40];
-    static const int nm_len = snprintf(nm, sizeof(nm), "dwl5_kernel<%s>", yr_dtype_name(yr_elem<T>::dtype));
+    static const int nm_len = snprintf(nm, sizeof(nm), "dwl5_kernel<%s,%d>", yr_dtype_name(yr_elem<T>::dtype), (int)SE);
     (void)nm_len;
     yr_note_kernel(nm);
-    if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((dwl5_kernel<T, 0>), dim3((unsigned)blocks), dim3(256), lds, s, a);
-    else if (a.act == YR_ACT_SWISH) hipLaunchKernelGGL((dwl5_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((dwl5_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((dwl5_kernel<T, 0, SE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    else if (a.act == YR_ACT_SWISH) hipLaunchKernelGGL((dwl5_kernel<T, 1, SE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((dwl5_kernel<T, 2, SE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
 }
 
 int yr_launch_depthwise_lds5(int dtype, const void* in, const float* w, const float* scale, const float* shift, void* out, int B, int H, int W,
-                             int C8, int ld_in, int ld_w, int ld_out, int pad_t, int pad_l, int act, hipStream_t s) {
+                             int C8, int ld_in, int ld_w, int ld_out, int pad_t, int pad_l, int act, float* part, int ld_part, int part_rows,
+                             hipStream_t s) {
     DwlArgs a;
     a.in = in; a.w = w; a.scale = scale; a.shift = shift; a.out = out;
     a.B = B; a.H = H; a.W = W; a.C8 = C8;
     a.ld_in = ld_in; a.ld_w = ld_w; a.ld_out = ld_out;
     a.pad_t = pad_t; a.pad_l = pad_l; a.act = act;
-    if (dtype == YR_BF16) return launch_dwl5_t<yr_bf16>(a, s);
-    if (dtype == YR_F16) return launch_dwl5_t<yr_f16>(a, s);
+    a.part = part; a.ld_part = ld_part;
+    if (dtype == YR_BF16) return part ? launch_dwl5_t<yr_bf16, true>(a, part_rows, s) : launch_dwl5_t<yr_bf16, false>(a, 0, s);
+    if (dtype == YR_F16) return part ? launch_dwl5_t<yr_f16, true>(a, part_rows, s) : launch_dwl5_t<yr_f16, false>(a, 0, s);
     yr_set_error("depthwise (LDS form): 16-bit maps only");
     return YR_ERR_ARG;
 }
