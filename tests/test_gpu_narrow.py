@@ -170,12 +170,14 @@ def test_pointwise16(dev, dt, case):
 
 
 @pytest.mark.parametrize('dt', DTYPES)
-@pytest.mark.parametrize('ci', [0, 3, 6, 9, 10, 15, 17])
+@pytest.mark.parametrize('ci', [0, 3, 4, 6, 9, 10, 14, 15, 17])
 def test_pointwise16_tile_shapes_are_bit_identical(dev, dt, ci):
-    """Every tile shape runs the same MFMA sequence per output: the autotuner may swap them freely."""
+    """Every tile shape runs the same MFMA sequence per output: the autotuner may swap them freely.  Shapes 1-10 the direct
+    kernel, 11-14 the walking small-K form, 15-18 the LDS-tiled form (single identity source with whole octets - cases 3, 4,
+    9 (SE-gated), 14; the others fall back to the direct kernel of the same tile)."""
     h, w, segs, cout, act, bn, residual, gate, out_f32, dense, pool, pre = PW16[ci]
     outs = []
-    n = 10
+    n = 18
     for cfg in range(0, n + 1):
         rng = np.random.default_rng(zlib.crc32(str(PW16[ci]).encode()))
         outs.append(run_pointwise16(dev, dt, rng, 2, h, w, segs, cout, act, bn, residual, gate, out_f32, dense, pool, pre, cfg=cfg))

@@ -225,6 +225,25 @@ __device__ __forceinline__ void pwh_finish_oct(const PwArgs& a, const f32x4& lo,
     }
 }
 
+// BatchNorm scale / shift of couts n..n+7 (n a multiple of 8).  Whole octets inside N of 16-byte aligned arrays: two
+// 16-byte loads each - as per-element loads they were 16 of a wave's 62 load instructions on a 5-chunk GEMM; couts
+// beyond N re-read the last one (their results are never stored).
+__device__ __forceinline__ void pwh_load_bn(const PwArgs& a, int n, float (&sc)[8], float (&sh)[8]) {
+    if (n + 8 <= a.N && a.scale && a.shift && (((uintptr_t)a.scale | (uintptr_t)a.shift) & 15) == 0) {
+        const float4 s0 = *reinterpret_cast<const float4*>(a.scale + n), s1 = *reinterpret_cast<const float4*>(a.scale + n + 4);
+        const float4 h0 = *reinterpret_cast<const float4*>(a.shift + n), h1 = *reinterpret_cast<const float4*>(a.shift + n + 4);
+        sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+        sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int nc = n + r < a.N ? n + r : a.N - 1;
+        sc[r] = a.scale ? a.scale[nc] : 1.f;
+        sh[r] = a.shift ? a.shift[nc] : 0.f;
+    }
+}
+
 // PT: 16-pixel tiles per wave, CP: 32-cout tile PAIRS per wave; 4 waves along the pixels: BM = 64*PT, BN = 32*CP.
 template <class T, int PT, int CP, int D, int MODE>
 __global__ __launch_bounds__(256) void pwh_kernel(PwArgs a) {
@@ -321,12 +340,7 @@ __global__ __launch_bounds__(256) void pwh_kernel(PwArgs a) {
     for (int c = 0; c < CP; ++c) {
         const int n = n0 + c * 32 + g * 8;
         float sc[8], sh[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int nc = n + r < a.N ? n + r : a.N - 1;
-            sc[r] = a.scale ? a.scale[nc] : 1.f;
-            sh[r] = a.shift ? a.shift[nc] : 0.f;
-        }
+        pwh_load_bn(a, n, sc, sh);
 #pragma unroll
         for (int p = 0; p < PT; ++p) pwh_finish_oct<T>(a, acc[2 * c][p], acc[2 * c + 1][p], sc, sh, m0 + p * 16 + li, n, li);
     }
@@ -366,14 +380,7 @@ __global__ __launch_bounds__(256) void pwhp_kernel(PwArgs a, int tiles_per_wg) {
     }
     float sc[CP][8], sh[CP][8];
 #pragma unroll
-    for (int c = 0; c < CP; ++c)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int n = n0 + c * 32 + g * 8 + r;
-            const int nc = n < a.N ? n : a.N - 1;
-            sc[c][r] = a.scale ? a.scale[nc] : 1.f;
-            sh[c][r] = a.shift ? a.shift[nc] : 0.f;
-        }
+    for (int c = 0; c < CP; ++c) pwh_load_bn(a, n0 + c * 32 + g * 8, sc[c], sh[c]);
 
     struct Tile {
         pwh_u4 x[NCH][PT];
@@ -427,6 +434,134 @@ __global__ __launch_bounds__(256) void pwhp_kernel(PwArgs a, int tiles_per_wg) {
     }
 }
 
+// LDS-tiled form (one identity source, whole channel octets, plain output rows): a workgroup computes up to 128 pixels x 128
+// couts.  The direct kernel above re-fetches every operand fragment per wave - with PT = 4, CP = 1 six 1 KB loads per
+// eight MFMAs - and the mid-size GEMMs of the unfused EfficientNet stages ([13k..51k pixels] x [136..1392] x [136..1392])
+// ran at 1.0-1.7 TB/s whatever the tile shape (tools/pwh_probe.py): bound by the L1/L2 -> register path, not by HBM or
+// the matrix pipe.  Here both operands of a 32-deep chunk are fetched once per workgroup (four 16-byte loads per thread),
+// parked in LDS in FRAGMENT order - tile of 16 rows = 64 lanes x 16 bytes, lane (k group g, row i) at slot 16g + i, so
+// the store of a wave's loads and every ds_read_b128 are linear, conflict-free - and each wave multiplies a 64 x 64
+// sub-tile (4 + 4 fragment reads per 16 MFMAs).  Two LDS buffers, one barrier per chunk, the next chunk's global loads in
+// flight during the MFMAs.  Same MFMA sequence and operand mapping per output as pwh_kernel: bit-identical results.
+// PT x CT: 16 x 16 MFMA tiles per wave (pixels x couts); 2 x 2 waves: BM = 32 PT, BN = 32 CT.
+template <class T, int PT, int CT, bool GATE>
+__global__ __launch_bounds__(256, 3) void pwhl_kernel(PwArgs a) {
+    constexpr int BM = 32 * PT, BN = 32 * CT;
+    constexpr int NWH = BN / 64, NXH = BM / 64;     // rows per loader thread
+    __shared__ pwh_u4 frag[2][2 * CT + 2 * PT][64];   // [buffer][16-row tile: weights first, then pixels][fragment lane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int wm = wave & 1, wn = wave >> 1;
+    const unsigned ntn = (a.N + BN - 1) / BN;
+    const unsigned L = yr_xcd_swizzle(blockIdx.x, gridDim.x);
+    const int m0 = (int)(L / ntn) * BM, n0 = (int)(L % ntn) * BN;
+    const int kp = a.S.kp, nch = (kp + 31) >> 5;
+
+    // loader: thread (row r = tid >> 2, k group lg = tid & 3) fetches rows r, r + 64 .. of both operands
+    const int lr = tid >> 2, lg = tid & 3;
+    const T* wrow[NWH];
+    const T* xrow[NXH];
+    const float* grow[NXH];   // GATE: the SE gate row of the pixel's image (float32), multiplied in before the operand is parked
+#pragma unroll
+    for (int h = 0; h < NWH; ++h) {
+        const int rho = lr + 64 * h, tile = rho >> 4, i = rho & 15;
+        const int n = n0 + (tile >> 1) * 32 + 8 * (i >> 2) + 4 * (tile & 1) + (i & 3);   // MFMA row i of tile <-> cout: as in pwh_kernel
+        wrow[h] = reinterpret_cast<const T*>(a.wt) + (size_t)(n < a.N ? n : 0) * kp;
+    }
+#pragma unroll
+    for (int h = 0; h < NXH; ++h) {
+        const int m = m0 + lr + 64 * h;
+        const int ml = m < a.M ? m : a.M - 1;
+        xrow[h] = reinterpret_cast<const T*>(a.S.s[0].ptr) + (size_t)ml * a.S.s[0].ld;
+        grow[h] = GATE ? a.gate + (size_t)(ml / (a.H * a.W)) * a.gate_ld : nullptr;
+    }
+    const int slot = (lr >> 4) * 64 + lg * 16 + (lr & 15);   // + 256 per further 64 rows
+    struct Stage { pwh_u4 w[NWH], x[NXH]; float4 g0[GATE ? NXH : 1], g1[GATE ? NXH : 1]; };
+    auto fetch = [&](int chunk, Stage& R) __attribute__((always_inline)) {
+        const int kraw = chunk * 32 + lg * 8;
+        const int k = kraw < kp ? kraw : kp - 8;   // the k tail of the weights meets zeroed activations
+#pragma unroll
+        for (int h = 0; h < NWH; ++h) R.w[h] = *reinterpret_cast<const pwh_u4*>(wrow[h] + k);
+#pragma unroll
+        for (int h = 0; h < NXH; ++h) {
+            R.x[h] = *reinterpret_cast<const pwh_u4*>(xrow[h] + k);
+            if (kraw >= kp) R.x[h] = (pwh_u4){0u, 0u, 0u, 0u};
+            if constexpr (GATE) {
+                R.g0[h] = *reinterpret_cast<const float4*>(grow[h] + k);
+                R.g1[h] = *reinterpret_cast<const float4*>(grow[h] + k + 4);
+            }
+        }
+    };
+    auto park = [&](int buf, const Stage& R) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < NWH; ++h) (&frag[buf][0][0])[slot + 256 * h] = R.w[h];
+#pragma unroll
+        for (int h = 0; h < NXH; ++h) (&frag[buf][2 * CT][0])[slot + 256 * h] = GATE ? pwh_finish<2, T>(R.x[h], R.g0[h], R.g1[h], 8) : R.x[h];
+    };
+
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int p = 0; p < PT; ++p) acc[t][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto multiply = [&](int buf) __attribute__((always_inline)) {
+        pwh_u4 w[CT], x[PT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) w[t] = frag[buf][wn * CT + t][lane];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) x[p] = frag[buf][2 * CT + wm * PT + p][lane];
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) acc[t][p] = pwh_mfma<T>(w[t], x[p], acc[t][p]);
+    };
+
+    // chunk c is multiplied out of LDS buffer c & 1 while chunk c + 1 is in flight into registers.  One barrier per chunk:
+    // the buffer parked into during chunk c is the one chunk c - 1 was read from, and everyone has passed the barrier
+    // since.  (A second register stage - chunk c + 2 in flight as well - costs 10 VGPRs = one wave per SIMD on the 128 x 64
+    // tile and measured 10-20 % SLOWER: waves in flight hide more latency than loads in flight per wave.)
+    Stage R;
+    fetch(0, R);
+    park(0, R);
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        if (c + 1 < nch) fetch(c + 1, R);   // (uniform)
+        multiply(c & 1);
+        if (c + 1 < nch) park((c & 1) ^ 1, R);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int c = 0; c < CT / 2; ++c) {
+        const int n = n0 + wn * 16 * CT + c * 32 + g * 8;
+        float sc[8], sh[8];
+        pwh_load_bn(a, n, sc, sh);
+#pragma unroll
+        for (int p = 0; p < PT; ++p) pwh_finish_oct<T>(a, acc[2 * c][p], acc[2 * c + 1][p], sc, sh, m0 + wm * 16 * PT + p * 16 + li, n, li);
+    }
+}
+
+template <class T, int PT, int CP>
+static int launch_h(const PwArgs& a, hipStream_t s);
+
+template <class T, int PT, int CT>
+static int launch_lds(const PwArgs& a, hipStream_t s) {
+    const bool plain = a.S.n == 1 && a.S.s[0].xform == YR_X_IDENTITY && !a.pool && !a.dw_w && (a.S.s[0].c & 7) == 0 &&
+                       (!a.gate || ((a.gate_ld & 3) == 0 && a.gate_ld >= a.S.kp));
+    if (!plain) return launch_h<T, PT / 2, CT>(a, s);   // the direct kernel of the same tile shape
+    constexpr int BM = 32 * PT, BN = 32 * CT;
+    dim3 grid((unsigned)((a.M + BM - 1) / BM) * (unsigned)((a.N + BN - 1) / BN));
+    static char nm[2][40];
+    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "pwhl_kernel<%s,%d,%d,0>", yr_dtype_name(yr_elem<T>::dtype), PT, CT) +
+                              snprintf(nm[1], sizeof(nm[1]), "pwhl_kernel<%s,%d,%d,1>", yr_dtype_name(yr_elem<T>::dtype), PT, CT);
+    (void)nm_len;
+    yr_note_kernel(nm[a.gate ? 1 : 0]);
+    if (a.gate) hipLaunchKernelGGL((pwhl_kernel<T, PT, CT, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pwhl_kernel<T, PT, CT, false>), grid, dim3(256), 0, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
 template <class T, int PT, int CP, int NCH>
 static int launch_hp(const PwArgs& a, int mode, hipStream_t s) {
     constexpr int BM = 64 * PT, BN = 32 * CP;
@@ -473,7 +608,7 @@ static const PwhCfg pwh_cfgs[] = {{64, 32}, {64, 64}, {64, 96}, {64, 128},
 constexpr int PWH_NCFG = sizeof(pwh_cfgs) / sizeof(pwh_cfgs[0]);
 // + the small-K walking form (pwhp_kernel) in four shapes; where it does not apply (more than 128 k, gathered sources)
 // these indices run the plain kernel of the same tile shape, so every index is valid for every op
-constexpr int PWH_NWALK = 4;
+constexpr int PWH_NWALK = 8;   // ... and the LDS-tiled form (pwhl_kernel) in four shapes as the last indices
 int yr_pwh_num_cfgs() { return PWH_NCFG + PWH_NWALK; }
 
 template <class T, int PT, int CP>
@@ -506,6 +641,10 @@ static int launch_h_cfg(int cfg, const PwArgs& a, hipStream_t s) {
         case 11: return launch_walk<T, 2, 1>(a, s);
         case 12: return launch_walk<T, 1, 2>(a, s);
         case 13: return launch_walk<T, 2, 2>(a, s);
+        case 14: return launch_lds<T, 4, 4>(a, s);
+        case 15: return launch_lds<T, 2, 4>(a, s);
+        case 16: return launch_lds<T, 4, 2>(a, s);
+        case 17: return launch_lds<T, 2, 2>(a, s);
         default: yr_set_error("pointwise: 16-bit tile shape %d out of range", cfg); return YR_ERR_ARG;
     }
 }
