@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void pwhp_kernel(PwArgs a, int tiles_per_wg) {
     }
 }
 
-// LDS-tiled form (one identity source, whole channel octets, plain output rows): a workgroup computes up to 128 pixels x 128
+// LDS-tiled form: a workgroup computes up to 128 pixels x 128
 // couts.  The direct kernel above re-fetches every operand fragment per wave - with PT = 4, CP = 1 six 1 KB loads per
 // eight MFMAs - and the mid-size GEMMs of the unfused EfficientNet stages ([13k..51k pixels] x [136..1392] x [136..1392])
 // ran at 1.0-1.7 TB/s whatever the tile shape (tools/pwh_probe.py): bound by the L1/L2 -> register path, not by HBM or
@@ -443,8 +443,10 @@ __global__ __launch_bounds__(256) void pwhp_kernel(PwArgs a, int tiles_per_wg) {
 // the store of a wave's loads and every ds_read_b128 are linear, conflict-free - and each wave multiplies a 64 x 64
 // sub-tile (4 + 4 fragment reads per 16 MFMAs).  Two LDS buffers, one barrier per chunk, the next chunk's global loads in
 // flight during the MFMAs.  Same MFMA sequence and operand mapping per output as pwh_kernel: bit-identical results.
-// PT x CT: 16 x 16 MFMA tiles per wave (pixels x couts); 2 x 2 waves: BM = 32 PT, BN = 32 CT.
-template <class T, int PT, int CT, bool GATE>
+// PT x CT: 16 x 16 MFMA tiles per wave (pixels x couts); 2 x 2 waves: BM = 32 PT, BN = 32 CT.  MODE as in PwhRow: the
+// pixel operand goes through the same row object as in pwh_kernel (gathers, pooled sources, SE gate and pad masking
+// included) - only WHO fetches an octet differs: loader thread (row tid >> 2, k group tid & 3) instead of MFMA lane.
+template <class T, int PT, int CT, int MODE, bool POOLS>
 __global__ __launch_bounds__(256, 3) void pwhl_kernel(PwArgs a) {
     constexpr int BM = 32 * PT, BN = 32 * CT;
     constexpr int NWH = BN / 64, NXH = BM / 64;     // rows per loader thread
@@ -460,8 +462,7 @@ __global__ __launch_bounds__(256, 3) void pwhl_kernel(PwArgs a) {
     // loader: thread (row r = tid >> 2, k group lg = tid & 3) fetches rows r, r + 64 .. of both operands
     const int lr = tid >> 2, lg = tid & 3;
     const T* wrow[NWH];
-    const T* xrow[NXH];
-    const float* grow[NXH];   // GATE: the SE gate row of the pixel's image (float32), multiplied in before the operand is parked
+    PwhRow<MODE, T> xrow[NXH];
 #pragma unroll
     for (int h = 0; h < NWH; ++h) {
         const int rho = lr + 64 * h, tile = rho >> 4, i = rho & 15;
@@ -469,34 +470,31 @@ __global__ __launch_bounds__(256, 3) void pwhl_kernel(PwArgs a) {
         wrow[h] = reinterpret_cast<const T*>(a.wt) + (size_t)(n < a.N ? n : 0) * kp;
     }
 #pragma unroll
-    for (int h = 0; h < NXH; ++h) {
-        const int m = m0 + lr + 64 * h;
-        const int ml = m < a.M ? m : a.M - 1;
-        xrow[h] = reinterpret_cast<const T*>(a.S.s[0].ptr) + (size_t)ml * a.S.s[0].ld;
-        grow[h] = GATE ? a.gate + (size_t)(ml / (a.H * a.W)) * a.gate_ld : nullptr;
-    }
+    for (int h = 0; h < NXH; ++h) xrow[h].init(a, m0 + lr + 64 * h);
     const int slot = (lr >> 4) * 64 + lg * 16 + (lr & 15);   // + 256 per further 64 rows
-    struct Stage { pwh_u4 w[NWH], x[NXH]; float4 g0[GATE ? NXH : 1], g1[GATE ? NXH : 1]; };
+    // uniform: most layers have whole octets and whole 32-deep chunks only, and then nothing needs masking
+    const bool need_mask = MODE != 1 || (a.S.s[0].c & 7) != 0 || (kp & 31) != 0;
+    struct Stage {
+        pwh_u4 w[NWH], x[NXH];
+        float4 g0[MODE == 2 ? NXH : 1], g1[MODE == 2 ? NXH : 1];
+        int cv[NXH];
+    };
     auto fetch = [&](int chunk, Stage& R) __attribute__((always_inline)) {
         const int kraw = chunk * 32 + lg * 8;
         const int k = kraw < kp ? kraw : kp - 8;   // the k tail of the weights meets zeroed activations
 #pragma unroll
         for (int h = 0; h < NWH; ++h) R.w[h] = *reinterpret_cast<const pwh_u4*>(wrow[h] + k);
 #pragma unroll
-        for (int h = 0; h < NXH; ++h) {
-            R.x[h] = *reinterpret_cast<const pwh_u4*>(xrow[h] + k);
-            if (kraw >= kp) R.x[h] = (pwh_u4){0u, 0u, 0u, 0u};
-            if constexpr (GATE) {
-                R.g0[h] = *reinterpret_cast<const float4*>(grow[h] + k);
-                R.g1[h] = *reinterpret_cast<const float4*>(grow[h] + k + 4);
-            }
-        }
+        for (int h = 0; h < NXH; ++h)
+            xrow[h].template issue<POOLS>(a, kraw, kp, R.x[h], R.g0[MODE == 2 ? h : 0], R.g1[MODE == 2 ? h : 0], R.cv[h]);
     };
     auto park = [&](int buf, const Stage& R) __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < NWH; ++h) (&frag[buf][0][0])[slot + 256 * h] = R.w[h];
 #pragma unroll
-        for (int h = 0; h < NXH; ++h) (&frag[buf][2 * CT][0])[slot + 256 * h] = GATE ? pwh_finish<2, T>(R.x[h], R.g0[h], R.g1[h], 8) : R.x[h];
+        for (int h = 0; h < NXH; ++h)
+            (&frag[buf][2 * CT][0])[slot + 256 * h] =
+                need_mask ? pwh_finish<MODE, T>(R.x[h], R.g0[MODE == 2 ? h : 0], R.g1[MODE == 2 ? h : 0], R.cv[h]) : R.x[h];
     };
 
     f32x4 acc[CT][PT];
@@ -546,18 +544,23 @@ static int launch_h(const PwArgs& a, hipStream_t s);
 
 template <class T, int PT, int CT>
 static int launch_lds(const PwArgs& a, hipStream_t s) {
-    const bool plain = a.S.n == 1 && a.S.s[0].xform == YR_X_IDENTITY && !a.pool && !a.dw_w && (a.S.s[0].c & 7) == 0 &&
-                       (!a.gate || ((a.gate_ld & 3) == 0 && a.gate_ld >= a.S.kp));
-    if (!plain) return launch_h<T, PT / 2, CT>(a, s);   // the direct kernel of the same tile shape
+    if (a.dw_w) return launch_h<T, PT / 2, CT>(a, s);   // (float32 plans only) the direct kernel of the same tile shape
     constexpr int BM = 32 * PT, BN = 32 * CT;
+    const int mode = (a.S.n == 1 && a.S.s[0].xform == YR_X_IDENTITY) ? (a.gate ? 2 : 1) : 0;
+    if (mode == 0 && a.gate) { yr_set_error("pointwise: an SE gate needs one identity source"); return YR_ERR_ARG; }
+    bool pooled = false;
+    for (int i = 0; i < YR_MAX_SRC; ++i) pooled |= a.S.s[i].xform == YR_X_MAXPOOL2 || a.S.s[i].xform == YR_X_MAXPOOL4;
     dim3 grid((unsigned)((a.M + BM - 1) / BM) * (unsigned)((a.N + BN - 1) / BN));
-    static char nm[2][40];
+    static char nm[3][40];
     static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "pwhl_kernel<%s,%d,%d,0>", yr_dtype_name(yr_elem<T>::dtype), PT, CT) +
-                              snprintf(nm[1], sizeof(nm[1]), "pwhl_kernel<%s,%d,%d,1>", yr_dtype_name(yr_elem<T>::dtype), PT, CT);
+                              snprintf(nm[1], sizeof(nm[1]), "pwhl_kernel<%s,%d,%d,1>", yr_dtype_name(yr_elem<T>::dtype), PT, CT) +
+                              snprintf(nm[2], sizeof(nm[2]), "pwhl_kernel<%s,%d,%d,2>", yr_dtype_name(yr_elem<T>::dtype), PT, CT);
     (void)nm_len;
-    yr_note_kernel(nm[a.gate ? 1 : 0]);
-    if (a.gate) hipLaunchKernelGGL((pwhl_kernel<T, PT, CT, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((pwhl_kernel<T, PT, CT, false>), grid, dim3(256), 0, s, a);
+    yr_note_kernel(nm[mode]);
+    if (mode == 1) hipLaunchKernelGGL((pwhl_kernel<T, PT, CT, 1, false>), grid, dim3(256), 0, s, a);
+    else if (mode == 2) hipLaunchKernelGGL((pwhl_kernel<T, PT, CT, 2, false>), grid, dim3(256), 0, s, a);
+    else if (pooled) hipLaunchKernelGGL((pwhl_kernel<T, PT, CT, 0, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pwhl_kernel<T, PT, CT, 0, false>), grid, dim3(256), 0, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
 }
