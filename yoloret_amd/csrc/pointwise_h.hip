@@ -517,7 +517,8 @@ __global__ __launch_bounds__(256, 3) void pwhl_kernel(PwArgs a) {
     // chunk c is multiplied out of LDS buffer c & 1 while chunk c + 1 is in flight into registers.  One barrier per chunk:
     // the buffer parked into during chunk c is the one chunk c - 1 was read from, and everyone has passed the barrier
     // since.  (A second register stage - chunk c + 2 in flight as well - costs 10 VGPRs = one wave per SIMD on the 128 x 64
-    // tile and measured 10-20 % SLOWER: waves in flight hide more latency than loads in flight per wave.)
+    // tile and measured 10-20 % SLOWER: waves in flight hide more latency than loads in flight per wave; three or four
+    // stages did not win on the long-k projections of the 20 x 20 maps either - tools/pwh_probe.py.)
     Stage R;
     fetch(0, R);
     park(0, R);
