@@ -244,7 +244,7 @@ def main():
         # sources + its output; for a fused block kernel that is the block's input + output only).  Arithmetic peak:
         # the 16-bit pointwise GEMM runs on bf16/f16 MFMA (2.5 PFLOP/s dense), everything else is float32 (fp32 MFMA
         # and packed fp32 FMA share the 157.3 TFLOP/s dense peak).
-        peak_tf = MFMA16_PEAK_TFLOPS if dom.startswith('pwh_kernel') else FP32_PEAK_TFLOPS
+        peak_tf = MFMA16_PEAK_TFLOPS if dom.startswith(('pwh_kernel', 'pwhp_kernel', 'pwhl_kernel')) else FP32_PEAK_TFLOPS
         gbs = d['hbm'] / d['launches'] / (avg_ms * 1e-3) / 1e9
         tfl = 2.0 * d['macs'] / (d['ms'] * 1e-3) / 1e12
         if tfl / peak_tf > gbs / HBM_PEAK_GBS:

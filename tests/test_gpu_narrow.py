@@ -170,11 +170,11 @@ def test_pointwise16(dev, dt, case):
 
 
 @pytest.mark.parametrize('dt', DTYPES)
-@pytest.mark.parametrize('ci', [0, 3, 4, 6, 9, 10, 14, 15, 17])
+@pytest.mark.parametrize('ci', [0, 3, 4, 5, 6, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18])
 def test_pointwise16_tile_shapes_are_bit_identical(dev, dt, ci):
     """Every tile shape runs the same MFMA sequence per output: the autotuner may swap them freely.  Shapes 1-10 the direct
-    kernel, 11-14 the walking small-K form, 15-18 the LDS-tiled form (single identity source with whole octets - cases 3, 4,
-    9 (SE-gated), 14; the others fall back to the direct kernel of the same tile)."""
+    kernel, 11-14 the walking small-K form, 15-18 the LDS-tiled form (every source mode: gathers with
+    upsampled / max-pooled / concatenated sources, the SE gate, pooled outputs, float32 outputs, hoisted partial sums)."""
     h, w, segs, cout, act, bn, residual, gate, out_f32, dense, pool, pre = PW16[ci]
     outs = []
     n = 18
