@@ -17,8 +17,16 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=o
          '-Wall', '-Wno-unused-function'] + os.environ.get('YOLORET_HIPCC_FLAGS', '').split()  # e.g. -DPW_BK=64 (experiments)
 
 
+FLAGS_FILE = os.path.join(CSRC, '_obj', 'flags.txt')   # the flags the library on disk was built with
+
+
 def _stale():
     if not os.path.exists(LIB):
+        return True
+    try:   # a library left behind by an experiment (YOLORET_HIPCC_FLAGS=-D...) is rebuilt, not shipped
+        if open(FLAGS_FILE).read() != ' '.join(FLAGS):
+            return True
+    except OSError:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
@@ -53,6 +61,8 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError('hipcc failed')
     subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    with open(FLAGS_FILE, 'w') as f:
+        f.write(' '.join(FLAGS))
     return LIB
 
 
