@@ -122,16 +122,23 @@ def test_squeeze_excite_blocks_of_a_16_bit_plan_fuse_expand_and_depthwise():
     """16-bit EfficientNet plan: every MBConv block with squeeze-excite and an expand conv of at most 128 inputs becomes
     MBX (expand + depthwise, per-tile channel sums out) -> SE_FC reading those sums -> gated projection; parameters,
     MACs and the conv-granular byte accounting are those of the unfused float32 plan."""
-    from yoloret_amd import layers as L, runtime as rt
+    from yoloret_amd import layers as L, runtime as rt, compiler as C
     f32 = _model('efficientnetb0', 416, 80).plan
     L.set_global_policy('mixed_bfloat16')
+    keep = C.MBX_K5_MAX_CEXP
     try:
+        default = _model('efficientnetb0', 416, 80).plan
+        C.MBX_K5_MAX_CEXP = 10 ** 6       # every eligible block (the default leaves the 5x5 stride-1 blocks unfused: measured)
         p = _model('efficientnetb0', 416, 80).plan
     finally:
+        C.MBX_K5_MAX_CEXP = keep
         L.set_global_policy('float32')
     ops = p.ops
     mbx = [i for i, o in enumerate(ops) if o.kind == rt.OP_MBX]
     assert len(mbx) == 11 and [ops[i].name for i in mbx][:2] == ['stage2_block0_mbx', 'stage2_block1_mbx']
+    dmbx = [o for o in default.ops if o.kind == rt.OP_MBX]
+    assert len(dmbx) == 7 and not any(o.k == 5 and o.stride == 1 for o in dmbx)
+    assert default.param_shapes == f32.param_shapes and default.total_macs() == f32.total_macs()
     for i in mbx:
         m, fc, proj = ops[i], ops[i + 1], ops[i + 2]
         assert fc.kind == rt.OP_SE_FC and proj.kind == rt.OP_POINTWISE

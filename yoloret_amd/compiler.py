@@ -269,6 +269,17 @@ STEMBLOCK_WIDTHS ={(12, 16), (16, 16), (16, 24), (20, 24), (24, 16), (24, 24)}  
 FUSE_MBH = os.environ.get('YOLORET_FUSE_MBH', '1') != '0'   # 16-bit plans: inverted-residual blocks on the MFMA block kernel (mbh.hip)
 MBH_LANE_MIN_PIXELS = int(os.environ.get('YOLORET_MBH_LANE_MIN_PIXELS', '10000'))
 MBH_LANE_MAX_CIN = int(os.environ.get('YOLORET_MBH_LANE_MAX_CIN', '16'))
+# (kernel size, stride) pairs the fused 16-bit block kernels do NOT take, e.g. '51,52' = 5x5 stride 1 and 2 (A/B runs)
+MBH_SKIP = set(os.environ.get('YOLORET_MBH_SKIP', '').replace(' ', '').split(',')) - {''}
+MBX_SKIP = set(os.environ.get('YOLORET_MBX_SKIP', '').replace(' ', '').split(',')) - {''}
+# 5x5 stride-1 blocks: since the LDS-tiled depthwise (depthwise_lds.hip) and the LDS-tiled pointwise form exist, the unfused
+# chain beats the fused block kernel where the block is deep (many 32-channel chunks, each a barrier-synchronous round of a
+# small tile): EfficientNet-lite0 stage 5 (26 x 26, 480 / 672 expanded channels) 0.31 -> 0.16 ms per block, the model
+# 28.05k -> 29.5k img/s; lite3's fused 5x5 blocks (80 x 80, 288 expanded channels) are 1.3 % better fused.  The squeeze-excite
+# form only fuses expand + depthwise, and its 5x5 stride-1 blocks lose to the unfused pair everywhere (B0 19.8k -> 20.7k, B3
+# 4.87k -> 4.94k).  Stride-2 5x5 blocks stay fused (lite0 -3.7 % unfused), 3x3 blocks too (lite3 -11 %).
+MBH_K5_MAX_CEXP = int(os.environ.get('YOLORET_MBH_K5_MAX_CEXP', '320'))
+MBX_K5_MAX_CEXP = int(os.environ.get('YOLORET_MBX_K5_MAX_CEXP', '0'))
 FUSE_STEMDW = os.environ.get('YOLORET_FUSE_STEMDW', '1') != '0'   # stem + first depthwise of the SE EfficientNets in one kernel
 FUSE_MBX = os.environ.get('YOLORET_FUSE_MBX', '1') != '0'   # 16-bit plans: expand + depthwise of squeeze-excite MBConv blocks in one kernel
 MBH_ACTS = ('relu6', 'swish')   # (swish in the fused 16-bit kernels: hardware exp2 / rcp, no register spills)
@@ -631,7 +642,7 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
         # MobileNetV2 block at batch 64 and the float32 lane kernels where both apply)
         mbh = None
         if (FUSE_MBH and dtype != 0 and blocks and exp is not None and d is not None and d.kind == rt.OP_DEPTHWISE and d.k in (3, 5)
-                and d.stride in (1, 2) and plain1(d) and private(d.out) and d.srcs[0].buf is exp.out and d.act == exp.act
+                and d.stride in (1, 2) and '%d%d' % (d.k, d.stride) not in MBH_SKIP and not (d.k == 5 and d.stride == 1 and d.cin > MBH_K5_MAX_CEXP) and plain1(d) and private(d.out) and d.srcs[0].buf is exp.out and d.act == exp.act
                 and d.act in MBH_ACTS and j + 1 < len(ops)):
             p = ops[j + 1]
             bi = exp.srcs[0]
@@ -648,7 +659,7 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                     mbh = None
         mbx = None
         if (FUSE_MBX and mbh is None and bufs is not None and dtype != 0 and blocks and exp is not None and d is not None
-                and d.kind == rt.OP_DEPTHWISE and d.k in (3, 5) and d.stride in (1, 2) and len(d.srcs) == 1
+                and d.kind == rt.OP_DEPTHWISE and d.k in (3, 5) and d.stride in (1, 2) and '%d%d' % (d.k, d.stride) not in MBX_SKIP and not (d.k == 5 and d.stride == 1 and d.cin > MBX_K5_MAX_CEXP) and len(d.srcs) == 1
                 and d.srcs[0].xform == 'identity' and d.srcs[0].buf is exp.out and d.act == exp.act and d.out.dtype == dtype
                 and exp.srcs[0].buf.dtype == dtype and exp.srcs[0].c <= 128 and d.out.external_slot < 0 and d.out.id not in output_buf_ids):
             # the squeeze of this depthwise map: an SE_FC op reading it (merged mean) or the partial sums it already writes
