@@ -280,6 +280,7 @@ MBX_SKIP = set(os.environ.get('YOLORET_MBX_SKIP', '').replace(' ', '').split(','
 # 4.87k -> 4.94k).  Stride-2 5x5 blocks stay fused (lite0 -3.7 % unfused), 3x3 blocks too (lite3 -11 %).
 MBH_K5_MAX_CEXP = int(os.environ.get('YOLORET_MBH_K5_MAX_CEXP', '320'))
 MBX_K5_MAX_CEXP = int(os.environ.get('YOLORET_MBX_K5_MAX_CEXP', '0'))
+MBH_K3_MAX_CEXP = int(os.environ.get('YOLORET_MBH_K3_MAX_CEXP', '1000000'))   # the same switch for 3x3 stride-1 blocks
 FUSE_STEMDW = os.environ.get('YOLORET_FUSE_STEMDW', '1') != '0'   # stem + first depthwise of the SE EfficientNets in one kernel
 FUSE_MBX = os.environ.get('YOLORET_FUSE_MBX', '1') != '0'   # 16-bit plans: expand + depthwise of squeeze-excite MBConv blocks in one kernel
 MBH_ACTS = ('relu6', 'swish')   # (swish in the fused 16-bit kernels: hardware exp2 / rcp, no register spills)
@@ -642,7 +643,7 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
         # MobileNetV2 block at batch 64 and the float32 lane kernels where both apply)
         mbh = None
         if (FUSE_MBH and dtype != 0 and blocks and exp is not None and d is not None and d.kind == rt.OP_DEPTHWISE and d.k in (3, 5)
-                and d.stride in (1, 2) and '%d%d' % (d.k, d.stride) not in MBH_SKIP and not (d.k == 5 and d.stride == 1 and d.cin > MBH_K5_MAX_CEXP) and plain1(d) and private(d.out) and d.srcs[0].buf is exp.out and d.act == exp.act
+                and d.stride in (1, 2) and '%d%d' % (d.k, d.stride) not in MBH_SKIP and not (d.k == 5 and d.stride == 1 and d.cin > MBH_K5_MAX_CEXP) and not (d.k == 3 and d.stride == 1 and d.cin > MBH_K3_MAX_CEXP) and plain1(d) and private(d.out) and d.srcs[0].buf is exp.out and d.act == exp.act
                 and d.act in MBH_ACTS and j + 1 < len(ops)):
             p = ops[j + 1]
             bi = exp.srcs[0]
