@@ -125,7 +125,10 @@ typedef enum {
                             wgt  = expand    [P][CINP x 2 (input-channel major), times the BN scale | 1 1 | BN shift 2],
                             wgt2 = depthwise [P][9 taps (ky,kx) x 2, times the BN scale | 1 1 | BN shift 2],
                             b1   = project W[2P][COP] (expanded-channel major), b2 = project BN scale[COP] ++ shift[COP].
-                            Built for (CINP/4,COP) in {(4,16),(4,24),(6,24),(6,32),(6,40),(6,48),(8,32),(8,40),(8,48)} */
+                            Built for (CINP/4,COP) in {(4,16),(4,24),(6,24),(6,32),(6,40),(6,48),(8,32),(8,40),(8,48)}.
+                            wgt = NULL: a block WITHOUT expand conv (expand ratio 1, efficientnet.py:467 skipped; stride 1,
+                            se_reduced = Cin): depthwise + project (+ residual) on the block input itself; built for
+                            (4,16), (6,24), (8,32) */
     YR_OP_MBX = 12       /* the first two thirds of an MBConv block WITH squeeze-excite (efficientnet.py:406-536), 16-bit
                             activations: expand 1x1 + BN + act (bf16 / f16 MFMA) -> depthwise K = 3 | 5, stride 1 | 2 + BN +
                             act, the expanded input of the depthwise conv staying in LDS; the depthwise map is stored and

@@ -91,6 +91,59 @@ def test_mblane(dev, case, dt):
         assert_rounded_once(from_dev16(out, dt, cout), ref, dt, 'mblane %s %s' % (dt, case), slack=5e-5)
 
 
+IDENT_CASES = [
+    # (h, w, c, cout == c, residual, act): blocks WITHOUT expand conv (expand ratio 1; EfficientNet stage 1, efficientnet.py:467)
+    (30, 44, 24, True, 'relu6'), (13, 13, 24, False, 'relu6'), (17, 15, 16, True, 'swish'), (9, 21, 32, True, 'relu6'),
+    (160, 160, 24, True, 'relu6'), (8, 8, 22, False, 'relu6'),
+]
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('case', IDENT_CASES, ids=[str(i) for i in range(len(IDENT_CASES))])
+def test_mblane_without_expand(dev, case, dt):
+    """wgt = NULL: depthwise 3x3 stride 1 + BN + act -> project 1x1 + BN (+ residual) on the block input itself."""
+    from yoloret_amd import runtime as rt
+    h, w, c, residual, act = case
+    cout = c
+    rng = np.random.default_rng(zlib.crc32(str(case).encode()))
+    b = 2
+    x = rng.standard_normal((b, h, w, c)).astype(np.float32)
+    if dt != 'f32':
+        x = q16(x, dt)
+    wd = (rng.standard_normal((3, 3, c)) * np.sqrt(2.0 / 9)).astype(np.float32)
+    sd, hd = rng.uniform(0.5, 1.5, c).astype(np.float32), rng.normal(0, 0.3, c).astype(np.float32)
+    t = _act((nn.depthwise(x, wd, 1, 'same') * sd + hd).astype(np.float32), act)
+    wp = (rng.standard_normal((c, cout)) * np.sqrt(1.0 / c)).astype(np.float32)
+    sp, hp = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.3, cout).astype(np.float32)
+    ref = (nn.pointwise(t, wp) * sp + hp).astype(np.float32)
+    if residual:
+        ref = ref + x
+    cop = round_up(cout, 8)
+    e2 = 2 * round_up((c + 1) // 2, 8)
+    wpp = np.zeros((e2, cop), np.float32)
+    wpp[:c, :cout] = wp
+    pb = np.zeros((2, cop), np.float32)
+    pb[0, :cout], pb[1, :cout] = sp, hp
+    keep = [torch.from_numpy(np.ascontiguousarray(a).ravel()).to(dev) for a in (_pairs(wd.reshape(9, c), sd, hd, e2), wpp, pb)]
+    xd = to_dev(x, dev) if dt == 'f32' else to_dev16(x, dev, dt)
+    op = rt.new_op(rt.OP_MBLANE, act)
+    op.dtype = op.out_dtype = rt.dtype_id(dt)
+    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc, op.se_reduced = h, w, c, cout, 3, 1, 1, c
+    op.src[0] = rt.make_src(xd, c=c)
+    op.wgt2, op.b1, op.b2 = [k.data_ptr() for k in keep]      # no `wgt`: no expand conv
+    if residual:
+        op.res, op.res_ld = xd.data_ptr(), xd.shape[3]
+    ldo = round_up(cout, 4) if dt == 'f32' else round_up(cout, 8)
+    out = torch.full((b, h, w, ldo), float('nan'), dtype=rt.TORCH_DTYPE[rt.dtype_id(dt)], device=dev)
+    op.out, op.out_ld = out.data_ptr(), ldo
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    if dt == 'f32':
+        assert_close(from_dev(out, cout), ref, 5e-5, 'mblane without expand %s' % (case,))
+    else:
+        assert_rounded_once(from_dev16(out, dt, cout), ref, dt, 'mblane without expand %s %s' % (dt, case), slack=5e-5)
+
+
 def test_mblane_rejects_unsupported_widths(dev):
     from yoloret_amd import runtime as rt
     x = torch.zeros((1, 8, 8, 64), dtype=torch.float32, device=dev)

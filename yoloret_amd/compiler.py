@@ -259,6 +259,8 @@ class Plan:
 FUSE_MAX_CIN = int(os.environ.get('YOLORET_FUSE_MAX_CIN', '32'))
 FUSE_MIN_PIXELS = int(os.environ.get('YOLORET_FUSE_MIN_PIXELS', '1600'))  # output H*W of the block
 FUSE_NO_EXPAND = os.environ.get('YOLORET_FUSE_NO_EXPAND', '0') != '0'    # also fuse DW+project blocks without expand
+FUSE_LANE_NO_EXPAND = os.environ.get('YOLORET_FUSE_LANE_NO_EXPAND', '1') != '0'   # ... in the lane-per-pixel kernel (any dtype)
+MBLANE_IDENT_WIDTHS = {(4, 16), (6, 24), (8, 32)}     # (Cin quads, padded Cout) of launch_ml_ident
 FUSE_STEM = os.environ.get('YOLORET_FUSE_STEM', '1') != '0'              # stem + first (expand-free) block in one kernel
 FUSE_LANE = os.environ.get('YOLORET_FUSE_LANE', '1') != '0'              # narrow fused blocks use mblane.hip instead of mbconv.hip
 FUSE_LANE_MIN_PIXELS = int(os.environ.get('YOLORET_FUSE_LANE_MIN_PIXELS', '600'))  # mblane still wins on 26x26 outputs (block_6)
@@ -539,9 +541,12 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
     def plain1(op):
         return len(op.srcs) == 1 and op.srcs[0].xform == 'identity' and op.gate is None
 
-    def lane_ok(exp, block_in, proj):  # the lane-per-pixel kernel (mblane.hip) is built for this block shape
-        return (FUSE_LANE and exp is not None and proj.out.ld % 2 == 0
-                and (round_up(block_in.c, 4) // 4, round_up(proj.cout, 8)) in MBLANE_WIDTHS)
+    def lane_ok(exp, block_in, proj, dw=None):  # the lane-per-pixel kernel (mblane.hip) is built for this block shape
+        widths = (round_up(block_in.c, 4) // 4, round_up(proj.cout, 8))
+        if exp is None:   # a block without expand conv (expand ratio 1): stride 1, a few widths (launch_ml_ident)
+            return (FUSE_LANE and FUSE_LANE_NO_EXPAND and dw is not None and dw.stride == 1 and proj.out.ld % 2 == 0
+                    and widths in MBLANE_IDENT_WIDTHS)
+        return FUSE_LANE and proj.out.ld % 2 == 0 and widths in MBLANE_WIDTHS
 
     def pad_to(fn, n, ld):
         def f(wd):
@@ -742,10 +747,10 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                 and d.srcs[0].buf.ld == round_up(d.cin, rt.VEC[dtype]) and j + 1 < len(ops)):
             p = ops[j + 1]
             block_in = exp.srcs[0] if exp is not None else d.srcs[0]
-            lane = lane_ok(exp, block_in, p)
+            lane = lane_ok(exp, block_in, p, d)
             if ((lane or dtype == 0) and p.kind == rt.OP_POINTWISE and plain1(p) and p.srcs[0].buf is d.out and p.act == 'none'
                     and 'scale' in p.params and p.cout <= 224 and block_in.buf.ld % 4 == 0
-                    and (exp is not None or FUSE_NO_EXPAND) and block_in.c <= max_cin
+                    and (exp is not None or FUSE_NO_EXPAND or lane) and block_in.c <= max_cin
                     and p.h * p.w >= (FUSE_LANE_MIN_PIXELS if lane else FUSE_MIN_PIXELS)
                     and (p.res is None or (p.res is block_in.buf and d.stride == 1 and p.cout == block_in.c))):
                 dw, proj = d, p
@@ -768,7 +773,7 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                 return o
             return f
         cinp, cop = round_up(block_in.c, 4), round_up(cout, 8)
-        if lane_ok(exp, block_in, proj):
+        if lane_ok(exp, block_in, proj, dw):
             # lane-per-pixel formulation (mblane.hip): everything packed per expanded-channel pair
             m.kind, m.name = rt.OP_MBLANE, m.name.replace('_mbconv', '_mblane')
             npair = round_up((cexp + 1) // 2, 8)
@@ -781,7 +786,7 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                 full[:-2, :cexp] = (rows[:, :cexp] * scale[None, :cexp]).astype(np.float32)
                 full[-2, :cexp], full[-1, :cexp] = 1.0, shift[:cexp]
                 return np.ascontiguousarray(full.reshape(-1, e2 // 2, 2).transpose(1, 0, 2)).reshape(e2 // 2, -1)
-            ep, dwp, pp_ = exp.params, dw.params, proj.params
+            ep, dwp, pp_ = (exp.params if exp is not None else None), dw.params, proj.params
 
             def expand_w(wd, ep=ep, cinp=cinp, pairs=pairs):
                 wt = ep['wgt'][1](wd)                      # pointwise layout Wt[cexp][kp]
@@ -793,7 +798,8 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                 o = np.zeros((e2, cop), np.float32)
                 o[:cexp, :cout] = pp_['wgt'][1](wd)[:, :cexp].T
                 return o
-            m.params['wgt'] = ((npair, cinp * 2 + 4), expand_w)
+            if exp is not None:          # (without expand conv the op has no `wgt`: the kernel copies the input pairs)
+                m.params['wgt'] = ((npair, cinp * 2 + 4), expand_w)
             m.params['wgt2'] = ((npair, 22), lambda wd, dwp=dwp, pairs=pairs: pairs(dwp['wgt'][1](wd), dwp['scale'][1](wd), dwp['shift'][1](wd)))
             m.params['b1'] = ((e2, cop), proj_w)
             m.params['b2'] = ((2 * cop,), lambda wd, pp_=pp_, cout=cout, cop=cop: np.concatenate(

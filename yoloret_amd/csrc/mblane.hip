@@ -149,7 +149,10 @@ __device__ __forceinline__ void ml_dw_project(const v2f* e, kptr w, kptr pw, v2f
 }
 
 // ------------------------------------------------------------------------------------------ stride 1
-template <int CQ, int COP, bool RELU6, class T>
+// IDENT: a block WITHOUT an expand conv (expand ratio 1: depthwise + project on the block input itself, efficientnet.py:
+// 467-484 skipped when expand_ratio == 1 - every EfficientNet stage 1): the "expanded" tensor is the input, copied to LDS
+// pair by pair (zero outside the image = TF's padding of the depthwise input); a.we is unused.
+template <int CQ, int COP, bool RELU6, class T, bool IDENT = false>
 __global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s1_kernel(MlArgs<T> a) {
     constexpr int TL = 14, WE = 8 * CQ + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -172,6 +175,30 @@ __global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s1_ke
     for (int n = 0; n < COP / 2; ++n) o[n] = (v2f){0.f, 0.f};
     const kptr we = (kptr)a.we, wd = (kptr)a.wd, wp = (kptr)a.wp;
 
+    if constexpr (IDENT) {
+        constexpr int NP = (2 * CQ + ML_CH - 1) / ML_CH * ML_CH;   // == a.npairs (the launcher checks)
+#pragma unroll
+        for (int p0 = 0; p0 < NP; p0 += ML_CH) {                   // unrolled: the pair picks its registers statically
+            v2f* buf = Es + ((p0 / ML_CH) & 1) * (ML_CH * 256);
+#pragma unroll
+            for (int j = 0; j < ML_CH; ++j) {
+                const int pr = p0 + j;
+                v2f v = {0.f, 0.f};
+                if (pr < 2 * CQ) v = (pr & 1) ? (v2f){x[pr / 2 < CQ ? pr / 2 : 0].z, x[pr / 2 < CQ ? pr / 2 : 0].w}
+                                              : (v2f){x[pr / 2 < CQ ? pr / 2 : 0].x, x[pr / 2 < CQ ? pr / 2 : 0].y};
+                buf[j * 256 + tid] = v;
+            }
+            __syncthreads();
+            if (is_out) {
+#pragma unroll 1
+                for (int j = 0; j < ML_CH; ++j) {
+                    const kptr w = wd + (p0 + j) * 22;
+                    const kptr pw = wp + (p0 + j) * 2 * COP;
+                    ml_dw_project<COP, 16, RELU6>(buf + j * 256 + tid - 17, w, pw, o, a.act);
+                }
+            }
+        }
+    } else {
     for (int p0 = 0; p0 < a.npairs; p0 += ML_CH) {
         v2f* buf = Es + ((p0 / ML_CH) & 1) * (ML_CH * 256);
 #pragma unroll 1
@@ -188,6 +215,8 @@ __global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s1_ke
             }
         }
     }
+    }
+    (void)hi; (void)we;
     if (is_out && hy < a.Ho && hx < a.Wo) {
         const kptr bp = (kptr)a.bp;
         T* op = a.out + ((size_t)(b * a.Ho + hy) * a.Wo + hx) * a.ld_out;
@@ -300,6 +329,23 @@ static int launch_ml(const MlArgs<T>& a, int batch, hipStream_t s) {
     return YR_OK;
 }
 
+// blocks without an expand conv (stride 1): the widths built
+template <int CQ, int COP, class T>
+static int launch_ml_ident(const MlArgs<T>& a, int batch, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * ML_CH * 256 * sizeof(v2f);
+    static char nm[2][56];
+    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "mblane_s1_kernel<%d,%d,0,%s,ident>", CQ, COP, yr_dtype_name(yr_elem<T>::dtype)) +
+                              snprintf(nm[1], sizeof(nm[1]), "mblane_s1_kernel<%d,%d,1,%s,ident>", CQ, COP, yr_dtype_name(yr_elem<T>::dtype));
+    (void)nm_len;
+    yr_note_kernel(nm[a.act == YR_ACT_RELU6 ? 1 : 0]);
+    YR_REQUIRE(a.npairs == (2 * CQ + ML_CH - 1) / ML_CH * ML_CH, "mblane: a block without expand conv has Cexp == Cin");
+    const dim3 grid((unsigned)(batch * a.tiles_x * a.tiles_y));
+    if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((mblane_s1_kernel<CQ, COP, true, T, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((mblane_s1_kernel<CQ, COP, false, T, true>), grid, dim3(256), lds, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
 template <int S, class T>
 static int launch_ml_widths(const MlArgs<T>& a, int cq, int cop, int batch, hipStream_t s) {
     switch (cq * 100 + cop) {
@@ -328,7 +374,9 @@ static int launch_mblane_t(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY, "mblane: needs one identity source");
     const yr_src& in = op.src[0];
     YR_REQUIRE(op.k == 3 && (op.stride == 1 || op.stride == 2), "mblane: only 3x3 stride 1|2 is fused");
-    YR_REQUIRE(in.ptr && op.out && op.wgt && op.wgt2 && op.b1 && op.b2, "mblane: null pointer");
+    YR_REQUIRE(in.ptr && op.out && op.wgt2 && op.b1 && op.b2, "mblane: null pointer");
+    const bool ident = op.wgt == nullptr;   // no expand conv: depthwise + project on the block input
+    if (ident) YR_REQUIRE(op.stride == 1 && op.se_reduced == in.c, "mblane: a block without expand weights needs stride 1 and Cexp == Cin");
     YR_REQUIRE(in.ld % yr_elem<T>::vec == 0 && op.out_ld % yr_elem<T>::vec == 0 && in.c == op.cin && in.ld >= yr_round_up(in.c, 4),
                "mblane: channel strides must be multiples of %d", yr_elem<T>::vec);
     YR_REQUIRE(((uintptr_t)in.ptr) % 16 == 0 && ((uintptr_t)op.out) % 8 == 0, "mblane: pointers must be 16-byte aligned");
@@ -350,6 +398,13 @@ static int launch_mblane_t(const yr_op& op, int batch, hipStream_t s) {
     const int cq = yr_round_up(in.c, 4) / 4, cop = yr_round_up(op.cout, 8);
     if (op.stride == 1) {
         a.tiles_x = (a.Wo + 13) / 14; a.tiles_y = (a.Ho + 13) / 14;
+        if (ident) {
+            if (cq == 6 && cop == 24) return launch_ml_ident<6, 24, T>(a, batch, s);
+            if (cq == 4 && cop == 16) return launch_ml_ident<4, 16, T>(a, batch, s);
+            if (cq == 8 && cop == 32) return launch_ml_ident<8, 32, T>(a, batch, s);
+            yr_set_error("mblane: widths Cin=%d Cout=%d unsupported without expand conv", a.Cin, a.Cout);
+            return YR_ERR_ARG;
+        }
         return launch_ml_widths<1, T>(a, cq, cop, batch, s);
     }
     YR_REQUIRE(a.ld_out % 2 == 0, "mblane: stride-2 stores need an even output channel stride");
