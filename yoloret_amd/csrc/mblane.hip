@@ -189,9 +189,10 @@ __global__ __launch_bounds__(256, (4 * CQ + COP > 72 ? 2 : 4)) void mblane_s1_ke
                 buf[j * 256 + tid] = v;
             }
             __syncthreads();
+            const int jn = 2 * CQ - p0 < ML_CH ? 2 * CQ - p0 : ML_CH;   // the zero pairs that pad the parameter rows are skipped
             if (is_out) {
 #pragma unroll 1
-                for (int j = 0; j < ML_CH; ++j) {
+                for (int j = 0; j < jn; ++j) {
                     const kptr w = wd + (p0 + j) * 22;
                     const kptr pw = wp + (p0 + j) * 2 * COP;
                     ml_dw_project<COP, 16, RELU6>(buf + j * 256 + tid - 17, w, pw, o, a.act);
