@@ -158,6 +158,9 @@ PW16 = [
     (14, 10, [(48, 'identity'), (96, 'identity')], 203, 'relu6', True, False, False, False, False, True, False),
     (12, 12, [(72, 'identity'), (96, 'identity')], 256, 'relu6', True, False, False, False, False, False, True),   # hoisted: up2_add
     (6, 6, [(256, 'identity')], 75, 'none', False, False, False, True, False, False, False),         # the _lowres half: fp32 out, padded
+    (13, 13, [(128, 'identity')], 75, 'none', True, False, True, False, False, False, False),        # SE-gated project, k <= 256 (stationary form)
+    (10, 10, [(320, 'identity')], 600, 'relu6', True, False, False, False, False, False, False),      # three cout ranges of the k-streaming form
+    (9, 9, [(200, 'identity')], 1400, 'relu6', True, True, False, False, False, False, False),        # 44 cout pairs walked by the stationary form
 ]
 
 
@@ -170,14 +173,15 @@ def test_pointwise16(dev, dt, case):
 
 
 @pytest.mark.parametrize('dt', DTYPES)
-@pytest.mark.parametrize('ci', [0, 3, 4, 5, 6, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize('ci', list(range(22)))
 def test_pointwise16_tile_shapes_are_bit_identical(dev, dt, ci):
     """Every tile shape runs the same MFMA sequence per output: the autotuner may swap them freely.  Shapes 1-10 the direct
-    kernel, 11-14 the walking small-K form, 15-18 the LDS-tiled form (every source mode: gathers with
-    upsampled / max-pooled / concatenated sources, the SE gate, pooled outputs, float32 outputs, hoisted partial sums)."""
+    kernel, 11-14 the walking small-K form, 15-18 the LDS-tiled form, 19-22 the activation-stationary form, 23-26 the all-couts
+    k-streaming form (every source mode: gathers with upsampled / max-pooled / concatenated sources, the SE gate, pooled
+    outputs, float32 outputs, hoisted partial sums; ops a form does not take fall back inside the library)."""
     h, w, segs, cout, act, bn, residual, gate, out_f32, dense, pool, pre = PW16[ci]
     outs = []
-    n = 18
+    n = 26
     for cfg in range(0, n + 1):
         rng = np.random.default_rng(zlib.crc32(str(PW16[ci]).encode()))
         outs.append(run_pointwise16(dev, dt, rng, 2, h, w, segs, cout, act, bn, residual, gate, out_f32, dense, pool, pre, cfg=cfg))

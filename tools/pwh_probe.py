@@ -10,11 +10,11 @@ dev = torch.device('cuda:0')
 dt = sys.argv[1] if len(sys.argv) > 1 else 'f16'
 did = rt.dtype_id(dt)
 tdt = rt.TORCH_DTYPE[did]
-ncfg = 18
+ncfg = 26
 only = int(sys.argv[2]) if len(sys.argv) > 2 else -1      # shape index
 only_cfg = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # tile shape (1-based), 0 = all
 shape_i = -1
-for name, b, h, k, n in [('lite3 s5 expand', 32, 40, 136, 816), ('lite3 s5 project', 32, 40, 816, 136), ('lite3 s6 expand', 32, 20, 232, 1392),
+for name, b, h, k, n in [('lite0 s5 expand', 128, 26, 112, 672), ('lite0 s5 project', 128, 26, 672, 112), ('lite3 s5 expand', 32, 40, 136, 816), ('lite3 s5 project', 32, 40, 816, 136), ('lite3 s6 expand', 32, 20, 232, 1392),
                          ('lite3 s6 project', 32, 20, 1392, 232), ('lite0 s6 expand', 128, 13, 192, 1152), ('lite0 s6 project', 128, 13, 1152, 192)]:
     shape_i += 1
     if only >= 0 and shape_i != only:
@@ -44,4 +44,4 @@ for name, b, h, k, n in [('lite3 s5 expand', 32, 40, 136, 816), ('lite3 s5 proje
         torch.cuda.synchronize()
         res.append((e0.elapsed_time(e1) / 20 * 1e3, cfg))
     mb = b * h * h * (kp + ldo) * 2 / 1e6
-    print('%-18s %.0f MB  ' % (name, mb) + '  '.join('c%d %.1f' % (c, t) for t, c in sorted(res)[:6]) + '   best %.2f TB/s' % (mb / min(res)[0]))
+    print('%-18s %.0f MB  ' % (name, mb) + '  '.join('c%d %.1f' % (c, t) for t, c in sorted(res)[:5]) + '  |  ' + '  '.join('c%d %.1f' % (c, t) for t, c in res[18:]) + '   best %.2f TB/s' % (mb / min(res)[0]))

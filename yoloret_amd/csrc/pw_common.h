@@ -318,3 +318,7 @@ int yr_pw_launch_lds(int shape, const PwArgs& a, hipStream_t s);
 // 16-bit kernel (pointwise_h.hip): cfg = tile shape index 0..yr_pwh_num_cfgs()-1, or -1 for its heuristic
 int yr_pw_launch_h(int dtype, int cfg, const PwArgs& a, hipStream_t s);
 int yr_pwh_num_cfgs();
+// its activation-stationary (pointwise_hs.hip) and all-couts k-streaming (pointwise_hq.hip) forms, variant 0..3 each;
+// -1: the form does not take this op (nothing launched, no error set)
+int yr_pwhs_launch(int dtype, int variant, const PwArgs& a, hipStream_t s);
+int yr_pwhq_launch(int dtype, int variant, const PwArgs& a, hipStream_t s);
