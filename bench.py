@@ -84,7 +84,10 @@ def usable_cores():
 
 
 def cpu_baseline(model_name, size, classes, anchors, seconds):
-    """The oracle's torch-CPU port (oneDNN) + C decode/NMS on all host cores; bounded sample."""
+    """The oracle's torch-CPU port (oneDNN) + C decode/NMS on all host cores; bounded sample.  BASELINE.md section 3: the
+    throughput sample in batches of 8 (`value`, plus the median of the per-batch times, at least 5 of them) and the
+    batch-1 latency the reference itself runs at (code/yolo.py:83-84): p50 over 200 runs after 20 warm-ups (fewer when
+    200 would not fit `seconds`; the count is stated)."""
     from oracle import cpost, params, torch_ref
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -93,22 +96,37 @@ def cpu_baseline(model_name, size, classes, anchors, seconds):
     b = 8
     x = params.synthetic_images(b, size, size)
 
-    def one():
-        ys = ref(x)
-        for i in range(b):
+    def one(xb):
+        ys = ref(xb)
+        for i in range(xb.shape[0]):
             cpost.yolo_eval([y[i] for y in ys], anchors, 3, classes, (size, size), 20, 0.2, 0.5)
-    one()  # warm-up (oneDNN primitive creation)
+    one(x)  # warm-up (oneDNN primitive creation)
     t0 = time.perf_counter()
     n = 0
+    per_batch = []
     while True:
-        one()
+        t1 = time.perf_counter()
+        one(x)
+        per_batch.append(time.perf_counter() - t1)
         n += b
         dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 4096:
+        if (dt >= seconds and len(per_batch) >= 5) or n >= 4096:
             break
+    x1 = x[:1]
+    for _ in range(20):
+        one(x1)
+    lat = []
+    t0 = time.perf_counter()
+    while len(lat) < 200 and (len(lat) < 20 or time.perf_counter() - t0 < seconds):
+        t1 = time.perf_counter()
+        one(x1)
+        lat.append(time.perf_counter() - t1)
     return {'value': round(n / dt, 2), 'unit': 'img/s', 'cores': cores, 'cpu': cpu_model(), 'kind': 'port',
+            'median_ms_b8': round(float(np.median(per_batch)) * 1e3, 2), 'runs_b8': len(per_batch),
+            'p50_ms_b1': round(float(np.median(lat)) * 1e3, 2), 'runs_b1': len(lat),
             'sample': '%d images (batches of %d) of the same %s@%d workload through oracle/torch_ref.py '
-                      '(torch-CPU/oneDNN fp32) + oracle C decode/NMS, %.1f s' % (n, b, model_name, size, dt)}
+                      '(torch-CPU/oneDNN fp32) + oracle C decode/NMS, %.1f s; then %d batch-1 runs after 20 warm-ups'
+                      % (n, b, model_name, size, dt, len(lat))}
 
 
 def main():
@@ -192,9 +210,13 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        allt = torch.empty(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allt, t)           # every rank's own clock around the same timed steps ...
+        per_rank = [float(v) for v in allt.cpu()]
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)       # ... the job's time is the slowest rank's
         elapsed = float(t.item())
     ms_per_step = elapsed / a.steps * 1e3
     value = world * b * a.steps / elapsed
@@ -234,28 +256,56 @@ def main():
             dict(name='pack', kind='pack', kernel='pack_kernel', ms=post_ms[2], macs=0, bytes=0)]
         by = {}
         for r in rows:
-            k = by.setdefault(r['kernel'], dict(ms=0.0, bytes=0, hbm=0, macs=0, launches=0))
+            k = by.setdefault(r['kernel'], dict(ms=0.0, bytes=0, hbm=0, macs=0, macs16=0, launches=0))
             k['ms'] += r['ms']; k['bytes'] += r['bytes']; k['macs'] += r['macs']; k['launches'] += 1
+            k['macs16'] += r.get('macs_mfma16', 0)
             k['hbm'] += r.get('hbm_bytes', r['bytes'])
         dom = max(by, key=lambda k: by[k]['ms'])
         d = by[dom]
         avg_ms = d['ms'] / d['launches']
-        # The dominant kernel against the roofline that bounds it.  Bytes = what the op must move through HBM (its
-        # sources + its output; for a fused block kernel that is the block's input + output only).  Arithmetic peak:
-        # the 16-bit pointwise GEMM runs on bf16/f16 MFMA (2.5 PFLOP/s dense), everything else is float32 (fp32 MFMA
-        # and packed fp32 FMA share the 157.3 TFLOP/s dense peak).
-        peak_tf = MFMA16_PEAK_TFLOPS if dom.startswith(('pwh_kernel', 'pwhp_kernel', 'pwhl_kernel')) else FP32_PEAK_TFLOPS
-        gbs = d['hbm'] / d['launches'] / (avg_ms * 1e-3) / 1e9
-        tfl = 2.0 * d['macs'] / (d['ms'] * 1e-3) / 1e12
-        if tfl / peak_tf > gbs / HBM_PEAK_GBS:
-            roofline = {'bound': 'mfma', 'kernel': dom, 'launches_per_step': d['launches'], 'avg_launch_ms': round(avg_ms, 4),
-                        'achieved': round(tfl, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
-                        'frac': round(tfl / peak_tf, 4), 'traffic': None,
-                        'flops_per_launch': int(2.0 * d['macs'] / d['launches']), 'hbm_gbs': round(gbs, 1)}
-        else:
+
+        def pipes(v):
+            """One symbol (or family) against the three resources: HBM bytes it must move, its multiply-adds on the 16-bit
+            matrix pipe (2.5 PFLOP/s dense) and those on the float32 pipe (fp32 MFMA / packed FMA: 157.3 TFLOP/s) - a fused
+            16-bit block kernel has both kinds, and summing them against one peak means nothing."""
+            sec = v['ms'] * 1e-3
+            gbs = v['hbm'] / sec / 1e9 if sec else 0.0
+            tf16 = 2.0 * v['macs16'] / sec / 1e12 if sec else 0.0
+            tf32 = 2.0 * (v['macs'] - v['macs16']) / sec / 1e12 if sec else 0.0
+            fr = {'hbm': gbs / HBM_PEAK_GBS, 'mfma16': tf16 / MFMA16_PEAK_TFLOPS, 'fp32': tf32 / FP32_PEAK_TFLOPS}
+            return gbs, tf16, tf32, fr
+        gbs, tf16, tf32, fr = pipes(d)
+        pipe_name = max(fr, key=fr.get)
+        # The dominant kernel against the roofline that bounds it (the resource with the largest fraction).  Bytes = what
+        # the op must move through HBM (its sources + its output; a fused block kernel: the block's input + output only).
+        if pipe_name == 'hbm':
             roofline = {'bound': 'hbm', 'kernel': dom, 'launches_per_step': d['launches'], 'avg_launch_ms': round(avg_ms, 4),
-                        'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None, 'tflops': round(tfl, 2)}
+                        'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(fr['hbm'], 4), 'traffic': None}
+        else:
+            tfl, peak_tf = (tf16, MFMA16_PEAK_TFLOPS) if pipe_name == 'mfma16' else (tf32, FP32_PEAK_TFLOPS)
+            roofline = {'bound': 'mfma', 'pipe': '16-bit MFMA' if pipe_name == 'mfma16' else 'float32 (fp32 MFMA / packed FMA)',
+                        'kernel': dom, 'launches_per_step': d['launches'], 'avg_launch_ms': round(avg_ms, 4),
+                        'achieved': round(tfl, 2), 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': round(tfl / peak_tf, 4), 'traffic': None,
+                        'flops_per_launch': int(2.0 * (d['macs16'] if pipe_name == 'mfma16' else d['macs'] - d['macs16']) / d['launches'])}
+        roofline['by_pipe'] = {'hbm_gbs': round(gbs, 1), 'frac_hbm': round(fr['hbm'], 4), 'mfma16_tflops': round(tf16, 2),
+                               'frac_mfma16': round(fr['mfma16'], 4), 'fp32_tflops': round(tf32, 2), 'frac_fp32': round(fr['fp32'], 4)}
+        # the same per kernel FAMILY: the lane-per-pixel front, the fused MFMA blocks ... are several symbols each
+        fams = [('lane_per_pixel_front', ('mblane', 'stemblock', 'stem_')), ('fused_blocks', ('mbh_kernel', 'mbconv')),
+                ('pointwise', ('pw_kernel', 'pwd_kernel', 'pwh', 'pwl')), ('depthwise', ('dw_kernel', 'dwl')),
+                ('squeeze_excite', ('se_',)), ('postprocess', ('decode', 'nms', 'pack'))]
+        total_ms = sum(v['ms'] for v in by.values())
+        roofline_family = {}
+        for fname, prefixes in fams:
+            agg = dict(ms=0.0, hbm=0, macs=0, macs16=0, launches=0)
+            for sym, v in by.items():
+                if sym.startswith(prefixes):
+                    for kk in agg:
+                        agg[kk] += v[kk]
+            if agg['launches']:
+                g_, t16_, t32_, fr_ = pipes(agg)
+                roofline_family[fname] = {'ms': round(agg['ms'], 4), 'share_of_step': round(agg['ms'] / total_ms, 4), 'launches': agg['launches'],
+                                          'moved_gbs': round(g_, 1), 'frac_hbm': round(fr_['hbm'], 4), 'fp32_tflops': round(t32_, 2),
+                                          'frac_fp32': round(fr_['fp32'], 4), 'mfma16_tflops': round(t16_, 2), 'frac_mfma16': round(fr_['mfma16'], 4)}
         roofline['bytes_per_launch'] = int(d['hbm'] / d['launches'])   # the `achieved` GB/s = this / avg_launch_ms
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
         # (profiles/rNN_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KiB, see tools/rocpd_summary.py); None if absent
@@ -432,11 +482,16 @@ def main():
                                       % (a.model, a.size, b,
                                          {'f32': 'fp32', 'bf16': 'bf16 activations + 1x1 weights on bf16 MFMA (fp32 accumulate, logits, decode, NMS)',
                                           'f16': 'fp16 activations + 1x1 weights on f16 MFMA (fp32 accumulate, logits, decode, NMS)'}[a.dtype],
-                                         a.classes, ' + all-gather of detections' if world > 1 else ''),
+                                         a.classes, ' + all-gather of detections' if world > 1 else '')
+                                      + ('; the -lite form = no squeeze-excite, ReLU6, and it KEEPS the width-scaled stem' if a.model.endswith('-lite') else ''),
                           'global_batch': b * world, 'parallelism': 'dp%d (image-sharded)' % world},
-               'p50_ms_b1': p50, 'roofline': roofline, 'roofline_step': roofline_step, 'incl_h2d': incl_h2d}
+               'p50_ms_b1': p50, 'roofline': roofline, 'roofline_family': roofline_family, 'roofline_step': roofline_step, 'incl_h2d': incl_h2d}
         if p50 is not None:
             out['p50_ms_b1_detail'] = {'eager_launches': p50_eager, 'hip_graph_replay': p50_graph}
+        if use_dist:
+            out['rccl_ranks'] = world
+            out['per_rank_img_s'] = [round(b * a.steps / v, 1) for v in per_rank]
+            out['collective'] = 'one all_gather_into_tensor of the packed records per step, on a second stream (overlapped with the next forward)'
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.model, a.size, a.classes, anchors, a.cpu_seconds)
     if use_dist:

@@ -1,0 +1,91 @@
+"""BASELINE.json configs 3, 4 and 5 at the FULL per-GPU batch the bench runs them at (config 2's twin is
+tests/test_gpu_graph.py::test_c2_batch64_properties): the throughput plan, with the tile table `yr_autotune` picks for
+that batch - per-layer pointwise tile shapes, fused-block output tiles, cout ranges of the activation-stationary GEMM -
+i.e. exactly the launches `bench.py --model .. --batch ..` times and no smaller test reaches.
+
+The oracle cannot run 128 images at 416 in seconds, so the checks are size-independent properties plus samples:
+  (i)   sampled images equal their own batch-1 run through the SAME plan bit for bit (batching == the reference applied
+        per image).  The batch-1 run is autotuned separately: different pointwise tile shapes (bit-identical
+        by construction, tests/test_gpu_narrow.py) and different fused-block output tiles - a per-output arithmetic that
+        depended on the tile (an MFMA tile position, a depthwise run, a chunk order) would show here;
+  (ii)  sampled images against the oracle: float32 at the 1e-4 bar (torch-CPU port of the graph, oracle/torch_ref.py);
+        16-bit plans against the float32 oracle with ABSOLUTE ceilings (tests/test_gpu_narrow.py::CEIL16, per model and
+        type) and against the NumPy emulation of the storage format (no less accurate than it, x1.5 mean / x2 max);
+  (iii) the oracle's post-processing of the GPU's own logits == the GPU's packed detections, bit for bit, for the samples.
+Reference: code/yolo3/model.py:192-217 (the model families), code/yolo.py:83-133 (the batch the reference itself never runs)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpost
+from oracle import model as om
+from oracle import params
+from tests.util import ANCHORS, assert_close
+
+pytestmark = pytest.mark.gpu
+
+from tests.test_gpu_narrow import CEIL16   # (scaled max, scaled mean) logit error ceilings per (model, 16-bit type)
+
+
+def _errs(a, ref):
+    e = np.abs(a.astype(np.float64) - ref) / np.maximum(1.0, np.abs(ref))
+    return float(e.max()), float(e.mean())
+
+
+@pytest.mark.parametrize('name,size,b,dt', [('efficientnetb0-lite', 416, 128, 'bf16'),     # config 3
+                                            ('mobilenetv2x14', 512, 64, 'f32'),            # config 4 (one GPU's share of 512)
+                                            ('efficientnetb3-lite', 640, 32, 'f16')])      # config 5 (one GPU's share of 256)
+def test_full_batch_properties(dev, name, size, b, dt):
+    from yoloret_amd import layers as L
+    from yoloret_amd.yolo3.model import yolov3_body, yolo_eval_packed, unpack_detections
+    hw = (size, size)
+    L.set_global_policy({'f32': 'float32', 'bf16': 'mixed_bfloat16', 'f16': 'mixed_float16'}[dt])
+    try:
+        m = yolov3_body(L.Input(shape=[size, size, 3]), name, 3, num_classes=20)
+    finally:
+        L.set_global_policy('float32')
+    m.small_batch = 0                                  # batch-1 runs go through the SAME (throughput) plan
+    P = params.ParamStore(1234, 'conditioned')
+    x = params.synthetic_images(b, size, size)
+    sample = [0, b // 2 + 3, b - 1]
+    # the oracle's walk over the sampled images creates every parameter (and is check (ii)'s float32 reference)
+    if dt == 'f32':
+        from oracle import torch_ref
+        ref = torch_ref.TorchReference(P, name, 3, 20)(x[sample[:2]])
+        emu = None
+    else:
+        ref = om.yolov3_body(P, x[sample[:1]], name, 3, 20)
+        emu = om.yolov3_body(params.QuantStore(1234, 'conditioned', dt), x[sample[:1]], name, 3, 20)
+    m.set_weights(P.values)
+    xd = torch.from_numpy(x).to(dev)
+    ys = [y.clone() for y in m(xd)]
+    torch.cuda.synchronize()
+    assert all(y.dtype == torch.float32 and torch.isfinite(y).all() for y in ys)
+    # (i) batch-B == batch-1, bit for bit
+    for i in sample:
+        one = m(xd[i:i + 1].contiguous())
+        for k, (a, full) in enumerate(zip(one, ys)):
+            assert torch.equal(a[0], full[i]), '%s %s: image %d, output %d differs between the batch-%d and the batch-1 run' % (name, dt, i, k + 1, b)
+    # (ii) samples against the oracle
+    if dt == 'f32':
+        for j, i in enumerate(sample[:2]):
+            for k, (y, r) in enumerate(zip(ys, ref)):
+                assert_close(y[i].cpu().numpy().reshape(r[j].shape), r[j], 1e-4, '%s B=%d image %d y%d' % (name, b, i, k + 1))
+    else:
+        i = sample[0]
+        for k, (y, r, e) in enumerate(zip(ys, ref, emu)):
+            g = y[i:i + 1].cpu().numpy()
+            gm, ga = _errs(g, r)
+            em, ea = _errs(e, r)
+            print('%s@%d %s B=%d image %d y%d  scaled error vs the fp32 oracle (max / mean):  HIP %.2e / %.2e   NumPy emulation %.2e / %.2e'
+                  % (name, size, dt, b, i, k + 1, gm, ga, em, ea))
+            assert gm <= CEIL16[(name, dt)][0] and ga <= CEIL16[(name, dt)][1], '%s %s y%d: scaled error max %.3e / mean %.3e above the ceilings' % (name, dt, k + 1, gm, ga)
+            assert ga <= 1.5 * ea + 1e-6 and gm <= 2.0 * em + 1e-5, '%s %s y%d: less accurate than the emulation of the format' % (name, dt, k + 1)
+    # (iii) GPU detections == the oracle's post-processing of the GPU's logits
+    det, cnt = yolo_eval_packed(ys, ANCHORS, 3, 20, hw, 20, 0.2, 0.5)
+    res = unpack_detections(det, cnt)
+    assert len(res) == b
+    for i in sample:
+        gb, gs, gc = [t.cpu().numpy() for t in res[i]]
+        ob, os_, oc, _ = cpost.yolo_eval([y[i].cpu().numpy() for y in ys], ANCHORS, 3, 20, hw, 20, 0.2, 0.5)
+        assert np.array_equal(gb, ob) and np.array_equal(gs, os_) and np.array_equal(gc, oc)

@@ -251,8 +251,18 @@ class Model:
         per_op_bytes = plan.algorithmic_bytes_per_op()
         per_op_hbm = plan.hbm_bytes_per_op()   # fused ops: only what still has to cross HBM (block in + out)
         for i, op in enumerate(plan.ops):
+            # which pipe the multiply-adds run on: the 1x1 convolutions of a 16-bit plan on bf16 / f16 MFMA (also inside the
+            # fused block kernels mbh / mbx, whose depthwise stage stays on packed float32 FMAs); everything else float32
+            m16 = 0
+            if op.dtype != 0:
+                if op.kind == rt.OP_POINTWISE:
+                    m16 = op.macs
+                elif op.kind in (rt.OP_MBH, rt.OP_MBX):
+                    kk = (op.k & 0xff) ** 2
+                    cexp = op.se_reduced if op.kind == rt.OP_MBH else op.cout
+                    m16 = max(op.macs - op.h * op.w * kk * cexp, 0)
             out.append(dict(name=op.name, kind=rt.OP_NAMES[op.kind], kernel=(names[i] or b'').decode(),
-                            ms=float(ms[i]), macs=op.macs * b, bytes=per_op_bytes[i] * b, hbm_bytes=per_op_hbm[i] * b))
+                            ms=float(ms[i]), macs=op.macs * b, macs_mfma16=m16 * b, bytes=per_op_bytes[i] * b, hbm_bytes=per_op_hbm[i] * b))
         return out
 
     def __del__(self):
