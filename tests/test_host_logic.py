@@ -249,6 +249,35 @@ def test_product_does_not_import_the_oracle():
     assert not bad, 'product modules import the test oracle: %s' % bad
 
 
+# kernels that may keep values in scratch memory, with the bytes per lane they are known to use (prefix of the mangled
+# name -> cap).  Everything else must not spill: a new spill is a register-allocation accident (an `#pragma unroll` that
+# was not obeyed, a select between array slots, a register cap set too low) and is caught at build time, without a GPU.
+SCRATCH_ALLOWED = {
+    '_Z10mbh_kernel': 200,         # the expand + depthwise (squeeze-excite) forms and the 4-cout-pair forms park prefetched parameters
+    '_Z16mblane_s1_kernel': 104,   # 16-bit instantiations: output staging
+    '_Z16mblane_s2_kernel': 104,
+    '_Z15nms_band_kernel': 200,    # the per-lane score list of the band-wise NMS
+    '_Z13mbconv_kernelILi16ELi16ELi1ELi2E': 156,   # float32 fallback block kernel (one shape)
+    '_Z10pwh_kernelIDF16_Li4ELi1ELi2ELi2E': 68,    # f16 direct form, four pixel tiles, gated source
+}
+
+
+def test_no_unexpected_scratch_spills():
+    """Reads the per-kernel resource report the build keeps (yoloret_amd/build.py: -Rpass-analysis=kernel-resource-usage)."""
+    from yoloret_amd import build as b
+    b.build()
+    bad, n = [], 0
+    for src, rows in b.kernel_resources().items():
+        for name, vgprs, scratch, occ, lds in rows:
+            n += 1
+            if scratch > 0:
+                cap = max([c for pre, c in SCRATCH_ALLOWED.items() if name.startswith(pre)] or [0])
+                if scratch > cap:
+                    bad.append('%s: %s spills %d bytes per lane (%d VGPRs, %d waves/SIMD)' % (src, name, scratch, vgprs, occ))
+    assert n > 500, 'resource report incomplete (%d kernels)' % n
+    assert not bad, 'kernels with scratch memory:\n' + '\n'.join(bad)
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from yoloret_amd import runtime as rt
     monkeypatch.setattr(rt, '_lib', None)

@@ -1,6 +1,10 @@
 """Builds libyoloret_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
     python -m yoloret_amd.build [--force]
+
+Every compile also asks for the kernel resource report (-Rpass-analysis=kernel-resource-usage); the per-kernel lines
+(VGPRs, scratch bytes per lane, waves per SIMD, LDS) are kept as csrc/_obj/<file>.regs.txt - `kernel_resources()` reads
+them, tests/test_host_logic.py holds the list of kernels that may spill and fails on any other.
 """
 import os
 import subprocess
@@ -28,11 +32,46 @@ def _stale():
             return True
     except OSError:
         return True
+    if not all(os.path.exists(os.path.join(CSRC, '_obj', f.replace('.hip', '.regs.txt'))) for f in SOURCES):
+        return True   # (a library from before the resource reports were kept)
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     deps.append(os.path.join(HERE, '..', 'include', 'yoloret_hip.h'))
     deps.append(os.path.abspath(__file__))
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _split_report(out):
+    """hipcc output -> (one line per kernel: name vgprs agprs scratch occupancy lds, everything that is not the report)."""
+    import re
+    rows, rest, cur = [], [], None
+    for line in out.split('\n'):
+        m = re.search(r'remark: .*?(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\S+)', line)
+        if m:
+            if m.group(1) == 'Function Name':
+                cur = {'name': m.group(2)}
+                rows.append(cur)
+            elif cur is not None:
+                cur[m.group(1).split(' ')[0]] = m.group(2)
+        elif 'remark:' not in line and '-Rpass-analysis' not in line:
+            rest.append(line)
+    text = ''.join('%s vgprs %s agprs %s scratch %s occupancy %s lds %s\n' % (r['name'], r.get('VGPRs', '?'), r.get('AGPRs', '?'), r.get('ScratchSize', '?'),
+                                                                             r.get('Occupancy', '?'), r.get('LDS', '?')) for r in rows)
+    return text, '\n'.join(rest)
+
+
+def kernel_resources():
+    """{source file: [(mangled kernel, vgprs, scratch bytes per lane, waves per SIMD, lds bytes)]} of the library on disk."""
+    res = {}
+    objdir = os.path.join(HERE, 'csrc', '_obj')
+    for src in SOURCES:
+        path = os.path.join(objdir, src.replace('.hip', '.regs.txt'))
+        rows = []
+        for line in open(path):
+            t = line.split()
+            rows.append((t[0], int(t[2]), int(t[6]), int(t[8]), int(t[10])))
+        res[src] = rows
+    return res
 
 
 def build(force=False, verbose=False):
@@ -46,7 +85,7 @@ def build(force=False, verbose=False):
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace('.hip', '.o'))
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -56,8 +95,12 @@ def build(force=False, verbose=False):
         if p.returncode != 0:
             failed = True
             sys.stderr.write('--- %s ---\n%s\n' % (src, out))
-        elif verbose and out.strip():
-            print(out)
+            continue
+        report, rest = _split_report(out)
+        with open(os.path.join(objdir, src.replace('.hip', '.regs.txt')), 'w') as f:
+            f.write(report)
+        if verbose and rest.strip():
+            print(rest)
     if failed:
         raise RuntimeError('hipcc failed')
     subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
@@ -66,5 +109,21 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def report():
+    """The register / scratch / occupancy table of every kernel of the library on disk (profiles/rNN_kernel_regs.txt)."""
+    lines = []
+    for src, rows in kernel_resources().items():
+        spill = [r for r in rows if r[2] > 0]
+        lines.append('%-20s %4d kernels, VGPRs %d..%d, %d with scratch%s' % (src, len(rows), min([r[1] for r in rows] or [0]), max([r[1] for r in rows] or [0]),
+                                                                            len(spill), (' (max %d bytes per lane)' % max(r[2] for r in spill)) if spill else ''))
+        for name, vg, sc, occ, lds in rows:
+            lines.append('    %-70s vgprs %3d scratch %4d waves/SIMD %d lds %6d' % (name, vg, sc, occ, lds))
+    return '\n'.join(lines)
+
+
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    if '--report' in sys.argv:
+        build()
+        print(report())
+    else:
+        print(build(force='--force' in sys.argv, verbose=True))

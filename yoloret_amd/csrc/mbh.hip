@@ -495,7 +495,6 @@ static int launch_mbh(const MbhArgs& a, int batch, hipStream_t s) {
     if (!attr_dev[dev & 63]) {
         YR_CHECK_HIP(hipFuncSetAttribute((const void*)mbh_kernel<T, K, S, CP, NG, 0, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         YR_CHECK_HIP(hipFuncSetAttribute((const void*)mbh_kernel<T, K, S, CP, NG, 1, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        YR_CHECK_HIP(hipFuncSetAttribute((const void*)mbh_kernel<T, K, S, CP, NG, 2, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_dev[dev & 63] = true;
     }
     static char nm[56];
@@ -506,7 +505,10 @@ static int launch_mbh(const MbhArgs& a, int batch, hipStream_t s) {
     const dim3 grid((unsigned)(batch * a.tiles_x * a.tiles_y));
     if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((mbh_kernel<T, K, S, CP, NG, 0, MODE>), grid, dim3(256), lds, s, a);
     else if (a.act == YR_ACT_SWISH) hipLaunchKernelGGL((mbh_kernel<T, K, S, CP, NG, 1, MODE>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((mbh_kernel<T, K, S, CP, NG, 2, MODE>), grid, dim3(256), lds, s, a);
+    else {   // (the graph compiler fuses ReLU6 and swish blocks only - compiler.MBH_ACTS; the run-time-switch form spilled up to 924 bytes per lane)
+        yr_set_error("mbh: activation %d is not fused (ReLU6 and swish are)", a.act);
+        return YR_ERR_ARG;
+    }
     YR_LAUNCH_CHECK();
     return YR_OK;
 }

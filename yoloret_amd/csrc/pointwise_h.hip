@@ -320,7 +320,7 @@ static int launch_h(const PwArgs& a, hipStream_t s);
 
 template <class T, int PT, int CT>
 static int launch_lds(const PwArgs& a, hipStream_t s) {
-    if (a.dw_w) return launch_h<T, PT / 2, CT>(a, s);   // (float32 plans only) the direct kernel of the same tile shape
+    if (a.dw_w) { yr_set_error("pointwise: the depthwise-folded source is a float32 feature"); return YR_ERR_ARG; }
     constexpr int BM = 32 * PT, BN = 32 * CT;
     const int mode = (a.S.n == 1 && a.S.s[0].xform == YR_X_IDENTITY) ? (a.gate ? 2 : 1) : 0;
     if (mode == 0 && a.gate) { yr_set_error("pointwise: an SE gate needs one identity source"); return YR_ERR_ARG; }
@@ -364,7 +364,8 @@ static int launch_hp(const PwArgs& a, int mode, hipStream_t s) {
 template <class T, int PT, int CP>
 static int launch_h(const PwArgs& a, hipStream_t s) {
     constexpr int BM = 64 * PT, BN = 32 * CP;
-    constexpr int D = PT + 2 * CP <= 4 ? 4 : (PT + 2 * CP <= 8 ? 3 : 2);
+    // chunks of loads in flight; four pixel tiles per wave keep two (three spilled 464-544 bytes per lane in the f16 gather form)
+    constexpr int D = PT >= 4 ? 2 : (PT + 2 * CP <= 4 ? 4 : (PT + 2 * CP <= 8 ? 3 : 2));
     dim3 grid((unsigned)((a.M + BM - 1) / BM) * (unsigned)((a.N + BN - 1) / BN));
     const int mode = (a.S.n == 1 && a.S.s[0].xform == YR_X_IDENTITY) ? (a.gate ? 2 : 1) : 0;
     if (mode == 0 && a.gate) { yr_set_error("pointwise: an SE gate needs one identity source"); return YR_ERR_ARG; }
@@ -416,7 +417,7 @@ static int launch_h_cfg(int cfg, const PwArgs& a, hipStream_t s) {
         case 4: return launch_h<T, 2, 1>(a, s);
         case 5: return launch_h<T, 2, 2>(a, s);
         case 6: return launch_h<T, 2, 3>(a, s);
-        case 7: return launch_h<T, 2, 4>(a, s);
+        case 7: return launch_lds<T, 2, 4>(a, s);   // (the direct kernel of this 128 x 128 shape spilled 272 bytes per lane: its LDS-tiled twin)
         case 8: return launch_h<T, 4, 1>(a, s);
         case 9: return launch_h<T, 4, 2>(a, s);
         case 10: return launch_walk<T, 1, 1>(a, s);

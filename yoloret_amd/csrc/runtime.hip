@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <exception>
 #include <map>
 #include <utility>
 #include <vector>
@@ -96,6 +97,33 @@ extern "C" int yr_create(const yr_op* ops, int n_ops, const yr_buf* bufs, int n_
             yr_set_error("yr_create: op references a buffer outside the table, or with a dtype other than the buffer's");
             return YR_ERR_ARG;
         }
+        // extents: what the op addresses in each buffer must lie inside it (a corrupt or truncated plan must not turn into
+        // out-of-bounds device accesses).  Sources: their own h x w x ld; output / residual: the op's rows x pitch.
+        const char* why = nullptr;
+        auto fits = [&](int32_t b, int64_t elems, int dtype) {
+            const yr_buf& d = h->bufs[b];
+            return elems > 0 && (d.external_slot >= 0 || elems * (int64_t)(dtype == YR_F32 ? 4 : 2) <= d.bytes_per_image);
+        };
+        if (op.h <= 0 || op.w <= 0 || op.h > (1 << 15) || op.w > (1 << 15) || op.out_ld <= 0 || op.out_ld > (1 << 20) || op.cout <= 0 || op.cin <= 0) why = "dims";
+        for (int i = 0; !why && i < op.nsrc; ++i) {
+            const yr_src& sr = op.src[i];
+            if (sr.h <= 0 || sr.w <= 0 || sr.h > (1 << 15) || sr.w > (1 << 15) || sr.c <= 0 || sr.ld < sr.c || sr.ld > (1 << 20) ||
+                !fits(sr.buf, (int64_t)sr.h * sr.w * sr.ld, sr.dtype)) why = "a source";
+        }
+        if (!why) {
+            // rows the op writes: its h x w (already the pooled dims when a pointwise op stores the 2x2-pooled map); the
+            // squeeze-excite ops write vectors; a depthwise / fused-block op with per-tile channel sums writes them to `gate`
+            int64_t rows = (int64_t)op.h * op.w;
+            if (op.kind == YR_OP_SE_MEAN || op.kind == YR_OP_SE_FC) rows = 1;
+            if (op.out_ld < (op.kind == YR_OP_SE_MEAN || op.kind == YR_OP_SE_FC ? op.cin : op.cout) || !fits(op.out_buf, rows * op.out_ld, op.out_dtype)) why = "the output";
+            else if (op.res_buf >= 0 && (op.res_ld < op.cout || !fits(op.res_buf, (int64_t)op.h * op.w * op.res_ld, op.dtype))) why = "the residual";
+            else if (op.gate_buf >= 0 && op.gate_ld <= 0) why = "the gate";
+        }
+        if (why) {
+            delete h;
+            yr_set_error("yr_create: %s of an op (kind %d, %d x %d) does not fit the buffer it names", why, op.kind, op.h, op.w);
+            return YR_ERR_ARG;
+        }
     }
     *out = h;
     return YR_OK;
@@ -112,6 +140,48 @@ struct yr_blob_header {
 };
 static_assert(sizeof(yr_blob_header) == 96, "serialised plan header is 96 bytes");
 
+// Floats of the blob a parameter of `op` occupies from its offset on (0: the role is not used by this kind, or its size is
+// not modelled here - the offset alone is then range-checked).  Mirrors the layouts documented in include/yoloret_hip.h.
+static int64_t param_floats(const yr_op& op, int role) {   // role: 0 wgt, 1 scale, 2 shift, 3 wgt2, 4 b1, 5 b2
+    const int V = yr_vec_of(op.dtype);
+    auto ru = [](int64_t v, int64_t m) { return (v + m - 1) / m * m; };
+    switch (op.kind) {
+        case YR_OP_POINTWISE: {
+            int64_t kp = 0;
+            for (int i = 0; i < op.nsrc; ++i)
+                if (op.src[i].xform != YR_X_UP2_ADD) kp += ru(op.src[i].c, V);
+            if (role == 0) return op.dtype == YR_F32 ? (int64_t)op.cout * kp : ((int64_t)op.cout * kp + 1) / 2;
+            if (role == 1 || role == 2) return op.cout;
+            return 0;
+        }
+        case YR_OP_DEPTHWISE:
+            if (role == 0) return (int64_t)op.k * op.k * ru(op.cin, V);
+            if (role == 1 || role == 2) return ru(op.cin, V);
+            return 0;
+        case YR_OP_STEM:
+            if (role == 0) return 27 * ru(op.cout, 4);
+            if (role == 1 || role == 2) return ru(op.cout, 4);
+            return 0;
+        case YR_OP_SE_FC: {
+            const int64_t ldc = ru(op.cin, 4);
+            if (role == 0 || role == 3) return (int64_t)op.se_reduced * ldc;
+            if (role == 4) return op.se_reduced;
+            if (role == 5) return ldc;
+            return 0;
+        }
+        case YR_OP_WSUM: return role == 0 ? 4 : 0;
+        case YR_OP_MBH: case YR_OP_MBX: {
+            const int64_t cexp = ru(op.kind == YR_OP_MBH ? op.se_reduced : op.cout, 32), kp = ru(op.cin, 32), kk = (op.k & 0xff) * (op.k & 0xff);
+            if (role == 0) return cexp * kp / 2;
+            if (role == 3) return (kk + 4) * cexp;
+            if (op.kind == YR_OP_MBH && role == 4) return (int64_t)op.cout * cexp / 2;
+            if (op.kind == YR_OP_MBH && role == 5) return 2 * ru(op.cout, 8);
+            return 0;
+        }
+        default: return 0;   // STEMBLOCK / MBLANE / MBCONV: pair-packed layouts, validated by their launchers' shape tables only
+    }
+}
+
 extern "C" int yr_create_from_blob(const void* blob, size_t bytes, yr_handle** out) {
     YR_REQUIRE(blob && out && bytes >= sizeof(yr_blob_header), "yr_create_from_blob: bad arguments");
     yr_blob_header hd;
@@ -120,38 +190,55 @@ extern "C" int yr_create_from_blob(const void* blob, size_t bytes, yr_handle** o
     YR_REQUIRE(hd.abi == YR_ABI_VERSION && hd.sizeof_op == sizeof(yr_op) && hd.sizeof_buf == sizeof(yr_buf),
                "yr_create_from_blob: plan written for ABI %u (yr_op %u bytes, yr_buf %u bytes); this library is ABI %d (%zu, %zu)",
                hd.abi, hd.sizeof_op, hd.sizeof_buf, YR_ABI_VERSION, sizeof(yr_op), sizeof(yr_buf));
+    // every count is bounded by what `bytes` could hold BEFORE anything is multiplied: the sum below cannot wrap
+    YR_REQUIRE(hd.n_ops > 0 && hd.n_bufs > 0 && hd.n_weight_floats > 0 && hd.n_ops <= bytes / sizeof(yr_op) && hd.n_bufs <= bytes / sizeof(yr_buf) &&
+               hd.n_weight_floats <= bytes / sizeof(float) && hd.n_tables <= bytes / sizeof(int32_t),
+               "yr_create_from_blob: the header's counts (%u ops, %u buffers, %llu weights, %u tables) exceed the %zu bytes given",
+               hd.n_ops, hd.n_bufs, (unsigned long long)hd.n_weight_floats, hd.n_tables, bytes);
     const size_t need = sizeof(hd) + (size_t)hd.n_ops * sizeof(yr_op) + (size_t)hd.n_bufs * sizeof(yr_buf) +
                         (size_t)hd.n_weight_floats * sizeof(float) + (size_t)hd.n_tables * (1 + (size_t)hd.n_ops) * sizeof(int32_t);
-    YR_REQUIRE(hd.n_ops > 0 && hd.n_bufs > 0 && hd.n_weight_floats > 0 && bytes == need,
-               "yr_create_from_blob: %zu bytes, the header describes %zu", bytes, need);
-    const char* p = static_cast<const char*>(blob) + sizeof(hd);
-    std::vector<yr_op> ops(hd.n_ops);
-    std::vector<yr_buf> bufs(hd.n_bufs);
-    memcpy(ops.data(), p, ops.size() * sizeof(yr_op));
-    p += ops.size() * sizeof(yr_op);
-    memcpy(bufs.data(), p, bufs.size() * sizeof(yr_buf));
-    p += bufs.size() * sizeof(yr_buf);
-    for (yr_op& op : ops) {   // a file must not smuggle pointers in
-        for (int i = 0; i < YR_MAX_SRC; ++i) op.src[i].ptr = nullptr;
-        op.out = nullptr; op.res = nullptr; op.gate = nullptr;
-        op.wgt = op.scale = op.shift = op.wgt2 = op.b1 = op.b2 = nullptr;
-        const int64_t offs[6] = {op.wgt_off, op.scale_off, op.shift_off, op.wgt2_off, op.b1_off, op.b2_off};
-        for (int64_t o : offs) YR_REQUIRE(o < (int64_t)hd.n_weight_floats, "yr_create_from_blob: parameter offset outside the weight blob");
-    }
+    YR_REQUIRE(bytes == need, "yr_create_from_blob: %zu bytes, the header describes %zu", bytes, need);
     yr_handle* h = nullptr;
-    int rc = yr_create(ops.data(), (int)ops.size(), bufs.data(), (int)bufs.size(), &h);
-    if (rc) return rc;
-    std::vector<float> w(hd.n_weight_floats);
-    memcpy(w.data(), p, w.size() * sizeof(float));
-    p += w.size() * sizeof(float);
-    rc = yr_load_weights(h, w.data(), w.size());
-    for (uint32_t t = 0; rc == YR_OK && t < hd.n_tables; ++t) {
-        std::vector<int32_t> tab(1 + hd.n_ops);
-        memcpy(tab.data(), p, tab.size() * sizeof(int32_t));
-        p += tab.size() * sizeof(int32_t);
-        rc = yr_set_tuning(h, tab[0], tab.data() + 1, (int)hd.n_ops);
+    try {   // no exception may cross the C boundary (std::bad_alloc / std::length_error from the vectors below)
+        const char* p = static_cast<const char*>(blob) + sizeof(hd);
+        std::vector<yr_op> ops(hd.n_ops);
+        std::vector<yr_buf> bufs(hd.n_bufs);
+        memcpy(ops.data(), p, ops.size() * sizeof(yr_op));
+        p += ops.size() * sizeof(yr_op);
+        memcpy(bufs.data(), p, bufs.size() * sizeof(yr_buf));
+        p += bufs.size() * sizeof(yr_buf);
+        for (yr_op& op : ops) {   // a file must not smuggle pointers in
+            for (int i = 0; i < YR_MAX_SRC; ++i) op.src[i].ptr = nullptr;
+            op.out = nullptr; op.res = nullptr; op.gate = nullptr;
+            op.wgt = op.scale = op.shift = op.wgt2 = op.b1 = op.b2 = nullptr;
+            YR_REQUIRE(op.nsrc >= 1 && op.nsrc <= YR_MAX_SRC && yr_dtype_ok(op.dtype), "yr_create_from_blob: op with %d sources / dtype %d", op.nsrc, op.dtype);
+            const int64_t offs[6] = {op.wgt_off, op.scale_off, op.shift_off, op.wgt2_off, op.b1_off, op.b2_off};
+            for (int role = 0; role < 6; ++role) {
+                if (offs[role] < 0) continue;   // role not used
+                const int64_t ext = param_floats(op, role);
+                YR_REQUIRE(ext >= 0 && offs[role] < (int64_t)hd.n_weight_floats && ext <= (int64_t)hd.n_weight_floats - offs[role],
+                           "yr_create_from_blob: a parameter of an op (kind %d, role %d: %lld floats at %lld) lies outside the weight blob of %llu",
+                           op.kind, role, (long long)ext, (long long)offs[role], (unsigned long long)hd.n_weight_floats);
+            }
+        }
+        int rc = yr_create(ops.data(), (int)ops.size(), bufs.data(), (int)bufs.size(), &h);
+        if (rc) return rc;
+        std::vector<float> w(hd.n_weight_floats);
+        memcpy(w.data(), p, w.size() * sizeof(float));
+        p += w.size() * sizeof(float);
+        rc = yr_load_weights(h, w.data(), w.size());
+        for (uint32_t t = 0; rc == YR_OK && t < hd.n_tables; ++t) {
+            std::vector<int32_t> tab(1 + hd.n_ops);
+            memcpy(tab.data(), p, tab.size() * sizeof(int32_t));
+            p += tab.size() * sizeof(int32_t);
+            rc = yr_set_tuning(h, tab[0], tab.data() + 1, (int)hd.n_ops);
+        }
+        if (rc) { yr_destroy(h); return rc; }
+    } catch (const std::exception& e) {
+        if (h) yr_destroy(h);
+        yr_set_error("yr_create_from_blob: %s", e.what());
+        return YR_ERR_ARG;
     }
-    if (rc) { yr_destroy(h); return rc; }
     h->in_hw[0] = hd.in_h; h->in_hw[1] = hd.in_w;
     memcpy(h->out_hwc, hd.out_hwc, sizeof(h->out_hwc));
     *out = h;
