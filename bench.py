@@ -48,6 +48,9 @@ def parse():
     ap.add_argument('--per-op', action='store_true', help='also print the per-op table to stderr')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise RCCL and issue the detection all-gather even with one rank (single-GPU check of the N>1 path)')
+    ap.add_argument('--depth', type=int, default=2,
+                    help='steps in flight (DetectionPipeline(depth=..)): consecutive steps run on consecutive execution contexts / HIP '
+                         'streams and fill each other\'s idle CUs; 1 = strictly one step after the other')
     ap.add_argument('--no-latency', action='store_true',
                     help='skip the batch-1 p50 loop (use under rocprofv3 so that every launch is a batch-%d launch)' % 64)
     return ap.parse_args()
@@ -166,7 +169,9 @@ def main():
     model = yolov3_body(L.Input(shape=[a.size, a.size, 3]), a.model, 3, num_classes=a.classes)
     model.set_weights(W.synthetic_weights(model, 1234, 'survey'))
     pipe = DetectionPipeline(model, anchors, a.classes, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5,
-                             record_slots=2 if use_dist else 1)
+                             record_slots=2 if (use_dist and a.depth <= 1) else 1, depth=a.depth)
+    # latency, ingestion and per-kernel measurements run strictly one step after the other
+    pipe1 = pipe if a.depth <= 1 else DetectionPipeline(model, anchors, a.classes, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5)
     gather = DetectionGatherer(always=a.force_dist)
     b = a.batch
     x = torch.from_numpy(W.synthetic_images(b, a.size, a.size, seed=20240416 + rank)).to(dev)
@@ -179,7 +184,9 @@ def main():
         # handle is waited for one step later (the final sync() covers the last one).  Every step still contains
         # exactly one collective.
         det, cnt = pipe(x, image_hw)
-        h = gather.start(det, cnt, pipe.record)
+        h = gather.start(det, cnt, pipe.record, after=pipe.done)
+        if h.released is not None:
+            pipe.release(h.released)          # the context that produced these records runs again only after the collective read them
         prev, pending[0] = pending[0], h
         return prev.wait() if prev is not None else None
 
@@ -200,6 +207,11 @@ def main():
     sync()
     if saved_stdout is not None:
         sys.stdout.flush()
+        try:   # RCCL's banner sits in the C library's stdout buffer (fully buffered on a pipe): it must leave through the
+            import ctypes   # redirected descriptor NOW, or it would follow the JSON line at exit
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
     for _ in range(a.warmup):
@@ -224,7 +236,7 @@ def main():
     out = None
     if rank == 0:
         plan = model.plan
-        n_boxes = pipe.n
+        n_boxes = pipe1.n
         alg_fwd = plan.algorithmic_bytes_per_image()
         alg_dec = n_boxes * (a.classes + 5) * 4 + n_boxes * (4 + a.classes) * 4
         alg_img = alg_fwd + alg_dec + plan.weight_bytes() / b
@@ -232,11 +244,11 @@ def main():
         # ---- live per-kernel measurement (hipEvent pair around every launch, same stream)
         prof = model.profile(x, iters=a.profile_iters)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        ys = pipe.forward(x)
+        ys = pipe1.forward(x)
         post_ms = np.zeros(3)
         reps = 5
         for _ in range(reps):
-            v = pipe._buffers(b, dev)
+            v = pipe1._buffers(b, dev)
             ev[0].record()
             from yoloret_amd import runtime as rt
             rt.decode([y for y in v['ys']], anchors, a.classes, image_hw, (a.size, a.size))
@@ -394,13 +406,13 @@ def main():
             x1 = x[:1].contiguous()
             hw1 = image_hw[:1].contiguous()
             for _ in range(20):
-                pipe(x1, hw1)
+                pipe1(x1, hw1)
             torch.cuda.synchronize(dev)
             ts = []
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for _ in range(200):
                 e0.record()
-                pipe(x1, hw1)
+                pipe1(x1, hw1)
                 e1.record()
                 e1.synchronize()
                 ts.append(e0.elapsed_time(e1))
@@ -408,14 +420,14 @@ def main():
             p50 = p50_eager
             # the same step replayed as ONE HIP graph launch (batch 1 is launch-bound: ~80 launches of a few us)
             try:
-                pipe.enable_graph(True)
+                pipe1.enable_graph(True)
                 for _ in range(20):
-                    pipe(x1, hw1)
+                    pipe1(x1, hw1)
                 torch.cuda.synchronize(dev)
                 ts = []
                 for _ in range(200):
                     e0.record()
-                    pipe(x1, hw1)
+                    pipe1(x1, hw1)
                     e1.record()
                     e1.synchronize()
                     ts.append(e0.elapsed_time(e1))
@@ -425,7 +437,7 @@ def main():
                 p50_graph = None
                 sys.stderr.write('hip graph replay failed: %s\n' % (e,))
             finally:
-                pipe.enable_graph(False)
+                pipe1.enable_graph(False)
         # ---- SURVEY.md 8(d) "incl. H2D": the same step fed from host memory the sane way - pinned uint8 batch over
         # PCIe (a quarter of the float32 bytes), /255 + letterbox on the GPU (yr_letterbox_batch), then the step.
         # Reported next to `value`, never as `value` (the boundary of the headline is a resident batch).
@@ -435,10 +447,14 @@ def main():
             u8 = (x * 255.0).round().clamp(0, 255).to(torch.uint8).cpu().pin_memory()
             dbuf = torch.empty(u8.shape, dtype=torch.uint8, device=dev)
 
+            def step_serial():   # one step after the other: x is rewritten for every batch here
+                det, cnt = pipe1(x, image_hw)
+                return gather.start(det, cnt, pipe1.record).wait()
+
             def step_h2d():
                 dbuf.copy_(u8, non_blocking=True)
                 rt.letterbox(dbuf, (a.size, a.size), out=x)
-                return step()
+                return step_serial()
             for _ in range(3):
                 step_h2d()
             sync()
@@ -459,7 +475,7 @@ def main():
             def step_fed():
                 feeder.submit(u8)
                 feeder.take(out=x)
-                return step()
+                return step_serial()
             feeder.submit(u8)
             for _ in range(3):
                 step_fed()
@@ -483,9 +499,10 @@ def main():
                                          {'f32': 'fp32', 'bf16': 'bf16 activations + 1x1 weights on bf16 MFMA (fp32 accumulate, logits, decode, NMS)',
                                           'f16': 'fp16 activations + 1x1 weights on f16 MFMA (fp32 accumulate, logits, decode, NMS)'}[a.dtype],
                                          a.classes, ' + all-gather of detections' if world > 1 else '')
+                                      + ('; %d steps in flight (each step = one whole batch on its own HIP stream and workspace)' % a.depth if a.depth > 1 else '')
                                       + ('; the -lite form = no squeeze-excite, ReLU6, and it KEEPS the width-scaled stem' if a.model.endswith('-lite') else ''),
                           'global_batch': b * world, 'parallelism': 'dp%d (image-sharded)' % world},
-               'p50_ms_b1': p50, 'roofline': roofline, 'roofline_family': roofline_family, 'roofline_step': roofline_step, 'incl_h2d': incl_h2d}
+               'steps_in_flight': a.depth, 'p50_ms_b1': p50, 'roofline': roofline, 'roofline_family': roofline_family, 'roofline_step': roofline_step, 'incl_h2d': incl_h2d}
         if p50 is not None:
             out['p50_ms_b1_detail'] = {'eager_launches': p50_eager, 'hip_graph_replay': p50_graph}
         if use_dist:

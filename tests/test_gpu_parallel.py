@@ -68,5 +68,64 @@ def test_single_rank_rccl_all_gather_of_detections(dev):
         torch.cuda.synchronize()
         for (d, c), (wd, wc) in zip(got, want):
             assert np.array_equal(d.cpu().numpy(), wd) and np.array_equal(c.cpu().numpy(), wc)
+        # two steps in flight (depth 2: each step on its own stream / workspace / buffers) with the overlapped collective
+        # reading the records behind the step's own completion event; a context runs again only after the collective that
+        # read its records is done (release).  Five steps over three different batches: every context is reused.
+        pipe2 = DetectionPipeline(m, ANCHORS, 20, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5, depth=2)
+        handles, got = [], []
+        order = [0, 1, 2, 0, 2]
+        for i in order:
+            det, cnt = pipe2(xs[i], hw)
+            h = g.start(det, cnt, pipe2.record, after=pipe2.done)
+            pipe2.release(h.released)
+            handles.append(h)
+            if len(handles) >= 2:
+                d, c = handles[-2].wait()
+                got.append((d.clone(), c.clone()))
+        d, c = handles[-1].wait()
+        got.append((d.clone(), c.clone()))
+        torch.cuda.synchronize()
+        for (d, c), i in zip(got, order):
+            assert np.array_equal(d.cpu().numpy(), want[i][0]) and np.array_equal(c.cpu().numpy(), want[i][1])
     finally:
         dist.destroy_process_group()
+
+
+def test_steps_in_flight_give_the_same_detections(dev):
+    """DetectionPipeline(depth=3): consecutive calls on three execution contexts (stream, model workspace, buffers each),
+    up to three steps in flight - the detections of every step equal those of the strictly serial pipeline, also when a
+    context is reused while its neighbours are still running, and a 16-bit plan behaves the same."""
+    from yoloret_amd import layers as L
+    from yoloret_amd.pipeline import DetectionPipeline
+    from yoloret_amd.weights import synthetic_weights
+    from yoloret_amd.yolo3.model import yolov3_body
+    for policy in ('float32', 'mixed_bfloat16'):
+        L.set_global_policy(policy)
+        try:
+            m = yolov3_body(L.Input(shape=[128, 128, 3]), 'efficientnetb0-lite', 3, num_classes=20)
+        finally:
+            L.set_global_policy('float32')
+        m.set_weights(synthetic_weights(m, 7, 'survey'))
+        b = 6
+        xs = [torch.from_numpy(params.synthetic_images(b, 128, 128, seed=s)).to(dev) for s in (11, 12, 13, 14)]
+        hw = torch.tensor([[128, 128]] * b, dtype=torch.int32, device=dev)
+        serial = DetectionPipeline(m, ANCHORS, 20, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5)
+        want = []
+        for x in xs:
+            det, cnt = serial(x, hw)
+            torch.cuda.synchronize()
+            want.append((det.cpu().numpy().copy(), cnt.cpu().numpy().copy()))
+        assert sum(int(c.sum()) for _, c in want) > 0
+        deep = DetectionPipeline(m, ANCHORS, 20, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5, depth=3)
+        order = [0, 1, 2, 3, 1, 0, 3, 2, 2]
+        outs = []
+        for i in order:
+            det, cnt = deep(xs[i], hw)
+            outs.append((det, cnt, deep.done, i))
+            if len(outs) >= 3:                      # consume the step issued two calls ago, before its context is reused
+                d, c, ev, j = outs[-3]
+                ev.synchronize()
+                assert np.array_equal(d.cpu().numpy(), want[j][0]) and np.array_equal(c.cpu().numpy(), want[j][1]), (policy, j)
+        torch.cuda.synchronize()
+        for d, c, ev, j in outs[-2:]:
+            assert np.array_equal(d.cpu().numpy(), want[j][0]) and np.array_equal(c.cpu().numpy(), want[j][1]), (policy, j)

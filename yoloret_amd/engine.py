@@ -153,7 +153,11 @@ class Model:
     def workspace_bytes(self, batch):
         return self.plan_for(batch).arena_bytes_per_image * batch
 
-    def __call__(self, x, out=None):
+    def __call__(self, x, out=None, ctx=0):
+        """ctx: execution context.  The plan handle is read-only during a forward; what a step owns is its WORKSPACE (the
+        arena of intermediate tensors).  Calls with different `ctx` use different workspaces and may therefore be in
+        flight at the same time on different HIP streams (pipeline.DetectionPipeline(depth=2)); calls with the same
+        `ctx` must be stream-ordered."""
         h, w, c = self.plan.input_shape
         if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
             raise ValueError('input must be a float32 CUDA tensor [B,%d,%d,%d] (NHWC)' % (h, w, c))
@@ -163,10 +167,11 @@ class Model:
         b = x.shape[0]
         idx, hd = self._handle(x.device, b)
         need = self.workspace_bytes(b)
-        ws = self._workspace.get(idx)
+        wkey = idx if ctx == 0 else (idx, ctx)
+        ws = self._workspace.get(wkey)
         if ws is None or ws.numel() < need:
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
-            self._workspace[idx] = ws
+            self._workspace[wkey] = ws
         ys = out
         if ys is None:
             ys = [torch.empty((b, ob.h, ob.w, ob.c), dtype=torch.float32, device=x.device)

@@ -27,6 +27,7 @@ class GatherHandle:
 
     def __init__(self, work, event, out, world, b, s, six, ready=None):
         self._work, self._event, self._out = work, event, out
+        self.released = None             # overlapped form: fires when the collective no longer reads the send buffer
         self._dims = (world, b, s, six)
         self._ready = ready              # single rank without a collective: the local (det, det_count) as they are
 
@@ -76,9 +77,12 @@ class DetectionGatherer:
             record = self._send
         return record, words
 
-    def start(self, det, det_count, record=None, overlap=True):
+    def start(self, det, det_count, record=None, overlap=True, after=None):
         """det int32 [b, S, 6], det_count int32 [b] (local shard); `record`: the flat buffer both are views of
-        (DetectionPipeline.record) - sent as is; without it the two tensors are first staged into one message."""
+        (DetectionPipeline.record) - sent as is; without it the two tensors are first staged into one message.
+        after: the event that marks the records complete when they were produced on ANOTHER stream than the current one
+        (DetectionPipeline(depth > 1).done); default: everything enqueued on the current stream so far.  The handle's
+        `released` event (overlapped form) fires when the collective has read the records."""
         b, s, six = det.shape
         if self.world == 1 and not self.always:
             return GatherHandle(None, None, det, 1, b, s, six, ready=(det, det_count))
@@ -93,8 +97,10 @@ class DetectionGatherer:
             return GatherHandle(None, None, out, self.world, b, s, six)
         if self._stream is None or self._stream.device != det.device:
             self._stream = torch.cuda.Stream(device=det.device)
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(det.device))          # after the step's pack kernel
+        ready = after
+        if ready is None:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(det.device))      # after the step's pack kernel
         with torch.cuda.stream(self._stream):
             self._stream.wait_event(ready)
             record.record_stream(self._stream)
@@ -103,7 +109,9 @@ class DetectionGatherer:
             work.wait()                                              # orders the side stream behind the collective
             done = torch.cuda.Event()
             done.record(self._stream)
-        return GatherHandle(None, done, out, self.world, b, s, six)
+        h = GatherHandle(None, done, out, self.world, b, s, six)
+        h.released = done
+        return h
 
     def __call__(self, det, det_count, record=None):
         """det int32 [b, S, 6], det_count int32 [b] (local shard) -> ([W*b, S, 6], [W*b])."""
