@@ -48,7 +48,7 @@ def parse():
     ap.add_argument('--per-op', action='store_true', help='also print the per-op table to stderr')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise RCCL and issue the detection all-gather even with one rank (single-GPU check of the N>1 path)')
-    ap.add_argument('--depth', type=int, default=2,
+    ap.add_argument('--depth', type=int, default=3,
                     help='steps in flight (DetectionPipeline(depth=..)): consecutive steps run on consecutive execution contexts / HIP '
                          'streams and fill each other\'s idle CUs; 1 = strictly one step after the other')
     ap.add_argument('--no-latency', action='store_true',

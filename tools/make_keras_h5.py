@@ -12,6 +12,10 @@ layers.json : [[layer name, keras class, explicitly_named], ...] in CREATION ord
               creation order; --gap-every N skips one number after every N-th such layer (the reference creates layers
               that never reach the saved model: discarded `y` convs, EfficientNet's top conv).  Layer groups are written
               in SORTED name order, not creation order, so a reader cannot lean on the file order.
+              A row whose layer name is null is a GHOST: a layer of that class the reference creates at that point but
+              which never reaches the saved model - it takes its number and nothing is written (the second backbone
+              `backbone_transfer` built only to copy ImageNet weights from, code/yolo3/model.py:180-181,193-194,206-207,
+              shifts every head layer's index by the backbone's layer count).
 """
 import json
 import sys
@@ -32,11 +36,12 @@ def main():
     layers = json.load(open(layers_json))
     counters, names = {}, {}
     for lname, cls, explicit in layers:
-        if explicit:
+        if explicit and lname is not None:
             names[lname] = lname
             continue
         i = counters.get(cls, 0)
-        names[lname] = cls if i == 0 else '%s_%d' % (cls, i)
+        if lname is not None:
+            names[lname] = cls if i == 0 else '%s_%d' % (cls, i)
         i += 1
         if gap and i % gap == 0:
             i += 1

@@ -606,8 +606,9 @@ __global__ __launch_bounds__(T, (T <= 256 ? NMS_BAND_WPE : 4)) void nms_band_ker
         }
         __syncthreads();
         const int lo = lo_s;
-        if (lo >= NB) {                      // the next bin alone overflows a band: the second pass redoes the problem
-            if (tid == 0) a.out_count[(size_t)b * a.C + c] = -1;
+        if (lo >= NB) {                      // the next bin alone overflows THIS band capacity
+            if (bcap < T) continue;          // (workgroup-uniform) a wider band may still hold it: 65..T equal or near-equal scores
+            if (tid == 0) a.out_count[(size_t)b * a.C + c] = -1;   // ... more than a band can ever hold: the second pass redoes the problem
             return;
         }
         {   // compact the band from the registers: per-lane count, wave scan, ONE LDS atomic per wave, then the writes

@@ -181,6 +181,7 @@ class File(Group):
             p += szlen
             blocks = [(p, chunk0)]
             tracked = bool(flags & 0x04)
+            seen = {p}
             while blocks:
                 p, n = blocks.pop(0)
                 end = p + n
@@ -193,6 +194,9 @@ class File(Group):
                         caddr, clen = struct.unpack_from('<QQ', body)
                         if self._read(caddr, 4) != b'OCHK':
                             raise H5Error('bad object-header continuation block')
+                        if caddr + 4 in seen or len(seen) > 4096:
+                            raise H5Error('object-header continuation blocks form a cycle')
+                        seen.add(caddr + 4)
                         blocks.append((caddr + 4, clen - 8))       # minus signature and checksum
                     elif mtype != 0:
                         msgs.append((mtype, mflags, body))
@@ -203,6 +207,7 @@ class File(Group):
         nmsg = self._u(addr + 2, 2)
         hsize = self._u(addr + 8, 4)
         blocks = [(addr + 16, hsize)]
+        seen = {addr + 16}
         while blocks and len(msgs) < nmsg + 64:
             p, n = blocks.pop(0)
             end = p + n
@@ -212,6 +217,9 @@ class File(Group):
                 p += 8 + msize
                 if mtype == 0x10:
                     caddr, clen = struct.unpack_from('<QQ', body)
+                    if caddr in seen or len(seen) > 4096:     # a block pointing back at itself would never end
+                        raise H5Error('object-header continuation blocks form a cycle')
+                    seen.add(caddr)
                     blocks.append((caddr, clen))
                 elif mtype != 0:
                     msgs.append((mtype, mflags, body))
@@ -475,23 +483,35 @@ def read_keras_weights(path_or_bytes):
         return _read_keras_weights(path_or_bytes)
     except H5Error:
         raise
-    except (ValueError, IndexError, KeyError, struct.error, zlib.error, OverflowError) as e:
+    except (ValueError, IndexError, KeyError, struct.error, zlib.error, OverflowError, RecursionError) as e:   # (RecursionError: a cyclic B-tree)
         raise H5Error('corrupt or truncated HDF5 file (%s: %s)' % (type(e).__name__, e))
 
 
 def _read_keras_weights(path_or_bytes):
     f = File(path_or_bytes)
-    root = f['model_weights'] if 'layer_names' not in f.attrs and 'model_weights' in f else f
-    if 'layer_names' not in root.attrs:
-        raise H5Error('no "layer_names" attribute: not a Keras weights file')
+    root = f['model_weights'] if 'layer_names' not in f.attrs and 'layer_names0' not in f.attrs and 'model_weights' in f else f
 
     def strs(v):
         return [x.decode('utf8') if isinstance(x, bytes) else str(x) for x in np.asarray(v, dtype=object).ravel()]
+
+    def names(attrs, key):
+        """Keras splits a name list that would exceed HDF5's 64 KB attribute limit into `key`0, `key`1, ...
+        (keras/saving/hdf5_format.py: save_attributes_to_hdf5_group)."""
+        if key in attrs:
+            return strs(attrs[key])
+        out, i = [], 0
+        while '%s%d' % (key, i) in attrs:
+            out += strs(attrs['%s%d' % (key, i)])
+            i += 1
+        return out if i else None
+    lnames = names(root.attrs, 'layer_names')
+    if lnames is None:
+        raise H5Error('no "layer_names" attribute: not a Keras weights file')
     out = {}
-    for lname in strs(root.attrs['layer_names']):
+    for lname in lnames:
         g = root[lname]
         wd = {}
-        for wname in strs(g.attrs.get('weight_names', [])):
+        for wname in names(g.attrs, 'weight_names') or []:
             arr = g[wname].read()
             base = wname.split('/')[-1].split(':')[0]
             if base in wd:

@@ -161,6 +161,10 @@ class DetectionPipeline:
     use_graph = False
 
     def enable_graph(self, on=True):
+        if on and (self.record_slots > 1 or self.depth > 1):
+            # a captured graph writes the record buffer it was captured with: the slots would stop rotating and a step could
+            # overwrite records an overlapped all-gather is still reading
+            raise ValueError('enable_graph: graph replay needs record_slots == 1 and depth == 1')
         self.use_graph = bool(on)
         if not on:
             self._graphs = {}

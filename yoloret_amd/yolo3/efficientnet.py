@@ -58,6 +58,9 @@ class BlockDecoder(object):
         if 'strides' not in fields or len(fields['strides'][0]) != 2:
             raise ValueError('Strides options should be a pair of integers.')
         values = {name: parse(raw) for name, (raw, parse) in fields.items()}
+        for prefix, (name, _, _) in _TOKENS.items():      # the reference indexes options['r'], ['k'], ... : KeyError
+            if prefix != 'se' and name not in values:
+                raise KeyError(prefix)
         values.setdefault('se_ratio', None)
         return BlockArgs(id_skip='noskip' not in block_string, **values)
 
@@ -68,7 +71,7 @@ class BlockDecoder(object):
             if prefix == 's':
                 parts.append('s%d%d' % tuple(value[:2]))
             elif prefix == 'se':
-                if value is not None and 0 < value <= 1:
+                if 0 < value <= 1:     # (se_ratio None: TypeError, as in the reference's comparison)
                     parts.append('se%s' % value)
             else:
                 parts.append(prefix + fmt % value)
