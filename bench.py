@@ -178,6 +178,7 @@ def main():
     image_hw = torch.tensor([[a.size, a.size]] * b, dtype=torch.int32, device=dev)
 
     pending = [None]
+    consumer = torch.cuda.Stream(dev) if a.depth > 1 else torch.cuda.current_stream(dev)
 
     def step():
         # N > 1: the all-gather of step i's records runs on a second stream while step i+1's forward is enqueued; its
@@ -188,7 +189,12 @@ def main():
         if h.released is not None:
             pipe.release(h.released)          # the context that produced these records runs again only after the collective read them
         prev, pending[0] = pending[0], h
-        return prev.wait() if prev is not None else None
+        if prev is None:
+            return None
+        # the consumer of the gathered detections waits on ITS stream: on the launch stream the wait would sit in front of
+        # the next step's `ready` event and tie every step to the collective two steps back (measured: 24.7k vs 28.4k img/s)
+        with torch.cuda.stream(consumer):
+            return prev.wait()
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -361,6 +367,7 @@ def main():
         step_s = b / per_gpu
         alg_gbs = per_gpu * alg_img / 1e9
         moved_min = sum(r.get('hbm_bytes', r['bytes']) for r in rows)     # per step: every op's sources + output
+        macs16_img = sum(r.get('macs_mfma16', 0) for r in rows) / b       # multiply-adds per image on the 16-bit matrix pipe
         fp32_roof = FP32_PEAK_TFLOPS * 1e12 / flops_img                   # img/s if the float32 pipe were the only limit
         # `achieved` / `frac` follow SURVEY.md 8(d)'s agreed accounting: conv-granular ALGORITHMIC bytes (a fused kernel is
         # credited the bytes of the convolutions it replaces) - a measure of work done per second, NOT of bandwidth used.
@@ -377,7 +384,11 @@ def main():
                          'moved_gbs_pmc': round(pmc_step_bytes / step_s / 1e9, 1) if pmc_step_bytes else None,
                          'frac_hbm_moved_pmc': round(pmc_step_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4) if pmc_step_bytes else None,
                          'tflops': round(per_gpu * flops_img / 1e12, 2),
-                         'frac_fp32_peak': round(per_gpu * flops_img / 1e12 / FP32_PEAK_TFLOPS, 4),
+                         # by pipe: the multiply-adds of a 16-bit plan's 1x1 convolutions run on the 16-bit matrix pipe
+                         'tflops_mfma16': round(per_gpu * 2.0 * macs16_img / 1e12, 2),
+                         'frac_mfma16_peak': round(per_gpu * 2.0 * macs16_img / 1e12 / MFMA16_PEAK_TFLOPS, 4),
+                         'tflops_fp32': round(per_gpu * (flops_img - 2.0 * macs16_img) / 1e12, 2),
+                         'frac_fp32_peak': round(per_gpu * (flops_img - 2.0 * macs16_img) / 1e12 / FP32_PEAK_TFLOPS, 4),
                          'fp32_roofline_img_s': round(fp32_roof, 0),
                          'hbm_roofline_img_s': round(HBM_PEAK_GBS * 1e9 / alg_img, 0),
                          'sum_kernel_ms': round(sum(r['ms'] for r in rows), 3),

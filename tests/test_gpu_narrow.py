@@ -197,7 +197,10 @@ def test_pointwise16_tile_shapes_are_bit_identical(dev, dt, ci):
                                            # kernel, wider than one 32-column tile
                                            (5, 1, 13, 13, 200, 'relu6'), (5, 1, 20, 20, 72, 'swish'), (5, 1, 40, 40, 136, 'relu6'),
                                            (5, 1, 7, 45, 64, 'none'), (5, 1, 37, 9, 100, 'swish'), (5, 1, 3, 3, 64, 'relu6'),
-                                           (5, 1, 26, 26, 96, 'leaky')])
+                                           (5, 1, 26, 26, 96, 'leaky'),
+                                           # 3x3 stride 1 with 64 channels or more: the same LDS-tiled form (heads: 52 x 52 x 128 ... 13 x 13 x 512)
+                                           (3, 1, 52, 52, 128, 'swish'), (3, 1, 26, 26, 256, 'relu6'), (3, 1, 13, 13, 512, 'swish'), (3, 1, 7, 45, 64, 'none'),
+                                           (3, 1, 37, 9, 100, 'leaky'), (3, 1, 2, 2, 72, 'relu6')])
 def test_depthwise16(dev, dt, k, s, h, w, c, act):
     rt = _rt()
     did = rt.dtype_id(dt)
@@ -563,8 +566,8 @@ def test_depthwise_se_form(dev, dt, k, s, h, w, c, r):
     rows = dw_se_geometry(ho * ((wo + xt - 1) // xt), c4)[2]
     if c4 <= 256 and 256 % c4 == 0:
         assert rows == (ho * ((wo + xt - 1) // xt) * c4 + 255) // 256
-    if DW_LDS and dt != 'f32' and k == 5 and s == 1 and c >= 64:     # the LDS-tiled form: one row per tile
-        ntx, nty = dwl_geometry(ho, wo)
+    if DW_LDS and dt != 'f32' and k in (3, 5) and s == 1 and c >= 64:     # the LDS-tiled form: one row per tile
+        ntx, nty = dwl_geometry(ho, wo, k)
         rows = ntx * nty
     part = torch.full((b, rows, ldc), float('nan'), dtype=torch.float32, device=dev)
     fused = dw(part, rows)

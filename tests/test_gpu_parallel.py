@@ -129,3 +129,81 @@ def test_steps_in_flight_give_the_same_detections(dev):
         torch.cuda.synchronize()
         for d, c, ev, j in outs[-2:]:
             assert np.array_equal(d.cpu().numpy(), want[j][0]) and np.array_equal(c.cpu().numpy(), want[j][1]), (policy, j)
+
+
+def _two_rank_worker(rank, world, port, q):
+    """One of two processes sharing the GPU: its contiguous shard of the global batch through a depth-2 pipeline (two steps
+    in flight on two streams), the records of both steps gathered over a 2-rank gloo group (host tensors)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from yoloret_amd import layers as L
+    from yoloret_amd.parallel import DetectionGatherer, shard_range
+    from yoloret_amd.pipeline import DetectionPipeline
+    from yoloret_amd.weights import synthetic_weights
+    from yoloret_amd.yolo3.model import yolov3_body
+    dev = torch.device('cuda:0')
+    m = yolov3_body(L.Input(shape=[96, 96, 3]), 'mobilenetv2x75', 3, num_classes=20)
+    m.set_weights(synthetic_weights(m, 5, 'survey'))
+    gb = 8
+    lo, hi = shard_range(gb, rank, world)
+    pipe = DetectionPipeline(m, ANCHORS, 20, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5, depth=2)
+    g = DetectionGatherer()
+    hw = torch.tensor([[96, 96]] * (hi - lo), dtype=torch.int32, device=dev)
+    outs = []
+    # consume as you go: step i is gathered before step i + 2 (which rewrites its context's buffers) is issued
+    pend = []
+    for seed in (1, 2, 3):
+        x = torch.from_numpy(params.synthetic_images(gb, 96, 96, seed=seed)[lo:hi]).to(dev)
+        if len(pend) == 2:
+            det, cnt, done = pend.pop(0)
+            done.synchronize()
+            outs.append(tuple(t.clone() for t in g(det.cpu(), cnt.cpu())))    # (the gatherer's result buffers alternate)
+        det, cnt = pipe(x, hw)
+        pend.append((det, cnt, pipe.done))
+    for det, cnt, done in pend:
+        done.synchronize()
+        outs.append(tuple(t.clone() for t in g(det.cpu(), cnt.cpu())))
+    q.put((rank, [(d.numpy().copy(), c.numpy().copy()) for d, c in outs]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_reproduce_the_single_rank_records(dev):
+    """Two processes on the one GPU (one shard each, depth-2 pipelines = four streams in all) + a 2-rank gloo all-gather of
+    the packed records == the records of the whole batch run by a single serial pipeline, for three consecutive batches:
+    sharding, steps in flight and the collective's row order together (the RCCL form of the collective is
+    test_single_rank_rccl_all_gather_of_detections)."""
+    import torch.multiprocessing as mp
+    from yoloret_amd import layers as L
+    from yoloret_amd.pipeline import DetectionPipeline
+    from yoloret_amd.weights import synthetic_weights
+    from yoloret_amd.yolo3.model import yolov3_body
+    m = yolov3_body(L.Input(shape=[96, 96, 3]), 'mobilenetv2x75', 3, num_classes=20)
+    m.set_weights(synthetic_weights(m, 5, 'survey'))
+    serial = DetectionPipeline(m, ANCHORS, 20, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5)
+    hw = torch.tensor([[96, 96]] * 8, dtype=torch.int32, device=dev)
+    want = []
+    for seed in (1, 2, 3):
+        det, cnt = serial(torch.from_numpy(params.synthetic_images(8, 96, 96, seed=seed)).to(dev), hw)
+        torch.cuda.synchronize()
+        want.append((det.cpu().numpy().copy(), cnt.cpu().numpy().copy()))
+    assert sum(int(c.sum()) for _, c in want) > 0
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        assert len(res[rank]) == 3
+        for (d, c), (wd, wc) in zip(res[rank], want):
+            assert np.array_equal(d, wd) and np.array_equal(c, wc), 'rank %d' % rank

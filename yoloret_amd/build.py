@@ -82,9 +82,21 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     procs = []
     objs = []
+    # incremental: a source is recompiled when it, any header, this file or the flags are newer than its object (or --force)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [os.path.join(HERE, '..', 'include', 'yoloret_hip.h'),
+                                                                                       os.path.abspath(__file__)]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    try:
+        same_flags = open(FLAGS_FILE).read() == ' '.join(FLAGS)
+    except OSError:
+        same_flags = False
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace('.hip', '.o'))
         objs.append(obj)
+        regs = os.path.join(objdir, src.replace('.hip', '.regs.txt'))
+        if (not force and same_flags and os.path.exists(obj) and os.path.exists(regs)
+                and os.path.getmtime(obj) > max(newest_header, os.path.getmtime(os.path.join(CSRC, src)))):
+            continue
         cmd = [hipcc] + FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd))

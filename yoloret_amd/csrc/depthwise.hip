@@ -283,7 +283,7 @@ static int launch_depthwise_t(const yr_op& op, int batch, hipStream_t s) {
     a.act = op.act;
     a.part = nullptr; a.ld_part = 0; a.cw = 1; a.ncb = 1;
     if (op.gate) YR_REQUIRE(op.gate_ld % 4 == 0 && op.gate_ld >= yr_round_up(in.c, V) && ((uintptr_t)op.gate % 16) == 0, "depthwise: bad SE partial-sum buffer");
-    // 16-bit 5x5 stride 1 on maps with at least one 64-channel chunk: the LDS-tiled form (depthwise_lds.hip, bit-identical
+    // 16-bit 5x5 / 3x3 stride 1 on maps with at least one 64-channel chunk: the LDS-tiled form (depthwise_lds.hip, bit-identical
     // maps; its SE rows are its tiles - compiler.se_partials_from_depthwise sizes the buffer for whichever form
     // YOLORET_DW_LDS selects, 0 keeps this kernel for A/B runs)
     if constexpr (sizeof(T) == 2) {
@@ -292,8 +292,8 @@ static int launch_depthwise_t(const yr_op& op, int batch, hipStream_t s) {
 #else
         static const bool lds_form = !(getenv("YOLORET_DW_LDS") && atoi(getenv("YOLORET_DW_LDS")) == 0);
 #endif
-        if (lds_form && op.k == 5 && op.stride == 1 && in.c >= 64)
-            return yr_launch_depthwise_lds5(op.dtype, in.ptr, op.wgt, op.scale, op.shift, op.out, batch, in.h, in.w, a.C4, a.ld_in, a.ld_w, a.ld_out,
+        if (lds_form && (op.k == 5 || op.k == 3) && op.stride == 1 && in.c >= 64)
+            return yr_launch_depthwise_lds(op.dtype, op.k, in.ptr, op.wgt, op.scale, op.shift, op.out, batch, in.h, in.w, a.C4, a.ld_in, a.ld_w, a.ld_out,
                                             a.pad_t, a.pad_l, a.act, const_cast<float*>(op.gate), op.gate_ld, op.se_reduced, s);
     }
     if (op.gate) {   // SE form: `gate` is an OUTPUT here - float32 [B][workgroups per image][gate_ld] channel sums

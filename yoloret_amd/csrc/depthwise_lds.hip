@@ -1,7 +1,9 @@
-// Depthwise 5x5 stride-1 convolution on 16-bit maps, LDS-tiled: the form for the wide EfficientNet stages whose blocks the
-// fused kernels do not take (more than 128 block inputs: efficientnet.py:501-510 with kernel_size 5).  Same arithmetic as
-// dw_kernel<5,1,..> - float32 accumulation in (ky, kx) order, BatchNorm, activation, one rounding on store - so the two
-// forms are bit-identical; only the data movement differs:
+// Depthwise K x K (K = 5 | 3) stride-1 convolution on 16-bit maps, LDS-tiled: the form for the wide EfficientNet stages whose
+// blocks the fused kernels do not take (more than 128 block inputs: efficientnet.py:501-510 with kernel_size 5) and - K = 3,
+// round 3 - for the detection heads' MBConv depthwise stages (code/yolo3/model.py:98-114: 52 x 52 x 128 ... 13 x 13 x 512,
+// squeeze-excite form) and every other 16-bit 3 x 3 map with 64 channels or more.  Same arithmetic as dw_kernel<K,1,..> -
+// float32 accumulation in (ky, kx) order, BatchNorm, activation, one rounding on store - so the two forms are
+// bit-identical; only the data movement differs (described for K = 5; K = 3: 9 taps, a ring of 3 rows, 6 columns per row):
 //
 //   dw_kernel: lane = 4 outputs x 8 channels straight from global memory.  Every input element is fetched and widened by
 //   ten lanes, the 25 x 8 float32 tap weights are re-fetched per lane (more load instructions than the data itself), and
@@ -55,9 +57,10 @@ __device__ __forceinline__ float dwl_act(float v, int act) {
 
 constexpr int DWL_STAGE_U = 10;   // 16-byte loads in flight per lane while staging: the usual tile (up to 320 halo pixels) in ONE round trip
 
-template <class T, int ACT, bool SE>
-__global__ __launch_bounds__(256) void dwl5_kernel(DwlArgs a) {
-    extern __shared__ unsigned dwl_tile[];   // [th + 4][32][twp]
+template <class T, int K, int ACT, bool SE>
+__global__ __launch_bounds__(256) void dwl_kernel(DwlArgs a) {
+    constexpr int HALO = K - 1, KK = K * K, NQ = (4 + HALO) / 2;   // extra rows / columns of the window; taps; 8-byte reads per input row
+    extern __shared__ unsigned dwl_tile[];   // [th + HALO][32][twp]
     const unsigned lin = yr_xcd_swizzle(blockIdx.x, a.nblocks);
     // spatially adjacent tiles of one channel chunk are consecutive: their halos meet in one XCD's L2
     const int tx = (int)(lin % (unsigned)a.ntx);
@@ -77,17 +80,17 @@ __global__ __launch_bounds__(256) void dwl5_kernel(DwlArgs a) {
     const int cfirst = cc * 64 + cp * 2;
     const bool chan_ok = cfirst < a.C8 * 8;
     const int cl = chan_ok ? cfirst : 0;
-    dwl_f2 w[25];
+    dwl_f2 w[KK];
 #pragma unroll
-    for (int k = 0; k < 25; ++k) w[k] = *reinterpret_cast<const dwl_f2*>(a.w + (size_t)k * a.ld_w + cl);
+    for (int k = 0; k < KK; ++k) w[k] = *reinterpret_cast<const dwl_f2*>(a.w + (size_t)k * a.ld_w + cl);
     const dwl_f2 sc = *reinterpret_cast<const dwl_f2*>(a.scale + cl);
     const dwl_f2 sh = *reinterpret_cast<const dwl_f2*>(a.shift + cl);
 
     // ---- stage the halo tile: thread = (channel vector cv, pixel slot); pixels walk the tile row-major in steps of 32
     {
         const int cv = tid & 7, slot = tid >> 3;
-        const int cols = a.tw + 4;
-        const int npix = (rows_here + 4) * cols;
+        const int cols = a.tw + HALO;
+        const int npix = (rows_here + HALO) * cols;
         const bool cv_ok = cc * 8 + cv < a.C8;
         const T* base = reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * a.ld_in + (size_t)(cv_ok ? cc * 8 + cv : 0) * 8;
         int r = slot / cols, j = slot - r * cols;
@@ -132,43 +135,43 @@ __global__ __launch_bounds__(256) void dwl5_kernel(DwlArgs a) {
 #ifdef YR_DW_EXPERIMENT
     if (a.dbg == 1) nrows = 0;
 #endif
-    const int nin = nrows > 0 ? nrows + 4 : 0;
+    const int nin = nrows > 0 ? nrows + HALO : 0;
     const int xo = x0 + strip * 4;
     T* orow = reinterpret_cast<T*>(a.out) + (((size_t)b * a.H + y0 + yb0) * a.W + xo) * a.ld_out + cl;
     const unsigned* trow = dwl_tile + (yb0 * 32 + cp) * a.twp + strip * 4;
     const int tpitch = 32 * a.twp;
     dwl_f2 psum = (dwl_f2){0.f, 0.f};   // SE: what this lane stored, per channel (rounded values, fixed order)
-    dwl_f2 acc[5][4];
+    dwl_f2 acc[K][4];
 #pragma unroll
-    for (int s = 0; s < 5; ++s)
+    for (int s = 0; s < K; ++s)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[s][i] = (dwl_f2){0.f, 0.f};
-    for (int rr0 = 0; rr0 < nin; rr0 += 5) {
+    for (int rr0 = 0; rr0 < nin; rr0 += K) {
 #pragma unroll
-        for (int ph = 0; ph < 5; ++ph) {
+        for (int ph = 0; ph < K; ++ph) {
             const int rr = rr0 + ph;
             if (rr < nin) {
                 const uint2* p = reinterpret_cast<const uint2*>(trow + rr * tpitch);
-                const uint2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                dwl_f2 col[8];
-                col[0] = dwl_widen<T>(q0.x); col[1] = dwl_widen<T>(q0.y);
-                col[2] = dwl_widen<T>(q1.x); col[3] = dwl_widen<T>(q1.y);
-                col[4] = dwl_widen<T>(q2.x); col[5] = dwl_widen<T>(q2.y);
-                col[6] = dwl_widen<T>(q3.x); col[7] = dwl_widen<T>(q3.y);
+                dwl_f2 col[2 * NQ];
 #pragma unroll
-                for (int ky = 0; ky < 5; ++ky) {
-                    const int s = (ph - ky + 5) % 5;
+                for (int q = 0; q < NQ; ++q) {
+                    const uint2 v = p[q];
+                    col[2 * q] = dwl_widen<T>(v.x);
+                    col[2 * q + 1] = dwl_widen<T>(v.y);
+                }
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) {
+                    const int s = (ph - ky + K) % K;
                     if (rr - ky >= 0 && rr - ky < nrows) {   // an output row of this band (the bands of a wave agree except at the tile's last rows)
 #pragma unroll
-                        for (int kx = 0; kx < 5; ++kx)
+                        for (int kx = 0; kx < K; ++kx)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) acc[s][i] = __builtin_elementwise_fma(col[i + kx], w[ky * 5 + kx], acc[s][i]);
+                            for (int i = 0; i < 4; ++i) acc[s][i] = __builtin_elementwise_fma(col[i + kx], w[ky * K + kx], acc[s][i]);
                     }
                 }
-                constexpr int DONE[5] = {1, 2, 3, 4, 0};   // (ph + 1) % 5: the slot of output row rr - 4
-                const int sd = DONE[ph];
-                if (rr >= 4) {
-                    T* op = orow + (size_t)(rr - 4) * a.W * a.ld_out;
+                const int sd = (ph + 1) % K;               // the slot of output row rr - HALO
+                if (rr >= HALO) {
+                    T* op = orow + (size_t)(rr - HALO) * a.W * a.ld_out;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const dwl_f2 y = __builtin_elementwise_fma(acc[sd][i], sc, sh);
@@ -204,13 +207,17 @@ __global__ __launch_bounds__(256) void dwl5_kernel(DwlArgs a) {
 // bands as still fit.  Among the tile widths, take the one with the least lane-time: workgroups x (rows a lane walks + the
 // 4 extra input rows of its band + its share of staging the halo tile), the tile height being what a third of a CU's LDS
 // holds.  40x40 -> 8 x 20 tiles in 4 bands of 5 rows, 20x20 -> 8 x 20, 13x13 -> 16 x 13 in 2 bands.
-static void dwl_geometry(int H, int W, DwlArgs* a) {
+static void dwl_geometry(int H, int W, int K, DwlArgs* a) {
+    const int halo = K - 1;
+    // cost of one output row of a lane, of one warm-up row of its band (fewer taps land), of staging one halo pixel - fitted
+    // to tools/dw5_probe.py for K = 5, scaled by the taps for K = 3
+    const long long row_cost = K == 5 ? 8000 : 3600, warm_cost = K == 5 ? 1280 : 576;
     long long best = 0;
     for (int tw = 4; tw <= 32; tw += 4) {
         const int nstrip = tw / 4, twp = tw + 6;
         const int ntx = (W + tw - 1) / tw;
         const int row_bytes = 32 * twp * 4;
-        int th = 48 * 1024 / row_bytes - 4;
+        int th = 48 * 1024 / row_bytes - halo;
         if (th > H) th = H;
         if (th < 4) th = 4;
         const int nty = (H + th - 1) / th;
@@ -219,8 +226,8 @@ static void dwl_geometry(int H, int W, DwlArgs* a) {
         if (nband > th) nband = th;
         const int band_rows = (th + nband - 1) / nband;
         nband = (th + band_rows - 1) / band_rows;
-        // in 1/8000 of the time of one output row of a lane (integers: compiler.dwl_geometry must pick the same tile)
-        const long long cost = (long long)(ntx * nty) * (8000 * band_rows + 5120 + 30 * (tw + 4) * (th + 4));
+        // integers: compiler.dwl_geometry must pick the same tile
+        const long long cost = (long long)(ntx * nty) * (row_cost * band_rows + warm_cost * halo + 30 * (tw + halo) * (th + halo));
         if (best == 0 || cost < best) {
             best = cost;
             a->ntx = ntx; a->tw = tw; a->twp = twp; a->nstrip = nstrip;
@@ -229,43 +236,51 @@ static void dwl_geometry(int H, int W, DwlArgs* a) {
     }
 }
 
-template <class T, bool SE>
-static int launch_dwl5_t(DwlArgs a, int expect_rows, hipStream_t s) {
-    dwl_geometry(a.H, a.W, &a);
+template <class T, int K, bool SE>
+static int launch_dwl_t(DwlArgs a, int expect_rows, hipStream_t s) {
+    constexpr int HALO = K - 1;
+    dwl_geometry(a.H, a.W, K, &a);
     if (SE) YR_REQUIRE(a.ntx * a.nty == expect_rows, "depthwise (LDS form): the SE partial-sum buffer must hold %d rows per image (has %d)", a.ntx * a.nty, expect_rows);
     a.ncc = (a.C8 + 7) / 8;
-    a.step_r = 32 / (a.tw + 4); a.step_j = 32 % (a.tw + 4);
+    a.step_r = 32 / (a.tw + HALO); a.step_j = 32 % (a.tw + HALO);
     {
-        const int items = ((a.th + 4) * (a.tw + 4) + 31) / 32, rounds = (items + DWL_STAGE_U - 1) / DWL_STAGE_U;
+        const int items = ((a.th + HALO) * (a.tw + HALO) + 31) / 32, rounds = (items + DWL_STAGE_U - 1) / DWL_STAGE_U;
         a.stage_u = (items + rounds - 1) / rounds;
     }
     const long long blocks = (long long)a.B * a.ncc * a.nty * a.ntx;
     YR_REQUIRE(blocks < (1ll << 31), "depthwise: grid too large");
     a.nblocks = (unsigned)blocks;
     a.dbg = getenv("YR_DWL_DBG") ? atoi(getenv("YR_DWL_DBG")) : 0;
-    const size_t lds = (size_t)(a.th + 4) * 32 * a.twp * 4;
+    const size_t lds = (size_t)(a.th + HALO) * 32 * a.twp * 4;
     static char nm[40];
-    static const int nm_len = snprintf(nm, sizeof(nm), "dwl5_kernel<%s,%d>", yr_dtype_name(yr_elem<T>::dtype), (int)SE);
+    static const int nm_len = snprintf(nm, sizeof(nm), "dwl%d_kernel<%s,%d>", K, yr_dtype_name(yr_elem<T>::dtype), (int)SE);
     (void)nm_len;
     yr_note_kernel(nm);
-    if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((dwl5_kernel<T, 0, SE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
-    else if (a.act == YR_ACT_SWISH) hipLaunchKernelGGL((dwl5_kernel<T, 1, SE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((dwl5_kernel<T, 2, SE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((dwl_kernel<T, K, 0, SE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    else if (a.act == YR_ACT_SWISH) hipLaunchKernelGGL((dwl_kernel<T, K, 1, SE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((dwl_kernel<T, K, 2, SE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     YR_LAUNCH_CHECK();
     return YR_OK;
 }
 
-int yr_launch_depthwise_lds5(int dtype, const void* in, const float* w, const float* scale, const float* shift, void* out, int B, int H, int W,
-                             int C8, int ld_in, int ld_w, int ld_out, int pad_t, int pad_l, int act, float* part, int ld_part, int part_rows,
-                             hipStream_t s) {
+template <class T>
+static int launch_dwl_k(const DwlArgs& a, int k, int part_rows, hipStream_t s) {
+    if (k == 5) return a.part ? launch_dwl_t<T, 5, true>(a, part_rows, s) : launch_dwl_t<T, 5, false>(a, 0, s);
+    return a.part ? launch_dwl_t<T, 3, true>(a, part_rows, s) : launch_dwl_t<T, 3, false>(a, 0, s);
+}
+
+int yr_launch_depthwise_lds(int dtype, int k, const void* in, const float* w, const float* scale, const float* shift, void* out, int B, int H, int W,
+                            int C8, int ld_in, int ld_w, int ld_out, int pad_t, int pad_l, int act, float* part, int ld_part, int part_rows,
+                            hipStream_t s) {
+    if (k != 3 && k != 5) { yr_set_error("depthwise (LDS form): 3 x 3 and 5 x 5 only"); return YR_ERR_ARG; }
     DwlArgs a;
     a.in = in; a.w = w; a.scale = scale; a.shift = shift; a.out = out;
     a.B = B; a.H = H; a.W = W; a.C8 = C8;
     a.ld_in = ld_in; a.ld_w = ld_w; a.ld_out = ld_out;
     a.pad_t = pad_t; a.pad_l = pad_l; a.act = act;
     a.part = part; a.ld_part = ld_part;
-    if (dtype == YR_BF16) return part ? launch_dwl5_t<yr_bf16, true>(a, part_rows, s) : launch_dwl5_t<yr_bf16, false>(a, 0, s);
-    if (dtype == YR_F16) return part ? launch_dwl5_t<yr_f16, true>(a, part_rows, s) : launch_dwl5_t<yr_f16, false>(a, 0, s);
+    if (dtype == YR_BF16) return launch_dwl_k<yr_bf16>(a, k, part_rows, s);
+    if (dtype == YR_F16) return launch_dwl_k<yr_f16>(a, k, part_rows, s);
     yr_set_error("depthwise (LDS form): 16-bit maps only");
     return YR_ERR_ARG;
 }

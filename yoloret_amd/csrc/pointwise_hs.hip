@@ -209,15 +209,19 @@ static int launch_s(const PwArgs& a, int mode, int target_wgs, hipStream_t s) {
     if ((npairs + nsplit - 1) / nsplit > PWHS_MAX_PAIRS) nsplit = (npairs + PWHS_MAX_PAIRS - 1) / PWHS_MAX_PAIRS;
     const int per = (npairs + nsplit - 1) / nsplit;
     nsplit = (npairs + per - 1) / per;
-    static char nm[3][48];
-    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "pwhs_kernel<%s,%d,%d,0>", yr_dtype_name(yr_elem<T>::dtype), PT, NCH) +
-                              snprintf(nm[1], sizeof(nm[1]), "pwhs_kernel<%s,%d,%d,1>", yr_dtype_name(yr_elem<T>::dtype), PT, NCH) +
-                              snprintf(nm[2], sizeof(nm[2]), "pwhs_kernel<%s,%d,%d,2>", yr_dtype_name(yr_elem<T>::dtype), PT, NCH);
-    (void)nm_len;
-    yr_note_kernel(nm[mode]);
+    const bool plain = !a.pre && !a.res && !a.pool && (a.act == YR_ACT_NONE || a.act == YR_ACT_RELU6);
+    const int form = !plain ? 0 : (a.act == YR_ACT_RELU6 ? 2 : 1);   // generic | plain | plain + ReLU6: the last two template arguments
+    static char nm[3][3][56];
+    static bool named = false;
+    if (!named) {
+        for (int m = 0; m < 3; ++m)
+            for (int f = 0; f < 3; ++f)
+                snprintf(nm[m][f], sizeof(nm[m][f]), "pwhs_kernel<%s,%d,%d,%d,%d,%d>", yr_dtype_name(yr_elem<T>::dtype), PT, NCH, m, f > 0, f > 1);
+        named = true;
+    }
+    yr_note_kernel(nm[mode][form]);
     const dim3 grid((unsigned)ntm * (unsigned)nsplit);
     const unsigned ob = pwh_out_bytes(a);
-    const bool plain = !a.pre && !a.res && !a.pool && (a.act == YR_ACT_NONE || a.act == YR_ACT_RELU6);
 #define PWHS_GO(MODE, PLAIN, CLAMP) hipLaunchKernelGGL((pwhs_kernel<T, PT, NCH, MODE, PLAIN, CLAMP>), grid, dim3(256), 0, s, a, per, nsplit, ob)
     if (plain && a.act == YR_ACT_RELU6) {
         if (mode == 1) PWHS_GO(1, true, true); else if (mode == 2) PWHS_GO(2, true, true); else PWHS_GO(0, true, true);

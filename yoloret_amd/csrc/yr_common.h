@@ -34,7 +34,7 @@ void yr_note_kernel(const char* name);
 int yr_launch_stem(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_pointwise(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_depthwise(const yr_op& op, int batch, hipStream_t s);
-int yr_launch_depthwise_lds5(int dtype, const void* in, const float* w, const float* scale, const float* shift, void* out, int B, int H, int W,
+int yr_launch_depthwise_lds(int dtype, int k, const void* in, const float* w, const float* scale, const float* shift, void* out, int B, int H, int W,
                              int C8, int ld_in, int ld_w, int ld_out, int pad_t, int pad_l, int act, float* part, int ld_part, int part_rows,
                              hipStream_t s);
 int yr_launch_se_mean(const yr_op& op, int batch, hipStream_t s);

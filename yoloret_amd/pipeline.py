@@ -134,6 +134,8 @@ class DetectionPipeline:
         self._bufs, self._turn = c['bufs'], c['turn']
         try:
             with torch.cuda.stream(st):
+                x.record_stream(st)            # the caching allocator must not recycle the inputs while this stream reads them
+                image_hw.record_stream(st)
                 v = self._buffers(b, dev)
                 ys = self.model(x, out=v['ys'], ctx=k)
                 out = self.postprocess(ys, image_hw)
