@@ -414,6 +414,18 @@ def main():
                                  % (k, v['launches'], v['ms'], v['hbm'] / (v['ms'] * 1e-3) / 1e9 if v['ms'] else 0,
                                     v['bytes'] / (v['ms'] * 1e-3) / 1e9 if v['ms'] else 0,
                                     2.0 * v['macs'] / (v['ms'] * 1e-3) / 1e12 if v['ms'] else 0))
+        # ---- the same K steps strictly one after the other (no steps in flight): what one step costs on an otherwise idle GPU
+        serial_steps = None
+        if world == 1 and a.depth > 1:
+            for _ in range(a.warmup + 3):
+                pipe1(x, image_hw)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                pipe1(x, image_hw)
+            torch.cuda.synchronize(dev)
+            dts = (time.perf_counter() - t1) / a.steps
+            serial_steps = {'img_s': round(b / dts, 1), 'ms_per_step': round(dts * 1e3, 4)}
         # ---- p50 per-image latency at B=1 (the second half of BASELINE.json's metric)
         p50 = None
         if world == 1 and not a.no_latency:
@@ -503,6 +515,36 @@ def main():
             sync()
             incl_h2d['overlapped'] = {'img_s': round(b / dtf, 1), 'ms_per_step': round(dtf * 1e3, 4),
                                       'path': 'HostFeeder: the H2D copy of batch i+1 on a second stream while batch i computes (two device buffers)'}
+            if a.depth > 1:
+                # ... and with the shipped number of steps in flight: one input buffer per context, rewritten (copy stream ->
+                # conversion on the launch stream) only after the step that last read it has finished
+                xs = [x] + [torch.empty_like(x) for _ in range(a.depth - 1)]
+                done_ev = [None] * a.depth
+                turn = [0]
+
+                def step_fed_deep():
+                    k = turn[0] % a.depth
+                    turn[0] += 1
+                    feeder.submit(u8)
+                    if done_ev[k] is not None:
+                        torch.cuda.current_stream(dev).wait_event(done_ev[k])
+                    feeder.take(out=xs[k])
+                    pipe(xs[k], image_hw)
+                    done_ev[k] = pipe.done
+                feeder.submit(u8)              # primed: every take() finds the batch submitted one call earlier
+                for _ in range(2 * a.depth):
+                    step_fed_deep()
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(nh):
+                    step_fed_deep()
+                sync()
+                dtd = (time.perf_counter() - t1) / nh
+                feeder.take(out=x)
+                sync()
+                incl_h2d['in_flight'] = {'img_s': round(b / dtd, 1), 'ms_per_step': round(dtd * 1e3, 4), 'steps_in_flight': a.depth,
+                                         'path': 'HostFeeder + DetectionPipeline(depth): copy of batch i+1 on the copy stream, conversion on the launch stream, '
+                                                 'steps on their contexts\' streams; one float32 input buffer per context'}
         out = {'metric': 'images/sec (+ p50 per-image ms) MobileNetV2-0.75x @416, 1/2/4/8 MI355X',
                'value': round(value, 1), 'unit': 'img/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
                'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
@@ -516,7 +558,7 @@ def main():
                                       + ('; %d steps in flight (each step = one whole batch on its own HIP stream and workspace)' % a.depth if a.depth > 1 else '')
                                       + ('; the -lite form = no squeeze-excite, ReLU6, and it KEEPS the width-scaled stem' if a.model.endswith('-lite') else ''),
                           'global_batch': b * world, 'parallelism': 'dp%d (image-sharded)' % world},
-               'steps_in_flight': a.depth, 'p50_ms_b1': p50, 'roofline': roofline, 'roofline_family': roofline_family, 'roofline_step': roofline_step, 'incl_h2d': incl_h2d}
+               'steps_in_flight': a.depth, 'serial_steps': serial_steps, 'p50_ms_b1': p50, 'roofline': roofline, 'roofline_family': roofline_family, 'roofline_step': roofline_step, 'incl_h2d': incl_h2d}
         if p50 is not None:
             out['p50_ms_b1_detail'] = {'eager_launches': p50_eager, 'hip_graph_replay': p50_graph}
         if use_dist:
