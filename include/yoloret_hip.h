@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define YR_ABI_VERSION 3   /* 3: op kind MBX, pair-packed STEM weights, BN scale folded into the packed taps of STEMBLOCK / MBLANE */
+#define YR_ABI_VERSION 4   /* 4: YR_U8 images (uint8 network entry); 3: op kind MBX, pair-packed STEM weights, BN scale folded into the packed taps of STEMBLOCK / MBLANE */
 #define YR_MAX_SRC 4
 
 typedef enum {
@@ -44,7 +44,11 @@ typedef enum {
 /* Element type of an activation tensor / of the POINTWISE weight matrix.  The 16-bit types are storage formats:
  * every kernel converts to float32 on load (bf16: exact widening) and rounds to nearest-even on store; only the
  * POINTWISE GEMM consumes them natively (v_mfma_f32_16x16x32_bf16 / _f16, float32 accumulate). */
-typedef enum { YR_F32 = 0, YR_BF16 = 1, YR_F16 = 2 } yr_dtype;
+typedef enum { YR_F32 = 0, YR_BF16 = 1, YR_F16 = 2,
+               YR_U8 = 3   /* ABI 4: uint8 - ONLY as the element type of the image (external slot 0) read by a STEM / STEMBLOCK op: the
+                              decoded bytes as they are, x / 255 (code/yolo.py:106) applied inside the kernel; the float32 batch
+                              (4x the bytes) is then never written or read */
+} yr_dtype;
 
 typedef enum { YR_ACT_NONE = 0, YR_ACT_RELU6 = 1, YR_ACT_SWISH = 2, YR_ACT_SIGMOID = 3, YR_ACT_LEAKY = 4 } yr_act;
 

@@ -357,3 +357,52 @@ def test_plan_blob_round_trip(dev, tmp_path):
     h = rt.PlanHandle(m16.save_plan())
     for a, w in zip(h(xd), want16):
         assert np.array_equal(a.cpu().numpy().reshape(w.shape), w)
+
+
+@pytest.mark.parametrize('name,policy', [('mobilenetv2x75', 'float32'), ('efficientnetb0-lite', 'mixed_bfloat16'),
+                                         ('efficientnetb0', 'float32'), ('efficientnetb3', 'mixed_float16')])
+def test_uint8_network_entry(dev, name, policy):
+    """Input(dtype='uint8'): the network-entry kernel (the fused stem block of the MobileNetV2 / -lite models, the stem and
+    stem + depthwise kernels of the squeeze-excite EfficientNets) reads the decoded image BYTES and applies the x / 255 of
+    tf.io.decode_image(dtype=float32) (reference code/yolo.py:106) itself.  Against the float32-input model fed u8 / 255:
+    the same logits up to the rounding of (sum w u) / 255 versus sum w (u / 255) (float32 plans: 1e-5 scaled; 16-bit plans
+    round activations, so a last-bit difference at the entry may flip a later rounding: within the plan's own noise);
+    float32 plans also against the oracle at the 1e-4 bar.  Odd sizes exercise the border paths."""
+    from yoloret_amd import layers as L
+    from yoloret_amd.yolo3.model import yolov3_body
+    hw = (96, 160)
+    rng = np.random.default_rng(3)
+    u8 = rng.integers(0, 256, (3, hw[0], hw[1], 3), dtype=np.uint8)
+    xf = (u8.astype(np.float32) / np.float32(255.0))
+    L.set_global_policy(policy)
+    try:
+        mf = yolov3_body(L.Input(shape=[hw[0], hw[1], 3]), name, 3, num_classes=20)
+        m8 = yolov3_body(L.Input(shape=[hw[0], hw[1], 3], dtype='uint8'), name, 3, num_classes=20)
+    finally:
+        L.set_global_policy('float32')
+    P = params.ParamStore(1234, 'conditioned')
+    ref = om.yolov3_body(P, xf, name, 3, 20)
+    for m in (mf, m8):
+        m.set_weights(P.values)
+        m.small_batch = 0
+    yf = [y.cpu().numpy() for y in mf(torch.from_numpy(xf).to(dev))]
+    y8 = [y.cpu().numpy() for y in m8(torch.from_numpy(u8).to(dev))]
+    assert m8.plan.input_buf.dtype == 3 and m8.plan.ops[0].srcs[0].buf.dtype == 3
+    with pytest.raises(ValueError, match='uint8'):
+        m8(torch.from_numpy(xf).to(dev))
+    for i, (a, b, r) in enumerate(zip(y8, yf, ref)):
+        if policy == 'float32':
+            assert_close(a, b, 1e-5, '%s y%d uint8 entry vs float32 entry' % (name, i + 1))
+            assert_close(a, r, 1e-4, '%s y%d uint8 entry vs oracle' % (name, i + 1))
+        else:
+            e8 = np.abs(a - r) / np.maximum(1.0, np.abs(r))
+            ef = np.abs(b - r) / np.maximum(1.0, np.abs(r))
+            assert e8.mean() <= 1.25 * ef.mean() + 1e-6 and e8.max() <= 2.0 * ef.max() + 1e-5, (name, i, e8.max(), ef.max())
+    # the latency plan (no block fusion: plain stem kernel) takes the bytes too
+    m8.small_batch = 4
+    y8s = [y.cpu().numpy() for y in m8(torch.from_numpy(u8[:2]).to(dev))]
+    for a, b in zip(y8s, yf):
+        if policy == 'float32':
+            assert_close(a, b[:2], 2e-5, '%s latency plan, uint8 entry' % name)
+        else:
+            assert np.isfinite(a).all()

@@ -13,30 +13,36 @@ O=gpurun_out/refresh
 mkdir -p $O
 db() { ls $O/$1/*.db 2>/dev/null | head -1; }
 WHAT=${*:-c2 c3 c4 c5 dist}
+ROUND=${ROUND:-03}
 
 one() {   # one <tag> <traffic-suffix> <sq: 0|1> <bench args...>
   local tag=$1 suf=$2 sq=$3; shift 3
   export YOLORET_TUNE_CACHE=$R/$O/tuned_$tag.json   # the first run tunes and saves; profiled runs reuse the table (no trial launches)
   rm -f $YOLORET_TUNE_CACHE
-  python bench.py "$@" $CPU > $O/bench_$tag.json 2> $O/bench_$tag.err
-  python bench.py "$@" --depth 1 --no-cpu-baseline --per-op > $O/bench_${tag}_depth1.json 2> $O/perop_$tag.txt
-  local B1="python bench.py $* --depth 1 --no-cpu-baseline --no-latency"
-  timeout 600 rocprofv3 --kernel-trace --stats -d $O/ps_$tag -o stats -- $B1 > $O/bench_${tag}_under_rocprof.json 2> $O/rocprof_$tag.err
-  python tools/rocpd_summary.py stats "$(db ps_$tag)" > $O/kernel_stats_$tag.txt
-  timeout 600 rocprofv3 --kernel-trace --stats -d $O/ps3_$tag -o stats -- python bench.py "$@" --no-cpu-baseline --no-latency > /dev/null 2>> $O/rocprof_$tag.err
-  python tools/rocpd_summary.py stats "$(db ps3_$tag)" > $O/kernel_stats_${tag}_in_flight.txt
+  python bench.py "$@" --depth 1 --steps 3 --warmup 1 --no-cpu-baseline --no-latency --profile-iters 0 > /dev/null 2> $O/tune_$tag.err
+  # ---- counters first (their traffic table is what the bench lines below quote as `traffic`)
   local BP="python bench.py $* --depth 1 --steps 5 --warmup 2 --no-cpu-baseline --no-latency --profile-iters 0"
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pf_$tag -o pmc -- $BP > /dev/null 2> $O/pmc_$tag.err
   timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pw_$tag -o pmc -- $BP > /dev/null 2>> $O/pmc_$tag.err
   python tools/rocpd_summary.py pmc "$(db pf_$tag)" > $O/pmc_fetch_$tag.txt
   python tools/rocpd_summary.py pmc "$(db pw_$tag)" > $O/pmc_write_$tag.txt
   python tools/rocpd_summary.py traffic "$(db pf_$tag)" "$(db pw_$tag)" > $O/traffic$suf.json
+  cp $O/traffic$suf.json profiles/r${ROUND}_traffic$suf.json      # (in this run's copy of the tree: bench.py reads it from profiles/)
   if [ "$sq" = 1 ]; then
     timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU -d $O/pq_$tag -o pmc -- $BP > /dev/null 2>> $O/pmc_$tag.err
     python tools/rocpd_summary.py pmc "$(db pq_$tag)" > $O/pmc_sq_$tag.txt
     timeout 600 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum -d $O/pl_$tag -o pmc -- $BP > /dev/null 2>> $O/pmc_$tag.err
     python tools/rocpd_summary.py pmc "$(db pl_$tag)" > $O/pmc_l2_$tag.txt
   fi
+  # ---- the bench lines: as shipped (steps in flight), and with --depth 1 + the per-op table
+  python bench.py "$@" $CPU > $O/bench_$tag.json 2> $O/bench_$tag.err
+  python bench.py "$@" --depth 1 --no-cpu-baseline --per-op > $O/bench_${tag}_depth1.json 2> $O/perop_$tag.txt
+  # ---- rocprofv3 kernel trace of the --depth 1 command (per-symbol averages == the live hipEvent figures) and of the shipped depth
+  local B1="python bench.py $* --depth 1 --no-cpu-baseline --no-latency"
+  timeout 600 rocprofv3 --kernel-trace --stats -d $O/ps_$tag -o stats -- $B1 > $O/bench_${tag}_under_rocprof.json 2> $O/rocprof_$tag.err
+  python tools/rocpd_summary.py stats "$(db ps_$tag)" > $O/kernel_stats_$tag.txt
+  timeout 600 rocprofv3 --kernel-trace --stats -d $O/ps3_$tag -o stats -- python bench.py "$@" --no-cpu-baseline --no-latency > /dev/null 2>> $O/rocprof_$tag.err
+  python tools/rocpd_summary.py stats "$(db ps3_$tag)" > $O/kernel_stats_${tag}_in_flight.txt
   rm -rf $O/ps_$tag $O/ps3_$tag $O/pf_$tag $O/pw_$tag $O/pq_$tag $O/pl_$tag
   unset YOLORET_TUNE_CACHE
 }

@@ -964,7 +964,7 @@ class Compiler:
                 self.layer_seq[n.name] = n.seq
         x = self.inputs
         h, w, c = x.shape
-        in_buf = self._new_buf(h, w, c, ld=c, external_slot=0, name='images')
+        in_buf = self._new_buf(h, w, c, ld=c, external_slot=0, name='images', dtype=rt.dtype_id(getattr(x, 'dtype', 'float32')))   # float32, or uint8 image bytes
         in_buf.first_def = -1
         self.values[id(x)] = Value([Seg(in_buf, c)])
         done = set()

@@ -79,7 +79,7 @@ extern "C" int yr_create(const yr_op* ops, int n_ops, const yr_buf* bufs, int n_
             }
             const int64_t end = b.arena_off_per_image + b.bytes_per_image;
             if (end > h->arena_per_image) h->arena_per_image = end;
-        } else if (b.external_slot > 3 || b.dtype != YR_F32) {
+        } else if (b.external_slot > 3 || (b.dtype != YR_F32 && !(b.external_slot == 0 && b.dtype == YR_U8))) {   // (the image may be uint8)
             delete h;
             yr_set_error("yr_create: external slot %d out of range (or not float32)", b.external_slot);
             return YR_ERR_ARG;
@@ -102,7 +102,7 @@ extern "C" int yr_create(const yr_op* ops, int n_ops, const yr_buf* bufs, int n_
         const char* why = nullptr;
         auto fits = [&](int32_t b, int64_t elems, int dtype) {
             const yr_buf& d = h->bufs[b];
-            return elems > 0 && (d.external_slot >= 0 || elems * (int64_t)(dtype == YR_F32 ? 4 : 2) <= d.bytes_per_image);
+            return elems > 0 && (d.external_slot >= 0 || elems * (int64_t)(dtype == YR_F32 ? 4 : dtype == YR_U8 ? 1 : 2) <= d.bytes_per_image);
         };
         if (op.h <= 0 || op.w <= 0 || op.h > (1 << 15) || op.w > (1 << 15) || op.out_ld <= 0 || op.out_ld > (1 << 20) || op.cout <= 0 || op.cin <= 0) why = "dims";
         for (int i = 0; !why && i < op.nsrc; ++i) {

@@ -16,7 +16,8 @@
 // T: element type of the OUTPUT map (the image, the weights and all arithmetic are float32).
 template <class T>
 struct StemArgs {
-    const float* in;     // [B][Hi][Wi][3] dense
+    const float* in;     // [B][Hi][Wi][3] dense float32 in [0,1] - or, in_u8 != 0, uint8 image bytes (x / 255 applied while staging)
+    int in_u8;
     const float* w;      // [27][ldw]  (tap-major: (ky*3+kx)*3+ci), zero padded to ldw
     const float* scale;  // [ldw]
     const float* shift;  // [ldw]
@@ -48,7 +49,8 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs<T> a) {
         const int iy = iy0 + ry, ixc = ix0 * 3 + rc;  // ixc = ix*3 + ci
         stage[u] = 0.f;
         if (i < ST_IH * ST_IW * 3 && iy >= 0 && iy < a.Hi && ixc >= 0 && ixc < a.Wi * 3)
-            stage[u] = a.in[((size_t)b * a.Hi + iy) * a.Wi * 3 + ixc];
+            stage[u] = a.in_u8 ? (float)reinterpret_cast<const unsigned char*>(a.in)[((size_t)b * a.Hi + iy) * a.Wi * 3 + ixc] * (1.0f / 255.0f)
+                               : a.in[((size_t)b * a.Hi + iy) * a.Wi * 3 + ixc];
     }
 #pragma unroll
     for (int u = 0; u < NLD; ++u)
@@ -125,7 +127,8 @@ __global__ __launch_bounds__(256) void stem_pair_kernel(StemArgs<T> a) {
         const int iy = iy0 + ry, ixc = ix0 * 3 + rc;
         stage[u] = 0.f;
         if (i < ST_IH * ST_IW * 3 && iy >= 0 && iy < a.Hi && ixc >= 0 && ixc < a.Wi * 3)
-            stage[u] = a.in[((size_t)b * a.Hi + iy) * a.Wi * 3 + ixc];
+            stage[u] = a.in_u8 ? (float)reinterpret_cast<const unsigned char*>(a.in)[((size_t)b * a.Hi + iy) * a.Wi * 3 + ixc] * (1.0f / 255.0f)
+                               : a.in[((size_t)b * a.Hi + iy) * a.Wi * 3 + ixc];
     }
 #pragma unroll
     for (int u = 0; u < NLD; ++u)
@@ -194,13 +197,13 @@ static int launch_stem(const StemArgs<T>& a, hipStream_t s) {
 
 template <class T>
 static int launch_stem_t(const yr_op& op, int batch, hipStream_t s) {
-    YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY && op.src[0].c == 3 && op.src[0].ld == 3 && op.src[0].dtype == YR_F32,
-               "stem: needs one dense 3-channel float32 source");
+    YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY && op.src[0].c == 3 && op.src[0].ld == 3 && (op.src[0].dtype == YR_F32 || op.src[0].dtype == YR_U8),
+               "stem: needs one dense 3-channel float32 (or uint8) source");
     YR_REQUIRE(op.out_dtype == op.dtype, "stem: the output has the op's dtype");
     YR_REQUIRE(op.k == 3 && op.stride == 2, "stem: only 3x3 stride 2 is supported");
     const yr_src& in = op.src[0];
     StemArgs<T> a;
-    a.in = (const float*)in.ptr; a.w = op.wgt; a.scale = op.scale; a.shift = op.shift; a.wpair = op.wgt2; a.out = (T*)op.out;
+    a.in = (const float*)in.ptr; a.in_u8 = in.dtype == YR_U8; a.w = op.wgt; a.scale = op.scale; a.shift = op.shift; a.wpair = op.wgt2; a.out = (T*)op.out;
     YR_REQUIRE(a.in && a.w && a.scale && a.shift && a.out, "stem: null pointer");
     a.B = batch; a.Hi = in.h; a.Wi = in.w; a.Ho = (in.h + 1) / 2; a.Wo = (in.w + 1) / 2;
     YR_REQUIRE(a.Ho == op.h && a.Wo == op.w, "stem: output dims mismatch");

@@ -34,7 +34,9 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte l
 // T: element type of the OUTPUT map (image, weights and arithmetic: float32; one rounding at the store).
 template <class T>
 struct SbArgs {
-    const float* in;   // [B][Hi][Wi][3]
+    const void* in;    // [B][Hi][Wi][3] float32 in [0,1] - or uint8 (IN8): the decoded image bytes as they are; the /255 of
+                       // code/yolo.py:106 (tf.io.decode_image(dtype=float32)) is then applied to the 27-tap sums (in_scale)
+    float in_scale;    // 1 (float32 images) | 1/255 (uint8 images)
     T* out;            // [B][Ho][Wo][ld_out]   (Ho = ceil(Hi/2))
     const float* ws;   // stem       [CP][SB_WS]
     const float* wd;   // depthwise  [CP][SB_WD]
@@ -54,7 +56,7 @@ __device__ __forceinline__ v2f sb_act(v2f v, int act) {
     return (v2f){yr_apply_act_t<T>(v.x, act), yr_apply_act_t<T>(v.y, act)};   // (16-bit maps: hardware exp2 / rcp swish)
 }
 
-template <int CP, int COP, bool RELU6, class T>
+template <int CP, int COP, bool RELU6, class T, bool IN8>
 __global__ __launch_bounds__(256, 4) void stemblock_kernel(SbArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     v2f* Es = reinterpret_cast<v2f*>(lds);                       // [CP][256]
@@ -76,9 +78,31 @@ __global__ __launch_bounds__(256, 4) void stemblock_kernel(SbArgs<T> a) {
         const int sy = oy0 - 1 + ey, sx = ox0 - 1 + ex;
         const bool valid = sy >= 0 && sy < a.Ho && sx >= 0 && sx < a.Wo;  // outside: zero (the depthwise's SAME padding)
         float in[27];
-        const float* img = a.in + (size_t)b * a.Hi * a.Wi * 3;
         const int iy = iy0 + 2 * ey, ic = (ix0 + 2 * ex) * 3, rowlen = a.Wi * 3;
         const bool interior = iy >= 0 && iy + 2 < a.Hi && ic >= 0 && ic + 8 < rowlen;
+        if constexpr (IN8) {
+            // uint8 image: a window row is 9 BYTES at a byte-aligned address - one global_load_dwordx3 (unaligned dword access
+            // is enabled for global memory), nine conversions; the float32 batch (4x the bytes) is never written or read
+            typedef unsigned u3 __attribute__((ext_vector_type(3), aligned(1)));
+            const unsigned char* img = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * a.Hi * a.Wi * 3;
+            if (interior && ic + 11 < rowlen) {      // (the 12-byte load stays inside the row)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const u3 v = *reinterpret_cast<const u3*>(img + (size_t)(iy + ky) * rowlen + ic);
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) in[ky * 9 + j] = (float)((v[j >> 2] >> (8 * (j & 3))) & 0xffu);
+                }
+            } else {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) {
+                        const int y = iy + ky, c = ic + j;
+                        in[ky * 9 + j] = (valid && y >= 0 && y < a.Hi && c >= 0 && c < rowlen) ? (float)img[(size_t)y * rowlen + c] : 0.f;
+                    }
+            }
+        } else {
+        const float* img = reinterpret_cast<const float*>(a.in) + (size_t)b * a.Hi * a.Wi * 3;
         if (interior) {
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
@@ -96,6 +120,7 @@ __global__ __launch_bounds__(256, 4) void stemblock_kernel(SbArgs<T> a) {
                     const int y = iy + ky, c = ic + j;
                     in[ky * 9 + j] = (valid && y >= 0 && y < a.Hi && c >= 0 && c < rowlen) ? img[(size_t)y * rowlen + c] : 0.f;
                 }
+        }
         }
         const kptr ws = (kptr)a.ws;
         const float hi = valid ? 6.f : 0.f;
@@ -116,7 +141,10 @@ __global__ __launch_bounds__(256, 4) void stemblock_kernel(SbArgs<T> a) {
             acc2 = sb_fma((v2f){in[25], in[25]}, (v2f){w[50], w[51]}, acc2);
             acc3 = sb_fma((v2f){in[26], in[26]}, (v2f){w[52], w[53]}, acc3);
             acc = (acc + acc2) + (acc3 + acc4);
-            acc += (v2f){w[56], w[57]};          // BN shift; the scale is folded into the taps by the host (w[54..55] hold 1)
+            // BN shift; the BN scale is folded into the taps by the host (w[54..55] hold 1).  uint8 images: the taps were
+            // multiplied with 0..255, the sum takes the 1/255 here (float32 images: an exact fma with 1)
+            if constexpr (IN8) acc = sb_fma(acc, (v2f){a.in_scale, a.in_scale}, (v2f){w[56], w[57]});
+            else acc += (v2f){w[56], w[57]};
             if (RELU6) {                         // upper clamp 0 outside the map = the depthwise's zero padding, for free
                 acc = (v2f){__builtin_amdgcn_fmed3f(acc.x, 0.f, hi), __builtin_amdgcn_fmed3f(acc.y, 0.f, hi)};
             } else {
@@ -235,17 +263,27 @@ __global__ __launch_bounds__(256, 4) void stemblock_kernel(SbArgs<T> a) {
 }
 
 template <int CP, int COP, class T>
-static int launch_sb(const SbArgs<T>& a, int batch, hipStream_t s) {
+static int launch_sb(const SbArgs<T>& a, bool in8, int batch, hipStream_t s) {
     constexpr size_t lds = (size_t)CP * 256 * 2 * sizeof(float);   // (COP == 0: its head doubles as the [4][2*CP] wave sums)
     static_assert(lds <= 64 * 1024, "stemblock LDS tile too large");
-    static char nm[2][48];
-    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "stemblock_kernel<%d,%d,0,%s>", CP, COP, yr_dtype_name(yr_elem<T>::dtype)) +
-                              snprintf(nm[1], sizeof(nm[1]), "stemblock_kernel<%d,%d,1,%s>", CP, COP, yr_dtype_name(yr_elem<T>::dtype));
-    (void)nm_len;
-    yr_note_kernel(nm[a.act == YR_ACT_RELU6 ? 1 : 0]);
+    static char nm[2][2][56];
+    static bool named = false;
+    if (!named) {
+        for (int r = 0; r < 2; ++r)
+            for (int u = 0; u < 2; ++u)
+                snprintf(nm[r][u], sizeof(nm[r][u]), u ? "stemblock_kernel<%d,%d,%d,%s,u8>" : "stemblock_kernel<%d,%d,%d,%s>", CP, COP, r, yr_dtype_name(yr_elem<T>::dtype));
+        named = true;
+    }
+    const bool relu6 = a.act == YR_ACT_RELU6;
+    yr_note_kernel(nm[relu6 ? 1 : 0][in8 ? 1 : 0]);
     const dim3 grid((unsigned)(batch * a.tiles_x * a.tiles_y));
-    if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((stemblock_kernel<CP, COP, true, T>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((stemblock_kernel<CP, COP, false, T>), grid, dim3(256), lds, s, a);
+    if (in8) {
+        if (relu6) hipLaunchKernelGGL((stemblock_kernel<CP, COP, true, T, true>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((stemblock_kernel<CP, COP, false, T, true>), grid, dim3(256), lds, s, a);
+    } else {
+        if (relu6) hipLaunchKernelGGL((stemblock_kernel<CP, COP, true, T, false>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((stemblock_kernel<CP, COP, false, T, false>), grid, dim3(256), lds, s, a);
+    }
     YR_LAUNCH_CHECK();
     return YR_OK;
 }
@@ -257,13 +295,14 @@ static int launch_sb(const SbArgs<T>& a, int batch, hipStream_t s) {
 //   b1   = project W[2*CP][COP] (input-channel major);  b2 = project BN scale [COP] ++ shift [COP].
 template <class T>
 static int launch_stemblock_t(const yr_op& op, int batch, hipStream_t s) {
-    YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY && op.src[0].c == 3 && op.src[0].ld == 3 && op.src[0].dtype == YR_F32,
-               "stemblock: needs one dense 3-channel float32 source");
+    YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY && op.src[0].c == 3 && op.src[0].ld == 3 && (op.src[0].dtype == YR_F32 || op.src[0].dtype == YR_U8),
+               "stemblock: needs one dense 3-channel float32 (or uint8) source");
+    const bool in8 = op.src[0].dtype == YR_U8;
     YR_REQUIRE(op.k == 3 && op.stride == 2, "stemblock: the stem is 3x3 stride 2");
     const yr_src& in = op.src[0];
     SbArgs<T> a;
     YR_REQUIRE(op.out_dtype == op.dtype && op.out_ld % (yr_elem<T>::vec == 8 ? 8 : 1) == 0, "stemblock: the output has the op's dtype (16-bit: out_ld %% 8 == 0)");
-    a.in = (const float*)in.ptr; a.out = (T*)op.out;
+    a.in = in.ptr; a.in_scale = in8 ? 1.0f / 255.0f : 1.0f; a.out = (T*)op.out;
     YR_REQUIRE(op.se_reduced >= 1 && op.cout >= 1, "stemblock: bad widths (C1=%d, Cout=%d)", op.se_reduced, op.cout);
     const int c1p = yr_round_up(op.se_reduced, 4), cop = yr_round_up(op.cout, 8);
     const bool noproj = op.b1 == nullptr;   // stem + depthwise only (cout == C1): the depthwise map and its squeeze sums leave
@@ -285,19 +324,19 @@ static int launch_stemblock_t(const yr_op& op, int batch, hipStream_t s) {
             a.part = const_cast<float*>(op.gate); a.ld_part = op.gate_ld;
         }
         switch (c1p / 2) {
-            case 16: return launch_sb<16, 0, T>(a, batch, s);    // EfficientNet-B0 / B1 (32)
-            case 20: return launch_sb<20, 0, T>(a, batch, s);    // B3 (40)
-            case 24: return launch_sb<24, 0, T>(a, batch, s);    // B4 / B5 (48)
+            case 16: return launch_sb<16, 0, T>(a, in8, batch, s);    // EfficientNet-B0 / B1 (32)
+            case 20: return launch_sb<20, 0, T>(a, in8, batch, s);    // B3 (40)
+            case 24: return launch_sb<24, 0, T>(a, in8, batch, s);    // B4 / B5 (48)
             default: yr_set_error("stemblock: stem width C1=%d unsupported without a projection", op.se_reduced); return YR_ERR_ARG;
         }
     }
     switch (c1p / 2 * 100 + cop) {
-        case 1216: return launch_sb<12, 16, T>(a, batch, s);
-        case 1616: return launch_sb<16, 16, T>(a, batch, s);
-        case 1624: return launch_sb<16, 24, T>(a, batch, s);
-        case 2024: return launch_sb<20, 24, T>(a, batch, s);
-        case 2416: return launch_sb<24, 16, T>(a, batch, s);
-        case 2424: return launch_sb<24, 24, T>(a, batch, s);
+        case 1216: return launch_sb<12, 16, T>(a, in8, batch, s);
+        case 1616: return launch_sb<16, 16, T>(a, in8, batch, s);
+        case 1624: return launch_sb<16, 24, T>(a, in8, batch, s);
+        case 2024: return launch_sb<20, 24, T>(a, in8, batch, s);
+        case 2416: return launch_sb<24, 16, T>(a, in8, batch, s);
+        case 2424: return launch_sb<24, 24, T>(a, in8, batch, s);
         default: yr_set_error("stemblock: widths C1=%d Cout=%d unsupported", op.se_reduced, op.cout); return YR_ERR_ARG;
     }
 }

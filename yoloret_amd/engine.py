@@ -159,8 +159,9 @@ class Model:
         flight at the same time on different HIP streams (pipeline.DetectionPipeline(depth=2)); calls with the same
         `ctx` must be stream-ordered."""
         h, w, c = self.plan.input_shape
-        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
-            raise ValueError('input must be a float32 CUDA tensor [B,%d,%d,%d] (NHWC)' % (h, w, c))
+        want = rt.TORCH_DTYPE[self.plan.input_buf.dtype]       # float32, or uint8 for a model built on Input(dtype='uint8')
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == want):
+            raise ValueError('input must be a %s CUDA tensor [B,%d,%d,%d] (NHWC)' % (str(want).replace('torch.', ''), h, w, c))
         if x.dim() != 4 or tuple(x.shape[1:]) != (h, w, c):
             raise ValueError('input shape %s does not match the model input [B,%d,%d,%d]' % (tuple(x.shape), h, w, c))
         x = x.contiguous()

@@ -61,9 +61,14 @@ class Node:
 
 
 def Input(shape, batch_size=None, dtype='float32', name='input'):
-    """tf.keras.layers.Input(shape=[H,W,3], batch_size=...) (reference code/yolo.py:82-84)."""
+    """tf.keras.layers.Input(shape=[H,W,3], batch_size=...) (reference code/yolo.py:82-84).  dtype='uint8': the model takes
+    the decoded image BYTES [B,H,W,3] (already of the network's size) and the network-entry kernel applies the x / 255 of
+    tf.io.decode_image(dtype=float32) (code/yolo.py:106) itself - the float32 batch is never materialised."""
+    if dtype not in ('float32', 'uint8'):
+        raise ValueError('Input dtype must be float32 or uint8, not %r' % (dtype,))
     t = Tensor(shape, None, name)
     t.batch_size = batch_size
+    t.dtype = dtype
     return t
 
 

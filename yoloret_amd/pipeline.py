@@ -237,6 +237,28 @@ class HostFeeder:
             self.copied[s].record(self.copy_stream)
         self._head += 1
 
+    def take_raw(self):
+        """The oldest submitted batch as the uint8 DEVICE buffer itself - for a model built on Input(dtype='uint8') (its
+        network-entry kernel reads the bytes and applies x / 255; only for batches that are already of the network's size:
+        no letterbox runs).  The current stream waits for the copy.  Returns (tensor, slot); the caller reports when the
+        readers of the tensor are done with `mark_released(slot, event)` (e.g. DetectionPipeline(depth > 1).done) - the
+        feeder overwrites the buffer only behind that event."""
+        if self._tail >= self._head:
+            raise RuntimeError('HostFeeder.take_raw: nothing was submitted')
+        if self.batch_shape[1:3] != self.input_hw:
+            raise ValueError('HostFeeder.take_raw: the batch is %dx%d, the network takes %dx%d (use take(): it letterboxes)'
+                             % (self.batch_shape[1:3] + self.input_hw))
+        s = self._tail % len(self.dbuf)
+        torch.cuda.current_stream(self.device).wait_event(self.copied[s])
+        self._tail += 1
+        return self.dbuf[s], s
+
+    def mark_released(self, slot, event=None):
+        if event is None:
+            event = torch.cuda.Event()
+            event.record(torch.cuda.current_stream(self.device))
+        self.released[slot] = event
+
     def take(self, out=None):
         """The oldest submitted batch as the float32 network input [B,H,W,3] (written into `out` if given), enqueued on
         the current stream of the feeder's device."""

@@ -19,11 +19,11 @@ XFORM = {'identity': 0, 'up2': 1, 'maxpool2': 2, 'maxpool4': 3, 'up2_add': 4, 'd
 OP_STEM, OP_POINTWISE, OP_DEPTHWISE, OP_SE_MEAN, OP_SE_FC, OP_WSUM, OP_GATHER, OP_MBCONV = 1, 2, 3, 4, 5, 6, 7, 8
 OP_STEMBLOCK, OP_MBLANE, OP_MBH, OP_MBX = 9, 10, 11, 12
 # yr_dtype: element type of activation tensors / pointwise weights (include/yoloret_hip.h)
-DTYPE = {'f32': 0, 'float32': 0, None: 0, 'bf16': 1, 'bfloat16': 1, 'f16': 2, 'float16': 2}
-DTYPE_NAME = {0: 'f32', 1: 'bf16', 2: 'f16'}
-ESIZE = {0: 4, 1: 2, 2: 2}
+DTYPE = {'f32': 0, 'float32': 0, None: 0, 'bf16': 1, 'bfloat16': 1, 'f16': 2, 'float16': 2, 'u8': 3, 'uint8': 3}   # (u8: images only)
+DTYPE_NAME = {0: 'f32', 1: 'bf16', 2: 'f16', 3: 'u8'}
+ESIZE = {0: 4, 1: 2, 2: 2, 3: 1}
 VEC = {0: 4, 1: 8, 2: 8}          # channels per 16 bytes: granule of `ld` and of the pointwise k-space
-TORCH_DTYPE = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
+TORCH_DTYPE = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16, 3: torch.uint8}
 
 
 def dtype_id(d):
@@ -85,7 +85,7 @@ class YrBuf(ctypes.Structure):
                 ('external_slot', ctypes.c_int32), ('dtype', ctypes.c_int32)]
 
 
-ABI_VERSION = 3   # == YR_ABI_VERSION of include/yoloret_hip.h
+ABI_VERSION = 4   # == YR_ABI_VERSION of include/yoloret_hip.h
 EXPORTS = ['yr_last_error', 'yr_abi_version', 'yr_abi_sizeof', 'yr_create', 'yr_create_from_blob', 'yr_plan_io_dims', 'yr_destroy', 'yr_load_weights', 'yr_workspace_bytes',
            'yr_forward', 'yr_forward_profile', 'yr_autotune', 'yr_get_tuning', 'yr_set_tuning', 'yr_plan_num_launches', 'yr_op_run', 'yr_decode', 'yr_decode_zoom', 'yr_yolo_head', 'yr_correct_boxes',
            'yr_nms', 'yr_pack_detections', 'yr_letterbox', 'yr_letterbox_batch']
