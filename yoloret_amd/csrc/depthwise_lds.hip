@@ -252,10 +252,13 @@ static int launch_dwl_t(DwlArgs a, int expect_rows, hipStream_t s) {
     a.nblocks = (unsigned)blocks;
     a.dbg = getenv("YR_DWL_DBG") ? atoi(getenv("YR_DWL_DBG")) : 0;
     const size_t lds = (size_t)(a.th + HALO) * 32 * a.twp * 4;
-    static char nm[40];
-    static const int nm_len = snprintf(nm, sizeof(nm), "dwl%d_kernel<%s,%d>", K, yr_dtype_name(yr_elem<T>::dtype), (int)SE);
+    const int actv = a.act == YR_ACT_RELU6 ? 0 : (a.act == YR_ACT_SWISH ? 1 : 2);
+    static char nm[3][48];   // spelled like the symbol (element type, K, activation variant, SE): profiles are joined on it
+    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "dwl_kernel<%s,%d,0,%d>", yr_dtype_name(yr_elem<T>::dtype), K, (int)SE) +
+                              snprintf(nm[1], sizeof(nm[1]), "dwl_kernel<%s,%d,1,%d>", yr_dtype_name(yr_elem<T>::dtype), K, (int)SE) +
+                              snprintf(nm[2], sizeof(nm[2]), "dwl_kernel<%s,%d,2,%d>", yr_dtype_name(yr_elem<T>::dtype), K, (int)SE);
     (void)nm_len;
-    yr_note_kernel(nm);
+    yr_note_kernel(nm[actv]);
     if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((dwl_kernel<T, K, 0, SE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     else if (a.act == YR_ACT_SWISH) hipLaunchKernelGGL((dwl_kernel<T, K, 1, SE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((dwl_kernel<T, K, 2, SE>), dim3((unsigned)blocks), dim3(256), lds, s, a);

@@ -314,8 +314,8 @@ static int launch_ml(const MlArgs<T>& a, int batch, hipStream_t s) {
     constexpr size_t lds = (S == 2 && red > es) ? red : es;  // stride 2 reuses Es as the cross-wave reduction buffer
     // (named as rocprof prints the symbol - template arguments in order - so that profiles can be joined by name)
     static char nm[2][56];
-    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "mblane_s%d_kernel<%d,%d,0,%s>", S, CQ, COP, yr_dtype_name(yr_elem<T>::dtype)) +
-                              snprintf(nm[1], sizeof(nm[1]), "mblane_s%d_kernel<%d,%d,1,%s>", S, CQ, COP, yr_dtype_name(yr_elem<T>::dtype));
+    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), S == 1 ? "mblane_s%d_kernel<%d,%d,0,%s,0>" : "mblane_s%d_kernel<%d,%d,0,%s>", S, CQ, COP, yr_dtype_name(yr_elem<T>::dtype)) +
+                              snprintf(nm[1], sizeof(nm[1]), S == 1 ? "mblane_s%d_kernel<%d,%d,1,%s,0>" : "mblane_s%d_kernel<%d,%d,1,%s>", S, CQ, COP, yr_dtype_name(yr_elem<T>::dtype));
     (void)nm_len;
     yr_note_kernel(nm[a.act == YR_ACT_RELU6 ? 1 : 0]);
     const dim3 grid((unsigned)(batch * a.tiles_x * a.tiles_y));
@@ -335,8 +335,8 @@ template <int CQ, int COP, class T>
 static int launch_ml_ident(const MlArgs<T>& a, int batch, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * ML_CH * 256 * sizeof(v2f);
     static char nm[2][56];
-    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "mblane_s1_kernel<%d,%d,0,%s,ident>", CQ, COP, yr_dtype_name(yr_elem<T>::dtype)) +
-                              snprintf(nm[1], sizeof(nm[1]), "mblane_s1_kernel<%d,%d,1,%s,ident>", CQ, COP, yr_dtype_name(yr_elem<T>::dtype));
+    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "mblane_s1_kernel<%d,%d,0,%s,1>", CQ, COP, yr_dtype_name(yr_elem<T>::dtype)) +
+                              snprintf(nm[1], sizeof(nm[1]), "mblane_s1_kernel<%d,%d,1,%s,1>", CQ, COP, yr_dtype_name(yr_elem<T>::dtype));
     (void)nm_len;
     yr_note_kernel(nm[a.act == YR_ACT_RELU6 ? 1 : 0]);
     YR_REQUIRE(a.npairs == (2 * CQ + ML_CH - 1) / ML_CH * ML_CH, "mblane: a block without expand conv has Cexp == Cin");

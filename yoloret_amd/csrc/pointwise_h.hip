@@ -327,12 +327,13 @@ static int launch_lds(const PwArgs& a, hipStream_t s) {
     bool pooled = false;
     for (int i = 0; i < YR_MAX_SRC; ++i) pooled |= a.S.s[i].xform == YR_X_MAXPOOL2 || a.S.s[i].xform == YR_X_MAXPOOL4;
     dim3 grid((unsigned)((a.M + BM - 1) / BM) * (unsigned)((a.N + BN - 1) / BN));
-    static char nm[3][40];
-    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "pwhl_kernel<%s,%d,%d,0>", yr_dtype_name(yr_elem<T>::dtype), PT, CT) +
-                              snprintf(nm[1], sizeof(nm[1]), "pwhl_kernel<%s,%d,%d,1>", yr_dtype_name(yr_elem<T>::dtype), PT, CT) +
-                              snprintf(nm[2], sizeof(nm[2]), "pwhl_kernel<%s,%d,%d,2>", yr_dtype_name(yr_elem<T>::dtype), PT, CT);
+    static char nm[4][48];   // spelled like the symbols: element type, PT, CT, MODE, POOLS
+    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "pwhl_kernel<%s,%d,%d,0,0>", yr_dtype_name(yr_elem<T>::dtype), PT, CT) +
+                              snprintf(nm[1], sizeof(nm[1]), "pwhl_kernel<%s,%d,%d,1,0>", yr_dtype_name(yr_elem<T>::dtype), PT, CT) +
+                              snprintf(nm[2], sizeof(nm[2]), "pwhl_kernel<%s,%d,%d,2,0>", yr_dtype_name(yr_elem<T>::dtype), PT, CT) +
+                              snprintf(nm[3], sizeof(nm[3]), "pwhl_kernel<%s,%d,%d,0,1>", yr_dtype_name(yr_elem<T>::dtype), PT, CT);
     (void)nm_len;
-    yr_note_kernel(nm[mode]);
+    yr_note_kernel(nm[mode == 0 && pooled ? 3 : mode]);
     if (mode == 1) hipLaunchKernelGGL((pwhl_kernel<T, PT, CT, 1, false>), grid, dim3(256), 0, s, a);
     else if (mode == 2) hipLaunchKernelGGL((pwhl_kernel<T, PT, CT, 2, false>), grid, dim3(256), 0, s, a);
     else if (pooled) hipLaunchKernelGGL((pwhl_kernel<T, PT, CT, 0, true>), grid, dim3(256), 0, s, a);

@@ -221,7 +221,7 @@ static int launch_cfg(const PwArgs& a, hipStream_t s) {
     if (a.dw_w != nullptr) {  // depthwise-folded source: built for the 64-row shapes with 3..8 cout tiles
         if constexpr (PT == 1 && WM == 4 && CT >= 3) {
             static char dnm[48];
-            static const int dnm_len = snprintf(dnm, sizeof(dnm), "pw_kernel<%d,%d,%d,%d,dw>", PT, CT, WM, WN);
+            static const int dnm_len = snprintf(dnm, sizeof(dnm), "pw_kernel<%d,%d,%d,%d,1,1>", PT, CT, WM, WN);   // (spelled like the symbol: SIMPLE, DW)
             (void)dnm_len;
             yr_note_kernel(dnm);
             hipLaunchKernelGGL((pw_kernel<PT, CT, WM, WN, true, true>), grid, dim3(256), (size_t)11 * a.S.kp * sizeof(float), s, a);
@@ -234,8 +234,8 @@ static int launch_cfg(const PwArgs& a, hipStream_t s) {
     }
     const bool simple = a.S.n == 1 && a.S.s[0].xform == YR_X_IDENTITY;
     static char nm[2][48];
-    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "pw_kernel<%d,%d,%d,%d,0>", PT, CT, WM, WN) +
-                              snprintf(nm[1], sizeof(nm[1]), "pw_kernel<%d,%d,%d,%d,1>", PT, CT, WM, WN);
+    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "pw_kernel<%d,%d,%d,%d,0,0>", PT, CT, WM, WN) +
+                              snprintf(nm[1], sizeof(nm[1]), "pw_kernel<%d,%d,%d,%d,1,0>", PT, CT, WM, WN);
     (void)nm_len;
     yr_note_kernel(nm[simple ? 1 : 0]);
     if (simple) hipLaunchKernelGGL((pw_kernel<PT, CT, WM, WN, true>), grid, dim3(256), 0, s, a);
