@@ -57,10 +57,24 @@ __device__ __forceinline__ float dwl_act(float v, int act) {
 
 constexpr int DWL_STAGE_U = 10;   // 16-byte loads in flight per lane while staging: the usual tile (up to 320 halo pixels) in ONE round trip
 
-template <class T, int K, int ACT, bool SE>
+// Both the halo tile's loads and the stores go through buffer descriptors (one image of the map each, < 2 GB): a lane whose
+// pixel is padding, whose channels are beyond C or whose column is beyond W passes an offset beyond num_records - the load
+// returns zeros, the store is dropped - so neither needs clamped coordinates, selects or a per-lane branch (round 3: the
+// kernel is VALU-bound and more than half of its instructions were NOT the multiply-adds, profiles/r03_pmc_sq_c3*).
+typedef __amdgpu_buffer_rsrc_t dwl_rsrc;
+typedef unsigned dwl_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dwl_rsrc dwl_make_rsrc(const void* base, unsigned bytes) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)base), hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)base >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+constexpr unsigned DWL_DEAD = 0x80000000u;
+
+// UNI: the two (strip, band) slots of every wave share their band (an even number of strips): the row conditions of the
+// sliding window are then wave-uniform and compile to scalar branches instead of exec masks.
+template <class T, int K, int ACT, bool SE, bool UNI>
 __global__ __launch_bounds__(256) void dwl_kernel(DwlArgs a) {
     constexpr int HALO = K - 1, KK = K * K, NQ = (4 + HALO) / 2;   // extra rows / columns of the window; taps; 8-byte reads per input row
-    extern __shared__ unsigned dwl_tile[];   // [th + HALO][32][twp]
+    extern __shared__ unsigned dwl_tile[];   // [th + HALO][32][twp], then 4 * twp words nobody reads (where staging slots beyond the tile write)
     const unsigned lin = yr_xcd_swizzle(blockIdx.x, a.nblocks);
     // spatially adjacent tiles of one channel chunk are consecutive: their halos meet in one XCD's L2
     const int tx = (int)(lin % (unsigned)a.ntx);
@@ -92,36 +106,34 @@ __global__ __launch_bounds__(256) void dwl_kernel(DwlArgs a) {
         const int cols = a.tw + HALO;
         const int npix = (rows_here + HALO) * cols;
         const bool cv_ok = cc * 8 + cv < a.C8;
-        const T* base = reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * a.ld_in + (size_t)(cv_ok ? cc * 8 + cv : 0) * 8;
+        const dwl_rsrc src = dwl_make_rsrc(reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * a.ld_in, (unsigned)(a.H * a.W * a.ld_in) * 2u);
+        const unsigned cvb = (unsigned)(cc * 8 + cv) * 16u;
+        const int sink = (a.th + HALO) * 32 * a.twp;
         int r = slot / cols, j = slot - r * cols;
-        for (int p0 = slot; p0 < npix; p0 += 32 * a.stage_u) {
-            uint4 v[DWL_STAGE_U];
+        for (int p0 = 0; p0 < npix; p0 += 32 * a.stage_u) {
+            dwl_u4 v[DWL_STAGE_U];
             int woff[DWL_STAGE_U];
-            unsigned okm = 0u;
 #pragma unroll
             for (int u = 0; u < DWL_STAGE_U; ++u) {
-                woff[u] = -1;
                 if (u < a.stage_u) {   // uniform
-                const int iy = y0 - a.pad_t + r, ix = x0 - a.pad_l + j;
-                const bool ok = cv_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && p0 + 32 * u < npix;
-                const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
+                    const int iy = y0 - a.pad_t + r, ix = x0 - a.pad_l + j;
+                    const bool in_tile = p0 + slot + 32 * u < npix;
+                    const bool ok = cv_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && in_tile;
+                    unsigned voff = (unsigned)((iy * a.W + ix) * a.ld_in) * 2u + cvb;
 #ifdef YR_DW_EXPERIMENT
-                v[u] = a.dbg == 2 ? make_uint4(cy, cx, 0u, 0u) : *reinterpret_cast<const uint4*>(base + ((size_t)cy * a.W + cx) * a.ld_in);
-#else
-                v[u] = *reinterpret_cast<const uint4*>(base + ((size_t)cy * a.W + cx) * a.ld_in);
+                    if (a.dbg == 2) voff = DWL_DEAD;
 #endif
-                okm |= ok ? 1u << u : 0u;
-                woff[u] = p0 + 32 * u < npix ? (r * 32 + cv * 4) * a.twp + j : -1;
-                j += a.step_j; r += a.step_r;          // 32 pixels on, row-major
-                if (j >= cols) { j -= cols; ++r; }
+                    v[u] = __builtin_amdgcn_raw_buffer_load_b128(src, ok ? voff : DWL_DEAD, 0, 0);
+                    woff[u] = in_tile ? (r * 32 + cv * 4) * a.twp + j : sink;
+                    j += a.step_j; r += a.step_r;          // 32 pixels on, row-major
+                    if (j >= cols) { j -= cols; ++r; }
                 }
             }
 #pragma unroll
             for (int u = 0; u < DWL_STAGE_U; ++u) {
-                if (u < a.stage_u && woff[u] >= 0) {
-                    const bool ok = (okm >> u) & 1u;
+                if (u < a.stage_u) {
                     unsigned* d = dwl_tile + woff[u];
-                    d[0] = ok ? v[u].x : 0u; d[a.twp] = ok ? v[u].y : 0u; d[2 * a.twp] = ok ? v[u].z : 0u; d[3 * a.twp] = ok ? v[u].w : 0u;
+                    d[0] = v[u].x; d[a.twp] = v[u].y; d[2 * a.twp] = v[u].z; d[3 * a.twp] = v[u].w;
                 }
             }
         }
@@ -131,13 +143,19 @@ __global__ __launch_bounds__(256) void dwl_kernel(DwlArgs a) {
     // ---- slide down the band: input row rr of the band feeds output rows rr - ky
     const int yb0 = band * a.band_rows;
     int nrows = min(a.band_rows, rows_here - yb0);
-    if (band >= a.nband || !chan_ok) nrows = 0;
+    if (band >= a.nband) nrows = 0;
 #ifdef YR_DW_EXPERIMENT
     if (a.dbg == 1) nrows = 0;
 #endif
+    if constexpr (UNI) nrows = __builtin_amdgcn_readfirstlane(nrows);
     const int nin = nrows > 0 ? nrows + HALO : 0;
     const int xo = x0 + strip * 4;
-    T* orow = reinterpret_cast<T*>(a.out) + (((size_t)b * a.H + y0 + yb0) * a.W + xo) * a.ld_out + cl;
+    const dwl_rsrc dst = dwl_make_rsrc(reinterpret_cast<T*>(a.out) + (size_t)b * a.H * a.W * a.ld_out, (unsigned)(a.H * a.W * a.ld_out) * 2u);
+    const unsigned opitch = (unsigned)(a.W * a.ld_out) * 2u;
+    unsigned ooff[4];   // the lane's four output pixels within a row (bytes), dead beyond W / C
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ooff[i] = chan_ok && xo + i < a.W ? (unsigned)((xo + i) * a.ld_out + cl) * 2u : DWL_DEAD;
+    unsigned orow = (unsigned)(y0 + yb0) * opitch;
     const unsigned* trow = dwl_tile + (yb0 * 32 + cp) * a.twp + strip * 4;
     const int tpitch = 32 * a.twp;
     dwl_f2 psum = (dwl_f2){0.f, 0.f};   // SE: what this lane stored, per channel (rounded values, fixed order)
@@ -166,25 +184,22 @@ __global__ __launch_bounds__(256) void dwl_kernel(DwlArgs a) {
 #pragma unroll
                         for (int kx = 0; kx < K; ++kx)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) acc[s][i] = __builtin_elementwise_fma(col[i + kx], w[ky * K + kx], acc[s][i]);
+                            for (int i = 0; i < 4; ++i)   // the row's first tap starts the sum from a literal zero: no pass that clears the slot
+                                acc[s][i] = __builtin_elementwise_fma(col[i + kx], w[ky * K + kx], ky == 0 && kx == 0 ? (dwl_f2){0.f, 0.f} : acc[s][i]);
                     }
                 }
                 const int sd = (ph + 1) % K;               // the slot of output row rr - HALO
                 if (rr >= HALO) {
-                    T* op = orow + (size_t)(rr - HALO) * a.W * a.ld_out;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
+                        typedef T t2 __attribute__((ext_vector_type(2)));
                         const dwl_f2 y = __builtin_elementwise_fma(acc[sd][i], sc, sh);
-                        if (xo + i < a.W) {
-                            typedef T t2 __attribute__((ext_vector_type(2)));
-                            const t2 r = __builtin_convertvector((dwl_f2){dwl_act<ACT, T>(y.x, a.act), dwl_act<ACT, T>(y.y, a.act)}, t2);
-                            *reinterpret_cast<t2*>(op + (size_t)i * a.ld_out) = r;
-                            if constexpr (SE) psum += __builtin_convertvector(r, dwl_f2);
-                        }
+                        const t2 r = __builtin_convertvector((dwl_f2){dwl_act<ACT, T>(y.x, a.act), dwl_act<ACT, T>(y.y, a.act)}, t2);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), dst, orow + ooff[i], 0, 0);
+                        if constexpr (SE) psum += ooff[i] != DWL_DEAD ? __builtin_convertvector(r, dwl_f2) : (dwl_f2){0.f, 0.f};
                     }
+                    orow += opitch;
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[sd][i] = (dwl_f2){0.f, 0.f};
             }
         }
     }
@@ -236,11 +251,28 @@ static void dwl_geometry(int H, int W, int K, DwlArgs* a) {
     }
 }
 
+template <class T, int K, bool SE, bool UNI>
+static int launch_dwl_u(const DwlArgs& a, size_t lds, hipStream_t s) {
+    const int actv = a.act == YR_ACT_RELU6 ? 0 : (a.act == YR_ACT_SWISH ? 1 : 2);
+    static char nm[3][48];   // spelled like the symbol (element type, K, activation variant, SE, UNI): profiles are joined on it
+    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "dwl_kernel<%s,%d,0,%d,%d>", yr_dtype_name(yr_elem<T>::dtype), K, (int)SE, (int)UNI) +
+                              snprintf(nm[1], sizeof(nm[1]), "dwl_kernel<%s,%d,1,%d,%d>", yr_dtype_name(yr_elem<T>::dtype), K, (int)SE, (int)UNI) +
+                              snprintf(nm[2], sizeof(nm[2]), "dwl_kernel<%s,%d,2,%d,%d>", yr_dtype_name(yr_elem<T>::dtype), K, (int)SE, (int)UNI);
+    (void)nm_len;
+    yr_note_kernel(nm[actv]);
+    if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((dwl_kernel<T, K, 0, SE, UNI>), dim3(a.nblocks), dim3(256), lds, s, a);
+    else if (a.act == YR_ACT_SWISH) hipLaunchKernelGGL((dwl_kernel<T, K, 1, SE, UNI>), dim3(a.nblocks), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((dwl_kernel<T, K, 2, SE, UNI>), dim3(a.nblocks), dim3(256), lds, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
 template <class T, int K, bool SE>
 static int launch_dwl_t(DwlArgs a, int expect_rows, hipStream_t s) {
     constexpr int HALO = K - 1;
     dwl_geometry(a.H, a.W, K, &a);
     if (SE) YR_REQUIRE(a.ntx * a.nty == expect_rows, "depthwise (LDS form): the SE partial-sum buffer must hold %d rows per image (has %d)", a.ntx * a.nty, expect_rows);
+    YR_REQUIRE((long long)a.H * a.W * (a.ld_in > a.ld_out ? a.ld_in : a.ld_out) * 2 < (1ll << 31), "depthwise (LDS form): one image of the map must be below 2 GB");
     a.ncc = (a.C8 + 7) / 8;
     a.step_r = 32 / (a.tw + HALO); a.step_j = 32 % (a.tw + HALO);
     {
@@ -251,19 +283,8 @@ static int launch_dwl_t(DwlArgs a, int expect_rows, hipStream_t s) {
     YR_REQUIRE(blocks < (1ll << 31), "depthwise: grid too large");
     a.nblocks = (unsigned)blocks;
     a.dbg = getenv("YR_DWL_DBG") ? atoi(getenv("YR_DWL_DBG")) : 0;
-    const size_t lds = (size_t)(a.th + HALO) * 32 * a.twp * 4;
-    const int actv = a.act == YR_ACT_RELU6 ? 0 : (a.act == YR_ACT_SWISH ? 1 : 2);
-    static char nm[3][48];   // spelled like the symbol (element type, K, activation variant, SE): profiles are joined on it
-    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "dwl_kernel<%s,%d,0,%d>", yr_dtype_name(yr_elem<T>::dtype), K, (int)SE) +
-                              snprintf(nm[1], sizeof(nm[1]), "dwl_kernel<%s,%d,1,%d>", yr_dtype_name(yr_elem<T>::dtype), K, (int)SE) +
-                              snprintf(nm[2], sizeof(nm[2]), "dwl_kernel<%s,%d,2,%d>", yr_dtype_name(yr_elem<T>::dtype), K, (int)SE);
-    (void)nm_len;
-    yr_note_kernel(nm[actv]);
-    if (a.act == YR_ACT_RELU6) hipLaunchKernelGGL((dwl_kernel<T, K, 0, SE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
-    else if (a.act == YR_ACT_SWISH) hipLaunchKernelGGL((dwl_kernel<T, K, 1, SE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((dwl_kernel<T, K, 2, SE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
-    YR_LAUNCH_CHECK();
-    return YR_OK;
+    const size_t lds = ((size_t)(a.th + HALO) * 32 + 4) * a.twp * 4;
+    return a.nstrip % 2 == 0 ? launch_dwl_u<T, K, SE, true>(a, lds, s) : launch_dwl_u<T, K, SE, false>(a, lds, s);
 }
 
 template <class T>
