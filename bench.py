@@ -251,7 +251,7 @@ def main():
         alg_img = alg_fwd + alg_dec + plan.weight_bytes() / b
         flops_img = 2.0 * plan.total_macs()
         # ---- live per-kernel measurement (hipEvent pair around every launch, same stream)
-        prof = model.profile(x, iters=a.profile_iters)
+        prof = model.profile(x, iters=max(1, a.profile_iters))   # (--profile-iters 0: one pass, the line needs its per-kernel table)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ys = pipe1.forward(x)
         post_ms = np.zeros(3)

@@ -384,21 +384,29 @@ def dw_se_geometry(strips, c4):
 DW_LDS = os.environ.get('YOLORET_DW_LDS', '1') != '0'
 
 
-def dwl_geometry(h, w, k=5):
-    """== dwl_geometry() in depthwise_lds.hip (integer arithmetic, the same choice): (tiles along x, tiles along y) of the
-    LDS-tiled k x k stride-1 depthwise form; its squeeze-excite variant writes one row of channel sums per tile."""
+def dwl_geometry(h, w, k=5, se=True):
+    """== dwp_geometry() in depthwise_lds.hip (integer arithmetic, the same choice): (tiles along x, tiles along y) of the
+    LDS-tiled k x k stride-1 depthwise form; its squeeze-excite variant (se: two tile buffers of at most 192 halo pixels,
+    208 without the partial sums behind them) writes one row of channel sums per tile."""
     halo = k - 1
-    row_cost, warm_cost = (8000, 1280) if k == 5 else (3600, 576)
+    cap = 192 if se else 208
+    row_cost, in_cost, round_cost, tile_cost = k * k * 4 + 21, 3 * (4 + halo), 12, 60
     best = None
-    for tw in range(4, 33, 4):
-        nstrip, twp = tw // 4, tw + 6
-        ntx = (w + tw - 1) // tw
-        th = max(4, min(h, 48 * 1024 // (32 * twp * 4) - halo))
+    for tw in range(8, 33, 8):
+        cols, nstrip = tw + halo, tw // 4
+        th = cap // cols - halo
+        if th < 1:
+            continue
+        th = min(th, h)
         nty = (h + th - 1) // th
         th = (h + nty - 1) // nty
+        ntx = (w + tw - 1) // tw
         nband = min(8 // nstrip, th)
         band_rows = (th + nband - 1) // nband
-        cost = ntx * nty * (row_cost * band_rows + warm_cost * halo + 30 * (tw + halo) * (th + halo))
+        if band_rows > 6:
+            continue
+        rounds = ((th + halo) * cols + 31) // 32
+        cost = ntx * nty * (row_cost * band_rows + in_cost * (band_rows + halo) + round_cost * rounds + tile_cost)
         if best is None or cost < best[0]:
             best = (cost, ntx, nty)
     return best[1], best[2]
