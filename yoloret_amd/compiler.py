@@ -281,6 +281,13 @@ MBX_SKIP = set(os.environ.get('YOLORET_MBX_SKIP', '').replace(' ', '').split(','
 # form only fuses expand + depthwise, and its 5x5 stride-1 blocks lose to the unfused pair everywhere (B0 19.8k -> 20.7k, B3
 # 4.87k -> 4.94k).  Stride-2 5x5 blocks stay fused (lite0 -3.7 % unfused), 3x3 blocks too (lite3 -11 %).
 MBH_K5_MAX_CEXP = int(os.environ.get('YOLORET_MBH_K5_MAX_CEXP', '320'))
+# Round 3, with the walking depthwise form (depthwise_lds.hip: 52 x 52 x 240 at batch 128 in 0.12 ms, was 0.17): on maps of at
+# most MBH_K5_SMALL_MAP pixels the unfused chain also wins from MBH_K5_SMALL_CEXP expanded channels on - lite0 stage 3
+# block 1 (52 x 52, 240 expanded): 36.0k -> 37.4k img/s with three steps in flight (serial 32.7k -> 32.9k: the three shorter
+# kernels overlap with the other steps' better than one long block kernel); lite3's 80 x 80 x 288 blocks stay fused
+# (9.8k -> 9.4k img/s unfused).
+MBH_K5_SMALL_MAP = int(os.environ.get('YOLORET_MBH_K5_SMALL_MAP', '4096'))
+MBH_K5_SMALL_CEXP = int(os.environ.get('YOLORET_MBH_K5_SMALL_CEXP', '200'))
 MBX_K5_MAX_CEXP = int(os.environ.get('YOLORET_MBX_K5_MAX_CEXP', '0'))
 MBH_K3_MAX_CEXP = int(os.environ.get('YOLORET_MBH_K3_MAX_CEXP', '1000000'))   # the same switch for 3x3 stride-1 blocks
 FUSE_STEMDW = os.environ.get('YOLORET_FUSE_STEMDW', '1') != '0'   # stem + first depthwise of the SE EfficientNets in one kernel
@@ -658,7 +665,7 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
         # MobileNetV2 block at batch 64 and the float32 lane kernels where both apply)
         mbh = None
         if (FUSE_MBH and dtype != 0 and blocks and exp is not None and d is not None and d.kind == rt.OP_DEPTHWISE and d.k in (3, 5)
-                and d.stride in (1, 2) and '%d%d' % (d.k, d.stride) not in MBH_SKIP and not (d.k == 5 and d.stride == 1 and d.cin > MBH_K5_MAX_CEXP) and not (d.k == 3 and d.stride == 1 and d.cin > MBH_K3_MAX_CEXP) and plain1(d) and private(d.out) and d.srcs[0].buf is exp.out and d.act == exp.act
+                and d.stride in (1, 2) and '%d%d' % (d.k, d.stride) not in MBH_SKIP and not (d.k == 5 and d.stride == 1 and (d.cin > MBH_K5_MAX_CEXP or (d.cin > MBH_K5_SMALL_CEXP and d.h * d.w <= MBH_K5_SMALL_MAP))) and not (d.k == 3 and d.stride == 1 and d.cin > MBH_K3_MAX_CEXP) and plain1(d) and private(d.out) and d.srcs[0].buf is exp.out and d.act == exp.act
                 and d.act in MBH_ACTS and j + 1 < len(ops)):
             p = ops[j + 1]
             bi = exp.srcs[0]
