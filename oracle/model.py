@@ -60,7 +60,8 @@ def mobilenet_v2(P, x, alpha, last_block=15):
     override only swaps BatchNormalization momentum, override.py:207-227)."""
     acts = {}
     first = _make_divisible(32 * alpha, 8)
-    x = nn.conv2d(x, P.conv('Conv1', 3, 3, first), stride=2, padding='same')
+    x, w = P.entry(x, P.conv('Conv1', 3, 3, first))
+    x = nn.conv2d(x, w, stride=2, padding='same')
     x = P.store(nn.relu6(_bn(P, 'bn_Conv1', x)))
     acts['Conv1_relu'] = x
     for b, (f, s, t) in enumerate(MBV2_BLOCKS[:last_block + 1]):
@@ -151,7 +152,10 @@ def efficientnet(P, x, width, depth, lite=False, last_stage=6):
     returns {'stage{n}': activation at end of stage n}."""
     act = nn.relu6 if lite else nn.swish
     stem = round_filters(32, width)
-    x = nn.conv2d(x, P.conv('stem_conv', 3, 3, stem), stride=2, padding='same')
+    w = P.conv('stem_conv', 3, 3, stem)
+    if lite:   # (the SE-free entry is one fused op of the product; the squeeze-excite networks' stem stays float32)
+        x, w = P.entry(x, w)
+    x = nn.conv2d(x, w, stride=2, padding='same')
     x = P.store(act(_bn(P, 'stem_BN', x)))
     acts = {}
     for si, (r, k, s, e, i, o, se) in enumerate(EFFNET_STAGES[:last_stage], start=1):

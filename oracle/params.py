@@ -79,6 +79,11 @@ class ParamStore:
         """Where a fused op writes its result to memory (oracle/model.py): float32 keeps the value as it is."""
         return x
 
+    @staticmethod
+    def entry(x, w):
+        """The image and the stem kernel as the fused network entry (stem + block 0) takes them: float32 as they are."""
+        return x, w
+
 
 def round16(a, dtype):
     """float32 -> nearest-even bfloat16 / float16 -> float32 (NumPy restatement of the storage rounding)."""
@@ -109,6 +114,11 @@ class QuantStore(ParamStore):
         if k == 1 and not name.endswith(('_se_reduce', '_se_expand')):
             return round16(w, self.dtype)
         return w
+
+    def entry(self, x, w):
+        """The fused network entry of a 16-bit plan runs its stem on the matrix pipe (stemblock_h.hip): image and stem
+        kernel are MFMA operands like every 1x1 convolution's (decoded uint8 pixels are exact in either type)."""
+        return round16(x, self.dtype), round16(w, self.dtype)
 
 
 def synthetic_images(batch, h, w, seed=20240416):

@@ -266,6 +266,10 @@ FUSE_LANE = os.environ.get('YOLORET_FUSE_LANE', '1') != '0'              # narro
 FUSE_LANE_MIN_PIXELS = int(os.environ.get('YOLORET_FUSE_LANE_MIN_PIXELS', '600'))  # mblane still wins on 26x26 outputs (block_6)
 MBLANE_WIDTHS = {(4, 16), (4, 24), (6, 24), (6, 32), (6, 40), (6, 48), (8, 32), (8, 40), (8, 48)}  # (CINP/4, round_up(cout,8)) built in mblane.hip
 STEMBLOCK_WIDTHS ={(12, 16), (16, 16), (16, 24), (20, 24), (24, 16), (24, 24)}  # (C1p/2, round_up(cout,8)) built in stemblock.hip
+STEM_MFMA = os.environ.get('YOLORET_STEM_MFMA', '1') != '0'   # 16-bit plans: the network entry on the matrix pipe (stemblock_h.hip)
+# ... for stems of at most 32 channels (MobileNetV2 x0.75 / x1.0, EfficientNet-lite0..2: 0.31 -> 0.22 ms per 128 images at 416).  The
+# depthwise stage works on 32-channel k steps: lite3's 40 channels pay for 64 and lose to the float32-pipe kernel (0.27 vs 0.24 ms)
+STEM_MFMA_MAX_C1 = int(os.environ.get('YOLORET_STEM_MFMA_MAX_C1', '32'))
 
 
 FUSE_MBH = os.environ.get('YOLORET_FUSE_MBH', '1') != '0'   # 16-bit plans: inverted-residual blocks on the MFMA block kernel (mbh.hip)
@@ -604,6 +608,39 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                     o[:, :cout] = pw(wd)[:, :c1p].T       # pointwise layout is Wt[cout][kp]
                     return o
                 pp2 = p.params
+                img = e.srcs[0].buf
+                if STEM_MFMA and dtype != 0 and img.h % 2 == 0 and img.w % 2 == 0 and c1 <= STEM_MFMA_MAX_C1 and cout <= 32:
+                    # 16-bit plans: the matrix-pipe form (stemblock_h.hip).  Stem weights as the plan's type, [C1P][32] with the k
+                    # space in the kernel's order: image rows 0..2 x values 0..7 of the row's 9 (kx, c) | value 8 of rows 0..2 | 0 x 5
+                    c1m, com = round_up(c1, 32), round_up(cout, 16)
+                    korder = [g * 9 + i_ for g in range(3) for i_ in range(8)] + [i_ * 9 + 8 for i_ in range(3)]
+
+                    def stem_w(wd, ew=e.params['wgt'][1], c1=c1, c1m=c1m, korder=korder):
+                        o = np.zeros((c1m, 32), np.float32)
+                        o[:c1, :27] = ew(wd)[korder, :c1].T
+                        return o
+
+                    def dw_rows(wd, dp=d.params, c1=c1, c1m=c1m):
+                        o = np.zeros((10, c1m), np.float32)
+                        sc = dp['scale'][1](wd)[:c1]
+                        o[:9, :c1] = (dp['wgt'][1](wd).reshape(9, -1)[:, :c1] * sc[None]).astype(np.float32)
+                        o[9, :c1] = dp['shift'][1](wd)[:c1]
+                        return o
+
+                    def proj_m(wd, pw=p.params['wgt'][1], c1=c1, c1m=c1m, com=com, cout=cout):
+                        o = np.zeros((com, c1m), np.float32)
+                        o[:cout, :c1] = pw(wd)[:cout, :c1]       # pointwise layout is Wt[cout][kp]
+                        return o
+                    m.params['wgt'] = ((c1m, 32), stem_w, dtype)
+                    m.params['scale'] = ((c1m,), pad_to(e.params['scale'][1], c1, c1m))
+                    m.params['shift'] = ((c1m,), pad_to(e.params['shift'][1], c1, c1m))
+                    m.params['wgt2'] = ((10, c1m), dw_rows)
+                    m.params['b1'] = ((com, c1m), proj_m, dtype)
+                    m.params['b2'] = ((2 * com,), lambda wd, pp2=pp2, cout=cout, com=com: np.concatenate(
+                        [pad_to(pp2['scale'][1], cout, com)(wd), pad_to(pp2['shift'][1], cout, com)(wd)]))
+                    out.append(m)
+                    i += 3
+                    continue
                 m.params['wgt'] = per_pair(e.params, 27)
                 m.params['wgt2'] = per_pair(d.params, 9)
                 m.params['b1'] = ((c1p, cop), proj_w)

@@ -341,4 +341,9 @@ static int launch_stemblock_t(const yr_op& op, int batch, hipStream_t s) {
     }
 }
 
-int yr_launch_stemblock(const yr_op& op, int batch, hipStream_t s) { return YR_BY_DTYPE(op.dtype, launch_stemblock_t, op, batch, s); }
+int yr_launch_stemblock_h(const yr_op& op, int batch, hipStream_t s);   // stemblock_h.hip: the matrix-pipe form of the 16-bit plans
+
+int yr_launch_stemblock(const yr_op& op, int batch, hipStream_t s) {
+    if (op.dtype != YR_F32 && op.scale != nullptr) return yr_launch_stemblock_h(op, batch, s);   // (the compiler's matrix-pipe parameter layout)
+    return YR_BY_DTYPE(op.dtype, launch_stemblock_t, op, batch, s);
+}
