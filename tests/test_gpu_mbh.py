@@ -56,6 +56,12 @@ def test_mbh(dev, case, dt):
     we = q16(rng.standard_normal((cin, cexp)) * np.sqrt(2.0 / cin), dt)
     se, he = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
     t = _act(nn.pointwise(x.astype(np.float64), we.astype(np.float64)) * se + he, act)
+    mbn = k == 3 and s == 2 and cin <= 32 and cin % 8 == 0 and cexp <= 96 and cout <= 32 and not residual and tile is None
+    if mbn:
+        # the narrow stride-2 block at the network's front runs on mbn_h.hip, which keeps the WHOLE expanded halo tile on chip
+        # in the 16-bit type (the unfused chain's rounding point, oracle/model.py P.store); an expanded value on a rounding
+        # boundary may go the other way than in float64: twice the slack
+        t = q16(t.astype(np.float32), dt).astype(np.float64)
     wd = (rng.standard_normal((k, k, cexp)) * np.sqrt(2.0 / (k * k))).astype(np.float32)
     sd, hd = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
     t = _act(nn.depthwise(t, wd.astype(np.float64), s, 'same') * sd + hd, act)
@@ -94,7 +100,7 @@ def test_mbh(dev, case, dt):
     op.out, op.out_ld = out.data_ptr(), ldo
     rt.run_op(op, b)
     torch.cuda.synchronize()
-    assert_rounded_once(from_dev16(out, dt, cout), ref, dt, 'mbh %s %s' % (dt, case), slack={'bf16': 4e-3, 'f16': 5e-4}[dt])
+    assert_rounded_once(from_dev16(out, dt, cout), ref, dt, 'mbh %s %s' % (dt, case), slack={'bf16': 4e-3, 'f16': 5e-4}[dt] * (2 if mbn else 1))
 
 
 def test_mbh_rejects_what_it_is_not_built_for(dev):

@@ -275,6 +275,7 @@ STEM_MFMA_MAX_C1 = int(os.environ.get('YOLORET_STEM_MFMA_MAX_C1', '32'))
 FUSE_MBH = os.environ.get('YOLORET_FUSE_MBH', '1') != '0'   # 16-bit plans: inverted-residual blocks on the MFMA block kernel (mbh.hip)
 MBH_LANE_MIN_PIXELS = int(os.environ.get('YOLORET_MBH_LANE_MIN_PIXELS', '10000'))
 MBH_LANE_MAX_CIN = int(os.environ.get('YOLORET_MBH_LANE_MAX_CIN', '16'))
+MBN = os.environ.get('YOLORET_MBN', '1') != '0'   # the narrow stride-2 3x3 front block of the 16-bit plans on its own matrix-pipe kernel (mbn_h.hip)
 # (kernel size, stride) pairs the fused 16-bit block kernels do NOT take, e.g. '51,52' = 5x5 stride 1 and 2 (A/B runs)
 MBH_SKIP = set(os.environ.get('YOLORET_MBH_SKIP', '').replace(' ', '').split(',')) - {''}
 MBX_SKIP = set(os.environ.get('YOLORET_MBX_SKIP', '').replace(' ', '').split(',')) - {''}
@@ -715,7 +716,10 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                 # halo tile leaves two workgroups per CU); from block_2 on (0.205 vs 0.138 ms) everything goes to mbh.  With 24
                 # block inputs the lane kernel loses there too (EfficientNet-lite3 stage 2 entry, 320 x 320 -> 160 x 160, 32 images:
                 # 0.48 vs 0.41 ms): only blocks of at most 16 inputs stay on it
-                if lane_ok(exp, bi, p) and d.k == 3 and d.stride == 2 and p.h * p.w >= MBH_LANE_MIN_PIXELS and bi.c <= MBH_LANE_MAX_CIN:
+                # round 3: that block has its own matrix-pipe kernel (mbn_h.hip, dispatched by yr_launch_mbh: 3x3 stride 2, at most 32
+                # inputs in whole 16-byte vectors, at most 96 expanded channels, at most 32 outputs)
+                mbn = MBN and d.k == 3 and d.stride == 2 and bi.c <= 32 and bi.c % 8 == 0 and d.cin <= 96 and p.cout <= 32 and p.res is None
+                if not mbn and lane_ok(exp, bi, p) and d.k == 3 and d.stride == 2 and p.h * p.w >= MBH_LANE_MIN_PIXELS and bi.c <= MBH_LANE_MAX_CIN:
                     mbh = None
         mbx = None
         if (FUSE_MBX and mbh is None and bufs is not None and dtype != 0 and blocks and exp is not None and d is not None

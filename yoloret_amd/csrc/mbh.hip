@@ -31,6 +31,11 @@
 // permutation of pointwise_h.hip).
 #include "yr_common.h"
 
+#include <cstdlib>
+
+bool yr_mbn_takes(const yr_op& op);                               // mbn_h.hip
+int yr_launch_mbn(const yr_op& op, int batch, hipStream_t s);
+
 typedef float mbh_f4 __attribute__((ext_vector_type(4)));
 typedef float mbh_f8 __attribute__((ext_vector_type(8)));
 typedef unsigned mbh_u4 __attribute__((ext_vector_type(4)));
@@ -583,6 +588,10 @@ static int launch_mbh_t(const yr_op& op, int batch, hipStream_t s) {
                "mbh: channel strides must be multiples of 8 and cover round_up(c,8)");
     YR_REQUIRE(((uintptr_t)in.ptr | (uintptr_t)op.out | (uintptr_t)op.wgt | (uintptr_t)op.b1 | (uintptr_t)op.wgt2) % 16 == 0, "mbh: pointers must be 16-byte aligned");
     YR_REQUIRE(op.cout >= 1 && op.cin >= 1 && op.cin <= 128, "mbh: widths out of range (cin <= 128)");
+    {   // the narrow stride-2 3x3 block at the network's front: its own kernel (mbn_h.hip; YOLORET_MBN=0: this one, for A/B runs)
+        static const bool mbn_on = !(getenv("YOLORET_MBN") && atoi(getenv("YOLORET_MBN")) == 0);
+        if (mbn_on && yr_mbn_takes(op)) return yr_launch_mbn(op, batch, s);
+    }
     MbhArgs a;
     a.x = in.ptr; a.out = op.out;
     a.Cin = in.c; a.Cout = op.cout;
