@@ -717,8 +717,8 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                 # block inputs the lane kernel loses there too (EfficientNet-lite3 stage 2 entry, 320 x 320 -> 160 x 160, 32 images:
                 # 0.48 vs 0.41 ms): only blocks of at most 16 inputs stay on it
                 # round 3: that block has its own matrix-pipe kernel (mbn_h.hip, dispatched by yr_launch_mbh: 3x3 stride 2, at most 32
-                # inputs in whole 16-byte vectors, at most 96 expanded channels, at most 32 outputs)
-                mbn = MBN and d.k == 3 and d.stride == 2 and bi.c <= 32 and bi.c % 8 == 0 and d.cin <= 96 and p.cout <= 32 and p.res is None
+                # inputs in whole 16-byte vectors, at most 192 expanded channels, at most 32 outputs)
+                mbn = MBN and d.k == 3 and d.stride == 2 and bi.c <= 32 and bi.c % 8 == 0 and d.cin <= 192 and p.cout <= 32 and p.res is None
                 if not mbn and lane_ok(exp, bi, p) and d.k == 3 and d.stride == 2 and p.h * p.w >= MBH_LANE_MIN_PIXELS and bi.c <= MBH_LANE_MAX_CIN:
                     mbh = None
         mbx = None

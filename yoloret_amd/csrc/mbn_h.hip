@@ -51,10 +51,14 @@ __device__ __forceinline__ float mbn_act(float v) {
     else return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));   // swish, as in mbh.hip
 }
 
-// NE = CexpP / 16 (2 | 4 | 6), NCO = round_up(Cout, 16) / 16 (1 | 2)
+// NE = CexpP / 16 (even, <= 12), NCO = round_up(Cout, 16) / 16 (1 | 2).  More than 96 expanded channels go in PASSES of 96
+// (lite3's 24 -> 144 -> 32 entry block: 96 + 64): the pixel operands stay in registers, Es holds one pass, the projection
+// accumulates over all of them.
 template <class T, int NE, int NCO, int ACT>
 __global__ __launch_bounds__(256) void mbn_kernel(MbnArgs a) {
-    constexpr int CEP = 16 * NE, KS = CEP / 32, LDE = CEP + 8;   // Es row pitch 80 / 144 / 208 bytes: conflict-free 16-byte rows
+    constexpr int CEP = 16 * NE, KS = CEP / 32;                  // all expanded channels: row pitch of the parameter arrays, k steps
+    constexpr int NEP = NE < 6 ? NE : 6, NP = (NE + 5) / 6;      // 16-channel tiles per pass, passes
+    constexpr int LDE = 16 * NEP + 8;                            // Es row pitch 80 / 144 / 208 bytes: conflict-free 16-byte rows
     extern __shared__ __attribute__((aligned(16))) char mbn_lds[];
     T* Es = reinterpret_cast<T*>(mbn_lds);   // [256 halo pixels][LDE]
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
@@ -65,12 +69,12 @@ __global__ __launch_bounds__(256) void mbn_kernel(MbnArgs a) {
     const int oy0 = ty * MBN_TH, ox0 = tx * MBN_TW;
     const int iy0 = oy0 * 2 - a.pad_t, ix0 = ox0 * 2 - a.pad_l;
 
-    // ---- 1. expand
+    // the halo pixels of this wave's four MFMA tiles: the expand GEMM's B operands, straight from global memory
+    mbn_u4 xf[4];
+    bool inmap[4];
     {
         const mbn_rsrc src = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(reinterpret_cast<const T*>(a.x) + (size_t)b * a.Hi * a.Wi * a.ld_in), 0, (unsigned)(a.Hi * a.Wi * a.ld_in) * 2u, 0x00020000);
-        mbn_u4 xf[4];
-        bool inmap[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int p = (wave * 4 + q) * 16 + li;
@@ -80,28 +84,8 @@ __global__ __launch_bounds__(256) void mbn_kernel(MbnArgs a) {
             const unsigned off = (unsigned)((iy * a.Wi + ix) * a.ld_in + 8 * g) * 2u;
             xf[q] = __builtin_bit_cast(mbn_u4, __builtin_amdgcn_raw_buffer_load_b128(src, inmap[q] && 8 * g < a.Cin ? off : 0x80000000u, 0, 0));
         }
-        mbn_u4 wef[NE];
-#pragma unroll
-        for (int j = 0; j < NE; ++j) wef[j] = *reinterpret_cast<const mbn_u4*>(reinterpret_cast<const T*>(a.we) + (size_t)(16 * j + li) * 32 + 8 * g);
-        const float* esc = a.prm + 11 * CEP + 4 * g;
-        const float* esh = a.prm + 12 * CEP + 4 * g;
-#pragma unroll
-        for (int j = 0; j < NE; ++j) {
-            const mbn_f4 sc = *reinterpret_cast<const mbn_f4*>(esc + 16 * j), sh = *reinterpret_cast<const mbn_f4*>(esh + 16 * j);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int p = (wave * 4 + q) * 16 + li;
-                const mbn_f4 acc = mbn_mfma<T>(wef[j], xf[q], (mbn_f4){0.f, 0.f, 0.f, 0.f});
-                mbn_f4 y = __builtin_elementwise_fma(acc, sc, sh);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) y[i] = inmap[q] ? mbn_act<ACT>(y[i]) : 0.f;
-                *reinterpret_cast<mbn_v4<T>*>(Es + (size_t)p * LDE + 16 * j + 4 * g) = __builtin_convertvector(y, mbn_v4<T>);
-            }
-        }
     }
-    __syncthreads();
-
-    // ---- 2. depthwise (stride 2) + projection: output pixel o = 16 wave + li of the tile's 56
+    // depthwise-phase identity: output pixel o = 16 wave + li of the tile's 56
     const int o = wave * 16 + li;
     const int oc = o < MBN_TH * MBN_TW ? o : MBN_TH * MBN_TW - 1;
     const int oy = oc >> 3, ox = oc & 7;
@@ -109,40 +93,69 @@ __global__ __launch_bounds__(256) void mbn_kernel(MbnArgs a) {
     mbn_f4 pacc[NCO];
 #pragma unroll
     for (int n = 0; n < NCO; ++n) pacc[n] = (mbn_f4){0.f, 0.f, 0.f, 0.f};
+
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int c0 = 32 * ks + 8 * g;
-        mbn_u4 wpf[NCO];
+    for (int ps = 0; ps < NP; ++ps) {
+        // ---- 1. expand: channels 96 ps ...
+        if (ps > 0) __syncthreads();   // the previous pass's windows have been read
 #pragma unroll
-        for (int n = 0; n < NCO; ++n) {
-            const int row = 16 * n + li;
-            wpf[n] = *reinterpret_cast<const mbn_u4*>(reinterpret_cast<const T*>(a.wp) + (size_t)(row < a.Cout ? row : 0) * CEP + c0);
+        for (int jj = 0; jj < NEP; ++jj) {
+            const int j = ps * 6 + jj;
+            if (j < NE) {
+                const mbn_u4 wef = *reinterpret_cast<const mbn_u4*>(reinterpret_cast<const T*>(a.we) + (size_t)(16 * j + li) * 32 + 8 * g);
+                const mbn_f4 sc = *reinterpret_cast<const mbn_f4*>(a.prm + 11 * CEP + 16 * j + 4 * g), sh = *reinterpret_cast<const mbn_f4*>(a.prm + 12 * CEP + 16 * j + 4 * g);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int p = (wave * 4 + q) * 16 + li;
+                    const mbn_f4 acc = mbn_mfma<T>(wef, xf[q], (mbn_f4){0.f, 0.f, 0.f, 0.f});
+                    mbn_f4 y = __builtin_elementwise_fma(acc, sc, sh);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] = inmap[q] ? mbn_act<ACT>(y[i]) : 0.f;
+                    *reinterpret_cast<mbn_v4<T>*>(Es + (size_t)p * LDE + 16 * jj + 4 * g) = __builtin_convertvector(y, mbn_v4<T>);
+                }
+            }
         }
-        mbn_f2 acc[4];
+        __syncthreads();
+
+        // ---- 2. depthwise (stride 2) + projection over this pass's k steps
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) {
-            const mbn_f4 wlo = *reinterpret_cast<const mbn_f4*>(a.prm + tp * CEP + c0), whi = *reinterpret_cast<const mbn_f4*>(a.prm + tp * CEP + c0 + 4);
-            const mbn_u4 raw = *reinterpret_cast<const mbn_u4*>(ewin + (size_t)((tp / 3) * MBN_IW + tp % 3) * LDE + 32 * ks);
-            const mbn_f8 xv = __builtin_convertvector(__builtin_bit_cast(mbn_v8<T>, raw), mbn_f8);   // (whole-vector cast: see stemblock_h.hip)
-            const mbn_f2 w2[4] = {(mbn_f2){wlo[0], wlo[1]}, (mbn_f2){wlo[2], wlo[3]}, (mbn_f2){whi[0], whi[1]}, (mbn_f2){whi[2], whi[3]}};
+        for (int kk = 0; kk < NEP / 2; ++kk) {
+            const int ks = ps * 3 + kk;
+            if (ks < KS) {
+                const int c0 = 32 * ks + 8 * g;
+                mbn_u4 wpf[NCO];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                acc[c] = __builtin_elementwise_fma((mbn_f2){xv[2 * c], xv[2 * c + 1]}, w2[c], tp == 0 ? (mbn_f2){0.f, 0.f} : acc[c]);
+                for (int n = 0; n < NCO; ++n) {
+                    const int row = 16 * n + li;
+                    wpf[n] = *reinterpret_cast<const mbn_u4*>(reinterpret_cast<const T*>(a.wp) + (size_t)(row < a.Cout ? row : 0) * CEP + c0);
+                }
+                mbn_f2 acc[4];
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const mbn_f4 wlo = *reinterpret_cast<const mbn_f4*>(a.prm + tp * CEP + c0), whi = *reinterpret_cast<const mbn_f4*>(a.prm + tp * CEP + c0 + 4);
+                    const mbn_u4 raw = *reinterpret_cast<const mbn_u4*>(ewin + (size_t)((tp / 3) * MBN_IW + tp % 3) * LDE + 32 * kk);
+                    const mbn_f8 xv = __builtin_convertvector(__builtin_bit_cast(mbn_v8<T>, raw), mbn_f8);   // (whole-vector cast: see stemblock_h.hip)
+                    const mbn_f2 w2[4] = {(mbn_f2){wlo[0], wlo[1]}, (mbn_f2){wlo[2], wlo[3]}, (mbn_f2){whi[0], whi[1]}, (mbn_f2){whi[2], whi[3]}};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[c] = __builtin_elementwise_fma((mbn_f2){xv[2 * c], xv[2 * c + 1]}, w2[c], tp == 0 ? (mbn_f2){0.f, 0.f} : acc[c]);
+                }
+                const mbn_f4 slo = *reinterpret_cast<const mbn_f4*>(a.prm + 9 * CEP + c0), shi = *reinterpret_cast<const mbn_f4*>(a.prm + 9 * CEP + c0 + 4);
+                const mbn_f4 hlo = *reinterpret_cast<const mbn_f4*>(a.prm + 10 * CEP + c0), hhi = *reinterpret_cast<const mbn_f4*>(a.prm + 10 * CEP + c0 + 4);
+                mbn_f8 d;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const mbn_f2 s2 = c < 2 ? (mbn_f2){slo[2 * c], slo[2 * c + 1]} : (mbn_f2){shi[2 * c - 4], shi[2 * c - 3]};
+                    const mbn_f2 h2 = c < 2 ? (mbn_f2){hlo[2 * c], hlo[2 * c + 1]} : (mbn_f2){hhi[2 * c - 4], hhi[2 * c - 3]};
+                    const mbn_f2 y = __builtin_elementwise_fma(acc[c], s2, h2);
+                    d[2 * c] = mbn_act<ACT>(y.x);
+                    d[2 * c + 1] = mbn_act<ACT>(y.y);
+                }
+                const mbn_u4 frag = __builtin_bit_cast(mbn_u4, __builtin_convertvector(d, mbn_v8<T>));
+#pragma unroll
+                for (int n = 0; n < NCO; ++n) pacc[n] = mbn_mfma<T>(wpf[n], frag, pacc[n]);
+            }
         }
-        const mbn_f4 slo = *reinterpret_cast<const mbn_f4*>(a.prm + 9 * CEP + c0), shi = *reinterpret_cast<const mbn_f4*>(a.prm + 9 * CEP + c0 + 4);
-        const mbn_f4 hlo = *reinterpret_cast<const mbn_f4*>(a.prm + 10 * CEP + c0), hhi = *reinterpret_cast<const mbn_f4*>(a.prm + 10 * CEP + c0 + 4);
-        mbn_f8 d;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const mbn_f2 s2 = c < 2 ? (mbn_f2){slo[2 * c], slo[2 * c + 1]} : (mbn_f2){shi[2 * c - 4], shi[2 * c - 3]};
-            const mbn_f2 h2 = c < 2 ? (mbn_f2){hlo[2 * c], hlo[2 * c + 1]} : (mbn_f2){hhi[2 * c - 4], hhi[2 * c - 3]};
-            const mbn_f2 y = __builtin_elementwise_fma(acc[c], s2, h2);
-            d[2 * c] = mbn_act<ACT>(y.x);
-            d[2 * c + 1] = mbn_act<ACT>(y.y);
-        }
-        const mbn_u4 frag = __builtin_bit_cast(mbn_u4, __builtin_convertvector(d, mbn_v8<T>));
-#pragma unroll
-        for (int n = 0; n < NCO; ++n) pacc[n] = mbn_mfma<T>(wpf[n], frag, pacc[n]);
     }
     // ---- 3. project BN, stores: lane = pixel o, couts 16 n + 4 g + 0..3
     const int gy = oy0 + oy, gx = ox0 + ox;
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(256) void mbn_kernel(MbnArgs a) {
 
 template <class T, int NE, int NCO>
 static int launch_mbn(const MbnArgs& a, int batch, hipStream_t s) {
-    constexpr size_t lds = (size_t)256 * (16 * NE + 8) * 2;
+    constexpr size_t lds = (size_t)256 * (16 * (NE < 6 ? NE : 6) + 8) * 2;
     static char nm[48];
     static const int nm_len = snprintf(nm, sizeof(nm), "mbn_kernel<%s,%d,%d>", yr_dtype_name(yr_elem<T>::dtype), NE, NCO);
     (void)nm_len;
@@ -179,9 +192,9 @@ static int launch_mbn(const MbnArgs& a, int batch, hipStream_t s) {
 }
 
 // Whether yr_launch_mbh hands the op over (its checks have passed): the whole block, 3x3 stride 2, at most 32 inputs in whole
-// 16-byte vectors, at most 96 expanded channels, at most 32 outputs, no residual, ReLU6 or swish.
+// 16-byte vectors, at most 192 expanded channels (two passes of 96), at most 32 outputs, no residual, ReLU6 or swish.
 bool yr_mbn_takes(const yr_op& op) {
-    return op.kind == YR_OP_MBH && (op.k & 0xff) == 3 && (op.k >> 8) == 0 && op.stride == 2 && op.src[0].c <= 32 && op.src[0].c % 8 == 0 && op.se_reduced <= 96 &&
+    return op.kind == YR_OP_MBH && (op.k & 0xff) == 3 && (op.k >> 8) == 0 && op.stride == 2 && op.src[0].c <= 32 && op.src[0].c % 8 == 0 && op.se_reduced <= 192 &&
            op.cout <= 32 && op.res == nullptr && (op.act == YR_ACT_RELU6 || op.act == YR_ACT_SWISH);
 }
 
@@ -209,6 +222,12 @@ static int launch_mbn_t(const yr_op& op, int batch, hipStream_t s) {
         case 42: return launch_mbn<T, 4, 2>(a, batch, s);
         case 61: return launch_mbn<T, 6, 1>(a, batch, s);
         case 62: return launch_mbn<T, 6, 2>(a, batch, s);
+        case 81: return launch_mbn<T, 8, 1>(a, batch, s);
+        case 82: return launch_mbn<T, 8, 2>(a, batch, s);
+        case 101: return launch_mbn<T, 10, 1>(a, batch, s);
+        case 102: return launch_mbn<T, 10, 2>(a, batch, s);
+        case 121: return launch_mbn<T, 12, 1>(a, batch, s);
+        case 122: return launch_mbn<T, 12, 2>(a, batch, s);
     }
     yr_set_error("mbn: widths Cexp=%d Cout=%d unsupported", op.se_reduced, op.cout);
     return YR_ERR_ARG;
