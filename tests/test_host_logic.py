@@ -321,3 +321,48 @@ def test_serialised_plan_is_validated():
     bad_abi[8] = 1
     assert load(bytes(bad_abi)) == -1 and b'ABI' in lib.yr_last_error()
     assert load(data[:50]) == -1
+
+
+def _plan16(name, size, policy='mixed_bfloat16'):
+    from yoloret_amd import layers as L
+    L.set_global_policy(policy)
+    try:
+        return _model(name, size).plan
+    finally:
+        L.set_global_policy('float32')
+
+
+def test_round3_plan_choices_of_the_16bit_configurations():
+    """What the graph compiler decides for BASELINE configs 3 and 5 since round 3 (measured choices):
+    the fused network entry carries the matrix-pipe parameter layout (stem BN as its own `scale` / `shift` rows, the stem kernel
+    as a [C1P][32] 16-bit matrix in the kernel's k order) for stems of at most 32 channels and even image sizes only; the first
+    stride-2 block is a YR_OP_MBH op (which the library hands to mbn_h.hip) instead of the float32 lane kernel; lite0's
+    52 x 52 x 240 5x5 block runs unfused (LDS-walk depthwise), lite3's 80 x 80 x 288 blocks stay fused."""
+    from yoloret_amd import runtime as rt
+    p3 = _plan16('efficientnetb0-lite', 416)
+    e = p3.ops[0]
+    assert e.kind == rt.OP_STEMBLOCK and 'scale' in e.params and e.params['wgt'][0] == (32, 32) and e.params['wgt'][2] == p3.dtype
+    assert e.params['wgt2'][0] == (10, 32) and e.params['b1'][0] == (16, 32)
+    blk = p3.ops[1]
+    assert blk.kind == rt.OP_MBH and blk.stride == 2 and blk.cin == 16 and blk.se_reduced == 96 and blk.cout == 24
+    assert rt.OP_MBLANE not in [o.kind for o in p3.ops]
+    names = [o.name for o in p3.ops]
+    assert any(n.startswith('stage3_block1') and n.endswith('_dw') for n in names), 'lite0 stage 3 block 1 runs unfused'
+    assert any(n.startswith('stage3_block0') and n.endswith('_mbh') for n in names), 'its stride-2 entry block stays fused'
+    # the permuted stem kernel holds exactly the 27 taps of every output channel
+    import numpy as np
+    from yoloret_amd.weights import synthetic_weights
+    m = _model('efficientnetb0-lite', 64)
+    wd = synthetic_weights(m, 3, 'survey')
+    p = _plan16('efficientnetb0-lite', 64)
+    ws = p.ops[0].params['wgt'][1](wd)
+    full = np.asarray(wd['stem_conv/kernel']).reshape(27, -1)
+    assert ws.shape == (32, 32) and np.array_equal(np.sort(ws[:, :27], axis=1), np.sort(full.T, axis=1)) and not ws[:, 27:].any()
+    # an odd image size keeps the float32-pipe entry kernel (pair-packed layout: no separate BN rows)
+    assert 'scale' not in _plan16('efficientnetb0-lite', 63).ops[0].params
+    p5 = _plan16('efficientnetb3-lite', 640, 'mixed_float16')
+    assert p5.ops[0].kind == rt.OP_STEMBLOCK and 'scale' not in p5.ops[0].params          # 40 stem channels: float32 pipe
+    k5 = [o for o in p5.ops if o.kind == rt.OP_MBH and o.k == 5 and o.stride == 1]
+    assert len(k5) == 2 and all(o.h == 80 and o.se_reduced == 288 for o in k5)
+    first_s2 = next(o for o in p5.ops if o.kind == rt.OP_MBH and o.stride == 2)
+    assert first_s2.cin == 24 and first_s2.se_reduced == 144 and first_s2.cout == 32            # mbn_h.hip's two-pass shape
