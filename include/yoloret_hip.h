@@ -114,14 +114,21 @@ typedef enum {
                             Built for (CP,COP) in {(12,16),(16,16),(16,24),(20,24),(24,16),(24,24)}; others: YR_ERR_ARG.
                             Without b1 (no projection; cout == C1, CP in {16,20,24}): stem + depthwise only - the depthwise
                             map is stored and, if `gate` is set, gate = OUTPUT float32 [B][ceil(h/14)*ceil(w/14)][gate_ld]
-                            per-tile channel sums of the stored values (the squeeze of the first SE block) */
+                            per-tile channel sums of the stored values (the squeeze of the first SE block).
+                            MATRIX-PIPE LAYOUT (16-bit plans, round 3; selected by scale != NULL; C1 <= 64, cout <= 32, even image
+                            sizes; C1P = round_up(C1,32), COP = round_up(cout,16), zero padded; stemblock_h.hip):
+                            wgt = stem kernel as dtype [C1P][32], k order: image rows 0..2 x values 0..7 of the row's 9 (kx,ci) |
+                            value 8 of rows 0..2 | 0 x 5;  scale / shift = stem BN [C1P];  wgt2 = float32 [10][C1P]: nine depthwise
+                            taps times the BN scale | BN shift;  b1 = project Wt[COP][C1P] as dtype;  b2 = project BN [2][COP] */
     YR_OP_MBH = 11,      /* the MBCONV block on 16-bit activations, both 1x1 convs on bf16 / f16 MFMA, depthwise K = 3 | 5 from an
                             LDS tile (dtype must be YR_BF16 / YR_F16; cin, cout <= 128).  se_reduced = Cexp; k = K, optionally
                             | th << 8 | tw << 16 to force the output tile.  CexpP = round_up(Cexp,32), KP = round_up(cin,32),
                             zero padded: wgt = expand Wt[CexpP][KP] (16-bit); wgt2 = [K*K + 4][CexpP] float32: depthwise taps |
                             depthwise BN scale | shift | expand BN scale | shift;
                             b1 = project Wt[cout][CexpP] (16-bit); b2 = project BN scale ++ shift, [round_up(cout,8)] each;
-                            res (optional) = the block input (stride 1, cin == cout) */
+                            res (optional) = the block input (stride 1, cin == cout).  The library runs K = 3, stride 2, cin <= 32
+                            (cin % 8 == 0), Cexp <= 192, cout <= 32, no residual, no forced tile on mbn_h.hip (whole expanded
+                            halo tile on chip in the 16-bit type: same op fields) */
     YR_OP_MBLANE = 10,   /* the MBCONV block (same layers, same op fields) in the lane-per-pixel formulation for narrow
                             block inputs (Cin <= 32): packed-fp32 FMA with scalar-register weights instead of MFMA.
                             se_reduced = Cexp; parameters packed per expanded-channel PAIR, P = round_up(ceil(Cexp/2),8),
