@@ -345,18 +345,24 @@ def test_plan_blob_round_trip(dev, tmp_path):
     # a 16-bit plan travels the same way
     from yoloret_amd import layers as L
     from yoloret_amd.yolo3.model import yolov3_body
-    L.set_global_policy('mixed_bfloat16')
-    try:
-        m16 = yolov3_body(L.Input(shape=[96, 96, 3]), 'efficientnetb0', 3, num_classes=20)
-    finally:
-        L.set_global_policy('float32')
     from yoloret_amd.weights import synthetic_weights
-    m16.set_weights(synthetic_weights(m16, 3, 'conditioned'))
     xd = torch.from_numpy(x).to(dev)
-    want16 = [y.cpu().numpy() for y in m16(xd)]
-    h = rt.PlanHandle(m16.save_plan())
-    for a, w in zip(h(xd), want16):
-        assert np.array_equal(a.cpu().numpy().reshape(w.shape), w)
+    # (-lite: the throughput plan's matrix-pipe network entry and first stride-2 block - parameter layouts the loader's
+    # extent checks know since round 3)
+    for name16 in ('efficientnetb0', 'efficientnetb0-lite'):
+        L.set_global_policy('mixed_bfloat16')
+        try:
+            m16 = yolov3_body(L.Input(shape=[96, 96, 3]), name16, 3, num_classes=20)
+        finally:
+            L.set_global_policy('float32')
+        m16.small_batch = 0
+        m16.set_weights(synthetic_weights(m16, 3, 'conditioned'))
+        want16 = [y.cpu().numpy() for y in m16(xd)]
+        if name16.endswith('-lite'):
+            assert m16.plan.ops[0].kind == rt.OP_STEMBLOCK and 'scale' in m16.plan.ops[0].params and m16.plan.ops[1].kind == rt.OP_MBH
+        h = rt.PlanHandle(m16.save_plan())
+        for a, w in zip(h(xd), want16):
+            assert np.array_equal(a.cpu().numpy().reshape(w.shape), w)
 
 
 @pytest.mark.parametrize('name,policy', [('mobilenetv2x75', 'float32'), ('efficientnetb0-lite', 'mixed_bfloat16'),

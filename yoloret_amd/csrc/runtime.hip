@@ -178,7 +178,28 @@ static int64_t param_floats(const yr_op& op, int role) {   // role: 0 wgt, 1 sca
             if (op.kind == YR_OP_MBH && role == 5) return 2 * ru(op.cout, 8);
             return 0;
         }
-        default: return 0;   // STEMBLOCK / MBLANE / MBCONV: pair-packed layouts, validated by their launchers' shape tables only
+        case YR_OP_STEMBLOCK: {
+            if (op.scale_off >= 0) {   // the matrix-pipe layout of the 16-bit plans (stemblock_h.hip)
+                const int64_t c1p = ru(op.se_reduced, 32), cop = ru(op.cout, 16);
+                const int64_t ext[6] = {c1p * 32 / 2, c1p, c1p, 10 * c1p, cop * c1p / 2, 2 * cop};
+                return ext[role];
+            }
+            const int64_t cp = ru(op.se_reduced, 4) / 2, cop = ru(op.cout, 8);   // pair-packed, float32 pipe (stemblock.hip)
+            if (role == 0) return cp * 58;
+            if (role == 3) return cp * 22;
+            if (role == 4) return 2 * cp * cop;
+            if (role == 5) return 2 * cop;
+            return 0;
+        }
+        case YR_OP_MBLANE: {
+            const int64_t pr = ru((op.se_reduced + 1) / 2, 8), cinp = ru(op.cin, 4), cop = ru(op.cout, 8);
+            if (role == 0) return pr * (cinp * 2 + 4);
+            if (role == 3) return pr * 22;
+            if (role == 4) return 2 * pr * cop;
+            if (role == 5) return 2 * cop;
+            return 0;
+        }
+        default: return 0;   // MBCONV: validated by its launcher's shape checks only
     }
 }
 
