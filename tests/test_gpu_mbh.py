@@ -38,6 +38,8 @@ CASES = [
     (26, 26, 48, 288, 48, 3, 1, True, 'relu6', (7, 8)),    # forced odd tile (14 runs: ragged groups)
     (13, 13, 120, 720, 120, 3, 1, True, 'relu6', (3, 4)),  # tiny tile: a single partial group
     (20, 20, 32, 192, 48, 3, 1, False, 'swish', None),     # generic activation path
+    (22, 18, 24, 144, 32, 3, 2, False, 'swish', None),     # the narrow stride-2 front block (mbn_h.hip) with swish, two passes
+    (12, 30, 32, 192, 16, 3, 2, False, 'relu6', None),     # ... 32 inputs, 192 expanded channels (two full passes), one cout tile
 ]
 
 
