@@ -93,6 +93,7 @@ __device__ __forceinline__ void dwp_static_for(F&& f) {
 // that exist - a band of R - 1 rows, or one cut by the map's last row, computes the others on whatever the tile buffer
 // holds there (zeros beyond the map; LDS reads beyond the allocation return zeros) and stores them nowhere.
 constexpr unsigned DWP_DEAD = 0x40000000u;   // store offsets: row part + pixel part, either may be dead, the sum must not wrap
+constexpr int DWP_ROUNDS = 7;               // DMA rounds of 32 pixels per tile buffer (208 halo pixels at most)
 template <class T, int K, int ACT, bool SE, int R>
 __device__ __forceinline__ void dwp_band(const unsigned* trow, int tpitch, const dwl_f2 (&w)[K * K], dwl_f2 sc, dwl_f2 sh, int act, dwl_rsrc dst,
                                          unsigned orow, unsigned opitch, const unsigned (&ooff)[4], int rows_ok, dwl_f2& psum) {
@@ -169,25 +170,38 @@ __global__ __launch_bounds__(256) void dwp_kernel(DwpArgs a) {
     const bool cv_ok = cc * 8 + cv < a.C8;
     const unsigned cvb = (unsigned)(cc * 8 + cv) * 16u;
     const int pl0 = wave * 8 + (lane >> 3);
-    const int r0 = pl0 / a.cols, j0 = pl0 - r0 * a.cols;
+    // per DMA round (at most DWP_ROUNDS: 208 halo pixels / 32): this lane's halo pixel (row, column) and its byte offset from the
+    // tile's origin - the same for every tile of the walk, so a fetch costs two adds, two compares and a select per round.
+    // A slot beyond the tile (or channels beyond C) gets a column no map has.
+    int rr_[DWP_ROUNDS], jj_[DWP_ROUNDS];
+    unsigned rel_[DWP_ROUNDS];
+    {
+        int r = pl0 / a.cols, j = pl0 - r * a.cols;
+#pragma unroll
+        for (int u = 0; u < DWP_ROUNDS; ++u) {
+            const bool slot = cv_ok && u * 32 + pl0 < a.npix;
+            rr_[u] = r; jj_[u] = slot ? j : 0x7fff0000;
+            rel_[u] = (unsigned)((r * a.W + j) * a.ld_in) * 2u + cvb;
+            j += a.step_j; r += a.step_r;
+            if (j >= a.cols) { j -= a.cols; ++r; }
+        }
+    }
     auto fetch = [&](int tx, int ty, int b, int buf) {
         const dwl_rsrc src = dwl_make_rsrc(reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * a.ld_in, (unsigned)(a.H * a.W * a.ld_in) * 2u);
         const int iy0 = ty * a.th - a.pad_t, ix0 = tx * a.tw - a.pad_l;
-        int r = r0, j = j0;
-        for (int u = 0; u < a.rounds; ++u) {
+        const unsigned tbase = (unsigned)((iy0 * a.W + ix0) * a.ld_in) * 2u;   // (may wrap below zero: the sums of the pixels inside the map do not)
+#pragma unroll
+        for (int u = 0; u < DWP_ROUNDS; ++u) {
             const int pw = u * 32 + wave * 8;   // the wave's first pixel of this round
-            if (pw < a.npix) {                  // (a wave of the last round wholly beyond the tile loads nothing)
-                const int iy = iy0 + r, ix = ix0 + j;
-                const bool ok = cv_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && u * 32 + pl0 < a.npix;
-                unsigned voff = (unsigned)((iy * a.W + ix) * a.ld_in) * 2u + cvb;
+            if (pw < a.npix) {                  // (wave-uniform: a wave of the last round wholly beyond the tile loads nothing)
+                const bool ok = (unsigned)(iy0 + rr_[u]) < (unsigned)a.H && (unsigned)(ix0 + jj_[u]) < (unsigned)a.W;
+                unsigned voff = tbase + rel_[u];
 #ifdef YR_DW_EXPERIMENT
                 if (a.dbg == 2) voff = DWL_DEAD;
 #endif
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (__attribute__((address_space(3))) void*)(dwp_lds + buf * a.buf_words + pw * 32), 16,
                                                          ok ? voff : DWL_DEAD, 0, 0, 0);
             }
-            j += a.step_j; r += a.step_r;
-            if (j >= a.cols) { j -= a.cols; ++r; }
         }
     };
 
