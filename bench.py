@@ -518,12 +518,15 @@ def main():
             if a.depth > 1:
                 # ... and with the shipped number of steps in flight: one input buffer per context, rewritten (copy stream ->
                 # conversion on the launch stream) only after the step that last read it has finished
-                xs = [x] + [torch.empty_like(x) for _ in range(a.depth - 1)]
-                done_ev = [None] * a.depth
+                # (2 * depth input buffers: with one per context the conversion of batch i waits for step i - depth, which is still
+                # in flight, and copy + conversion sit on the steps' critical path)
+                nbuf = 2 * a.depth
+                xs = [x] + [torch.empty_like(x) for _ in range(nbuf - 1)]
+                done_ev = [None] * nbuf
                 turn = [0]
 
                 def step_fed_deep():
-                    k = turn[0] % a.depth
+                    k = turn[0] % nbuf
                     turn[0] += 1
                     feeder.submit(u8)
                     if done_ev[k] is not None:
@@ -544,7 +547,7 @@ def main():
                 sync()
                 incl_h2d['in_flight'] = {'img_s': round(b / dtd, 1), 'ms_per_step': round(dtd * 1e3, 4), 'steps_in_flight': a.depth,
                                          'path': 'HostFeeder + DetectionPipeline(depth): copy of batch i+1 on the copy stream, conversion on the launch stream, '
-                                                 'steps on their contexts\' streams; one float32 input buffer per context'}
+                                                 'steps on their contexts\' streams; 2 x depth float32 input buffers'}
         # ---- the same with a uint8 network entry: the model is built on Input(dtype='uint8'), its first kernel reads the image
         # bytes (x / 255 inside): no conversion launch, no float32 batch (133 MB written + read per 64 images)
         if incl_h2d is not None:
@@ -552,7 +555,10 @@ def main():
                 model8 = yolov3_body(L.Input(shape=[a.size, a.size, 3], dtype='uint8'), a.model, 3, num_classes=a.classes)
                 model8.set_weights(model.get_weights())
                 pipe8 = DetectionPipeline(model8, anchors, a.classes, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5, depth=a.depth)
-                feeder8 = HostFeeder(tuple(u8.shape), (a.size, a.size), dev, slots=a.depth + 1)
+                # 2 * depth + 2 device batches: the copy into a slot waits for the step that last read it - with depth + 1 slots that
+                # step is still in flight and every copy (0.6 ms per 64 images) sits on the steps' critical path (24.1k img/s), with
+                # 8 slots the copies run ahead (27.9k = 0.99 of the resident figure; tools/u8_probe.py)
+                feeder8 = HostFeeder(tuple(u8.shape), (a.size, a.size), dev, slots=2 * a.depth + 2)
 
                 def step_u8():
                     feeder8.submit(u8)
