@@ -127,9 +127,6 @@ class DetectionPipeline:
         ready = torch.cuda.Event()
         ready.record(cur)                      # whatever produced x / image_hw on the caller's stream
         st.wait_event(ready)
-        if c['release'] is not None:           # a consumer (the all-gather) still reading this context's records
-            st.wait_event(c['release'])
-            c['release'] = None
         saved = (self._bufs, self._turn)
         self._bufs, self._turn = c['bufs'], c['turn']
         try:
@@ -138,6 +135,9 @@ class DetectionPipeline:
                 image_hw.record_stream(st)
                 v = self._buffers(b, dev)
                 ys = self.model(x, out=v['ys'], ctx=k)
+                if c['release'] is not None:   # a consumer (the all-gather) still reading this context's records: only the
+                    st.wait_event(c['release'])   # post-processing rewrites them - the forward pass above does not wait
+                    c['release'] = None
                 out = self.postprocess(ys, image_hw)
                 done = torch.cuda.Event()
                 done.record(st)
