@@ -19,6 +19,11 @@ import os
 import sys
 import time
 
+# Steps in flight run on several HIP streams (three execution contexts, the all-gather's side stream, RCCL's own, the consumer's):
+# with the runtime's default of 4 hardware queues they share queues and a step waits behind another stream's collective
+# (one RCCL rank, depth 3: 22-25k instead of 27.8k img/s, tools/dist_probe.py).  Read by the HIP runtime when it initialises.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import numpy as np
 import torch
 
@@ -50,8 +55,8 @@ def parse():
                     help='initialise RCCL and issue the detection all-gather even with one rank (single-GPU check of the N>1 path)')
     ap.add_argument('--depth', type=int, default=0,
                     help='steps in flight (DetectionPipeline(depth=..)): consecutive steps run on consecutive execution contexts / HIP '
-                         'streams and fill each other\'s idle CUs; 1 = strictly one step after the other; 0 (default) = 3 on one GPU, 2 when every step '
-                         'ends in the all-gather (measured with one RCCL rank: depth 2 26.6k img/s = -0.8 %% against no collective, depth 3 25.0k)')
+                         'streams and fill each other\'s idle CUs; 1 = strictly one step after the other; 0 (default) = 3, with or without the '
+                         'all-gather (one RCCL rank: depth 3 28.2k img/s against 28.3k without the collective, depth 2 26.9k)')
     ap.add_argument('--no-latency', action='store_true',
                     help='skip the batch-1 p50 loop (use under rocprofv3 so that every launch is a batch-%d launch)' % 64)
     return ap.parse_args()
@@ -147,7 +152,7 @@ def main():
     dev = torch.device('cuda', local)
     use_dist = world > 1 or a.force_dist
     if a.depth <= 0:
-        a.depth = 2 if use_dist else 3
+        a.depth = 3   # (also with the all-gather in every step, since the streams have their own hardware queues: GPU_MAX_HW_QUEUES above)
     # RCCL prints a banner (hostname, library path, ...) on STDOUT when the first communicator is created; stdout
     # must carry exactly one JSON line, so fd 1 points at stderr until the set-up step (which runs the first
     # collective) is over
