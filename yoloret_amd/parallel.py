@@ -96,7 +96,8 @@ class DetectionGatherer:
             dist.all_gather_into_tensor(out, record, group=self.group)
             return GatherHandle(None, None, out, self.world, b, s, six)
         if self._stream is None or self._stream.device != det.device:
-            self._stream = torch.cuda.Stream(device=det.device)
+            from .pipeline import _shared_stream
+            self._stream = _shared_stream(det.device, 'gather')
         ready = after
         if ready is None:
             ready = torch.cuda.Event()

@@ -13,6 +13,25 @@ import torch
 from . import runtime as rt
 
 
+_STREAMS = {}
+
+
+def _shared_stream(device, role):
+    """One HIP stream per (device, role) for the whole process: execution context k of every DetectionPipeline, the copy stream of
+    every HostFeeder.  Streams are mapped onto a few hardware queues (GPU_MAX_HW_QUEUES, 8 set by the package) in the order of
+    their first launch and streams that share a queue wait for each other - a second pipeline or feeder with streams of its own
+    pushed the count past the queues (bench.py's uint8-entry pipeline beside the float32 one: 0.97 -> 0.89 of the resident rate).
+    The stream does its first launch here (a queue is taken at the first launch, not at creation)."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), role)
+    st = _STREAMS.get(key)
+    if st is None:
+        st = _STREAMS[key] = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(st):
+            torch.zeros(1, device=device)
+    return st
+
+
 class DetectionPipeline:
     def __init__(self, model, anchors, num_classes, num_scales=3, max_boxes=20, score_threshold=.2,
                  iou_threshold=.5, record_slots=1, depth=1):
@@ -125,10 +144,8 @@ class DetectionPipeline:
             # RCCL's own, a consumer's): HIP streams share a few hardware queues and are mapped to them in the order of first use - with
             # the collective's streams first used between two contexts' streams, a context shared a queue with it and every step
             # waited for the previous collective (one RCCL rank, depth 3: 25.0k instead of 28.3k img/s, tools/dist_probe.py)
-            for cc in self._ctx:
-                cc['stream'] = torch.cuda.Stream(device=dev)
-                with torch.cuda.stream(cc['stream']):      # (a queue is taken at a stream's first launch, not at its creation)
-                    torch.zeros(1, device=dev)
+            for i, cc in enumerate(self._ctx):
+                cc['stream'] = _shared_stream(dev, 'ctx%d' % i)
         st = c['stream']
         cur = torch.cuda.current_stream(dev)
         ready = torch.cuda.Event()
@@ -221,7 +238,7 @@ class HostFeeder:
         self.device = torch.device(device)
         self.input_hw = (int(input_hw[0]), int(input_hw[1]))
         self.batch_shape = tuple(int(v) for v in batch_shape)
-        self.copy_stream = torch.cuda.Stream(self.device)
+        self.copy_stream = _shared_stream(self.device, 'copy')
         self.dbuf = [torch.empty(self.batch_shape, dtype=torch.uint8, device=self.device) for _ in range(slots)]
         self.copied = [torch.cuda.Event() for _ in range(slots)]
         self.released = [None] * slots
