@@ -140,6 +140,23 @@ typedef enum {
                             wgt = NULL: a block WITHOUT expand conv (expand ratio 1, efficientnet.py:467 skipped; stride 1,
                             se_reduced = Cin): depthwise + project (+ residual) on the block input itself; built for
                             (4,16), (6,24), (8,32) */
+    YR_OP_MBR = 13,      /* the MBCONV block (same layers) in float32 on the fp32 matrix pipe, ROW-WALKING and REGISTER-CHAINED
+                            (mbr.hip): a wave walks a strip of 16 input columns row by row; expand GEMM (v_mfma_f32_16x16x4_f32, the
+                            strip row's pixels as N, block input straight from global memory in operand layout) -> the MFMA result
+                            registers ARE the depthwise conv's input (horizontal taps by DPP, vertical taps = the last three rows kept
+                            in registers) -> the depthwise result registers ARE the projection MFMAs' B operand.  The expanded tensor
+                            never leaves the register file; the waves of a workgroup split the expanded channels and add their partial
+                            projections through LDS.  dtype = YR_F32; act = YR_ACT_RELU6; cin % 16 in {0, 8}; se_reduced = Cexp, a
+                            multiple of 16; cout % 4 == 0; k = 3 | nw << 8 | segs << 16 (nw: waves per workgroup, segs: row segments
+                            per strip; 0 = the library's choice); res (optional) = the block input.  T = Cexp / 16 expanded tiles,
+                            TO = ceil(cout / 16), KE = cin / 4 expand steps; scale / shift / b1 unused:
+                            wgt  = MFMA A fragments [T][KE + 4 TO][64 lanes]; register rho of lane l (m = l % 16, g = l / 16) of tile j:
+                                   rho < KE: We[16 j + m][kperm(rho, g)] x expand BN scale, kperm(4 c + s, g) = 16 c + 4 g + s for the full
+                                   16-channel chunks of cin and 16 n + 2 g + s (s < 2) for a trailing 8;
+                                   rho = KE + 4 t + s: Wp[16 t + m][16 j + 4 g + s] x project BN scale (0 for 16 t + m >= cout);
+                            wgt2 = [T][11][16]: the nine depthwise taps (ky, kx) x depthwise BN scale | depthwise BN shift | expand BN shift;
+                            b2   = project BN shift [16 TO].
+                            Built for the MobileNetV2 x0.75 / x1.4 blocks (mbr.hip: MBR_CASE list); other shapes: YR_ERR_ARG */
     YR_OP_MBX = 12       /* the first two thirds of an MBConv block WITH squeeze-excite (efficientnet.py:406-536), 16-bit
                             activations: expand 1x1 + BN + act (bf16 / f16 MFMA) -> depthwise K = 3 | 5, stride 1 | 2 + BN +
                             act, the expanded input of the depthwise conv staying in LDS; the depthwise map is stored and

@@ -1,0 +1,75 @@
+"""Row-walking register-chained fused inverted-residual block (YR_OP_MBR, csrc/mbr.hip: expand 1x1 + BN + ReLU6 ->
+DW 3x3 s1|s2 + BN + ReLU6 -> project 1x1 + BN (+ residual), float32 on the fp32 matrix pipe) against the three oracle ops
+composed, through yr_op_run.  Reference: MobileNetV2 blocks [3P] via code/yolo3/override.py:290-341."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn
+from tests.util import assert_close, from_dev, to_dev
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (h, w, cin, cexp, cout, stride, residual, nw, segs)
+    (16, 16, 16, 96, 24, 2, False, 0, 0),      # MobileNetV2 x0.75 block_1 shape
+    (104, 104, 16, 96, 24, 2, False, 1, 0),    # ... many strips / segments, one wave per workgroup
+    (31, 45, 16, 96, 24, 2, False, 2, 3),      # odd sizes (pad 1/1), ragged strips and segments
+    (13, 13, 24, 144, 24, 1, True, 0, 0),      # block_2 (+add): cin = 16 + 8 (the two-step tail chunk)
+    (52, 52, 24, 144, 32, 2, False, 0, 0),     # block_3
+    (30, 44, 32, 192, 32, 1, True, 0, 0),      # block_4/5, ragged strips
+    (30, 44, 32, 192, 32, 1, True, 0, 5),      # ... forced segments
+    (52, 52, 32, 192, 48, 2, False, 0, 0),     # block_6
+    (26, 26, 48, 288, 48, 1, True, 6, 0),      # block_7..9
+    (26, 26, 48, 288, 48, 1, True, 8, 2),      # ... eight waves, uneven tile shares (3,3,2,2,2,2,2,2)
+    (9, 7, 48, 288, 48, 1, True, 8, 1),        # tiny map
+    (26, 26, 48, 288, 72, 1, False, 6, 0),     # block_10
+    (26, 26, 48, 288, 72, 1, False, 8, 0),
+]
+
+
+def _reference(x, we, se, he, wd, sd, hd, wp, sp, hp, s, residual):
+    t = nn.relu6((nn.pointwise(x, we) * se + he).astype(np.float32))
+    t = nn.relu6((nn.depthwise(t, wd, s, 'same') * sd + hd).astype(np.float32))
+    ref = (nn.pointwise(t, wp) * sp + hp).astype(np.float32)
+    return ref + x if residual else ref
+
+
+def make_block(case, dev, b=2, seed=None):
+    from yoloret_amd import runtime as rt
+    from yoloret_amd.compiler import mbr_pack
+    h, w, cin, cexp, cout, s, residual, nw, segs = case
+    rng = np.random.default_rng(zlib.crc32(str(case).encode()) if seed is None else seed)
+    x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
+    we = (rng.standard_normal((cin, cexp)) * np.sqrt(2.0 / cin)).astype(np.float32)
+    se, he = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
+    wd = (rng.standard_normal((3, 3, cexp)) * np.sqrt(2.0 / 9)).astype(np.float32)
+    sd, hd = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
+    wp = (rng.standard_normal((cexp, cout)) * np.sqrt(1.0 / cexp)).astype(np.float32)
+    sp, hp = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.3, cout).astype(np.float32)
+    packed = mbr_pack(we.T, se, he, wd.reshape(9, cexp), sd, hd, wp.T, sp, hp)
+    keep = [torch.from_numpy(np.ascontiguousarray(a).ravel()).to(dev) for a in packed]
+    xd = to_dev(x, dev)
+    ho, wo = (h + s - 1) // s, (w + s - 1) // s
+    op = rt.new_op(rt.OP_MBR, 'relu6')
+    op.dtype = op.out_dtype = rt.dtype_id('f32')
+    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc, op.se_reduced = ho, wo, cin, cout, 3 | nw << 8 | segs << 16, s, 1, cexp
+    op.src[0] = rt.make_src(xd, c=cin)
+    op.wgt, op.wgt2, op.b2 = [k.data_ptr() for k in keep]
+    if residual:
+        op.res, op.res_ld = xd.data_ptr(), xd.shape[3]
+    out = torch.full((b, ho, wo, cout), float('nan'), dtype=torch.float32, device=dev)
+    op.out, op.out_ld = out.data_ptr(), cout
+    return op, out, (x, we, se, he, wd, sd, hd, wp, sp, hp, s, residual), keep + [xd]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[str(i) for i in range(len(CASES))])
+def test_mbr(dev, case):
+    from yoloret_amd import runtime as rt
+    op, out, params, keep = make_block(case, dev)
+    ref = _reference(*params)
+    rt.run_op(op, 2)
+    torch.cuda.synchronize()
+    assert_close(from_dev(out), ref, 5e-5, 'mbr %s' % (case,))

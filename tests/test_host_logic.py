@@ -28,10 +28,10 @@ def test_macs_match_survey(name, size, macs_m):
 
 def test_plan_structure_and_accounting():
     from yoloret_amd import compiler, runtime as rt
-    knobs = ('FUSE_MAX_CIN', 'FUSE_STEM', 'HOIST_UPSAMPLE', 'POOL_IN_PRODUCER', 'MERGE_SE_MEAN', 'FOLD_DW')
+    knobs = ('FUSE_MAX_CIN', 'FUSE_STEM', 'HOIST_UPSAMPLE', 'POOL_IN_PRODUCER', 'MERGE_SE_MEAN', 'FOLD_DW', 'FUSE_MBR')
     saved = [getattr(compiler, k) for k in knobs]
     try:
-        for k, v in zip(knobs, (0, False, False, False, False, False)):   # every rewrite off: the plan = SURVEY.md Appendix B rows
+        for k, v in zip(knobs, (0, False, False, False, False, False, False)):   # every rewrite off: the plan = SURVEY.md Appendix B rows
             setattr(compiler, k, v)
         p = _model().plan
     finally:
@@ -50,7 +50,8 @@ def test_plan_structure_and_accounting():
     fused = fm.plan
     from yoloret_amd.weights import synthetic_weights
     assert np.isfinite(fused.build_blob(synthetic_weights(fm, 1, 'survey'))).all()   # every fused packing runs
-    assert sum(o.kind == rt.OP_MBLANE for o in fused.ops) == 6 and fused.ops[0].kind == rt.OP_STEMBLOCK  # block_1..6
+    nlane, nmbr = (sum(o.kind == k for o in fused.ops) for k in (rt.OP_MBLANE, rt.OP_MBR))
+    assert fused.ops[0].kind == rt.OP_STEMBLOCK and nlane + nmbr >= 6 and nmbr >= 4   # block_1..6 fused as before; the 26 x 26 blocks on mbr.hip
     assert abs(fused.algorithmic_bytes_per_image() - p.algorithmic_bytes_per_image()) < 1  # accounting is fusion-invariant
     assert fused.total_macs() == p.total_macs()
     assert fused.arena_bytes_per_image < p.arena_bytes_per_image
@@ -59,13 +60,15 @@ def test_plan_structure_and_accounting():
 def test_fold_depthwise_plan_keeps_the_accounting():
     from yoloret_amd import compiler, runtime as rt
     from yoloret_amd.weights import synthetic_weights
-    base = _model().plan
-    saved = compiler.FOLD_DW
-    compiler.FOLD_DW = True
+    saved = compiler.FOLD_DW, compiler.FUSE_MBR
+    compiler.FOLD_DW, compiler.FUSE_MBR = True, False   # (an alternative to fusing the same blocks into one kernel)
     try:
+        compiler.FOLD_DW = saved[0]
+        base = _model().plan
+        compiler.FOLD_DW = True
         fm = _model()
     finally:
-        compiler.FOLD_DW = saved
+        compiler.FOLD_DW, compiler.FUSE_MBR = saved
     p = fm.plan
     folded = [o for o in p.ops if o.kind == rt.OP_POINTWISE and o.srcs[0].xform == 'dw3']
     assert [o.name for o in folded] == ['block_%d_project' % i for i in range(7, 16)]   # block_16: cout 240 > one tile

@@ -272,6 +272,20 @@ STEM_MFMA = os.environ.get('YOLORET_STEM_MFMA', '1') != '0'   # 16-bit plans: th
 STEM_MFMA_MAX_C1 = int(os.environ.get('YOLORET_STEM_MFMA_MAX_C1', '32'))
 
 
+# float32 plans: inverted-residual blocks on the row-walking register-chained matrix-pipe kernel (mbr.hip).  (cin, cexp, cout,
+# stride, residual) -> (waves per workgroup, row segments; 0 = the library's choice): the shapes built there and measured
+# ahead of what the plan would run otherwise (tools/mbr_probe.py, batch 64).  YOLORET_FUSE_MBR=0 switches it off,
+# YOLORET_MBR_BLOCKS="block_7,block_8" restricts it to the named blocks.
+FUSE_MBR = os.environ.get('YOLORET_FUSE_MBR', '1') != '0'
+MBR_BLOCKS = [b for b in os.environ.get('YOLORET_MBR_BLOCKS', '').split(',') if b]
+MBR_SHAPES = {
+    (32, 192, 48, 2, False): (4, 0),     # MobileNetV2 x0.75 block_6
+    (48, 288, 48, 1, True): (8, 0),      # block_7..9
+    (48, 288, 72, 1, False): (8, 0),     # block_10
+}
+if os.environ.get('YOLORET_MBR_ALL', '0') != '0':   # (experiments: every shape mbr.hip is built for)
+    MBR_SHAPES.update({(16, 96, 24, 2, False): (2, 0), (24, 144, 24, 1, True): (3, 0), (24, 144, 32, 2, False): (3, 0),
+                       (32, 192, 32, 1, True): (4, 0)})
 FUSE_MBH = os.environ.get('YOLORET_FUSE_MBH', '1') != '0'   # 16-bit plans: inverted-residual blocks on the MFMA block kernel (mbh.hip)
 MBH_LANE_MIN_PIXELS = int(os.environ.get('YOLORET_MBH_LANE_MIN_PIXELS', '10000'))
 MBH_LANE_MAX_CIN = int(os.environ.get('YOLORET_MBH_LANE_MAX_CIN', '16'))
@@ -539,6 +553,37 @@ def fold_depthwise_into_project(ops, output_buf_ids, min_pixels=0):
     return out
 
 
+def mbr_pack(we_t, e_scale, e_shift, dw, d_scale, d_shift, wp_t, p_scale, p_shift):
+    """Parameters of a YR_OP_MBR block in the layout of include/yoloret_hip.h (mbr.hip): the MFMA A fragments of both 1x1
+    convolutions in REGISTER order (one coalesced dword load per register), BN scales folded in.
+    we_t [cexp][>=cin] expand (pointwise layout), dw [9][>=cexp] depthwise taps, wp_t [cout][>=cexp] project; BN vectors per layer.
+    -> (wgt [T][KE + 4 TO][64], wgt2 [T][11][16], b2 [16 TO]) float32."""
+    cexp, cout = dw.shape[1] // 16 * 16, wp_t.shape[0]
+    cin = we_t.shape[1] // 8 * 8
+    assert dw.shape[1] >= cexp and cexp % 16 == 0 and cin % 16 in (0, 8), (dw.shape, we_t.shape)
+    T, TO, KE, nmain = cexp // 16, (cout + 15) // 16, cin // 4, cin // 16
+    wef = (we_t[:cexp, :cin] * e_scale[:cexp, None]).astype(np.float32)
+    wpf = np.zeros((16 * TO, cexp), np.float32)
+    wpf[:cout] = (wp_t[:, :cexp] * p_scale[:cout, None]).astype(np.float32)
+    lane = np.arange(64)
+    m, g = lane % 16, lane // 16
+    wa = np.zeros((T, KE + 4 * TO, 64), np.float32)
+    for j in range(T):
+        for q in range(KE):
+            c, s = divmod(q, 4)
+            kidx = 16 * c + 4 * g + s if c < nmain else 16 * nmain + 2 * g + s   # (a trailing 8-channel chunk: two steps)
+            wa[j, q] = wef[16 * j + m, kidx]
+        for t in range(TO):
+            for s in range(4):
+                wa[j, KE + 4 * t + s] = wpf[16 * t + m, 16 * j + 4 * g + s]
+    tab = np.zeros((T, 11, 16), np.float32)
+    tab[:, :9] = (dw[:, :cexp] * d_scale[None, :cexp]).astype(np.float32).reshape(9, T, 16).transpose(1, 0, 2)
+    tab[:, 9], tab[:, 10] = d_shift[:cexp].reshape(T, 16), e_shift[:cexp].reshape(T, 16)
+    b2 = np.zeros(16 * TO, np.float32)
+    b2[:cout] = p_shift[:cout]
+    return wa, tab, b2
+
+
 def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None):
     """Peephole over the lowered op list: [POINTWISE expand+act ->] DEPTHWISE 3x3+act -> POINTWISE
     project (+residual == block input) becomes one MBCONV op whose expanded tensors never reach HBM.
@@ -701,6 +746,33 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
         # 16-bit plans: the MFMA block kernel (mbh.hip) takes every expand -> depthwise 3x3 | 5x5 -> project block with up
         # to 128 input / output channels, whatever the map size (measured: it beats the unfused chain on every
         # MobileNetV2 block at batch 64 and the float32 lane kernels where both apply)
+        if (FUSE_MBR and dtype == 0 and blocks and exp is not None and d is not None and d.kind == rt.OP_DEPTHWISE and d.k == 3
+                and d.stride in (1, 2) and plain1(d) and private(d.out) and d.srcs[0].buf is exp.out and d.act == exp.act == 'relu6'
+                and j + 1 < len(ops)):
+            p, bi = ops[j + 1], exp.srcs[0]
+            key = (bi.c, d.cin, p.cout if p.kind == rt.OP_POINTWISE else 0, d.stride, p.res is not None)
+            bname = exp.name.rsplit('_', 1)[0]
+            if (key in MBR_SHAPES and (not MBR_BLOCKS or bname in MBR_BLOCKS) and p.kind == rt.OP_POINTWISE and plain1(p)
+                    and p.srcs[0].buf is d.out and p.act == 'none' and 'scale' in p.params and bi.xform == 'identity'
+                    and bi.buf.ld % 4 == 0 and p.out.ld % 4 == 0 and bi.buf.dtype == 0 and p.out.dtype == 0
+                    and (p.res is None or (p.res is bi.buf and d.stride == 1 and p.cout == bi.c))):
+                cin, cexp, cout = bi.c, d.cin, p.cout
+                nw, segs = MBR_SHAPES[key]
+                T, TO, KE = cexp // 16, (cout + 15) // 16, cin // 4
+                m = OpRec(rt.OP_MBR, bname + '_mbr', act='relu6', h=p.h, w=p.w, cin=cin, cout=cout, k=3 | nw << 8 | segs << 16,
+                          stride=d.stride, se_reduced=cexp, srcs=[bi], out=p.out, res=p.res, macs=exp.macs + d.macs + p.macs, dtype=0)
+                m.fused = [exp, d, p]
+                ep, dp, pp = exp.params, d.params, p.params
+
+                def packed(which, ep=ep, dp=dp, pp=pp, cexp=cexp):
+                    def f(wd):
+                        return mbr_pack(ep['wgt'][1](wd), ep['scale'][1](wd), ep['shift'][1](wd), dp['wgt'][1](wd).reshape(9, -1),
+                                        dp['scale'][1](wd), dp['shift'][1](wd), pp['wgt'][1](wd), pp['scale'][1](wd), pp['shift'][1](wd))[which]
+                    return f
+                m.params = {'wgt': ((T, KE + 4 * TO, 64), packed(0)), 'wgt2': ((T, 11, 16), packed(1)), 'b2': ((16 * TO,), packed(2))}
+                out.append(m)
+                i = j + 2
+                continue
         mbh = None
         if (FUSE_MBH and dtype != 0 and blocks and exp is not None and d is not None and d.kind == rt.OP_DEPTHWISE and d.k in (3, 5)
                 and d.stride in (1, 2) and '%d%d' % (d.k, d.stride) not in MBH_SKIP and not (d.k == 5 and d.stride == 1 and (d.cin > MBH_K5_MAX_CEXP or (d.cin > MBH_K5_SMALL_CEXP and d.h * d.w <= MBH_K5_SMALL_MAP))) and not (d.k == 3 and d.stride == 1 and d.cin > MBH_K3_MAX_CEXP) and plain1(d) and private(d.out) and d.srcs[0].buf is exp.out and d.act == exp.act

@@ -1,0 +1,345 @@
+// Fused inverted-residual block, float32, ROW-WALKING REGISTER-CHAINED formulation (YR_OP_MBR):
+//   expand 1x1 + BN + ReLU6 -> depthwise 3x3 (stride 1|2, TF SAME) + BN + ReLU6 -> project 1x1 + BN (+ residual)
+// (MobileNetV2 block_1..15 [3P], reference code/yolo3/override.py:290-341; SE-free MBConv, efficientnet.py:467-536).
+//
+// Both 1x1 convolutions run on v_mfma_f32_16x16x4_f32 (exact float32 FMA chains) and the expanded tensor never leaves the
+// register file - not even for LDS:
+//   * a wave owns a STRIP of 16 adjacent input columns and walks down the rows.  The expand GEMM of one row is
+//     D[expanded channel][pixel] = We * X with the 16 pixels of the strip row as the MFMA's N dimension; X comes straight
+//     from global memory in operand layout (lane (pixel p, k group g) loads channels 16c + 4g .. +3 as one 16-byte load
+//     and uses component s in MFMA step 4c + s; the weights are permuted the same way by the host).  The BN shift is the
+//     accumulator's initial value (the scale is folded into the weights), ReLU6 one v_med3 whose upper bound is 0 for
+//     lanes / rows outside the image (= TF's zero padding of the depthwise input).
+//   * the MFMA result layout IS the layout the depthwise conv wants and the layout the projection's B operand wants:
+//     a lane holds 4 consecutive channels of ONE pixel, the 16 lanes of a DPP row are the 16 pixels.  The three
+//     horizontal taps are the lane itself and its row_shr:1 / row_shl:1 neighbours (DPP, no LDS), the three vertical
+//     taps are the last three rows of the walk, kept in registers (a ring of two rows + the new one).  The depthwise
+//     result (BN shift as the first addend, v_med3) is used AS IS as the B operand of the projection MFMAs.
+//   * the A operands (expand and project weights of the wave's expanded-channel tiles) are STATIONARY in registers for the
+//     whole walk; only the nine depthwise taps per tile come from a small LDS table.
+//   * the NW waves of a workgroup share one strip and split the expanded channels (tiles of 16); their partial projections
+//     of an output row meet in LDS (one barrier per output row, two buffers), the wave that finishes a cout tile adds the
+//     BN shift and the residual and stores 16 bytes per lane.
+// HBM traffic = block input + output; LDS traffic = 10 x 16 bytes per lane per tile-row + the partial sums.
+// Strip geometry: lane l of a DPP row is input column base + l; outputs sit at lanes S*j + 1, j < 14 / S (the lanes whose
+// three taps are inside the strip): 14 (stride 1) or 7 (stride 2) output columns per strip.
+#include "yr_common.h"
+#include <type_traits>
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct MbrArgs {
+    const float* x; float* out;
+    const float* wa;   // A fragments: [T][KE + 4 * TO][64 lanes]
+    const float* wt;   // per expanded tile [T][11][16]: nine depthwise taps (times the BN scale) | depthwise BN shift | expand BN shift
+    const float* bp;   // project BN shift [16 * TO] (the scale is folded into the project weights)
+    int H, W, Ho, Wo, ld_in, ld_out, pad_t, pad_l, strips, segs, seg_rows;
+};
+
+#define MBR_TAB 176   // floats of one tile's LDS table
+
+__device__ __forceinline__ float mbr_shr1(float v) {   // lane l <- lane l - 1 of the same 16-lane row, 0 at the row start
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float mbr_shl1(float v) {   // lane l <- lane l + 1, 0 at the row end
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, true));
+}
+
+// One tap ROW of the 3x3 depthwise conv for the lane's 4 channels: acc[i] += shr(e[i]) * w0[i] + e[i] * w1[i] + shl(e[i]) * w2[i].
+// The DPP shift rides on the multiply-add's first operand (v_fmac_f32_dpp: no v_mov_dpp, no extra register) and the four
+// channels' chains are interleaved tap-major, so a dependent instruction sits four slots behind its producer.  hipcc 7.2 does
+// not fold update_dpp into the fma (left to itself: 6 v_mov_b32_dpp + hazard nops per channel, one chain after the other).
+// s_nop 1: a VALU write of e[] must be two wait states ahead of a DPP read (the hazard recogniser does not look into asm).
+// (A packed form - v_pk_fma_f32 on row_shr / row_shl copies made once per row, scatter order - needs 26 instead of 36 VALU
+// slots per tile row, but its register tuples made hipcc 7.2 spill 100-600 bytes per lane on the stride-1 kernels: measured
+// slower everywhere it spilled, equal elsewhere.)
+#define MBR_DPP(ctl) " " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void mbr_dw_row(v4f& acc, const v4f e, const v4f w0, const v4f w1, const v4f w2) {
+    float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %4, %8" MBR_DPP("row_shr:1")
+        "v_fmac_f32_dpp %1, %5, %9" MBR_DPP("row_shr:1")
+        "v_fmac_f32_dpp %2, %6, %10" MBR_DPP("row_shr:1")
+        "v_fmac_f32_dpp %3, %7, %11" MBR_DPP("row_shr:1")
+        "v_fmac_f32 %0, %4, %12\n\t"
+        "v_fmac_f32 %1, %5, %13\n\t"
+        "v_fmac_f32 %2, %6, %14\n\t"
+        "v_fmac_f32 %3, %7, %15\n\t"
+        "v_fmac_f32_dpp %0, %4, %16" MBR_DPP("row_shl:1")
+        "v_fmac_f32_dpp %1, %5, %17" MBR_DPP("row_shl:1")
+        "v_fmac_f32_dpp %2, %6, %18" MBR_DPP("row_shl:1")
+        "v_fmac_f32_dpp %3, %7, %19" MBR_DPP("row_shl:1")
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(w0[0]), "v"(w0[1]), "v"(w0[2]), "v"(w0[3]),
+          "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(w1[3]), "v"(w2[0]), "v"(w2[1]), "v"(w2[2]), "v"(w2[3]));
+    acc = (v4f){a0, a1, a2, a3};
+}
+
+typedef __amdgpu_buffer_rsrc_t mbr_rsrc;
+__device__ __forceinline__ mbr_rsrc mbr_make_rsrc(const void* base, unsigned bytes) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)base), hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)base >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+#define MBR_DEAD 0x7f000000u   // a byte offset beyond every descriptor's num_records: the load returns zeros, the store is dropped
+
+template <int CIN, int CEXP, int COUT, int S, int NW, bool RES, int NT>
+__device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const int w, float* lds) {
+    constexpr int T = CEXP / 16, TO = (COUT + 15) / 16, NMAIN = CIN / 16, TAIL = CIN % 16, KE = NMAIN * 4 + TAIL / 4;
+    constexpr int NREG = KE + 4 * TO, NOUT = 14 / S;
+    static_assert(TAIL == 0 || TAIL == 8, "block input width must be 16 n or 16 n + 8");
+    static_assert(CEXP % 16 == 0 && COUT % 4 == 0, "widths");
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, px = lane & 15, mg = lane >> 4;
+    // ---- which strip segment
+    int bid = (int)yr_xcd_swizzle(blockIdx.x, gridDim.x);
+    const int seg = bid % a.segs; bid /= a.segs;
+    const int strip = bid % a.strips;
+    const int b = bid / a.strips;
+    const int yo0 = seg * a.seg_rows, yo1 = min(yo0 + a.seg_rows, a.Ho);
+    const int xin = S * NOUT * strip - a.pad_l + px;
+    const int xc = min(max(xin, 0), a.W - 1);
+    const float hi = (xin >= 0 && xin < a.W) ? 6.f : 0.f;
+    const int jo = (px - 1) / S, xo = NOUT * strip + jo;
+    const bool out_lane = px >= 1 && px <= 14 && (px - 1) % S == 0 && xo < a.Wo;
+
+    // ---- stationary A fragments of this wave's tiles
+    float we[NT][KE], wp[NT][TO][4];
+    v4f se[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const float* p = a.wa + ((size_t)(t0 + j) * NREG) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < KE; ++q) we[j][q] = p[q * 64];
+#pragma unroll
+        for (int t = 0; t < TO; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wp[j][t][s] = p[(KE + 4 * t + s) * 64];
+        se[j] = *reinterpret_cast<const v4f*>(a.wt + (size_t)(t0 + j) * MBR_TAB + 160 + 4 * mg);
+    }
+    // ---- the depthwise table of all tiles -> LDS
+    float* tab = lds;
+    for (int i = threadIdx.x; i < T * MBR_TAB; i += 64 * NW) tab[i] = a.wt[i];
+    v4f* red = reinterpret_cast<v4f*>(lds + T * MBR_TAB);   // [2][NW][TO][64]
+    __syncthreads();
+
+    // Every global access of the walk is UNCONDITIONAL, through buffer descriptors (dead lanes pass an offset beyond
+    // num_records): the compiler can then COUNT the outstanding operations, and the wait for the next row's pixels does
+    // not wait for the store just issued (a store under a per-lane branch turns every later wait into vmcnt(0)).
+    const mbr_rsrc xsrc = mbr_make_rsrc(a.x + (size_t)b * a.H * a.W * a.ld_in, (unsigned)(a.H * a.W * a.ld_in) * 4u);
+    const mbr_rsrc osrc = mbr_make_rsrc(a.out + (size_t)b * a.Ho * a.Wo * a.ld_out, (unsigned)(a.Ho * a.Wo * a.ld_out) * 4u);
+    const int rbeg = S * yo0 - a.pad_t, nout = yo1 - yo0;
+    const unsigned xoff = ((unsigned)xc * (unsigned)a.ld_in + 4u * mg) * 4u, xtoff = ((unsigned)xc * (unsigned)a.ld_in + 16u * NMAIN + 2u * mg) * 4u;
+    const unsigned xrow = (unsigned)(a.W * a.ld_in) * 4u;
+    // the B operands of a row: two register sets used alternately (the loads of row r + 1 are issued at the start of row r)
+    struct XRow { v4f m[NMAIN > 0 ? NMAIN : 1]; v2f t; };
+    XRow xa, xb;
+    auto load_row = [&](XRow& x, int r) {
+        const unsigned so = (unsigned)min(max(r, 0), a.H - 1) * xrow;
+#pragma unroll
+        for (int c = 0; c < NMAIN; ++c) x.m[c] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff + 64u * c, so, 0));
+        if constexpr (TAIL != 0) x.t = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(xsrc, xtoff, so, 0));
+    };
+    load_row(xa, rbeg);
+    // the cout tiles this wave finishes (tile t = w + tt * NW): BN shift once, the residual one row ahead of its use
+    constexpr int NF = (TO + NW - 1) / NW;
+    v4f fsh[NF], fres[NF];
+    bool flive[NF];
+#pragma unroll
+    for (int tt = 0; tt < NF; ++tt) {
+        const int t = w + tt * NW, co = 16 * t + 4 * mg;
+        flive[tt] = t < TO && out_lane && co < COUT;
+        fsh[tt] = *reinterpret_cast<const v4f*>(a.bp + (co < 16 * TO ? co : 0));
+        fres[tt] = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+    // the last two expanded rows of this wave's tiles (after ReLU6, zero outside the image): with the new row, the three tap rows
+    v4f ea[NT], eb[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { ea[j] = (v4f){0.f, 0.f, 0.f, 0.f}; eb[j] = ea[j]; }
+    int buf = 0;
+
+    // one input row r = rbeg + k of the walk; EMIT: it is the last tap row of output row yo (rows r - 2, r - 1, r)
+    auto row = [&](auto emit_c, const int k, const int yo, const XRow& xc_, XRow& xn_) {
+        constexpr bool EMIT = decltype(emit_c)::value;
+        const int r = rbeg + k;
+        load_row(xn_, r + 1);
+        float xq[KE];
+#pragma unroll
+        for (int c = 0; c < NMAIN; ++c) { xq[4 * c] = xc_.m[c][0]; xq[4 * c + 1] = xc_.m[c][1]; xq[4 * c + 2] = xc_.m[c][2]; xq[4 * c + 3] = xc_.m[c][3]; }
+        if constexpr (TAIL != 0) { xq[4 * NMAIN] = xc_.t[0]; xq[4 * NMAIN + 1] = xc_.t[1]; }
+        if constexpr (EMIT && RES) {
+#pragma unroll
+            for (int tt = 0; tt < NF; ++tt) {
+                const unsigned off = flive[tt] ? (((unsigned)yo * (unsigned)a.Wo + (unsigned)xo) * (unsigned)a.ld_in + 16u * (w + tt * NW) + 4u * mg) * 4u : MBR_DEAD;
+                fres[tt] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
+            }
+        }
+        const float hr = (r >= 0 && r < a.H) ? hi : 0.f;
+        // ---- expand: NT independent accumulator chains, step-major
+        v4f ec[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) ec[j] = se[j];
+#pragma unroll
+        for (int q = 0; q < KE; ++q)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ec[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(we[j][q], xq[q], ec[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ec[j][i] = __builtin_amdgcn_fmed3f(ec[j][i], 0.f, hr);
+
+        if constexpr (EMIT) {
+            v4f P[TO];
+#pragma unroll
+            for (int t = 0; t < TO; ++t) P[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const v4f* tb = reinterpret_cast<const v4f*>(tab + (t0 + j) * MBR_TAB) + mg;
+                v4f d = tb[36];   // the BN shift is the first addend
+                mbr_dw_row(d, ea[j], tb[0], tb[4], tb[8]);
+                mbr_dw_row(d, eb[j], tb[12], tb[16], tb[20]);
+                mbr_dw_row(d, ec[j], tb[24], tb[28], tb[32]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[i] = __builtin_amdgcn_fmed3f(d[i], 0.f, 6.f);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int t = 0; t < TO; ++t) P[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[j][t][s], d[s], P[t], 0, 0, 0);
+            }
+            const unsigned opix = ((unsigned)yo * (unsigned)a.Wo + (unsigned)xo) * (unsigned)a.ld_out * 4u;
+            if constexpr (NW == 1) {
+#pragma unroll
+                for (int t = 0; t < TO; ++t) {
+                    v4f v = P[t] + fsh[t];
+                    if (RES) v += fres[t];   // (after the sum: the load issued at the row's start is not waited for before here)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), osrc, flive[t] ? opix + (16u * t + 4u * mg) * 4u : MBR_DEAD, 0, 0);
+                }
+            } else {
+                v4f* rb = red + buf * (NW * TO * 64);
+#pragma unroll
+                for (int t = 0; t < TO; ++t) rb[(w * TO + t) * 64 + lane] = P[t];
+                __syncthreads();
+#pragma unroll
+                for (int tt = 0; tt < NF; ++tt) {
+                    const int t = w + tt * NW;
+                    v4f v = fsh[tt];
+                    if (t < TO) {   // (wave-uniform; LDS reads only - the store below stays unconditional)
+#pragma unroll
+                        for (int ww = 0; ww < NW; ++ww) v += rb[(ww * TO + t) * 64 + lane];
+                    }
+                    if (RES) v += fres[tt];   // last: the residual load issued at the row's start is waited for only here
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), osrc, flive[tt] ? opix + (16u * t + 4u * mg) * 4u : MBR_DEAD, 0, 0);
+                }
+                buf ^= 1;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { ea[j] = eb[j]; eb[j] = ec[j]; }
+    };
+    constexpr std::true_type Y{};
+    constexpr std::false_type N{};
+    // rows k = 0 .. 2 - S warm the ring up; then every output row takes S input rows, the last of which emits
+    if constexpr (S == 2) {
+        row(N, 0, 0, xa, xb);
+        for (int i = 0; i < nout; ++i) {
+            row(N, 2 * i + 1, 0, xb, xa);
+            row(Y, 2 * i + 2, yo0 + i, xa, xb);
+        }
+    } else {
+        row(N, 0, 0, xa, xb);
+        row(N, 1, 0, xb, xa);
+        int i = 0;
+        for (; i + 1 < nout; i += 2) {
+            row(Y, i + 2, yo0 + i, xa, xb);
+            row(Y, i + 3, yo0 + i + 1, xb, xa);
+        }
+        if (i < nout) row(Y, i + 2, yo0 + i, xa, xb);
+    }
+}
+
+template <int CIN, int CEXP, int COUT, int S, int NW, bool RES, int MW>
+__global__ __launch_bounds__(64 * NW, MW) void mbr_kernel(MbrArgs a) {
+    constexpr int T = CEXP / 16, NTL = T / NW, R = T % NW, NTH = NTL + (R ? 1 : 0);
+    static_assert(NTL >= 1, "more waves than expanded tiles");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (R != 0) {
+        if (w < R) { mbr_body<CIN, CEXP, COUT, S, NW, RES, NTH>(a, w * NTH, w, lds); return; }
+    }
+    mbr_body<CIN, CEXP, COUT, S, NW, RES, NTL>(a, R * NTH + (w - R) * NTL, w, lds);
+}
+
+template <int CIN, int CEXP, int COUT, int S, int NW, bool RES>
+static int launch_mbr(const MbrArgs& a0, int batch, int want_segs, hipStream_t s) {
+    MbrArgs a = a0;
+    constexpr int T = CEXP / 16, TO = (COUT + 15) / 16, NOUT = 14 / S;
+    a.strips = (a.Wo + NOUT - 1) / NOUT;
+    // segments: enough workgroups for ~2 generations of the chip's SIMDs, not so many that the 2 halo rows matter
+    const int walks = batch * a.strips;
+    int segs = (2 * 1024 + walks * NW - 1) / (walks * NW);
+    const int max_segs = (a.Ho + 5) / 6;
+    if (segs > max_segs) segs = max_segs;
+    if (segs < 1) segs = 1;
+    if (want_segs > 0) segs = want_segs < a.Ho ? want_segs : a.Ho;
+    a.seg_rows = (a.Ho + segs - 1) / segs;
+    a.segs = (a.Ho + a.seg_rows - 1) / a.seg_rows;
+    const size_t lds = (size_t)T * MBR_TAB * 4 + (NW > 1 ? (size_t)2 * NW * TO * 64 * 16 : 0);
+    static char nm[64];
+    static const int nm_len = snprintf(nm, sizeof(nm), "mbr_kernel<%d,%d,%d,%d,%d,%d>", CIN, CEXP, COUT, S, NW, (int)RES);
+    (void)nm_len;
+    yr_note_kernel(nm);
+    auto kern = mbr_kernel<CIN, CEXP, COUT, S, NW, RES, (NW > 4 || (T + NW - 1) / NW > 3 ? 2 : 3)>;   // waves per SIMD the register allocator leaves room for   // waves per SIMD the register allocator must leave room for
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        YR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(batch * a.strips * a.segs)), dim3(64 * NW), lds, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
+// op fields: src[0] = block input (float32, c % 8 == 0, c % 16 in {0, 8}); se_reduced = Cexp (multiple of 16); k = 3 | nw << 8 | segs << 16
+// (nw: waves per workgroup, segs: row segments per strip; 0 = the library's choice); stride 1 | 2; act = ReLU6; res (optional) = the block input.  Parameters (float32):
+//   wgt  = A fragments [T = Cexp/16][KE + 4 TO][64]: register rho of lane (m = l % 16, g = l / 16) of tile j:
+//          rho < KE (expand step q = rho): We[16 j + m][kperm(q, g)] * expand BN scale, kperm(4 c + s, g) = 16 c + 4 g + s for the
+//          full 16-channel chunks, 16 n + 2 g + s (s < 2) for a trailing 8;  rho = KE + 4 t + s: Wp[16 t + m][16 j + 4 g + s] * project
+//          BN scale (0 beyond cout);
+//   wgt2 = [T][11][16]: depthwise taps (ky, kx) times the depthwise BN scale | depthwise BN shift | expand BN shift;
+//   b2   = project BN shift [16 TO].
+int yr_launch_mbr(const yr_op& op, int batch, hipStream_t s) {
+    YR_REQUIRE(op.dtype == YR_F32 && op.out_dtype == YR_F32, "mbr: float32 plans only");
+    YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY && op.src[0].dtype == YR_F32, "mbr: needs one float32 identity source");
+    const yr_src& in = op.src[0];
+    YR_REQUIRE((op.k & 0xff) == 3 && (op.stride == 1 || op.stride == 2) && op.act == YR_ACT_RELU6, "mbr: 3x3, stride 1|2, ReLU6");
+    YR_REQUIRE(in.ptr && op.out && op.wgt && op.wgt2 && op.b2, "mbr: null pointer");
+    YR_REQUIRE(in.ld % 4 == 0 && op.out_ld % 4 == 0 && in.c == op.cin && in.ld >= in.c && op.out_ld >= op.cout, "mbr: channel strides");
+    YR_REQUIRE(((uintptr_t)in.ptr) % 16 == 0 && ((uintptr_t)op.out) % 16 == 0, "mbr: pointers must be 16-byte aligned");
+    MbrArgs a;
+    a.x = (const float*)in.ptr; a.out = (float*)op.out; a.wa = op.wgt; a.wt = op.wgt2; a.bp = op.b2;
+    a.H = in.h; a.W = in.w; a.Ho = (in.h + op.stride - 1) / op.stride; a.Wo = (in.w + op.stride - 1) / op.stride;
+    YR_REQUIRE(a.Ho == op.h && a.Wo == op.w, "mbr: output dims mismatch");
+    a.ld_in = in.ld; a.ld_out = op.out_ld;
+    const int pth = (a.Ho - 1) * op.stride + 3 - in.h, ptw = (a.Wo - 1) * op.stride + 3 - in.w;
+    a.pad_t = (pth > 0 ? pth : 0) / 2; a.pad_l = (ptw > 0 ? ptw : 0) / 2;
+    const bool res = op.res != nullptr;
+    if (res) YR_REQUIRE(op.res == in.ptr && op.stride == 1 && in.c == op.cout, "mbr: the residual must be the block input (stride 1, Cin == Cout)");
+    a.strips = a.segs = a.seg_rows = 0;
+    const int nw = (op.k >> 8) & 0xff;
+#define MBR_CASE(CIN, CEXP, COUT, S, NW, RES)                                                              \
+    if (in.c == CIN && op.se_reduced == CEXP && op.cout == COUT && op.stride == S && res == RES && (nw == 0 || nw == NW)) \
+        return launch_mbr<CIN, CEXP, COUT, S, NW, RES>(a, batch, (op.k >> 16) & 0xff, s);
+    MBR_CASE(16, 96, 24, 2, 2, false)      // MobileNetV2 x0.75 block_1
+    MBR_CASE(16, 96, 24, 2, 1, false)
+    MBR_CASE(24, 144, 24, 1, 3, true)      // block_2
+    MBR_CASE(24, 144, 32, 2, 3, false)     // block_3
+    MBR_CASE(32, 192, 32, 1, 4, true)      // block_4, 5
+    MBR_CASE(32, 192, 48, 2, 4, false)     // block_6
+    MBR_CASE(48, 288, 48, 1, 6, true)      // block_7..9
+    MBR_CASE(48, 288, 48, 1, 8, true)
+    MBR_CASE(48, 288, 72, 1, 6, false)     // block_10
+    MBR_CASE(48, 288, 72, 1, 8, false)
+#undef MBR_CASE
+    yr_set_error("mbr: block %d -> %d -> %d stride %d res %d (nw %d) is not built", in.c, op.se_reduced, op.cout, op.stride, (int)res, nw);
+    return YR_ERR_ARG;
+}
