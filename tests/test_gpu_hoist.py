@@ -170,3 +170,42 @@ def test_depthwise_folded_into_project_is_bit_identical(dev, name, size):
         outs[fold] = [y.cpu().numpy() for y in m(x)]
     for a, b in zip(outs[False], outs[True]):
         assert np.array_equal(a, b)
+
+
+def test_compiler_folds_head_projections_into_their_1x1_consumers(dev):
+    """compiler.fold_projection_into_consumers: W_c (s_p W_p d + h_p) = (W_c diag(s_p) W_p) d + W_c h_p.  The 52 x 52 head
+    projections (td3 -> bu3_conv; bu3 -> {y, down conv + maxpool}) and bu1 -> y disappear, their consumers read the gated
+    depthwise map; accounting unchanged; logits equal the unfolded plan's to rounding and the oracle's within 1e-4
+    (reference: code/yolo3/model.py:98-114,296-308; efficientnet.py:517-533)."""
+    from oracle import model as om, params
+    from yoloret_amd import compiler, layers as L
+    from yoloret_amd.yolo3.model import yolov3_body
+    m = yolov3_body(L.Input(shape=[128, 128, 3]), 'mobilenetv2x75', 3, num_classes=20)
+    names = [o.name for o in m.plan.ops]
+    assert not any(n in names for n in ('td3_mb_project', 'bu3_mb_project', 'bu1_mb_project'))
+    assert all(n in names for n in ('td1_mb_project', 'td2_mb_project', 'bu2_mb_project'))   # composed MACs would be 1.14x .. 2.3x
+    folded = {o.name: o for o in m.plan.ops if getattr(o, 'folded_projection', None)}
+    assert sorted(folded) == ['bu1_y', 'bu3_conv', 'bu3_down_conv', 'bu3_y']
+    assert all(o.gate is not None and o.cin == o.srcs[0].c and o.srcs[0].buf.name.endswith('_mb_dw') for o in folded.values())
+    assert getattr(folded['bu3_down_conv'], 'stride', 0) == 2    # the pooled store still rides on the (composed) conv
+    saved = compiler.FOLD_PROJ
+    try:
+        compiler.FOLD_PROJ = False
+        plain = yolov3_body(L.Input(shape=[128, 128, 3]), 'mobilenetv2x75', 3, num_classes=20)
+    finally:
+        compiler.FOLD_PROJ = saved
+    assert len(plain.plan.ops) == len(m.plan.ops) + 3
+    assert plain.plan.total_macs() == m.plan.total_macs()
+    assert abs(plain.plan.algorithmic_bytes_per_image() - m.plan.algorithmic_bytes_per_image()) < 1
+    P = params.ParamStore(12, 'conditioned')
+    x = params.synthetic_images(2, 128, 128)
+    ref = om.yolov3_body(P, x, 'mobilenetv2x75', 3, 20)
+    got = []
+    for model in (m, plain):
+        model.set_weights(P.values)
+        ys = [y.cpu().numpy() for y in model(torch.from_numpy(x).to(dev))]
+        got.append(ys)
+        for y, r in zip(ys, ref):
+            assert_close(y.reshape(r.shape), r, 1e-4, 'graph with folded projections')
+    for a, b in zip(*got):
+        assert_close(a, b, 3e-5, 'folded vs unfolded plan')

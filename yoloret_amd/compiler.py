@@ -361,6 +361,66 @@ def hoist_upsampled_sources(ops, bufs):
     return out
 
 
+# Two 1x1 convolutions with nothing non-linear between them are one: the projection of the detection heads' MBConv block has
+# BatchNorm but no activation (efficientnet.py:517-533), and what reads its 75-channel output are 1x1 convolutions again
+# (the `y` conv of make_last_layers, model.py:110-114; the bottom-up 75 -> 128 conv + maxpool, :298-308; the next block's
+# first conv).  W_c (s_p * W_p d + h_p) = (W_c diag(s_p) W_p) d + W_c h_p: each consumer reads the gated depthwise map itself
+# with the composed weights (products formed in float64, rounded once), the projection launch and its 75-channel tensor
+# disappear.  Done where it does not cost arithmetic: composed MACs <= FOLD_PROJ_MAX_RATIO x the MACs of the convs replaced
+# (the 52 x 52 heads, F = 128: td3 -> bu3_conv 0.85, bu3 -> {y, down} 1.05; bu1 -> y 0.87; not the F = 256 / 512 ones).
+FOLD_PROJ = os.environ.get('YOLORET_FOLD_PROJ', '1') != '0'
+FOLD_PROJ_MAX_RATIO = float(os.environ.get('YOLORET_FOLD_PROJ_MAX_RATIO', '1.1'))
+
+
+def fold_projection_into_consumers(ops, output_buf_ids):
+    readers = {}
+    for op in ops:
+        for s in op.srcs:
+            readers.setdefault(id(s.buf), []).append((op, s))
+        for b in (op.res, op.gate):
+            if b is not None:
+                readers.setdefault(id(b), []).append((op, None))
+    drop, repl = set(), {}
+    for P in ops:
+        rd = readers.get(id(P.out), [])
+        if (P.kind != rt.OP_POINTWISE or P.act != 'none' or 'scale' not in P.params or P.res is not None or len(P.srcs) != 1
+                or P.srcs[0].xform != 'identity' or P.out.external_slot >= 0 or P.out.id in output_buf_ids or not rd
+                or (P.h == 1 and P.w == 1) or P.dtype != 0 or getattr(P, 'accounted_in', None)):
+            continue
+        if any(s is None or C.kind != rt.OP_POINTWISE or len(C.srcs) != 1 or s.xform != 'identity' or C.gate is not None
+               or C.res is not None or s.c != P.cout or C.dtype != 0 or id(C) in repl for C, s in rd):
+            continue
+        cin, cp = P.cin, P.cout
+        if sum(cin * C.cout for C, _ in rd) > FOLD_PROJ_MAX_RATIO * (cin * cp + sum(cp * C.cout for C, _ in rd)):
+            continue
+        pw, psc, psh = P.params['wgt'][1], P.params['scale'][1], P.params['shift'][1]
+        for n, (C, s) in enumerate(rd):
+            m = OpRec(rt.OP_POINTWISE, C.name, act=C.act, h=C.h, w=C.w, cin=cin, cout=C.cout, srcs=[Seg(P.srcs[0].buf, P.srcs[0].c, 'identity')],
+                      out=C.out, gate=P.gate, macs=C.macs + (P.macs if n == 0 else 0), dtype=0)
+            cw = C.params['wgt'][1]
+            csc = C.params['scale'][1] if 'scale' in C.params else None
+            csh = C.params['shift'][1] if 'shift' in C.params else None
+
+            def wgt(wd, pw=pw, psc=psc, cw=cw, cp=cp):
+                return (cw(wd)[:, :cp].astype(np.float64) @ (psc(wd)[:cp, None].astype(np.float64) * pw(wd)[:cp].astype(np.float64))).astype(np.float32)
+
+            def shift(wd, psh=psh, cw=cw, csc=csc, csh=csh, cp=cp):
+                b = cw(wd)[:, :cp].astype(np.float64) @ psh(wd)[:cp].astype(np.float64)
+                if csc is not None:
+                    b = csc(wd).astype(np.float64) * b + csh(wd).astype(np.float64)
+                return b.astype(np.float32)
+            m.params = {'wgt': (P.params['wgt'][0][:0] + (C.cout, P.params['wgt'][0][1]), wgt, 0),
+                        'scale': ((C.cout,), csc if csc is not None else (lambda wd, n_=C.cout: np.ones(n_, np.float32))),
+                        'shift': ((C.cout,), shift)}
+            # conv-granular accounting stays that of the convolutions replaced: the first consumer carries the
+            # projection's share, every consumer is charged the 75-channel input it used to read
+            m.fused = [P, C] if n == 0 else [C]
+            m.folded_projection = P.name
+            repl[id(C)] = m
+        drop.add(id(P))
+    return [repl.get(id(op), op) for op in ops if id(op) not in drop]
+
+
 MERGE_SE_MEAN = os.environ.get('YOLORET_MERGE_SE_MEAN', '1') != '0'
 
 
@@ -1108,6 +1168,8 @@ class Compiler:
             outs.append(v.segs[0].buf)
         ops = self.ops
         if self.fuse:
+            if FOLD_PROJ and self.dtype == 0:
+                ops = fold_projection_into_consumers(ops, set(b.id for b in outs))
             if HOIST_UPSAMPLE:
                 ops = hoist_upsampled_sources(ops, self.bufs)
             if POOL_IN_PRODUCER:

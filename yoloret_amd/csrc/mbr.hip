@@ -288,7 +288,13 @@ static int launch_mbr(const MbrArgs& a0, int batch, int want_segs, hipStream_t s
     static const int nm_len = snprintf(nm, sizeof(nm), "mbr_kernel<%d,%d,%d,%d,%d,%d>", CIN, CEXP, COUT, S, NW, (int)RES);
     (void)nm_len;
     yr_note_kernel(nm);
-    auto kern = mbr_kernel<CIN, CEXP, COUT, S, NW, RES, (NW > 4 || (T + NW - 1) / NW > 3 ? 2 : 3)>;   // waves per SIMD the register allocator leaves room for   // waves per SIMD the register allocator must leave room for
+    // waves per SIMD the register allocator must leave room for, from an estimate of what a wave holds: the stationary
+    // fragments + BN shifts, ring and new row, projection accumulators, two rows of pixel operands, ~44 others
+    constexpr int NTH = (T + NW - 1) / NW, KE = CIN / 4;
+    constexpr int EST = NTH * (KE + 4 * TO + 4 + 12) + 4 * TO + 2 * KE + 44;
+    constexpr int MW = EST <= 164 ? 3 : EST <= 250 ? 2 : 1;
+    static_assert(NW <= 4 * MW, "a workgroup's waves must fit one CU at this register budget");
+    auto kern = mbr_kernel<CIN, CEXP, COUT, S, NW, RES, MW>;   // waves per SIMD the register allocator must leave room for
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         YR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -339,6 +345,8 @@ int yr_launch_mbr(const yr_op& op, int batch, hipStream_t s) {
     MBR_CASE(48, 288, 48, 1, 8, true)
     MBR_CASE(48, 288, 72, 1, 6, false)     // block_10
     MBR_CASE(48, 288, 72, 1, 8, false)
+    MBR_CASE(72, 224, 72, 1, 7, true)      // (experiment: half of block_11's expanded channels)
+    MBR_CASE(120, 192, 120, 1, 4, true)    // (experiment: a quarter of block_14's expanded channels)
 #undef MBR_CASE
     yr_set_error("mbr: block %d -> %d -> %d stride %d res %d (nw %d) is not built", in.c, op.se_reduced, op.cout, op.stride, (int)res, nw);
     return YR_ERR_ARG;
