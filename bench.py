@@ -193,9 +193,8 @@ def main():
         # handle is waited for one step later (the final sync() covers the last one).  Every step still contains
         # exactly one collective.
         det, cnt = pipe(x, image_hw)
-        h = gather.start(det, cnt, pipe.record, after=pipe.done)
-        if h.released is not None:
-            pipe.release(h.released)          # the context that produced these records runs again only after the collective read them
+        # (pipeline=pipe: the context that produced these records runs again only after the collective has read them)
+        h = gather.start(det, cnt, pipe.record, after=pipe.done, pipeline=pipe)
         prev, pending[0] = pending[0], h
         if prev is None:
             return None

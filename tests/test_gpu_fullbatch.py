@@ -89,3 +89,45 @@ def test_full_batch_properties(dev, name, size, b, dt):
         gb, gs, gc = [t.cpu().numpy() for t in res[i]]
         ob, os_, oc, _ = cpost.yolo_eval([y[i].cpu().numpy() for y in ys], ANCHORS, 3, 20, hw, 20, 0.2, 0.5)
         assert np.array_equal(gb, ob) and np.array_equal(gs, os_) and np.array_equal(gc, oc)
+
+
+def test_c2_three_steps_in_flight_equal_the_serial_pipeline(dev):
+    """BASELINE config 2 exactly as `bench.py` runs it - MobileNetV2 x0.75 @416, 64 images per step, DetectionPipeline(depth=3) -
+    on three DIFFERENT batches: the packed records of every step equal those of the strictly serial pipeline on the same
+    Model, bit for bit, also when a context is reused while its neighbours still run and when a serial step (the bare
+    workspace, ctx 0) is issued between steps in flight (each context owns its workspace: engine.Model.__call__)."""
+    from yoloret_amd import layers as L
+    from yoloret_amd.pipeline import DetectionPipeline
+    from yoloret_amd.weights import synthetic_weights
+    from yoloret_amd.yolo3.model import yolov3_body
+    size, b = 416, 64
+    m = yolov3_body(L.Input(shape=[size, size, 3]), 'mobilenetv2x75', 3, num_classes=20)
+    m.set_weights(synthetic_weights(m, 1234, 'survey'))       # the bench's recipe
+    xs = [torch.from_numpy(params.synthetic_images(b, size, size, seed=s)).to(dev) for s in (21, 22, 23)]
+    hw = torch.tensor([[size, size]] * b, dtype=torch.int32, device=dev)
+    serial = DetectionPipeline(m, ANCHORS, 20, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5)
+    want = []
+    for x in xs:
+        det, cnt = serial(x, hw)
+        torch.cuda.synchronize()
+        want.append((det.cpu().numpy().copy(), cnt.cpu().numpy().copy()))
+    assert min(int(c.sum()) for _, c in want) > 0 and not np.array_equal(want[0][0], want[1][0])
+    deep = DetectionPipeline(m, ANCHORS, 20, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5, depth=3)
+    order = [0, 1, 2, 1, 0, 2, 2, 0]
+    outs = []
+    for n, i in enumerate(order):
+        det, cnt = deep(xs[i], hw)
+        outs.append((det, cnt, deep.done, i))
+        if n == 4:                                   # a serial step on the same Model while three steps are in flight
+            sd, sc = serial(xs[1], hw)
+            s_ev = torch.cuda.Event()
+            s_ev.record(torch.cuda.current_stream(dev))
+        if len(outs) >= 3:
+            d, c, ev, j = outs[-3]
+            ev.synchronize()
+            assert np.array_equal(d.cpu().numpy(), want[j][0]) and np.array_equal(c.cpu().numpy(), want[j][1]), (n, j)
+    s_ev.synchronize()
+    assert np.array_equal(sd.cpu().numpy(), want[1][0]) and np.array_equal(sc.cpu().numpy(), want[1][1])
+    torch.cuda.synchronize()
+    for d, c, ev, j in outs[-2:]:
+        assert np.array_equal(d.cpu().numpy(), want[j][0]) and np.array_equal(c.cpu().numpy(), want[j][1]), j

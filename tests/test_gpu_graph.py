@@ -412,3 +412,28 @@ def test_uint8_network_entry(dev, name, policy):
             assert_close(a, b[:2], 2e-5, '%s latency plan, uint8 entry' % name)
         else:
             assert np.isfinite(a).all()
+
+
+@pytest.mark.parametrize('name,size', [('mobilenetv2x75', 416), ('efficientnetb3', 640)])
+def test_latency_plan_at_full_resolution_batch_1(dev, name, size):
+    """Batch 1 at the BASELINE resolution is the reference's ONLY operating point (code/yolo.py:83-84: Input(batch_size=1))
+    and what `p50_ms_b1` times: the latency plan (Model.small_batch = 4: no block fusion, its own blob and tile table) must
+    meet the 1e-4 logit bar there, and the oracle's post-processing of the GPU's logits must equal the GPU's detections
+    bit for bit.  (The other tests pin YOLORET_SMALL_BATCH=0 so that their small batches exercise the fused kernels.)"""
+    from oracle import torch_ref
+    from yoloret_amd import runtime as rt
+    from yoloret_amd.yolo3.model import yolo_eval
+    m, P = _build(name, (size, size), 20)
+    x = params.synthetic_images(1, size, size)
+    ref = torch_ref.TorchReference(P, name, 3, 20)(x)   # (the torch-CPU graph: checked against the NumPy restatement in tests/test_golden.py)
+    m.set_weights(P.values)
+    m.small_batch = 4
+    assert m.variant(1) == 'latency'
+    kinds = set(o.kind for o in m.plan_for(1).ops)
+    assert not kinds & {rt.OP_MBLANE, rt.OP_MBCONV, rt.OP_MBR, rt.OP_MBH}
+    ys = m(torch.from_numpy(x).to(dev))
+    torch.cuda.synchronize()
+    for i, (y, r) in enumerate(zip(ys, ref)):
+        assert_close(y.cpu().numpy().reshape(r.shape), r, 1e-4, '%s@%d latency plan y%d' % (name, size, i + 1))
+    res = yolo_eval(ys, ANCHORS, 3, 20, (size, size), max_boxes=20, score_threshold=0.2, iou_threshold=0.5)   # (one image: one triple)
+    _check_detections_with_margins(ys, [r.reshape(tuple(y.shape)) for y, r in zip(ys, ref)], [res], (size, size))

@@ -18,7 +18,9 @@ CASES = [
     (104, 104, 16, 96, 24, 2, False, 1, 0),    # ... many strips / segments, one wave per workgroup
     (31, 45, 16, 96, 24, 2, False, 2, 3),      # odd sizes (pad 1/1), ragged strips and segments
     (13, 13, 24, 144, 24, 1, True, 0, 0),      # block_2 (+add): cin = 16 + 8 (the two-step tail chunk)
-    (52, 52, 24, 144, 32, 2, False, 0, 0),     # block_3
+    (52, 52, 24, 144, 32, 2, False, 0, 0),     # MobileNetV2 x1.4 block_1 shape
+    (52, 52, 24, 144, 24, 2, False, 0, 0),     # x0.75 block_3
+    (27, 27, 24, 144, 48, 2, False, 0, 2),     # x0.75 block_6, odd size
     (30, 44, 32, 192, 32, 1, True, 0, 0),      # block_4/5, ragged strips
     (30, 44, 32, 192, 32, 1, True, 0, 5),      # ... forced segments
     (52, 52, 32, 192, 48, 2, False, 0, 0),     # block_6

@@ -87,6 +87,34 @@ def test_single_rank_rccl_all_gather_of_detections(dev):
         torch.cuda.synchronize()
         for (d, c), i in zip(got, order):
             assert np.array_equal(d.cpu().numpy(), want[i][0]) and np.array_equal(c.cpu().numpy(), want[i][1])
+        # BASELINE config 2 as bench.py --force-dist runs it: 64 images @416 per step, THREE steps in flight, the collective
+        # behind every step's own completion event, the context released by the gatherer itself (start(pipeline=...))
+        size, b = 416, 64
+        m2 = yolov3_body(L.Input(shape=[size, size, 3]), 'mobilenetv2x75', 3, num_classes=20)
+        m2.set_weights(synthetic_weights(m2, 1234, 'survey'))
+        xs = [torch.from_numpy(params.synthetic_images(b, size, size, seed=s)).to(dev) for s in (31, 32, 33)]
+        hw = torch.tensor([[size, size]] * b, dtype=torch.int32, device=dev)
+        ser = DetectionPipeline(m2, ANCHORS, 20, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5)
+        want = []
+        for x in xs:
+            det, cnt = ser(x, hw)
+            torch.cuda.synchronize()
+            want.append((det.cpu().numpy().copy(), cnt.cpu().numpy().copy()))
+        pipe3 = DetectionPipeline(m2, ANCHORS, 20, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5, depth=3)
+        handles, got = [], []
+        order = [0, 1, 2, 2, 0, 1, 1]
+        for i in order:
+            det, cnt = pipe3(xs[i], hw)
+            handles.append(g.start(det, cnt, pipe3.record, after=pipe3.done, pipeline=pipe3))
+            if len(handles) >= 2:                   # (a handle's result views live until the second start() after it)
+                d, c = handles[-2].wait()
+                got.append((d.clone(), c.clone()))
+        d, c = handles[-1].wait()
+        got.append((d.clone(), c.clone()))
+        torch.cuda.synchronize()
+        assert len(got) == len(order)
+        for (d, c), i in zip(got, order):
+            assert np.array_equal(d.cpu().numpy(), want[i][0]) and np.array_equal(c.cpu().numpy(), want[i][1]), i
     finally:
         dist.destroy_process_group()
 

@@ -15,16 +15,16 @@ from yoloret_amd import runtime as rt        # noqa: E402
 BLOCKS = {   # name: (h, w, cin, cexp, cout, stride, residual), r03 time of the shipped kernels in ms
     'block_1': ((208, 208, 16, 96, 24, 2, False), 0.2173),
     'block_2': ((104, 104, 24, 144, 24, 1, True), 0.2042),
-    'block_3': ((104, 104, 24, 144, 32, 2, False), 0.1275),
-    'block_4': ((52, 52, 32, 192, 32, 1, True), 0.0665),
-    'block_6': ((52, 52, 32, 192, 48, 2, False), 0.0845),
+    'block_3': ((104, 104, 24, 144, 24, 2, False), 0.1275),
+    'block_4': ((52, 52, 24, 144, 24, 1, True), 0.0665),
+    'block_6': ((52, 52, 24, 144, 48, 2, False), 0.0845),
     'block_7': ((26, 26, 48, 288, 48, 1, True), 0.0835),
     'block_10': ((26, 26, 48, 288, 72, 1, False), 0.0850),
     'half11': ((26, 26, 72, 224, 72, 1, True), 0.124),      # batch 128 = the grid of a 2-way channel split at batch 64
     'quarter14': ((13, 13, 120, 192, 120, 1, True), 0.086),  # batch 256 = a 4-way split
 }
 BATCH = {'half11': 128, 'quarter14': 256}
-NWS = {'half11': [7], 'quarter14': [4], 'block_1': [1, 2], 'block_2': [3], 'block_3': [3], 'block_4': [4], 'block_6': [4], 'block_7': [6, 8], 'block_10': [6, 8]}
+NWS = {'half11': [7], 'quarter14': [4], 'block_1': [1, 2], 'block_2': [3], 'block_3': [3], 'block_4': [3], 'block_6': [3], 'block_7': [6, 8], 'block_10': [6, 8]}
 
 
 def timed(op, b, n=30):

@@ -279,13 +279,13 @@ STEM_MFMA_MAX_C1 = int(os.environ.get('YOLORET_STEM_MFMA_MAX_C1', '32'))
 FUSE_MBR = os.environ.get('YOLORET_FUSE_MBR', '1') != '0'
 MBR_BLOCKS = [b for b in os.environ.get('YOLORET_MBR_BLOCKS', '').split(',') if b]
 MBR_SHAPES = {
-    (32, 192, 48, 2, False): (4, 0),     # MobileNetV2 x0.75 block_6
+    (24, 144, 48, 2, False): (3, 0),     # MobileNetV2 x0.75 block_6 (52 x 52 -> 26 x 26)
     (48, 288, 48, 1, True): (8, 0),      # block_7..9
     (48, 288, 72, 1, False): (8, 0),     # block_10
 }
 if os.environ.get('YOLORET_MBR_ALL', '0') != '0':   # (experiments: every shape mbr.hip is built for)
-    MBR_SHAPES.update({(16, 96, 24, 2, False): (2, 0), (24, 144, 24, 1, True): (3, 0), (24, 144, 32, 2, False): (3, 0),
-                       (32, 192, 32, 1, True): (4, 0)})
+    MBR_SHAPES.update({(16, 96, 24, 2, False): (2, 0), (24, 144, 24, 1, True): (3, 0), (24, 144, 24, 2, False): (3, 0),
+                       (24, 144, 32, 2, False): (3, 0), (32, 192, 32, 1, True): (4, 0), (32, 192, 48, 2, False): (4, 0)})
 FUSE_MBH = os.environ.get('YOLORET_FUSE_MBH', '1') != '0'   # 16-bit plans: inverted-residual blocks on the MFMA block kernel (mbh.hip)
 MBH_LANE_MIN_PIXELS = int(os.environ.get('YOLORET_MBH_LANE_MIN_PIXELS', '10000'))
 MBH_LANE_MAX_CIN = int(os.environ.get('YOLORET_MBH_LANE_MAX_CIN', '16'))

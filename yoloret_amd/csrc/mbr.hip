@@ -337,10 +337,12 @@ int yr_launch_mbr(const yr_op& op, int batch, hipStream_t s) {
         return launch_mbr<CIN, CEXP, COUT, S, NW, RES>(a, batch, (op.k >> 16) & 0xff, s);
     MBR_CASE(16, 96, 24, 2, 2, false)      // MobileNetV2 x0.75 block_1
     MBR_CASE(16, 96, 24, 2, 1, false)
-    MBR_CASE(24, 144, 24, 1, 3, true)      // block_2
-    MBR_CASE(24, 144, 32, 2, 3, false)     // block_3
-    MBR_CASE(32, 192, 32, 1, 4, true)      // block_4, 5
-    MBR_CASE(32, 192, 48, 2, 4, false)     // block_6
+    MBR_CASE(24, 144, 24, 1, 3, true)      // block_2, 4, 5
+    MBR_CASE(24, 144, 24, 2, 3, false)     // block_3 (x0.75: 32 * 0.75 = 24 outputs)
+    MBR_CASE(24, 144, 48, 2, 3, false)     // block_6
+    MBR_CASE(24, 144, 32, 2, 3, false)     // MobileNetV2 x1.4 block_1 / x1.0 block_3
+    MBR_CASE(32, 192, 32, 1, 4, true)      // x1.4 block_2 / x1.0 block_4, 5
+    MBR_CASE(32, 192, 48, 2, 4, false)     // x1.4 block_3
     MBR_CASE(48, 288, 48, 1, 6, true)      // block_7..9
     MBR_CASE(48, 288, 48, 1, 8, true)
     MBR_CASE(48, 288, 72, 1, 6, false)     // block_10

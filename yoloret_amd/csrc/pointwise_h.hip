@@ -431,11 +431,11 @@ static int launch_h_cfg(int cfg, const PwArgs& a, hipStream_t s) {
         case 17: return launch_lds<T, 2, 2>(a, s);
         case 18: case 19: case 20: case 21: {
             const int rc = yr_pwhs_launch(yr_elem<T>::dtype, cfg - 18, a, s);
-            return rc == -1 ? launch_lds<T, 4, 2>(a, s) : rc;
+            return rc == YR_NOT_TAKEN ? launch_lds<T, 4, 2>(a, s) : rc;
         }
         case 22: case 23: case 24: case 25: {
             const int rc = yr_pwhq_launch(yr_elem<T>::dtype, cfg - 22, a, s);
-            return rc == -1 ? launch_lds<T, 4, 2>(a, s) : rc;
+            return rc == YR_NOT_TAKEN ? launch_lds<T, 4, 2>(a, s) : rc;
         }
         default: yr_set_error("pointwise: 16-bit tile shape %d out of range", cfg); return YR_ERR_ARG;
     }

@@ -161,19 +161,19 @@ static int launch_q_pt(const PwArgs& a, int mode, int cap, hipStream_t s) {
         if (per <= 6) return launch_q<T, PT, 6>(a, mode, s);
         return launch_q<T, PT, 8>(a, mode, s);
     }
-    return -1;
+    return YR_NOT_TAKEN;
 }
 
 // variant: 0 = one pixel tile per wave, up to 256 couts per workgroup; 1 = two pixel tiles, up to 160 couts; 2 / 3 = the same
 // with up to 128 / 96 couts (more workgroups on the small maps, the activations read once per cout range - from L2).
-// Returns -1 (no launch, no error text) when the form does not take the op: the caller falls back.
+// Returns YR_NOT_TAKEN (no launch, no error text) when the form does not take the op: the caller falls back; real errors propagate.
 int yr_pwhq_launch(int dtype, int variant, const PwArgs& a, hipStream_t s) {
     const int mode = (a.S.n == 1 && a.S.s[0].xform == YR_X_IDENTITY) ? (a.gate ? 2 : 1) : 0;
-    if (a.dw_w != nullptr || (mode == 0 && a.gate) || !pwh_out_fits_rsrc(a)) return -1;
+    if (a.dw_w != nullptr || (mode == 0 && a.gate) || !pwh_out_fits_rsrc(a)) return YR_NOT_TAKEN;
     for (int i = 0; i < YR_MAX_SRC; ++i)
-        if (a.S.s[i].xform == YR_X_MAXPOOL2 || a.S.s[i].xform == YR_X_MAXPOOL4) return -1;
+        if (a.S.s[i].xform == YR_X_MAXPOOL2 || a.S.s[i].xform == YR_X_MAXPOOL4) return YR_NOT_TAKEN;
     const int cap = (variant & 1) ? (variant >= 2 ? 3 : 5) : (variant >= 2 ? 4 : 8);
     if (dtype == YR_BF16) return (variant & 1) ? launch_q_pt<yr_bf16, 2>(a, mode, cap, s) : launch_q_pt<yr_bf16, 1>(a, mode, cap, s);
     if (dtype == YR_F16) return (variant & 1) ? launch_q_pt<yr_f16, 2>(a, mode, cap, s) : launch_q_pt<yr_f16, 1>(a, mode, cap, s);
-    return -1;
+    return YR_NOT_TAKEN;
 }

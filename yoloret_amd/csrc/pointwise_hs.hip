@@ -247,14 +247,15 @@ static int launch_s_pt(const PwArgs& a, int mode, int target_wgs, hipStream_t s)
 }
 
 // variant: 0 / 1 = one / two pixel tiles per wave with ~512 workgroups wanted, 2 / 3 = the same with ~1280.
-// Returns YR_ERR_UNSUPPORTED-like -1 (no launch, no error text) when the form does not take the op: the caller falls back.
+// Returns YR_NOT_TAKEN (pw_common.h: positive, distinct from every yr_status error; no launch, no error text) when the form
+// does not take the op: the caller falls back.  Real argument errors keep their negative codes and are propagated.
 int yr_pwhs_launch(int dtype, int variant, const PwArgs& a, hipStream_t s) {
     const int mode = (a.S.n == 1 && a.S.s[0].xform == YR_X_IDENTITY) ? (a.gate ? 2 : 1) : 0;
-    if (a.S.kp > 256 || a.dw_w != nullptr || (mode == 0 && a.gate) || !pwh_out_fits_rsrc(a)) return -1;
+    if (a.S.kp > 256 || a.dw_w != nullptr || (mode == 0 && a.gate) || !pwh_out_fits_rsrc(a)) return YR_NOT_TAKEN;
     for (int i = 0; i < YR_MAX_SRC; ++i)
-        if (a.S.s[i].xform == YR_X_MAXPOOL2 || a.S.s[i].xform == YR_X_MAXPOOL4) return -1;
+        if (a.S.s[i].xform == YR_X_MAXPOOL2 || a.S.s[i].xform == YR_X_MAXPOOL4) return YR_NOT_TAKEN;
     const int target = variant >= 2 ? 1280 : 512;
     if (dtype == YR_BF16) return (variant & 1) ? launch_s_pt<yr_bf16, 2>(a, mode, target, s) : launch_s_pt<yr_bf16, 1>(a, mode, target, s);
     if (dtype == YR_F16) return (variant & 1) ? launch_s_pt<yr_f16, 2>(a, mode, target, s) : launch_s_pt<yr_f16, 1>(a, mode, target, s);
-    return -1;
+    return YR_NOT_TAKEN;
 }

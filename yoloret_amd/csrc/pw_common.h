@@ -320,5 +320,8 @@ int yr_pw_launch_h(int dtype, int cfg, const PwArgs& a, hipStream_t s);
 int yr_pwh_num_cfgs();
 // its activation-stationary (pointwise_hs.hip) and all-couts k-streaming (pointwise_hq.hip) forms, variant 0..3 each;
 // -1: the form does not take this op (nothing launched, no error set)
+// what a form-specific launcher returns when the form does not take the op (the caller falls back to another form):
+// positive, so it cannot be mistaken for a yr_status error (YR_ERR_ARG is -1), which is propagated as it is
+#define YR_NOT_TAKEN 1
 int yr_pwhs_launch(int dtype, int variant, const PwArgs& a, hipStream_t s);
 int yr_pwhq_launch(int dtype, int variant, const PwArgs& a, hipStream_t s);

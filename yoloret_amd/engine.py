@@ -157,7 +157,9 @@ class Model:
         """ctx: execution context.  The plan handle is read-only during a forward; what a step owns is its WORKSPACE (the
         arena of intermediate tensors).  Calls with different `ctx` use different workspaces and may therefore be in
         flight at the same time on different HIP streams (pipeline.DetectionPipeline(depth=2)); calls with the same
-        `ctx` must be stream-ordered."""
+        `ctx` must be stream-ordered.  ctx 0 is the workspace of plain `model(x)` calls on the caller's stream;
+        DetectionPipeline(depth > 1) runs its contexts as ctx 1 .. depth, so a serial step on the same Model never shares an
+        arena with a step in flight on a context stream."""
         h, w, c = self.plan.input_shape
         want = rt.TORCH_DTYPE[self.plan.input_buf.dtype]       # float32, or uint8 for a model built on Input(dtype='uint8')
         if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == want):

@@ -25,14 +25,18 @@ class GatherHandle:
     (all_det [W*b,S,6], all_cnt [W*b]) - views of one of the gatherer's two result buffers, valid until the second
     start() after this one."""
 
-    def __init__(self, work, event, out, world, b, s, six, ready=None):
+    def __init__(self, work, event, out, world, b, s, six, ready=None, after=None):
         self._work, self._event, self._out = work, event, out
+        self._after = after              # single rank, records produced on another stream: what wait() must wait for
         self.released = None             # overlapped form: fires when the collective no longer reads the send buffer
         self._dims = (world, b, s, six)
         self._ready = ready              # single rank without a collective: the local (det, det_count) as they are
 
     def wait(self):
         if self._ready is not None:
+            if self._after is not None:
+                torch.cuda.current_stream(self._ready[0].device).wait_event(self._after)
+                self._after = None
             return self._ready
         if self._work is not None:
             self._work.wait()            # the current stream waits for the collective (no host block on GPU backends)
@@ -77,15 +81,21 @@ class DetectionGatherer:
             record = self._send
         return record, words
 
-    def start(self, det, det_count, record=None, overlap=True, after=None):
+    def start(self, det, det_count, record=None, overlap=True, after=None, pipeline=None):
         """det int32 [b, S, 6], det_count int32 [b] (local shard); `record`: the flat buffer both are views of
         (DetectionPipeline.record) - sent as is; without it the two tensors are first staged into one message.
         after: the event that marks the records complete when they were produced on ANOTHER stream than the current one
         (DetectionPipeline(depth > 1).done); default: everything enqueued on the current stream so far.  The handle's
-        `released` event (overlapped form) fires when the collective has read the records."""
+        `released` event (overlapped form) fires when the collective has read the records.  pipeline: the
+        DetectionPipeline(depth > 1) that produced them - its context is released with that event here (what
+        `pipeline.release(handle.released)` does by hand)."""
+        ctx = pipeline._last if pipeline is not None else None   # (the context of the step just issued, before anything else runs)
         b, s, six = det.shape
         if self.world == 1 and not self.always:
-            return GatherHandle(None, None, det, 1, b, s, six, ready=(det, det_count))
+            return GatherHandle(None, None, det, 1, b, s, six, ready=(det, det_count), after=after if det.is_cuda else None)
+        if after is not None and det.is_cuda and (record is None or record.numel() != b * s * six + b or not overlap):
+            # the staging copy of _message() and the plain collective run on the CURRENT stream: it must see complete records
+            torch.cuda.current_stream(det.device).wait_event(after)
         record, words = self._message(det, det_count, record)
         slot = self._slot
         self._slot ^= 1
@@ -112,6 +122,8 @@ class DetectionGatherer:
             done.record(self._stream)
         h = GatherHandle(None, done, out, self.world, b, s, six)
         h.released = done
+        if pipeline is not None:
+            pipeline.release(done, ctx)
         return h
 
     def __call__(self, det, det_count, record=None):

@@ -32,6 +32,9 @@ def _shared_stream(device, role):
     return st
 
 
+_PENDING = object()   # HostFeeder: a buffer handed out by take_raw() whose readers' completion event is not known yet
+
+
 class DetectionPipeline:
     def __init__(self, model, anchors, num_classes, num_scales=3, max_boxes=20, score_threshold=.2,
                  iou_threshold=.5, record_slots=1, depth=1):
@@ -48,7 +51,8 @@ class DetectionPipeline:
         once; its (det, det_count) are complete when `self.done` (an event on the context's stream) has fired:
         `wait()` makes the current stream wait for the newest step, consumers on other streams wait for `done`.  The
         caller keeps `x` / `image_hw` untouched until then.  A context's buffers are rewritten d calls later - a consumer
-        that needs them longer hands its own completion event to `release(event)` (the all-gather of parallel.py does)."""
+        that needs them longer hands its own completion event to `release(event, ctx)`: the caller does that, or passes
+        `pipeline=self` to DetectionGatherer.start(), which then releases the context behind its collective."""
         self.model = model
         self.anchors = np.ascontiguousarray(np.asarray(anchors, np.float32).reshape(-1, 2))
         self.num_classes, self.num_scales = int(num_classes), int(num_scales)
@@ -158,7 +162,7 @@ class DetectionPipeline:
                 x.record_stream(st)            # the caching allocator must not recycle the inputs while this stream reads them
                 image_hw.record_stream(st)
                 v = self._buffers(b, dev)
-                ys = self.model(x, out=v['ys'], ctx=k)
+                ys = self.model(x, out=v['ys'], ctx=k + 1)   # (never the bare workspace of stream-ordered callers on the caller's stream: Model.__call__)
                 if c['release'] is not None:   # a consumer (the all-gather) still reading this context's records: only the
                     st.wait_event(c['release'])   # post-processing rewrites them - the forward pass above does not wait
                     c['release'] = None
@@ -176,11 +180,17 @@ class DetectionPipeline:
         if self.done is not None:
             torch.cuda.current_stream().wait_event(self.done)
 
-    def release(self, event):
-        """`event`: when the consumer of the NEWEST step's records is finished with them; the context that produced them
-        waits for it before it runs again (depth calls from now)."""
+    def release(self, event, ctx=None):
+        """`event`: when the consumer of a step's records is finished with them; the context that produced them waits for
+        it before its post-processing runs again (depth calls later).  ctx: that context (`last_context` read right after
+        the step's call); default: the newest step's - only right before the next call of the pipeline."""
         if self.depth > 1:
-            self._ctx[self._last]['release'] = event
+            self._ctx[self._last if ctx is None else ctx]['release'] = event
+
+    @property
+    def last_context(self):
+        """The execution context (0 .. depth - 1) the newest step ran on: the `ctx` of release()."""
+        return self._last
 
     # ---- HIP-graph replay: the whole step (about 80 launches) is captured once per (batch, device) and replayed
     # as one graph launch.  It pays when the step is launch-bound, i.e. at small batches (batch-1 latency).
@@ -254,6 +264,9 @@ class HostFeeder:
         if self._head - self._tail >= len(self.dbuf):
             raise RuntimeError('HostFeeder.submit: all %d buffers hold batches that were not taken yet' % len(self.dbuf))
         s = self._head % len(self.dbuf)
+        if self.released[s] is _PENDING:
+            raise RuntimeError('HostFeeder.submit: buffer %d was handed out by take_raw() and never released - call '
+                               'mark_released(slot, event) with the event that marks its readers done' % s)
         with torch.cuda.stream(self.copy_stream):
             if self.released[s] is not None:
                 self.copy_stream.wait_event(self.released[s])    # the conversion that read this buffer last
@@ -275,6 +288,7 @@ class HostFeeder:
         s = self._tail % len(self.dbuf)
         torch.cuda.current_stream(self.device).wait_event(self.copied[s])
         self._tail += 1
+        self.released[s] = _PENDING       # submit() refuses the slot until mark_released() names the readers' event
         return self.dbuf[s], s
 
     def mark_released(self, slot, event=None):
