@@ -59,7 +59,70 @@ def parse():
                          'all-gather (one RCCL rank: depth 3 28.2k img/s against 28.3k without the collective, depth 2 26.9k)')
     ap.add_argument('--no-latency', action='store_true',
                     help='skip the batch-1 p50 loop (use under rocprofv3 so that every launch is a batch-%d launch)' % 64)
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the short runs of BASELINE.json configs 3, 4, 5 (and the SE EfficientNets) that the default 1-GPU run attaches as `other_configs`')
     return ap.parse_args()
+
+
+# BASELINE.json's other single-GPU workloads (the share of one GPU) and the reference's own
+# squeeze-excite EfficientNets beside the build-defined `-lite` forms.  `alg_mb`: SURVEY 8(d)'s conv-granular bytes per image.
+OTHER_CONFIGS = [
+    ('c3', 'efficientnetb0-lite', 416, 128, 'bf16'), ('c4', 'mobilenetv2x14', 512, 64, 'f32'), ('c5', 'efficientnetb3-lite', 640, 32, 'f16'),
+    ('c3_se', 'efficientnetb0', 416, 128, 'bf16'), ('c5_se', 'efficientnetb3', 640, 32, 'f16'),
+]
+
+
+def other_configs(dev, anchors, classes, steps, depth, budget_s=75.0):
+    """{name: {img_s (steps in flight), serial_img_s, roofline_step_frac, dtype, workload, ...}}: each configuration set up
+    exactly like the headline (same weight recipe, same pipeline, autotuned tile table), `steps` timed steps with `depth`
+    steps in flight and `steps` strictly serial ones.  Never `value`."""
+    from yoloret_amd import layers as L
+    from yoloret_amd import weights as W
+    from yoloret_amd.pipeline import DetectionPipeline
+    from yoloret_amd.yolo3.model import yolov3_body
+    res = {}
+    t_all = time.perf_counter()
+    for tag, name, size, b, dt in OTHER_CONFIGS:
+        if time.perf_counter() - t_all > budget_s:
+            res[tag] = {'skipped': 'time budget of %.0f s for the other configurations used up' % budget_s}
+            continue
+        t_cfg = time.perf_counter()
+        L.set_global_policy({'f32': 'float32', 'bf16': 'mixed_bfloat16', 'f16': 'mixed_float16'}[dt])
+        try:
+            m = yolov3_body(L.Input(shape=[size, size, 3]), name, 3, num_classes=classes)
+        finally:
+            L.set_global_policy('float32')
+        m.set_weights(W.synthetic_weights(m, 1234, 'survey'))
+        x = torch.from_numpy(W.synthetic_images(b, size, size, seed=20240416)).to(dev)
+        hw = torch.tensor([[size, size]] * b, dtype=torch.int32, device=dev)
+        out = {}
+        for d in (depth, 1):
+            pipe = DetectionPipeline(m, anchors, classes, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5, depth=d)
+            for _ in range(12):     # set-up (allocation, tile autotuning on the first call) + clocks
+                pipe(x, hw)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                pipe(x, hw)
+            torch.cuda.synchronize(dev)
+            out[d] = b * steps / (time.perf_counter() - t0)
+            del pipe
+        plan = m.plan
+        n_boxes = sum(3 * (size // s) ** 2 for s in (32, 16, 8))
+        alg_img = plan.algorithmic_bytes_per_image() + n_boxes * (classes + 5) * 4 + n_boxes * (4 + classes) * 4 + plan.weight_bytes() / b
+        res[tag] = {'img_s': round(out[depth], 1), 'serial_img_s': round(out[1], 1), 'steps': steps, 'steps_in_flight': depth,
+                    'roofline_step_frac': round(out[depth] * alg_img / (HBM_PEAK_GBS * 1e9), 4),
+                    'serial_roofline_step_frac': round(out[1] * alg_img / (HBM_PEAK_GBS * 1e9), 4),
+                    'hbm_roofline_img_s': round(HBM_PEAK_GBS * 1e9 / alg_img, 0), 'alg_bytes_per_image': int(alg_img),
+                    'dtype': dt, 'launches_per_step': len(plan.ops) + 4,
+                    'workload': '%s @%d, batch %d (one GPU\'s share), %s, C=%d, same recipe and pipeline as the headline' % (name, size, b, dt, classes),
+                    'setup_and_run_s': round(time.perf_counter() - t_cfg, 1)}
+        if dt != 'f32':   # (tests/test_gpu_narrow.py, tests/test_gpu_fullbatch.py: measured against the float32 oracle on the conditioned recipe)
+            res[tag]['accuracy_note'] = ('16-bit storage plan: logits are NOT within 1e-4 of the float32 reference - scaled max / mean logit error vs '
+                                         'the float32 oracle and the share of its detections reproduced are in README.md (16-bit plans) and profiles/')
+        del m, x, hw
+        torch.cuda.empty_cache()
+    return res
 
 
 def canon_symbol(name):
@@ -180,7 +243,8 @@ def main():
                              record_slots=2 if (use_dist and a.depth <= 1) else 1, depth=a.depth)
     # latency, ingestion and per-kernel measurements run strictly one step after the other
     pipe1 = pipe if a.depth <= 1 else DetectionPipeline(model, anchors, a.classes, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5)
-    gather = DetectionGatherer(always=a.force_dist)
+    gather = DetectionGatherer(always=a.force_dist, timing=use_dist)
+    timed_handles = []
     b = a.batch
     x = torch.from_numpy(W.synthetic_images(b, a.size, a.size, seed=20240416 + rank)).to(dev)
     image_hw = torch.tensor([[a.size, a.size]] * b, dtype=torch.int32, device=dev)
@@ -195,6 +259,8 @@ def main():
         det, cnt = pipe(x, image_hw)
         # (pipeline=pipe: the context that produced these records runs again only after the collective has read them)
         h = gather.start(det, cnt, pipe.record, after=pipe.done, pipeline=pipe)
+        if timed_handles is not None and use_dist:
+            timed_handles.append(h)
         prev, pending[0] = pending[0], h
         if prev is None:
             return None
@@ -230,6 +296,7 @@ def main():
     for _ in range(a.warmup):
         step()
     sync()
+    del timed_handles[:]      # (only the timed steps' collectives are kept)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -605,6 +672,16 @@ def main():
             out['rccl_ranks'] = world
             out['per_rank_img_s'] = [round(b * a.steps / v, 1) for v in per_rank]
             out['collective'] = 'one all_gather_into_tensor of the packed records per step, on a second stream (overlapped with the next forward)'
+            cms = [h.elapsed_ms() for h in timed_handles[:a.steps]]
+            cms = [v for v in cms if v is not None]
+            if cms:   # event pair around the collective on its own stream: what the exchange costs, not what the step waits for it
+                out['collective_ms_per_step'] = {'mean': round(float(np.mean(cms)), 4), 'p50': round(float(np.median(cms)), 4), 'max': round(float(np.max(cms)), 4),
+                                                 'bytes_per_rank': int(pipe.record.numel() * 4)}
+        from yoloret_amd.pipeline import hw_queue_check
+        out['hw_queues'] = hw_queue_check(dev)
+        if (world == 1 and not a.no_other_configs and not a.force_dist
+                and (a.model, a.size, a.batch, a.dtype) == ('mobilenetv2x75', 416, 64, 'f32')):
+            out['other_configs'] = other_configs(dev, anchors, a.classes, max(a.steps, 20), a.depth)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.model, a.size, a.classes, anchors, a.cpu_seconds)
     if use_dist:

@@ -273,13 +273,14 @@ STEM_MFMA_MAX_C1 = int(os.environ.get('YOLORET_STEM_MFMA_MAX_C1', '32'))
 
 
 # float32 plans: inverted-residual blocks on the row-walking register-chained matrix-pipe kernel (mbr.hip).  (cin, cexp, cout,
-# stride, residual) -> (waves per workgroup, row segments; 0 = the library's choice): the shapes built there and measured
+# stride, residual) -> (waves per workgroup, row segments; 0 = the library's choice[, largest output map in pixels]): the shapes built there and measured
 # ahead of what the plan would run otherwise (tools/mbr_probe.py, batch 64).  YOLORET_FUSE_MBR=0 switches it off,
 # YOLORET_MBR_BLOCKS="block_7,block_8" restricts it to the named blocks.
 FUSE_MBR = os.environ.get('YOLORET_FUSE_MBR', '1') != '0'
 MBR_BLOCKS = [b for b in os.environ.get('YOLORET_MBR_BLOCKS', '').split(',') if b]
 MBR_SHAPES = {
-    (24, 144, 48, 2, False): (3, 0),     # MobileNetV2 x0.75 block_6 (52 x 52 -> 26 x 26)
+    (24, 144, 48, 2, False): (3, 0),     # MobileNetV2 x0.75 block_6 (52 x 52 -> 26 x 26): 84 -> 46 us
+    (24, 144, 24, 1, True): (3, 0, 4096),   # block_4, 5 at 52 x 52 (66 -> 60 us); block_2 at 104 x 104 stays on the lane kernel (209 vs 240 us in the pipeline)
     (48, 288, 48, 1, True): (8, 0),      # block_7..9
     (48, 288, 72, 1, False): (8, 0),     # block_10
 }
@@ -813,11 +814,12 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
             key = (bi.c, d.cin, p.cout if p.kind == rt.OP_POINTWISE else 0, d.stride, p.res is not None)
             bname = exp.name.rsplit('_', 1)[0]
             if (key in MBR_SHAPES and (not MBR_BLOCKS or bname in MBR_BLOCKS) and p.kind == rt.OP_POINTWISE and plain1(p)
+                    and (len(MBR_SHAPES[key]) < 3 or p.h * p.w <= MBR_SHAPES[key][2])
                     and p.srcs[0].buf is d.out and p.act == 'none' and 'scale' in p.params and bi.xform == 'identity'
                     and bi.buf.ld % 4 == 0 and p.out.ld % 4 == 0 and bi.buf.dtype == 0 and p.out.dtype == 0
                     and (p.res is None or (p.res is bi.buf and d.stride == 1 and p.cout == bi.c))):
                 cin, cexp, cout = bi.c, d.cin, p.cout
-                nw, segs = MBR_SHAPES[key]
+                nw, segs = MBR_SHAPES[key][:2]
                 T, TO, KE = cexp // 16, (cout + 15) // 16, cin // 4
                 m = OpRec(rt.OP_MBR, bname + '_mbr', act='relu6', h=p.h, w=p.w, cin=cin, cout=cout, k=3 | nw << 8 | segs << 16,
                           stride=d.stride, se_reduced=cexp, srcs=[bi], out=p.out, res=p.res, macs=exp.macs + d.macs + p.macs, dtype=0)

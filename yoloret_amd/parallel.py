@@ -32,6 +32,14 @@ class GatherHandle:
         self._dims = (world, b, s, six)
         self._ready = ready              # single rank without a collective: the local (det, det_count) as they are
 
+    def elapsed_ms(self):
+        """Milliseconds the collective took on its stream (DetectionGatherer(timing=True), overlapped form; after the events
+        have fired - e.g. after a device synchronize); None otherwise."""
+        t0 = getattr(self, '_t0', None)
+        if t0 is None or self.released is None:
+            return None
+        return t0.elapsed_time(self.released)
+
     def wait(self):
         if self._ready is not None:
             if self._after is not None:
@@ -60,8 +68,10 @@ class DetectionGatherer:
     pipeline's record buffer, DetectionPipeline(record_slots=2)) and the result side are double buffered, so a step
     never overwrites bytes a collective in flight still reads or a consumer still holds."""
 
-    def __init__(self, group=None, always=False):
-        """always=True issues the collective even for a 1-rank group (exercises RCCL on a single GPU)."""
+    def __init__(self, group=None, always=False, timing=False):
+        """always=True issues the collective even for a 1-rank group (exercises RCCL on a single GPU).  timing=True: the
+        overlapped form brackets every collective with a timing event pair on ITS stream (GatherHandle.elapsed_ms())."""
+        self.timing = bool(timing)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.always = always and dist.is_initialized()
@@ -116,12 +126,17 @@ class DetectionGatherer:
             self._stream.wait_event(ready)
             record.record_stream(self._stream)
             out.record_stream(self._stream)
+            t0 = None
+            if self.timing:
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record(self._stream)
             work = dist.all_gather_into_tensor(out, record, group=self.group, async_op=True)
             work.wait()                                              # orders the side stream behind the collective
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(enable_timing=self.timing)
             done.record(self._stream)
         h = GatherHandle(None, done, out, self.world, b, s, six)
         h.released = done
+        h._t0 = t0
         if pipeline is not None:
             pipeline.release(done, ctx)
         return h

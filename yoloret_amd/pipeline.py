@@ -29,7 +29,33 @@ def _shared_stream(device, role):
         st = _STREAMS[key] = torch.cuda.Stream(device=device)
         with torch.cuda.stream(st):
             torch.zeros(1, device=device)
+        chk = hw_queue_check(device)
+        if not chk['ok']:
+            import warnings
+            warnings.warn('yoloret_amd: %d HIP streams of this package on %s (+ the default stream, + RCCL\'s own under a collective) '
+                          'share GPU_MAX_HW_QUEUES=%s hardware queues: streams that share a queue wait for each other (one RCCL rank, '
+                          'depth 3: 25.0k instead of 28.2k img/s).  Export GPU_MAX_HW_QUEUES=8 before the process makes its first HIP '
+                          'call (importing yoloret_amd first does it; a C-ABI host sets it itself: INTEGRATION.md 2).'
+                          % (chk['streams'], device, chk['queues_env'] or 'unset (runtime default 4)'), RuntimeWarning, stacklevel=3)
     return st
+
+
+def hw_queue_check(device=None):
+    """How many streams this package holds on `device` (all devices if None) against the hardware queues the HIP runtime was
+    told to use.  {'streams', 'queues', 'queues_env', 'ok'}: ok = the package's streams + the default stream + two for a
+    collective (the gather's side stream is counted, RCCL's internal one is not) fit the queues.  The environment variable is
+    what the runtime read IF it was set before the first HIP call - which cannot be verified from here, hence a self-check
+    and not a proof."""
+    import os
+    dev = None if device is None else torch.device(device)
+    idx = None if dev is None else (dev.index if dev.index is not None else torch.cuda.current_device())
+    n = sum(1 for k in _STREAMS if idx is None or k[1] == idx)
+    env = os.environ.get('GPU_MAX_HW_QUEUES')
+    try:
+        q = int(env) if env else 4
+    except ValueError:
+        q = 4
+    return {'streams': n, 'queues': q, 'queues_env': env, 'ok': n + 2 <= q}
 
 
 _PENDING = object()   # HostFeeder: a buffer handed out by take_raw() whose readers' completion event is not known yet
