@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define YR_ABI_VERSION 4   /* 4: YR_U8 images (uint8 network entry); 3: op kind MBX, pair-packed STEM weights, BN scale folded into the packed taps of STEMBLOCK / MBLANE */
+#define YR_ABI_VERSION 5   /* 5: op kinds MBR / MBE (float32 blocks on the matrix pipe, register-chained), MBCONV removed; 4: YR_U8 images (uint8 network entry); 3: op kind MBX, pair-packed STEM weights, BN scale folded into the packed taps of STEMBLOCK / MBLANE */
 #define YR_MAX_SRC 4
 
 typedef enum {
@@ -103,8 +103,8 @@ typedef enum {
                             sums [B][h*w][ld] to add up and divide by k (the depthwise SE form above) */
     YR_OP_WSUM = 6,      /* WeightedSum of 4 gathered sources          (model.py:117-137,157) */
     YR_OP_GATHER = 7,    /* materialise upsample/maxpool/concat        (standalone K5; testing / unfused use) */
-    YR_OP_MBCONV = 8,    /* fused inverted-residual block: expand 1x1+BN+act -> DW3x3+BN+act -> project 1x1+BN (+residual)
-                            (MobileNetV2 block_* [3P]; SE-free MBConv, efficientnet.py:467-536); the expanded tensor stays in LDS */
+    YR_OP_MBCONV = 8,    /* (removed in ABI 5: the float32 LDS-tiled block kernel; no shipped plan selected it since MBLANE, and MBR / MBE
+                            now take the blocks it was the fallback for.  The number stays reserved; yr_op_run returns YR_ERR_ARG) */
     YR_OP_STEMBLOCK = 9, /* fused network entry: stem Conv2D 3x3 s2 (Cin=3)+BN+act -> DW3x3 s1+BN+act -> project 1x1+BN
                             (MobileNetV2 Conv1 + expanded_conv block [3P]); se_reduced = stem width C1.  Parameters are packed
                             per channel PAIR (CP = round_up(C1,4)/2, COP = round_up(cout,8), zero padded; scale/shift unused):
@@ -157,6 +157,13 @@ typedef enum {
                             wgt2 = [T][11][16]: the nine depthwise taps (ky, kx) x depthwise BN scale | depthwise BN shift | expand BN shift;
                             b2   = project BN shift [16 TO].
                             Built for the MobileNetV2 x0.75 / x1.4 blocks (mbr.hip: MBR_CASE list); other shapes: YR_ERR_ARG */
+    YR_OP_MBE = 14,      /* the first two thirds of the MBCONV block in float32 - expand 1x1 + BN + ReLU6 -> depthwise 3x3 (stride 1 | 2) +
+                            BN + ReLU6 - in YR_OP_MBR's register-chained form (mbr.hip: mbe_kernel), for blocks whose weights do not fit
+                            one CU's register file (MobileNetV2 x0.75 block_11 on): every wave walks a strip segment for a few expanded
+                            tiles and stores the depthwise map; the expand output never exists, the projection stays a POINTWISE op.
+                            src[0] = block input (cin % 16 in {0, 8}); cout = Cexp (multiple of 16); k = 3 | segs << 16; act = RELU6;
+                            wgt = expand A fragments [T][KE][64] (YR_OP_MBR's register order, rho < KE); wgt2 = [T][11][16] as YR_OP_MBR.
+                            Built for cin in {48, 72, 88, 120, 136, 224} */
     YR_OP_MBX = 12       /* the first two thirds of an MBConv block WITH squeeze-excite (efficientnet.py:406-536), 16-bit
                             activations: expand 1x1 + BN + act (bf16 / f16 MFMA) -> depthwise K = 3 | 5, stride 1 | 2 + BN +
                             act, the expanded input of the depthwise conv staying in LDS; the depthwise map is stored and
@@ -196,10 +203,7 @@ typedef struct {
      *   STEM:      wgt = [27][round_up(cout,4)] ; scale/shift [round_up(cout,4)]
      *   SE_FC:     wgt = W1t[reduced][ldc], b1 [reduced], wgt2 = W2[reduced][ldc], b2 [ldc], ldc = round_up(c,4)
      *   WSUM:      wgt = alpha[4]
-     *   MBCONV:    se_reduced = expanded width Cexp, ldE = round_up(Cexp,4); wgt = expand Wt[Cexp][round_up(cin,4)]
-     *              (null: no expand stage), scale/shift = expand BN [ldE]; wgt2 = DW [9][ldE] ++ DW scale [ldE] ++
-     *              DW shift [ldE]; b1 = project Wt[cout][ldE]; b2 = project scale [ldo] ++ shift [ldo], ldo = round_up(cout,4);
-     *              res (optional) must alias src[0] (the residual is taken from the on-chip input tile) */
+     *   (the fused block ops document their packed layouts at their yr_op_kind above) */
     const float* wgt;    int64_t wgt_off;
     const float* scale;  int64_t scale_off;
     const float* shift;  int64_t shift_off;

@@ -154,8 +154,10 @@ def test_model_errors(dev):
 
 
 def test_unfused_plan_matches_fused(dev):
-    """The fused inverted-residual kernel and the unfused op chain agree (and both match the oracle)."""
+    """The fused inverted-residual kernels (lane-per-pixel front, register-chained matrix-pipe blocks, expand + depthwise) and
+    the unfused op chain agree (and both match the oracle)."""
     from yoloret_amd import layers as L
+    from yoloret_amd import runtime as rt
     from yoloret_amd.yolo3.model import yolov3_body
     import os
     hw = (96, 96)
@@ -174,7 +176,9 @@ def test_unfused_plan_matches_fused(dev):
             os.environ.pop('YOLORET_FUSE', None)
             compiler.FUSE_MAX_CIN, compiler.FUSE_MIN_PIXELS = saved
         kinds = set(o.kind for o in m.plan.ops)
-        assert (8 in kinds) == (fuse == '1')
+        fused_kinds = {rt.OP_STEMBLOCK, rt.OP_MBLANE, rt.OP_MBR, rt.OP_MBE}
+        # (at 96 x 96 the lane-per-pixel kernel's minimum map size keeps block_1..3 unfused: the matrix-pipe forms carry the test)
+        assert ({rt.OP_STEMBLOCK, rt.OP_MBR, rt.OP_MBE} <= kinds) if fuse == '1' else not (fused_kinds & kinds)
         m.set_weights(P.values)
         outs[fuse] = [y.cpu().numpy() for y in m(torch.from_numpy(x).to(dev))]
         for y, r in zip(outs[fuse], ref):

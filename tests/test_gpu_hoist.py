@@ -154,12 +154,12 @@ def test_depthwise_folded_into_project_is_bit_identical(dev, name, size):
     from yoloret_amd.yolo3.model import yolov3_body
     outs = {}
     for fold in (False, True):
-        saved = compiler.FOLD_DW
-        compiler.FOLD_DW = fold
+        saved = compiler.FOLD_DW, compiler.FUSE_MBR, compiler.FUSE_MBE
+        compiler.FOLD_DW, compiler.FUSE_MBR, compiler.FUSE_MBE = fold, False, False   # (the register-chained block kernels take the same blocks)
         try:
             m = yolov3_body(L.Input(shape=[size, size, 3]), name, 3, num_classes=20)
         finally:
-            compiler.FOLD_DW = saved
+            compiler.FOLD_DW, compiler.FUSE_MBR, compiler.FUSE_MBE = saved
         m.small_batch = 0
         folded = [o for o in m.plan.ops if o.kind == rt.OP_POINTWISE and o.srcs[0].xform == 'dw3']
         assert (len(folded) >= 5) == fold

@@ -75,3 +75,47 @@ def test_mbr(dev, case):
     rt.run_op(op, 2)
     torch.cuda.synchronize()
     assert_close(from_dev(out), ref, 5e-5, 'mbr %s' % (case,))
+
+
+MBE_CASES = [
+    # (h, w, cin, cexp, stride, segs): YR_OP_MBE = expand 1x1 + BN + ReLU6 -> depthwise 3x3 + BN + ReLU6, the map stored
+    (26, 26, 72, 432, 1, 0),      # MobileNetV2 x0.75 block_11, 12
+    (26, 26, 72, 432, 2, 0),      # block_13
+    (13, 13, 120, 720, 1, 0),     # block_14, 15 (cin = 112 + 8: the two-step tail chunk)
+    (13, 13, 120, 720, 1, 2),
+    (9, 21, 72, 112, 1, 1),       # ragged: 7 tiles = 2 full groups of 3 + a short one, two strips
+    (15, 11, 48, 288, 2, 3),      # odd sizes (pad 1 / 1), segments
+    (32, 32, 88, 528, 1, 0),      # MobileNetV2 x1.4 block_7..9
+    (16, 16, 224, 1344, 1, 0),    # x1.4 block_14, 15: 84 tiles, one per wave
+    (32, 32, 136, 816, 2, 0),     # x1.4 block_13
+]
+
+
+@pytest.mark.parametrize('case', MBE_CASES, ids=[str(i) for i in range(len(MBE_CASES))])
+def test_mbe(dev, case):
+    from yoloret_amd import runtime as rt
+    from yoloret_amd.compiler import mbr_pack
+    h, w, cin, cexp, s, segs = case
+    rng = np.random.default_rng(zlib.crc32(str(case).encode()))
+    b = 2
+    x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
+    we = (rng.standard_normal((cin, cexp)) * np.sqrt(2.0 / cin)).astype(np.float32)
+    se, he = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
+    wd = (rng.standard_normal((3, 3, cexp)) * np.sqrt(2.0 / 9)).astype(np.float32)
+    sd, hd = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
+    t = nn.relu6((nn.pointwise(x, we) * se + he).astype(np.float32))
+    ref = nn.relu6((nn.depthwise(t, wd, s, 'same') * sd + hd).astype(np.float32))
+    wa, tab, _ = mbr_pack(we.T, se, he, wd.reshape(9, cexp), sd, hd, None, None, None)
+    keep = [torch.from_numpy(np.ascontiguousarray(a).ravel()).to(dev) for a in (wa, tab)]
+    xd = to_dev(x, dev)
+    ho, wo = ref.shape[1], ref.shape[2]
+    op = rt.new_op(rt.OP_MBE, 'relu6')
+    op.dtype = op.out_dtype = rt.dtype_id('f32')
+    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc = ho, wo, cin, cexp, 3 | segs << 16, s, 1
+    op.src[0] = rt.make_src(xd, c=cin)
+    op.wgt, op.wgt2 = [k.data_ptr() for k in keep]
+    out = torch.full((b, ho, wo, cexp), float('nan'), dtype=torch.float32, device=dev)
+    op.out, op.out_ld = out.data_ptr(), cexp
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    assert_close(from_dev(out), ref, 5e-5, 'mbe %s' % (case,))

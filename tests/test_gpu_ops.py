@@ -331,64 +331,11 @@ def test_bad_arguments_report_errors(dev):
         rt.run_op(op, 1)
 
 
-MB_CASES = [
-    # (h, w, cin, cexp, cout, stride, residual, expand, act)
-    (16, 16, 16, 96, 24, 2, False, True, 'relu6'),     # MobileNetV2 block_1 shape
-    (13, 13, 24, 144, 24, 1, True, True, 'relu6'),     # block_2 (+add)
-    (20, 12, 24, 24, 16, 1, False, False, 'relu6'),    # block_0: no expand stage
-    (10, 10, 120, 720, 120, 1, True, True, 'relu6'),   # block_14/15: 15 chunks, 8 cout tiles
-    (9, 7, 72, 432, 120, 2, False, True, 'relu6'),     # odd size, stride 2 (pad 1/1), 4x8 tiles
-    (26, 26, 48, 288, 72, 1, False, True, 'relu6'),    # block_10
-    (12, 16, 40, 240, 40, 1, True, True, 'swish'),     # SE-free MBConv flavour (lite variants)
-    (8, 8, 16, 100, 20, 1, False, True, 'relu6'),      # expanded width not a multiple of 48 / 16
-]
-
-
-@pytest.mark.parametrize('case', MB_CASES, ids=[str(i) for i in range(len(MB_CASES))])
-def test_mbconv_fused(dev, case):
-    """Fused expand+DW+project block == the three oracle ops composed."""
+def test_removed_op_kind_is_refused(dev):
+    """YR_OP_MBCONV (8) was removed in ABI 5 (mbconv.hip: no shipped plan selected it; YR_OP_MBR / MBE / MBLANE take its blocks):
+    the number stays reserved and the C-ABI says so instead of crashing."""
     rt = _rt()
-    h, w, cin, cexp, cout, s, residual, expand, act = case
-    rng = np.random.default_rng(zlib.crc32(str(case).encode()))
-    b = 2
-    x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
-    t = x
-    if expand:
-        we = (rng.standard_normal((cin, cexp)) * np.sqrt(2.0 / cin)).astype(np.float32)
-        se, he = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
-        t = _act_np((nn.pointwise(t, we) * se + he).astype(np.float32), act)
-    wd = (rng.standard_normal((3, 3, cexp)) * np.sqrt(2.0 / 9)).astype(np.float32)
-    sd, hd = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
-    t = _act_np((nn.depthwise(t, wd, s, 'same') * sd + hd).astype(np.float32), act)
-    wp = (rng.standard_normal((cexp, cout)) * np.sqrt(1.0 / cexp)).astype(np.float32)
-    sp, hp = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.3, cout).astype(np.float32)
-    ref = (nn.pointwise(t, wp) * sp + hp).astype(np.float32)
-    if residual:
-        ref = ref + x
-    lde, ldo, kpi = round_up(cexp, 4), round_up(cout, 4), round_up(cin, 4)
-    xd = to_dev(x, dev)
-    keep = []
-    op = rt.new_op(rt.OP_MBCONV, act)
-    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc, op.se_reduced = ref.shape[1], ref.shape[2], cin, cout, 3, s, 1, cexp
-    op.src[0] = rt.make_src(xd, c=cin)
-    if expand:
-        wet = np.zeros((cexp, kpi), np.float32)
-        wet[:, :cin] = we.T
-        keep += [_dev_vec(wet, dev), _dev_vec(se, dev, lde), _dev_vec(he, dev, lde)]
-        op.wgt, op.scale, op.shift = [k.data_ptr() for k in keep[-3:]]
-    dwp = np.zeros((11, lde), np.float32)
-    dwp[:9, :cexp] = wd.reshape(9, cexp)
-    dwp[9, :cexp], dwp[10, :cexp] = sd, hd
-    wpt = np.zeros((cout, lde), np.float32)
-    wpt[:, :cexp] = wp.T
-    pb = np.zeros((2, ldo), np.float32)
-    pb[0, :cout], pb[1, :cout] = sp, hp
-    keep += [_dev_vec(dwp, dev), _dev_vec(wpt, dev), _dev_vec(pb, dev)]
-    op.wgt2, op.b1, op.b2 = [k.data_ptr() for k in keep[-3:]]
-    if residual:
-        op.res, op.res_ld = xd.data_ptr(), xd.shape[3]
-    out = torch.full((b, ref.shape[1], ref.shape[2], ldo), float('nan'), dtype=torch.float32, device=dev)
-    op.out, op.out_ld = out.data_ptr(), ldo
-    rt.run_op(op, b)
-    torch.cuda.synchronize()
-    assert_close(from_dev(out, cout), ref, 5e-5, 'mbconv %s' % (case,))
+    op = rt.new_op(rt.OP_MBCONV)
+    op.nsrc = 1
+    rc = rt.lib().yr_op_run(ctypes.byref(op), 1, None)
+    assert rc == -1 and b'removed in ABI 5' in rt.lib().yr_last_error()

@@ -28,10 +28,10 @@ def test_macs_match_survey(name, size, macs_m):
 
 def test_plan_structure_and_accounting():
     from yoloret_amd import compiler, runtime as rt
-    knobs = ('FUSE_MAX_CIN', 'FUSE_STEM', 'HOIST_UPSAMPLE', 'POOL_IN_PRODUCER', 'MERGE_SE_MEAN', 'FOLD_DW', 'FUSE_MBR', 'FOLD_PROJ')
+    knobs = ('FUSE_MAX_CIN', 'FUSE_STEM', 'HOIST_UPSAMPLE', 'POOL_IN_PRODUCER', 'MERGE_SE_MEAN', 'FOLD_DW', 'FUSE_MBR', 'FOLD_PROJ', 'FUSE_MBE')
     saved = [getattr(compiler, k) for k in knobs]
     try:
-        for k, v in zip(knobs, (0, False, False, False, False, False, False, False)):   # every rewrite off: the plan = SURVEY.md Appendix B rows
+        for k, v in zip(knobs, (0, False, False, False, False, False, False, False, False)):   # every rewrite off: the plan = SURVEY.md Appendix B rows
             setattr(compiler, k, v)
         p = _model().plan
     finally:
@@ -62,6 +62,7 @@ def test_fold_depthwise_plan_keeps_the_accounting():
     from yoloret_amd.weights import synthetic_weights
     saved = compiler.FOLD_DW, compiler.FUSE_MBR
     compiler.FOLD_DW, compiler.FUSE_MBR = True, False   # (an alternative to fusing the same blocks into one kernel)
+    saved_mbe, compiler.FUSE_MBE = compiler.FUSE_MBE, False
     try:
         compiler.FOLD_DW = saved[0]
         base = _model().plan
@@ -69,6 +70,7 @@ def test_fold_depthwise_plan_keeps_the_accounting():
         fm = _model()
     finally:
         compiler.FOLD_DW, compiler.FUSE_MBR = saved
+        compiler.FUSE_MBE = saved_mbe
     p = fm.plan
     folded = [o for o in p.ops if o.kind == rt.OP_POINTWISE and o.srcs[0].xform == 'dw3']
     assert [o.name for o in folded] == ['block_%d_project' % i for i in range(7, 16)]   # block_16: cout 240 > one tile
@@ -233,7 +235,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
         assert hasattr(L, sym), 'libyoloret_hip.so does not export %s' % sym
     assert declared == set(rt.EXPORTS)
     L.yr_abi_version.restype = ctypes.c_int
-    assert L.yr_abi_version() == 4 == rt.ABI_VERSION
+    assert L.yr_abi_version() == 5 == rt.ABI_VERSION
     # struct layouts agree with the header's (the library reports its own sizeof)
     for which, st in enumerate((rt.YrSrc, rt.YrOp, rt.YrBuf)):
         assert L.yr_abi_sizeof(which) == ctypes.sizeof(st), st.__name__
@@ -260,7 +262,6 @@ SCRATCH_ALLOWED = {
     '_Z16mblane_s1_kernel': 104,   # 16-bit instantiations: output staging
     '_Z16mblane_s2_kernel': 104,
     '_Z15nms_band_kernel': 200,    # the per-lane score list of the band-wise NMS
-    '_Z13mbconv_kernelILi16ELi16ELi1ELi2E': 156,   # float32 fallback block kernel (one shape)
     '_Z10pwh_kernelIDF16_Li4ELi1ELi2ELi2E': 68,    # f16 direct form, four pixel tiles, gated source
 }
 

@@ -287,6 +287,12 @@ MBR_SHAPES = {
 if os.environ.get('YOLORET_MBR_ALL', '0') != '0':   # (experiments: every shape mbr.hip is built for)
     MBR_SHAPES.update({(16, 96, 24, 2, False): (2, 0), (24, 144, 24, 1, True): (3, 0), (24, 144, 24, 2, False): (3, 0),
                        (24, 144, 32, 2, False): (3, 0), (32, 192, 32, 1, True): (4, 0), (32, 192, 48, 2, False): (4, 0)})
+# float32 plans, blocks too wide for mbr.hip's one-workgroup form: expand + depthwise in one register-chained kernel (YR_OP_MBE),
+# the projection stays a pointwise op.  Block input widths built in mbr.hip (MBE_CASE).
+FUSE_MBE = os.environ.get('YOLORET_FUSE_MBE', '1') != '0'
+# (measured, MobileNetV2 x0.75 @416 batch 64: block_11 / 12 85 -> 60 us, block_13 67 -> 56 us; the 13 x 13 blocks (120 inputs) tie
+# at 53 us and stay unfused)
+MBE_CINS = set(int(v) for v in os.environ.get('YOLORET_MBE_CINS', '72').split(',') if v)
 FUSE_MBH = os.environ.get('YOLORET_FUSE_MBH', '1') != '0'   # 16-bit plans: inverted-residual blocks on the MFMA block kernel (mbh.hip)
 MBH_LANE_MIN_PIXELS = int(os.environ.get('YOLORET_MBH_LANE_MIN_PIXELS', '10000'))
 MBH_LANE_MAX_CIN = int(os.environ.get('YOLORET_MBH_LANE_MAX_CIN', '16'))
@@ -619,7 +625,10 @@ def mbr_pack(we_t, e_scale, e_shift, dw, d_scale, d_shift, wp_t, p_scale, p_shif
     convolutions in REGISTER order (one coalesced dword load per register), BN scales folded in.
     we_t [cexp][>=cin] expand (pointwise layout), dw [9][>=cexp] depthwise taps, wp_t [cout][>=cexp] project; BN vectors per layer.
     -> (wgt [T][KE + 4 TO][64], wgt2 [T][11][16], b2 [16 TO]) float32."""
-    cexp, cout = dw.shape[1] // 16 * 16, wp_t.shape[0]
+    cexp = dw.shape[1] // 16 * 16
+    if wp_t is None:     # YR_OP_MBE: expand + depthwise only
+        wp_t, p_scale, p_shift = np.zeros((0, cexp), np.float32), np.zeros(0, np.float32), np.zeros(0, np.float32)
+    cout = wp_t.shape[0]
     cin = we_t.shape[1] // 8 * 8
     assert dw.shape[1] >= cexp and cexp % 16 == 0 and cin % 16 in (0, 8), (dw.shape, we_t.shape)
     T, TO, KE, nmain = cexp // 16, (cout + 15) // 16, cin // 4, cin // 16
@@ -835,6 +844,28 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                 out.append(m)
                 i = j + 2
                 continue
+        if (FUSE_MBE and dtype == 0 and blocks and exp is not None and d is not None and d.kind == rt.OP_DEPTHWISE and d.k == 3
+                and d.stride in (1, 2) and plain1(d) and d.gate is None and d.srcs[0].buf is exp.out and d.act == exp.act == 'relu6'
+                and exp.srcs[0].c in MBE_CINS and d.cin % 16 == 0 and d.cin * 11 * 4 <= 64 * 1024 and exp.srcs[0].xform == 'identity'
+                and exp.srcs[0].buf.ld % 4 == 0 and d.out.ld % 4 == 0 and exp.srcs[0].buf.dtype == 0 and d.out.dtype == 0
+                and d.out.ld == round_up(d.cin, 4)):
+            bi, cexp = exp.srcs[0], d.cin
+            T, KE = cexp // 16, bi.c // 4
+            m = OpRec(rt.OP_MBE, exp.name.rsplit('_', 1)[0] + '_mbe', act='relu6', h=d.h, w=d.w, cin=bi.c, cout=cexp, k=3, stride=d.stride,
+                      srcs=[bi], out=d.out, macs=exp.macs + d.macs, dtype=0)
+            m.fused = [exp, d]
+            ep, dp = exp.params, d.params
+
+            def packed_e(which, ep=ep, dp=dp):
+                def f(wd):
+                    wa, tab, _ = mbr_pack(ep['wgt'][1](wd), ep['scale'][1](wd), ep['shift'][1](wd), dp['wgt'][1](wd).reshape(9, -1),
+                                          dp['scale'][1](wd), dp['shift'][1](wd), None, None, None)
+                    return wa if which == 0 else tab
+                return f
+            m.params = {'wgt': ((T, KE, 64), packed_e(0)), 'wgt2': ((T, 11, 16), packed_e(1))}
+            out.append(m)
+            i = j + 1
+            continue
         mbh = None
         if (FUSE_MBH and dtype != 0 and blocks and exp is not None and d is not None and d.kind == rt.OP_DEPTHWISE and d.k in (3, 5)
                 and d.stride in (1, 2) and '%d%d' % (d.k, d.stride) not in MBH_SKIP and not (d.k == 5 and d.stride == 1 and (d.cin > MBH_K5_MAX_CEXP or (d.cin > MBH_K5_SMALL_CEXP and d.h * d.w <= MBH_K5_SMALL_MAP))) and not (d.k == 3 and d.stride == 1 and d.cin > MBH_K3_MAX_CEXP) and plain1(d) and private(d.out) and d.srcs[0].buf is exp.out and d.act == exp.act
@@ -940,7 +971,7 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
             p = ops[j + 1]
             block_in = exp.srcs[0] if exp is not None else d.srcs[0]
             lane = lane_ok(exp, block_in, p, d)
-            if ((lane or dtype == 0) and p.kind == rt.OP_POINTWISE and plain1(p) and p.srcs[0].buf is d.out and p.act == 'none'
+            if (lane and p.kind == rt.OP_POINTWISE and plain1(p) and p.srcs[0].buf is d.out and p.act == 'none'
                     and 'scale' in p.params and p.cout <= 224 and block_in.buf.ld % 4 == 0
                     and (exp is not None or FUSE_NO_EXPAND or lane) and block_in.c <= max_cin
                     and p.h * p.w >= (FUSE_LANE_MIN_PIXELS if lane else FUSE_MIN_PIXELS)
@@ -953,7 +984,7 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
         block_in = exp.srcs[0] if exp is not None else dw.srcs[0]
         cexp, cout = dw.cin, proj.cout
         lde, ldo = round_up(cexp, 4), round_up(cout, 4)
-        m = OpRec(rt.OP_MBCONV, (exp or dw).name.rsplit('_', 1)[0] + '_mbconv', act=dw.act, h=proj.h, w=proj.w,
+        m = OpRec(rt.OP_MBLANE, (exp or dw).name.rsplit('_', 1)[0] + '_mblane', act=dw.act, h=proj.h, w=proj.w,
                   cin=block_in.c, cout=cout, k=3, stride=dw.stride, se_reduced=cexp, srcs=[block_in], out=proj.out,
                   res=proj.res, macs=(exp.macs if exp else 0) + dw.macs + proj.macs, dtype=dtype)
         m.fused = [o for o in (exp, dw, proj) if o is not None]
@@ -967,7 +998,6 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
         cinp, cop = round_up(block_in.c, 4), round_up(cout, 8)
         if lane_ok(exp, block_in, proj, dw):
             # lane-per-pixel formulation (mblane.hip): everything packed per expanded-channel pair
-            m.kind, m.name = rt.OP_MBLANE, m.name.replace('_mbconv', '_mblane')
             npair = round_up((cexp + 1) // 2, 8)
             e2 = 2 * npair
 
@@ -999,19 +1029,7 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
             out.append(m)
             i = j + 2
             continue
-        if exp is not None:
-            m.params['wgt'] = exp.params['wgt']
-            m.params['scale'] = ((lde,), padded(exp.params['scale'][1], cexp, lde))
-            m.params['shift'] = ((lde,), padded(exp.params['shift'][1], cexp, lde))
-        dwp = dw.params
-        m.params['wgt2'] = ((11 * lde,), lambda wd, dwp=dwp: np.concatenate(
-            [dwp['wgt'][1](wd).ravel(), dwp['scale'][1](wd), dwp['shift'][1](wd)]))
-        m.params['b1'] = proj.params['wgt']
-        pp_ = proj.params
-        m.params['b2'] = ((2 * ldo,), lambda wd, pp_=pp_, cout=cout, ldo=ldo: np.concatenate(
-            [padded(pp_['scale'][1], cout, ldo)(wd), padded(pp_['shift'][1], cout, ldo)(wd)]))
-        out.append(m)
-        i = j + 2
+        raise AssertionError('a fused float32 block that the lane-per-pixel kernel does not take (mbconv.hip was removed)')
     return out
 
 

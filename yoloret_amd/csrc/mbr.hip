@@ -305,6 +305,196 @@ static int launch_mbr(const MbrArgs& a0, int batch, int want_segs, hipStream_t s
     return YR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// YR_OP_MBE: the first two thirds of the block - expand 1x1 + BN + ReLU6 -> depthwise 3x3 + BN + ReLU6 - in the same
+// register-chained form, for blocks whose three A-fragment sets do not fit one CU's register file (MobileNetV2 x0.75 block_11
+// on: 72 -> 432 -> 72 and wider).  Without the projection nothing couples the expanded channels: every WAVE is on its own - a
+// strip segment x NT expanded tiles - and the depthwise map is stored (16 bytes per lane and tile); the projection stays a
+// pointwise op.  The 6x-wide EXPAND output (written once, read once: half of the unfused chain's bytes) never exists.
+struct MbeArgs {
+    const float* x; float* out;
+    const float* wa;   // expand A fragments [T][KE][64]
+    const float* wt;   // [T][11][16]: depthwise taps x BN scale | depthwise BN shift | expand BN shift
+    int H, W, Ho, Wo, ld_in, ld_out, pad_t, pad_l, strips, segs, seg_rows, T, groups, nwaves;
+};
+
+template <int CIN, int S, int NT, int MW>
+__global__ __launch_bounds__(256, MW) void mbe_kernel(MbeArgs a) {
+    constexpr int NMAIN = CIN / 16, TAIL = CIN % 16, KE = NMAIN * 4 + TAIL / 4, NOUT = 14 / S;
+    static_assert(TAIL == 0 || TAIL == 8, "block input width must be 16 n or 16 n + 8");
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float tab[];
+    for (int i = threadIdx.x; i < a.T * MBR_TAB; i += 256) tab[i] = a.wt[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, px = lane & 15, mg = lane >> 4;
+    int gw = (int)yr_xcd_swizzle(blockIdx.x, gridDim.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (gw >= a.nwaves) return;
+    const int g = gw % a.groups; gw /= a.groups;      // (the tile groups of one strip segment are neighbours: same pixels, L1 / L2)
+    const int seg = gw % a.segs; gw /= a.segs;
+    const int strip = gw % a.strips;
+    const int b = gw / a.strips;
+    const int t0 = g * NT;
+    const int yo0 = seg * a.seg_rows, yo1 = min(yo0 + a.seg_rows, a.Ho);
+    const int xin = S * NOUT * strip - a.pad_l + px;
+    const int xc = min(max(xin, 0), a.W - 1);
+    const float hi = (xin >= 0 && xin < a.W) ? 6.f : 0.f;
+    const int xo = NOUT * strip + (px - 1) / S;
+    const bool out_lane = px >= 1 && px <= 14 && (px - 1) % S == 0 && xo < a.Wo;
+
+    float we[NT][KE];
+    v4f se[NT];
+    unsigned ooff[NT];   // byte offset of this lane's 4 channels of tile j within a pixel, or dead
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int t = min(t0 + j, a.T - 1);           // (a short last group recomputes the last tile; its stores are dead)
+        const float* p = a.wa + ((size_t)t * KE) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < KE; ++q) we[j][q] = p[q * 64];
+        se[j] = *reinterpret_cast<const v4f*>(a.wt + (size_t)t * MBR_TAB + 160 + 4 * mg);
+        ooff[j] = (t0 + j < a.T && out_lane) ? (16u * (t0 + j) + 4u * mg) * 4u : MBR_DEAD;
+    }
+    const mbr_rsrc xsrc = mbr_make_rsrc(a.x + (size_t)b * a.H * a.W * a.ld_in, (unsigned)(a.H * a.W * a.ld_in) * 4u);
+    const mbr_rsrc osrc = mbr_make_rsrc(a.out + (size_t)b * a.Ho * a.Wo * a.ld_out, (unsigned)(a.Ho * a.Wo * a.ld_out) * 4u);
+    const int rbeg = S * yo0 - a.pad_t, nout = yo1 - yo0;
+    const unsigned xoff = ((unsigned)xc * (unsigned)a.ld_in + 4u * mg) * 4u, xtoff = ((unsigned)xc * (unsigned)a.ld_in + 16u * NMAIN + 2u * mg) * 4u;
+    const unsigned xrow = (unsigned)(a.W * a.ld_in) * 4u;
+    struct XRow { v4f m[NMAIN > 0 ? NMAIN : 1]; v2f t; };
+    XRow xa, xb;
+    auto load_row = [&](XRow& x, int r) {
+        const unsigned so = (unsigned)min(max(r, 0), a.H - 1) * xrow;
+#pragma unroll
+        for (int c = 0; c < NMAIN; ++c) x.m[c] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff + 64u * c, so, 0));
+        if constexpr (TAIL != 0) x.t = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(xsrc, xtoff, so, 0));
+    };
+    load_row(xa, rbeg);
+    v4f ea[NT], eb[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { ea[j] = (v4f){0.f, 0.f, 0.f, 0.f}; eb[j] = ea[j]; }
+
+    auto row = [&](auto emit_c, const int k, const int yo, const XRow& xc_, XRow& xn_) {
+        constexpr bool EMIT = decltype(emit_c)::value;
+        const int r = rbeg + k;
+        load_row(xn_, r + 1);
+        float xq[KE];
+#pragma unroll
+        for (int c = 0; c < NMAIN; ++c) { xq[4 * c] = xc_.m[c][0]; xq[4 * c + 1] = xc_.m[c][1]; xq[4 * c + 2] = xc_.m[c][2]; xq[4 * c + 3] = xc_.m[c][3]; }
+        if constexpr (TAIL != 0) { xq[4 * NMAIN] = xc_.t[0]; xq[4 * NMAIN + 1] = xc_.t[1]; }
+        const float hr = (r >= 0 && r < a.H) ? hi : 0.f;
+        v4f ec[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) ec[j] = se[j];
+#pragma unroll
+        for (int q = 0; q < KE; ++q)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ec[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(we[j][q], xq[q], ec[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ec[j][i] = __builtin_amdgcn_fmed3f(ec[j][i], 0.f, hr);
+        if constexpr (EMIT) {
+            const unsigned opix = ((unsigned)yo * (unsigned)a.Wo + (unsigned)xo) * (unsigned)a.ld_out * 4u;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const v4f* tb = reinterpret_cast<const v4f*>(tab + min(t0 + j, a.T - 1) * MBR_TAB) + mg;
+                v4f d = tb[36];
+                mbr_dw_row(d, ea[j], tb[0], tb[4], tb[8]);
+                mbr_dw_row(d, eb[j], tb[12], tb[16], tb[20]);
+                mbr_dw_row(d, ec[j], tb[24], tb[28], tb[32]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[i] = __builtin_amdgcn_fmed3f(d[i], 0.f, 6.f);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, d), osrc, ooff[j] == MBR_DEAD ? MBR_DEAD : opix + ooff[j], 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { ea[j] = eb[j]; eb[j] = ec[j]; }
+    };
+    constexpr std::true_type Y{};
+    constexpr std::false_type N{};
+    if constexpr (S == 2) {
+        row(N, 0, 0, xa, xb);
+        for (int i = 0; i < nout; ++i) {
+            row(N, 2 * i + 1, 0, xb, xa);
+            row(Y, 2 * i + 2, yo0 + i, xa, xb);
+        }
+    } else {
+        row(N, 0, 0, xa, xb);
+        row(N, 1, 0, xb, xa);
+        int i = 0;
+        for (; i + 1 < nout; i += 2) {
+            row(Y, i + 2, yo0 + i, xa, xb);
+            row(Y, i + 3, yo0 + i + 1, xb, xa);
+        }
+        if (i < nout) row(Y, i + 2, yo0 + i, xa, xb);
+    }
+}
+
+template <int CIN, int S, int NT>
+static int launch_mbe(const MbeArgs& a0, int batch, int want_segs, hipStream_t s) {
+    MbeArgs a = a0;
+    constexpr int NOUT = 14 / S, KE = CIN / 4;
+    constexpr int EST = NT * (KE + 16) + 2 * KE + 44;      // registers a wave holds (stationary fragments, ring, two rows of pixels, ~44 others)
+    constexpr int MW = EST <= 150 ? 3 : EST <= 250 ? 2 : 1;
+    a.strips = (a.Wo + NOUT - 1) / NOUT;
+    a.groups = (a.T + NT - 1) / NT;
+    const int walks = batch * a.strips * a.groups;             // waves at one segment per strip
+    int segs = (3 * 1024 + walks - 1) / walks;                 // ~3 waves per SIMD of the chip
+    const int max_segs = (a.Ho + 5) / 6;
+    if (segs > max_segs) segs = max_segs;
+    if (segs < 1) segs = 1;
+    if (want_segs > 0) segs = want_segs < a.Ho ? want_segs : a.Ho;
+    a.seg_rows = (a.Ho + segs - 1) / segs;
+    a.segs = (a.Ho + a.seg_rows - 1) / a.seg_rows;
+    a.nwaves = batch * a.strips * a.segs * a.groups;
+    const size_t lds = (size_t)a.T * MBR_TAB * 4;
+    YR_REQUIRE(lds <= 64 * 1024, "mbe: %d expanded channels exceed the depthwise table's LDS budget", a.T * 16);
+    static char nm[48];
+    static const int nm_len = snprintf(nm, sizeof(nm), "mbe_kernel<%d,%d,%d,%d>", CIN, S, NT, MW);
+    (void)nm_len;
+    yr_note_kernel(nm);
+    auto kern = mbe_kernel<CIN, S, NT, MW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        YR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.nwaves + 3) / 4)), dim3(256), lds, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
+// op fields: src[0] = block input (float32, c % 16 in {0, 8}); cout = Cexp = width of the stored depthwise map (multiple of 16);
+// k = 3 | segs << 16; stride 1 | 2; act = ReLU6 (both activations).  wgt = expand A fragments [T][KE][64] (register order of
+// YR_OP_MBR, rho < KE); wgt2 = [T][11][16] as YR_OP_MBR.
+int yr_launch_mbe(const yr_op& op, int batch, hipStream_t s) {
+    YR_REQUIRE(op.dtype == YR_F32 && op.out_dtype == YR_F32, "mbe: float32 plans only");
+    YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY && op.src[0].dtype == YR_F32, "mbe: needs one float32 identity source");
+    const yr_src& in = op.src[0];
+    YR_REQUIRE((op.k & 0xff) == 3 && (op.stride == 1 || op.stride == 2) && op.act == YR_ACT_RELU6, "mbe: 3x3, stride 1|2, ReLU6");
+    YR_REQUIRE(in.ptr && op.out && op.wgt && op.wgt2 && op.res == nullptr, "mbe: null pointer (or a residual)");
+    YR_REQUIRE(in.ld % 4 == 0 && op.out_ld % 4 == 0 && in.c == op.cin && in.ld >= in.c && op.out_ld >= op.cout && op.cout % 16 == 0, "mbe: channel strides / widths");
+    YR_REQUIRE(((uintptr_t)in.ptr) % 16 == 0 && ((uintptr_t)op.out) % 16 == 0, "mbe: pointers must be 16-byte aligned");
+    MbeArgs a;
+    a.x = (const float*)in.ptr; a.out = (float*)op.out; a.wa = op.wgt; a.wt = op.wgt2;
+    a.H = in.h; a.W = in.w; a.Ho = (in.h + op.stride - 1) / op.stride; a.Wo = (in.w + op.stride - 1) / op.stride;
+    YR_REQUIRE(a.Ho == op.h && a.Wo == op.w, "mbe: output dims mismatch");
+    a.ld_in = in.ld; a.ld_out = op.out_ld; a.T = op.cout / 16;
+    const int pth = (a.Ho - 1) * op.stride + 3 - in.h, ptw = (a.Wo - 1) * op.stride + 3 - in.w;
+    a.pad_t = (pth > 0 ? pth : 0) / 2; a.pad_l = (ptw > 0 ? ptw : 0) / 2;
+    a.strips = a.segs = a.seg_rows = a.groups = a.nwaves = 0;
+    const int segs = (op.k >> 16) & 0xff;
+#define MBE_CASE(CIN, NT)                                                                     \
+    if (in.c == CIN) return op.stride == 1 ? launch_mbe<CIN, 1, NT>(a, batch, segs, s) : launch_mbe<CIN, 2, NT>(a, batch, segs, s);
+    MBE_CASE(48, 3)
+    MBE_CASE(72, 3)      // MobileNetV2 x0.75 block_11..13
+    MBE_CASE(88, 2)      // x1.4 block_7..10
+    MBE_CASE(120, 2)     // x0.75 block_14, 15
+    MBE_CASE(136, 2)     // x1.4 block_11..13
+    MBE_CASE(224, 1)     // x1.4 block_14, 15
+#undef MBE_CASE
+    yr_set_error("mbe: block input width %d is not built", in.c);
+    return YR_ERR_ARG;
+}
+
 // op fields: src[0] = block input (float32, c % 8 == 0, c % 16 in {0, 8}); se_reduced = Cexp (multiple of 16); k = 3 | nw << 8 | segs << 16
 // (nw: waves per workgroup, segs: row segments per strip; 0 = the library's choice); stride 1 | 2; act = ReLU6; res (optional) = the block input.  Parameters (float32):
 //   wgt  = A fragments [T = Cexp/16][KE + 4 TO][64]: register rho of lane (m = l % 16, g = l / 16) of tile j:

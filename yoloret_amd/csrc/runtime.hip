@@ -39,11 +39,12 @@ static int dispatch(const yr_op& op, int batch, hipStream_t s) {
         case YR_OP_SE_FC: return yr_launch_se_fc(op, batch, s);
         case YR_OP_WSUM: return yr_launch_wsum(op, batch, s);
         case YR_OP_GATHER: return yr_launch_gather(op, batch, s);
-        case YR_OP_MBCONV: return yr_launch_mbconv(op, batch, s);
+        case YR_OP_MBCONV: yr_set_error("YR_OP_MBCONV (8) was removed in ABI 5: superseded by YR_OP_MBR / YR_OP_MBE (matrix pipe) and YR_OP_MBLANE"); return YR_ERR_ARG;
         case YR_OP_STEMBLOCK: return yr_launch_stemblock(op, batch, s);
         case YR_OP_MBLANE: return yr_launch_mblane(op, batch, s);
         case YR_OP_MBH: case YR_OP_MBX: return yr_launch_mbh(op, batch, s);
         case YR_OP_MBR: return yr_launch_mbr(op, batch, s);
+        case YR_OP_MBE: return yr_launch_mbe(op, batch, s);
         default: yr_set_error("unknown op kind %d", op.kind); return YR_ERR_ARG;
     }
 }
@@ -200,6 +201,12 @@ static int64_t param_floats(const yr_op& op, int role) {   // role: 0 wgt, 1 sca
             if (role == 5) return 2 * cop;
             return 0;
         }
+        case YR_OP_MBE: {
+            const int64_t t = op.cout / 16, ke = op.cin / 4;
+            if (role == 0) return t * ke * 64;
+            if (role == 3) return t * 176;
+            return 0;
+        }
         case YR_OP_MBR: {
             const int64_t t = op.se_reduced / 16, to = ru(op.cout, 16) / 16, ke = op.cin / 4;
             if (role == 0) return t * (ke + 4 * to) * 64;
@@ -207,7 +214,7 @@ static int64_t param_floats(const yr_op& op, int role) {   // role: 0 wgt, 1 sca
             if (role == 5) return 16 * to;
             return 0;
         }
-        default: return 0;   // MBCONV: validated by its launcher's shape checks only
+        default: return 0;
     }
 }
 

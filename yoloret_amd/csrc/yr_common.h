@@ -41,11 +41,11 @@ int yr_launch_se_mean(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_se_fc(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_wsum(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_gather(const yr_op& op, int batch, hipStream_t s);
-int yr_launch_mbconv(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_stemblock(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_mblane(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_mbh(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_mbr(const yr_op& op, int batch, hipStream_t s);
+int yr_launch_mbe(const yr_op& op, int batch, hipStream_t s);
 int yr_pointwise_num_cfgs(int dtype);
 
 static inline int yr_round_up(int v, int m) { return (v + m - 1) / m * m; }

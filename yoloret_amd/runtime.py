@@ -17,7 +17,7 @@ YR_MAX_SRC = 4
 ACT = {'none': 0, None: 0, 'relu6': 1, 'swish': 2, 'sigmoid': 3, 'leaky': 4}
 XFORM = {'identity': 0, 'up2': 1, 'maxpool2': 2, 'maxpool4': 3, 'up2_add': 4, 'dw3': 5}
 OP_STEM, OP_POINTWISE, OP_DEPTHWISE, OP_SE_MEAN, OP_SE_FC, OP_WSUM, OP_GATHER, OP_MBCONV = 1, 2, 3, 4, 5, 6, 7, 8
-OP_STEMBLOCK, OP_MBLANE, OP_MBH, OP_MBX, OP_MBR = 9, 10, 11, 12, 13
+OP_STEMBLOCK, OP_MBLANE, OP_MBH, OP_MBX, OP_MBR, OP_MBE = 9, 10, 11, 12, 13, 14
 # yr_dtype: element type of activation tensors / pointwise weights (include/yoloret_hip.h)
 DTYPE = {'f32': 0, 'float32': 0, None: 0, 'bf16': 1, 'bfloat16': 1, 'f16': 2, 'float16': 2, 'u8': 3, 'uint8': 3}   # (u8: images only)
 DTYPE_NAME = {0: 'f32', 1: 'bf16', 2: 'f16', 3: 'u8'}
@@ -55,7 +55,7 @@ def from_bits16(b, dtype):
         return b.view(np.float16).astype(np.float32)
     return (b.astype(np.uint32) << 16).view(np.float32)
 OP_NAMES = {1: 'stem', 2: 'pointwise', 3: 'depthwise', 4: 'se_mean', 5: 'se_fc', 6: 'wsum', 7: 'gather', 8: 'mbconv',
-            9: 'stemblock', 10: 'mblane', 11: 'mbh', 12: 'mbx', 13: 'mbr'}
+            9: 'stemblock', 10: 'mblane', 11: 'mbh', 12: 'mbx', 13: 'mbr', 14: 'mbe'}
 
 
 class YrSrc(ctypes.Structure):
@@ -85,7 +85,7 @@ class YrBuf(ctypes.Structure):
                 ('external_slot', ctypes.c_int32), ('dtype', ctypes.c_int32)]
 
 
-ABI_VERSION = 4   # == YR_ABI_VERSION of include/yoloret_hip.h
+ABI_VERSION = 5   # == YR_ABI_VERSION of include/yoloret_hip.h
 EXPORTS = ['yr_last_error', 'yr_abi_version', 'yr_abi_sizeof', 'yr_create', 'yr_create_from_blob', 'yr_plan_io_dims', 'yr_destroy', 'yr_load_weights', 'yr_workspace_bytes',
            'yr_forward', 'yr_forward_profile', 'yr_autotune', 'yr_get_tuning', 'yr_set_tuning', 'yr_plan_num_launches', 'yr_op_run', 'yr_decode', 'yr_decode_zoom', 'yr_yolo_head', 'yr_correct_boxes',
            'yr_nms', 'yr_pack_detections', 'yr_letterbox', 'yr_letterbox_batch']
