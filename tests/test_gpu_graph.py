@@ -206,7 +206,9 @@ def test_tuning_table_round_trip(dev, tmp_path, monkeypatch):
     table = json.load(open(cache))
     (key, cfg), = table.items()
     assert key.endswith(':2') and len(cfg) == len(m.plan.ops)
-    assert all((c == 0) or (o.kind == rt.OP_POINTWISE) for c, o in zip(cfg, m.plan.ops)) and any(cfg)
+    # tuned entries: a pointwise tile shape, or the walk geometry of a register-chained block (waves << 8 | row segments << 16)
+    assert all((c == 0) or (o.kind in (rt.OP_POINTWISE, rt.OP_MBR, rt.OP_MBE)) for c, o in zip(cfg, m.plan.ops)) and any(cfg)
+    assert all((c & 0xff) == 0 for c, o in zip(cfg, m.plan.ops) if o.kind in (rt.OP_MBR, rt.OP_MBE))
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
     bad = (ctypes.c_int32 * 3)(1, 2, 3)

@@ -325,7 +325,7 @@ extern "C" int yr_set_tuning(yr_handle* h, int batch, const int32_t* cfg, int n)
     for (int i = 0; i < n; ++i) {
         const int ncfg = yr_pointwise_num_cfgs(h->ops[i].dtype);
         const bool pw_ok = cfg[i] >= 0 && cfg[i] <= ncfg && (cfg[i] == 0 || h->ops[i].kind == YR_OP_POINTWISE);
-        const bool mbh_ok = (h->ops[i].kind == YR_OP_MBH || h->ops[i].kind == YR_OP_MBX) && cfg[i] >= 0 && (cfg[i] & 0xff) == 0 && cfg[i] < (1 << 24);   // th << 8 | tw << 16
+        const bool mbh_ok = (h->ops[i].kind == YR_OP_MBH || h->ops[i].kind == YR_OP_MBX || h->ops[i].kind == YR_OP_MBR || h->ops[i].kind == YR_OP_MBE) && cfg[i] >= 0 && (cfg[i] & 0xff) == 0 && cfg[i] < (1 << 24);   // th << 8 | tw << 16
         YR_REQUIRE(pw_ok || mbh_ok, "yr_set_tuning: entry %d = %d is not a valid tile shape for that op", i, cfg[i]);
         t[i] = cfg[i];
     }
@@ -354,6 +354,9 @@ static int resolve_op(const yr_handle* h, size_t i, int batch, float* const ext[
     } else if (op.kind == YR_OP_MBH || op.kind == YR_OP_MBX) {   // the tuned output tile (th << 8 | tw << 16) rides in the upper bytes of k
         auto it = h->tuned.find(batch);
         if (it != h->tuned.end()) op.k = (op.k & 0xff) | it->second[i];
+    } else if (op.kind == YR_OP_MBR || op.kind == YR_OP_MBE) {   // (waves per workgroup << 8 | row segments << 16: the tuned walk geometry)
+        auto it = h->tuned.find(batch);
+        if (it != h->tuned.end() && it->second[i] != 0) op.k = (op.k & 0xff) | it->second[i];
     }
     *out = op;
     return YR_OK;
@@ -473,6 +476,44 @@ extern "C" int yr_autotune(yr_handle* h, const float* images, int batch, float* 
                     YR_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
                     if (ms < best_ms * 0.98f) { best_ms = ms; best_cfg = cfg; }
                 }
+            best[i] = best_cfg;
+            continue;
+        }
+        if (h->ops[i].kind == YR_OP_MBR || h->ops[i].kind == YR_OP_MBE) {
+            // register-chained float32 blocks: row segments per strip (how many waves the walk is cut into; each segment
+            // recomputes two halo rows), IN CONTEXT - right behind the predecessor, whose output is what the caches hold (in
+            // isolation block_2 measured 203 us, in the pipeline 240).  Results do not depend on the choice.
+            yr_op op, prev;
+            rc = resolve_op(h, i, batch, ext, static_cast<char*>(workspace), &op);
+            if (rc) break;
+            bool have_prev = i > 0;
+            if (have_prev) {
+                rc = resolve_op(h, i - 1, batch, ext, static_cast<char*>(workspace), &prev);
+                if (rc) break;
+                if (h->ops[i - 1].kind == YR_OP_POINTWISE) prev.k = best[i - 1];
+                else if (best[i - 1] != 0) prev.k = (prev.k & 0xff) | best[i - 1];
+            }
+            static const int segs_list[] = {0, 1, 2, 3, 4, 6, 8};
+            const int base = op.k & 0xffff;     // 3 | nw << 8: the workgroup shape the plan asks for
+            float best_ms = 1e30f;
+            int best_cfg = 0;
+            for (int c = 0; c < (int)(sizeof(segs_list) / sizeof(segs_list[0])); ++c) {
+                if (segs_list[c] > h->ops[i].h) continue;
+                op.k = base | (segs_list[c] << 16);
+                if (dispatch(op, batch, s) != YR_OK) continue;
+                float ms = 1e30f;
+                for (int it = 0; it < 2 * iters + 1; ++it) {
+                    if (have_prev && dispatch(prev, batch, s) != YR_OK) break;
+                    YR_CHECK_HIP(hipEventRecord(e0, s));
+                    (void)dispatch(op, batch, s);
+                    YR_CHECK_HIP(hipEventRecord(e1, s));
+                    YR_CHECK_HIP(hipEventSynchronize(e1));
+                    float t = 0.f;
+                    YR_CHECK_HIP(hipEventElapsedTime(&t, e0, e1));
+                    if (t < ms) ms = t;
+                }
+                if (ms < best_ms * 0.98f) { best_ms = ms; best_cfg = (base & 0xff00) | (segs_list[c] << 16); }
+            }
             best[i] = best_cfg;
             continue;
         }
