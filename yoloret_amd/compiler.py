@@ -291,8 +291,8 @@ if os.environ.get('YOLORET_MBR_ALL', '0') != '0':   # (experiments: every shape 
 # the projection stays a pointwise op.  Block input widths built in mbr.hip (MBE_CASE).
 FUSE_MBE = os.environ.get('YOLORET_FUSE_MBE', '1') != '0'
 # (measured, MobileNetV2 x0.75 @416 batch 64: block_11 / 12 85 -> 60 us, block_13 67 -> 56 us; the 13 x 13 blocks (120 inputs) tie
-# at 53 us and stay unfused)
-MBE_CINS = set(int(v) for v in os.environ.get('YOLORET_MBE_CINS', '72').split(',') if v)
+# at 53 us untuned, 43 us with the tuned row segments; MobileNetV2 x1.4 @512: 88- and 136-wide blocks c4 +4 %, the 224-wide ones -4 %)
+MBE_CINS = set(int(v) for v in os.environ.get('YOLORET_MBE_CINS', '72,88,120,136').split(',') if v)
 FUSE_MBH = os.environ.get('YOLORET_FUSE_MBH', '1') != '0'   # 16-bit plans: inverted-residual blocks on the MFMA block kernel (mbh.hip)
 MBH_LANE_MIN_PIXELS = int(os.environ.get('YOLORET_MBH_LANE_MIN_PIXELS', '10000'))
 MBH_LANE_MAX_CIN = int(os.environ.get('YOLORET_MBH_LANE_MAX_CIN', '16'))
