@@ -35,6 +35,8 @@
 
 bool yr_mbn_takes(const yr_op& op);                               // mbn_h.hip
 int yr_launch_mbn(const yr_op& op, int batch, hipStream_t s);
+bool yr_mbxr_takes(const yr_op& op);                              // mbxr_h.hip: YR_OP_MBX row-walking, register-chained
+int yr_launch_mbxr(const yr_op& op, int batch, int segs, hipStream_t s);
 
 typedef float mbh_f4 __attribute__((ext_vector_type(4)));
 typedef float mbh_f8 __attribute__((ext_vector_type(8)));
@@ -620,6 +622,15 @@ static int launch_mbh_t(const yr_op& op, int batch, hipStream_t s) {
     a.has_res = op.res != nullptr;
     if (a.has_res) YR_REQUIRE(op.res == in.ptr && op.stride == 1 && in.c == op.cout, "mbh: the residual must be the block input (stride 1, cin == cout)");
     a.act = op.act;
+    if (!full) {
+        // the expand + depthwise form has a second kernel (mbxr_h.hip): forced tile th = 255 selects it (tw = row segments),
+        // no forced tile: it is the default where it is built (YOLORET_MBXR=0: the LDS-tiled form below, for A/B runs)
+        static const bool mbxr_on = !(getenv("YOLORET_MBXR") && atoi(getenv("YOLORET_MBXR")) == 0);
+        if ((fth == 255 || (fth == 0 && mbxr_on)) && yr_mbxr_takes(op)) return yr_launch_mbxr(op, batch, fth == 255 ? ftw : 0, s);
+        YR_REQUIRE(fth != 255, "mbx: the register-chained form (tile 255) is not built for this op");
+    } else {
+        YR_REQUIRE(fth != 255, "mbh: tile 255 (the register-chained expand + depthwise form) applies to YR_OP_MBX only");
+    }
     const int cp = !full ? 0 : op.cout <= 32 ? 1 : (op.cout <= 64 ? 2 : 4);
     if (fth && ftw) { a.th = fth; a.tw = ftw; }
     else mbh_pick_tile(a.Ho, a.Wo, batch, K, op.stride, a.KP, cp, a.rows_cap, &a.th, &a.tw);

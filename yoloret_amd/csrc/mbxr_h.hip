@@ -1,0 +1,329 @@
+// YR_OP_MBX on 16-bit activations, ROW-WALKING and REGISTER-CHAINED (the float32 twin is mbr.hip: mbe_kernel):
+//   expand 1x1 + BN + act (v_mfma_f32_16x16x32_bf16 / _f16) -> depthwise KxK (K = 3 | 5, stride 1 | 2, TF SAME) + BN + act,
+// the depthwise map stored (16-bit) and, for the squeeze of squeeze-excite (reference code/yolo3/efficientnet.py:406-438,
+// 467-536: tf.reduce_mean over H, W), the per-channel sums of what was stored.
+//
+// The LDS-tiled form (mbh.hip MODE 1) moves every expanded value through LDS K times and holds one to three workgroups per CU
+// (PMC round 3: 51-57 % of its wave time waiting, 0.04-0.08 of any pipe).  Here NOTHING of the walk touches LDS:
+//   * a wave owns a strip of 16 input columns x NT expanded tiles of 16 channels and walks down the rows; the expand GEMM of
+//     a row has the strip's pixels as the MFMA's N dimension, the pixel operand comes from global memory as it lies there
+//     (lane (pixel p, k group g): the 8 consecutive channels 32 c + 8 g .. + 7 = one 16-byte load = one MFMA B operand);
+//   * the MFMA result layout (a lane: 4 consecutive channels of one pixel; the 16 lanes of a DPP row: the 16 pixels) is the
+//     layout the depthwise conv wants: horizontal taps by DPP row shifts riding on the multiply-add's operand
+//     (v_fmac_f32_dpp), vertical taps = the last K rows of the walk in registers;
+//   * expand weights (A fragments), BN parameters and the K x K taps of the wave's tiles are STATIONARY in registers;
+//   * the matrix pipe is its own pipe for 16-bit operands, so the kernel is bound by the depthwise VALU work alone:
+//     K*K multiply-adds + two activations + the rounding per value - what the arithmetic itself costs.
+// Same op, same parameter layouts as mbh.hip MODE 1 (yoloret_hip.h: YR_OP_MBX); the forced "tile" th = 255 selects this form
+// and tw = row segments per strip (0: the launcher's choice) - yr_autotune times it next to the LDS-tiled tiles.
+// Numerics: expand accumulates in float32, BN in float32, activation (swish: hardware exp2 + rcp, as mbh.hip), the expanded
+// value stays float32 (never rounded), depthwise in float32 with the BN scale folded into the taps, one rounding at the store.
+#include "yr_common.h"
+#include <type_traits>
+#include <cstdlib>
+
+typedef float xr_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned xr_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned xr_u2 __attribute__((ext_vector_type(2)));
+template <class T> using xr_v8 = T __attribute__((ext_vector_type(8)));
+typedef __amdgpu_buffer_rsrc_t xr_rsrc;
+
+struct MbxrArgs {
+    const void* x; void* out; const void* we; const float* prm;
+    float* part; int ld_part, rows_cap;
+    int H, W, Ho, Wo, Cin, CexpP, ld_in, ld_out, KP, pad_t, pad_l;
+    int strips, segs, seg_rows, T, groups, nwaves;
+};
+
+__device__ __forceinline__ xr_rsrc xr_make_rsrc(const void* base, unsigned bytes) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)base), hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)base >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+#define XR_DEAD 0x7f000000u
+
+template <class T>
+__device__ __forceinline__ xr_f4 xr_mfma(xr_u4 w, xr_u4 x, xr_f4 acc) {
+    if constexpr (yr_elem<T>::dtype == YR_BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xr_v8<__bf16>, w), __builtin_bit_cast(xr_v8<__bf16>, x), acc, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(xr_v8<_Float16>, w), __builtin_bit_cast(xr_v8<_Float16>, x), acc, 0, 0, 0);
+}
+
+// one tap ROW of the depthwise conv for the lane's 4 channels (see mbr.hip: the DPP shift rides on v_fmac's first operand,
+// the four channels' chains interleaved tap-major; s_nop 1 covers the VALU-write -> DPP-read hazard the compiler cannot see)
+#define XR_DPP(ctl) " " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void xr_row3(xr_f4& acc, const xr_f4 e, const xr_f4 w0, const xr_f4 w1, const xr_f4 w2) {
+    float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %4, %8" XR_DPP("row_shr:1") "v_fmac_f32_dpp %1, %5, %9" XR_DPP("row_shr:1")
+        "v_fmac_f32_dpp %2, %6, %10" XR_DPP("row_shr:1") "v_fmac_f32_dpp %3, %7, %11" XR_DPP("row_shr:1")
+        "v_fmac_f32 %0, %4, %12\n\t" "v_fmac_f32 %1, %5, %13\n\t" "v_fmac_f32 %2, %6, %14\n\t" "v_fmac_f32 %3, %7, %15\n\t"
+        "v_fmac_f32_dpp %0, %4, %16" XR_DPP("row_shl:1") "v_fmac_f32_dpp %1, %5, %17" XR_DPP("row_shl:1")
+        "v_fmac_f32_dpp %2, %6, %18" XR_DPP("row_shl:1") "v_fmac_f32_dpp %3, %7, %19" XR_DPP("row_shl:1")
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(w0[0]), "v"(w0[1]), "v"(w0[2]), "v"(w0[3]),
+          "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(w1[3]), "v"(w2[0]), "v"(w2[1]), "v"(w2[2]), "v"(w2[3]));
+    acc = (xr_f4){a0, a1, a2, a3};
+}
+// five taps: two asm blocks (an asm statement takes at most 30 operands): taps 0..2 at row_shr:2, row_shr:1, 0; taps 3..4 at row_shl:1, row_shl:2
+__device__ __forceinline__ void xr_row5(xr_f4& acc, const xr_f4 e, const xr_f4 w0, const xr_f4 w1, const xr_f4 w2, const xr_f4 w3, const xr_f4 w4) {
+    float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %4, %8" XR_DPP("row_shr:2") "v_fmac_f32_dpp %1, %5, %9" XR_DPP("row_shr:2")
+        "v_fmac_f32_dpp %2, %6, %10" XR_DPP("row_shr:2") "v_fmac_f32_dpp %3, %7, %11" XR_DPP("row_shr:2")
+        "v_fmac_f32_dpp %0, %4, %12" XR_DPP("row_shr:1") "v_fmac_f32_dpp %1, %5, %13" XR_DPP("row_shr:1")
+        "v_fmac_f32_dpp %2, %6, %14" XR_DPP("row_shr:1") "v_fmac_f32_dpp %3, %7, %15" XR_DPP("row_shr:1")
+        "v_fmac_f32 %0, %4, %16\n\t" "v_fmac_f32 %1, %5, %17\n\t" "v_fmac_f32 %2, %6, %18\n\t" "v_fmac_f32 %3, %7, %19\n\t"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(w0[0]), "v"(w0[1]), "v"(w0[2]), "v"(w0[3]),
+          "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(w1[3]), "v"(w2[0]), "v"(w2[1]), "v"(w2[2]), "v"(w2[3]));
+    asm("v_fmac_f32_dpp %0, %4, %8" XR_DPP("row_shl:1") "v_fmac_f32_dpp %1, %5, %9" XR_DPP("row_shl:1")
+        "v_fmac_f32_dpp %2, %6, %10" XR_DPP("row_shl:1") "v_fmac_f32_dpp %3, %7, %11" XR_DPP("row_shl:1")
+        "v_fmac_f32_dpp %0, %4, %12" XR_DPP("row_shl:2") "v_fmac_f32_dpp %1, %5, %13" XR_DPP("row_shl:2")
+        "v_fmac_f32_dpp %2, %6, %14" XR_DPP("row_shl:2") "v_fmac_f32_dpp %3, %7, %15" XR_DPP("row_shl:2")
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(w3[0]), "v"(w3[1]), "v"(w3[2]), "v"(w3[3]),
+          "v"(w4[0]), "v"(w4[1]), "v"(w4[2]), "v"(w4[3]));
+    acc = (xr_f4){a0, a1, a2, a3};
+}
+
+template <int ACT>
+__device__ __forceinline__ float xr_act(float v, float hi) {   // hi: 6 (relu6) / 1 (swish) inside the image, 0 outside
+    if constexpr (ACT == 0) return __builtin_amdgcn_fmed3f(v, 0.0f, hi);
+    else return hi * (v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f)));
+}
+
+// K: depthwise kernel, S: stride, ACT: 0 relu6 / 1 swish (both activations), NC: 32-channel chunks of the block input, NT: tiles per wave
+template <class T, int K, int S, int ACT, int NC, int NT, int MW>
+__global__ __launch_bounds__(256, MW) void mbxr_kernel(MbxrArgs a) {
+    constexpr int KK = K * K, PAD = (K - 1) / 2, NOUT = (16 - K) / S + 1;
+    const int lane = threadIdx.x & 63, px = lane & 15, mg = lane >> 4;
+    int gw = (int)yr_xcd_swizzle(blockIdx.x, gridDim.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (gw >= a.nwaves) return;
+    const int g = gw % a.groups; gw /= a.groups;
+    const int seg = gw % a.segs; gw /= a.segs;
+    const int strip = gw % a.strips;
+    const int b = gw / a.strips;
+    const int t0 = g * NT;
+    const int yo0 = seg * a.seg_rows, yo1 = min(yo0 + a.seg_rows, a.Ho);
+    const int xin = S * NOUT * strip - a.pad_l + px;
+    const int xc = min(max(xin, 0), a.W - 1);
+    constexpr float HI = ACT == 0 ? 6.f : 1.f;
+    const float hi = (xin >= 0 && xin < a.W) ? HI : 0.f;
+    const int jo = (px - PAD) / S, xo = NOUT * strip + jo;
+    const bool out_lane = px >= PAD && (px - PAD) % S == 0 && jo < NOUT && xo < a.Wo;
+    const float omask = out_lane ? 1.f : 0.f;
+
+    // ---- stationary: expand A fragments, BN rows, taps (times the depthwise BN scale) of this wave's tiles
+    xr_u4 aw[NT][NC];
+    xr_f4 es[NT], eh[NT], dh[NT], tp[NT][KK], ssum[NT];
+    unsigned ooff[NT];
+    bool tlive[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        tlive[j] = t0 + j < a.T;
+        const int t = min(t0 + j, a.T - 1);
+        const int ch = 16 * t + 4 * mg;                                   // this lane's 4 expanded channels of tile j
+        const char* wrow = reinterpret_cast<const char*>(a.we) + ((size_t)(16 * t + px) * a.KP + 8 * mg) * 2;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) aw[j][c] = *reinterpret_cast<const xr_u4*>(wrow + 64 * c);
+        const xr_f4 dsc = *reinterpret_cast<const xr_f4*>(a.prm + (size_t)KK * a.CexpP + ch);
+        dh[j] = *reinterpret_cast<const xr_f4*>(a.prm + (size_t)(KK + 1) * a.CexpP + ch);
+        es[j] = *reinterpret_cast<const xr_f4*>(a.prm + (size_t)(KK + 2) * a.CexpP + ch);
+        eh[j] = *reinterpret_cast<const xr_f4*>(a.prm + (size_t)(KK + 3) * a.CexpP + ch);
+#pragma unroll
+        for (int q = 0; q < KK; ++q) tp[j][q] = *reinterpret_cast<const xr_f4*>(a.prm + (size_t)q * a.CexpP + ch) * dsc;
+        ssum[j] = (xr_f4){0.f, 0.f, 0.f, 0.f};
+        ooff[j] = (tlive[j] && out_lane) ? (unsigned)ch * 2u : XR_DEAD;
+    }
+    const xr_rsrc xsrc = xr_make_rsrc(reinterpret_cast<const T*>(a.x) + (size_t)b * a.H * a.W * a.ld_in, (unsigned)(a.H * a.W * a.ld_in) * 2u);
+    const xr_rsrc osrc = xr_make_rsrc(reinterpret_cast<T*>(a.out) + (size_t)b * a.Ho * a.Wo * a.ld_out, (unsigned)(a.Ho * a.Wo * a.ld_out) * 2u);
+    const int rbeg = S * yo0 - a.pad_t, nout = yo1 - yo0;
+    unsigned xoff[NC];     // the lane's 16 bytes of chunk c within the row; k groups beyond the input's channels read zeros (dead offset)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) xoff[c] = (32 * c + 8 * mg < a.Cin) ? ((unsigned)xc * (unsigned)a.ld_in + 32u * c + 8u * mg) * 2u : XR_DEAD;
+    const unsigned xrow = (unsigned)(a.W * a.ld_in) * 2u;
+    struct XRow { xr_u4 m[NC]; };
+    XRow xa, xb;
+    auto load_row = [&](XRow& x, int r) {
+        const unsigned so = (unsigned)min(max(r, 0), a.H - 1) * xrow;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) x.m[c] = __builtin_bit_cast(xr_u4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[c], so, 0));
+    };
+    load_row(xa, rbeg);
+    xr_f4 ring[NT][K - 1];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int q = 0; q < K - 1; ++q) ring[j][q] = (xr_f4){0.f, 0.f, 0.f, 0.f};
+
+    auto row = [&](auto emit_c, const int k, const int yo, const XRow& xc_, XRow& xn_) {
+        constexpr bool EMIT = decltype(emit_c)::value;
+        const int r = rbeg + k;
+        load_row(xn_, r + 1);
+        const float hr = (r >= 0 && r < a.H) ? hi : 0.f;
+        xr_f4 ec[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            xr_f4 d = (xr_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) d = xr_mfma<T>(aw[j][c], xc_.m[c], d);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ec[j][i] = xr_act<ACT>(__builtin_fmaf(d[i], es[j][i], eh[j][i]), hr);
+        }
+        if constexpr (EMIT) {
+            const unsigned opix = ((unsigned)yo * (unsigned)a.Wo + (unsigned)xo) * (unsigned)a.ld_out * 2u;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                xr_f4 d = dh[j];
+                if constexpr (K == 3) {
+                    xr_row3(d, ring[j][0], tp[j][0], tp[j][1], tp[j][2]);
+                    xr_row3(d, ring[j][1], tp[j][3], tp[j][4], tp[j][5]);
+                    xr_row3(d, ec[j], tp[j][6], tp[j][7], tp[j][8]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xr_row5(d, ring[j][q], tp[j][5 * q], tp[j][5 * q + 1], tp[j][5 * q + 2], tp[j][5 * q + 3], tp[j][5 * q + 4]);
+                    xr_row5(d, ec[j], tp[j][20], tp[j][21], tp[j][22], tp[j][23], tp[j][24]);
+                }
+                typedef T t4 __attribute__((ext_vector_type(4)));
+                xr_f4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = xr_act<ACT>(d[i], HI);
+                const t4 o = __builtin_convertvector(v, t4);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(xr_u2, o), osrc, ooff[j] == XR_DEAD ? XR_DEAD : opix + ooff[j], 0, 0);
+                const xr_f4 stored = __builtin_convertvector(o, xr_f4);   // the squeeze sums what was STORED (rounded)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ssum[j][i] = __builtin_fmaf(stored[i], omask, ssum[j][i]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int q = 0; q + 1 < K - 1; ++q) ring[j][q] = ring[j][q + 1];
+            ring[j][K - 2] = ec[j];
+        }
+    };
+    constexpr std::true_type Y{};
+    constexpr std::false_type N{};
+    // rows 0 .. K - S - 1 warm the ring up; then every output row takes S input rows, the last of which emits
+    int k = 0;
+    if constexpr ((K - S) % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < (K - S) / 2; ++q) { row(N, k, 0, xa, xb); row(N, k + 1, 0, xb, xa); k += 2; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < (K - S) / 2; ++q) { row(N, k, 0, xa, xb); row(N, k + 1, 0, xb, xa); k += 2; }
+        row(N, k, 0, xa, xb); k += 1;
+    }
+    if constexpr (S == 2) {   // (an odd warm-up: the current row's operands are in xb)
+        for (int i = 0; i < nout; ++i) {
+            row(N, k, 0, xb, xa);
+            row(Y, k + 1, yo0 + i, xa, xb);
+            k += 2;
+        }
+    } else {
+        int i = 0;
+        for (; i + 1 < nout; i += 2) {
+            row(Y, k, yo0 + i, xa, xb);
+            row(Y, k + 1, yo0 + i + 1, xb, xa);
+            k += 2;
+        }
+        if (i < nout) row(Y, k, yo0 + i, xa, xb);
+    }
+    // ---- the squeeze: this wave's channel sums over its segment -> row (strip, segment) of the partial-sum buffer
+    if (a.part != nullptr) {
+        const int prow = strip * a.segs + seg;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            xr_f4 v = ssum[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {   // fixed butterfly over the 16 pixels of the DPP row: deterministic
+                v[i] += __shfl_xor(v[i], 8, 16);
+                v[i] += __shfl_xor(v[i], 4, 16);
+                v[i] += __shfl_xor(v[i], 2, 16);
+                v[i] += __shfl_xor(v[i], 1, 16);
+            }
+            const int ch = 16 * (t0 + j) + 4 * mg;
+            if (tlive[j] && px == 0 && ch < a.ld_part) {
+                float* p = a.part + ((size_t)b * a.rows_cap + prow) * a.ld_part + ch;
+                *reinterpret_cast<xr_f4*>(p) = v;
+                if (strip == 0 && seg == 0)     // rows no (strip, segment) owns: zero (the buffer is sized for the LDS-tiled form's smallest tile)
+                    for (int rr = a.strips * a.segs; rr < a.rows_cap; ++rr)
+                        *reinterpret_cast<xr_f4*>(a.part + ((size_t)b * a.rows_cap + rr) * a.ld_part + ch) = (xr_f4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+}
+
+template <class T, int K, int S, int ACT, int NC, int NT>
+static int launch_mbxr(const MbxrArgs& a0, int batch, int want_segs, hipStream_t s) {
+    MbxrArgs a = a0;
+    constexpr int NOUT = (16 - K) / S + 1;
+    constexpr int EST = NT * (4 * NC + 16 + 4 * K * K + 4 * (K - 1) + 8) + 8 * NC + 48;
+    constexpr int MW = EST <= 120 ? 4 : EST <= 160 ? 3 : EST <= 250 ? 2 : 1;
+    a.strips = (a.Wo + NOUT - 1) / NOUT;
+    a.groups = (a.T + NT - 1) / NT;
+    const int walks = batch * a.strips * a.groups;
+    int segs = (3 * 1024 + walks - 1) / walks;
+    const int max_segs = (a.Ho + 5) / 6;
+    if (segs > max_segs) segs = max_segs;
+    if (segs < 1) segs = 1;
+    if (want_segs > 0) segs = want_segs < a.Ho ? want_segs : a.Ho;
+    if (a.part != nullptr && a.strips * segs > a.rows_cap) segs = a.rows_cap / a.strips;   // one row of the partial-sum buffer per (strip, segment)
+    YR_REQUIRE(segs >= 1, "mbxr: %d strips exceed the %d rows of the partial-sum buffer", a.strips, a.rows_cap);
+    a.seg_rows = (a.Ho + segs - 1) / segs;
+    a.segs = (a.Ho + a.seg_rows - 1) / a.seg_rows;
+    a.nwaves = batch * a.strips * a.segs * a.groups;
+    static char nm[64];
+    static const int nm_len = snprintf(nm, sizeof(nm), "mbxr_kernel<%s,%d,%d,%d,%d,%d,%d>", yr_dtype_name(yr_elem<T>::dtype), K, S, ACT, NC, NT, MW);
+    (void)nm_len;
+    yr_note_kernel(nm);
+    hipLaunchKernelGGL((mbxr_kernel<T, K, S, ACT, NC, NT, MW>), dim3((unsigned)((a.nwaves + 3) / 4)), dim3(256), 0, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
+template <class T, int K, int S, int ACT>
+static int launch_mbxr_nc(const MbxrArgs& a, int batch, int segs, hipStream_t s) {
+    constexpr int NT = K == 3 ? 2 : 1;
+    switch (a.KP / 32) {
+        case 1: return launch_mbxr<T, K, S, ACT, 1, NT>(a, batch, segs, s);
+        case 2: return launch_mbxr<T, K, S, ACT, 2, NT>(a, batch, segs, s);
+        case 3: return launch_mbxr<T, K, S, ACT, 3, NT>(a, batch, segs, s);
+        case 4: return launch_mbxr<T, K, S, ACT, 4, NT>(a, batch, segs, s);
+        default: yr_set_error("mbxr: %d input channels are not built", a.Cin); return YR_ERR_ARG;
+    }
+}
+
+// whether the register-chained form is built for this YR_OP_MBX op (mbh.hip asks before it dispatches here)
+bool yr_mbxr_takes(const yr_op& op) {
+    const int K = op.k & 0xff;
+    return op.kind == YR_OP_MBX && (op.dtype == YR_BF16 || op.dtype == YR_F16) && (K == 3 || K == 5) && (op.stride == 1 || op.stride == 2) &&
+           (op.act == YR_ACT_RELU6 || op.act == YR_ACT_SWISH) && op.cin % 8 == 0 && op.cin <= 128 && op.cout % 16 == 0 && op.nsrc == 1 &&
+           op.out_ld % 4 == 0 && (op.gate == nullptr || op.gate_ld % 4 == 0);
+}
+
+template <class T>
+static int launch_mbxr_t(const yr_op& op, int batch, int segs, hipStream_t s) {
+    const yr_src& in = op.src[0];
+    const int K = op.k & 0xff;
+    MbxrArgs a;
+    a.x = in.ptr; a.out = op.out; a.we = op.wgt; a.prm = op.wgt2;
+    a.part = const_cast<float*>(op.gate); a.ld_part = op.gate ? op.gate_ld : 0; a.rows_cap = op.gate ? op.se_reduced : 0;
+    a.H = in.h; a.W = in.w; a.Ho = op.h; a.Wo = op.w; a.Cin = in.c; a.CexpP = yr_round_up(op.cout, 32); a.KP = yr_round_up(in.c, 32);
+    a.ld_in = in.ld; a.ld_out = op.out_ld; a.T = op.cout / 16;
+    const int pth = (a.Ho - 1) * op.stride + K - in.h, ptw = (a.Wo - 1) * op.stride + K - in.w;
+    a.pad_t = (pth > 0 ? pth : 0) / 2; a.pad_l = (ptw > 0 ? ptw : 0) / 2;
+    a.strips = a.segs = a.seg_rows = a.groups = a.nwaves = 0;
+    const int act = op.act == YR_ACT_RELU6 ? 0 : 1;
+#define XR_GO(KV, SV) (act == 0 ? launch_mbxr_nc<T, KV, SV, 0>(a, batch, segs, s) : launch_mbxr_nc<T, KV, SV, 1>(a, batch, segs, s))
+    if (K == 3) return op.stride == 1 ? XR_GO(3, 1) : XR_GO(3, 2);
+    return op.stride == 1 ? XR_GO(5, 1) : XR_GO(5, 2);
+#undef XR_GO
+}
+
+// (the argument checks of mbh.hip's launcher have run: pointers, strides, dims)
+int yr_launch_mbxr(const yr_op& op, int batch, int segs, hipStream_t s) {
+    YR_REQUIRE(yr_mbxr_takes(op), "mbxr: the register-chained form is not built for this op");
+    return op.dtype == YR_BF16 ? launch_mbxr_t<yr_bf16>(op, batch, segs, s) : launch_mbxr_t<yr_f16>(op, batch, segs, s);
+}

@@ -456,7 +456,9 @@ extern "C" int yr_autotune(yr_handle* h, const float* images, int batch, float* 
             // fused 16-bit block: time a fixed list of output tiles (runs of 4 along x: tw % 4 == 0); tiles the op
             // cannot take (too many pixels for its accumulators, LDS footprint) are refused by the launcher and skipped
             static const int tiles[][2] = {{4, 8}, {8, 4}, {7, 4}, {7, 8}, {8, 8}, {13, 4}, {4, 16}, {8, 16}, {7, 16}, {13, 8},
-                                           {16, 8}, {13, 16}, {8, 12}, {7, 12}, {13, 12}, {16, 12}, {16, 16}, {4, 12}, {6, 8}};
+                                           {16, 8}, {13, 16}, {8, 12}, {7, 12}, {13, 12}, {16, 12}, {16, 16}, {4, 12}, {6, 8},
+                                           // YR_OP_MBX: the row-walking register-chained form (mbxr_h.hip), 1 .. 6 row segments per strip
+                                           {255, 1}, {255, 2}, {255, 3}, {255, 4}, {255, 6}};
             yr_op op;
             rc = resolve_op(h, i, batch, ext, static_cast<char*>(workspace), &op);
             if (rc) break;
