@@ -47,18 +47,34 @@ def _act(t, act):
     return {'relu6': nn.relu6, 'swish': nn.swish}[act](t)
 
 
+def _chained_built(cin, cexp, cout, k):
+    """mbxr_h.hip: yr_mbhr_built - the shapes the register-chained whole-block kernel (mbhr_kernel) is instantiated for."""
+    if not (k == 3 and cin % 8 == 0 and cin <= 64 and cexp % 16 == 0 and cexp <= 256 and cout % 4 == 0 and cout <= 80):
+        return False
+    return (round_up(cin, 32) // 32, (cout + 15) // 16, (cexp // 16 + 1) // 2) in {(1, 2, 3), (1, 2, 6), (1, 3, 6), (2, 5, 8), (2, 3, 8)}
+
+
+@pytest.mark.parametrize('form', ['lds', 'chained'])
 @pytest.mark.parametrize('dt', ['bf16', 'f16'])
 @pytest.mark.parametrize('case', CASES, ids=[str(i) for i in range(len(CASES))])
-def test_mbh(dev, case, dt):
+def test_mbh(dev, case, dt, form):
+    """form 'lds': the LDS-tiled kernels (mbh.hip, mbn_h.hip; forced tile 254 = their own tile choice); 'chained': the
+    row-walking register-chained kernel (mbxr_h.hip: mbhr_kernel; forced tile 255, one or three row segments) where built."""
     from yoloret_amd import runtime as rt
     h, w, cin, cexp, cout, k, s, residual, act, tile = case
+    if form == 'chained':
+        if tile is not None or not _chained_built(cin, cexp, cout, k):
+            pytest.skip('the register-chained form is not built for this shape')
+        tile = (255, 3 if h > 20 else 0)
+    elif tile is None:
+        tile = (254, 0)
     rng = np.random.default_rng(zlib.crc32(str(case).encode()))
     b = 2
     x = q16(rng.standard_normal((b, h, w, cin)), dt)
     we = q16(rng.standard_normal((cin, cexp)) * np.sqrt(2.0 / cin), dt)
     se, he = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
     t = _act(nn.pointwise(x.astype(np.float64), we.astype(np.float64)) * se + he, act)
-    mbn = k == 3 and s == 2 and cin <= 32 and cin % 8 == 0 and cexp <= 192 and cout <= 32 and not residual and tile is None
+    mbn = k == 3 and s == 2 and cin <= 32 and cin % 8 == 0 and cexp <= 192 and cout <= 32 and not residual and tile == (254, 0)
     if mbn:
         # the narrow stride-2 block at the network's front runs on mbn_h.hip, which keeps the WHOLE expanded halo tile on chip
         # in the 16-bit type (the unfused chain's rounding point, oracle/model.py P.store); an expanded value on a rounding

@@ -37,6 +37,9 @@ bool yr_mbn_takes(const yr_op& op);                               // mbn_h.hip
 int yr_launch_mbn(const yr_op& op, int batch, hipStream_t s);
 bool yr_mbxr_takes(const yr_op& op);                              // mbxr_h.hip: YR_OP_MBX row-walking, register-chained
 int yr_launch_mbxr(const yr_op& op, int batch, int segs, hipStream_t s);
+bool yr_mbhr_built(const yr_op& op);                              // mbxr_h.hip: YR_OP_MBH (the whole block) in the same form
+int yr_launch_mbhr(const yr_op& op, int batch, int segs, hipStream_t s);
+bool yr_mbh_prefers_chained(const yr_op& op);
 
 typedef float mbh_f4 __attribute__((ext_vector_type(4)));
 typedef float mbh_f8 __attribute__((ext_vector_type(8)));
@@ -578,7 +581,12 @@ static void mbh_pick_tile(int ho, int wo, int batch, int k, int s, int kp, int c
 // wgt, wgt2 as above; no b1 / b2 / res; gate (optional) = OUTPUT, float32 [B][se_reduced][gate_ld] per-tile channel sums
 // (se_reduced = rows of the buffer >= tiles per image; the rows no tile owns are zeroed).
 template <class T>
-static int launch_mbh_t(const yr_op& op, int batch, hipStream_t s) {
+static int launch_mbh_t(const yr_op& op_in, int batch, hipStream_t s) {
+    // forced tile th = 254: this file's (and mbn_h.hip's) own choice, never the register-chained forms - the tuner's way to
+    // time both, and the A/B switch of the tests
+    const bool legacy = ((op_in.k >> 8) & 0xff) == 254;
+    yr_op op = op_in;
+    if (legacy) op.k &= 0xff;
     const bool full = op.kind == YR_OP_MBH;
     YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY, "mbh: needs one identity source");
     const yr_src& in = op.src[0];
@@ -590,6 +598,16 @@ static int launch_mbh_t(const yr_op& op, int batch, hipStream_t s) {
                "mbh: channel strides must be multiples of 8 and cover round_up(c,8)");
     YR_REQUIRE(((uintptr_t)in.ptr | (uintptr_t)op.out | (uintptr_t)op.wgt | (uintptr_t)op.b1 | (uintptr_t)op.wgt2) % 16 == 0, "mbh: pointers must be 16-byte aligned");
     YR_REQUIRE(op.cout >= 1 && op.cin >= 1 && op.cin <= 128, "mbh: widths out of range (cin <= 128)");
+    if (full) {
+        // the whole block in the register-chained form (mbxr_h.hip: mbhr_kernel): forced tile th = 255 (tw = row segments);
+        // without a forced tile it is the default where it is built (YOLORET_MBHR=0: the kernels below, for A/B runs)
+        if (!legacy && yr_mbh_prefers_chained(op) && yr_mbhr_built(op)) {
+            YR_REQUIRE(op.res == nullptr || (op.res == in.ptr && op.stride == 1 && in.c == op.cout), "mbh: the residual must be the block input (stride 1, cin == cout)");
+            YR_REQUIRE((in.h + op.stride - 1) / op.stride == op.h && (in.w + op.stride - 1) / op.stride == op.w, "mbh: output dims mismatch");
+            return yr_launch_mbhr(op, batch, fth == 255 ? ftw : 0, s);
+        }
+        YR_REQUIRE(fth != 255, "mbh: the register-chained whole-block form (tile 255) is not built for this op");
+    }
     {   // the narrow stride-2 3x3 block at the network's front: its own kernel (mbn_h.hip; YOLORET_MBN=0: this one, for A/B runs)
         static const bool mbn_on = !(getenv("YOLORET_MBN") && atoi(getenv("YOLORET_MBN")) == 0);
         if (mbn_on && yr_mbn_takes(op)) return yr_launch_mbn(op, batch, s);
@@ -625,11 +643,8 @@ static int launch_mbh_t(const yr_op& op, int batch, hipStream_t s) {
     if (!full) {
         // the expand + depthwise form has a second kernel (mbxr_h.hip): forced tile th = 255 selects it (tw = row segments),
         // no forced tile: it is the default where it is built (YOLORET_MBXR=0: the LDS-tiled form below, for A/B runs)
-        static const bool mbxr_on = !(getenv("YOLORET_MBXR") && atoi(getenv("YOLORET_MBXR")) == 0);
-        if ((fth == 255 || (fth == 0 && mbxr_on)) && yr_mbxr_takes(op)) return yr_launch_mbxr(op, batch, fth == 255 ? ftw : 0, s);
+        if (!legacy && yr_mbh_prefers_chained(op) && yr_mbxr_takes(op)) return yr_launch_mbxr(op, batch, fth == 255 ? ftw : 0, s);
         YR_REQUIRE(fth != 255, "mbx: the register-chained form (tile 255) is not built for this op");
-    } else {
-        YR_REQUIRE(fth != 255, "mbh: tile 255 (the register-chained expand + depthwise form) applies to YR_OP_MBX only");
     }
     const int cp = !full ? 0 : op.cout <= 32 ? 1 : (op.cout <= 64 ? 2 : 4);
     if (fth && ftw) { a.th = fth; a.tw = ftw; }

@@ -295,6 +295,257 @@ static int launch_mbxr_nc(const MbxrArgs& a, int batch, int segs, hipStream_t s)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// YR_OP_MBH in the same form: the WHOLE block - expand -> depthwise 3x3 -> project 1x1 + BN (+ residual) - for blocks of at
+// most 16 expanded tiles (the network fronts: MobileNetV2 block_1..6, EfficientNet-lite stage 2, lite0 stage 4 entry).  A
+// workgroup's NW waves share one strip segment; wave w owns the expanded tile PAIR (2w, 2w + 1) = one 32-deep k step of the
+// projection: its depthwise results, rounded to the 16-bit type, ARE the projection MFMA's B operand (the lane's 4 channels
+// of tile 2w and of tile 2w + 1 = the 8 k values of its k group; the weight fragment is gathered in the same order), the
+// partial projections of an output row meet in LDS (one barrier per output row, two buffers).  Same parameters as mbh.hip.
+struct MbhrArgs {
+    const void* x; void* out; const void* we; const float* prm; const void* wp; const float* sp; const float* hp;
+    int H, W, Ho, Wo, Cin, CexpP, Cout, ld_in, ld_out, KP, pad_t, pad_l, strips, segs, seg_rows, T, has_res;
+};
+
+template <class T, int S, int ACT, int NC, int TO, int NW, int MW>
+__global__ __launch_bounds__(64 * NW, MW) void mbhr_kernel(MbhrArgs a) {
+    constexpr int K = 3, KK = 9, NOUT = (16 - K) / S + 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    xr_f4* red = reinterpret_cast<xr_f4*>(lds);            // [2][NW][TO][64]
+    const int lane = threadIdx.x & 63, px = lane & 15, mg = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int bid = (int)yr_xcd_swizzle(blockIdx.x, gridDim.x);
+    const int seg = bid % a.segs; bid /= a.segs;
+    const int strip = bid % a.strips;
+    const int b = bid / a.strips;
+    const int yo0 = seg * a.seg_rows, yo1 = min(yo0 + a.seg_rows, a.Ho);
+    const int xin = S * NOUT * strip - a.pad_l + px;
+    const int xc = min(max(xin, 0), a.W - 1);
+    constexpr float HI = ACT == 0 ? 6.f : 1.f;
+    const float hi = (xin >= 0 && xin < a.W) ? HI : 0.f;
+    const int jo = (px - 1) / S, xo = NOUT * strip + jo;
+    const bool out_lane = px >= 1 && (px - 1) % S == 0 && jo < NOUT && xo < a.Wo;
+
+    // ---- stationary: the wave's two expanded tiles (a tile beyond T: all-zero parameters -> its depthwise result is act(0) = 0)
+    xr_u4 aw[2][NC], wpf[TO];
+    xr_f4 es[2], eh[2], dh[2], tp[2][KK];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int t = 2 * w + j;
+        const bool live = t < a.T;
+        const int tc = live ? t : 0, ch = 16 * tc + 4 * mg;
+        const char* wrow = reinterpret_cast<const char*>(a.we) + ((size_t)(16 * tc + px) * a.KP + 8 * mg) * 2;
+        const xr_f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) aw[j][c] = live ? *reinterpret_cast<const xr_u4*>(wrow + 64 * c) : (xr_u4){0u, 0u, 0u, 0u};
+        const xr_f4 dsc = *reinterpret_cast<const xr_f4*>(a.prm + (size_t)KK * a.CexpP + ch);
+        dh[j] = live ? *reinterpret_cast<const xr_f4*>(a.prm + (size_t)(KK + 1) * a.CexpP + ch) : z;
+        es[j] = live ? *reinterpret_cast<const xr_f4*>(a.prm + (size_t)(KK + 2) * a.CexpP + ch) : z;
+        eh[j] = live ? *reinterpret_cast<const xr_f4*>(a.prm + (size_t)(KK + 3) * a.CexpP + ch) : z;
+#pragma unroll
+        for (int q = 0; q < KK; ++q) tp[j][q] = live ? *reinterpret_cast<const xr_f4*>(a.prm + (size_t)q * a.CexpP + ch) * dsc : z;
+    }
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {   // project A fragment of cout tile t for this wave's k step: W[16 t + m][16 (2w) + 4 g ..] ++ W[..][16 (2w + 1) + 4 g ..]
+        const int co = 16 * t + px;
+        const char* prow = reinterpret_cast<const char*>(a.wp) + ((size_t)(co < a.Cout ? co : 0) * a.CexpP + 32 * w + 4 * mg) * 2;
+        xr_u2 lo = *reinterpret_cast<const xr_u2*>(prow), hi2 = *reinterpret_cast<const xr_u2*>(prow + 32);
+        if (co >= a.Cout) { lo = (xr_u2){0u, 0u}; hi2 = lo; }
+        wpf[t] = (xr_u4){lo[0], lo[1], hi2[0], hi2[1]};
+    }
+    // the cout tile this wave finishes (t = w, if w < TO): project BN rows
+    const int fco = 16 * w + 4 * mg;
+    const bool flive = w < TO && out_lane && fco < a.Cout;
+    const bool rlive = flive && a.has_res;
+    xr_f4 fsc = {0.f, 0.f, 0.f, 0.f}, fsh = fsc;
+    if (w < TO && fco < a.Cout) { fsc = *reinterpret_cast<const xr_f4*>(a.sp + fco); fsh = *reinterpret_cast<const xr_f4*>(a.hp + fco); }
+
+    const xr_rsrc xsrc = xr_make_rsrc(reinterpret_cast<const T*>(a.x) + (size_t)b * a.H * a.W * a.ld_in, (unsigned)(a.H * a.W * a.ld_in) * 2u);
+    const xr_rsrc osrc = xr_make_rsrc(reinterpret_cast<T*>(a.out) + (size_t)b * a.Ho * a.Wo * a.ld_out, (unsigned)(a.Ho * a.Wo * a.ld_out) * 2u);
+    const int rbeg = S * yo0 - a.pad_t, nout = yo1 - yo0;
+    unsigned xoff[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) xoff[c] = (32 * c + 8 * mg < a.Cin) ? ((unsigned)xc * (unsigned)a.ld_in + 32u * c + 8u * mg) * 2u : XR_DEAD;
+    const unsigned xrow = (unsigned)(a.W * a.ld_in) * 2u;
+    struct XRow { xr_u4 m[NC]; };
+    XRow xa, xb;
+    auto load_row = [&](XRow& x, int r) {
+        const unsigned so = (unsigned)min(max(r, 0), a.H - 1) * xrow;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) x.m[c] = __builtin_bit_cast(xr_u4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[c], so, 0));
+    };
+    load_row(xa, rbeg);
+    xr_f4 ring[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { ring[j][0] = (xr_f4){0.f, 0.f, 0.f, 0.f}; ring[j][1] = ring[j][0]; }
+    int buf = 0;
+    typedef T t4 __attribute__((ext_vector_type(4)));
+
+    auto row = [&](auto emit_c, const int k, const int yo, const XRow& xc_, XRow& xn_) {
+        constexpr bool EMIT = decltype(emit_c)::value;
+        const int r = rbeg + k;
+        load_row(xn_, r + 1);
+        xr_u2 resv = {0u, 0u};
+        if constexpr (EMIT)   // UNCONDITIONAL (a dead offset reads zeros without a residual): a load under a branch makes every later wait vmcnt(0)
+            resv = __builtin_bit_cast(xr_u2, __builtin_amdgcn_raw_buffer_load_b64(xsrc, rlive ? (((unsigned)yo * (unsigned)a.Wo + (unsigned)xo) * (unsigned)a.ld_in + (unsigned)fco) * 2u : XR_DEAD, 0, 0));
+        __builtin_amdgcn_sched_barrier(0);   // (both loads are issued HERE: left alone the scheduler sinks the residual load to its use behind the barrier)
+        const float hr = (r >= 0 && r < a.H) ? hi : 0.f;
+        xr_f4 ec[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            xr_f4 d = (xr_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) d = xr_mfma<T>(aw[j][c], xc_.m[c], d);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ec[j][i] = xr_act<ACT>(__builtin_fmaf(d[i], es[j][i], eh[j][i]), hr);
+        }
+        if constexpr (EMIT) {
+            t4 dq[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                xr_f4 d = dh[j];
+                xr_row3(d, ring[j][0], tp[j][0], tp[j][1], tp[j][2]);
+                xr_row3(d, ring[j][1], tp[j][3], tp[j][4], tp[j][5]);
+                xr_row3(d, ec[j], tp[j][6], tp[j][7], tp[j][8]);
+                xr_f4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = xr_act<ACT>(d[i], HI);
+                dq[j] = __builtin_convertvector(v, t4);      // rounded: the projection's operand type
+            }
+            const xr_u2 b0 = __builtin_bit_cast(xr_u2, dq[0]), b1 = __builtin_bit_cast(xr_u2, dq[1]);
+            const xr_u4 bop = {b0[0], b0[1], b1[0], b1[1]};
+            xr_f4* rb = red + buf * (NW * TO * 64);
+#pragma unroll
+            for (int t = 0; t < TO; ++t) rb[(w * TO + t) * 64 + lane] = xr_mfma<T>(wpf[t], bop, (xr_f4){0.f, 0.f, 0.f, 0.f});
+            __syncthreads();
+            xr_f4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (w < TO) {
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) acc += rb[(ww * TO + w) * 64 + lane];
+            }
+            xr_f4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(acc[i], fsc[i], fsh[i]);
+            v += __builtin_convertvector(__builtin_bit_cast(t4, resv), xr_f4);   // (zeros without a residual)
+            const t4 o = __builtin_convertvector(v, t4);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(xr_u2, o), osrc,
+                                                  flive ? (((unsigned)yo * (unsigned)a.Wo + (unsigned)xo) * (unsigned)a.ld_out + (unsigned)fco) * 2u : XR_DEAD, 0, 0);
+            buf ^= 1;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { ring[j][0] = ring[j][1]; ring[j][1] = ec[j]; }
+    };
+    constexpr std::true_type Y{};
+    constexpr std::false_type N{};
+    if constexpr (S == 2) {
+        row(N, 0, 0, xa, xb);
+        for (int i = 0; i < nout; ++i) {
+            row(N, 2 * i + 1, 0, xb, xa);
+            row(Y, 2 * i + 2, yo0 + i, xa, xb);
+        }
+    } else {
+        row(N, 0, 0, xa, xb);
+        row(N, 1, 0, xb, xa);
+        int i = 0;
+        for (; i + 1 < nout; i += 2) {
+            row(Y, i + 2, yo0 + i, xa, xb);
+            row(Y, i + 3, yo0 + i + 1, xb, xa);
+        }
+        if (i < nout) row(Y, i + 2, yo0 + i, xa, xb);
+    }
+}
+
+template <class T, int S, int ACT, int NC, int TO, int NW>
+static int launch_mbhr(const MbhrArgs& a0, int batch, int want_segs, hipStream_t s) {
+    MbhrArgs a = a0;
+    constexpr int NOUT = (16 - 3) / S + 1;
+    constexpr int MW = (NW <= 6 && S == 2) ? 3 : 2;   // (measured allocations: 161-180 registers for the one-chunk blocks - three waves per SIMD take 168)
+    static_assert(NW <= 4 * MW, "the workgroup's waves must fit one CU");
+    a.strips = (a.Wo + NOUT - 1) / NOUT;
+    const int walks = batch * a.strips;
+    int segs = (2 * 1024 + walks * NW - 1) / (walks * NW);
+    const int max_segs = (a.Ho + 5) / 6;
+    if (segs > max_segs) segs = max_segs;
+    if (segs < 1) segs = 1;
+    if (want_segs > 0) segs = want_segs < a.Ho ? want_segs : a.Ho;
+    a.seg_rows = (a.Ho + segs - 1) / segs;
+    a.segs = (a.Ho + a.seg_rows - 1) / a.seg_rows;
+    const size_t lds = (size_t)2 * NW * TO * 64 * 16;
+    static char nm[64];
+    static const int nm_len = snprintf(nm, sizeof(nm), "mbhr_kernel<%s,%d,%d,%d,%d,%d,%d>", yr_dtype_name(yr_elem<T>::dtype), S, ACT, NC, TO, NW, MW);
+    (void)nm_len;
+    yr_note_kernel(nm);
+    auto kern = mbhr_kernel<T, S, ACT, NC, TO, NW, MW>;
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        YR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(batch * a.strips * a.segs)), dim3(64 * NW), lds, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
+// the whole-block register-chained form is built for: 3x3, at most 16 expanded tiles, cin <= 64, cout <= 80
+bool yr_mbhr_takes(const yr_op& op) {
+    return op.kind == YR_OP_MBH && (op.dtype == YR_BF16 || op.dtype == YR_F16) && (op.k & 0xff) == 3 && (op.stride == 1 || op.stride == 2) &&
+           (op.act == YR_ACT_RELU6 || op.act == YR_ACT_SWISH) && op.cin % 8 == 0 && op.cin <= 64 && op.se_reduced % 16 == 0 && op.se_reduced <= 256 &&
+           op.cout % 4 == 0 && op.cout <= 80 && op.nsrc == 1 && op.out_ld % 4 == 0;
+}
+
+template <class T, int S, int ACT>
+static int launch_mbhr_shape(const MbhrArgs& a, int batch, int segs, hipStream_t s) {
+    const int nc = a.KP / 32, to = (a.Cout + 15) / 16, nw = (a.T + 1) / 2;
+#define HR_CASE(NCV, TOV, NWV) if (nc == NCV && to == TOV && nw == NWV) return launch_mbhr<T, S, ACT, NCV, TOV, NWV>(a, batch, segs, s);
+    // (measured, tools/mbhr_probe.py: the five-wave workgroups of the 144-channel blocks - 24 -> 144 -> 24 / 32 / 48 - lose to the
+    // LDS-tiled kernels, 0.29 vs 0.25 ms and 0.44 vs 0.33 ms: one such workgroup per CU at two waves per SIMD; not built)
+    HR_CASE(1, 2, 3)    // 16 -> 96 -> 24 (MobileNetV2 block_1, lite0 stage 2 entry): 0.36 -> 0.24 ms at batch 128
+    HR_CASE(1, 2, 6)    // 32 -> 192 -> 32 (lite3 stage 2): 0.23 -> 0.18 ms at batch 32
+    HR_CASE(1, 3, 6)    // 32 -> 192 -> 48
+    HR_CASE(2, 5, 8)    // 40 -> 240 -> 80 (lite0 stage 4 entry): 0.16 -> 0.075 ms
+    HR_CASE(2, 3, 8)    // 40 -> 240 -> 40
+#undef HR_CASE
+    yr_set_error("mbhr: block %d -> %d -> %d is not built", a.Cin, a.T * 16, a.Cout);
+    return YR_ERR_ARG;
+}
+
+bool yr_mbhr_built(const yr_op& op) {
+    if (!yr_mbhr_takes(op)) return false;
+    const int nc = yr_round_up(op.cin, 32) / 32, to = (op.cout + 15) / 16, nw = (op.se_reduced / 16 + 1) / 2;
+    const int key = nc * 10000 + to * 100 + nw;
+    return key == 10203 || key == 10206 || key == 10306 || key == 20508 || key == 20308;
+}
+
+template <class T>
+static int launch_mbhr_t(const yr_op& op, int batch, int segs, hipStream_t s) {
+    const yr_src& in = op.src[0];
+    MbhrArgs a;
+    a.x = in.ptr; a.out = op.out; a.we = op.wgt; a.prm = op.wgt2; a.wp = op.b1; a.sp = op.b2; a.hp = op.b2 + yr_round_up(op.cout, 8);
+    a.H = in.h; a.W = in.w; a.Ho = op.h; a.Wo = op.w; a.Cin = in.c; a.CexpP = yr_round_up(op.se_reduced, 32); a.KP = yr_round_up(in.c, 32);
+    a.Cout = op.cout; a.ld_in = in.ld; a.ld_out = op.out_ld; a.T = op.se_reduced / 16; a.has_res = op.res != nullptr;
+    const int pth = (a.Ho - 1) * op.stride + 3 - in.h, ptw = (a.Wo - 1) * op.stride + 3 - in.w;
+    a.pad_t = (pth > 0 ? pth : 0) / 2; a.pad_l = (ptw > 0 ? ptw : 0) / 2;
+    a.strips = a.segs = a.seg_rows = 0;
+    if (op.act == YR_ACT_RELU6) return op.stride == 1 ? launch_mbhr_shape<T, 1, 0>(a, batch, segs, s) : launch_mbhr_shape<T, 2, 0>(a, batch, segs, s);
+    return op.stride == 1 ? launch_mbhr_shape<T, 1, 1>(a, batch, segs, s) : launch_mbhr_shape<T, 2, 1>(a, batch, segs, s);
+}
+
+// Whether the register-chained form is what a plain launch (no forced tile) of this MBH / MBX op runs.  The choice is by SHAPE,
+// never by the tuner (which only picks the row segments): the two forms round differently (the LDS-tiled mbn_h.hip keeps the
+// expanded tile in the 16-bit type, the accumulation orders differ), and a batch must equal its images run one by one.
+bool yr_mbxr_takes(const yr_op& op);
+bool yr_mbh_prefers_chained(const yr_op& op) {
+    static const bool mbxr_on = !(getenv("YOLORET_MBXR") && atoi(getenv("YOLORET_MBXR")) == 0);
+    static const bool mbhr_on = !(getenv("YOLORET_MBHR") && atoi(getenv("YOLORET_MBHR")) == 0);
+    if (((op.k >> 8) & 0xff) != 0) return ((op.k >> 8) & 0xff) == 255;
+    return op.kind == YR_OP_MBX ? (mbxr_on && yr_mbxr_takes(op)) : (mbhr_on && yr_mbhr_built(op));
+}
+
+int yr_launch_mbhr(const yr_op& op, int batch, int segs, hipStream_t s) {
+    YR_REQUIRE(yr_mbhr_built(op), "mbhr: the register-chained whole-block form is not built for this op");
+    return op.dtype == YR_BF16 ? launch_mbhr_t<yr_bf16>(op, batch, segs, s) : launch_mbhr_t<yr_f16>(op, batch, segs, s);
+}
+
 // whether the register-chained form is built for this YR_OP_MBX op (mbh.hip asks before it dispatches here)
 bool yr_mbxr_takes(const yr_op& op) {
     const int K = op.k & 0xff;

@@ -456,18 +456,21 @@ extern "C" int yr_autotune(yr_handle* h, const float* images, int batch, float* 
             // fused 16-bit block: time a fixed list of output tiles (runs of 4 along x: tw % 4 == 0); tiles the op
             // cannot take (too many pixels for its accumulators, LDS footprint) are refused by the launcher and skipped
             static const int tiles[][2] = {{4, 8}, {8, 4}, {7, 4}, {7, 8}, {8, 8}, {13, 4}, {4, 16}, {8, 16}, {7, 16}, {13, 8},
-                                           {16, 8}, {13, 16}, {8, 12}, {7, 12}, {13, 12}, {16, 12}, {16, 16}, {4, 12}, {6, 8},
-                                           // YR_OP_MBX: the row-walking register-chained form (mbxr_h.hip), 1 .. 6 row segments per strip
-                                           {255, 1}, {255, 2}, {255, 3}, {255, 4}, {255, 6}};
+                                           {16, 8}, {13, 16}, {8, 12}, {7, 12}, {13, 12}, {16, 12}, {16, 16}, {4, 12}, {6, 8}};
+            // ops that run the row-walking register-chained form (mbxr_h.hip; chosen by shape): 1 .. 6 row segments per strip
+            static const int chained[][2] = {{255, 1}, {255, 2}, {255, 3}, {255, 4}, {255, 6}};
             yr_op op;
             rc = resolve_op(h, i, batch, ext, static_cast<char*>(workspace), &op);
             if (rc) break;
             const int kk = op.k & 0xff;
             float best_ms = 1e30f;
             int best_cfg = 0;
+            const bool ch = yr_mbh_prefers_chained(op);
+            const int (*cand)[2] = ch ? chained : tiles;
+            const int ncand = ch ? (int)(sizeof(chained) / sizeof(chained[0])) : (int)(sizeof(tiles) / sizeof(tiles[0]));
             for (int pass = 0; pass < 2; ++pass)                 // two passes, minimum: one noisy sample must not decide
-                for (int c = -1; c < (int)(sizeof(tiles) / sizeof(tiles[0])); ++c) {
-                    const int cfg = c < 0 ? 0 : (tiles[c][0] << 8) | (tiles[c][1] << 16);
+                for (int c = -1; c < ncand; ++c) {
+                    const int cfg = c < 0 ? 0 : (cand[c][0] << 8) | (cand[c][1] << 16);
                     op.k = kk | cfg;
                     if (dispatch(op, batch, s) != YR_OK) continue;          // warm-up / validity
                     YR_CHECK_HIP(hipEventRecord(e0, s));
