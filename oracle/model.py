@@ -4,9 +4,12 @@ Test infrastructure only (see ``oracle/__init__.py``).  Follows, function by
 function, /root/reference/code/yolo3/model.py, .../efficientnet.py and the
 third-party ``tf.keras.applications.MobileNetV2`` graph.
 All tensors NHWC; ``P`` is a parameter provider (``oracle.params.ParamStore``).
-``P.store(x)`` marks where a fused op of the product writes its result to memory: the identity for
-the float32 oracle, a rounding to bfloat16 / float16 for ``oracle.params.QuantStore`` (the emulation the
-16-bit configs are measured against; the reference itself has no reduced-precision mode).
+``P.store(x)`` marks the output of every convolution (+ BN + activation), gate and merge of the GRAPH - the places
+where the unfused layer-by-layer execution holds a tensor in memory: the identity for the float32 oracle, a rounding
+to bfloat16 / float16 for ``oracle.params.QuantStore`` (the emulation the 16-bit configs are measured against; the
+reference itself has no reduced-precision mode).  The placement follows the reference's layers, not the product's
+fusion boundaries; ``P.entry`` (image + stem kernel) is the one point that depends on the plan under test, and the
+test passes that in (``QuantStore(round_entry=...)``).
 
 Layer names: MobileNetV2 layers use the Keras names (``Conv1``, ``bn_Conv1``,
 ``expanded_conv_*``, ``block_{b}_{expand,depthwise,project}[_BN]``); layers the
@@ -153,8 +156,7 @@ def efficientnet(P, x, width, depth, lite=False, last_stage=6):
     act = nn.relu6 if lite else nn.swish
     stem = round_filters(32, width)
     w = P.conv('stem_conv', 3, 3, stem)
-    if lite:   # (the SE-free entry is one fused op of the product; the squeeze-excite networks' stem stays float32)
-        x, w = P.entry(x, w)
+    x, w = P.entry(x, w)
     x = nn.conv2d(x, w, stride=2, padding='same')
     x = P.store(act(_bn(P, 'stem_BN', x)))
     acts = {}

@@ -81,7 +81,7 @@ class ParamStore:
 
     @staticmethod
     def entry(x, w):
-        """The image and the stem kernel as the fused network entry (stem + block 0) takes them: float32 as they are."""
+        """The image and the stem kernel as the network's first convolution takes them: float32 as they are."""
         return x, w
 
 
@@ -102,9 +102,15 @@ class QuantStore(ParamStore):
     activations are rounded to `dtype` wherever a fused op stores them and the 1x1-convolution kernels (the MFMA
     operands; not the SE FCs, which stay float32) are rounded once.  Arithmetic in between is float32."""
 
-    def __init__(self, seed=1234, recipe='conditioned', dtype='bf16'):
+    def __init__(self, seed=1234, recipe='conditioned', dtype='bf16', round_entry=False):
+        """round_entry: whether the image and the stem kernel are rounded too - a property of the plan UNDER TEST (its network
+        entry runs on the 16-bit matrix pipe or on the float32 pipe), so the test passes it in (tests/util.py:
+        entry_on_matrix_pipe(model)); the oracle's graph code knows nothing of the product's kernels.  Everything else is the
+        UNFUSED placement: one rounding at every convolution / gate / merge output of the graph, whatever the product fuses
+        (a fused kernel keeps intermediates in float32: it can only be more accurate than this, never less)."""
         super().__init__(seed, recipe)
         self.dtype = dtype
+        self.round_entry = bool(round_entry)
 
     def store(self, x):
         return round16(x, self.dtype) if x.dtype == np.float32 else x
@@ -116,9 +122,9 @@ class QuantStore(ParamStore):
         return w
 
     def entry(self, x, w):
-        """The fused network entry of a 16-bit plan runs its stem on the matrix pipe (stemblock_h.hip): image and stem
-        kernel are MFMA operands like every 1x1 convolution's (decoded uint8 pixels are exact in either type)."""
-        return round16(x, self.dtype), round16(w, self.dtype)
+        """Image and stem kernel as the network entry takes them: rounded like every 1x1 convolution's operands when the plan
+        under test runs its stem on the matrix pipe (round_entry; decoded uint8 pixels are exact in either type), else as is."""
+        return (round16(x, self.dtype), round16(w, self.dtype)) if self.round_entry else (x, w)
 
 
 def synthetic_images(batch, h, w, seed=20240416):

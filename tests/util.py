@@ -88,3 +88,11 @@ def assert_rounded_once(got, ref64, dt, what, slack=2e-5):
     bad = np.abs(got - ref) > tol
     assert not bad.any(), '%s: %d of %d beyond half an ulp; worst |d|/tol = %.2f' % (
         what, bad.sum(), bad.size, float((np.abs(got - ref) / tol).max()))
+
+
+def entry_on_matrix_pipe(model):
+    """Whether the plan's network entry takes image and stem kernel as 16-bit MFMA operands (stemblock_h.hip: a STEMBLOCK op in
+    the matrix-pipe layout, which carries BN `scale` rows) - what QuantStore(round_entry=...) must emulate for this plan."""
+    rt = _rt()
+    op = model.plan.ops[0]
+    return model.plan.dtype != 0 and op.kind == rt.OP_STEMBLOCK and 'scale' in op.params

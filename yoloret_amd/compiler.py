@@ -392,10 +392,10 @@ def fold_projection_into_consumers(ops, output_buf_ids):
         rd = readers.get(id(P.out), [])
         if (P.kind != rt.OP_POINTWISE or P.act != 'none' or 'scale' not in P.params or P.res is not None or len(P.srcs) != 1
                 or P.srcs[0].xform != 'identity' or P.out.external_slot >= 0 or P.out.id in output_buf_ids or not rd
-                or (P.h == 1 and P.w == 1) or P.dtype != 0 or getattr(P, 'accounted_in', None)):
+                or (P.h == 1 and P.w == 1) or getattr(P, 'accounted_in', None)):
             continue
         if any(s is None or C.kind != rt.OP_POINTWISE or len(C.srcs) != 1 or s.xform != 'identity' or C.gate is not None
-               or C.res is not None or s.c != P.cout or C.dtype != 0 or id(C) in repl for C, s in rd):
+               or C.res is not None or s.c != P.cout or C.dtype != P.dtype or id(C) in repl for C, s in rd):
             continue
         cin, cp = P.cin, P.cout
         if sum(cin * C.cout for C, _ in rd) > FOLD_PROJ_MAX_RATIO * (cin * cp + sum(cp * C.cout for C, _ in rd)):
@@ -403,7 +403,7 @@ def fold_projection_into_consumers(ops, output_buf_ids):
         pw, psc, psh = P.params['wgt'][1], P.params['scale'][1], P.params['shift'][1]
         for n, (C, s) in enumerate(rd):
             m = OpRec(rt.OP_POINTWISE, C.name, act=C.act, h=C.h, w=C.w, cin=cin, cout=C.cout, srcs=[Seg(P.srcs[0].buf, P.srcs[0].c, 'identity')],
-                      out=C.out, gate=P.gate, macs=C.macs + (P.macs if n == 0 else 0), dtype=0)
+                      out=C.out, gate=P.gate, macs=C.macs + (P.macs if n == 0 else 0), dtype=P.dtype)
             cw = C.params['wgt'][1]
             csc = C.params['scale'][1] if 'scale' in C.params else None
             csh = C.params['shift'][1] if 'shift' in C.params else None
@@ -416,7 +416,7 @@ def fold_projection_into_consumers(ops, output_buf_ids):
                 if csc is not None:
                     b = csc(wd).astype(np.float64) * b + csh(wd).astype(np.float64)
                 return b.astype(np.float32)
-            m.params = {'wgt': (P.params['wgt'][0][:0] + (C.cout, P.params['wgt'][0][1]), wgt, 0),
+            m.params = {'wgt': (P.params['wgt'][0][:0] + (C.cout, P.params['wgt'][0][1]), wgt, P.dtype),   # (16-bit plans: ONE rounding of the composed matrix)
                         'scale': ((C.cout,), csc if csc is not None else (lambda wd, n_=C.cout: np.ones(n_, np.float32))),
                         'shift': ((C.cout,), shift)}
             # conv-granular accounting stays that of the convolutions replaced: the first consumer carries the
@@ -1188,7 +1188,7 @@ class Compiler:
             outs.append(v.segs[0].buf)
         ops = self.ops
         if self.fuse:
-            if FOLD_PROJ and self.dtype == 0:
+            if FOLD_PROJ:
                 ops = fold_projection_into_consumers(ops, set(b.id for b in outs))
             if HOIST_UPSAMPLE:
                 ops = hoist_upsampled_sources(ops, self.bufs)
