@@ -73,14 +73,17 @@ def test_stemblock(dev, hw, c1, cout, act, dt):
         assert_rounded_once(from_dev16(out, dt, cout), ref, dt, 'stemblock %s' % dt, slack=3e-5)
 
 
-@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f16', 'bf16-mfma', 'f16-mfma'])
 @pytest.mark.parametrize('with_sums', [True, False])
 @pytest.mark.parametrize('hw,c1,act', [((64, 64), 32, 'swish'), ((62, 90), 40, 'swish'), ((30, 22), 48, 'relu6'), ((416, 416), 32, 'swish')])
 def test_stem_plus_depthwise(dev, hw, c1, act, with_sums, dt):
     """YR_OP_STEMBLOCK without a projection (the entry of the squeeze-excite EfficientNets, efficientnet.py:636-645 + the
     first block's depthwise conv): the depthwise map, one rounding at the store, plus the per-tile channel sums of the
-    STORED values (the squeeze), every row of the sum buffer written."""
+    STORED values (the squeeze), every row of the sum buffer written.  '-mfma': the matrix-pipe form (k = 3 | 1 << 8,
+    mbxr_h.hip: stemxr_kernel): image and (BN-scaled) stem kernel are 16-bit MFMA operands - the reference rounds them."""
     from yoloret_amd import runtime as rt
+    mfma = dt.endswith('-mfma')
+    dt = dt.split('-')[0]
     rng = np.random.default_rng(zlib.crc32(str((hw, c1)).encode()))
     b = 2
     x = rng.random((b, hw[0], hw[1], 3), dtype=np.float32)
@@ -89,7 +92,11 @@ def test_stem_plus_depthwise(dev, hw, c1, act, with_sums, dt):
     ss, hs = rng.uniform(0.5, 1.5, c1).astype(np.float32), rng.normal(0, 0.3, c1).astype(np.float32)
     wd = (rng.standard_normal((3, 3, c1)) * np.sqrt(2.0 / 9)).astype(np.float32)
     sd, hd = rng.uniform(0.5, 1.5, c1).astype(np.float32), rng.normal(0, 0.3, c1).astype(np.float32)
-    t = actf(nn.conv2d(x.astype(np.float64), ws.astype(np.float64), 2, 'same') * ss + hs)
+    if mfma:
+        from tests.util import q16
+        t = actf(nn.conv2d(q16(x, dt).astype(np.float64), q16((ws * ss).astype(np.float32), dt).astype(np.float64), 2, 'same') + hs)
+    else:
+        t = actf(nn.conv2d(x.astype(np.float64), ws.astype(np.float64), 2, 'same') * ss + hs)
     ref = actf(nn.depthwise(t, wd.astype(np.float64), 1, 'same') * sd + hd)
     c1p = round_up(c1, 4)
 
@@ -107,7 +114,7 @@ def test_stem_plus_depthwise(dev, hw, c1, act, with_sums, dt):
     part = torch.full((b, rows, ldo), float('nan'), dtype=torch.float32, device=dev)
     op = rt.new_op(rt.OP_STEMBLOCK, act)
     op.dtype = op.out_dtype = did
-    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc, op.se_reduced = ho, wo, 3, c1, 3, 2, 1, c1
+    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc, op.se_reduced = ho, wo, 3, c1, 3 | (1 << 8 if mfma else 0), 2, 1, c1
     op.src[0] = rt.make_src(xd, c=3, ld=3)
     op.wgt, op.wgt2 = keep[0].data_ptr(), keep[1].data_ptr()
     op.out, op.out_ld = out.data_ptr(), ldo

@@ -92,7 +92,7 @@ def assert_rounded_once(got, ref64, dt, what, slack=2e-5):
 
 def entry_on_matrix_pipe(model):
     """Whether the plan's network entry takes image and stem kernel as 16-bit MFMA operands (stemblock_h.hip: a STEMBLOCK op in
-    the matrix-pipe layout, which carries BN `scale` rows) - what QuantStore(round_entry=...) must emulate for this plan."""
+    the matrix-pipe layout, which carries BN `scale` rows, or the stem + depthwise entry asked for in its matrix-pipe form, k = 3 | 1 << 8) - what QuantStore(round_entry=...) must emulate for this plan."""
     rt = _rt()
     op = model.plan.ops[0]
-    return model.plan.dtype != 0 and op.kind == rt.OP_STEMBLOCK and 'scale' in op.params
+    return model.plan.dtype != 0 and op.kind == rt.OP_STEMBLOCK and ('scale' in op.params or ((op.k >> 8) & 0xff) == 1)

@@ -317,6 +317,7 @@ MBH_K5_SMALL_CEXP = int(os.environ.get('YOLORET_MBH_K5_SMALL_CEXP', '200'))
 MBX_K5_MAX_CEXP = int(os.environ.get('YOLORET_MBX_K5_MAX_CEXP', '0'))
 MBH_K3_MAX_CEXP = int(os.environ.get('YOLORET_MBH_K3_MAX_CEXP', '1000000'))   # the same switch for 3x3 stride-1 blocks
 FUSE_STEMDW = os.environ.get('YOLORET_FUSE_STEMDW', '1') != '0'   # stem + first depthwise of the SE EfficientNets in one kernel
+FUSE_STEMDW_MFMA = os.environ.get('YOLORET_FUSE_STEMDW_MFMA', '1') != '0'   # ... on the 16-bit matrix pipe, register-chained (16-bit plans)
 FUSE_MBX = os.environ.get('YOLORET_FUSE_MBX', '1') != '0'   # 16-bit plans: expand + depthwise of squeeze-excite MBConv blocks in one kernel
 MBH_ACTS = ('relu6', 'swish')   # (swish in the fused 16-bit kernels: hardware exp2 / rcp, no register spills)
 
@@ -791,7 +792,12 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                 else:
                     part.h, part.elems = rows, rows * part.w * part.ld
                     part.bytes = part.elems * rt.ESIZE[part.dtype]
-                m = OpRec(rt.OP_STEMBLOCK, e.name + '_dw', act=e.act, h=d.h, w=d.w, cin=3, cout=c1, k=3, stride=2,
+                # the matrix-pipe form of this entry (mbxr_h.hip: stemxr_kernel; float32 image of even size, at most 48 stem channels):
+                # asked for by the PLAN (k = 3 | 1 << 8), so that every batch size rounds the same way
+                src0 = e.srcs[0].buf
+                mfma_entry = (FUSE_STEMDW_MFMA and src0.dtype == 0 and src0.h % 2 == 0 and src0.w % 2 == 0 and c1 <= 48 and c1 % 4 == 0
+                              and e.act in ('relu6', 'swish') and d.out.ld % 4 == 0)
+                m = OpRec(rt.OP_STEMBLOCK, e.name + '_dw', act=e.act, h=d.h, w=d.w, cin=3, cout=c1, k=3 | (1 << 8 if mfma_entry else 0), stride=2,
                           se_reduced=c1, srcs=[e.srcs[0]], out=d.out, gate=part, macs=e.macs + d.macs, dtype=dtype)
                 m.fused = [e, d]
 

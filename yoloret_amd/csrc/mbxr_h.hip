@@ -296,6 +296,208 @@ static int launch_mbxr_nc(const MbxrArgs& a, int batch, int segs, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// The network entry of the squeeze-excite EfficientNets in the same form (YR_OP_STEMBLOCK without a projection: stem Conv2D
+// 3x3 stride 2 + BN + act -> stage-1 depthwise 3x3 + BN + act, the map stored, its squeeze sums per 14 x 14 tile; reference
+// code/yolo3/efficientnet.py:636-645 and the first MBConvBlock, :467-536 with expand_ratio 1).  The stem is ONE
+// v_mfma_f32_16x16x32 per 16 stem channels: K = 27 taps in the order of stemblock_h.hip - k group g < 3 = image row 2y + g, the
+// first 8 of its 9 (kx, c) values = 32 contiguous bytes of the image; group 3 = value 8 of the three rows + zeros - the image
+// rounded to the 16-bit type like every MFMA operand.  Parameters as the float32-pipe kernel takes them (stemblock.hip: packed
+// per channel pair, BN scale folded in); the A fragment is gathered (and rounded) from them once per wave.  Even image sizes,
+// float32 images; a wave = one 14 x 14 output tile (strip of 14 columns x 14 rows: one row of the squeeze-sum buffer), all C1
+// channels (NT = 2 | 3 tiles).  Was: stemblock_kernel on the float32 pipe, 0.52 ms per 128 images at 416 (B0).
+struct StemxrArgs {
+    const float* img; void* out; const float* ws; const float* wd; float* part;
+    int Hi, Wi, Ho, Wo, C1, ld_out, ld_part, tiles_x, tiles_y, nwaves;
+};
+
+template <class T, int NT, int ACT>
+__global__ __launch_bounds__(256, 2) void stemxr_kernel(StemxrArgs a) {
+    const int lane = threadIdx.x & 63, px = lane & 15, mg = lane >> 4;
+    int gw = (int)yr_xcd_swizzle(blockIdx.x, gridDim.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (gw >= a.nwaves) return;
+    const int tx = gw % a.tiles_x; gw /= a.tiles_x;
+    const int ty = gw % a.tiles_y;
+    const int b = gw / a.tiles_y;
+    const int yo0 = 14 * ty, yo1 = min(yo0 + 14, a.Ho);
+    const int xs = 14 * tx - 1 + px;                       // this lane's stem-output column (= depthwise input column)
+    const int xsc = min(max(xs, 0), a.Wo - 1);
+    constexpr float HI = ACT == 0 ? 6.f : 1.f;
+    const float hi = (xs >= 0 && xs < a.Wo) ? HI : 0.f;
+    const int xo = 14 * tx + px - 1;
+    const bool out_lane = px >= 1 && px <= 14 && xo < a.Wo;
+    const float omask = out_lane ? 1.f : 0.f;
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    typedef T t2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+
+    // ---- stationary: stem A fragments (gathered from the pair-packed float32 rows, rounded), shifts, depthwise taps
+    xr_u4 aw[NT];
+    xr_f4 sh[NT], dh[NT], tp[NT][9], ssum[NT];
+    unsigned ooff[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        {   // A: lane (m = px, k group mg): W[16 j + m][k], k = 9 mg + i (mg < 3, i < 8) | taps 8, 17, 26 (mg == 3)
+            const int ch = 16 * j + px;
+            const float* wr = a.ws + (size_t)(ch >> 1) * 58 + (ch & 1);
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = mg < 3 ? 9 * mg + i : (i < 3 ? 9 * i + 8 : 0);
+                v[i] = (ch < a.C1 && (mg < 3 || i < 3)) ? wr[2 * k] : 0.f;
+            }
+            unsigned u[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) u[i] = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){v[2 * i], v[2 * i + 1]}, t2));
+            aw[j] = (xr_u4){u[0], u[1], u[2], u[3]};
+        }
+        const int ch = 16 * j + 4 * mg;                    // this lane's 4 channels of tile j in the MFMA result
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = ch + i;
+            const bool live = c < a.C1;
+            const float* wr = a.ws + (size_t)(c >> 1) * 58 + (c & 1);
+            const float* dr = a.wd + (size_t)(c >> 1) * 22 + (c & 1);
+            sh[j][i] = live ? wr[56] : 0.f;
+            dh[j][i] = live ? dr[20] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) tp[j][q][i] = live ? dr[2 * q] : 0.f;
+        }
+        ssum[j] = (xr_f4){0.f, 0.f, 0.f, 0.f};
+        ooff[j] = (out_lane && ch < a.C1) ? (unsigned)ch * 2u : XR_DEAD;
+    }
+    const xr_rsrc isrc = xr_make_rsrc(a.img + (size_t)b * a.Hi * a.Wi * 3, (unsigned)(a.Hi * a.Wi * 3) * 4u);
+    const xr_rsrc osrc = xr_make_rsrc(reinterpret_cast<T*>(a.out) + (size_t)b * a.Ho * a.Wo * a.ld_out, (unsigned)(a.Ho * a.Wo * a.ld_out) * 2u);
+    const unsigned irow = (unsigned)a.Wi * 12u;            // bytes per image row
+    const unsigned icol = (unsigned)(2 * xsc) * 12u;       // the window's first byte within a row (even sizes: no left padding)
+    const bool last_col = 2 * xsc + 2 >= a.Wi;             // kx = 2 lies beyond the row: values 6, 7 (k groups 0..2) and group 3 are padding
+    // the B operand of stem row ys for this lane: 8 image values of its k group, rounded
+    auto load_b = [&](int ys) -> xr_u4 {
+        const int ysc = min(max(ys, 0), a.Ho - 1);
+        float v[8];
+        if (mg < 3) {
+            const int iy = 2 * ysc + mg;
+            const unsigned off = iy < a.Hi ? (unsigned)iy * irow + icol : XR_DEAD;
+            const xr_f4 lo = __builtin_bit_cast(xr_f4, __builtin_amdgcn_raw_buffer_load_b128(isrc, off, 0, 0));
+            const xr_f4 hi4 = __builtin_bit_cast(xr_f4, __builtin_amdgcn_raw_buffer_load_b128(isrc, off == XR_DEAD ? XR_DEAD : off + 16u, 0, 0));
+            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi4[0]; v[5] = hi4[1];
+            v[6] = last_col ? 0.f : hi4[2]; v[7] = last_col ? 0.f : hi4[3];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int iy = 2 * ysc + i;
+                const unsigned off = (iy < a.Hi && !last_col) ? (unsigned)iy * irow + icol + 32u : XR_DEAD;
+                v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(isrc, off, 0, 0));
+            }
+            v[3] = v[4] = v[5] = v[6] = v[7] = 0.f;
+        }
+        unsigned u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){v[2 * i], v[2 * i + 1]}, t2));
+        return (xr_u4){u[0], u[1], u[2], u[3]};
+    };
+    const int rbeg = yo0 - 1, nout = yo1 - yo0;
+    xr_f4 ring[NT][2];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { ring[j][0] = (xr_f4){0.f, 0.f, 0.f, 0.f}; ring[j][1] = ring[j][0]; }
+    xr_u4 bcur = load_b(rbeg);
+    for (int k = 0; k < nout + 2; ++k) {
+        const int ys = rbeg + k;
+        const xr_u4 bnext = load_b(ys + 1);
+        const float hr = (ys >= 0 && ys < a.Ho) ? hi : 0.f;
+        xr_f4 ec[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const xr_f4 d = xr_mfma<T>(aw[j], bcur, sh[j]);       // (the BN shift is the accumulator's initial value)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ec[j][i] = xr_act<ACT>(d[i], hr);
+        }
+        if (k >= 2) {
+            const int yo = yo0 + k - 2;
+            const unsigned opix = ((unsigned)yo * (unsigned)a.Wo + (unsigned)xo) * (unsigned)a.ld_out * 2u;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                xr_f4 d = dh[j];
+                xr_row3(d, ring[j][0], tp[j][0], tp[j][1], tp[j][2]);
+                xr_row3(d, ring[j][1], tp[j][3], tp[j][4], tp[j][5]);
+                xr_row3(d, ec[j], tp[j][6], tp[j][7], tp[j][8]);
+                xr_f4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = xr_act<ACT>(d[i], HI);
+                const t4 o = __builtin_convertvector(v, t4);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(xr_u2, o), osrc, ooff[j] == XR_DEAD ? XR_DEAD : opix + ooff[j], 0, 0);
+                const xr_f4 stored = __builtin_convertvector(o, xr_f4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ssum[j][i] = __builtin_fmaf(stored[i], omask, ssum[j][i]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { ring[j][0] = ring[j][1]; ring[j][1] = ec[j]; }
+        bcur = bnext;
+    }
+    if (a.part != nullptr) {
+        const int prow = ty * a.tiles_x + tx;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            xr_f4 v = ssum[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] += __shfl_xor(v[i], 8, 16);
+                v[i] += __shfl_xor(v[i], 4, 16);
+                v[i] += __shfl_xor(v[i], 2, 16);
+                v[i] += __shfl_xor(v[i], 1, 16);
+            }
+            const int ch = 16 * j + 4 * mg;
+            if (px == 0 && ch < a.C1) {
+                float* p = a.part + ((size_t)b * a.tiles_x * a.tiles_y + prow) * a.ld_part + ch;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (ch + i < a.ld_part) p[i] = v[i];
+            }
+        }
+    }
+}
+
+// whether the matrix-pipe register-chained entry is built for this STEMBLOCK op (no projection, 16-bit output, float32 image,
+// even sizes, C1 <= 48, relu6 / swish)
+bool yr_stemxr_takes(const yr_op& op) {
+    return op.kind == YR_OP_STEMBLOCK && op.b1 == nullptr && (op.dtype == YR_BF16 || op.dtype == YR_F16) && op.out_dtype == op.dtype &&
+           op.nsrc == 1 && op.src[0].dtype == YR_F32 && op.src[0].c == 3 && op.src[0].ld == 3 && op.src[0].h % 2 == 0 && op.src[0].w % 2 == 0 &&
+           op.se_reduced <= 48 && op.se_reduced % 4 == 0 && op.cout == op.se_reduced && op.out_ld % 4 == 0 &&
+           (op.act == YR_ACT_RELU6 || op.act == YR_ACT_SWISH);
+}
+
+template <class T>
+static int launch_stemxr_t(const yr_op& op, int batch, hipStream_t s) {
+    const yr_src& in = op.src[0];
+    StemxrArgs a;
+    a.img = (const float*)in.ptr; a.out = op.out; a.ws = op.wgt; a.wd = op.wgt2;
+    a.part = const_cast<float*>(op.gate); a.ld_part = op.gate ? op.gate_ld : 0;
+    a.Hi = in.h; a.Wi = in.w; a.Ho = in.h / 2; a.Wo = in.w / 2; a.C1 = op.se_reduced; a.ld_out = op.out_ld;
+    a.tiles_x = (a.Wo + 13) / 14; a.tiles_y = (a.Ho + 13) / 14;
+    a.nwaves = batch * a.tiles_x * a.tiles_y;
+    const int nt = (a.C1 + 15) / 16, act = op.act == YR_ACT_RELU6 ? 0 : 1;
+    static char nm[48];
+    snprintf(nm, sizeof(nm), "stemxr_kernel<%s,%d,%d>", yr_dtype_name(yr_elem<T>::dtype), nt, act);
+    yr_note_kernel(nm);
+    const dim3 grid((unsigned)((a.nwaves + 3) / 4));
+#define SX_GO(NTV)                                                                                   \
+    do {                                                                                            \
+        if (act == 0) hipLaunchKernelGGL((stemxr_kernel<T, NTV, 0>), grid, dim3(256), 0, s, a);    \
+        else hipLaunchKernelGGL((stemxr_kernel<T, NTV, 1>), grid, dim3(256), 0, s, a);             \
+    } while (0)
+    if (nt == 2) SX_GO(2); else if (nt == 3) SX_GO(3); else SX_GO(1);
+#undef SX_GO
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
+int yr_launch_stemxr(const yr_op& op, int batch, hipStream_t s) {
+    YR_REQUIRE(yr_stemxr_takes(op), "stemxr: the matrix-pipe entry is not built for this op");
+    YR_REQUIRE(op.src[0].ptr && op.out && op.wgt && op.wgt2 && op.h == op.src[0].h / 2 && op.w == op.src[0].w / 2 && op.out_ld >= op.cout, "stemxr: bad arguments");
+    YR_REQUIRE(op.gate == nullptr || (op.gate_ld >= op.cout && ((uintptr_t)op.gate % 4) == 0), "stemxr: bad squeeze-sum buffer");
+    return op.dtype == YR_BF16 ? launch_stemxr_t<yr_bf16>(op, batch, s) : launch_stemxr_t<yr_f16>(op, batch, s);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // YR_OP_MBH in the same form: the WHOLE block - expand -> depthwise 3x3 -> project 1x1 + BN (+ residual) - for blocks of at
 // most 16 expanded tiles (the network fronts: MobileNetV2 block_1..6, EfficientNet-lite stage 2, lite0 stage 4 entry).  A
 // workgroup's NW waves share one strip segment; wave w owns the expanded tile PAIR (2w, 2w + 1) = one 32-deep k step of the

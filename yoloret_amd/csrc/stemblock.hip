@@ -343,7 +343,19 @@ static int launch_stemblock_t(const yr_op& op, int batch, hipStream_t s) {
 
 int yr_launch_stemblock_h(const yr_op& op, int batch, hipStream_t s);   // stemblock_h.hip: the matrix-pipe form of the 16-bit plans
 
-int yr_launch_stemblock(const yr_op& op, int batch, hipStream_t s) {
+bool yr_stemxr_takes(const yr_op& op);                                   // mbxr_h.hip: stem + first depthwise of the SE networks, matrix pipe
+int yr_launch_stemxr(const yr_op& op, int batch, hipStream_t s);
+
+int yr_launch_stemblock(const yr_op& op_in, int batch, hipStream_t s) {
+    yr_op op = op_in;
+    // k = 3 | 1 << 8: the plan asks for the matrix-pipe form of the stem + depthwise entry (image and stem kernel rounded to the
+    // 16-bit type like every MFMA operand: a property of the PLAN, compiler.FUSE_STEMDW_MFMA, so that every batch size runs the same)
+    const bool mfma_entry = ((op.k >> 8) & 0xff) == 1;
+    op.k &= 0xff;
+    if (mfma_entry) {
+        YR_REQUIRE(yr_stemxr_takes(op), "stemblock: the matrix-pipe stem + depthwise form (k = 3 | 1 << 8) is not built for this op");
+        return yr_launch_stemxr(op, batch, s);
+    }
     if (op.dtype != YR_F32 && op.scale != nullptr) return yr_launch_stemblock_h(op, batch, s);   // (the compiler's matrix-pipe parameter layout)
     return YR_BY_DTYPE(op.dtype, launch_stemblock_t, op, batch, s);
 }
