@@ -12,16 +12,16 @@ cd "$R" || exit 1
 O=gpurun_out/refresh
 mkdir -p $O
 db() { ls $O/$1/*.db 2>/dev/null | head -1; }
-WHAT=${*:-c2 c3 c4 c5 dist}
-ROUND=${ROUND:-03}
+WHAT=${*:-c2 c3 c4 c5 c3se c5se dist}
+ROUND=${ROUND:-04}
 
 one() {   # one <tag> <traffic-suffix> <sq: 0|1> <bench args...>
   local tag=$1 suf=$2 sq=$3; shift 3
   export YOLORET_TUNE_CACHE=$R/$O/tuned_$tag.json   # the first run tunes and saves; profiled runs reuse the table (no trial launches)
   rm -f $YOLORET_TUNE_CACHE
-  python bench.py "$@" --depth 1 --steps 3 --warmup 1 --no-cpu-baseline --no-latency --profile-iters 0 > /dev/null 2> $O/tune_$tag.err
+  python bench.py "$@" --depth 1 --steps 3 --warmup 1 --no-cpu-baseline --no-latency --no-other-configs --profile-iters 0 > /dev/null 2> $O/tune_$tag.err
   # ---- counters first (their traffic table is what the bench lines below quote as `traffic`)
-  local BP="python bench.py $* --depth 1 --steps 5 --warmup 2 --no-cpu-baseline --no-latency --profile-iters 0"
+  local BP="python bench.py $* --depth 1 --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-other-configs --profile-iters 0"
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pf_$tag -o pmc -- $BP > /dev/null 2> $O/pmc_$tag.err
   timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pw_$tag -o pmc -- $BP > /dev/null 2>> $O/pmc_$tag.err
   python tools/rocpd_summary.py pmc "$(db pf_$tag)" > $O/pmc_fetch_$tag.txt
@@ -36,12 +36,12 @@ one() {   # one <tag> <traffic-suffix> <sq: 0|1> <bench args...>
   fi
   # ---- the bench lines: as shipped (steps in flight), and with --depth 1 + the per-op table
   python bench.py "$@" $CPU > $O/bench_$tag.json 2> $O/bench_$tag.err
-  python bench.py "$@" --depth 1 --no-cpu-baseline --per-op > $O/bench_${tag}_depth1.json 2> $O/perop_$tag.txt
+  python bench.py "$@" --depth 1 --no-cpu-baseline --no-other-configs --per-op > $O/bench_${tag}_depth1.json 2> $O/perop_$tag.txt
   # ---- rocprofv3 kernel trace of the --depth 1 command (per-symbol averages == the live hipEvent figures) and of the shipped depth
-  local B1="python bench.py $* --depth 1 --no-cpu-baseline --no-latency"
+  local B1="python bench.py $* --depth 1 --no-cpu-baseline --no-latency --no-other-configs"
   timeout 600 rocprofv3 --kernel-trace --stats -d $O/ps_$tag -o stats -- $B1 > $O/bench_${tag}_under_rocprof.json 2> $O/rocprof_$tag.err
   python tools/rocpd_summary.py stats "$(db ps_$tag)" > $O/kernel_stats_$tag.txt
-  timeout 600 rocprofv3 --kernel-trace --stats -d $O/ps3_$tag -o stats -- python bench.py "$@" --no-cpu-baseline --no-latency > /dev/null 2>> $O/rocprof_$tag.err
+  timeout 600 rocprofv3 --kernel-trace --stats -d $O/ps3_$tag -o stats -- python bench.py "$@" --no-cpu-baseline --no-latency --no-other-configs > /dev/null 2>> $O/rocprof_$tag.err
   python tools/rocpd_summary.py stats "$(db ps3_$tag)" > $O/kernel_stats_${tag}_in_flight.txt
   rm -rf $O/ps_$tag $O/ps3_$tag $O/pf_$tag $O/pw_$tag $O/pq_$tag $O/pl_$tag
   unset YOLORET_TUNE_CACHE
@@ -53,11 +53,12 @@ for w in $WHAT; do
     c3) CPU="--no-cpu-baseline" one c3 _efficientnetb0lite_416_b128_bf16 1 --model efficientnetb0-lite --batch 128 --dtype bf16 ;;
     c4) CPU="--no-cpu-baseline" one c4 _mobilenetv2x14_512_b64_f32 0 --model mobilenetv2x14 --size 512 --batch 64 ;;
     c5) CPU="--no-cpu-baseline" one c5 _efficientnetb3lite_640_b32_f16 1 --model efficientnetb3-lite --size 640 --batch 32 --dtype f16 ;;
+    # the reference's own EfficientNets (squeeze-excite + swish, efficientnet.py:406-536), same batch / size / type as c3 / c5
+    c3se) CPU="--no-cpu-baseline" one c3se _efficientnetb0_416_b128_bf16 1 --model efficientnetb0 --batch 128 --dtype bf16 ;;
+    c5se) CPU="--no-cpu-baseline" one c5se _efficientnetb3_640_b32_f16 1 --model efficientnetb3 --size 640 --batch 32 --dtype f16 ;;
     dist)   # the N > 1 path with one rank: RCCL initialised, the all-gather of the records issued for real on its own stream
-      python bench.py --force-dist --no-cpu-baseline --no-latency > $O/bench_c2_force_dist.json 2> /dev/null
+      python bench.py --force-dist --no-cpu-baseline --no-latency --no-other-configs > $O/bench_c2_force_dist.json 2> /dev/null
       python bench.py --force-dist --depth 1 --no-cpu-baseline --no-latency > $O/bench_c2_force_dist_depth1.json 2> /dev/null
-      python bench.py --model efficientnetb0 --batch 128 --dtype bf16 --no-cpu-baseline > $O/bench_effb0_bf16.json 2> /dev/null
-      python bench.py --model efficientnetb3 --size 640 --batch 32 --dtype f16 --no-cpu-baseline > $O/bench_effb3_f16.json 2> /dev/null
       python bench.py --dtype bf16 --no-cpu-baseline > $O/bench_c2_bf16.json 2> /dev/null ;;
   esac
 done

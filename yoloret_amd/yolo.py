@@ -3,8 +3,9 @@
 structure, torch/NumPy instead of TensorFlow, all device arithmetic in libyoloret_hip.so.
 
 Differences that follow from the platform, not from taste:
-  * weights come from an ``.npz`` (``Model.save_weights``) or a dict; Keras ``.h5`` checkpoints need an offline
-    conversion (no h5py here; the reference's own checkpoints are not shipped - .MISSING_LARGE_BLOBS);
+  * weights: a Keras weights-only ``.h5`` checkpoint of the reference is read directly (``Model.load_weights`` -> the package's
+    own HDF5 subset reader ``h5lite.py`` + the Keras layer-name mapping ``keras_h5.py``; reference code/yolo.py:87), an ``.npz``
+    (``Model.save_weights``) or a dict work too; the reference's own checkpoints are not shipped (.MISSING_LARGE_BLOBS), so
     ``model_path='synthetic[:seed]'`` draws the seeded random weights used by the bench;
   * image bytes are decoded on the host with PIL (JPEG/PNG decode is not on the GPU path, SURVEY.md 8(f)-1);
     /255, bilinear letterbox resize and zero padding run in the HIP letterbox kernel;
