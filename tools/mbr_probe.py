@@ -20,11 +20,9 @@ BLOCKS = {   # name: (h, w, cin, cexp, cout, stride, residual), r03 time of the 
     'block_6': ((52, 52, 24, 144, 48, 2, False), 0.0845),
     'block_7': ((26, 26, 48, 288, 48, 1, True), 0.0835),
     'block_10': ((26, 26, 48, 288, 72, 1, False), 0.0850),
-    'half11': ((26, 26, 72, 224, 72, 1, True), 0.124),      # batch 128 = the grid of a 2-way channel split at batch 64
-    'quarter14': ((13, 13, 120, 192, 120, 1, True), 0.086),  # batch 256 = a 4-way split
 }
-BATCH = {'half11': 128, 'quarter14': 256}
-NWS = {'half11': [7], 'quarter14': [4], 'block_1': [1, 2], 'block_2': [3], 'block_3': [3], 'block_4': [3], 'block_6': [3], 'block_7': [6, 8], 'block_10': [6, 8]}
+BATCH = {}
+NWS = {'block_1': [1, 2], 'block_2': [3], 'block_3': [3], 'block_4': [3], 'block_6': [3], 'block_7': [6, 8], 'block_10': [6, 8]}
 
 
 def timed(op, b, n=30):

@@ -24,9 +24,30 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=o
 FLAGS_FILE = os.path.join(CSRC, '_obj', 'flags.txt')   # the flags the library on disk was built with
 
 
+def _fingerprint():
+    """sha256 over the flags and the CONTENT of every source and header: what the library on disk must have been built from.
+    (File times say nothing after a fresh checkout or a copy - round 3's _stale() compared mtimes.)"""
+    import hashlib
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h')))
+    deps += [os.path.join(HERE, '..', 'include', 'yoloret_hip.h'), os.path.abspath(__file__)]
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        h.update(open(d, 'rb').read())
+    return h.hexdigest()
+
+
+STAMP_FILE = os.path.join(CSRC, '_obj', 'fingerprint.txt')
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
+    try:
+        if open(STAMP_FILE).read().strip() == _fingerprint():
+            return False        # built from exactly these sources and flags, whatever the file times say
+    except OSError:
+        pass
     try:   # a library left behind by an experiment (YOLORET_HIPCC_FLAGS=-D...) is rebuilt, not shipped
         if open(FLAGS_FILE).read() != ' '.join(FLAGS):
             return True
@@ -118,6 +139,8 @@ def build(force=False, verbose=False):
     subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
     with open(FLAGS_FILE, 'w') as f:
         f.write(' '.join(FLAGS))
+    with open(STAMP_FILE, 'w') as f:
+        f.write(_fingerprint())
     return LIB
 
 

@@ -537,8 +537,6 @@ int yr_launch_mbr(const yr_op& op, int batch, hipStream_t s) {
     MBR_CASE(48, 288, 48, 1, 8, true)
     MBR_CASE(48, 288, 72, 1, 6, false)     // block_10
     MBR_CASE(48, 288, 72, 1, 8, false)
-    MBR_CASE(72, 224, 72, 1, 7, true)      // (experiment: half of block_11's expanded channels)
-    MBR_CASE(120, 192, 120, 1, 4, true)    // (experiment: a quarter of block_14's expanded channels)
 #undef MBR_CASE
     yr_set_error("mbr: block %d -> %d -> %d stride %d res %d (nw %d) is not built", in.c, op.se_reduced, op.cout, op.stride, (int)res, nw);
     return YR_ERR_ARG;
