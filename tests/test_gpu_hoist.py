@@ -209,3 +209,42 @@ def test_compiler_folds_head_projections_into_their_1x1_consumers(dev):
             assert_close(y.reshape(r.shape), r, 1e-4, 'graph with folded projections')
     for a, b in zip(*got):
         assert_close(a, b, 3e-5, 'folded vs unfolded plan')
+
+
+@pytest.mark.parametrize('model_name,dtype', [('mobilenetv2x75', 'f32'), ('efficientnetb0', 'f32')])
+def test_compiler_folds_the_rfcr_weighted_sum(dev, model_name, dtype):
+    """compiler.fold_weighted_sum: a0 up2(W1 x1) + a1 W2 x2 + a2 maxpool2(W3 x3) + a3 W4 maxpool4(x4) as ONE pointwise conv over
+    [up2(x1) | x2 | maxpool2(W3 x3) | maxpool4(x4)] with the weights [a0 W1 | a1 W2 | a2 I | a3 W4] (reference:
+    code/yolo3/model.py:117-137 WeightedSum, :146-168 rfcr_module).  The alphas are unconstrained in the reference: the test
+    makes the one behind the max-pool NEGATIVE (it must not be pulled through the maximum)."""
+    from oracle import model as om, params
+    from yoloret_amd import compiler, layers as L, runtime as rt
+    from yoloret_amd.yolo3.model import yolov3_body
+    m = yolov3_body(L.Input(shape=[128, 128, 3]), model_name, 3, num_classes=20)
+    names = [o.name for o in m.plan.ops]
+    assert 'rfcr_b3c' in names and not any(n in names for n in ('rfcr_b1c', 'rfcr_b2c', 'rfcr_b4c'))
+    ws = next(o for o in m.plan.ops if o.name == 'rfcr_wsum')
+    assert ws.kind == rt.OP_POINTWISE and getattr(ws, 'folded_wsum', False)
+    assert [s.xform for s in ws.srcs] == ['up2', 'identity', 'identity', 'maxpool4'] and ws.srcs[2].buf.name == 'rfcr_b3c_pooled'
+    saved = compiler.FOLD_WSUM
+    try:
+        compiler.FOLD_WSUM = False
+        plain = yolov3_body(L.Input(shape=[128, 128, 3]), model_name, 3, num_classes=20)
+    finally:
+        compiler.FOLD_WSUM = saved
+    assert len(plain.plan.ops) == len(m.plan.ops) + 3 and any(o.kind == rt.OP_WSUM for o in plain.plan.ops)
+    assert plain.plan.total_macs() == m.plan.total_macs()
+    assert abs(plain.plan.algorithmic_bytes_per_image() - m.plan.algorithmic_bytes_per_image()) < 1
+    P = params.ParamStore(5, 'conditioned')
+    P.values['rfcr_wsum/alpha'] = np.array([0.8, 1.1, -0.9, 0.6], np.float32)
+    x = params.synthetic_images(2, 128, 128)
+    ref = om.yolov3_body(P, x, model_name, 3, 20)
+    got = []
+    for model in (m, plain):
+        model.set_weights(P.values)
+        ys = [y.cpu().numpy() for y in model(torch.from_numpy(x).to(dev))]
+        got.append(ys)
+        for y, r in zip(ys, ref):
+            assert_close(y.reshape(r.shape), r, 1e-4, 'graph with the folded weighted sum')
+    for a, b in zip(*got):
+        assert_close(a, b, 3e-5, 'folded vs literal weighted sum')

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 CASES = [
     # (h, w, cin, cexp, cout, stride, residual, nw, segs)
     (16, 16, 16, 96, 24, 2, False, 0, 0),      # MobileNetV2 x0.75 block_1 shape
-    (104, 104, 16, 96, 24, 2, False, 1, 0),    # ... many strips / segments, one wave per workgroup
+    (104, 104, 16, 96, 24, 2, False, 3, 0),    # ... many strips / segments, three waves per workgroup
     (31, 45, 16, 96, 24, 2, False, 2, 3),      # odd sizes (pad 1/1), ragged strips and segments
     (13, 13, 24, 144, 24, 1, True, 0, 0),      # block_2 (+add): cin = 16 + 8 (the two-step tail chunk)
     (52, 52, 24, 144, 32, 2, False, 0, 0),     # MobileNetV2 x1.4 block_1 shape

@@ -28,10 +28,10 @@ def test_macs_match_survey(name, size, macs_m):
 
 def test_plan_structure_and_accounting():
     from yoloret_amd import compiler, runtime as rt
-    knobs = ('FUSE_MAX_CIN', 'FUSE_STEM', 'HOIST_UPSAMPLE', 'POOL_IN_PRODUCER', 'MERGE_SE_MEAN', 'FOLD_DW', 'FUSE_MBR', 'FOLD_PROJ', 'FUSE_MBE')
+    knobs = ('FUSE_MAX_CIN', 'FUSE_STEM', 'HOIST_UPSAMPLE', 'POOL_IN_PRODUCER', 'MERGE_SE_MEAN', 'FOLD_DW', 'FUSE_MBR', 'FOLD_PROJ', 'FUSE_MBE', 'FOLD_WSUM')
     saved = [getattr(compiler, k) for k in knobs]
     try:
-        for k, v in zip(knobs, (0, False, False, False, False, False, False, False, False)):   # every rewrite off: the plan = SURVEY.md Appendix B rows
+        for k, v in zip(knobs, (0, False, False, False, False, False, False, False, False, False)):   # every rewrite off: the plan = SURVEY.md Appendix B rows
             setattr(compiler, k, v)
         p = _model().plan
     finally:

@@ -22,7 +22,7 @@ BLOCKS = {   # name: (h, w, cin, cexp, cout, stride, residual), r03 time of the 
     'block_10': ((26, 26, 48, 288, 72, 1, False), 0.0850),
 }
 BATCH = {}
-NWS = {'block_1': [1, 2], 'block_2': [3], 'block_3': [3], 'block_4': [3], 'block_6': [3], 'block_7': [6, 8], 'block_10': [6, 8]}
+NWS = {'block_1': [2, 3], 'block_2': [3], 'block_3': [3], 'block_4': [3], 'block_6': [3], 'block_7': [6, 8], 'block_10': [6, 8]}
 
 
 def timed(op, b, n=30):

@@ -191,7 +191,7 @@ class Plan:
         reads + writes (+ residual reads); upsample / maxpool / concat / SE-scale free; the weighted
         sum is charged its source reads and its consumer DW no input read (they are one fused op
         in the accounting); SE mean costs its C outputs."""
-        wsum_outs = set(id(op.out) for op in self.ops if op.kind == rt.OP_WSUM)
+        wsum_outs = set(id(op.out) for op in self.ops if op.kind == rt.OP_WSUM or getattr(op, 'folded_wsum', False))
 
         def src_elems(op, s):
             # SURVEY.md Appendix B accounting (the agreed figure: 198.9 MB/img for MBV2x0.75@416):
@@ -279,14 +279,18 @@ STEM_MFMA_MAX_C1 = int(os.environ.get('YOLORET_STEM_MFMA_MAX_C1', '32'))
 FUSE_MBR = os.environ.get('YOLORET_FUSE_MBR', '1') != '0'
 MBR_BLOCKS = [b for b in os.environ.get('YOLORET_MBR_BLOCKS', '').split(',') if b]
 MBR_SHAPES = {
-    (24, 144, 48, 2, False): (3, 0),     # MobileNetV2 x0.75 block_6 (52 x 52 -> 26 x 26): 84 -> 46 us
-    (24, 144, 24, 1, True): (3, 0, 4096),   # block_4, 5 at 52 x 52 (66 -> 60 us); block_2 at 104 x 104 stays on the lane kernel (209 vs 240 us in the pipeline)
+    # stride 2 (paired output rows: even columns in lanes 0..7, odd ones in 8..15, two output rows share one projection)
+    (16, 96, 24, 2, False): (2, 4),      # MobileNetV2 x0.75 block_1 (208 x 208 -> 104 x 104): lane kernel 232 us -> 201
+    (24, 144, 24, 2, False): (3, 0),     # block_3 (104 x 104 -> 52 x 52): lane kernel 132 us -> 111
+    (24, 144, 48, 2, False): (3, 0),     # block_6 (52 x 52 -> 26 x 26): 84 -> 40 us
+    (24, 144, 32, 2, False): (3, 0),     # MobileNetV2 x1.4 block_1
+    (32, 192, 48, 2, False): (4, 0),     # x1.4 block_3
+    (24, 144, 24, 1, True): (3, 0),      # block_4, 5 at 52 x 52 (66 -> 60 us); block_2 at 104 x 104: lane kernel 209 us -> 186 (behind block_1 on mbr; 240 behind the lane kernel)
     (48, 288, 48, 1, True): (8, 0),      # block_7..9
     (48, 288, 72, 1, False): (8, 0),     # block_10
 }
 if os.environ.get('YOLORET_MBR_ALL', '0') != '0':   # (experiments: every shape mbr.hip is built for)
-    MBR_SHAPES.update({(16, 96, 24, 2, False): (2, 0), (24, 144, 24, 1, True): (3, 0), (24, 144, 24, 2, False): (3, 0),
-                       (24, 144, 32, 2, False): (3, 0), (32, 192, 32, 1, True): (4, 0), (32, 192, 48, 2, False): (4, 0)})
+    MBR_SHAPES.update({(32, 192, 32, 1, True): (4, 0)})
 # float32 plans, blocks too wide for mbr.hip's one-workgroup form: expand + depthwise in one register-chained kernel (YR_OP_MBE),
 # the projection stays a pointwise op.  Block input widths built in mbr.hip (MBE_CASE).
 FUSE_MBE = os.environ.get('YOLORET_FUSE_MBE', '1') != '0'
@@ -426,6 +430,70 @@ def fold_projection_into_consumers(ops, output_buf_ids):
             m.folded_projection = P.name
             repl[id(C)] = m
         drop.add(id(P))
+    return [repl.get(id(op), op) for op in ops if id(op) not in drop]
+
+
+# RFCR's weighted sum (model.py:117-137, 146-168) adds four 48-channel maps, three of which are LINEAR 1x1 convolutions (no
+# BatchNorm, no activation) of backbone features: a0 * up2(W1 x1) + a1 * W2 x2 + a2 * maxpool2(W3 x3) + a3 * W4 maxpool4(x4).
+# A nearest-neighbour upsample commutes with a 1x1 convolution and so does the scalar, so the three linear terms are ONE
+# pointwise convolution over the concatenation [up2(x1) | x2 | maxpool4(x4)] with the weight matrix [a0 W1 | a1 W2 | a3 W4]; the
+# term behind the max-pool (not linear: the alphas are unconstrained, a2 may be negative) rides along as a fourth source with the
+# weight block a2 * I.  Four launches (three convs + the sum; 62 us of the MobileNetV2 x0.75 step at batch 64) become one
+# conv at 26 x 26, and three 48-channel maps are never written.  Rounding differs from the reference's order of operations
+# like any fp32 re-association (the 1e-4 logit bar holds; YOLORET_FOLD_WSUM=0 keeps the literal chain, which the op-level
+# bit-exactness test of the WeightedSum kernel uses).
+FOLD_WSUM = os.environ.get('YOLORET_FOLD_WSUM', '1') != '0'
+
+
+def fold_weighted_sum(ops, output_buf_ids, V=4):
+    producer = {id(op.out): op for op in ops}
+    nreaders = {}
+    for op in ops:
+        for sg in op.srcs:
+            nreaders[id(sg.buf)] = nreaders.get(id(sg.buf), 0) + 1
+        for b in (op.res, op.gate):
+            if b is not None:
+                nreaders[id(b)] = nreaders.get(id(b), 0) + 1
+    drop, repl = set(), {}
+    for W in ops:
+        if W.kind != rt.OP_WSUM or len(W.srcs) != 4 or W.out.id in output_buf_ids:
+            continue
+        segs, parts, folded = [], [], []   # parts: (alpha index, weight function or None = identity block, columns)
+        for i, sg in enumerate(W.srcs):
+            P = producer.get(id(sg.buf))
+            ok = (P is not None and P.kind == rt.OP_POINTWISE and P.act == 'none' and 'scale' not in P.params and P.res is None
+                  and P.gate is None and getattr(P, 'stride', 0) != 2 and nreaders.get(id(P.out), 0) == 1 and P.out.external_slot < 0
+                  and P.out.id not in output_buf_ids and P.dtype == W.dtype and sg.c == P.cout and not getattr(P, 'accounted_in', None)
+                  and (sg.xform == 'identity' or (sg.xform == 'up2' and all(q.xform == 'identity' for q in P.srcs))))
+            if ok:
+                segs += [Seg(q.buf, q.c, 'up2' if sg.xform == 'up2' else q.xform) for q in P.srcs]
+                parts.append((i, P.params['wgt'][1], sum(round_up(q.c, V) for q in P.srcs)))
+                folded.append(P)
+            else:
+                segs.append(Seg(sg.buf, sg.c, sg.xform))
+                parts.append((i, None, round_up(sg.c, V)))
+        if len(folded) < 2 or len(segs) > rt.YR_MAX_SRC or any(sg.xform not in ('identity', 'up2', 'maxpool2', 'maxpool4') for sg in segs):
+            continue
+        cout, kp = W.cout, sum(p[2] for p in parts)
+        m = OpRec(rt.OP_POINTWISE, W.name, act='none', h=W.h, w=W.w, cin=sum(sg.c for sg in segs), cout=cout, srcs=segs, out=W.out,
+                  macs=sum(P.macs for P in folded), dtype=W.dtype)
+        alpha = W.params['wgt'][1]
+
+        def wgt(wd, parts=parts, alpha=alpha, cout=cout, kp=kp):
+            a = np.asarray(alpha(wd), np.float64)
+            o, kb = np.zeros((cout, kp), np.float64), 0
+            for i, wf, cols in parts:
+                if wf is None:
+                    o[:, kb:kb + cout] = a[i] * np.eye(cout)
+                else:
+                    o[:, kb:kb + cols] = a[i] * np.asarray(wf(wd), np.float64)[:cout]
+                kb += cols
+            return o.astype(np.float32)
+        m.params = {'wgt': ((cout, kp), wgt, W.dtype)}
+        m.fused = folded + [W]        # conv-granular accounting: the convolutions and the sum it replaces
+        m.folded_wsum = True
+        repl[id(W)] = m
+        drop.update(id(P) for P in folded)
     return [repl.get(id(op), op) for op in ops if id(op) not in drop]
 
 
@@ -1200,6 +1268,8 @@ class Compiler:
                 ops = hoist_upsampled_sources(ops, self.bufs)
             if POOL_IN_PRODUCER:
                 ops = pool_into_producers(ops, self.bufs, set(b.id for b in outs))
+            if FOLD_WSUM:
+                ops = fold_weighted_sum(ops, set(b.id for b in outs), self.V)
             # fuse == 'latency': the plan for batches of a few images.  A fused inverted-residual block is ONE long
             # workgroup chain (block_4 at batch 1: 14 workgroups x 60 us) where its three unfused launches take 10 us
             # each, and a merged SE launch pools 2704 pixels in one workgroup: at batch <= 4 the unfused plan is

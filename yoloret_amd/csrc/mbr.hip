@@ -76,6 +76,33 @@ __device__ __forceinline__ void mbr_dw_row(v4f& acc, const v4f e, const v4f w0, 
     acc = (v4f){a0, a1, a2, a3};
 }
 
+// STRIDE 2, PAIRED OUTPUT ROWS.  With lane = input column, a stride-2 strip has its 7 outputs in every other lane and the projection
+// MFMAs run at 7 useful columns of 16.  The expand conv does not care which pixel sits in which lane, so a stride-2 strip loads the
+// EVEN input columns E_0..E_7 into lanes 0..7 of a DPP row and the ODD ones O_0..O_7 into lanes 8..15; output column j needs
+// E_j, O_j, E_j+1:
+//   * an even output row computes in lanes 0..6 (own lane, row_shl:8, row_shl:1) and writes banks 0-1 only (bank_mask:0x3),
+//   * the next (odd) output row computes in lanes 8..14 (row_shr:8, own lane, row_shr:7) and writes banks 2-3 only,
+// into the SAME accumulator registers: one clamp and ONE set of projection MFMAs (14 useful columns of 16) per pair of output rows.
+#define MBR_DPPM(ctl, bank) " " ctl " row_mask:0xf bank_mask:" bank " bound_ctrl:1\n\t"
+#define MBR_DW2(c0, c1, c2, bank)                                                                                                    \
+    asm("s_nop 1\n\t"                                                                                                                \
+        "v_fmac_f32_dpp %0, %4, %8" MBR_DPPM(c0, bank) "v_fmac_f32_dpp %1, %5, %9" MBR_DPPM(c0, bank)                               \
+        "v_fmac_f32_dpp %2, %6, %10" MBR_DPPM(c0, bank) "v_fmac_f32_dpp %3, %7, %11" MBR_DPPM(c0, bank)                             \
+        "v_fmac_f32_dpp %0, %4, %12" MBR_DPPM(c1, bank) "v_fmac_f32_dpp %1, %5, %13" MBR_DPPM(c1, bank)                             \
+        "v_fmac_f32_dpp %2, %6, %14" MBR_DPPM(c1, bank) "v_fmac_f32_dpp %3, %7, %15" MBR_DPPM(c1, bank)                             \
+        "v_fmac_f32_dpp %0, %4, %16" MBR_DPPM(c2, bank) "v_fmac_f32_dpp %1, %5, %17" MBR_DPPM(c2, bank)                             \
+        "v_fmac_f32_dpp %2, %6, %18" MBR_DPPM(c2, bank) "v_fmac_f32_dpp %3, %7, %19" MBR_DPPM(c2, bank)                             \
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)                                                                                     \
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(w0[0]), "v"(w0[1]), "v"(w0[2]), "v"(w0[3]),                                \
+          "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(w1[3]), "v"(w2[0]), "v"(w2[1]), "v"(w2[2]), "v"(w2[3]))
+template <bool ODD>
+__device__ __forceinline__ void mbr_dw_row2(v4f& acc, const v4f e, const v4f w0, const v4f w1, const v4f w2) {
+    float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+    if constexpr (!ODD) MBR_DW2("quad_perm:[0,1,2,3]", "row_shl:8", "row_shl:1", "0x3");
+    else MBR_DW2("row_shr:8", "quad_perm:[0,1,2,3]", "row_shr:7", "0xc");
+    acc = (v4f){a0, a1, a2, a3};
+}
+
 typedef __amdgpu_buffer_rsrc_t mbr_rsrc;
 __device__ __forceinline__ mbr_rsrc mbr_make_rsrc(const void* base, unsigned bytes) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)base), hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)base >> 32));
@@ -97,11 +124,14 @@ __device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const i
     const int strip = bid % a.strips;
     const int b = bid / a.strips;
     const int yo0 = seg * a.seg_rows, yo1 = min(yo0 + a.seg_rows, a.Ho);
-    const int xin = S * NOUT * strip - a.pad_l + px;
+    // stride 1: lane = input column, outputs at lanes 1..14; stride 2: even columns in lanes 0..7, odd ones in 8..15, the outputs
+    // of an even output row in lanes 0..6, of the odd row below it in lanes 8..14 (see mbr_dw_row2)
+    const int podd = S == 2 ? px >> 3 : 0;
+    const int xin = S * NOUT * strip - a.pad_l + (S == 2 ? 2 * (px & 7) + podd : px);
     const int xc = min(max(xin, 0), a.W - 1);
     const float hi = (xin >= 0 && xin < a.W) ? 6.f : 0.f;
-    const int jo = (px - 1) / S, xo = NOUT * strip + jo;
-    const bool out_lane = px >= 1 && px <= 14 && (px - 1) % S == 0 && xo < a.Wo;
+    const int jo = S == 2 ? (px & 7) : px - 1, xo = NOUT * strip + jo;
+    const bool out_lane = (S == 2 ? (px & 7) < 7 : (px >= 1 && px <= 14)) && xo < a.Wo;
 
     // ---- stationary A fragments of this wave's tiles
     float we[NT][KE], wp[NT][TO][4];
@@ -158,9 +188,13 @@ __device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const i
     for (int j = 0; j < NT; ++j) { ea[j] = (v4f){0.f, 0.f, 0.f, 0.f}; eb[j] = ea[j]; }
     int buf = 0;
 
-    // one input row r = rbeg + k of the walk; EMIT: it is the last tap row of output row yo (rows r - 2, r - 1, r)
-    auto row = [&](auto emit_c, const int k, const int yo, const XRow& xc_, XRow& xn_) {
-        constexpr bool EMIT = decltype(emit_c)::value;
+    // one input row r = rbeg + k of the walk.  Stride 1: PH = 1 if it is the last tap row of output row yo (rows r - 2, r - 1, r), else 0.
+    // Stride 2: PH = 0 warms the ring up (row rbeg); PH = 1..4 are the four input rows of a PAIR of output rows (yo, yo + 1): taps
+    // 0-1-2 of row yo are the previous row 4 (ea) and rows 1, 2; those of row yo + 1 are rows 2, 3, 4; row 4 projects and stores.
+    v4f d2[S == 2 ? NT : 1];
+    auto row = [&](auto ph_c, const int k, const int yo, const XRow& xc_, XRow& xn_) {
+        constexpr int PH = decltype(ph_c)::value;
+        constexpr bool EMIT = S == 2 ? PH == 4 : PH == 1;
         const int r = rbeg + k;
         load_row(xn_, r + 1);
         float xq[KE];
@@ -188,10 +222,37 @@ __device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const i
 #pragma unroll
             for (int i = 0; i < 4; ++i) ec[j][i] = __builtin_amdgcn_fmed3f(ec[j][i], 0.f, hr);
 
+        v4f P[TO];
         if constexpr (EMIT) {
-            v4f P[TO];
 #pragma unroll
             for (int t = 0; t < TO; ++t) P[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (S == 2 && PH != 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const v4f* tb = reinterpret_cast<const v4f*>(tab + (t0 + j) * MBR_TAB) + mg;
+                if constexpr (PH == 1) {
+                    d2[j] = tb[36];   // the BN shift is the first addend, in every lane
+                    mbr_dw_row2<false>(d2[j], ea[j], tb[0], tb[4], tb[8]);
+                    mbr_dw_row2<false>(d2[j], ec[j], tb[12], tb[16], tb[20]);
+                } else if constexpr (PH == 2) {
+                    mbr_dw_row2<false>(d2[j], ec[j], tb[24], tb[28], tb[32]);
+                    mbr_dw_row2<true>(d2[j], ec[j], tb[0], tb[4], tb[8]);
+                } else if constexpr (PH == 3) {
+                    mbr_dw_row2<true>(d2[j], ec[j], tb[12], tb[16], tb[20]);
+                } else {
+                    mbr_dw_row2<true>(d2[j], ec[j], tb[24], tb[28], tb[32]);
+                    v4f d = d2[j];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d[i] = __builtin_amdgcn_fmed3f(d[i], 0.f, 6.f);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int t = 0; t < TO; ++t) P[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[j][t][s], d[s], P[t], 0, 0, 0);
+                }
+            }
+        }
+        if constexpr (S == 1 && EMIT) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const v4f* tb = reinterpret_cast<const v4f*>(tab + (t0 + j) * MBR_TAB) + mg;
@@ -206,13 +267,17 @@ __device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const i
 #pragma unroll
                     for (int t = 0; t < TO; ++t) P[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[j][t][s], d[s], P[t], 0, 0, 0);
             }
-            const unsigned opix = ((unsigned)yo * (unsigned)a.Wo + (unsigned)xo) * (unsigned)a.ld_out * 4u;
+        }
+        if constexpr (EMIT) {
+            const int yl = yo + podd;   // (stride 2: lanes 8..15 hold the row below)
+            const bool rlive = S == 1 || yl < yo1;
+            const unsigned opix = ((unsigned)yl * (unsigned)a.Wo + (unsigned)xo) * (unsigned)a.ld_out * 4u;
             if constexpr (NW == 1) {
 #pragma unroll
                 for (int t = 0; t < TO; ++t) {
                     v4f v = P[t] + fsh[t];
                     if (RES) v += fres[t];   // (after the sum: the load issued at the row's start is not waited for before here)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), osrc, flive[t] ? opix + (16u * t + 4u * mg) * 4u : MBR_DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), osrc, flive[t] && rlive ? opix + (16u * t + 4u * mg) * 4u : MBR_DEAD, 0, 0);
                 }
             } else {
                 v4f* rb = red + buf * (NW * TO * 64);
@@ -228,32 +293,41 @@ __device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const i
                         for (int ww = 0; ww < NW; ++ww) v += rb[(ww * TO + t) * 64 + lane];
                     }
                     if (RES) v += fres[tt];   // last: the residual load issued at the row's start is waited for only here
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), osrc, flive[tt] ? opix + (16u * t + 4u * mg) * 4u : MBR_DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), osrc, flive[tt] && rlive ? opix + (16u * t + 4u * mg) * 4u : MBR_DEAD, 0, 0);
                 }
                 buf ^= 1;
             }
         }
+        if constexpr (S == 1) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) { ea[j] = eb[j]; eb[j] = ec[j]; }
-    };
-    constexpr std::true_type Y{};
-    constexpr std::false_type N{};
-    // rows k = 0 .. 2 - S warm the ring up; then every output row takes S input rows, the last of which emits
-    if constexpr (S == 2) {
-        row(N, 0, 0, xa, xb);
-        for (int i = 0; i < nout; ++i) {
-            row(N, 2 * i + 1, 0, xb, xa);
-            row(Y, 2 * i + 2, yo0 + i, xa, xb);
+            for (int j = 0; j < NT; ++j) { ea[j] = eb[j]; eb[j] = ec[j]; }
+        } else if constexpr (PH == 0 || PH == 4) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ea[j] = ec[j];
         }
-    } else {
-        row(N, 0, 0, xa, xb);
-        row(N, 1, 0, xb, xa);
+    };
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
+    if constexpr (S == 2) {
+        constexpr std::integral_constant<int, 2> P2{};
+        constexpr std::integral_constant<int, 3> P3{};
+        constexpr std::integral_constant<int, 4> P4{};
+        row(P0, 0, 0, xa, xb);
+        for (int i = 0; i < nout; i += 2) {   // a pair of output rows per turn (an odd segment's last pair stores its even row only)
+            row(P1, 2 * i + 1, 0, xb, xa);
+            row(P2, 2 * i + 2, 0, xa, xb);
+            row(P3, 2 * i + 3, 0, xb, xa);
+            row(P4, 2 * i + 4, yo0 + i, xa, xb);
+        }
+    } else {   // rows 0, 1 warm the ring up; then every input row emits
+        row(P0, 0, 0, xa, xb);
+        row(P0, 1, 0, xb, xa);
         int i = 0;
         for (; i + 1 < nout; i += 2) {
-            row(Y, i + 2, yo0 + i, xa, xb);
-            row(Y, i + 3, yo0 + i + 1, xb, xa);
+            row(P1, i + 2, yo0 + i, xa, xb);
+            row(P1, i + 3, yo0 + i + 1, xb, xa);
         }
-        if (i < nout) row(Y, i + 2, yo0 + i, xa, xb);
+        if (i < nout) row(P1, i + 2, yo0 + i, xa, xb);
     }
 }
 
@@ -282,6 +356,7 @@ static int launch_mbr(const MbrArgs& a0, int batch, int want_segs, hipStream_t s
     if (segs < 1) segs = 1;
     if (want_segs > 0) segs = want_segs < a.Ho ? want_segs : a.Ho;
     a.seg_rows = (a.Ho + segs - 1) / segs;
+    if (S == 2) a.seg_rows += a.seg_rows & 1;   // (output rows are processed in pairs)
     a.segs = (a.Ho + a.seg_rows - 1) / a.seg_rows;
     const size_t lds = (size_t)T * MBR_TAB * 4 + (NW > 1 ? (size_t)2 * NW * TO * 64 * 16 : 0);
     static char nm[64];
@@ -526,7 +601,7 @@ int yr_launch_mbr(const yr_op& op, int batch, hipStream_t s) {
     if (in.c == CIN && op.se_reduced == CEXP && op.cout == COUT && op.stride == S && res == RES && (nw == 0 || nw == NW)) \
         return launch_mbr<CIN, CEXP, COUT, S, NW, RES>(a, batch, (op.k >> 16) & 0xff, s);
     MBR_CASE(16, 96, 24, 2, 2, false)      // MobileNetV2 x0.75 block_1
-    MBR_CASE(16, 96, 24, 2, 1, false)
+    MBR_CASE(16, 96, 24, 2, 3, false)
     MBR_CASE(24, 144, 24, 1, 3, true)      // block_2, 4, 5
     MBR_CASE(24, 144, 24, 2, 3, false)     // block_3 (x0.75: 32 * 0.75 = 24 outputs)
     MBR_CASE(24, 144, 48, 2, 3, false)     // block_6
