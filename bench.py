@@ -382,10 +382,13 @@ def main():
         roofline['by_pipe'] = {'hbm_gbs': round(gbs, 1), 'frac_hbm': round(fr['hbm'], 4), 'mfma16_tflops': round(tf16, 2),
                                'frac_mfma16': round(fr['mfma16'], 4), 'fp32_tflops': round(tf32, 2), 'frac_fp32': round(fr['fp32'], 4)}
         # the same per kernel FAMILY: the lane-per-pixel front, the fused MFMA blocks ... are several symbols each
-        fams = [('lane_per_pixel_front', ('mblane', 'stemblock', 'stem_')), ('fused_blocks', ('mbh_kernel', 'mbn_kernel', 'mbr_kernel', 'mbconv')),
+        fams = [('lane_per_pixel_front', ('mblane', 'stemblock', 'stem_')),
+                ('fused_blocks', ('mbh_kernel', 'mbn_kernel', 'mbr_kernel', 'mbe_kernel', 'mbx_kernel', 'mbxr_kernel', 'mbhr_kernel', 'stemxr_kernel')),
                 ('pointwise', ('pw_kernel', 'pwd_kernel', 'pwh', 'pwl')), ('depthwise', ('dw_kernel', 'dwp_kernel', 'dwl')),
                 ('elementwise', ('wsum', 'gather', 'letterbox')),
                 ('squeeze_excite', ('se_',)), ('postprocess', ('decode', 'nms', 'pack'))]
+        known = tuple(p_ for _, ps in fams for p_ in ps)
+        fams.append(('other', tuple(sym for sym in by if not sym.startswith(known)) or ('\0',)))   # (nothing may fall through: the shares add up to 1)
         total_ms = sum(v['ms'] for v in by.values())
         roofline_family = {}
         for fname, prefixes in fams:

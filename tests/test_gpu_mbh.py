@@ -40,6 +40,9 @@ CASES = [
     (20, 20, 32, 192, 48, 3, 1, False, 'swish', None),     # generic activation path
     (22, 18, 24, 144, 32, 3, 2, False, 'swish', None),     # the narrow stride-2 front block (mbn_h.hip) with swish, two passes
     (12, 30, 32, 192, 16, 3, 2, False, 'relu6', None),     # ... 32 inputs, 192 expanded channels (two full passes), one cout tile
+    (20, 24, 32, 192, 48, 5, 2, False, 'relu6', None),     # EfficientNet-lite3 stage 3 entry (k5 s2; tile-wise chained form: 4 waves x 3 tiles)
+    (23, 17, 48, 288, 48, 5, 1, True, 'relu6', None),      # ... stage 3 (k5, two input chunks, 6 waves x 3 tiles), odd sizes
+    (27, 31, 24, 144, 40, 5, 2, False, 'relu6', None),     # lite0 stage 3 entry at an odd size (pad 2/2)
 ]
 
 
@@ -47,11 +50,15 @@ def _act(t, act):
     return {'relu6': nn.relu6, 'swish': nn.swish}[act](t)
 
 
-def _chained_built(cin, cexp, cout, k):
-    """mbxr_h.hip: yr_mbhr_built - the shapes the register-chained whole-block kernel (mbhr_kernel) is instantiated for."""
-    if not (k == 3 and cin % 8 == 0 and cin <= 64 and cexp % 16 == 0 and cexp <= 256 and cout % 4 == 0 and cout <= 80):
+def _chained_built(cin, cexp, cout, k, act='relu6'):
+    """mbxr_h.hip: yr_mbhr_built - the shapes the register-chained whole-block kernels are instantiated for: the tile-pair form
+    (mbhr_kernel, 3x3) and the tile-wise form (mbhq_kernel: 3x3 / 5x5, ReLU6, MBHQ_SHAPES)."""
+    if not (cin % 8 == 0 and cin <= 64 and cexp % 16 == 0 and cout % 4 == 0):
         return False
-    return (round_up(cin, 32) // 32, (cout + 15) // 16, (cexp // 16 + 1) // 2) in {(1, 2, 3), (1, 2, 6), (1, 3, 6), (2, 5, 8), (2, 3, 8)}
+    nc, to = round_up(cin, 32) // 32, (cout + 15) // 16
+    if k == 3 and cexp <= 256 and cout <= 80 and (nc, to, (cexp // 16 + 1) // 2) in {(1, 2, 3), (1, 2, 6), (1, 3, 6), (2, 5, 8), (2, 3, 8)}:
+        return True
+    return act == 'relu6' and (k, nc, to, cexp // 16) in {(5, 1, 3, 9), (5, 1, 3, 12), (5, 2, 3, 18), (5, 2, 3, 15), (3, 1, 2, 9)}
 
 
 @pytest.mark.parametrize('form', ['lds', 'chained'])
@@ -63,7 +70,7 @@ def test_mbh(dev, case, dt, form):
     from yoloret_amd import runtime as rt
     h, w, cin, cexp, cout, k, s, residual, act, tile = case
     if form == 'chained':
-        if tile is not None or not _chained_built(cin, cexp, cout, k):
+        if tile is not None or not _chained_built(cin, cexp, cout, k, act):
             pytest.skip('the register-chained form is not built for this shape')
         tile = (255, 3 if h > 20 else 0)
     elif tile is None:

@@ -93,6 +93,42 @@ __device__ __forceinline__ float xr_act(float v, float hi) {   // hi: 6 (relu6) 
     else return hi * (v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f)));
 }
 
+// The same on the 4 channels of a lane at once, the multiplies and adds as PACKED float32 instructions (v_pk_mul_f32 / v_pk_add_f32 /
+// v_pk_fma_f32: two values per issue slot, each IEEE-exact like its scalar form, so results are bit-identical to xr_act).  These
+// kernels are bound by VALU issue, and with a 3x3 depthwise conv the two swishes are 60 % of it (tools/valu_rate.hip: v_exp_f32 and
+// v_rcp_f32 cost two slots each on gfx950, everything else one): 9 -> 6.5 slots per expanded value, 8 -> 6 per stored value.
+typedef float xr_f2 __attribute__((ext_vector_type(2)));
+template <int ACT>
+__device__ __forceinline__ xr_f4 xr_act4(const xr_f4 v, const float hi) {
+    xr_f4 o;
+    if constexpr (ACT == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_fmed3f(v[i], 0.0f, hi);
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const xr_f2 x = {v[2 * h], v[2 * h + 1]};
+            const xr_f2 u = x * (xr_f2){-1.44269504088896341f, -1.44269504088896341f};
+            const xr_f2 e = (xr_f2){__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])} + (xr_f2){1.0f, 1.0f};
+            const xr_f2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+            const xr_f2 y = (xr_f2){hi, hi} * (x * r);
+            o[2 * h] = y[0]; o[2 * h + 1] = y[1];
+        }
+    }
+    return o;
+}
+// ... behind the expand conv's BatchNorm: act(d * scale + shift)
+template <int ACT>
+__device__ __forceinline__ xr_f4 xr_bn_act4(const xr_f4 d, const xr_f4 sc, const xr_f4 sh, const float hi) {
+    xr_f4 t;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const xr_f2 y = __builtin_elementwise_fma((xr_f2){d[2 * h], d[2 * h + 1]}, (xr_f2){sc[2 * h], sc[2 * h + 1]}, (xr_f2){sh[2 * h], sh[2 * h + 1]});
+        t[2 * h] = y[0]; t[2 * h + 1] = y[1];
+    }
+    return xr_act4<ACT>(t, hi);
+}
+
 // K: depthwise kernel, S: stride, ACT: 0 relu6 / 1 swish (both activations), NC: 32-channel chunks of the block input, NT: tiles per wave
 template <class T, int K, int S, int ACT, int NC, int NT, int MW>
 __global__ __launch_bounds__(256, MW) void mbxr_kernel(MbxrArgs a) {
@@ -168,8 +204,7 @@ __global__ __launch_bounds__(256, MW) void mbxr_kernel(MbxrArgs a) {
             xr_f4 d = (xr_f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < NC; ++c) d = xr_mfma<T>(aw[j][c], xc_.m[c], d);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ec[j][i] = xr_act<ACT>(__builtin_fmaf(d[i], es[j][i], eh[j][i]), hr);
+            ec[j] = xr_bn_act4<ACT>(d, es[j], eh[j], hr);
         }
         if constexpr (EMIT) {
             const unsigned opix = ((unsigned)yo * (unsigned)a.Wo + (unsigned)xo) * (unsigned)a.ld_out * 2u;
@@ -186,9 +221,7 @@ __global__ __launch_bounds__(256, MW) void mbxr_kernel(MbxrArgs a) {
                     xr_row5(d, ec[j], tp[j][20], tp[j][21], tp[j][22], tp[j][23], tp[j][24]);
                 }
                 typedef T t4 __attribute__((ext_vector_type(4)));
-                xr_f4 v;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = xr_act<ACT>(d[i], HI);
+                const xr_f4 v = xr_act4<ACT>(d, HI);
                 const t4 o = __builtin_convertvector(v, t4);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(xr_u2, o), osrc, ooff[j] == XR_DEAD ? XR_DEAD : opix + ooff[j], 0, 0);
                 const xr_f4 stored = __builtin_convertvector(o, xr_f4);   // the squeeze sums what was STORED (rounded)
@@ -408,8 +441,7 @@ __global__ __launch_bounds__(256, 2) void stemxr_kernel(StemxrArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const xr_f4 d = xr_mfma<T>(aw[j], bcur, sh[j]);       // (the BN shift is the accumulator's initial value)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ec[j][i] = xr_act<ACT>(d[i], hr);
+            ec[j] = xr_act4<ACT>(d, hr);
         }
         if (k >= 2) {
             const int yo = yo0 + k - 2;
@@ -420,9 +452,7 @@ __global__ __launch_bounds__(256, 2) void stemxr_kernel(StemxrArgs a) {
                 xr_row3(d, ring[j][0], tp[j][0], tp[j][1], tp[j][2]);
                 xr_row3(d, ring[j][1], tp[j][3], tp[j][4], tp[j][5]);
                 xr_row3(d, ec[j], tp[j][6], tp[j][7], tp[j][8]);
-                xr_f4 v;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = xr_act<ACT>(d[i], HI);
+                const xr_f4 v = xr_act4<ACT>(d, HI);
                 const t4 o = __builtin_convertvector(v, t4);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(xr_u2, o), osrc, ooff[j] == XR_DEAD ? XR_DEAD : opix + ooff[j], 0, 0);
                 const xr_f4 stored = __builtin_convertvector(o, xr_f4);
@@ -598,8 +628,7 @@ __global__ __launch_bounds__(64 * NW, MW) void mbhr_kernel(MbhrArgs a) {
             xr_f4 d = (xr_f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < NC; ++c) d = xr_mfma<T>(aw[j][c], xc_.m[c], d);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ec[j][i] = xr_act<ACT>(__builtin_fmaf(d[i], es[j][i], eh[j][i]), hr);
+            ec[j] = xr_bn_act4<ACT>(d, es[j], eh[j], hr);
         }
         if constexpr (EMIT) {
             t4 dq[2];
@@ -609,9 +638,7 @@ __global__ __launch_bounds__(64 * NW, MW) void mbhr_kernel(MbhrArgs a) {
                 xr_row3(d, ring[j][0], tp[j][0], tp[j][1], tp[j][2]);
                 xr_row3(d, ring[j][1], tp[j][3], tp[j][4], tp[j][5]);
                 xr_row3(d, ec[j], tp[j][6], tp[j][7], tp[j][8]);
-                xr_f4 v;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = xr_act<ACT>(d[i], HI);
+                const xr_f4 v = xr_act4<ACT>(d, HI);
                 dq[j] = __builtin_convertvector(v, t4);      // rounded: the projection's operand type
             }
             const xr_u2 b0 = __builtin_bit_cast(xr_u2, dq[0]), b1 = __builtin_bit_cast(xr_u2, dq[1]);
@@ -688,6 +715,436 @@ static int launch_mbhr(const MbhrArgs& a0, int batch, int want_segs, hipStream_t
     return YR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The whole block once more, for the shapes the tile-PAIR form above does not fit: 5x5 depthwise kernels, and expanded widths
+// whose tile pairs would make a five-wave workgroup (144 channels = 9 tiles).  Wave w owns NT expanded tiles (any number) and the
+// projection runs per TILE on v_mfma_f32_16x16x16_{bf16,f16}: the lane's 4 depthwise results of one tile, rounded to the
+// 16-bit type, are exactly that instruction's B operand (k = 4 g .. 4 g + 3 of the tile's 16 channels).  Twice the MFMA
+// issue slots per multiply-add of the 32-deep form - on a matrix pipe that idles under the depthwise VALU work.  5x5: the
+// 25 taps x 4 channels per tile do not fit the register file next to a four-row ring: two registers per channel hold them
+// lane-wise and DPP row broadcasts deliver them (xr_bc5_row below).
+template <class T>
+__device__ __forceinline__ xr_f4 xr_mfma16(xr_u2 w, xr_u2 x, xr_f4 acc) {
+    typedef short xr_s4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 xr_h4 __attribute__((ext_vector_type(4)));
+    if constexpr (yr_elem<T>::dtype == YR_BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(xr_s4, w), __builtin_bit_cast(xr_s4, x), acc, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(xr_h4, w), __builtin_bit_cast(xr_h4, x), acc, 0, 0, 0);
+}
+
+// 5x5 depthwise taps WITHOUT a register per tap: the 25 taps of a channel live in TWO registers, lane p of every 16-lane row
+// holding tap p (register 0) / tap 16 + p (register 1) of the lane's channel, and a multiply-add reads the tap it needs through
+// DPP row_newbcast:p (gfx90a+: lane p of the row, broadcast to the row; tools/dpp_bcast_test.hip).  DPP modifies one operand
+// only, so the horizontal shift cannot ride on the same instruction: the five COLUMN sums S_dx = sum_ky tap(ky, dx) * e_ky are
+// accumulated unshifted and the shifts are applied once per output row, to the sums:
+//   out = shift + S_2 + shr2(S_0) + shr1(S_1) + shl1(S_3) + shl2(S_4)
+// 30 instead of 25 instructions per channel and output row, 8 instead of 100 tap registers per tile, no LDS table (an LDS table
+// read where it is used costs 25 ds_read_b128 per tile and output row: 0.31 ms on EfficientNet-lite0's stage-3 entry, LDS-bound).
+template <int KY> __device__ __forceinline__ void xr_bc5_row(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1);
+template <> __device__ __forceinline__ void xr_bc5_row<0>(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
+    asm("v_mul_f32_dpp %0, %16, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %17, %13 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %2, %18, %14 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %3, %19, %15 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %4, %16, %12 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %5, %17, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %6, %18, %14 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %7, %19, %15 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %8, %16, %12 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %9, %17, %13 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %10, %18, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %11, %19, %15 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        : "=&v"(S[0][0]), "=&v"(S[0][1]), "=&v"(S[0][2]), "=&v"(S[0][3]), "=&v"(S[1][0]), "=&v"(S[1][1]), "=&v"(S[1][2]), "=&v"(S[1][3]), "=&v"(S[2][0]), "=&v"(S[2][1]), "=&v"(S[2][2]), "=&v"(S[2][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+    asm("v_mul_f32_dpp %0, %12, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %13, %9 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %2, %14, %10 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %3, %15, %11 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %4, %12, %8 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %5, %13, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %6, %14, %10 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %7, %15, %11 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        : "=&v"(S[3][0]), "=&v"(S[3][1]), "=&v"(S[3][2]), "=&v"(S[3][3]), "=&v"(S[4][0]), "=&v"(S[4][1]), "=&v"(S[4][2]), "=&v"(S[4][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+}
+template <> __device__ __forceinline__ void xr_bc5_row<1>(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
+    asm("v_fmac_f32_dpp %0, %16, %12 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %17, %13 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %18, %14 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %19, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %16, %12 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %17, %13 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %18, %14 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %19, %15 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %8, %16, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %9, %17, %13 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %10, %18, %14 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %11, %19, %15 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[2][0]), "+v"(S[2][1]), "+v"(S[2][2]), "+v"(S[2][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+    asm("v_fmac_f32_dpp %0, %12, %8 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %13, %9 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %14, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %15, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %12, %8 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %13, %9 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %14, %10 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %15, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(S[3][0]), "+v"(S[3][1]), "+v"(S[3][2]), "+v"(S[3][3]), "+v"(S[4][0]), "+v"(S[4][1]), "+v"(S[4][2]), "+v"(S[4][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+}
+template <> __device__ __forceinline__ void xr_bc5_row<2>(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
+    asm("v_fmac_f32_dpp %0, %16, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %17, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %18, %14 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %19, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %16, %12 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %17, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %18, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %19, %15 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %8, %16, %12 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %9, %17, %13 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %10, %18, %14 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %11, %19, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[2][0]), "+v"(S[2][1]), "+v"(S[2][2]), "+v"(S[2][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+    asm("v_fmac_f32_dpp %0, %12, %8 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %13, %9 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %14, %10 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %15, %11 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %12, %8 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %13, %9 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %14, %10 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %15, %11 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(S[3][0]), "+v"(S[3][1]), "+v"(S[3][2]), "+v"(S[3][3]), "+v"(S[4][0]), "+v"(S[4][1]), "+v"(S[4][2]), "+v"(S[4][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+}
+template <> __device__ __forceinline__ void xr_bc5_row<3>(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
+    asm("v_fmac_f32_dpp %0, %16, %12 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %17, %13 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %18, %14 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %19, %15 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %20, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %21, %13 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %22, %14 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %23, %15 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %8, %20, %12 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %9, %21, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %10, %22, %14 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %11, %23, %15 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[2][0]), "+v"(S[2][1]), "+v"(S[2][2]), "+v"(S[2][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+    asm("v_fmac_f32_dpp %0, %16, %8 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %17, %9 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %18, %10 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %19, %11 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %16, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %17, %9 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %18, %10 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %19, %11 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(S[3][0]), "+v"(S[3][1]), "+v"(S[3][2]), "+v"(S[3][3]), "+v"(S[4][0]), "+v"(S[4][1]), "+v"(S[4][2]), "+v"(S[4][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+}
+template <> __device__ __forceinline__ void xr_bc5_row<4>(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
+    asm("v_fmac_f32_dpp %0, %20, %12 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %21, %13 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %22, %14 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %23, %15 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %20, %12 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %21, %13 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %22, %14 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %23, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %8, %20, %12 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %9, %21, %13 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %10, %22, %14 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %11, %23, %15 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[2][0]), "+v"(S[2][1]), "+v"(S[2][2]), "+v"(S[2][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+    asm("v_fmac_f32_dpp %0, %16, %8 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %17, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %18, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %19, %11 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %16, %8 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %17, %9 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %18, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %19, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(S[3][0]), "+v"(S[3][1]), "+v"(S[3][2]), "+v"(S[3][3]), "+v"(S[4][0]), "+v"(S[4][1]), "+v"(S[4][2]), "+v"(S[4][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+}
+__device__ __forceinline__ xr_f4 xr_bc5_finish(const float (&S)[5][4], const xr_f4 shift) {
+    float o0 = shift[0] + S[2][0], o1 = shift[1] + S[2][1], o2 = shift[2] + S[2][2], o3 = shift[3] + S[2][3];
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %5, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %6, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %7, %3 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %8, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %9, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %10, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %11, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %12, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %13, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %14, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %15, %3 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %16, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %17, %1 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %18, %2 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %19, %3 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
+        : "v"(S[0][0]), "v"(S[0][1]), "v"(S[0][2]), "v"(S[0][3]), "v"(S[1][0]), "v"(S[1][1]), "v"(S[1][2]), "v"(S[1][3]), "v"(S[3][0]), "v"(S[3][1]), "v"(S[3][2]), "v"(S[3][3]), "v"(S[4][0]), "v"(S[4][1]), "v"(S[4][2]), "v"(S[4][3]));
+    return (xr_f4){o0, o1, o2, o3};
+}
+
+template <class T, int K, int S, int ACT, int NC, int TO, int NT, int NW, int MW>
+__global__ __launch_bounds__(64 * NW, MW) void mbhq_kernel(MbhrArgs a) {
+    constexpr int KK = K * K, PAD = K / 2, NOUT = (16 - K) / S + 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    xr_f4* red = reinterpret_cast<xr_f4*>(lds);            // [2][NW][TO][64]
+    const int lane = threadIdx.x & 63, px = lane & 15, mg = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int bid = (int)yr_xcd_swizzle(blockIdx.x, gridDim.x);
+    const int seg = bid % a.segs; bid /= a.segs;
+    const int strip = bid % a.strips;
+    const int b = bid / a.strips;
+    const int yo0 = seg * a.seg_rows, yo1 = min(yo0 + a.seg_rows, a.Ho);
+    const int xin = S * NOUT * strip - a.pad_l + px;
+    const int xc = min(max(xin, 0), a.W - 1);
+    constexpr float HI = ACT == 0 ? 6.f : 1.f;
+    const float hi = (xin >= 0 && xin < a.W) ? HI : 0.f;
+    const int jo = (px - PAD) / S, xo = NOUT * strip + jo;
+    const bool out_lane = px >= PAD && (px - PAD) % S == 0 && jo < NOUT && xo < a.Wo;
+
+    // ---- stationary: the wave's NT expanded tiles (a tile beyond T: all-zero parameters -> its depthwise result is act(0) = 0)
+    xr_u4 aw[NT][NC];
+    xr_u2 wpf[NT][TO];
+    xr_f4 es[NT], eh[NT], dh[NT], tp[NT][K == 3 ? KK : 2];   // 3x3: a register per tap; 5x5: lane p of a row holds tap p / tap 16 + p
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int t = NT * w + j;
+        const bool live = t < a.T;
+        const int tc = live ? t : 0, ch = 16 * tc + 4 * mg;
+        const char* wrow = reinterpret_cast<const char*>(a.we) + ((size_t)(16 * tc + px) * a.KP + 8 * mg) * 2;
+        const xr_f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) aw[j][c] = live ? *reinterpret_cast<const xr_u4*>(wrow + 64 * c) : (xr_u4){0u, 0u, 0u, 0u};
+        dh[j] = live ? *reinterpret_cast<const xr_f4*>(a.prm + (size_t)(KK + 1) * a.CexpP + ch) : z;
+        es[j] = live ? *reinterpret_cast<const xr_f4*>(a.prm + (size_t)(KK + 2) * a.CexpP + ch) : z;
+        eh[j] = live ? *reinterpret_cast<const xr_f4*>(a.prm + (size_t)(KK + 3) * a.CexpP + ch) : z;
+        const xr_f4 dsc = *reinterpret_cast<const xr_f4*>(a.prm + (size_t)KK * a.CexpP + ch);
+        if constexpr (K == 3) {
+#pragma unroll
+            for (int q = 0; q < KK; ++q) tp[j][q] = live ? *reinterpret_cast<const xr_f4*>(a.prm + (size_t)q * a.CexpP + ch) * dsc : z;
+        } else {
+            tp[j][0] = live ? *reinterpret_cast<const xr_f4*>(a.prm + (size_t)px * a.CexpP + ch) * dsc : z;
+            tp[j][1] = (live && 16 + px < KK) ? *reinterpret_cast<const xr_f4*>(a.prm + (size_t)(16 + px) * a.CexpP + ch) * dsc : z;
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < TO; ++t2) {   // project A fragment of cout tile t2 for this tile's 16-deep k step: W[16 t2 + m][16 t + 4 g ..]
+            const int co = 16 * t2 + px;
+            const char* prow = reinterpret_cast<const char*>(a.wp) + ((size_t)(co < a.Cout ? co : 0) * a.CexpP + 16 * tc + 4 * mg) * 2;
+            xr_u2 v = *reinterpret_cast<const xr_u2*>(prow);
+            if (co >= a.Cout || !live) v = (xr_u2){0u, 0u};
+            wpf[j][t2] = v;
+        }
+    }
+    // the cout tile this wave finishes (t = w, if w < TO; with fewer waves than cout tiles, wave w also finishes w + NW, ...)
+    constexpr int NF = (TO + NW - 1) / NW;
+    bool flive[NF];
+    int fco[NF];
+    xr_f4 fsc[NF], fsh[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int t = w + f * NW;
+        fco[f] = 16 * t + 4 * mg;
+        const bool in = t < TO && fco[f] < a.Cout;
+        flive[f] = in && out_lane;
+        fsc[f] = in ? *reinterpret_cast<const xr_f4*>(a.sp + fco[f]) : (xr_f4){0.f, 0.f, 0.f, 0.f};
+        fsh[f] = in ? *reinterpret_cast<const xr_f4*>(a.hp + fco[f]) : (xr_f4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    const xr_rsrc xsrc = xr_make_rsrc(reinterpret_cast<const T*>(a.x) + (size_t)b * a.H * a.W * a.ld_in, (unsigned)(a.H * a.W * a.ld_in) * 2u);
+    const xr_rsrc osrc = xr_make_rsrc(reinterpret_cast<T*>(a.out) + (size_t)b * a.Ho * a.Wo * a.ld_out, (unsigned)(a.Ho * a.Wo * a.ld_out) * 2u);
+    const int rbeg = S * yo0 - a.pad_t, nout = yo1 - yo0;
+    unsigned xoff[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) xoff[c] = (32 * c + 8 * mg < a.Cin) ? ((unsigned)xc * (unsigned)a.ld_in + 32u * c + 8u * mg) * 2u : XR_DEAD;
+    const unsigned xrow = (unsigned)(a.W * a.ld_in) * 2u;
+    struct XRow { xr_u4 m[NC]; };
+    XRow xa, xb;
+    auto load_row = [&](XRow& x, int r) {
+        const unsigned so = (unsigned)min(max(r, 0), a.H - 1) * xrow;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) x.m[c] = __builtin_bit_cast(xr_u4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[c], so, 0));
+    };
+    load_row(xa, rbeg);
+    xr_f4 ring[NT][K - 1];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int q = 0; q < K - 1; ++q) ring[j][q] = (xr_f4){0.f, 0.f, 0.f, 0.f};
+    int buf = 0;
+    typedef T t4 __attribute__((ext_vector_type(4)));
+
+    auto row = [&](auto emit_c, const int k, const int yo, const XRow& xc_, XRow& xn_) {
+        constexpr bool EMIT = decltype(emit_c)::value;
+        const int r = rbeg + k;
+        load_row(xn_, r + 1);
+        xr_u2 resv[NF];
+        if constexpr (EMIT) {   // UNCONDITIONAL (a dead offset reads zeros without a residual): a load under a branch makes every later wait vmcnt(0)
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+                resv[f] = __builtin_bit_cast(xr_u2, __builtin_amdgcn_raw_buffer_load_b64(xsrc, (flive[f] && a.has_res) ? (((unsigned)yo * (unsigned)a.Wo + (unsigned)xo) * (unsigned)a.ld_in + (unsigned)fco[f]) * 2u : XR_DEAD, 0, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (the loads are issued HERE: left alone the scheduler sinks the residual load to its use behind the barrier)
+        const float hr = (r >= 0 && r < a.H) ? hi : 0.f;
+        xr_f4 ec[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            xr_f4 d = (xr_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) d = xr_mfma<T>(aw[j][c], xc_.m[c], d);
+            ec[j] = xr_bn_act4<ACT>(d, es[j], eh[j], hr);
+        }
+        if constexpr (EMIT) {
+            xr_f4 P[TO];
+#pragma unroll
+            for (int t = 0; t < TO; ++t) P[t] = (xr_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                xr_f4 d = dh[j];
+                if constexpr (K == 3) {
+                    xr_row3(d, ring[j][0], tp[j][0], tp[j][1], tp[j][2]);
+                    xr_row3(d, ring[j][1], tp[j][3], tp[j][4], tp[j][5]);
+                    xr_row3(d, ec[j], tp[j][6], tp[j][7], tp[j][8]);
+                } else {
+                    float cs[5][4];   // the five column sums (see xr_bc5_row)
+                    xr_bc5_row<0>(cs, ring[j][0], tp[j][0], tp[j][1]);
+                    xr_bc5_row<1>(cs, ring[j][1], tp[j][0], tp[j][1]);
+                    xr_bc5_row<2>(cs, ring[j][2], tp[j][0], tp[j][1]);
+                    xr_bc5_row<3>(cs, ring[j][3], tp[j][0], tp[j][1]);
+                    xr_bc5_row<4>(cs, ec[j], tp[j][0], tp[j][1]);
+                    d = xr_bc5_finish(cs, d);
+                }
+                const xr_f4 v = xr_act4<ACT>(d, HI);
+                const xr_u2 bop = __builtin_bit_cast(xr_u2, __builtin_convertvector(v, t4));   // rounded: the projection's operand type
+#pragma unroll
+                for (int t = 0; t < TO; ++t) P[t] = xr_mfma16<T>(wpf[j][t], bop, P[t]);
+            }
+            xr_f4* rb = red + buf * (NW * TO * 64);
+#pragma unroll
+            for (int t = 0; t < TO; ++t) rb[(w * TO + t) * 64 + lane] = P[t];
+            __syncthreads();
+            const unsigned opix = ((unsigned)yo * (unsigned)a.Wo + (unsigned)xo) * (unsigned)a.ld_out;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int t = w + f * NW;
+                xr_f4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (t < TO) {
+#pragma unroll
+                    for (int ww = 0; ww < NW; ++ww) acc += rb[(ww * TO + t) * 64 + lane];
+                }
+                xr_f4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(acc[i], fsc[f][i], fsh[f][i]);
+                v += __builtin_convertvector(__builtin_bit_cast(t4, resv[f]), xr_f4);   // (zeros without a residual)
+                const t4 o = __builtin_convertvector(v, t4);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(xr_u2, o), osrc, flive[f] ? (opix + (unsigned)fco[f]) * 2u : XR_DEAD, 0, 0);
+            }
+            buf ^= 1;
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int q = 0; q + 1 < K - 1; ++q) ring[j][q] = ring[j][q + 1];
+            ring[j][K - 2] = ec[j];
+        }
+    };
+    constexpr std::true_type Y{};
+    constexpr std::false_type N{};
+    // rows 0 .. K - S - 1 warm the ring up; then every output row takes S input rows, the last of which emits
+    int k = 0;
+#pragma unroll
+    for (int q = 0; q < (K - S) / 2; ++q) { row(N, k, 0, xa, xb); row(N, k + 1, 0, xb, xa); k += 2; }
+    if constexpr ((K - S) % 2 != 0) { row(N, k, 0, xa, xb); k += 1; }
+    if constexpr (S == 2) {   // (an odd warm-up: the current row's operands are in xb)
+        for (int i = 0; i < nout; ++i) {
+            row(N, k, 0, xb, xa);
+            row(Y, k + 1, yo0 + i, xa, xb);
+            k += 2;
+        }
+    } else {
+        int i = 0;
+        for (; i + 1 < nout; i += 2) {
+            row(Y, k, yo0 + i, xa, xb);
+            row(Y, k + 1, yo0 + i + 1, xb, xa);
+            k += 2;
+        }
+        if (i < nout) row(Y, k, yo0 + i, xa, xb);
+    }
+}
+
+template <class T, int K, int S, int ACT, int NC, int TO, int NT, int NW>
+static int launch_mbhq(const MbhrArgs& a0, int batch, int want_segs, hipStream_t s) {
+    MbhrArgs a = a0;
+    constexpr int NOUT = (16 - K) / S + 1;
+    constexpr int MW = 2;
+    static_assert(NW <= 4 * MW, "the workgroup's waves must fit one CU");
+    a.strips = (a.Wo + NOUT - 1) / NOUT;
+    const int walks = batch * a.strips;
+    int segs = (2 * 1024 + walks * NW - 1) / (walks * NW);
+    const int max_segs = (a.Ho + 3 * K - 1) / (3 * K);   // (a segment recomputes K - S halo rows)
+    if (segs > max_segs) segs = max_segs;
+    if (segs < 1) segs = 1;
+    if (want_segs > 0) segs = want_segs < a.Ho ? want_segs : a.Ho;
+    a.seg_rows = (a.Ho + segs - 1) / segs;
+    a.segs = (a.Ho + a.seg_rows - 1) / a.seg_rows;
+    const size_t lds = (size_t)2 * NW * TO * 64 * 16;
+    static char nm[64];
+    static const int nm_len = snprintf(nm, sizeof(nm), "mbhq_kernel<%s,%d,%d,%d,%d,%d,%d,%d>", yr_dtype_name(yr_elem<T>::dtype), K, S, ACT, NC, TO, NT, NW);
+    (void)nm_len;
+    yr_note_kernel(nm);
+    auto kern = mbhq_kernel<T, K, S, ACT, NC, TO, NT, NW, MW>;
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        YR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(batch * a.strips * a.segs)), dim3(64 * NW), lds, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
+// shapes of the tile-wise form: (kernel, input chunks, cout tiles, expanded tiles) -> (tiles per wave, waves)
+struct MbhqShape { int k, nc, to, t, nt, nw; };
+static const MbhqShape MBHQ_SHAPES[] = {
+    {5, 1, 3, 9, 3, 3},     // 24 -> 144 -> 40 (EfficientNet-lite0 stage 3 entry, stride 2)
+    {5, 1, 3, 12, 3, 4},    // 32 -> 192 -> 48 (lite3 stage 3 entry, stride 2)
+    {5, 2, 3, 18, 3, 6},    // 48 -> 288 -> 48 (lite3 stage 3)
+    {5, 2, 3, 15, 2, 8},    // 40 -> 240 -> 40 (lite0 stage 3)
+    {3, 1, 2, 9, 3, 3},     // 24 -> 144 -> 24 / 32 (lite0 stage 2, lite3 stage 2 entry, MobileNetV2 x0.75 block_2, 3)
+};
+static const MbhqShape* mbhq_shape(int k, int cin, int cexp, int cout) {
+    const int nc = yr_round_up(cin, 32) / 32, to = (cout + 15) / 16, t = cexp / 16;
+    for (const MbhqShape& sh : MBHQ_SHAPES)
+        if (sh.k == k && sh.nc == nc && sh.to == to && sh.t == t) return &sh;
+    return nullptr;
+}
+
+template <class T, int S>
+static int launch_mbhq_shape(const MbhrArgs& a, int k, int batch, int segs, hipStream_t s) {
+    const MbhqShape* sh = mbhq_shape(k, a.Cin, a.T * 16, a.Cout);
+    YR_REQUIRE(sh != nullptr, "mbhq: block %d -> %d -> %d (%d x %d) is not built", a.Cin, a.T * 16, a.Cout, k, k);
+#define HQ_CASE(KV, NCV, TOV, TV, NTV, NWV) if (sh->k == KV && sh->nc == NCV && sh->to == TOV && sh->t == TV) return launch_mbhq<T, KV, S, 0, NCV, TOV, NTV, NWV>(a, batch, segs, s);
+    HQ_CASE(5, 1, 3, 9, 3, 3)
+    HQ_CASE(5, 1, 3, 12, 3, 4)
+    HQ_CASE(5, 2, 3, 18, 3, 6)
+    HQ_CASE(5, 2, 3, 15, 2, 8)
+    HQ_CASE(3, 1, 2, 9, 3, 3)
+#undef HQ_CASE
+    return YR_ERR_ARG;
+}
+
 // the whole-block register-chained form is built for: 3x3, at most 16 expanded tiles, cin <= 64, cout <= 80
 bool yr_mbhr_takes(const yr_op& op) {
     return op.kind == YR_OP_MBH && (op.dtype == YR_BF16 || op.dtype == YR_F16) && (op.k & 0xff) == 3 && (op.stride == 1 || op.stride == 2) &&
@@ -711,12 +1168,21 @@ static int launch_mbhr_shape(const MbhrArgs& a, int batch, int segs, hipStream_t
     return YR_ERR_ARG;
 }
 
-bool yr_mbhr_built(const yr_op& op) {
+static bool mbhr_pair_built(const yr_op& op) {
     if (!yr_mbhr_takes(op)) return false;
     const int nc = yr_round_up(op.cin, 32) / 32, to = (op.cout + 15) / 16, nw = (op.se_reduced / 16 + 1) / 2;
     const int key = nc * 10000 + to * 100 + nw;
     return key == 10203 || key == 10206 || key == 10306 || key == 20508 || key == 20308;
 }
+// the tile-wise form (mbhq_kernel): 3x3 / 5x5, ReLU6, the shapes of MBHQ_SHAPES
+static bool mbhq_built(const yr_op& op) {
+    static const bool on = !(getenv("YOLORET_MBHQ") && atoi(getenv("YOLORET_MBHQ")) == 0);
+    const int K = op.k & 0xff;
+    return on && op.kind == YR_OP_MBH && (op.dtype == YR_BF16 || op.dtype == YR_F16) && (K == 3 || K == 5) && (op.stride == 1 || op.stride == 2) &&
+           op.act == YR_ACT_RELU6 && op.cin % 8 == 0 && op.cin <= 64 && op.se_reduced % 16 == 0 && op.cout % 4 == 0 && op.nsrc == 1 &&
+           op.out_ld % 4 == 0 && mbhq_shape(K, op.cin, op.se_reduced, op.cout) != nullptr;
+}
+bool yr_mbhr_built(const yr_op& op) { return mbhr_pair_built(op) || mbhq_built(op); }
 
 template <class T>
 static int launch_mbhr_t(const yr_op& op, int batch, int segs, hipStream_t s) {
@@ -725,9 +1191,11 @@ static int launch_mbhr_t(const yr_op& op, int batch, int segs, hipStream_t s) {
     a.x = in.ptr; a.out = op.out; a.we = op.wgt; a.prm = op.wgt2; a.wp = op.b1; a.sp = op.b2; a.hp = op.b2 + yr_round_up(op.cout, 8);
     a.H = in.h; a.W = in.w; a.Ho = op.h; a.Wo = op.w; a.Cin = in.c; a.CexpP = yr_round_up(op.se_reduced, 32); a.KP = yr_round_up(in.c, 32);
     a.Cout = op.cout; a.ld_in = in.ld; a.ld_out = op.out_ld; a.T = op.se_reduced / 16; a.has_res = op.res != nullptr;
-    const int pth = (a.Ho - 1) * op.stride + 3 - in.h, ptw = (a.Wo - 1) * op.stride + 3 - in.w;
+    const int K = op.k & 0xff;
+    const int pth = (a.Ho - 1) * op.stride + K - in.h, ptw = (a.Wo - 1) * op.stride + K - in.w;
     a.pad_t = (pth > 0 ? pth : 0) / 2; a.pad_l = (ptw > 0 ? ptw : 0) / 2;
     a.strips = a.segs = a.seg_rows = 0;
+    if (!mbhr_pair_built(op)) return op.stride == 1 ? launch_mbhq_shape<T, 1>(a, K, batch, segs, s) : launch_mbhq_shape<T, 2>(a, K, batch, segs, s);
     if (op.act == YR_ACT_RELU6) return op.stride == 1 ? launch_mbhr_shape<T, 1, 0>(a, batch, segs, s) : launch_mbhr_shape<T, 2, 0>(a, batch, segs, s);
     return op.stride == 1 ? launch_mbhr_shape<T, 1, 1>(a, batch, segs, s) : launch_mbhr_shape<T, 2, 1>(a, batch, segs, s);
 }
