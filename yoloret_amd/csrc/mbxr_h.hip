@@ -129,6 +129,169 @@ __device__ __forceinline__ xr_f4 xr_bn_act4(const xr_f4 d, const xr_f4 sc, const
     return xr_act4<ACT>(t, hi);
 }
 
+// 5x5 depthwise taps WITHOUT a register per tap: the 25 taps of a channel live in TWO registers, lane p of every 16-lane row
+// holding tap p (register 0) / tap 16 + p (register 1) of the lane's channel, and a multiply-add reads the tap it needs through
+// DPP row_newbcast:p (gfx90a+: lane p of the row, broadcast to the row; tools/dpp_bcast_test.hip).  DPP modifies one operand
+// only, so the horizontal shift cannot ride on the same instruction: the five COLUMN sums S_dx = sum_ky tap(ky, dx) * e_ky are
+// accumulated unshifted and the shifts are applied once per output row, to the sums:
+//   out = shift + S_2 + shr2(S_0) + shr1(S_1) + shl1(S_3) + shl2(S_4)
+// 30 instead of 25 instructions per channel and output row, 8 instead of 100 tap registers per tile, no LDS table (an LDS table
+// read where it is used costs 25 ds_read_b128 per tile and output row: 0.31 ms on EfficientNet-lite0's stage-3 entry, LDS-bound).
+template <int KY> __device__ __forceinline__ void xr_bc5_row(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1);
+template <> __device__ __forceinline__ void xr_bc5_row<0>(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
+    asm("v_mul_f32_dpp %0, %16, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %17, %13 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %2, %18, %14 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %3, %19, %15 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %4, %16, %12 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %5, %17, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %6, %18, %14 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %7, %19, %15 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %8, %16, %12 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %9, %17, %13 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %10, %18, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %11, %19, %15 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        : "=&v"(S[0][0]), "=&v"(S[0][1]), "=&v"(S[0][2]), "=&v"(S[0][3]), "=&v"(S[1][0]), "=&v"(S[1][1]), "=&v"(S[1][2]), "=&v"(S[1][3]), "=&v"(S[2][0]), "=&v"(S[2][1]), "=&v"(S[2][2]), "=&v"(S[2][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+    asm("v_mul_f32_dpp %0, %12, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %13, %9 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %2, %14, %10 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %3, %15, %11 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %4, %12, %8 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %5, %13, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %6, %14, %10 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %7, %15, %11 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        : "=&v"(S[3][0]), "=&v"(S[3][1]), "=&v"(S[3][2]), "=&v"(S[3][3]), "=&v"(S[4][0]), "=&v"(S[4][1]), "=&v"(S[4][2]), "=&v"(S[4][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+}
+template <> __device__ __forceinline__ void xr_bc5_row<1>(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
+    asm("v_fmac_f32_dpp %0, %16, %12 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %17, %13 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %18, %14 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %19, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %16, %12 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %17, %13 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %18, %14 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %19, %15 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %8, %16, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %9, %17, %13 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %10, %18, %14 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %11, %19, %15 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[2][0]), "+v"(S[2][1]), "+v"(S[2][2]), "+v"(S[2][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+    asm("v_fmac_f32_dpp %0, %12, %8 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %13, %9 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %14, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %15, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %12, %8 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %13, %9 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %14, %10 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %15, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(S[3][0]), "+v"(S[3][1]), "+v"(S[3][2]), "+v"(S[3][3]), "+v"(S[4][0]), "+v"(S[4][1]), "+v"(S[4][2]), "+v"(S[4][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+}
+template <> __device__ __forceinline__ void xr_bc5_row<2>(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
+    asm("v_fmac_f32_dpp %0, %16, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %17, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %18, %14 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %19, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %16, %12 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %17, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %18, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %19, %15 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %8, %16, %12 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %9, %17, %13 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %10, %18, %14 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %11, %19, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[2][0]), "+v"(S[2][1]), "+v"(S[2][2]), "+v"(S[2][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+    asm("v_fmac_f32_dpp %0, %12, %8 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %13, %9 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %14, %10 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %15, %11 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %12, %8 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %13, %9 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %14, %10 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %15, %11 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(S[3][0]), "+v"(S[3][1]), "+v"(S[3][2]), "+v"(S[3][3]), "+v"(S[4][0]), "+v"(S[4][1]), "+v"(S[4][2]), "+v"(S[4][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+}
+template <> __device__ __forceinline__ void xr_bc5_row<3>(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
+    asm("v_fmac_f32_dpp %0, %16, %12 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %17, %13 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %18, %14 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %19, %15 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %20, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %21, %13 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %22, %14 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %23, %15 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %8, %20, %12 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %9, %21, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %10, %22, %14 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %11, %23, %15 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[2][0]), "+v"(S[2][1]), "+v"(S[2][2]), "+v"(S[2][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+    asm("v_fmac_f32_dpp %0, %16, %8 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %17, %9 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %18, %10 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %19, %11 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %16, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %17, %9 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %18, %10 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %19, %11 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(S[3][0]), "+v"(S[3][1]), "+v"(S[3][2]), "+v"(S[3][3]), "+v"(S[4][0]), "+v"(S[4][1]), "+v"(S[4][2]), "+v"(S[4][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+}
+template <> __device__ __forceinline__ void xr_bc5_row<4>(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
+    asm("v_fmac_f32_dpp %0, %20, %12 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %21, %13 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %22, %14 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %23, %15 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %20, %12 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %21, %13 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %22, %14 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %23, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %8, %20, %12 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %9, %21, %13 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %10, %22, %14 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %11, %23, %15 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[2][0]), "+v"(S[2][1]), "+v"(S[2][2]), "+v"(S[2][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+    asm("v_fmac_f32_dpp %0, %16, %8 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %17, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %18, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %19, %11 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %16, %8 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %17, %9 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %18, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %19, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(S[3][0]), "+v"(S[3][1]), "+v"(S[3][2]), "+v"(S[3][3]), "+v"(S[4][0]), "+v"(S[4][1]), "+v"(S[4][2]), "+v"(S[4][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+}
+__device__ __forceinline__ xr_f4 xr_bc5_finish(const float (&S)[5][4], const xr_f4 shift) {
+    float o0 = shift[0] + S[2][0], o1 = shift[1] + S[2][1], o2 = shift[2] + S[2][2], o3 = shift[3] + S[2][3];
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %5, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %6, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %7, %3 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %8, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %9, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %10, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %11, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %12, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %13, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %14, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %15, %3 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %16, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %17, %1 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %18, %2 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %19, %3 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
+        : "v"(S[0][0]), "v"(S[0][1]), "v"(S[0][2]), "v"(S[0][3]), "v"(S[1][0]), "v"(S[1][1]), "v"(S[1][2]), "v"(S[1][3]), "v"(S[3][0]), "v"(S[3][1]), "v"(S[3][2]), "v"(S[3][3]), "v"(S[4][0]), "v"(S[4][1]), "v"(S[4][2]), "v"(S[4][3]));
+    return (xr_f4){o0, o1, o2, o3};
+}
+
 // K: depthwise kernel, S: stride, ACT: 0 relu6 / 1 swish (both activations), NC: 32-channel chunks of the block input, NT: tiles per wave
 template <class T, int K, int S, int ACT, int NC, int NT, int MW>
 __global__ __launch_bounds__(256, MW) void mbxr_kernel(MbxrArgs a) {
@@ -152,7 +315,11 @@ __global__ __launch_bounds__(256, MW) void mbxr_kernel(MbxrArgs a) {
 
     // ---- stationary: expand A fragments, BN rows, taps (times the depthwise BN scale) of this wave's tiles
     xr_u4 aw[NT][NC];
-    xr_f4 es[NT], eh[NT], dh[NT], tp[NT][KK], ssum[NT];
+    // 5x5 behind four input chunks: the broadcast-tap form (lane p of a row holds tap p / tap 16 + p, xr_bc5_row) - a register per tap
+    // leaves those blocks two waves per SIMD at 242 registers; with fewer chunks the 20 % more instructions of that form cost more
+    // than the registers (measured, batch 128: 24 -> 144 s2 0.227 vs 0.270 ms; 112 -> 672 s2 0.126 vs 0.107)
+    constexpr bool BC5 = K == 5 && NC >= 4;
+    xr_f4 es[NT], eh[NT], dh[NT], tp[NT][BC5 ? 2 : KK], ssum[NT];
     unsigned ooff[NT];
     bool tlive[NT];
 #pragma unroll
@@ -167,8 +334,13 @@ __global__ __launch_bounds__(256, MW) void mbxr_kernel(MbxrArgs a) {
         dh[j] = *reinterpret_cast<const xr_f4*>(a.prm + (size_t)(KK + 1) * a.CexpP + ch);
         es[j] = *reinterpret_cast<const xr_f4*>(a.prm + (size_t)(KK + 2) * a.CexpP + ch);
         eh[j] = *reinterpret_cast<const xr_f4*>(a.prm + (size_t)(KK + 3) * a.CexpP + ch);
+        if constexpr (BC5) {
+            tp[j][0] = *reinterpret_cast<const xr_f4*>(a.prm + (size_t)px * a.CexpP + ch) * dsc;
+            tp[j][1] = 16 + px < KK ? *reinterpret_cast<const xr_f4*>(a.prm + (size_t)(16 + px) * a.CexpP + ch) * dsc : (xr_f4){0.f, 0.f, 0.f, 0.f};
+        } else {
 #pragma unroll
-        for (int q = 0; q < KK; ++q) tp[j][q] = *reinterpret_cast<const xr_f4*>(a.prm + (size_t)q * a.CexpP + ch) * dsc;
+            for (int q = 0; q < KK; ++q) tp[j][q] = *reinterpret_cast<const xr_f4*>(a.prm + (size_t)q * a.CexpP + ch) * dsc;
+        }
         ssum[j] = (xr_f4){0.f, 0.f, 0.f, 0.f};
         ooff[j] = (tlive[j] && out_lane) ? (unsigned)ch * 2u : XR_DEAD;
     }
@@ -215,10 +387,18 @@ __global__ __launch_bounds__(256, MW) void mbxr_kernel(MbxrArgs a) {
                     xr_row3(d, ring[j][0], tp[j][0], tp[j][1], tp[j][2]);
                     xr_row3(d, ring[j][1], tp[j][3], tp[j][4], tp[j][5]);
                     xr_row3(d, ec[j], tp[j][6], tp[j][7], tp[j][8]);
-                } else {
+                } else if constexpr (!BC5) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) xr_row5(d, ring[j][q], tp[j][5 * q], tp[j][5 * q + 1], tp[j][5 * q + 2], tp[j][5 * q + 3], tp[j][5 * q + 4]);
                     xr_row5(d, ec[j], tp[j][20], tp[j][21], tp[j][22], tp[j][23], tp[j][24]);
+                } else {
+                    float cs[5][4];   // the five column sums
+                    xr_bc5_row<0>(cs, ring[j][0], tp[j][0], tp[j][1]);
+                    xr_bc5_row<1>(cs, ring[j][1], tp[j][0], tp[j][1]);
+                    xr_bc5_row<2>(cs, ring[j][2], tp[j][0], tp[j][1]);
+                    xr_bc5_row<3>(cs, ring[j][3], tp[j][0], tp[j][1]);
+                    xr_bc5_row<4>(cs, ec[j], tp[j][0], tp[j][1]);
+                    d = xr_bc5_finish(cs, d);
                 }
                 typedef T t4 __attribute__((ext_vector_type(4)));
                 const xr_f4 v = xr_act4<ACT>(d, HI);
@@ -292,7 +472,8 @@ template <class T, int K, int S, int ACT, int NC, int NT>
 static int launch_mbxr(const MbxrArgs& a0, int batch, int want_segs, hipStream_t s) {
     MbxrArgs a = a0;
     constexpr int NOUT = (16 - K) / S + 1;
-    constexpr int EST = NT * (4 * NC + 16 + 4 * K * K + 4 * (K - 1) + 8) + 8 * NC + 48;
+    constexpr bool BC5 = K == 5 && NC >= 4;
+    constexpr int EST = NT * (4 * NC + 16 + (BC5 ? 8 : 4 * K * K) + 4 * (K - 1) + 8) + 8 * NC + 48 + (BC5 ? 20 : 0);
     constexpr int MW = EST <= 120 ? 4 : EST <= 160 ? 3 : EST <= 250 ? 2 : 1;
     a.strips = (a.Wo + NOUT - 1) / NOUT;
     a.groups = (a.T + NT - 1) / NT;
@@ -323,7 +504,7 @@ static int launch_mbxr_nc(const MbxrArgs& a, int batch, int segs, hipStream_t s)
         case 1: return launch_mbxr<T, K, S, ACT, 1, NT>(a, batch, segs, s);
         case 2: return launch_mbxr<T, K, S, ACT, 2, NT>(a, batch, segs, s);
         case 3: return launch_mbxr<T, K, S, ACT, 3, NT>(a, batch, segs, s);
-        case 4: return launch_mbxr<T, K, S, ACT, 4, NT>(a, batch, segs, s);
+        case 4: return launch_mbxr<T, K, S, ACT, 4, 2>(a, batch, segs, s);   // (5x5: the broadcast-tap form, two tiles per wave)
         default: yr_set_error("mbxr: %d input channels are not built", a.Cin); return YR_ERR_ARG;
     }
 }
@@ -731,169 +912,6 @@ __device__ __forceinline__ xr_f4 xr_mfma16(xr_u2 w, xr_u2 x, xr_f4 acc) {
         return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(xr_s4, w), __builtin_bit_cast(xr_s4, x), acc, 0, 0, 0);
     else
         return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(xr_h4, w), __builtin_bit_cast(xr_h4, x), acc, 0, 0, 0);
-}
-
-// 5x5 depthwise taps WITHOUT a register per tap: the 25 taps of a channel live in TWO registers, lane p of every 16-lane row
-// holding tap p (register 0) / tap 16 + p (register 1) of the lane's channel, and a multiply-add reads the tap it needs through
-// DPP row_newbcast:p (gfx90a+: lane p of the row, broadcast to the row; tools/dpp_bcast_test.hip).  DPP modifies one operand
-// only, so the horizontal shift cannot ride on the same instruction: the five COLUMN sums S_dx = sum_ky tap(ky, dx) * e_ky are
-// accumulated unshifted and the shifts are applied once per output row, to the sums:
-//   out = shift + S_2 + shr2(S_0) + shr1(S_1) + shl1(S_3) + shl2(S_4)
-// 30 instead of 25 instructions per channel and output row, 8 instead of 100 tap registers per tile, no LDS table (an LDS table
-// read where it is used costs 25 ds_read_b128 per tile and output row: 0.31 ms on EfficientNet-lite0's stage-3 entry, LDS-bound).
-template <int KY> __device__ __forceinline__ void xr_bc5_row(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1);
-template <> __device__ __forceinline__ void xr_bc5_row<0>(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
-    asm("v_mul_f32_dpp %0, %16, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %1, %17, %13 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %2, %18, %14 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %3, %19, %15 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %4, %16, %12 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %5, %17, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %6, %18, %14 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %7, %19, %15 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %8, %16, %12 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %9, %17, %13 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %10, %18, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %11, %19, %15 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-        : "=&v"(S[0][0]), "=&v"(S[0][1]), "=&v"(S[0][2]), "=&v"(S[0][3]), "=&v"(S[1][0]), "=&v"(S[1][1]), "=&v"(S[1][2]), "=&v"(S[1][3]), "=&v"(S[2][0]), "=&v"(S[2][1]), "=&v"(S[2][2]), "=&v"(S[2][3])
-        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
-    asm("v_mul_f32_dpp %0, %12, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %1, %13, %9 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %2, %14, %10 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %3, %15, %11 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %4, %12, %8 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %5, %13, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %6, %14, %10 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %7, %15, %11 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-        : "=&v"(S[3][0]), "=&v"(S[3][1]), "=&v"(S[3][2]), "=&v"(S[3][3]), "=&v"(S[4][0]), "=&v"(S[4][1]), "=&v"(S[4][2]), "=&v"(S[4][3])
-        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
-}
-template <> __device__ __forceinline__ void xr_bc5_row<1>(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
-    asm("v_fmac_f32_dpp %0, %16, %12 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %1, %17, %13 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %2, %18, %14 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %3, %19, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %4, %16, %12 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %5, %17, %13 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %6, %18, %14 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %7, %19, %15 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %8, %16, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %9, %17, %13 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %10, %18, %14 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %11, %19, %15 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-        : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[2][0]), "+v"(S[2][1]), "+v"(S[2][2]), "+v"(S[2][3])
-        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
-    asm("v_fmac_f32_dpp %0, %12, %8 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %1, %13, %9 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %2, %14, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %3, %15, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %4, %12, %8 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %5, %13, %9 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %6, %14, %10 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %7, %15, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-        : "+v"(S[3][0]), "+v"(S[3][1]), "+v"(S[3][2]), "+v"(S[3][3]), "+v"(S[4][0]), "+v"(S[4][1]), "+v"(S[4][2]), "+v"(S[4][3])
-        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
-}
-template <> __device__ __forceinline__ void xr_bc5_row<2>(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
-    asm("v_fmac_f32_dpp %0, %16, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %1, %17, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %2, %18, %14 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %3, %19, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %4, %16, %12 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %5, %17, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %6, %18, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %7, %19, %15 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %8, %16, %12 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %9, %17, %13 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %10, %18, %14 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %11, %19, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
-        : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[2][0]), "+v"(S[2][1]), "+v"(S[2][2]), "+v"(S[2][3])
-        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
-    asm("v_fmac_f32_dpp %0, %12, %8 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %1, %13, %9 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %2, %14, %10 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %3, %15, %11 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %4, %12, %8 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %5, %13, %9 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %6, %14, %10 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %7, %15, %11 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
-        : "+v"(S[3][0]), "+v"(S[3][1]), "+v"(S[3][2]), "+v"(S[3][3]), "+v"(S[4][0]), "+v"(S[4][1]), "+v"(S[4][2]), "+v"(S[4][3])
-        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
-}
-template <> __device__ __forceinline__ void xr_bc5_row<3>(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
-    asm("v_fmac_f32_dpp %0, %16, %12 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %1, %17, %13 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %2, %18, %14 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %3, %19, %15 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %4, %20, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %5, %21, %13 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %6, %22, %14 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %7, %23, %15 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %8, %20, %12 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %9, %21, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %10, %22, %14 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %11, %23, %15 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-        : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[2][0]), "+v"(S[2][1]), "+v"(S[2][2]), "+v"(S[2][3])
-        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
-    asm("v_fmac_f32_dpp %0, %16, %8 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %1, %17, %9 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %2, %18, %10 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %3, %19, %11 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %4, %16, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %5, %17, %9 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %6, %18, %10 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %7, %19, %11 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-        : "+v"(S[3][0]), "+v"(S[3][1]), "+v"(S[3][2]), "+v"(S[3][3]), "+v"(S[4][0]), "+v"(S[4][1]), "+v"(S[4][2]), "+v"(S[4][3])
-        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
-}
-template <> __device__ __forceinline__ void xr_bc5_row<4>(float (&S)[5][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
-    asm("v_fmac_f32_dpp %0, %20, %12 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %1, %21, %13 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %2, %22, %14 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %3, %23, %15 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %4, %20, %12 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %5, %21, %13 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %6, %22, %14 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %7, %23, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %8, %20, %12 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %9, %21, %13 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %10, %22, %14 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %11, %23, %15 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-        : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[2][0]), "+v"(S[2][1]), "+v"(S[2][2]), "+v"(S[2][3])
-        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
-    asm("v_fmac_f32_dpp %0, %16, %8 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %1, %17, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %2, %18, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %3, %19, %11 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %4, %16, %8 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %5, %17, %9 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %6, %18, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %7, %19, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-        : "+v"(S[3][0]), "+v"(S[3][1]), "+v"(S[3][2]), "+v"(S[3][3]), "+v"(S[4][0]), "+v"(S[4][1]), "+v"(S[4][2]), "+v"(S[4][3])
-        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
-}
-__device__ __forceinline__ xr_f4 xr_bc5_finish(const float (&S)[5][4], const xr_f4 shift) {
-    float o0 = shift[0] + S[2][0], o1 = shift[1] + S[2][1], o2 = shift[2] + S[2][2], o3 = shift[3] + S[2][3];
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %4, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %5, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %2, %6, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %3, %7, %3 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %0, %8, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %9, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %2, %10, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %3, %11, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %0, %12, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %13, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %2, %14, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %3, %15, %3 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %0, %16, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %17, %1 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %2, %18, %2 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %3, %19, %3 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
-        : "v"(S[0][0]), "v"(S[0][1]), "v"(S[0][2]), "v"(S[0][3]), "v"(S[1][0]), "v"(S[1][1]), "v"(S[1][2]), "v"(S[1][3]), "v"(S[3][0]), "v"(S[3][1]), "v"(S[3][2]), "v"(S[3][3]), "v"(S[4][0]), "v"(S[4][1]), "v"(S[4][2]), "v"(S[4][3]));
-    return (xr_f4){o0, o1, o2, o3};
 }
 
 template <class T, int K, int S, int ACT, int NC, int TO, int NT, int NW, int MW>
