@@ -154,6 +154,9 @@ MBX_CASES = [
     (13, 13, 80, 480, 3, 1, 'swish', None),      # stage 4
     (13, 13, 112, 672, 5, 1, 'swish', None),     # stage 5: four k-steps of the expand GEMM
     (14, 14, 112, 672, 5, 2, 'swish', None),     # stage 6 entry
+    (27, 31, 16, 96, 3, 2, 'swish', None),       # stride 2 at odd sizes (pad 1/1): the paired-row walk, an odd last pair
+    (23, 29, 24, 144, 5, 2, 'swish', None),      # ... 5x5 (pad 2/2)
+    (37, 18, 32, 192, 3, 2, 'relu6', None),      # ... several segments
     (26, 26, 32, 192, 3, 1, 'relu6', (13, 12)),  # two pixel groups per wave
     (9, 11, 14, 52, 3, 1, 'swish', (4, 8)),      # pad lanes in the input (NaN-filled), width not a multiple of 8
     (20, 20, 48, 288, 5, 1, 'swish', (8, 16)),

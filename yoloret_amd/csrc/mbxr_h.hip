@@ -129,6 +129,46 @@ __device__ __forceinline__ xr_f4 xr_bn_act4(const xr_f4 d, const xr_f4 sc, const
     return xr_act4<ACT>(t, hi);
 }
 
+// STRIDE 2, PAIRED OUTPUT ROWS (as mbr.hip): the expand conv does not care which pixel sits in which lane, so a stride-2 strip
+// loads the EVEN input columns E_0..E_7 into lanes 0..7 of a DPP row and the ODD ones O_0..O_7 into lanes 8..15.  Tap dx of output
+// column j is E_(j + dx/2) (dx even) or O_(j + (dx-1)/2) (dx odd).  An even output row accumulates in lanes 0..7 (bank_mask 0x3:
+// own lane, row_shl:8, row_shl:1, row_shl:9, row_shl:2), the odd row below it in lanes 8..15 of the SAME registers (bank_mask
+// 0xc: row_shr:8, own lane, row_shr:7, row_shl:1, row_shr:6): one activation, one rounding, one store (and in the whole-block
+// kernels one projection and one barrier) per PAIR of output rows, all 16 lanes of it useful (14 / 12 of 16 for 3x3 / 5x5).
+#define XR_DPPM(ctl, bank) " " ctl " row_mask:0xf bank_mask:" bank " bound_ctrl:1\n\t"
+#define XR_PAIR3(c0, c1, c2, bank)                                                                                                   \
+    asm("s_nop 1\n\t"                                                                                                                \
+        "v_fmac_f32_dpp %0, %4, %8" XR_DPPM(c0, bank) "v_fmac_f32_dpp %1, %5, %9" XR_DPPM(c0, bank)                                 \
+        "v_fmac_f32_dpp %2, %6, %10" XR_DPPM(c0, bank) "v_fmac_f32_dpp %3, %7, %11" XR_DPPM(c0, bank)                               \
+        "v_fmac_f32_dpp %0, %4, %12" XR_DPPM(c1, bank) "v_fmac_f32_dpp %1, %5, %13" XR_DPPM(c1, bank)                               \
+        "v_fmac_f32_dpp %2, %6, %14" XR_DPPM(c1, bank) "v_fmac_f32_dpp %3, %7, %15" XR_DPPM(c1, bank)                               \
+        "v_fmac_f32_dpp %0, %4, %16" XR_DPPM(c2, bank) "v_fmac_f32_dpp %1, %5, %17" XR_DPPM(c2, bank)                               \
+        "v_fmac_f32_dpp %2, %6, %18" XR_DPPM(c2, bank) "v_fmac_f32_dpp %3, %7, %19" XR_DPPM(c2, bank)                               \
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)                                                                                     \
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(w[0][0]), "v"(w[0][1]), "v"(w[0][2]), "v"(w[0][3]),                        \
+          "v"(w[1][0]), "v"(w[1][1]), "v"(w[1][2]), "v"(w[1][3]), "v"(w[2][0]), "v"(w[2][1]), "v"(w[2][2]), "v"(w[2][3]))
+#define XR_PAIR2(c3, c4, bank)                                                                                                       \
+    asm("v_fmac_f32_dpp %0, %4, %8" XR_DPPM(c3, bank) "v_fmac_f32_dpp %1, %5, %9" XR_DPPM(c3, bank)                                 \
+        "v_fmac_f32_dpp %2, %6, %10" XR_DPPM(c3, bank) "v_fmac_f32_dpp %3, %7, %11" XR_DPPM(c3, bank)                               \
+        "v_fmac_f32_dpp %0, %4, %12" XR_DPPM(c4, bank) "v_fmac_f32_dpp %1, %5, %13" XR_DPPM(c4, bank)                               \
+        "v_fmac_f32_dpp %2, %6, %14" XR_DPPM(c4, bank) "v_fmac_f32_dpp %3, %7, %15" XR_DPPM(c4, bank)                               \
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)                                                                                     \
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(w[3][0]), "v"(w[3][1]), "v"(w[3][2]), "v"(w[3][3]),                        \
+          "v"(w[4][0]), "v"(w[4][1]), "v"(w[4][2]), "v"(w[4][3]))
+// one tap row (K taps at w[0..K-1]) of the paired form: ODD = the odd output row of the pair (lanes 8..15)
+template <int K, bool ODD>
+__device__ __forceinline__ void xr_row_pair(xr_f4& acc, const xr_f4 e, const xr_f4* w) {
+    float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+    if constexpr (K == 3) {
+        if constexpr (!ODD) XR_PAIR3("quad_perm:[0,1,2,3]", "row_shl:8", "row_shl:1", "0x3");
+        else XR_PAIR3("row_shr:8", "quad_perm:[0,1,2,3]", "row_shr:7", "0xc");
+    } else {
+        if constexpr (!ODD) { XR_PAIR3("quad_perm:[0,1,2,3]", "row_shl:8", "row_shl:1", "0x3"); XR_PAIR2("row_shl:9", "row_shl:2", "0x3"); }
+        else { XR_PAIR3("row_shr:8", "quad_perm:[0,1,2,3]", "row_shr:7", "0xc"); XR_PAIR2("row_shl:1", "row_shr:6", "0xc"); }
+    }
+    acc = (xr_f4){a0, a1, a2, a3};
+}
+
 // 5x5 depthwise taps WITHOUT a register per tap: the 25 taps of a channel live in TWO registers, lane p of every 16-lane row
 // holding tap p (register 0) / tap 16 + p (register 1) of the lane's channel, and a multiply-add reads the tap it needs through
 // DPP row_newbcast:p (gfx90a+: lane p of the row, broadcast to the row; tools/dpp_bcast_test.hip).  DPP modifies one operand
@@ -305,12 +345,15 @@ __global__ __launch_bounds__(256, MW) void mbxr_kernel(MbxrArgs a) {
     const int b = gw / a.strips;
     const int t0 = g * NT;
     const int yo0 = seg * a.seg_rows, yo1 = min(yo0 + a.seg_rows, a.Ho);
-    const int xin = S * NOUT * strip - a.pad_l + px;
+    constexpr bool BC5 = K == 5 && NC >= 4;
+    constexpr bool PAIR = S == 2 && !BC5;   // stride 2: pairs of output rows, even input columns in lanes 0..7, odd ones in 8..15 (xr_row_pair)
+    const int podd = PAIR ? px >> 3 : 0;
+    const int xin = S * NOUT * strip - a.pad_l + (PAIR ? 2 * (px & 7) + podd : px);
     const int xc = min(max(xin, 0), a.W - 1);
     constexpr float HI = ACT == 0 ? 6.f : 1.f;
     const float hi = (xin >= 0 && xin < a.W) ? HI : 0.f;
-    const int jo = (px - PAD) / S, xo = NOUT * strip + jo;
-    const bool out_lane = px >= PAD && (px - PAD) % S == 0 && jo < NOUT && xo < a.Wo;
+    const int jo = PAIR ? (px & 7) : (px - PAD) / S, xo = NOUT * strip + jo;
+    const bool out_lane = (PAIR ? true : (px >= PAD && (px - PAD) % S == 0)) && jo < NOUT && xo < a.Wo;
     const float omask = out_lane ? 1.f : 0.f;
 
     // ---- stationary: expand A fragments, BN rows, taps (times the depthwise BN scale) of this wave's tiles
@@ -318,7 +361,6 @@ __global__ __launch_bounds__(256, MW) void mbxr_kernel(MbxrArgs a) {
     // 5x5 behind four input chunks: the broadcast-tap form (lane p of a row holds tap p / tap 16 + p, xr_bc5_row) - a register per tap
     // leaves those blocks two waves per SIMD at 242 registers; with fewer chunks the 20 % more instructions of that form cost more
     // than the registers (measured, batch 128: 24 -> 144 s2 0.227 vs 0.270 ms; 112 -> 672 s2 0.126 vs 0.107)
-    constexpr bool BC5 = K == 5 && NC >= 4;
     xr_f4 es[NT], eh[NT], dh[NT], tp[NT][BC5 ? 2 : KK], ssum[NT];
     unsigned ooff[NT];
     bool tlive[NT];
@@ -418,6 +460,84 @@ __global__ __launch_bounds__(256, MW) void mbxr_kernel(MbxrArgs a) {
     };
     constexpr std::true_type Y{};
     constexpr std::false_type N{};
+    if constexpr (PAIR) {
+        // A pair of output rows (y, y + 1) reads input rows rho = 0 .. K + 1 (counted from 2 y - pad_t): row y taps ky = rho, row
+        // y + 1 taps ky = rho - 2.  The first K - 2 of them are the last rows of the previous pair (cr), four are new; the
+        // accumulators of the pair (d2) take every row's contribution as soon as the row is expanded.
+        xr_f4 d2[NT], cr[NT][K - 2];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < K - 2; ++q) cr[j][q] = (xr_f4){0.f, 0.f, 0.f, 0.f};
+        auto prow = [&](auto ph_c, const int k, const int yo, const XRow& xc_, XRow& xn_) {
+            constexpr int PH = decltype(ph_c)::value;   // 0: warm-up row; 1..4: the pair's new rows rho = K - 3 + PH
+            const int r = rbeg + k;
+            load_row(xn_, r + 1);
+            const float hr = (r >= 0 && r < a.H) ? hi : 0.f;
+            xr_f4 ec[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                xr_f4 d = (xr_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < NC; ++c) d = xr_mfma<T>(aw[j][c], xc_.m[c], d);
+                ec[j] = xr_bn_act4<ACT>(d, es[j], eh[j], hr);
+            }
+            if constexpr (PH >= 1) {
+                constexpr int RHO = K - 3 + PH;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if constexpr (PH == 1) {
+                        d2[j] = dh[j];   // the BN shift is the first addend, in every lane
+#pragma unroll
+                        for (int c = 0; c < K - 2; ++c) {
+                            xr_row_pair<K, false>(d2[j], cr[j][c], &tp[j][K * c]);
+                            if (c >= 2) xr_row_pair<K, true>(d2[j], cr[j][c], &tp[j][K * (c >= 2 ? c - 2 : 0)]);
+                        }
+                    }
+                    if constexpr (RHO < K) xr_row_pair<K, false>(d2[j], ec[j], &tp[j][K * (RHO < K ? RHO : 0)]);
+                    if constexpr (RHO >= 2) xr_row_pair<K, true>(d2[j], ec[j], &tp[j][K * (RHO >= 2 ? RHO - 2 : 0)]);
+                }
+            }
+            if constexpr (PH == 4) {
+                const int yl = yo + podd;   // (lanes 8..15 hold the row below)
+                const bool rlive = yl < yo1;
+                const float om = rlive ? omask : 0.f;
+                const unsigned opix = ((unsigned)yl * (unsigned)a.Wo + (unsigned)xo) * (unsigned)a.ld_out * 2u;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    typedef T t4 __attribute__((ext_vector_type(4)));
+                    const xr_f4 v = xr_act4<ACT>(d2[j], HI);
+                    const t4 o = __builtin_convertvector(v, t4);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(xr_u2, o), osrc, (ooff[j] == XR_DEAD || !rlive) ? XR_DEAD : opix + ooff[j], 0, 0);
+                    const xr_f4 stored = __builtin_convertvector(o, xr_f4);   // the squeeze sums what was STORED (rounded)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ssum[j][i] = __builtin_fmaf(stored[i], om, ssum[j][i]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+#pragma unroll
+                for (int q = 0; q + 1 < K - 2; ++q) cr[j][q] = cr[j][q + 1];
+                cr[j][K - 3] = ec[j];
+            }
+        };
+        constexpr std::integral_constant<int, 0> P0{};
+        constexpr std::integral_constant<int, 1> P1{};
+        constexpr std::integral_constant<int, 2> P2{};
+        constexpr std::integral_constant<int, 3> P3{};
+        constexpr std::integral_constant<int, 4> P4{};
+        int k = 0;   // K - 2 warm-up rows (odd: afterwards the current row's operands are in xb)
+#pragma unroll
+        for (int q = 0; q < (K - 2) / 2; ++q) { prow(P0, k, 0, xa, xb); prow(P0, k + 1, 0, xb, xa); k += 2; }
+        prow(P0, k, 0, xa, xb); k += 1;
+        for (int i = 0; i < nout; i += 2) {   // (an odd segment's last pair stores its even row only)
+            prow(P1, k, 0, xb, xa);
+            prow(P2, k + 1, 0, xa, xb);
+            prow(P3, k + 2, 0, xb, xa);
+            prow(P4, k + 3, yo0 + i, xa, xb);
+            k += 4;
+        }
+    } else {
     // rows 0 .. K - S - 1 warm the ring up; then every output row takes S input rows, the last of which emits
     int k = 0;
     if constexpr ((K - S) % 2 == 0) {
@@ -442,6 +562,7 @@ __global__ __launch_bounds__(256, MW) void mbxr_kernel(MbxrArgs a) {
             k += 2;
         }
         if (i < nout) row(Y, k, yo0 + i, xa, xb);
+    }
     }
     // ---- the squeeze: this wave's channel sums over its segment -> row (strip, segment) of the partial-sum buffer
     if (a.part != nullptr) {
@@ -486,6 +607,7 @@ static int launch_mbxr(const MbxrArgs& a0, int batch, int want_segs, hipStream_t
     if (a.part != nullptr && a.strips * segs > a.rows_cap) segs = a.rows_cap / a.strips;   // one row of the partial-sum buffer per (strip, segment)
     YR_REQUIRE(segs >= 1, "mbxr: %d strips exceed the %d rows of the partial-sum buffer", a.strips, a.rows_cap);
     a.seg_rows = (a.Ho + segs - 1) / segs;
+    if (S == 2 && !BC5) a.seg_rows += a.seg_rows & 1;   // (output rows are processed in pairs)
     a.segs = (a.Ho + a.seg_rows - 1) / a.seg_rows;
     a.nwaves = batch * a.strips * a.segs * a.groups;
     static char nm[64];
