@@ -332,6 +332,180 @@ __device__ __forceinline__ xr_f4 xr_bc5_finish(const float (&S)[5][4], const xr_
     return (xr_f4){o0, o1, o2, o3};
 }
 
+// ... and the broadcast-tap form for PAIRED output rows (stride 2, even input columns E in lanes 0..7, odd ones O in 8..15).  The
+// column sums live at their INPUT lane: S_dx with dx even is only ever needed at E lanes, with dx odd only at O lanes, so S_0 | S_1
+// share a register (lanes 0..7 | 8..15, bank masks), S_2 | S_3 the next, S_4 a third: three registers per channel and output row of
+// the pair.  An input row feeds the even output row's sums with its taps ky and the odd row's sums with ky - 2 (same code, other array).
+template <int KY> __device__ __forceinline__ void xr_bc5_half_row(float (&S)[3][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1);
+template <> __device__ __forceinline__ void xr_bc5_half_row<0>(float (&S)[3][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
+    asm("v_fmac_f32_dpp %0, %16, %12 row_newbcast:0 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %1, %17, %13 row_newbcast:0 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %2, %18, %14 row_newbcast:0 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %3, %19, %15 row_newbcast:0 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %0, %16, %12 row_newbcast:1 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %1, %17, %13 row_newbcast:1 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %2, %18, %14 row_newbcast:1 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %3, %19, %15 row_newbcast:1 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %4, %16, %12 row_newbcast:2 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %5, %17, %13 row_newbcast:2 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %6, %18, %14 row_newbcast:2 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %7, %19, %15 row_newbcast:2 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %4, %16, %12 row_newbcast:3 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %5, %17, %13 row_newbcast:3 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %6, %18, %14 row_newbcast:3 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %7, %19, %15 row_newbcast:3 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %8, %16, %12 row_newbcast:4 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %9, %17, %13 row_newbcast:4 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %10, %18, %14 row_newbcast:4 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %11, %19, %15 row_newbcast:4 row_mask:0xf bank_mask:0x3\n\t"
+        : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[2][0]), "+v"(S[2][1]), "+v"(S[2][2]), "+v"(S[2][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+}
+template <> __device__ __forceinline__ void xr_bc5_half_row<1>(float (&S)[3][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
+    asm("v_fmac_f32_dpp %0, %16, %12 row_newbcast:5 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %1, %17, %13 row_newbcast:5 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %2, %18, %14 row_newbcast:5 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %3, %19, %15 row_newbcast:5 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %0, %16, %12 row_newbcast:6 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %1, %17, %13 row_newbcast:6 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %2, %18, %14 row_newbcast:6 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %3, %19, %15 row_newbcast:6 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %4, %16, %12 row_newbcast:7 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %5, %17, %13 row_newbcast:7 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %6, %18, %14 row_newbcast:7 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %7, %19, %15 row_newbcast:7 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %4, %16, %12 row_newbcast:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %5, %17, %13 row_newbcast:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %6, %18, %14 row_newbcast:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %7, %19, %15 row_newbcast:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %8, %16, %12 row_newbcast:9 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %9, %17, %13 row_newbcast:9 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %10, %18, %14 row_newbcast:9 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %11, %19, %15 row_newbcast:9 row_mask:0xf bank_mask:0x3\n\t"
+        : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[2][0]), "+v"(S[2][1]), "+v"(S[2][2]), "+v"(S[2][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+}
+template <> __device__ __forceinline__ void xr_bc5_half_row<2>(float (&S)[3][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
+    asm("v_fmac_f32_dpp %0, %16, %12 row_newbcast:10 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %1, %17, %13 row_newbcast:10 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %2, %18, %14 row_newbcast:10 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %3, %19, %15 row_newbcast:10 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %0, %16, %12 row_newbcast:11 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %1, %17, %13 row_newbcast:11 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %2, %18, %14 row_newbcast:11 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %3, %19, %15 row_newbcast:11 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %4, %16, %12 row_newbcast:12 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %5, %17, %13 row_newbcast:12 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %6, %18, %14 row_newbcast:12 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %7, %19, %15 row_newbcast:12 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %4, %16, %12 row_newbcast:13 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %5, %17, %13 row_newbcast:13 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %6, %18, %14 row_newbcast:13 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %7, %19, %15 row_newbcast:13 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %8, %16, %12 row_newbcast:14 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %9, %17, %13 row_newbcast:14 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %10, %18, %14 row_newbcast:14 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %11, %19, %15 row_newbcast:14 row_mask:0xf bank_mask:0x3\n\t"
+        : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[2][0]), "+v"(S[2][1]), "+v"(S[2][2]), "+v"(S[2][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+}
+template <> __device__ __forceinline__ void xr_bc5_half_row<3>(float (&S)[3][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
+    asm("v_fmac_f32_dpp %0, %16, %12 row_newbcast:15 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %1, %17, %13 row_newbcast:15 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %2, %18, %14 row_newbcast:15 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %3, %19, %15 row_newbcast:15 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %0, %20, %12 row_newbcast:0 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %1, %21, %13 row_newbcast:0 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %2, %22, %14 row_newbcast:0 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %3, %23, %15 row_newbcast:0 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %4, %20, %12 row_newbcast:1 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %5, %21, %13 row_newbcast:1 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %6, %22, %14 row_newbcast:1 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %7, %23, %15 row_newbcast:1 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %4, %20, %12 row_newbcast:2 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %5, %21, %13 row_newbcast:2 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %6, %22, %14 row_newbcast:2 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %7, %23, %15 row_newbcast:2 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %8, %20, %12 row_newbcast:3 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %9, %21, %13 row_newbcast:3 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %10, %22, %14 row_newbcast:3 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %11, %23, %15 row_newbcast:3 row_mask:0xf bank_mask:0x3\n\t"
+        : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[2][0]), "+v"(S[2][1]), "+v"(S[2][2]), "+v"(S[2][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+}
+template <> __device__ __forceinline__ void xr_bc5_half_row<4>(float (&S)[3][4], const xr_f4 e, const xr_f4 t0, const xr_f4 t1) {
+    asm("v_fmac_f32_dpp %0, %20, %12 row_newbcast:4 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %1, %21, %13 row_newbcast:4 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %2, %22, %14 row_newbcast:4 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %3, %23, %15 row_newbcast:4 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %0, %20, %12 row_newbcast:5 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %1, %21, %13 row_newbcast:5 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %2, %22, %14 row_newbcast:5 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %3, %23, %15 row_newbcast:5 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %4, %20, %12 row_newbcast:6 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %5, %21, %13 row_newbcast:6 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %6, %22, %14 row_newbcast:6 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %7, %23, %15 row_newbcast:6 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %4, %20, %12 row_newbcast:7 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %5, %21, %13 row_newbcast:7 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %6, %22, %14 row_newbcast:7 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %7, %23, %15 row_newbcast:7 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %8, %20, %12 row_newbcast:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %9, %21, %13 row_newbcast:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %10, %22, %14 row_newbcast:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f32_dpp %11, %23, %15 row_newbcast:8 row_mask:0xf bank_mask:0x3\n\t"
+        : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[2][0]), "+v"(S[2][1]), "+v"(S[2][2]), "+v"(S[2][3])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]));
+}
+// the pair's depthwise results: the even row's in lanes 0..7, the odd row's in lanes 8..15
+__device__ __forceinline__ xr_f4 xr_bc5_pair_finish(const float (&SA)[3][4], const float (&SB)[3][4], const xr_f4 shift) {
+    float o0 = shift[0], o1 = shift[1], o2 = shift[2], o3 = shift[3];
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %4, %0 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %5, %1 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %6, %2 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %7, %3 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shl:8 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %5, %1 row_shl:8 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %6, %2 row_shl:8 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %7, %3 row_shl:8 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %8, %0 row_shl:1 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %9, %1 row_shl:1 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %10, %2 row_shl:1 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %11, %3 row_shl:1 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %8, %0 row_shl:9 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %9, %1 row_shl:9 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %10, %2 row_shl:9 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %11, %3 row_shl:9 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %12, %0 row_shl:2 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %13, %1 row_shl:2 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %14, %2 row_shl:2 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %15, %3 row_shl:2 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %16, %0 row_shr:8 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %17, %1 row_shr:8 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %18, %2 row_shr:8 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %19, %3 row_shr:8 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %16, %0 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %17, %1 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %18, %2 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %19, %3 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %20, %0 row_shr:7 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %21, %1 row_shr:7 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %22, %2 row_shr:7 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %23, %3 row_shr:7 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %20, %0 row_shl:1 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %21, %1 row_shl:1 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %22, %2 row_shl:1 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %23, %3 row_shl:1 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %24, %0 row_shr:6 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %25, %1 row_shr:6 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %26, %2 row_shr:6 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %27, %3 row_shr:6 row_mask:0xf bank_mask:0xc bound_ctrl:1\n\t"
+        : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
+        : "v"(SA[0][0]), "v"(SA[0][1]), "v"(SA[0][2]), "v"(SA[0][3]), "v"(SA[1][0]), "v"(SA[1][1]), "v"(SA[1][2]), "v"(SA[1][3]), "v"(SA[2][0]), "v"(SA[2][1]), "v"(SA[2][2]), "v"(SA[2][3]), "v"(SB[0][0]), "v"(SB[0][1]), "v"(SB[0][2]), "v"(SB[0][3]), "v"(SB[1][0]), "v"(SB[1][1]), "v"(SB[1][2]), "v"(SB[1][3]), "v"(SB[2][0]), "v"(SB[2][1]), "v"(SB[2][2]), "v"(SB[2][3]));
+    return (xr_f4){o0, o1, o2, o3};
+}
+
 // K: depthwise kernel, S: stride, ACT: 0 relu6 / 1 swish (both activations), NC: 32-channel chunks of the block input, NT: tiles per wave
 template <class T, int K, int S, int ACT, int NC, int NT, int MW>
 __global__ __launch_bounds__(256, MW) void mbxr_kernel(MbxrArgs a) {
@@ -1048,17 +1222,20 @@ __global__ __launch_bounds__(64 * NW, MW) void mbhq_kernel(MbhrArgs a) {
     const int strip = bid % a.strips;
     const int b = bid / a.strips;
     const int yo0 = seg * a.seg_rows, yo1 = min(yo0 + a.seg_rows, a.Ho);
-    const int xin = S * NOUT * strip - a.pad_l + px;
+    constexpr bool PAIR = S == 2;   // stride 2: pairs of output rows, even input columns in lanes 0..7, odd ones in 8..15 (xr_row_pair)
+    const int podd = PAIR ? px >> 3 : 0;
+    const int xin = S * NOUT * strip - a.pad_l + (PAIR ? 2 * (px & 7) + podd : px);
     const int xc = min(max(xin, 0), a.W - 1);
     constexpr float HI = ACT == 0 ? 6.f : 1.f;
     const float hi = (xin >= 0 && xin < a.W) ? HI : 0.f;
-    const int jo = (px - PAD) / S, xo = NOUT * strip + jo;
-    const bool out_lane = px >= PAD && (px - PAD) % S == 0 && jo < NOUT && xo < a.Wo;
+    const int jo = PAIR ? (px & 7) : (px - PAD) / S, xo = NOUT * strip + jo;
+    const bool out_lane = (PAIR ? true : (px >= PAD && (px - PAD) % S == 0)) && jo < NOUT && xo < a.Wo;
 
     // ---- stationary: the wave's NT expanded tiles (a tile beyond T: all-zero parameters -> its depthwise result is act(0) = 0)
     xr_u4 aw[NT][NC];
     xr_u2 wpf[NT][TO];
-    xr_f4 es[NT], eh[NT], dh[NT], tp[NT][K == 3 ? KK : 2];   // 3x3: a register per tap; 5x5: lane p of a row holds tap p / tap 16 + p
+    constexpr bool BC5 = K == 5;   // 5x5: lane p of a row holds tap p / tap 16 + p (xr_bc5_row, xr_bc5_pair_row); 3x3: a register per tap
+    xr_f4 es[NT], eh[NT], dh[NT], tp[NT][BC5 ? 2 : KK];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int t = NT * w + j;
@@ -1072,7 +1249,7 @@ __global__ __launch_bounds__(64 * NW, MW) void mbhq_kernel(MbhrArgs a) {
         es[j] = live ? *reinterpret_cast<const xr_f4*>(a.prm + (size_t)(KK + 2) * a.CexpP + ch) : z;
         eh[j] = live ? *reinterpret_cast<const xr_f4*>(a.prm + (size_t)(KK + 3) * a.CexpP + ch) : z;
         const xr_f4 dsc = *reinterpret_cast<const xr_f4*>(a.prm + (size_t)KK * a.CexpP + ch);
-        if constexpr (K == 3) {
+        if constexpr (!BC5) {
 #pragma unroll
             for (int q = 0; q < KK; ++q) tp[j][q] = live ? *reinterpret_cast<const xr_f4*>(a.prm + (size_t)q * a.CexpP + ch) * dsc : z;
         } else {
@@ -1202,6 +1379,114 @@ __global__ __launch_bounds__(64 * NW, MW) void mbhq_kernel(MbhrArgs a) {
     };
     constexpr std::true_type Y{};
     constexpr std::false_type N{};
+    if constexpr (PAIR) {
+        // (see mbxr_kernel: a pair of output rows reads input rows rho = 0 .. K + 1; the first K - 2 are carried over, four are new)
+        xr_f4 d2[NT], cr[NT][K - 2];
+        float csa[NT][3][4], csb[NT][3][4];   // (5x5: the column sums of the pair's even / odd row)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < K - 2; ++q) cr[j][q] = (xr_f4){0.f, 0.f, 0.f, 0.f};
+        auto prow = [&](auto ph_c, const int k, const int yo, const XRow& xc_, XRow& xn_) {
+            constexpr int PH = decltype(ph_c)::value;
+            const int r = rbeg + k;
+            load_row(xn_, r + 1);
+            const float hr = (r >= 0 && r < a.H) ? hi : 0.f;
+            xr_f4 ec[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                xr_f4 d = (xr_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < NC; ++c) d = xr_mfma<T>(aw[j][c], xc_.m[c], d);
+                ec[j] = xr_bn_act4<ACT>(d, es[j], eh[j], hr);
+            }
+            if constexpr (PH >= 1) {
+                constexpr int RHO = K - 3 + PH;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if constexpr (K == 3) {
+                        if constexpr (PH == 1) {
+                            d2[j] = dh[j];
+                            xr_row_pair<K, false>(d2[j], cr[j][0], &tp[j][0]);
+                        }
+                        if constexpr (RHO < K) xr_row_pair<K, false>(d2[j], ec[j], &tp[j][K * (RHO < K ? RHO : 0)]);
+                        if constexpr (RHO >= 2) xr_row_pair<K, true>(d2[j], ec[j], &tp[j][K * (RHO >= 2 ? RHO - 2 : 0)]);
+                    } else {
+                        if constexpr (PH == 1) {
+#pragma unroll
+                            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) { csa[j][q][i] = 0.f; csb[j][q][i] = 0.f; }
+                            xr_bc5_half_row<0>(csa[j], cr[j][0], tp[j][0], tp[j][1]);
+                            xr_bc5_half_row<1>(csa[j], cr[j][1], tp[j][0], tp[j][1]);
+                            xr_bc5_half_row<2>(csa[j], cr[j][2], tp[j][0], tp[j][1]);
+                            xr_bc5_half_row<0>(csb[j], cr[j][2], tp[j][0], tp[j][1]);
+                        }
+                        if constexpr (RHO < K) xr_bc5_half_row<(RHO < K ? RHO : 0)>(csa[j], ec[j], tp[j][0], tp[j][1]);
+                        xr_bc5_half_row<RHO - 2>(csb[j], ec[j], tp[j][0], tp[j][1]);
+                        if constexpr (PH == 4) d2[j] = xr_bc5_pair_finish(csa[j], csb[j], dh[j]);
+                    }
+                }
+            }
+            if constexpr (PH == 4) {
+                xr_f4 P[TO];
+#pragma unroll
+                for (int t = 0; t < TO; ++t) P[t] = (xr_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const xr_f4 v = xr_act4<ACT>(d2[j], HI);
+                    const xr_u2 bop = __builtin_bit_cast(xr_u2, __builtin_convertvector(v, t4));
+#pragma unroll
+                    for (int t = 0; t < TO; ++t) P[t] = xr_mfma16<T>(wpf[j][t], bop, P[t]);
+                }
+                xr_f4* rb = red + buf * (NW * TO * 64);
+#pragma unroll
+                for (int t = 0; t < TO; ++t) rb[(w * TO + t) * 64 + lane] = P[t];
+                __syncthreads();
+                const int yl = yo + podd;   // (lanes 8..15 hold the row below)
+                const bool rlive = yl < yo1;
+                const unsigned opix = ((unsigned)yl * (unsigned)a.Wo + (unsigned)xo) * (unsigned)a.ld_out;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const int t = w + f * NW;
+                    xr_f4 acc = {0.f, 0.f, 0.f, 0.f};
+                    if (t < TO) {
+#pragma unroll
+                        for (int ww = 0; ww < NW; ++ww) acc += rb[(ww * TO + t) * 64 + lane];
+                    }
+                    xr_f4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(acc[i], fsc[f][i], fsh[f][i]);
+                    const t4 o = __builtin_convertvector(v, t4);   // (a stride-2 block has no residual)
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(xr_u2, o), osrc, (flive[f] && rlive) ? (opix + (unsigned)fco[f]) * 2u : XR_DEAD, 0, 0);
+                }
+                buf ^= 1;
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+#pragma unroll
+                for (int q = 0; q + 1 < K - 2; ++q) cr[j][q] = cr[j][q + 1];
+                cr[j][K - 3] = ec[j];
+            }
+        };
+        constexpr std::integral_constant<int, 0> P0{};
+        constexpr std::integral_constant<int, 1> P1{};
+        constexpr std::integral_constant<int, 2> P2{};
+        constexpr std::integral_constant<int, 3> P3{};
+        constexpr std::integral_constant<int, 4> P4{};
+        int k = 0;
+#pragma unroll
+        for (int q = 0; q < (K - 2) / 2; ++q) { prow(P0, k, 0, xa, xb); prow(P0, k + 1, 0, xb, xa); k += 2; }
+        prow(P0, k, 0, xa, xb); k += 1;
+        for (int i = 0; i < nout; i += 2) {
+            prow(P1, k, 0, xb, xa);
+            prow(P2, k + 1, 0, xa, xb);
+            prow(P3, k + 2, 0, xb, xa);
+            prow(P4, k + 3, yo0 + i, xa, xb);
+            k += 4;
+        }
+        return;
+    }
     // rows 0 .. K - S - 1 warm the ring up; then every output row takes S input rows, the last of which emits
     int k = 0;
 #pragma unroll
@@ -1238,6 +1523,7 @@ static int launch_mbhq(const MbhrArgs& a0, int batch, int want_segs, hipStream_t
     if (segs < 1) segs = 1;
     if (want_segs > 0) segs = want_segs < a.Ho ? want_segs : a.Ho;
     a.seg_rows = (a.Ho + segs - 1) / segs;
+    if (S == 2) a.seg_rows += a.seg_rows & 1;   // (output rows are processed in pairs)
     a.segs = (a.Ho + a.seg_rows - 1) / a.seg_rows;
     const size_t lds = (size_t)2 * NW * TO * 64 * 16;
     static char nm[64];
@@ -1256,24 +1542,28 @@ static int launch_mbhq(const MbhrArgs& a0, int batch, int want_segs, hipStream_t
 }
 
 // shapes of the tile-wise form: (kernel, input chunks, cout tiles, expanded tiles) -> (tiles per wave, waves)
-struct MbhqShape { int k, nc, to, t, nt, nw; };
+struct MbhqShape { int k, s, nc, to, t, nt, nw; };   // (s: the stride the shape is built for, 0 = both)
 static const MbhqShape MBHQ_SHAPES[] = {
-    {5, 1, 3, 9, 3, 3},     // 24 -> 144 -> 40 (EfficientNet-lite0 stage 3 entry, stride 2)
-    {5, 1, 3, 12, 3, 4},    // 32 -> 192 -> 48 (lite3 stage 3 entry, stride 2)
-    {5, 2, 3, 18, 3, 6},    // 48 -> 288 -> 48 (lite3 stage 3)
-    {5, 2, 3, 15, 2, 8},    // 40 -> 240 -> 40 (lite0 stage 3)
-    {3, 1, 2, 9, 3, 3},     // 24 -> 144 -> 24 / 32 (lite0 stage 2, lite3 stage 2 entry, MobileNetV2 x0.75 block_2, 3)
+    {5, 0, 1, 3, 9, 3, 3},     // 24 -> 144 -> 40 (EfficientNet-lite0 stage 3 entry, stride 2)
+    {5, 0, 1, 3, 12, 3, 4},    // 32 -> 192 -> 48 (lite3 stage 3 entry, stride 2)
+    {5, 0, 2, 3, 18, 3, 6},    // 48 -> 288 -> 48 (lite3 stage 3)
+    {5, 0, 2, 3, 15, 2, 8},    // 40 -> 240 -> 40 (lite0 stage 3)
+    {3, 0, 1, 2, 9, 3, 3},     // 24 -> 144 -> 24 / 32 (lite0 stage 2, lite3 stage 2 entry, MobileNetV2 x0.75 block_2, 3)
+    // stride-2 blocks the tile-pair form (mbhr_kernel) is also built for: here they walk pairs of output rows
+    {3, 2, 1, 2, 6, 2, 3},     // 16 -> 96 -> 24 (MobileNetV2 block_1, lite0 stage 2 entry)
+    {3, 2, 2, 5, 15, 2, 8},    // 40 -> 240 -> 80 (lite0 stage 4 entry)
 };
-static const MbhqShape* mbhq_shape(int k, int cin, int cexp, int cout) {
+static const MbhqShape* mbhq_shape(int k, int stride, int cin, int cexp, int cout) {
+    static const bool s2 = !(getenv("YOLORET_MBHQ_S2") && atoi(getenv("YOLORET_MBHQ_S2")) == 0);
     const int nc = yr_round_up(cin, 32) / 32, to = (cout + 15) / 16, t = cexp / 16;
     for (const MbhqShape& sh : MBHQ_SHAPES)
-        if (sh.k == k && sh.nc == nc && sh.to == to && sh.t == t) return &sh;
+        if (sh.k == k && (sh.s == 0 || (sh.s == stride && s2)) && sh.nc == nc && sh.to == to && sh.t == t) return &sh;
     return nullptr;
 }
 
 template <class T, int S>
 static int launch_mbhq_shape(const MbhrArgs& a, int k, int batch, int segs, hipStream_t s) {
-    const MbhqShape* sh = mbhq_shape(k, a.Cin, a.T * 16, a.Cout);
+    const MbhqShape* sh = mbhq_shape(k, S, a.Cin, a.T * 16, a.Cout);
     YR_REQUIRE(sh != nullptr, "mbhq: block %d -> %d -> %d (%d x %d) is not built", a.Cin, a.T * 16, a.Cout, k, k);
 #define HQ_CASE(KV, NCV, TOV, TV, NTV, NWV) if (sh->k == KV && sh->nc == NCV && sh->to == TOV && sh->t == TV) return launch_mbhq<T, KV, S, 0, NCV, TOV, NTV, NWV>(a, batch, segs, s);
     HQ_CASE(5, 1, 3, 9, 3, 3)
@@ -1281,6 +1571,10 @@ static int launch_mbhq_shape(const MbhrArgs& a, int k, int batch, int segs, hipS
     HQ_CASE(5, 2, 3, 18, 3, 6)
     HQ_CASE(5, 2, 3, 15, 2, 8)
     HQ_CASE(3, 1, 2, 9, 3, 3)
+    if constexpr (S == 2) {
+        HQ_CASE(3, 1, 2, 6, 2, 3)
+        HQ_CASE(3, 2, 5, 15, 2, 8)
+    }
 #undef HQ_CASE
     return YR_ERR_ARG;
 }
@@ -1320,7 +1614,7 @@ static bool mbhq_built(const yr_op& op) {
     const int K = op.k & 0xff;
     return on && op.kind == YR_OP_MBH && (op.dtype == YR_BF16 || op.dtype == YR_F16) && (K == 3 || K == 5) && (op.stride == 1 || op.stride == 2) &&
            op.act == YR_ACT_RELU6 && op.cin % 8 == 0 && op.cin <= 64 && op.se_reduced % 16 == 0 && op.cout % 4 == 0 && op.nsrc == 1 &&
-           op.out_ld % 4 == 0 && mbhq_shape(K, op.cin, op.se_reduced, op.cout) != nullptr;
+           op.out_ld % 4 == 0 && mbhq_shape(K, op.stride, op.cin, op.se_reduced, op.cout) != nullptr;
 }
 bool yr_mbhr_built(const yr_op& op) { return mbhr_pair_built(op) || mbhq_built(op); }
 
@@ -1335,7 +1629,7 @@ static int launch_mbhr_t(const yr_op& op, int batch, int segs, hipStream_t s) {
     const int pth = (a.Ho - 1) * op.stride + K - in.h, ptw = (a.Wo - 1) * op.stride + K - in.w;
     a.pad_t = (pth > 0 ? pth : 0) / 2; a.pad_l = (ptw > 0 ? ptw : 0) / 2;
     a.strips = a.segs = a.seg_rows = 0;
-    if (!mbhr_pair_built(op)) return op.stride == 1 ? launch_mbhq_shape<T, 1>(a, K, batch, segs, s) : launch_mbhq_shape<T, 2>(a, K, batch, segs, s);
+    if (mbhq_built(op)) return op.stride == 1 ? launch_mbhq_shape<T, 1>(a, K, batch, segs, s) : launch_mbhq_shape<T, 2>(a, K, batch, segs, s);
     if (op.act == YR_ACT_RELU6) return op.stride == 1 ? launch_mbhr_shape<T, 1, 0>(a, batch, segs, s) : launch_mbhr_shape<T, 2, 0>(a, batch, segs, s);
     return op.stride == 1 ? launch_mbhr_shape<T, 1, 1>(a, batch, segs, s) : launch_mbhr_shape<T, 2, 1>(a, batch, segs, s);
 }
