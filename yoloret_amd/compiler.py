@@ -286,17 +286,16 @@ MBR_SHAPES = {
     (24, 144, 32, 2, False): (3, 0),     # MobileNetV2 x1.4 block_1
     (32, 192, 48, 2, False): (4, 0),     # x1.4 block_3
     (24, 144, 24, 1, True): (3, 0),      # block_4, 5 at 52 x 52 (66 -> 60 us); block_2 at 104 x 104: lane kernel 209 us -> 186 (behind block_1 on mbr; 240 behind the lane kernel)
+    (32, 192, 32, 1, True): (4, 0),      # MobileNetV2 x1.4 block_2 (c4 +2.4 % in flight behind block_1 on mbr)
     (48, 288, 48, 1, True): (8, 0),      # block_7..9
     (48, 288, 72, 1, False): (8, 0),     # block_10
 }
-if os.environ.get('YOLORET_MBR_ALL', '0') != '0':   # (experiments: every shape mbr.hip is built for)
-    MBR_SHAPES.update({(32, 192, 32, 1, True): (4, 0)})
 # float32 plans, blocks too wide for mbr.hip's one-workgroup form: expand + depthwise in one register-chained kernel (YR_OP_MBE),
 # the projection stays a pointwise op.  Block input widths built in mbr.hip (MBE_CASE).
 FUSE_MBE = os.environ.get('YOLORET_FUSE_MBE', '1') != '0'
 # (measured, MobileNetV2 x0.75 @416 batch 64: block_11 / 12 85 -> 60 us, block_13 67 -> 56 us; the 13 x 13 blocks (120 inputs) tie
 # at 53 us untuned, 43 us with the tuned row segments; MobileNetV2 x1.4 @512: 88- and 136-wide blocks c4 +4 %, the 224-wide ones -4 %)
-MBE_CINS = set(int(v) for v in os.environ.get('YOLORET_MBE_CINS', '72,88,120,136').split(',') if v)
+MBE_CINS = set(int(v) for v in os.environ.get('YOLORET_MBE_CINS', '48,72,88,120,136').split(',') if v)   # (48: MobileNetV2 x1.4 block_6, 48 -> 288 -> 88 stride 2: c4 +1.7 %)
 FUSE_MBH = os.environ.get('YOLORET_FUSE_MBH', '1') != '0'   # 16-bit plans: inverted-residual blocks on the MFMA block kernel (mbh.hip)
 MBH_LANE_MIN_PIXELS = int(os.environ.get('YOLORET_MBH_LANE_MIN_PIXELS', '10000'))
 MBH_LANE_MAX_CIN = int(os.environ.get('YOLORET_MBH_LANE_MAX_CIN', '16'))
