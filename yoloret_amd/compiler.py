@@ -269,7 +269,8 @@ STEMBLOCK_WIDTHS ={(12, 16), (16, 16), (16, 24), (20, 24), (24, 16), (24, 24)}  
 STEM_MFMA = os.environ.get('YOLORET_STEM_MFMA', '1') != '0'   # 16-bit plans: the network entry on the matrix pipe (stemblock_h.hip)
 # ... for stems of at most 32 channels (MobileNetV2 x0.75 / x1.0, EfficientNet-lite0..2: 0.31 -> 0.22 ms per 128 images at 416).  The
 # depthwise stage works on 32-channel k steps: lite3's 40 channels pay for 64 and lose to the float32-pipe kernel (0.27 vs 0.24 ms)
-STEM_MFMA_MAX_C1 = int(os.environ.get('YOLORET_STEM_MFMA_MAX_C1', '32'))
+# (round 4: stems of 33..48 channels run on the register-chained form with projection, stemxp_kernel in mbxr_h.hip, same parameter layout)
+STEM_MFMA_MAX_C1 = int(os.environ.get('YOLORET_STEM_MFMA_MAX_C1', '48'))
 
 
 # float32 plans: inverted-residual blocks on the row-walking register-chained matrix-pipe kernel (mbr.hip).  (cin, cexp, cout,

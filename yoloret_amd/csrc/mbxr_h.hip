@@ -49,6 +49,17 @@ __device__ __forceinline__ xr_f4 xr_mfma(xr_u4 w, xr_u4 x, xr_f4 acc) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(xr_v8<_Float16>, w), __builtin_bit_cast(xr_v8<_Float16>, x), acc, 0, 0, 0);
 }
 
+// ... and the 16-deep step (v_mfma_f32_16x16x16_{bf16,f16}): B = the lane's 4 values of k = 4 g .. 4 g + 3
+template <class T>
+__device__ __forceinline__ xr_f4 xr_mfma16(xr_u2 w, xr_u2 x, xr_f4 acc) {
+    typedef short xr_s4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 xr_h4 __attribute__((ext_vector_type(4)));
+    if constexpr (yr_elem<T>::dtype == YR_BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(xr_s4, w), __builtin_bit_cast(xr_s4, x), acc, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(xr_h4, w), __builtin_bit_cast(xr_h4, x), acc, 0, 0, 0);
+}
+
 // one tap ROW of the depthwise conv for the lane's 4 channels (see mbr.hip: the DPP shift rides on v_fmac's first operand,
 // the four channels' chains interleaved tap-major; s_nop 1 covers the VALU-write -> DPP-read hazard the compiler cannot see)
 #define XR_DPP(ctl) " " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -1005,6 +1016,177 @@ int yr_launch_stemxr(const yr_op& op, int batch, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// The network entry of the 16-bit plans WITH the projection (stem 3x3 s2 + BN + act -> depthwise 3x3 + BN + act -> project 1x1 +
+// BN; MobileNetV2 Conv1 + expanded_conv [3P], EfficientNet-lite stem + stage 1) in the register-chained form: stemxr_kernel's walk,
+// and the depthwise results of the wave's NT tiles, rounded, are the B operands of v_mfma_f32_16x16x16 projection steps whose
+// accumulators never leave the wave (one wave owns all channels of its 14 x 14 tile: no LDS, no barrier).  Parameters in the
+// layout of stemblock_h.hip (the compiler's matrix-pipe layout, see launch_stemblock_h_t); float32 image.
+struct StemxpArgs {
+    const float* img; void* out; const void* ws; const float* ssc; const float* ssh; const float* wd; const void* wp; const float* bp;
+    int Hi, Wi, Ho, Wo, C1, C1P, Cout, COP, ld_out, tiles_x, tiles_y, nwaves;
+};
+
+template <class T, int NT, int TO, int ACT>
+__global__ __launch_bounds__(256, 2) void stemxp_kernel(StemxpArgs a) {
+    const int lane = threadIdx.x & 63, px = lane & 15, mg = lane >> 4;
+    int gw = (int)yr_xcd_swizzle(blockIdx.x, gridDim.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (gw >= a.nwaves) return;
+    const int tx = gw % a.tiles_x; gw /= a.tiles_x;
+    const int ty = gw % a.tiles_y;
+    const int b = gw / a.tiles_y;
+    const int yo0 = 14 * ty, yo1 = min(yo0 + 14, a.Ho);
+    const int xs = 14 * tx - 1 + px;                       // this lane's stem-output column (= depthwise input column)
+    const int xsc = min(max(xs, 0), a.Wo - 1);
+    constexpr float HI = ACT == 0 ? 6.f : 1.f;
+    const float hi = (xs >= 0 && xs < a.Wo) ? HI : 0.f;
+    const int xo = 14 * tx + px - 1;
+    const bool out_lane = px >= 1 && px <= 14 && xo < a.Wo;
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    typedef T t2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+
+    // ---- stationary: stem A fragments, stem BN rows, depthwise taps (times the BN scale) and shift, projection A fragments
+    xr_u4 aw[NT];
+    xr_u2 wpf[NT][TO];
+    xr_f4 es[NT], eh[NT], dh[NT], tp[NT][9];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        aw[j] = *reinterpret_cast<const xr_u4*>(reinterpret_cast<const char*>(a.ws) + ((size_t)(16 * j + px) * 32 + 8 * mg) * 2);
+        const int ch = 16 * j + 4 * mg;                    // this lane's 4 channels of tile j in the MFMA result (< C1P: zero padded)
+        es[j] = *reinterpret_cast<const xr_f4*>(a.ssc + ch);
+        eh[j] = *reinterpret_cast<const xr_f4*>(a.ssh + ch);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) tp[j][q] = *reinterpret_cast<const xr_f4*>(a.wd + (size_t)q * a.C1P + ch);
+        dh[j] = *reinterpret_cast<const xr_f4*>(a.wd + (size_t)9 * a.C1P + ch);
+#pragma unroll
+        for (int t = 0; t < TO; ++t)
+            wpf[j][t] = *reinterpret_cast<const xr_u2*>(reinterpret_cast<const char*>(a.wp) + ((size_t)(16 * t + px) * a.C1P + ch) * 2);
+    }
+    xr_f4 psc[TO], psh[TO];
+    unsigned ooff[TO];
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
+        const int co = 16 * t + 4 * mg;
+        psc[t] = *reinterpret_cast<const xr_f4*>(a.bp + co);
+        psh[t] = *reinterpret_cast<const xr_f4*>(a.bp + a.COP + co);
+        ooff[t] = (out_lane && co < a.Cout) ? (unsigned)co * 2u : XR_DEAD;
+    }
+    const xr_rsrc isrc = xr_make_rsrc(a.img + (size_t)b * a.Hi * a.Wi * 3, (unsigned)(a.Hi * a.Wi * 3) * 4u);
+    const xr_rsrc osrc = xr_make_rsrc(reinterpret_cast<T*>(a.out) + (size_t)b * a.Ho * a.Wo * a.ld_out, (unsigned)(a.Ho * a.Wo * a.ld_out) * 2u);
+    const unsigned irow = (unsigned)a.Wi * 12u;            // bytes per image row
+    const unsigned icol = (unsigned)(2 * xsc) * 12u;       // the window's first byte within a row (even sizes: no left padding)
+    const bool last_col = 2 * xsc + 2 >= a.Wi;             // kx = 2 lies beyond the row: values 6, 7 (k groups 0..2) and group 3 are padding
+    auto load_b = [&](int ys) -> xr_u4 {                   // (as stemxr_kernel: 8 image values of the lane's k group, rounded)
+        const int ysc = min(max(ys, 0), a.Ho - 1);
+        float v[8];
+        if (mg < 3) {
+            const int iy = 2 * ysc + mg;
+            const unsigned off = iy < a.Hi ? (unsigned)iy * irow + icol : XR_DEAD;
+            const xr_f4 lo = __builtin_bit_cast(xr_f4, __builtin_amdgcn_raw_buffer_load_b128(isrc, off, 0, 0));
+            const xr_f4 hi4 = __builtin_bit_cast(xr_f4, __builtin_amdgcn_raw_buffer_load_b128(isrc, off == XR_DEAD ? XR_DEAD : off + 16u, 0, 0));
+            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi4[0]; v[5] = hi4[1];
+            v[6] = last_col ? 0.f : hi4[2]; v[7] = last_col ? 0.f : hi4[3];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int iy = 2 * ysc + i;
+                const unsigned off = (iy < a.Hi && !last_col) ? (unsigned)iy * irow + icol + 32u : XR_DEAD;
+                v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(isrc, off, 0, 0));
+            }
+            v[3] = v[4] = v[5] = v[6] = v[7] = 0.f;
+        }
+        unsigned u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){v[2 * i], v[2 * i + 1]}, t2));
+        return (xr_u4){u[0], u[1], u[2], u[3]};
+    };
+    const int rbeg = yo0 - 1, nout = yo1 - yo0;
+    xr_f4 ring[NT][2];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { ring[j][0] = (xr_f4){0.f, 0.f, 0.f, 0.f}; ring[j][1] = ring[j][0]; }
+    xr_u4 bcur = load_b(rbeg);
+    for (int k = 0; k < nout + 2; ++k) {
+        const int ys = rbeg + k;
+        const xr_u4 bnext = load_b(ys + 1);
+        const float hr = (ys >= 0 && ys < a.Ho) ? hi : 0.f;
+        xr_f4 ec[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) ec[j] = xr_bn_act4<ACT>(xr_mfma<T>(aw[j], bcur, (xr_f4){0.f, 0.f, 0.f, 0.f}), es[j], eh[j], hr);
+        if (k >= 2) {
+            const int yo = yo0 + k - 2;
+            xr_f4 P[TO];
+#pragma unroll
+            for (int t = 0; t < TO; ++t) P[t] = (xr_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                xr_f4 d = dh[j];
+                xr_row3(d, ring[j][0], tp[j][0], tp[j][1], tp[j][2]);
+                xr_row3(d, ring[j][1], tp[j][3], tp[j][4], tp[j][5]);
+                xr_row3(d, ec[j], tp[j][6], tp[j][7], tp[j][8]);
+                const xr_u2 bop = __builtin_bit_cast(xr_u2, __builtin_convertvector(xr_act4<ACT>(d, HI), t4));   // rounded: the projection's operand type
+#pragma unroll
+                for (int t = 0; t < TO; ++t) P[t] = xr_mfma16<T>(wpf[j][t], bop, P[t]);
+            }
+            const unsigned opix = ((unsigned)yo * (unsigned)a.Wo + (unsigned)xo) * (unsigned)a.ld_out * 2u;
+#pragma unroll
+            for (int t = 0; t < TO; ++t) {
+                xr_f4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(P[t][i], psc[t][i], psh[t][i]);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(xr_u2, __builtin_convertvector(v, t4)), osrc, ooff[t] == XR_DEAD ? XR_DEAD : opix + ooff[t], 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { ring[j][0] = ring[j][1]; ring[j][1] = ec[j]; }
+        bcur = bnext;
+    }
+}
+
+// whether this matrix-pipe-layout STEMBLOCK op (stem + depthwise + projection) runs on stemxp_kernel: float32 image of even sizes,
+// at most 48 stem channels and 32 outputs.  By SHAPE (stems of more than 32 channels; YOLORET_STEMXP=1: every stem it is built
+// for, =0: none) - never by the tuner.
+bool yr_stemxp_takes(const yr_op& op) {
+    static const int mode = getenv("YOLORET_STEMXP") ? atoi(getenv("YOLORET_STEMXP")) : -1;
+    if (mode == 0) return false;
+    return op.kind == YR_OP_STEMBLOCK && op.scale != nullptr && op.b1 != nullptr && (op.dtype == YR_BF16 || op.dtype == YR_F16) && op.out_dtype == op.dtype &&
+           op.nsrc == 1 && op.src[0].dtype == YR_F32 && op.src[0].c == 3 && op.src[0].ld == 3 && op.src[0].h % 2 == 0 && op.src[0].w % 2 == 0 &&
+           op.se_reduced <= 48 && (mode == 1 || op.se_reduced > 32) && op.cout <= 32 && op.out_ld % 4 == 0 && (op.act == YR_ACT_RELU6 || op.act == YR_ACT_SWISH);
+}
+
+template <class T>
+static int launch_stemxp_t(const yr_op& op, int batch, hipStream_t s) {
+    const yr_src& in = op.src[0];
+    StemxpArgs a;
+    a.img = (const float*)in.ptr; a.out = op.out; a.ws = op.wgt; a.ssc = op.scale; a.ssh = op.shift; a.wd = op.wgt2; a.wp = op.b1; a.bp = op.b2;
+    a.Hi = in.h; a.Wi = in.w; a.Ho = in.h / 2; a.Wo = in.w / 2; a.C1 = op.se_reduced; a.C1P = yr_round_up(op.se_reduced, 32);
+    a.Cout = op.cout; a.COP = yr_round_up(op.cout, 16); a.ld_out = op.out_ld;
+    a.tiles_x = (a.Wo + 13) / 14; a.tiles_y = (a.Ho + 13) / 14;
+    a.nwaves = batch * a.tiles_x * a.tiles_y;
+    const int nt = (a.C1 + 15) / 16, to = a.COP / 16, act = op.act == YR_ACT_RELU6 ? 0 : 1;
+    static char nm[48];
+    snprintf(nm, sizeof(nm), "stemxp_kernel<%s,%d,%d,%d>", yr_dtype_name(yr_elem<T>::dtype), nt, to, act);
+    yr_note_kernel(nm);
+    const dim3 grid((unsigned)((a.nwaves + 3) / 4));
+#define SP_GO(NTV, TOV)                                                                                   \
+    do {                                                                                                 \
+        if (act == 0) hipLaunchKernelGGL((stemxp_kernel<T, NTV, TOV, 0>), grid, dim3(256), 0, s, a);    \
+        else hipLaunchKernelGGL((stemxp_kernel<T, NTV, TOV, 1>), grid, dim3(256), 0, s, a);             \
+    } while (0)
+    if (to == 1) { if (nt == 3) SP_GO(3, 1); else if (nt == 2) SP_GO(2, 1); else SP_GO(1, 1); }
+    else { if (nt == 3) SP_GO(3, 2); else if (nt == 2) SP_GO(2, 2); else SP_GO(1, 2); }
+#undef SP_GO
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+
+int yr_launch_stemxp(const yr_op& op, int batch, hipStream_t s) {
+    YR_REQUIRE(yr_stemxp_takes(op), "stemxp: the register-chained entry with projection is not built for this op");
+    YR_REQUIRE(op.src[0].ptr && op.out && op.wgt && op.wgt2 && op.shift && op.b2 && op.h == op.src[0].h / 2 && op.w == op.src[0].w / 2 && op.out_ld >= op.cout && op.k == 3 && op.stride == 2,
+               "stemxp: bad arguments");
+    return op.dtype == YR_BF16 ? launch_stemxp_t<yr_bf16>(op, batch, s) : launch_stemxp_t<yr_f16>(op, batch, s);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // YR_OP_MBH in the same form: the WHOLE block - expand -> depthwise 3x3 -> project 1x1 + BN (+ residual) - for blocks of at
 // most 16 expanded tiles (the network fronts: MobileNetV2 block_1..6, EfficientNet-lite stage 2, lite0 stage 4 entry).  A
 // workgroup's NW waves share one strip segment; wave w owns the expanded tile PAIR (2w, 2w + 1) = one 32-deep k step of the
@@ -1200,15 +1382,6 @@ static int launch_mbhr(const MbhrArgs& a0, int batch, int want_segs, hipStream_t
 // issue slots per multiply-add of the 32-deep form - on a matrix pipe that idles under the depthwise VALU work.  5x5: the
 // 25 taps x 4 channels per tile do not fit the register file next to a four-row ring: two registers per channel hold them
 // lane-wise and DPP row broadcasts deliver them (xr_bc5_row below).
-template <class T>
-__device__ __forceinline__ xr_f4 xr_mfma16(xr_u2 w, xr_u2 x, xr_f4 acc) {
-    typedef short xr_s4 __attribute__((ext_vector_type(4)));
-    typedef _Float16 xr_h4 __attribute__((ext_vector_type(4)));
-    if constexpr (yr_elem<T>::dtype == YR_BF16)
-        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(xr_s4, w), __builtin_bit_cast(xr_s4, x), acc, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(xr_h4, w), __builtin_bit_cast(xr_h4, x), acc, 0, 0, 0);
-}
 
 template <class T, int K, int S, int ACT, int NC, int TO, int NT, int NW, int MW>
 __global__ __launch_bounds__(64 * NW, MW) void mbhq_kernel(MbhrArgs a) {

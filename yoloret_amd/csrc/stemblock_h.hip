@@ -304,6 +304,7 @@ static int launch_stemblock_h_t(const yr_op& op, int batch, hipStream_t s) {
 }
 
 int yr_launch_stemblock_h(const yr_op& op, int batch, hipStream_t s) {
+    if (yr_stemxp_takes(op)) return yr_launch_stemxp(op, batch, s);   // (stems of more than 32 channels: the register-chained form, mbxr_h.hip)
     if (op.dtype == YR_BF16) return launch_stemblock_h_t<yr_bf16>(op, batch, s);
     if (op.dtype == YR_F16) return launch_stemblock_h_t<yr_f16>(op, batch, s);
     yr_set_error("stemblock (matrix pipe): 16-bit plans only");

@@ -44,7 +44,9 @@ int yr_launch_gather(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_stemblock(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_mblane(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_mbh(const yr_op& op, int batch, hipStream_t s);
-bool yr_mbh_prefers_chained(const yr_op& op);   // mbxr_h.hip: a plain launch of this MBH / MBX op runs the register-chained form
+bool yr_mbh_prefers_chained(const yr_op& op);
+bool yr_stemxp_takes(const yr_op& op);                                  // mbxr_h.hip: the entry with projection, register-chained
+int yr_launch_stemxp(const yr_op& op, int batch, hipStream_t s);   // mbxr_h.hip: a plain launch of this MBH / MBX op runs the register-chained form
 int yr_launch_mbr(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_mbe(const yr_op& op, int batch, hipStream_t s);
 int yr_pointwise_num_cfgs(int dtype);
