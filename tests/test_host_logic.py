@@ -365,7 +365,8 @@ def test_round3_plan_choices_of_the_16bit_configurations():
     # an odd image size keeps the float32-pipe entry kernel (pair-packed layout: no separate BN rows)
     assert 'scale' not in _plan16('efficientnetb0-lite', 63).ops[0].params
     p5 = _plan16('efficientnetb3-lite', 640, 'mixed_float16')
-    assert p5.ops[0].kind == rt.OP_STEMBLOCK and 'scale' not in p5.ops[0].params          # 40 stem channels: float32 pipe
+    e5 = p5.ops[0]      # 40 stem channels: the matrix-pipe layout too (stemxp_kernel, the register-chained form with projection)
+    assert e5.kind == rt.OP_STEMBLOCK and e5.params['wgt'][0] == (64, 32) and e5.params['wgt2'][0] == (10, 64) and e5.params['b1'][0] == (32, 64)
     k5 = [o for o in p5.ops if o.kind == rt.OP_MBH and o.k == 5 and o.stride == 1]
     assert len(k5) == 2 and all(o.h == 80 and o.se_reduced == 288 for o in k5)
     first_s2 = next(o for o in p5.ops if o.kind == rt.OP_MBH and o.stride == 2)
