@@ -546,7 +546,22 @@ def dw_se_geometry(strips, c4):
 DW_LDS = os.environ.get('YOLORET_DW_LDS', '1') != '0'
 
 
+DW_WALK = os.environ.get('YOLORET_DW_WALK', '1') != '0'
+
+
 def dwl_geometry(h, w, k=5, se=True):
+    """(rows along x, rows along y) of the squeeze-excite sums the 16-bit k x k stride-1 depthwise form writes per image.
+    The walking form (depthwise_walk.hip, == dwq_geometry() / dwq_quanta() there): column blocks of at most 8 four-column
+    strips x row quanta fixed by the map's height - independent of the batch and of how a launch cuts the rows into segments."""
+    if DW_WALK and k == 5 and w <= 32:     # launch_depthwise_t's choice (depthwise.hip)
+        strips = (w + 3) // 4
+        q = min(8, max(1, h // 10))
+        rows = round_up((h + q - 1) // q, k)      # quanta of a multiple of k rows
+        return (strips + 7) // 8, (h + rows - 1) // rows
+    return dwp_geometry(h, w, k, se)
+
+
+def dwp_geometry(h, w, k=5, se=True):
     """== dwp_geometry() in depthwise_lds.hip (integer arithmetic, the same choice): (tiles along x, tiles along y) of the
     LDS-tiled k x k stride-1 depthwise form; its squeeze-excite variant (se: two tile buffers of at most 192 halo pixels,
     208 without the partial sums behind them) writes one row of channel sums per tile."""

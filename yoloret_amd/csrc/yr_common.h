@@ -37,6 +37,9 @@ int yr_launch_depthwise(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_depthwise_lds(int dtype, int k, const void* in, const float* w, const float* scale, const float* shift, void* out, int B, int H, int W,
                              int C8, int ld_in, int ld_w, int ld_out, int pad_t, int pad_l, int act, float* part, int ld_part, int part_rows,
                              hipStream_t s);
+int yr_launch_depthwise_walk(int dtype, int k, const void* in, const float* w, const float* scale, const float* shift, void* out, int B, int H, int W,
+                              int C8, int ld_in, int ld_w, int ld_out, int pad_t, int pad_l, int act, float* part, int ld_part, int part_rows,
+                              hipStream_t s);
 int yr_launch_se_mean(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_se_fc(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_wsum(const yr_op& op, int batch, hipStream_t s);
