@@ -609,6 +609,55 @@ def test_depthwise_se_form(dev, dt, k, s, h, w, c, r):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dt', DTYPES)
+def test_depthwise_walk_is_batch_independent(dev, dt):
+    """The walking 5x5 form (depthwise_walk.hip) cuts the rows of an image into segments by how many workgroups a LAUNCH has
+    (a batch of 2: one segment per row quantum; a batch of 400 on this map: whole images) - the stored map and the
+    squeeze-excite sums (one row per quantum whatever the segmentation) of an image must not depend on it.  Also an odd batch
+    (the second image slot of the last workgroup is empty) and the float64 reference on the large batch."""
+    rt = _rt()
+    from yoloret_amd.compiler import dwl_geometry, DW_LDS, DW_WALK
+    if not (DW_LDS and DW_WALK):
+        pytest.skip('the walking form is switched off')
+    did = rt.dtype_id(dt)
+    k, c = 5, 64
+    rng = np.random.default_rng(77)
+    wk = (rng.standard_normal((k, k, c)) * 0.2).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    shift = rng.normal(0, 0.3, c).astype(np.float32)
+    keep = [_dev_vec(wk.reshape(k * k, c), dev), _dev_vec(scale, dev), _dev_vec(shift, dev)]
+    for h, w, big in [(26, 26, 400), (13, 13, 7), (33, 20, 301)]:
+        ntx, nty = dwl_geometry(h, w, k)
+        x = q16(rng.standard_normal((big, h, w, c)), dt)
+        xd = to_dev16(x, dev, dt)
+
+        def run(b):
+            out = torch.full((b, h, w, c), float('nan'), dtype=rt.TORCH_DTYPE[did], device=dev)
+            part = torch.full((b, ntx * nty, c), float('nan'), dtype=torch.float32, device=dev)
+            op = rt.new_op(rt.OP_DEPTHWISE, 'swish')
+            op.dtype = op.out_dtype = did
+            op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc = h, w, c, c, k, 1, 1
+            op.src[0] = rt.make_src(xd[:b], c=c)
+            op.wgt, op.scale, op.shift = [t.data_ptr() for t in keep]
+            op.out, op.out_ld = out.data_ptr(), c
+            op.gate, op.gate_ld, op.se_reduced = part.data_ptr(), c, ntx * nty
+            rt.run_op(op, b)
+            torch.cuda.synchronize()
+            return out, part
+        out_big, part_big = run(big)
+        ref = _act(nn.depthwise(x[:16].astype(np.float64), wk.astype(np.float64), 1, 'same') * scale + shift, 'swish')
+        assert_rounded_once(from_dev16(out_big[:16], dt, c), ref, dt, 'walking depthwise %dx%d' % (h, w))
+        assert not torch.isnan(part_big).any()
+        for b in (1, 2, 3):
+            out_b, part_b = run(b)
+            assert torch.equal(out_b.view(torch.int16), out_big[:b].view(torch.int16)), (h, w, b)
+            assert torch.equal(part_b, part_big[:b]), (h, w, b)
+        sums = part_big.sum(dim=1).double().cpu().numpy()
+        stored = out_big.double().sum(dim=(1, 2)).cpu().numpy()
+        assert np.abs(sums - stored).max() <= 2e-5 * max(1.0, np.abs(stored).max())
+
+
+@pytest.mark.gpu
 def test_depthwise_lds_form_geometry_mirror(dev):
     """compiler.dwl_geometry must pick the tile the launcher picks (depthwise_lds.hip) for every map size: the SE partial-sum
     buffer is sized from it and the launcher refuses a buffer of another height.  64 channels, one image, a grid of map

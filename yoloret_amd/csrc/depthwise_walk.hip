@@ -322,15 +322,19 @@ static bool dwq_geometry(int K, bool se, DwqArgs* a, size_t* lds) {
     a->nig = (a->B + a->ni - 1) / a->ni;
     static const int force = getenv("YR_DWQ_QPS") ? atoi(getenv("YR_DWQ_QPS")) : 0;
     const long long slots = 256ll * per_cu, units = (long long)a->ncc * a->nig * a->nblk;
-    const int row_cost = K * K * 5 + 45, in_cost = 30, seg_cost = 150;
-    long long best = 0;
+    // time of a launch ~ (what a segment costs) x max(1, segments per resident slot): rows x the instructions of a row + the halo
+    // rows' reads and conversions + the fixed part (taps, descriptors, the first group's round trip: about 3.5 rows' worth).
+    // Fitted on tools/dwq_probe.py with YR_DWQ_QPS (26x26x480 @128: one segment 51 us, two 57; 40x40x816 @32: one 63, two 58).
+    const int row_cost = K * K * 5 + 45, in_cost = 30, seg_cost = 600;
+    double best = 0;
     for (int qps = 1; qps <= a->nq; ++qps) {
         if (force && qps != (force < a->nq ? force : a->nq)) continue;
         const int nseg = (a->nq + qps - 1) / qps;
         if ((nseg - 1) * qps >= a->nq) continue;
         const int n = qps * a->Q < a->H ? qps * a->Q : a->H;
-        const long long gens = (units * nseg + slots - 1) / slots;
-        const long long cost = gens * ((long long)n * row_cost + halo * in_cost + seg_cost);
+        double gens = (double)(units * nseg) / (double)slots;
+        if (gens < 1) gens = 1;
+        const double cost = gens * ((double)n * row_cost + halo * in_cost + seg_cost);
         if (best == 0 || cost <= best) {   // (ties: the longer segments)
             best = cost;
             a->qps = qps; a->nseg = nseg;
