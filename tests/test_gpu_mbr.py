@@ -39,9 +39,9 @@ def _reference(x, we, se, he, wd, sd, hd, wp, sp, hp, s, residual):
     return ref + x if residual else ref
 
 
-def make_block(case, dev, b=2, seed=None):
+def make_block(case, dev, b=2, seed=None, split=False):
     from yoloret_amd import runtime as rt
-    from yoloret_amd.compiler import mbr_pack
+    from yoloret_amd.compiler import mbr_pack, mbs_pack
     h, w, cin, cexp, cout, s, residual, nw, segs = case
     rng = np.random.default_rng(zlib.crc32(str(case).encode()) if seed is None else seed)
     x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
@@ -51,13 +51,14 @@ def make_block(case, dev, b=2, seed=None):
     sd, hd = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
     wp = (rng.standard_normal((cexp, cout)) * np.sqrt(1.0 / cexp)).astype(np.float32)
     sp, hp = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.3, cout).astype(np.float32)
-    packed = mbr_pack(we.T, se, he, wd.reshape(9, cexp), sd, hd, wp.T, sp, hp)
+    packed = (mbs_pack(we.T, se, he, wd.reshape(9, cexp), sd, hd, wp.T, sp, hp, nw) if split else
+              mbr_pack(we.T, se, he, wd.reshape(9, cexp), sd, hd, wp.T, sp, hp))
     keep = [torch.from_numpy(np.ascontiguousarray(a).ravel()).to(dev) for a in packed]
     xd = to_dev(x, dev)
     ho, wo = (h + s - 1) // s, (w + s - 1) // s
     op = rt.new_op(rt.OP_MBR, 'relu6')
     op.dtype = op.out_dtype = rt.dtype_id('f32')
-    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc, op.se_reduced = ho, wo, cin, cout, 3 | nw << 8 | segs << 16, s, 1, cexp
+    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc, op.se_reduced = ho, wo, cin, cout, 3 | int(split) << 7 | nw << 8 | segs << 16, s, 1, cexp
     op.src[0] = rt.make_src(xd, c=cin)
     op.wgt, op.wgt2, op.b2 = [k.data_ptr() for k in keep]
     if residual:
@@ -75,6 +76,32 @@ def test_mbr(dev, case):
     rt.run_op(op, 2)
     torch.cuda.synchronize()
     assert_close(from_dev(out), ref, 5e-5, 'mbr %s' % (case,))
+
+
+MBS_CASES = [
+    # the SPLIT form (k bit 7): both 1x1 convolutions on the 16-bit matrix pipe, float32 operands as two float16 planes each
+    (16, 16, 16, 96, 24, 2, False, 3, 0),
+    (31, 45, 16, 96, 24, 2, False, 3, 3),      # odd sizes, ragged strips and segments
+    (13, 13, 24, 144, 24, 1, True, 3, 0),      # block_2 (+add)
+    (52, 40, 24, 144, 24, 1, True, 3, 2),
+    (52, 52, 24, 144, 24, 2, False, 3, 0),     # block_3
+    (27, 27, 24, 144, 48, 2, False, 3, 2),     # block_6, odd size
+    (26, 26, 48, 288, 48, 1, True, 6, 0),      # block_7..9: two K = 32 steps
+    (9, 7, 48, 288, 48, 1, True, 6, 1),        # tiny map
+    (26, 26, 48, 288, 72, 1, False, 6, 0),     # block_10
+]
+
+
+@pytest.mark.parametrize('case', MBS_CASES, ids=[str(i) for i in range(len(MBS_CASES))])
+def test_mbr_split_form(dev, case):
+    """Same bar as the float32-MFMA form (5e-5 of the float64-free oracle composition): two float16 planes per operand and three
+    products keep 22 bits of every factor.  Inputs with a wide dynamic range (x 100, x 0.01 per image) included."""
+    from yoloret_amd import runtime as rt
+    op, out, params, keep = make_block(case, dev, split=True)
+    ref = _reference(*params)
+    rt.run_op(op, 2)
+    torch.cuda.synchronize()
+    assert_close(from_dev(out), ref, 5e-5, 'mbr split %s' % (case,))
 
 
 MBE_CASES = [

@@ -263,6 +263,8 @@ SCRATCH_ALLOWED = {
     '_Z16mblane_s2_kernel': 104,
     '_Z15nms_band_kernel': 200,    # the per-lane score list of the band-wise NMS
     '_Z10pwh_kernelIDF16_Li4ELi1ELi2ELi2E': 68,    # f16 direct form, four pixel tiles, gated source
+    '_Z10dwq_kernelIDF16_Li5ELi1ELb1E': 16,        # f16 5x5 swish squeeze-excite walk: three values parked outside the row loop at 168 registers
+    '_Z10mbr_kernel': 12,          # split form (..ELb1EEv): the three-wave stride-1 block at 168 registers and 48 -> 288 -> 72 at 256 park two values
 }
 
 

@@ -291,6 +291,16 @@ MBR_SHAPES = {
     (48, 288, 48, 1, True): (8, 0),      # block_7..9
     (48, 288, 72, 1, False): (8, 0),     # block_10
 }
+# The SPLIT form of YR_OP_MBR (mbr.hip SP, round 4): both 1x1 convolutions on the 16-bit matrix pipe, every float32 operand as two
+# float16 planes (22 bits; measured error against float64 = the float32-MFMA form's, tools/mbs_probe.py) - the float32 MFMA
+# shares the FMA lanes with the depthwise stage, the 16-bit pipe does not.  (cin, cexp, cout, stride, residual) -> waves per
+# workgroup the fragments are packed for.  YOLORET_MBR_SPLIT=0 keeps the float32-MFMA form.
+MBR_SPLIT = os.environ.get('YOLORET_MBR_SPLIT', '1') != '0'
+MBS_SHAPES = {
+    (16, 96, 24, 2, False): 3, (24, 144, 24, 1, True): 3, (24, 144, 24, 2, False): 3, (24, 144, 48, 2, False): 3,
+    (48, 288, 48, 1, True): 6, (48, 288, 72, 1, False): 6,
+    (24, 144, 32, 2, False): 3, (32, 192, 32, 1, True): 4, (32, 192, 48, 2, False): 4,     # MobileNetV2 x1.4
+}
 # float32 plans, blocks too wide for mbr.hip's one-workgroup form: expand + depthwise in one register-chained kernel (YR_OP_MBE),
 # the projection stays a pointwise op.  Block input widths built in mbr.hip (MBE_CASE).
 FUSE_MBE = os.environ.get('YOLORET_FUSE_MBE', '1') != '0'
@@ -738,6 +748,61 @@ def mbr_pack(we_t, e_scale, e_shift, dw, d_scale, d_shift, wp_t, p_scale, p_shif
     return wa, tab, b2
 
 
+def mbs_wave_pairs(T, nw):
+    """The expanded-tile pairs of the SPLIT form of YR_OP_MBR in the order of the packed projection fragments: mbr_kernel gives
+    the first T % nw waves one tile more than the others; a wave pairs ITS tiles (t0, t0 + 1), (t0 + 2, t0 + 3) ... and an odd
+    last one with nothing."""
+    ntl, r = divmod(T, nw)
+    pairs, t0 = [], 0
+    for w in range(nw):
+        nt = ntl + (1 if w < r else 0)
+        for q in range(0, nt, 2):
+            pairs.append((t0 + q, t0 + q + 1 if q + 1 < nt else None))
+        t0 += nt
+    return pairs
+
+
+def mbs_pack(we_t, e_scale, e_shift, dw, d_scale, d_shift, wp_t, p_scale, p_shift, nw):
+    """Parameters of a YR_OP_MBR block in its SPLIT form (k bit 7; mbr.hip, SP): both 1x1 convolutions on the 16-bit matrix pipe
+    with every float32 operand cut into two float16 planes, w = h + 2^-11 m.  wgt = [T][NKE][2 planes][64 lanes][8 halves] for the
+    expand conv (lane (m, g) of tile j, step c: We[16 j + m][32 c + 8 g + i] * BN scale, zero beyond cin), then per tile pair of
+    mbs_wave_pairs(T, nw) [TO][2 planes][64][8]: Wp[16 t + m][16 tA + 4 g + i] (i < 4) | [16 tB + 4 g + i - 4] * BN scale - as the
+    float32 words that hold them; wgt2 and b2 as mbr_pack."""
+    _, tab, b2 = mbr_pack(we_t, e_scale, e_shift, dw, d_scale, d_shift, wp_t, p_scale, p_shift)
+    cexp = dw.shape[1] // 16 * 16
+    cout, cin = wp_t.shape[0], we_t.shape[1] // 8 * 8
+    T, TO, NKE = cexp // 16, (cout + 15) // 16, (cin + 31) // 32
+    wef = np.zeros((cexp, 32 * NKE), np.float32)
+    wef[:, :cin] = (we_t[:cexp, :cin] * e_scale[:cexp, None]).astype(np.float32)
+    wpf = np.zeros((16 * TO, cexp), np.float32)
+    wpf[:cout] = (wp_t[:, :cexp] * p_scale[:cout, None]).astype(np.float32)
+    assert max(np.abs(wef).max(), np.abs(wpf).max()) < 60000.0, 'mbs_pack: a weight beyond the float16 range'
+
+    def planes(x):
+        h = x.astype(np.float16)
+        m = ((x - h.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+        return h, m
+    lane = np.arange(64)
+    m_, g = lane % 16, lane // 16
+    i8 = np.arange(8)
+    ex = np.zeros((T, NKE, 2, 64, 8), np.float16)
+    for j in range(T):
+        for c in range(NKE):
+            v = wef[(16 * j + m_)[:, None], 32 * c + 8 * g[:, None] + i8[None, :]]
+            ex[j, c, 0], ex[j, c, 1] = planes(v)
+    pairs = mbs_wave_pairs(T, nw)
+    pr = np.zeros((len(pairs), TO, 2, 64, 8), np.float16)
+    for q, (ta, tb) in enumerate(pairs):
+        for t in range(TO):
+            v = np.zeros((64, 8), np.float32)
+            v[:, :4] = wpf[(16 * t + m_)[:, None], 16 * ta + 4 * g[:, None] + i8[None, :4]]
+            if tb is not None:
+                v[:, 4:] = wpf[(16 * t + m_)[:, None], 16 * tb + 4 * g[:, None] + i8[None, :4]]
+            pr[q, t, 0], pr[q, t, 1] = planes(v)
+    wa = np.concatenate([ex.ravel(), pr.ravel()]).view(np.float32)
+    return wa, tab, b2
+
+
 def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None):
     """Peephole over the lowered op list: [POINTWISE expand+act ->] DEPTHWISE 3x3+act -> POINTWISE
     project (+residual == block input) becomes one MBCONV op whose expanded tensors never reach HBM.
@@ -918,11 +983,25 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                     and (p.res is None or (p.res is bi.buf and d.stride == 1 and p.cout == bi.c))):
                 cin, cexp, cout = bi.c, d.cin, p.cout
                 nw, segs = MBR_SHAPES[key][:2]
+                split = MBR_SPLIT and key in MBS_SHAPES
+                if split:
+                    nw = MBS_SHAPES[key]
                 T, TO, KE = cexp // 16, (cout + 15) // 16, cin // 4
-                m = OpRec(rt.OP_MBR, bname + '_mbr', act='relu6', h=p.h, w=p.w, cin=cin, cout=cout, k=3 | nw << 8 | segs << 16,
+                m = OpRec(rt.OP_MBR, bname + '_mbr', act='relu6', h=p.h, w=p.w, cin=cin, cout=cout, k=3 | (0x80 if split else 0) | nw << 8 | segs << 16,
                           stride=d.stride, se_reduced=cexp, srcs=[bi], out=p.out, res=p.res, macs=exp.macs + d.macs + p.macs, dtype=0)
                 m.fused = [exp, d, p]
                 ep, dp, pp = exp.params, d.params, p.params
+                if split:
+                    def packed_s(which, ep=ep, dp=dp, pp=pp, nw=nw):
+                        def f(wd):
+                            return mbs_pack(ep['wgt'][1](wd), ep['scale'][1](wd), ep['shift'][1](wd), dp['wgt'][1](wd).reshape(9, -1),
+                                            dp['scale'][1](wd), dp['shift'][1](wd), pp['wgt'][1](wd), pp['scale'][1](wd), pp['shift'][1](wd), nw)[which]
+                        return f
+                    nwords = (T * ((cin + 31) // 32) + len(mbs_wave_pairs(T, nw)) * TO) * 512
+                    m.params = {'wgt': ((nwords,), packed_s(0)), 'wgt2': ((T, 11, 16), packed_s(1)), 'b2': ((16 * TO,), packed_s(2))}
+                    out.append(m)
+                    i = j + 2
+                    continue
 
                 def packed(which, ep=ep, dp=dp, pp=pp, cexp=cexp):
                     def f(wd):

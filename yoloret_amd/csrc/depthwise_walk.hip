@@ -141,7 +141,8 @@ __device__ __forceinline__ void dwq_group(const unsigned* lrow, int rpitch, dwq_
 }
 
 template <class T, int K, int ACT, bool SE>
-__global__ __launch_bounds__(256, K == 5 ? 3 : 4) void dwq_kernel(DwqArgs a) {
+// (launch bounds: the generic activation's switch needs more registers than 3 waves per SIMD leave)
+__global__ __launch_bounds__(256, K == 5 ? (ACT == 2 ? 2 : 3) : 4) void dwq_kernel(DwqArgs a) {
     constexpr int KK = K * K, HALO = K - 1;
     extern __shared__ unsigned dwq_lds[];   // two group buffers; SE: then 2 x 256 float2 of slot sums
     unsigned lin = yr_xcd_swizzle(blockIdx.x, a.nblocks);

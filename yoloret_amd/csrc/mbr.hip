@@ -110,10 +110,38 @@ __device__ __forceinline__ mbr_rsrc mbr_make_rsrc(const void* base, unsigned byt
 }
 #define MBR_DEAD 0x7f000000u   // a byte offset beyond every descriptor's num_records: the load returns zeros, the store is dropped
 
-template <int CIN, int CEXP, int COUT, int S, int NW, bool RES, int NT>
+// ---- SPLIT form (SP, round 4): the two 1x1 convolutions on the 16-bit matrix pipe with float32-grade operands.  On gfx950 the
+// float32 MFMA runs on the VALU's FMA lanes (its cycles ADD to the depthwise stage's), v_mfma_f32_16x16x32_f16 has its own pipe and
+// 8 x the rate.  Every float32 operand is cut into two float16 planes, x = h + 2^-11 m with h = f16(x), m = f16((x - h) 2^11)
+// (x - h is exact; 22 significant bits, the scaled plane never leaves the normal range for |x| > 2^-13 and degrades gracefully
+// below), and a product needs three MFMAs - h h' into one accumulator, h m' + m h' into a second that joins with 2^-11 at the
+// end (the dropped m m' term is below 2^-24 of |x| |w|).  The weights' planes are cut by the host (compiler.mbs_pack), the
+// pixels' and the depthwise results' in registers (5 VALU operations per pair of values).  Precondition: |x| < 65504 for the
+// block input (a float16 plane has no more range; beyond it the result is NaN, not a wrong number); the depthwise
+// results are ReLU6'd.  One K = 32 step takes 8 channels per lane: the block input's channels 32 c + 8 g .. + 7, and for the
+// projection the four channels of expanded tile 2 q and the four of tile 2 q + 1 a lane holds after the depthwise stage.
+typedef _Float16 mbs_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 mbs_h8 __attribute__((ext_vector_type(8)));
+typedef unsigned mbs_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mbs_split8(const float (&v)[8], mbs_u4& h, mbs_u4& m) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const mbs_h2 hh = __builtin_convertvector((v2f){v[2 * p], v[2 * p + 1]}, mbs_h2);
+        const v2f r = (v2f){v[2 * p], v[2 * p + 1]} - __builtin_convertvector(hh, v2f);
+        const mbs_h2 mm = __builtin_convertvector(r * 2048.0f, mbs_h2);
+        h[p] = __builtin_bit_cast(unsigned, hh);
+        m[p] = __builtin_bit_cast(unsigned, mm);
+    }
+}
+__device__ __forceinline__ v4f mbs_mfma(mbs_u4 a, mbs_u4 b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mbs_h8, a), __builtin_bit_cast(mbs_h8, b), c, 0, 0, 0);
+}
+
+template <int CIN, int CEXP, int COUT, int S, int NW, bool RES, int NT, bool SP>
 __device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const int w, float* lds) {
     constexpr int T = CEXP / 16, TO = (COUT + 15) / 16, NMAIN = CIN / 16, TAIL = CIN % 16, KE = NMAIN * 4 + TAIL / 4;
     constexpr int NREG = KE + 4 * TO, NOUT = 14 / S;
+    constexpr int NKE = (CIN + 31) / 32, NP = (NT + 1) / 2;   // SP: K = 32 steps of the expand conv, tile pairs of this wave
     static_assert(TAIL == 0 || TAIL == 8, "block input width must be 16 n or 16 n + 8");
     static_assert(CEXP % 16 == 0 && COUT % 4 == 0, "widths");
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
@@ -134,19 +162,42 @@ __device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const i
     const bool out_lane = (S == 2 ? (px & 7) < 7 : (px >= 1 && px <= 14)) && xo < a.Wo;
 
     // ---- stationary A fragments of this wave's tiles
-    float we[NT][KE], wp[NT][TO][4];
+    float we[SP ? 1 : NT][SP ? 1 : KE], wp[SP ? 1 : NT][TO][4];
+    mbs_u4 weh[SP ? NT : 1][NKE], wem[SP ? NT : 1][NKE], wph[SP ? NP : 1][TO], wpm[SP ? NP : 1][TO];
     v4f se[NT];
+    if constexpr (!SP) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const float* p = a.wa + ((size_t)(t0 + j) * NREG) * 64 + lane;
+        for (int j = 0; j < NT; ++j) {
+            const float* p = a.wa + ((size_t)(t0 + j) * NREG) * 64 + lane;
 #pragma unroll
-        for (int q = 0; q < KE; ++q) we[j][q] = p[q * 64];
+            for (int q = 0; q < KE; ++q) we[j][q] = p[q * 64];
 #pragma unroll
-        for (int t = 0; t < TO; ++t)
+            for (int t = 0; t < TO; ++t)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) wp[j][t][s] = p[(KE + 4 * t + s) * 64];
-        se[j] = *reinterpret_cast<const v4f*>(a.wt + (size_t)(t0 + j) * MBR_TAB + 160 + 4 * mg);
+                for (int s = 0; s < 4; ++s) wp[j][t][s] = p[(KE + 4 * t + s) * 64];
+        }
+    } else {   // [T][NKE][2 planes][64 lanes] x 16 bytes, then per (wave's tile pair)[TO][2 planes][64] (compiler.mbs_pack)
+        const mbs_u4* pe = reinterpret_cast<const mbs_u4*>(a.wa);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int c = 0; c < NKE; ++c) {
+                weh[j][c] = pe[(((size_t)(t0 + j) * NKE + c) * 2 + 0) * 64 + lane];
+                wem[j][c] = pe[(((size_t)(t0 + j) * NKE + c) * 2 + 1) * 64 + lane];
+            }
+        constexpr int TT = CEXP / 16, NTL_ = TT / NW, R_ = TT % NW, NTH_ = NTL_ + (R_ ? 1 : 0);
+        const int pair0 = w < R_ ? w * ((NTH_ + 1) / 2) : R_ * ((NTH_ + 1) / 2) + (w - R_) * ((NTL_ + 1) / 2);   // the pairs of the waves before this one
+        const mbs_u4* pp = pe + (size_t)TT * NKE * 2 * 64;
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int t = 0; t < TO; ++t) {
+                wph[q][t] = pp[(((size_t)(pair0 + q) * TO + t) * 2 + 0) * 64 + lane];
+                wpm[q][t] = pp[(((size_t)(pair0 + q) * TO + t) * 2 + 1) * 64 + lane];
+            }
     }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) se[j] = *reinterpret_cast<const v4f*>(a.wt + (size_t)(t0 + j) * MBR_TAB + 160 + 4 * mg);
     // ---- the depthwise table of all tiles -> LDS
     float* tab = lds;
     for (int i = threadIdx.x; i < T * MBR_TAB; i += 64 * NW) tab[i] = a.wt[i];
@@ -162,13 +213,27 @@ __device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const i
     const unsigned xoff = ((unsigned)xc * (unsigned)a.ld_in + 4u * mg) * 4u, xtoff = ((unsigned)xc * (unsigned)a.ld_in + 16u * NMAIN + 2u * mg) * 4u;
     const unsigned xrow = (unsigned)(a.W * a.ld_in) * 4u;
     // the B operands of a row: two register sets used alternately (the loads of row r + 1 are issued at the start of row r)
-    struct XRow { v4f m[NMAIN > 0 ? NMAIN : 1]; v2f t; };
+    struct XRow { v4f m[SP ? 2 * NKE : (NMAIN > 0 ? NMAIN : 1)]; v2f t; };
     XRow xa, xb;
+    // SP: step c takes the lane's channels 32 c + 8 g .. + 7 (two 16-byte loads; a group beyond the block input reads zeros)
+    unsigned xsoff[SP ? NKE : 1];
+    if constexpr (SP) {
+#pragma unroll
+        for (int c = 0; c < NKE; ++c) xsoff[c] = 32 * c + 8 * mg < CIN ? ((unsigned)xc * (unsigned)a.ld_in + 32u * c + 8u * mg) * 4u : MBR_DEAD;
+    }
     auto load_row = [&](XRow& x, int r) {
         const unsigned so = (unsigned)min(max(r, 0), a.H - 1) * xrow;
+        if constexpr (SP) {
 #pragma unroll
-        for (int c = 0; c < NMAIN; ++c) x.m[c] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff + 64u * c, so, 0));
-        if constexpr (TAIL != 0) x.t = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(xsrc, xtoff, so, 0));
+            for (int c = 0; c < NKE; ++c) {
+                x.m[2 * c] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xsoff[c], so, 0));
+                x.m[2 * c + 1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xsoff[c] == MBR_DEAD ? MBR_DEAD : xsoff[c] + 16u, so, 0));
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NMAIN; ++c) x.m[c] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff + 64u * c, so, 0));
+            if constexpr (TAIL != 0) x.t = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(xsrc, xtoff, so, 0));
+        }
     };
     load_row(xa, rbeg);
     // the cout tiles this wave finishes (tile t = w + tt * NW): BN shift once, the residual one row ahead of its use
@@ -197,10 +262,19 @@ __device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const i
         constexpr bool EMIT = S == 2 ? PH == 4 : PH == 1;
         const int r = rbeg + k;
         load_row(xn_, r + 1);
-        float xq[KE];
+        float xq[SP ? 1 : KE];
+        mbs_u4 xh[SP ? NKE : 1], xm[SP ? NKE : 1];
+        if constexpr (SP) {
 #pragma unroll
-        for (int c = 0; c < NMAIN; ++c) { xq[4 * c] = xc_.m[c][0]; xq[4 * c + 1] = xc_.m[c][1]; xq[4 * c + 2] = xc_.m[c][2]; xq[4 * c + 3] = xc_.m[c][3]; }
-        if constexpr (TAIL != 0) { xq[4 * NMAIN] = xc_.t[0]; xq[4 * NMAIN + 1] = xc_.t[1]; }
+            for (int c = 0; c < NKE; ++c) {
+                const float v[8] = {xc_.m[2 * c][0], xc_.m[2 * c][1], xc_.m[2 * c][2], xc_.m[2 * c][3], xc_.m[2 * c + 1][0], xc_.m[2 * c + 1][1], xc_.m[2 * c + 1][2], xc_.m[2 * c + 1][3]};
+                mbs_split8(v, xh[c], xm[c]);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NMAIN; ++c) { xq[4 * c] = xc_.m[c][0]; xq[4 * c + 1] = xc_.m[c][1]; xq[4 * c + 2] = xc_.m[c][2]; xq[4 * c + 3] = xc_.m[c][3]; }
+            if constexpr (TAIL != 0) { xq[4 * NMAIN] = xc_.t[0]; xq[4 * NMAIN + 1] = xc_.t[1]; }
+        }
         if constexpr (EMIT && RES) {
 #pragma unroll
             for (int tt = 0; tt < NF; ++tt) {
@@ -213,20 +287,53 @@ __device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const i
         v4f ec[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) ec[j] = se[j];
+        if constexpr (SP) {
+            v4f e1[NT];
 #pragma unroll
-        for (int q = 0; q < KE; ++q)
+            for (int j = 0; j < NT; ++j) e1[j] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < NT; ++j) ec[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(we[j][q], xq[q], ec[j], 0, 0, 0);
+            for (int c = 0; c < NKE; ++c) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) ec[j] = mbs_mfma(weh[j][c], xh[c], ec[j]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) e1[j] = mbs_mfma(weh[j][c], xm[c], e1[j]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) e1[j] = mbs_mfma(wem[j][c], xh[c], e1[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ec[j] = e1[j] * 0.00048828125f + ec[j];
+        } else {
+#pragma unroll
+            for (int q = 0; q < KE; ++q)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) ec[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(we[j][q], xq[q], ec[j], 0, 0, 0);
+        }
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) ec[j][i] = __builtin_amdgcn_fmed3f(ec[j][i], 0.f, hr);
 
-        v4f P[TO];
+        v4f P[TO], P1[SP ? TO : 1];
         if constexpr (EMIT) {
 #pragma unroll
             for (int t = 0; t < TO; ++t) P[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+            if constexpr (SP) {
+#pragma unroll
+                for (int t = 0; t < TO; ++t) P1[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+            }
         }
+        // SP: the projection of one tile pair - the 8 depthwise results a lane holds are its 8 k values of the step
+        auto project_pair = [&](const int q, const v4f dA, const v4f dB) {
+            const float v[8] = {dA[0], dA[1], dA[2], dA[3], dB[0], dB[1], dB[2], dB[3]};
+            mbs_u4 bh, bm;
+            mbs_split8(v, bh, bm);
+#pragma unroll
+            for (int t = 0; t < TO; ++t) {
+                P[t] = mbs_mfma(wph[q][t], bh, P[t]);
+                P1[t] = mbs_mfma(wph[q][t], bm, P1[t]);
+                P1[t] = mbs_mfma(wpm[q][t], bh, P1[t]);
+            }
+        };
         if constexpr (S == 2 && PH != 0) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -245,14 +352,21 @@ __device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const i
                     v4f d = d2[j];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) d[i] = __builtin_amdgcn_fmed3f(d[i], 0.f, 6.f);
+                    if constexpr (SP) {
+                        d2[j] = d;
+                        if (j % 2 == 1) project_pair(j / 2, d2[j - 1], d2[j]);   // (j is a constant once unrolled)
+                        else if (j == NT - 1) project_pair(j / 2, d2[j], (v4f){0.f, 0.f, 0.f, 0.f});
+                    } else {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
+                        for (int s = 0; s < 4; ++s)
 #pragma unroll
-                        for (int t = 0; t < TO; ++t) P[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[j][t][s], d[s], P[t], 0, 0, 0);
+                            for (int t = 0; t < TO; ++t) P[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[j][t][s], d[s], P[t], 0, 0, 0);
+                    }
                 }
             }
         }
         if constexpr (S == 1 && EMIT) {
+            v4f dprev = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const v4f* tb = reinterpret_cast<const v4f*>(tab + (t0 + j) * MBR_TAB) + mg;
@@ -262,11 +376,21 @@ __device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const i
                 mbr_dw_row(d, ec[j], tb[24], tb[28], tb[32]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) d[i] = __builtin_amdgcn_fmed3f(d[i], 0.f, 6.f);
+                if constexpr (SP) {
+                    if (j % 2 == 1) project_pair(j / 2, dprev, d);   // (j is a constant once unrolled)
+                    else if (j == NT - 1) project_pair(j / 2, d, (v4f){0.f, 0.f, 0.f, 0.f});
+                    dprev = d;
+                } else {
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                    for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int t = 0; t < TO; ++t) P[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[j][t][s], d[s], P[t], 0, 0, 0);
+                        for (int t = 0; t < TO; ++t) P[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[j][t][s], d[s], P[t], 0, 0, 0);
+                }
             }
+        }
+        if constexpr (EMIT && SP) {
+#pragma unroll
+            for (int t = 0; t < TO; ++t) P[t] = P1[t] * 0.00048828125f + P[t];
         }
         if constexpr (EMIT) {
             const int yl = yo + podd;   // (stride 2: lanes 8..15 hold the row below)
@@ -331,19 +455,19 @@ __device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const i
     }
 }
 
-template <int CIN, int CEXP, int COUT, int S, int NW, bool RES, int MW>
+template <int CIN, int CEXP, int COUT, int S, int NW, bool RES, int MW, bool SP>
 __global__ __launch_bounds__(64 * NW, MW) void mbr_kernel(MbrArgs a) {
     constexpr int T = CEXP / 16, NTL = T / NW, R = T % NW, NTH = NTL + (R ? 1 : 0);
     static_assert(NTL >= 1, "more waves than expanded tiles");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if constexpr (R != 0) {
-        if (w < R) { mbr_body<CIN, CEXP, COUT, S, NW, RES, NTH>(a, w * NTH, w, lds); return; }
+        if (w < R) { mbr_body<CIN, CEXP, COUT, S, NW, RES, NTH, SP>(a, w * NTH, w, lds); return; }
     }
-    mbr_body<CIN, CEXP, COUT, S, NW, RES, NTL>(a, R * NTH + (w - R) * NTL, w, lds);
+    mbr_body<CIN, CEXP, COUT, S, NW, RES, NTL, SP>(a, R * NTH + (w - R) * NTL, w, lds);
 }
 
-template <int CIN, int CEXP, int COUT, int S, int NW, bool RES>
+template <int CIN, int CEXP, int COUT, int S, int NW, bool RES, bool SP = false>
 static int launch_mbr(const MbrArgs& a0, int batch, int want_segs, hipStream_t s) {
     MbrArgs a = a0;
     constexpr int T = CEXP / 16, TO = (COUT + 15) / 16, NOUT = 14 / S;
@@ -360,16 +484,20 @@ static int launch_mbr(const MbrArgs& a0, int batch, int want_segs, hipStream_t s
     a.segs = (a.Ho + a.seg_rows - 1) / a.seg_rows;
     const size_t lds = (size_t)T * MBR_TAB * 4 + (NW > 1 ? (size_t)2 * NW * TO * 64 * 16 : 0);
     static char nm[64];
-    static const int nm_len = snprintf(nm, sizeof(nm), "mbr_kernel<%d,%d,%d,%d,%d,%d>", CIN, CEXP, COUT, S, NW, (int)RES);
+    static const int nm_len = SP ? snprintf(nm, sizeof(nm), "mbs_kernel<%d,%d,%d,%d,%d,%d>", CIN, CEXP, COUT, S, NW, (int)RES)   // (the symbol is mbr_kernel<..., true>)
+                                 : snprintf(nm, sizeof(nm), "mbr_kernel<%d,%d,%d,%d,%d,%d>", CIN, CEXP, COUT, S, NW, (int)RES);
     (void)nm_len;
     yr_note_kernel(nm);
     // waves per SIMD the register allocator must leave room for, from an estimate of what a wave holds: the stationary
     // fragments + BN shifts, ring and new row, projection accumulators, two rows of pixel operands, ~44 others
     constexpr int NTH = (T + NW - 1) / NW, KE = CIN / 4;
-    constexpr int EST = NTH * (KE + 4 * TO + 4 + 12) + 4 * TO + 2 * KE + 44;
-    constexpr int MW = EST <= 164 ? 3 : EST <= 250 ? 2 : 1;
+    constexpr int NKE = (CIN + 31) / 32, NPH = (NTH + 1) / 2;
+    constexpr int EST = SP ? NTH * (8 * NKE + 4 + 12 + 4) + NPH * 8 * TO + 8 * TO + 16 * NKE + 8 * NKE + 60
+                           : NTH * (KE + 4 * TO + 4 + 12) + 4 * TO + 2 * KE + 44;
+    // (SP: measured register counts - the stride-1 three-wave kernels fit 168, the others spill there)
+    constexpr int MW = SP ? (S == 1 && NW <= 3 ? 3 : 2) : EST <= 164 ? 3 : EST <= 250 ? 2 : 1;
     static_assert(NW <= 4 * MW, "a workgroup's waves must fit one CU at this register budget");
-    auto kern = mbr_kernel<CIN, CEXP, COUT, S, NW, RES, MW>;   // waves per SIMD the register allocator must leave room for
+    auto kern = mbr_kernel<CIN, CEXP, COUT, S, NW, RES, MW, SP>;   // waves per SIMD the register allocator must leave room for
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         YR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -570,7 +698,7 @@ int yr_launch_mbe(const yr_op& op, int batch, hipStream_t s) {
     return YR_ERR_ARG;
 }
 
-// op fields: src[0] = block input (float32, c % 8 == 0, c % 16 in {0, 8}); se_reduced = Cexp (multiple of 16); k = 3 | nw << 8 | segs << 16
+// op fields: src[0] = block input (float32, c % 8 == 0, c % 16 in {0, 8}); se_reduced = Cexp (multiple of 16); k = 3 | split << 7 | nw << 8 | segs << 16
 // (nw: waves per workgroup, segs: row segments per strip; 0 = the library's choice); stride 1 | 2; act = ReLU6; res (optional) = the block input.  Parameters (float32):
 //   wgt  = A fragments [T = Cexp/16][KE + 4 TO][64]: register rho of lane (m = l % 16, g = l / 16) of tile j:
 //          rho < KE (expand step q = rho): We[16 j + m][kperm(q, g)] * expand BN scale, kperm(4 c + s, g) = 16 c + 4 g + s for the
@@ -578,11 +706,16 @@ int yr_launch_mbe(const yr_op& op, int batch, hipStream_t s) {
 //          BN scale (0 beyond cout);
 //   wgt2 = [T][11][16]: depthwise taps (ky, kx) times the depthwise BN scale | depthwise BN shift | expand BN shift;
 //   b2   = project BN shift [16 TO].
+// split = 1: the SPLIT form (both 1x1 convolutions on the 16-bit matrix pipe, every operand as two float16 planes: see mbs_split8) -
+//   wgt  = the float32 words that hold [T][NKE = ceil(cin / 32)][2 planes][64 lanes][8 halves]: We[16 j + m][32 c + 8 g + i] * BN scale
+//          (h plane, then m plane = f16((w - h) 2^11)), followed by, per tile pair (tA, tB) of the nw waves in order (a wave pairs ITS tiles;
+//          an odd last one pairs with nothing), [TO][2 planes][64][8]: Wp[16 t + m][16 tA + 4 g + i] (i < 4) | Wp[16 t + m][16 tB + 4 g + i - 4];
+//          nw must be the value the fragments were packed for.  wgt2, b2 as above.
 int yr_launch_mbr(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(op.dtype == YR_F32 && op.out_dtype == YR_F32, "mbr: float32 plans only");
     YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY && op.src[0].dtype == YR_F32, "mbr: needs one float32 identity source");
     const yr_src& in = op.src[0];
-    YR_REQUIRE((op.k & 0xff) == 3 && (op.stride == 1 || op.stride == 2) && op.act == YR_ACT_RELU6, "mbr: 3x3, stride 1|2, ReLU6");
+    YR_REQUIRE((op.k & 0x7f) == 3 && (op.stride == 1 || op.stride == 2) && op.act == YR_ACT_RELU6, "mbr: 3x3, stride 1|2, ReLU6");
     YR_REQUIRE(in.ptr && op.out && op.wgt && op.wgt2 && op.b2, "mbr: null pointer");
     YR_REQUIRE(in.ld % 4 == 0 && op.out_ld % 4 == 0 && in.c == op.cin && in.ld >= in.c && op.out_ld >= op.cout, "mbr: channel strides");
     YR_REQUIRE(((uintptr_t)in.ptr) % 16 == 0 && ((uintptr_t)op.out) % 16 == 0, "mbr: pointers must be 16-byte aligned");
@@ -597,6 +730,23 @@ int yr_launch_mbr(const yr_op& op, int batch, hipStream_t s) {
     if (res) YR_REQUIRE(op.res == in.ptr && op.stride == 1 && in.c == op.cout, "mbr: the residual must be the block input (stride 1, Cin == Cout)");
     a.strips = a.segs = a.seg_rows = 0;
     const int nw = (op.k >> 8) & 0xff;
+    if (op.k & 0x80) {   // the SPLIT form (bit 7 of k): wgt holds float16 planes packed for exactly this many waves (compiler.mbs_pack)
+#define MBS_CASE(CIN, CEXP, COUT, S, NW, RES)                                                              \
+    if (in.c == CIN && op.se_reduced == CEXP && op.cout == COUT && op.stride == S && res == RES && nw == NW) \
+        return launch_mbr<CIN, CEXP, COUT, S, NW, RES, true>(a, batch, (op.k >> 16) & 0xff, s);
+        MBS_CASE(16, 96, 24, 2, 3, false)
+        MBS_CASE(24, 144, 24, 1, 3, true)
+        MBS_CASE(24, 144, 24, 2, 3, false)
+        MBS_CASE(24, 144, 48, 2, 3, false)
+        MBS_CASE(48, 288, 48, 1, 6, true)
+        MBS_CASE(48, 288, 72, 1, 6, false)
+        MBS_CASE(24, 144, 32, 2, 3, false)     // MobileNetV2 x1.4 block_1
+        MBS_CASE(32, 192, 32, 1, 4, true)      // x1.4 block_2
+        MBS_CASE(32, 192, 48, 2, 4, false)     // x1.4 block_3
+#undef MBS_CASE
+        yr_set_error("mbr (split form): block %d -> %d -> %d stride %d res %d nw %d is not built", in.c, op.se_reduced, op.cout, op.stride, (int)res, nw);
+        return YR_ERR_ARG;
+    }
 #define MBR_CASE(CIN, CEXP, COUT, S, NW, RES)                                                              \
     if (in.c == CIN && op.se_reduced == CEXP && op.cout == COUT && op.stride == S && res == RES && (nw == 0 || nw == NW)) \
         return launch_mbr<CIN, CEXP, COUT, S, NW, RES>(a, batch, (op.k >> 16) & 0xff, s);

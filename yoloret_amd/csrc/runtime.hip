@@ -209,6 +209,13 @@ static int64_t param_floats(const yr_op& op, int role) {   // role: 0 wgt, 1 sca
         }
         case YR_OP_MBR: {
             const int64_t t = op.se_reduced / 16, to = ru(op.cout, 16) / 16, ke = op.cin / 4;
+            if (role == 0 && (op.k & 0x80)) {   // the split form: float16 planes, projection fragments per tile pair of the nw waves
+                const int64_t nw = (op.k >> 8) & 0xff, nke = (op.cin + 31) / 32;
+                if (nw < 1 || nw > t) return -1;
+                const int64_t ntl = t / nw, r = t % nw;
+                const int64_t pairs = r * ((ntl + 2) / 2) + (nw - r) * ((ntl + 1) / 2);
+                return (t * nke + pairs * to) * 2 * 64 * 4;
+            }
             if (role == 0) return t * (ke + 4 * to) * 64;
             if (role == 3) return t * 176;
             if (role == 5) return 16 * to;

@@ -269,6 +269,8 @@ class Model:
                     kk = (op.k & 0xff) ** 2
                     cexp = op.se_reduced if op.kind == rt.OP_MBH else op.cout
                     m16 = max(op.macs - op.h * op.w * kk * cexp, 0)
+            elif op.kind == rt.OP_MBR and op.k & 0x80:   # the split form: both 1x1 convolutions on the 16-bit pipe (three float16 products each)
+                m16 = max(op.macs - op.h * op.w * 9 * op.se_reduced, 0)
             out.append(dict(name=op.name, kind=rt.OP_NAMES[op.kind], kernel=(names[i] or b'').decode(),
                             ms=float(ms[i]), macs=op.macs * b, macs_mfma16=m16 * b, bytes=per_op_bytes[i] * b, hbm_bytes=per_op_hbm[i] * b))
         return out
