@@ -348,9 +348,10 @@ def main():
             dict(name='pack', kind='pack', kernel='pack_kernel', ms=post_ms[2], macs=0, bytes=0)]
         by = {}
         for r in rows:
-            k = by.setdefault(r['kernel'], dict(ms=0.0, bytes=0, hbm=0, macs=0, macs16=0, launches=0))
+            k = by.setdefault(r['kernel'], dict(ms=0.0, bytes=0, hbm=0, macs=0, macs16=0, macs32=0, launches=0))
             k['ms'] += r['ms']; k['bytes'] += r['bytes']; k['macs'] += r['macs']; k['launches'] += 1
             k['macs16'] += r.get('macs_mfma16', 0)
+            k['macs32'] += r.get('macs_fp32', r['macs'] - r.get('macs_mfma16', 0))   # (split-form blocks: 3 float16 products per 1x1 multiply-add on the 16-bit pipe, the depthwise stage here)
             k['hbm'] += r.get('hbm_bytes', r['bytes'])
         dom = max(by, key=lambda k: by[k]['ms'])
         d = by[dom]
@@ -363,7 +364,7 @@ def main():
             sec = v['ms'] * 1e-3
             gbs = v['hbm'] / sec / 1e9 if sec else 0.0
             tf16 = 2.0 * v['macs16'] / sec / 1e12 if sec else 0.0
-            tf32 = 2.0 * (v['macs'] - v['macs16']) / sec / 1e12 if sec else 0.0
+            tf32 = 2.0 * v['macs32'] / sec / 1e12 if sec else 0.0
             fr = {'hbm': gbs / HBM_PEAK_GBS, 'mfma16': tf16 / MFMA16_PEAK_TFLOPS, 'fp32': tf32 / FP32_PEAK_TFLOPS}
             return gbs, tf16, tf32, fr
         gbs, tf16, tf32, fr = pipes(d)
@@ -378,12 +379,12 @@ def main():
             roofline = {'bound': 'mfma', 'pipe': '16-bit MFMA' if pipe_name == 'mfma16' else 'float32 (fp32 MFMA / packed FMA)',
                         'kernel': dom, 'launches_per_step': d['launches'], 'avg_launch_ms': round(avg_ms, 4),
                         'achieved': round(tfl, 2), 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': round(tfl / peak_tf, 4), 'traffic': None,
-                        'flops_per_launch': int(2.0 * (d['macs16'] if pipe_name == 'mfma16' else d['macs'] - d['macs16']) / d['launches'])}
+                        'flops_per_launch': int(2.0 * (d['macs16'] if pipe_name == 'mfma16' else d['macs32']) / d['launches'])}
         roofline['by_pipe'] = {'hbm_gbs': round(gbs, 1), 'frac_hbm': round(fr['hbm'], 4), 'mfma16_tflops': round(tf16, 2),
                                'frac_mfma16': round(fr['mfma16'], 4), 'fp32_tflops': round(tf32, 2), 'frac_fp32': round(fr['fp32'], 4)}
         # the same per kernel FAMILY: the lane-per-pixel front, the fused MFMA blocks ... are several symbols each
         fams = [('lane_per_pixel_front', ('mblane', 'stemblock', 'stem_')),
-                ('fused_blocks', ('mbh_kernel', 'mbn_kernel', 'mbr_kernel', 'mbe_kernel', 'mbx_kernel', 'mbxr_kernel', 'mbhr_kernel', 'stemxr_kernel')),
+                ('fused_blocks', ('mbh_kernel', 'mbn_kernel', 'mbr_kernel', 'mbs_kernel', 'mbe_kernel', 'mbes_kernel', 'mbx_kernel', 'mbxr_kernel', 'mbhr_kernel', 'stemxr_kernel')),
                 ('pointwise', ('pw_kernel', 'pwd_kernel', 'pwh', 'pwl')), ('depthwise', ('dw_kernel', 'dwp_kernel', 'dwq_kernel', 'dwl')),
                 ('elementwise', ('wsum', 'gather', 'letterbox')),
                 ('squeeze_excite', ('se_',)), ('postprocess', ('decode', 'nms', 'pack'))]
@@ -392,7 +393,7 @@ def main():
         total_ms = sum(v['ms'] for v in by.values())
         roofline_family = {}
         for fname, prefixes in fams:
-            agg = dict(ms=0.0, hbm=0, macs=0, macs16=0, launches=0)
+            agg = dict(ms=0.0, hbm=0, macs=0, macs16=0, macs32=0, launches=0)
             for sym, v in by.items():
                 if sym.startswith(prefixes):
                     for kk in agg:
@@ -446,7 +447,8 @@ def main():
         alg_gbs = per_gpu * alg_img / 1e9
         moved_min = sum(r.get('hbm_bytes', r['bytes']) for r in rows)     # per step: every op's sources + output
         macs16_img = sum(r.get('macs_mfma16', 0) for r in rows) / b       # multiply-adds per image on the 16-bit matrix pipe
-        fp32_roof = FP32_PEAK_TFLOPS * 1e12 / flops_img                   # img/s if the float32 pipe were the only limit
+        macs32_img = sum(r.get('macs_fp32', r['macs'] - r.get('macs_mfma16', 0)) for r in rows) / b   # ... on the float32 pipe (fp32 MFMA / packed FMA)
+        fp32_roof = FP32_PEAK_TFLOPS * 1e12 / max(2.0 * macs32_img, 1.0)   # img/s if the float32 pipe were the only limit
         # `achieved` / `frac` follow SURVEY.md 8(d)'s agreed accounting: conv-granular ALGORITHMIC bytes (a fused kernel is
         # credited the bytes of the convolutions it replaces) - a measure of work done per second, NOT of bandwidth used.
         # What actually crosses HBM is `moved_*`: the plan's minimum (each launched op's inputs + output) and, when the
@@ -465,8 +467,8 @@ def main():
                          # by pipe: the multiply-adds of a 16-bit plan's 1x1 convolutions run on the 16-bit matrix pipe
                          'tflops_mfma16': round(per_gpu * 2.0 * macs16_img / 1e12, 2),
                          'frac_mfma16_peak': round(per_gpu * 2.0 * macs16_img / 1e12 / MFMA16_PEAK_TFLOPS, 4),
-                         'tflops_fp32': round(per_gpu * (flops_img - 2.0 * macs16_img) / 1e12, 2),
-                         'frac_fp32_peak': round(per_gpu * (flops_img - 2.0 * macs16_img) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                         'tflops_fp32': round(per_gpu * 2.0 * macs32_img / 1e12, 2),
+                         'frac_fp32_peak': round(per_gpu * 2.0 * macs32_img / 1e12 / FP32_PEAK_TFLOPS, 4),
                          'fp32_roofline_img_s': round(fp32_roof, 0),
                          'hbm_roofline_img_s': round(HBM_PEAK_GBS * 1e9 / alg_img, 0),
                          'sum_kernel_ms': round(sum(r['ms'] for r in rows), 3),

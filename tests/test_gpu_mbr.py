@@ -118,11 +118,14 @@ MBE_CASES = [
 ]
 
 
+@pytest.mark.parametrize('split', [False, True], ids=['f32', 'split'])
 @pytest.mark.parametrize('case', MBE_CASES, ids=[str(i) for i in range(len(MBE_CASES))])
-def test_mbe(dev, case):
+def test_mbe(dev, case, split):
     from yoloret_amd import runtime as rt
-    from yoloret_amd.compiler import mbr_pack
+    from yoloret_amd.compiler import mbr_pack, mbs_pack
     h, w, cin, cexp, s, segs = case
+    if split and cin == 224:
+        pytest.skip('the split form is not built for 224 block inputs (compiler.MBS_MBE_CINS)')
     rng = np.random.default_rng(zlib.crc32(str(case).encode()))
     b = 2
     x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
@@ -132,13 +135,14 @@ def test_mbe(dev, case):
     sd, hd = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
     t = nn.relu6((nn.pointwise(x, we) * se + he).astype(np.float32))
     ref = nn.relu6((nn.depthwise(t, wd, s, 'same') * sd + hd).astype(np.float32))
-    wa, tab, _ = mbr_pack(we.T, se, he, wd.reshape(9, cexp), sd, hd, None, None, None)
+    wa, tab, _ = (mbs_pack(we.T, se, he, wd.reshape(9, cexp), sd, hd, None, None, None, 0) if split else
+                  mbr_pack(we.T, se, he, wd.reshape(9, cexp), sd, hd, None, None, None))
     keep = [torch.from_numpy(np.ascontiguousarray(a).ravel()).to(dev) for a in (wa, tab)]
     xd = to_dev(x, dev)
     ho, wo = ref.shape[1], ref.shape[2]
     op = rt.new_op(rt.OP_MBE, 'relu6')
     op.dtype = op.out_dtype = rt.dtype_id('f32')
-    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc = ho, wo, cin, cexp, 3 | segs << 16, s, 1
+    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc = ho, wo, cin, cexp, 3 | int(split) << 7 | segs << 16, s, 1
     op.src[0] = rt.make_src(xd, c=cin)
     op.wgt, op.wgt2 = [k.data_ptr() for k in keep]
     out = torch.full((b, ho, wo, cexp), float('nan'), dtype=torch.float32, device=dev)

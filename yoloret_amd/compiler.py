@@ -301,6 +301,7 @@ MBS_SHAPES = {
     (48, 288, 48, 1, True): 6, (48, 288, 72, 1, False): 6,
     (24, 144, 32, 2, False): 3, (32, 192, 32, 1, True): 4, (32, 192, 48, 2, False): 4,     # MobileNetV2 x1.4
 }
+MBS_MBE_CINS = (48, 72, 88, 120, 136)      # YR_OP_MBE's split form is built for these block input widths
 # float32 plans, blocks too wide for mbr.hip's one-workgroup form: expand + depthwise in one register-chained kernel (YR_OP_MBE),
 # the projection stays a pointwise op.  Block input widths built in mbr.hip (MBE_CASE).
 FUSE_MBE = os.environ.get('YOLORET_FUSE_MBE', '1') != '0'
@@ -770,13 +771,15 @@ def mbs_pack(we_t, e_scale, e_shift, dw, d_scale, d_shift, wp_t, p_scale, p_shif
     float32 words that hold them; wgt2 and b2 as mbr_pack."""
     _, tab, b2 = mbr_pack(we_t, e_scale, e_shift, dw, d_scale, d_shift, wp_t, p_scale, p_shift)
     cexp = dw.shape[1] // 16 * 16
+    if wp_t is None:     # YR_OP_MBE: the expand part only
+        wp_t, p_scale, nw = np.zeros((0, cexp), np.float32), np.zeros(0, np.float32), 0
     cout, cin = wp_t.shape[0], we_t.shape[1] // 8 * 8
     T, TO, NKE = cexp // 16, (cout + 15) // 16, (cin + 31) // 32
     wef = np.zeros((cexp, 32 * NKE), np.float32)
     wef[:, :cin] = (we_t[:cexp, :cin] * e_scale[:cexp, None]).astype(np.float32)
     wpf = np.zeros((16 * TO, cexp), np.float32)
     wpf[:cout] = (wp_t[:, :cexp] * p_scale[:cout, None]).astype(np.float32)
-    assert max(np.abs(wef).max(), np.abs(wpf).max()) < 60000.0, 'mbs_pack: a weight beyond the float16 range'
+    assert max(np.abs(wef).max(), np.abs(wpf).max() if wpf.size else 0.0) < 60000.0, 'mbs_pack: a weight beyond the float16 range'
 
     def planes(x):
         h = x.astype(np.float16)
@@ -790,7 +793,7 @@ def mbs_pack(we_t, e_scale, e_shift, dw, d_scale, d_shift, wp_t, p_scale, p_shif
         for c in range(NKE):
             v = wef[(16 * j + m_)[:, None], 32 * c + 8 * g[:, None] + i8[None, :]]
             ex[j, c, 0], ex[j, c, 1] = planes(v)
-    pairs = mbs_wave_pairs(T, nw)
+    pairs = mbs_wave_pairs(T, nw) if nw else []
     pr = np.zeros((len(pairs), TO, 2, 64, 8), np.float16)
     for q, (ta, tb) in enumerate(pairs):
         for t in range(TO):
@@ -1019,10 +1022,21 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                 and d.out.ld == round_up(d.cin, 4)):
             bi, cexp = exp.srcs[0], d.cin
             T, KE = cexp // 16, bi.c // 4
-            m = OpRec(rt.OP_MBE, exp.name.rsplit('_', 1)[0] + '_mbe', act='relu6', h=d.h, w=d.w, cin=bi.c, cout=cexp, k=3, stride=d.stride,
+            m = OpRec(rt.OP_MBE, exp.name.rsplit('_', 1)[0] + '_mbe', act='relu6', h=d.h, w=d.w, cin=bi.c, cout=cexp, k=3 | (0x80 if MBR_SPLIT and bi.c in MBS_MBE_CINS else 0), stride=d.stride,
                       srcs=[bi], out=d.out, macs=exp.macs + d.macs, dtype=0)
             m.fused = [exp, d]
             ep, dp = exp.params, d.params
+            if MBR_SPLIT and bi.c in MBS_MBE_CINS:
+                def packed_es(which, ep=ep, dp=dp):
+                    def f(wd):
+                        wa, tab, _ = mbs_pack(ep['wgt'][1](wd), ep['scale'][1](wd), ep['shift'][1](wd), dp['wgt'][1](wd).reshape(9, -1),
+                                              dp['scale'][1](wd), dp['shift'][1](wd), None, None, None, 0)
+                        return wa if which == 0 else tab
+                    return f
+                m.params = {'wgt': ((T * ((bi.c + 31) // 32) * 512,), packed_es(0)), 'wgt2': ((T, 11, 16), packed_es(1))}
+                out.append(m)
+                i = j + 1
+                continue
 
             def packed_e(which, ep=ep, dp=dp):
                 def f(wd):

@@ -521,9 +521,10 @@ struct MbeArgs {
     int H, W, Ho, Wo, ld_in, ld_out, pad_t, pad_l, strips, segs, seg_rows, T, groups, nwaves;
 };
 
-template <int CIN, int S, int NT, int MW>
+template <int CIN, int S, int NT, int MW, bool SP>
 __global__ __launch_bounds__(256, MW) void mbe_kernel(MbeArgs a) {
     constexpr int NMAIN = CIN / 16, TAIL = CIN % 16, KE = NMAIN * 4 + TAIL / 4, NOUT = 14 / S;
+    constexpr int NKE = (CIN + 31) / 32;   // SP (the split form, see mbs_split8): K = 32 steps of the expand conv
     static_assert(TAIL == 0 || TAIL == 8, "block input width must be 16 n or 16 n + 8");
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float tab[];
@@ -544,15 +545,22 @@ __global__ __launch_bounds__(256, MW) void mbe_kernel(MbeArgs a) {
     const int xo = NOUT * strip + (px - 1) / S;
     const bool out_lane = px >= 1 && px <= 14 && (px - 1) % S == 0 && xo < a.Wo;
 
-    float we[NT][KE];
+    float we[SP ? 1 : NT][SP ? 1 : KE];
+    mbs_u4 weh[SP ? NT : 1][NKE], wem[SP ? NT : 1][NKE];
     v4f se[NT];
     unsigned ooff[NT];   // byte offset of this lane's 4 channels of tile j within a pixel, or dead
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int t = min(t0 + j, a.T - 1);           // (a short last group recomputes the last tile; its stores are dead)
-        const float* p = a.wa + ((size_t)t * KE) * 64 + lane;
+        if constexpr (SP) {
+            const mbs_u4* pe = reinterpret_cast<const mbs_u4*>(a.wa) + ((size_t)t * NKE) * 2 * 64 + lane;
 #pragma unroll
-        for (int q = 0; q < KE; ++q) we[j][q] = p[q * 64];
+            for (int c = 0; c < NKE; ++c) { weh[j][c] = pe[(2 * c) * 64]; wem[j][c] = pe[(2 * c + 1) * 64]; }
+        } else {
+            const float* p = a.wa + ((size_t)t * KE) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < KE; ++q) we[j][q] = p[q * 64];
+        }
         se[j] = *reinterpret_cast<const v4f*>(a.wt + (size_t)t * MBR_TAB + 160 + 4 * mg);
         ooff[j] = (t0 + j < a.T && out_lane) ? (16u * (t0 + j) + 4u * mg) * 4u : MBR_DEAD;
     }
@@ -561,13 +569,26 @@ __global__ __launch_bounds__(256, MW) void mbe_kernel(MbeArgs a) {
     const int rbeg = S * yo0 - a.pad_t, nout = yo1 - yo0;
     const unsigned xoff = ((unsigned)xc * (unsigned)a.ld_in + 4u * mg) * 4u, xtoff = ((unsigned)xc * (unsigned)a.ld_in + 16u * NMAIN + 2u * mg) * 4u;
     const unsigned xrow = (unsigned)(a.W * a.ld_in) * 4u;
-    struct XRow { v4f m[NMAIN > 0 ? NMAIN : 1]; v2f t; };
+    struct XRow { v4f m[SP ? 2 * NKE : (NMAIN > 0 ? NMAIN : 1)]; v2f t; };
     XRow xa, xb;
+    unsigned xsoff[SP ? NKE : 1];   // SP: step c takes the lane's channels 32 c + 8 g .. + 7 (a group beyond the block input reads zeros)
+    if constexpr (SP) {
+#pragma unroll
+        for (int c = 0; c < NKE; ++c) xsoff[c] = 32 * c + 8 * mg < CIN ? ((unsigned)xc * (unsigned)a.ld_in + 32u * c + 8u * mg) * 4u : MBR_DEAD;
+    }
     auto load_row = [&](XRow& x, int r) {
         const unsigned so = (unsigned)min(max(r, 0), a.H - 1) * xrow;
+        if constexpr (SP) {
 #pragma unroll
-        for (int c = 0; c < NMAIN; ++c) x.m[c] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff + 64u * c, so, 0));
-        if constexpr (TAIL != 0) x.t = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(xsrc, xtoff, so, 0));
+            for (int c = 0; c < NKE; ++c) {
+                x.m[2 * c] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xsoff[c], so, 0));
+                x.m[2 * c + 1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xsoff[c] == MBR_DEAD ? MBR_DEAD : xsoff[c] + 16u, so, 0));
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NMAIN; ++c) x.m[c] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff + 64u * c, so, 0));
+            if constexpr (TAIL != 0) x.t = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(xsrc, xtoff, so, 0));
+        }
     };
     load_row(xa, rbeg);
     v4f ea[NT], eb[NT];
@@ -578,18 +599,38 @@ __global__ __launch_bounds__(256, MW) void mbe_kernel(MbeArgs a) {
         constexpr bool EMIT = decltype(emit_c)::value;
         const int r = rbeg + k;
         load_row(xn_, r + 1);
-        float xq[KE];
-#pragma unroll
-        for (int c = 0; c < NMAIN; ++c) { xq[4 * c] = xc_.m[c][0]; xq[4 * c + 1] = xc_.m[c][1]; xq[4 * c + 2] = xc_.m[c][2]; xq[4 * c + 3] = xc_.m[c][3]; }
-        if constexpr (TAIL != 0) { xq[4 * NMAIN] = xc_.t[0]; xq[4 * NMAIN + 1] = xc_.t[1]; }
         const float hr = (r >= 0 && r < a.H) ? hi : 0.f;
         v4f ec[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) ec[j] = se[j];
+        if constexpr (SP) {
+            v4f e1[NT];
 #pragma unroll
-        for (int q = 0; q < KE; ++q)
+            for (int j = 0; j < NT; ++j) e1[j] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < NT; ++j) ec[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(we[j][q], xq[q], ec[j], 0, 0, 0);
+            for (int c = 0; c < NKE; ++c) {
+                const float v[8] = {xc_.m[2 * c][0], xc_.m[2 * c][1], xc_.m[2 * c][2], xc_.m[2 * c][3], xc_.m[2 * c + 1][0], xc_.m[2 * c + 1][1], xc_.m[2 * c + 1][2], xc_.m[2 * c + 1][3]};
+                mbs_u4 xh, xm;
+                mbs_split8(v, xh, xm);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) ec[j] = mbs_mfma(weh[j][c], xh, ec[j]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) e1[j] = mbs_mfma(weh[j][c], xm, e1[j]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) e1[j] = mbs_mfma(wem[j][c], xh, e1[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ec[j] = e1[j] * 0.00048828125f + ec[j];
+        } else {
+            float xq[KE];
+#pragma unroll
+            for (int c = 0; c < NMAIN; ++c) { xq[4 * c] = xc_.m[c][0]; xq[4 * c + 1] = xc_.m[c][1]; xq[4 * c + 2] = xc_.m[c][2]; xq[4 * c + 3] = xc_.m[c][3]; }
+            if constexpr (TAIL != 0) { xq[4 * NMAIN] = xc_.t[0]; xq[4 * NMAIN + 1] = xc_.t[1]; }
+#pragma unroll
+            for (int q = 0; q < KE; ++q)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) ec[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(we[j][q], xq[q], ec[j], 0, 0, 0);
+        }
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -631,11 +672,11 @@ __global__ __launch_bounds__(256, MW) void mbe_kernel(MbeArgs a) {
     }
 }
 
-template <int CIN, int S, int NT>
+template <int CIN, int S, int NT, bool SP = false>
 static int launch_mbe(const MbeArgs& a0, int batch, int want_segs, hipStream_t s) {
     MbeArgs a = a0;
-    constexpr int NOUT = 14 / S, KE = CIN / 4;
-    constexpr int EST = NT * (KE + 16) + 2 * KE + 44;      // registers a wave holds (stationary fragments, ring, two rows of pixels, ~44 others)
+    constexpr int NOUT = 14 / S, KE = SP ? 8 * ((CIN + 31) / 32) : CIN / 4;
+    constexpr int EST = NT * (KE + 16 + (SP ? 4 : 0)) + 2 * KE + (SP ? 8 : 0) + 44;      // registers a wave holds (stationary fragments, ring, two rows of pixels, ~44 others)
     constexpr int MW = EST <= 150 ? 3 : EST <= 250 ? 2 : 1;
     a.strips = (a.Wo + NOUT - 1) / NOUT;
     a.groups = (a.T + NT - 1) / NT;
@@ -651,10 +692,10 @@ static int launch_mbe(const MbeArgs& a0, int batch, int want_segs, hipStream_t s
     const size_t lds = (size_t)a.T * MBR_TAB * 4;
     YR_REQUIRE(lds <= 64 * 1024, "mbe: %d expanded channels exceed the depthwise table's LDS budget", a.T * 16);
     static char nm[48];
-    static const int nm_len = snprintf(nm, sizeof(nm), "mbe_kernel<%d,%d,%d,%d>", CIN, S, NT, MW);
+    static const int nm_len = snprintf(nm, sizeof(nm), SP ? "mbes_kernel<%d,%d,%d,%d>" : "mbe_kernel<%d,%d,%d,%d>", CIN, S, NT, MW);   // (mbes: the symbol is mbe_kernel<..., true>)
     (void)nm_len;
     yr_note_kernel(nm);
-    auto kern = mbe_kernel<CIN, S, NT, MW>;
+    auto kern = mbe_kernel<CIN, S, NT, MW, SP>;
     static bool attr_set = false;
     if (!attr_set) {
         YR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -672,7 +713,7 @@ int yr_launch_mbe(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(op.dtype == YR_F32 && op.out_dtype == YR_F32, "mbe: float32 plans only");
     YR_REQUIRE(op.nsrc == 1 && op.src[0].xform == YR_X_IDENTITY && op.src[0].dtype == YR_F32, "mbe: needs one float32 identity source");
     const yr_src& in = op.src[0];
-    YR_REQUIRE((op.k & 0xff) == 3 && (op.stride == 1 || op.stride == 2) && op.act == YR_ACT_RELU6, "mbe: 3x3, stride 1|2, ReLU6");
+    YR_REQUIRE((op.k & 0x7f) == 3 && (op.stride == 1 || op.stride == 2) && op.act == YR_ACT_RELU6, "mbe: 3x3, stride 1|2, ReLU6");
     YR_REQUIRE(in.ptr && op.out && op.wgt && op.wgt2 && op.res == nullptr, "mbe: null pointer (or a residual)");
     YR_REQUIRE(in.ld % 4 == 0 && op.out_ld % 4 == 0 && in.c == op.cin && in.ld >= in.c && op.out_ld >= op.cout && op.cout % 16 == 0, "mbe: channel strides / widths");
     YR_REQUIRE(((uintptr_t)in.ptr) % 16 == 0 && ((uintptr_t)op.out) % 16 == 0, "mbe: pointers must be 16-byte aligned");
@@ -685,15 +726,18 @@ int yr_launch_mbe(const yr_op& op, int batch, hipStream_t s) {
     a.pad_t = (pth > 0 ? pth : 0) / 2; a.pad_l = (ptw > 0 ? ptw : 0) / 2;
     a.strips = a.segs = a.seg_rows = a.groups = a.nwaves = 0;
     const int segs = (op.k >> 16) & 0xff;
-#define MBE_CASE(CIN, NT)                                                                     \
+    // k bit 7: the SPLIT form - wgt holds the float16 planes [T][NKE][2][64 lanes][8 halves] of YR_OP_MBR's split form (expand part)
+    // (NTS: tiles per wave of the split form - its two rows of pixel operands are 16 registers per K = 32 step)
+#define MBE_CASE(CIN, NT, NTS)                                                                \
+    if (in.c == CIN && (op.k & 0x80)) return op.stride == 1 ? launch_mbe<CIN, 1, NTS, true>(a, batch, segs, s) : launch_mbe<CIN, 2, NTS, true>(a, batch, segs, s); \
     if (in.c == CIN) return op.stride == 1 ? launch_mbe<CIN, 1, NT>(a, batch, segs, s) : launch_mbe<CIN, 2, NT>(a, batch, segs, s);
-    MBE_CASE(48, 3)
-    MBE_CASE(72, 3)      // MobileNetV2 x0.75 block_11..13
-    MBE_CASE(88, 2)      // x1.4 block_7..10
-    MBE_CASE(120, 2)     // x0.75 block_14, 15
-    MBE_CASE(136, 2)     // x1.4 block_11..13
-    MBE_CASE(224, 1)     // x1.4 block_14, 15
+    MBE_CASE(48, 3, 3)
+    MBE_CASE(72, 3, 2)      // MobileNetV2 x0.75 block_11..13
+    MBE_CASE(88, 2, 2)      // x1.4 block_7..10
+    MBE_CASE(120, 2, 2)     // x0.75 block_14, 15
+    MBE_CASE(136, 2, 1)     // x1.4 block_11..13
 #undef MBE_CASE
+    if (in.c == 224 && !(op.k & 0x80)) return op.stride == 1 ? launch_mbe<224, 1, 1>(a, batch, segs, s) : launch_mbe<224, 2, 1>(a, batch, segs, s);   // x1.4 block_14, 15
     yr_set_error("mbe: block input width %d is not built", in.c);
     return YR_ERR_ARG;
 }

@@ -203,6 +203,7 @@ static int64_t param_floats(const yr_op& op, int role) {   // role: 0 wgt, 1 sca
         }
         case YR_OP_MBE: {
             const int64_t t = op.cout / 16, ke = op.cin / 4;
+            if (role == 0 && (op.k & 0x80)) return t * ((op.cin + 31) / 32) * 2 * 64 * 4;   // the split form: float16 planes
             if (role == 0) return t * ke * 64;
             if (role == 3) return t * 176;
             return 0;

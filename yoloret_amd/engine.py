@@ -261,7 +261,7 @@ class Model:
         for i, op in enumerate(plan.ops):
             # which pipe the multiply-adds run on: the 1x1 convolutions of a 16-bit plan on bf16 / f16 MFMA (also inside the
             # fused block kernels mbh / mbx, whose depthwise stage stays on packed float32 FMAs); everything else float32
-            m16 = 0
+            m16, m32 = 0, None      # (m32: multiply-adds on the float32 pipe where that is not macs - m16)
             if op.dtype != 0:
                 if op.kind == rt.OP_POINTWISE:
                     m16 = op.macs
@@ -269,10 +269,13 @@ class Model:
                     kk = (op.k & 0xff) ** 2
                     cexp = op.se_reduced if op.kind == rt.OP_MBH else op.cout
                     m16 = max(op.macs - op.h * op.w * kk * cexp, 0)
-            elif op.kind == rt.OP_MBR and op.k & 0x80:   # the split form: both 1x1 convolutions on the 16-bit pipe (three float16 products each)
-                m16 = max(op.macs - op.h * op.w * 9 * op.se_reduced, 0)
+            elif op.kind in (rt.OP_MBE, rt.OP_MBR) and op.k & 0x80:
+                # the split form: the 1x1 convolutions run on the 16-bit pipe as THREE float16 products per multiply-add (what that
+                # pipe executes), the depthwise stage on the float32 pipe
+                m32 = op.h * op.w * 9 * (op.cout if op.kind == rt.OP_MBE else op.se_reduced)
+                m16 = 3 * max(op.macs - m32, 0)
             out.append(dict(name=op.name, kind=rt.OP_NAMES[op.kind], kernel=(names[i] or b'').decode(),
-                            ms=float(ms[i]), macs=op.macs * b, macs_mfma16=m16 * b, bytes=per_op_bytes[i] * b, hbm_bytes=per_op_hbm[i] * b))
+                            ms=float(ms[i]), macs=op.macs * b, macs_mfma16=m16 * b, macs_fp32=(op.macs - m16 if m32 is None else m32) * b, bytes=per_op_bytes[i] * b, hbm_bytes=per_op_hbm[i] * b))
         return out
 
     def __del__(self):
