@@ -253,6 +253,13 @@ int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
         const int shape = (op.k >= 1 && op.k <= NLDS) ? op.k - 1 : -1;
         return yr_pw_launch_lds(shape, a, s);
     }
+    // The SPLIT form (pointwise_split.hip): every float32 conv with at least one K = 32 step and no depthwise-folded source - by
+    // the op's SHAPE, never by the tuner or the batch (the two forms round differently: a batch must equal its images run one
+    // by one).  The tuner's index picks the tile shape (the direct kernels' indices map onto the LDS shapes).  YOLORET_PW_SPLIT=0:
+    // the float32-MFMA kernels.
+    static const bool split_on = !(getenv("YOLORET_PW_SPLIT") && atoi(getenv("YOLORET_PW_SPLIT")) == 0);
+    const bool split = split_on && a.S.kp >= 32;
+    if (split && op.k >= 1 && op.k <= NCFG) return yr_pw_launch_split((op.k - 1) % NLDS, a, s);
     if (op.k >= 1 && op.k <= NCFG) return cfgs[op.k - 1].fn(a, s);
     // tuning override: YR_PW_CFG="BMxBN" forces one tile shape for every layer (experiments only)
     static const char* force = getenv("YR_PW_CFG");
@@ -277,6 +284,7 @@ int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
     double bc = cost(cfgs[0]);
     for (int i = 1; i < NLDS; ++i)
         if (cost(cfgs[i]) < bc) { bc = cost(cfgs[i]); best = &cfgs[i]; }
+    if (split) return yr_pw_launch_split((int)(best - cfgs), a, s);
     return best->fn(a, s);
 }
 

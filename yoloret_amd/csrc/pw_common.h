@@ -315,6 +315,8 @@ __device__ __forceinline__ float4 pw_finish(float4 v, const float4& gt, int cval
 // LDS-staged kernel, tile shape index 0..13: (BM x BN) = 256x16, 128x32, 128x48, 128x64, 128x80, 128x96, 128x128,
 // 64x16, 64x32, 64x48, 64x64, 64x80, 64x96, 64x128
 int yr_pw_launch_lds(int shape, const PwArgs& a, hipStream_t s);
+// the same tile shapes on the 16-bit matrix pipe with float32-grade operands (pointwise_split.hip: two float16 planes per operand)
+int yr_pw_launch_split(int shape, const PwArgs& a, hipStream_t s);
 // 16-bit kernel (pointwise_h.hip): cfg = tile shape index 0..yr_pwh_num_cfgs()-1, or -1 for its heuristic
 int yr_pw_launch_h(int dtype, int cfg, const PwArgs& a, hipStream_t s);
 int yr_pwh_num_cfgs();
