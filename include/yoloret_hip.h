@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define YR_ABI_VERSION 5   /* 5: op kinds MBR / MBE (float32 blocks on the matrix pipe, register-chained), MBCONV removed; 4: YR_U8 images (uint8 network entry); 3: op kind MBX, pair-packed STEM weights, BN scale folded into the packed taps of STEMBLOCK / MBLANE */
+#define YR_ABI_VERSION 6   /* 6: split forms - k bit 7 of MBR / MBE (float16-plane fragments), se_reduced bit 16 of a float32 POINTWISE op (= keep the float32 MFMA); float32 POINTWISE ops at least 16 channels deep otherwise run on the 16-bit matrix pipe with two float16 planes per operand (pointwise_split.hip; same results to float32 rounding, |x|, |w| < 65504); 5: op kinds MBR / MBE (float32 blocks on the matrix pipe, register-chained), MBCONV removed; 4: YR_U8 images (uint8 network entry); 3: op kind MBX, pair-packed STEM weights, BN scale folded into the packed taps of STEMBLOCK / MBLANE */
 #define YR_MAX_SRC 4
 
 typedef enum {
@@ -156,14 +156,22 @@ typedef enum {
                                    rho = KE + 4 t + s: Wp[16 t + m][16 j + 4 g + s] x project BN scale (0 for 16 t + m >= cout);
                             wgt2 = [T][11][16]: the nine depthwise taps (ky, kx) x depthwise BN scale | depthwise BN shift | expand BN shift;
                             b2   = project BN shift [16 TO].
-                            Built for the MobileNetV2 x0.75 / x1.4 blocks (mbr.hip: MBR_CASE list); other shapes: YR_ERR_ARG */
+                            k bit 7 (0x80) = the SPLIT form (ABI 6): both 1x1 convolutions on the 16-bit matrix pipe with float32-grade operands -
+                            every float32 value as two float16 planes, x = h + 2^-11 m, three MFMAs per product (mbr.hip "SPLIT form") -; then
+                            wgt  = the float32 words holding [T][ceil(cin / 32)][2 planes][64 lanes][8 halves] (lane (m, g), step c:
+                                   We[16 j + m][32 c + 8 g + i] x BN scale, zero beyond cin) followed by, per expanded-tile pair (tA, tB) of the nw
+                                   waves in order (a wave pairs ITS tiles, an odd last one with nothing), [TO][2 planes][64][8]:
+                                   Wp[16 t + m][16 tA + 4 g + i] (i < 4) | Wp[16 t + m][16 tB + 4 g + i - 4]; nw must be what the fragments were
+                                   packed for (yoloret_amd.compiler.mbs_pack).  Precondition: |block input| < 65504 (else NaN).
+                            Built for the MobileNetV2 x0.75 / x1.4 blocks (mbr.hip: MBR_CASE / MBS_CASE lists); other shapes: YR_ERR_ARG */
     YR_OP_MBE = 14,      /* the first two thirds of the MBCONV block in float32 - expand 1x1 + BN + ReLU6 -> depthwise 3x3 (stride 1 | 2) +
                             BN + ReLU6 - in YR_OP_MBR's register-chained form (mbr.hip: mbe_kernel), for blocks whose weights do not fit
                             one CU's register file (MobileNetV2 x0.75 block_11 on): every wave walks a strip segment for a few expanded
                             tiles and stores the depthwise map; the expand output never exists, the projection stays a POINTWISE op.
                             src[0] = block input (cin % 16 in {0, 8}); cout = Cexp (multiple of 16); k = 3 | segs << 16; act = RELU6;
                             wgt = expand A fragments [T][KE][64] (YR_OP_MBR's register order, rho < KE); wgt2 = [T][11][16] as YR_OP_MBR.
-                            Built for cin in {48, 72, 88, 120, 136, 224} */
+                            k bit 7 = the split form (see YR_OP_MBR): wgt = the float32 words holding [T][ceil(cin / 32)][2 planes][64][8 halves].
+                            Built for cin in {48, 72, 88, 120, 136, 224} (the split form: all but 224) */
     YR_OP_MBX = 12       /* the first two thirds of an MBConv block WITH squeeze-excite (efficientnet.py:406-536), 16-bit
                             activations: expand 1x1 + BN + act (bf16 / f16 MFMA) -> depthwise K = 3 | 5, stride 1 | 2 + BN +
                             act, the expanded input of the depthwise conv staying in LDS; the depthwise map is stored and

@@ -168,8 +168,13 @@ def test_depthwise_folded_into_project_is_bit_identical(dev, name, size):
         m.set_weights(synthetic_weights(m, 7, 'conditioned'))
         x = torch.from_numpy(synthetic_images(3, size, size)).to(dev)
         outs[fold] = [y.cpu().numpy() for y in m(x)]
-    for a, b in zip(outs[False], outs[True]):
-        assert np.array_equal(a, b)
+    import os
+    split = os.environ.get('YOLORET_PW_SPLIT', '1') != '0'   # (round 4: the unfolded projections run in the split form - float16 planes on
+    for a, b in zip(outs[False], outs[True]):                #  the 16-bit matrix pipe -, the folded ones keep the float32 MFMA: same values,
+        if split:                                            #  other roundings; YOLORET_PW_SPLIT=0 restores the bit-for-bit comparison)
+            assert_close(a, b, 2e-5, 'dw3-folded plan vs unfolded plan')
+        else:
+            assert np.array_equal(a, b)
 
 
 def test_compiler_folds_head_projections_into_their_1x1_consumers(dev):

@@ -1392,6 +1392,13 @@ class Compiler:
             fold = FOLD_DW if isinstance(FOLD_DW, str) else ('1' if FOLD_DW else '0')   # (tests assign booleans)
             if fold != '0' and not latency and self.dtype == 0:
                 ops = fold_depthwise_into_project(ops, set(b.id for b in outs), 0 if fold == '1' else FOLD_DW_MIN_PIXELS)
+            if latency and self.dtype == 0:
+                # the plan for a few images keeps the float32-MFMA pointwise kernels: at 169 ... 2704 pixels per map a conv waits for
+                # its round trips, not for the matrix pipe, and the split form's plane-cutting stage is pure overhead there
+                # (batch 1 @416: p50 0.64 ms against 0.68).  se_reduced bit 16 of a POINTWISE op = "not the split form".
+                for o in ops:
+                    if o.kind == rt.OP_POINTWISE and not any(s_.xform == 'dw3' for s_ in o.srcs):
+                        o.se_reduced |= 0x10000
         plan = Plan(ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape, self.dtype)
         plan.layer_seq = dict(self.layer_seq)
         return plan

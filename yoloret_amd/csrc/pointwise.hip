@@ -253,12 +253,12 @@ int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
         const int shape = (op.k >= 1 && op.k <= NLDS) ? op.k - 1 : -1;
         return yr_pw_launch_lds(shape, a, s);
     }
-    // The SPLIT form (pointwise_split.hip): every float32 conv with at least one K = 32 step and no depthwise-folded source - by
+    // The SPLIT form (pointwise_split.hip): every float32 conv at least 16 channels deep without a depthwise-folded source - by
     // the op's SHAPE, never by the tuner or the batch (the two forms round differently: a batch must equal its images run one
     // by one).  The tuner's index picks the tile shape (the direct kernels' indices map onto the LDS shapes).  YOLORET_PW_SPLIT=0:
     // the float32-MFMA kernels.
     static const bool split_on = !(getenv("YOLORET_PW_SPLIT") && atoi(getenv("YOLORET_PW_SPLIT")) == 0);
-    const bool split = split_on && a.S.kp >= 32;
+    const bool split = split_on && a.S.kp >= 16 && !(op.se_reduced & 0x10000);   // (bit 16 of se_reduced: the plan asks for the float32 MFMA - its few-image form)   // (a 16- or 24-deep conv pads its one step with zeros: the MFMAs are not what it waits for)
     if (split && op.k >= 1 && op.k <= NCFG) return yr_pw_launch_split((op.k - 1) % NLDS, a, s);
     if (op.k >= 1 && op.k <= NCFG) return cfgs[op.k - 1].fn(a, s);
     // tuning override: YR_PW_CFG="BMxBN" forces one tile shape for every layer (experiments only)
