@@ -455,7 +455,7 @@ __device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const i
     }
 }
 
-template <int CIN, int CEXP, int COUT, int S, int NW, bool RES, int MW, bool SP>
+template <int CIN, int CEXP, int COUT, int S, int NW, bool RES, bool SP, int MW>
 __global__ __launch_bounds__(64 * NW, MW) void mbr_kernel(MbrArgs a) {
     constexpr int T = CEXP / 16, NTL = T / NW, R = T % NW, NTH = NTL + (R ? 1 : 0);
     static_assert(NTL >= 1, "more waves than expanded tiles");
@@ -484,8 +484,7 @@ static int launch_mbr(const MbrArgs& a0, int batch, int want_segs, hipStream_t s
     a.segs = (a.Ho + a.seg_rows - 1) / a.seg_rows;
     const size_t lds = (size_t)T * MBR_TAB * 4 + (NW > 1 ? (size_t)2 * NW * TO * 64 * 16 : 0);
     static char nm[64];
-    static const int nm_len = SP ? snprintf(nm, sizeof(nm), "mbs_kernel<%d,%d,%d,%d,%d,%d>", CIN, CEXP, COUT, S, NW, (int)RES)   // (the symbol is mbr_kernel<..., true>)
-                                 : snprintf(nm, sizeof(nm), "mbr_kernel<%d,%d,%d,%d,%d,%d>", CIN, CEXP, COUT, S, NW, (int)RES);
+    static const int nm_len = snprintf(nm, sizeof(nm), "mbr_kernel<%d,%d,%d,%d,%d,%d,%d>", CIN, CEXP, COUT, S, NW, (int)RES, (int)SP);   // (... SP = 1: the split form)
     (void)nm_len;
     yr_note_kernel(nm);
     // waves per SIMD the register allocator must leave room for, from an estimate of what a wave holds: the stationary
@@ -497,7 +496,7 @@ static int launch_mbr(const MbrArgs& a0, int batch, int want_segs, hipStream_t s
     // (SP: measured register counts - the stride-1 three-wave kernels fit 168, the others spill there)
     constexpr int MW = SP ? (S == 1 && NW <= 3 ? 3 : 2) : EST <= 164 ? 3 : EST <= 250 ? 2 : 1;
     static_assert(NW <= 4 * MW, "a workgroup's waves must fit one CU at this register budget");
-    auto kern = mbr_kernel<CIN, CEXP, COUT, S, NW, RES, MW, SP>;   // waves per SIMD the register allocator must leave room for
+    auto kern = mbr_kernel<CIN, CEXP, COUT, S, NW, RES, SP, MW>;   // waves per SIMD the register allocator must leave room for
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         YR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -692,7 +691,7 @@ static int launch_mbe(const MbeArgs& a0, int batch, int want_segs, hipStream_t s
     const size_t lds = (size_t)a.T * MBR_TAB * 4;
     YR_REQUIRE(lds <= 64 * 1024, "mbe: %d expanded channels exceed the depthwise table's LDS budget", a.T * 16);
     static char nm[48];
-    static const int nm_len = snprintf(nm, sizeof(nm), SP ? "mbes_kernel<%d,%d,%d,%d>" : "mbe_kernel<%d,%d,%d,%d>", CIN, S, NT, MW);   // (mbes: the symbol is mbe_kernel<..., true>)
+    static const int nm_len = snprintf(nm, sizeof(nm), "mbe_kernel<%d,%d,%d,%d,%d>", CIN, S, NT, MW, (int)SP);   // (... SP = 1: the split form)
     (void)nm_len;
     yr_note_kernel(nm);
     auto kern = mbe_kernel<CIN, S, NT, MW, SP>;
