@@ -162,7 +162,7 @@ typedef enum {
                                    We[16 j + m][32 c + 8 g + i] x BN scale, zero beyond cin) followed by, per expanded-tile pair (tA, tB) of the nw
                                    waves in order (a wave pairs ITS tiles, an odd last one with nothing), [TO][2 planes][64][8]:
                                    Wp[16 t + m][16 tA + 4 g + i] (i < 4) | Wp[16 t + m][16 tB + 4 g + i - 4]; nw must be what the fragments were
-                                   packed for (yoloret_amd.compiler.mbs_pack).  Precondition: |block input| < 65504 (else NaN).
+                                   packed for (yoloret_amd.compiler.mbs_pack).  Precondition: |block input| < 65504 (undefined beyond: NaN or a ReLU6-clamped value).
                             Built for the MobileNetV2 x0.75 / x1.4 blocks (mbr.hip: MBR_CASE / MBS_CASE lists); other shapes: YR_ERR_ARG */
     YR_OP_MBE = 14,      /* the first two thirds of the MBCONV block in float32 - expand 1x1 + BN + ReLU6 -> depthwise 3x3 (stride 1 | 2) +
                             BN + ReLU6 - in YR_OP_MBR's register-chained form (mbr.hip: mbe_kernel), for blocks whose weights do not fit

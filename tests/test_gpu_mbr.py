@@ -81,6 +81,7 @@ def test_mbr(dev, case):
 MBS_CASES = [
     # the SPLIT form (k bit 7): both 1x1 convolutions on the 16-bit matrix pipe, float32 operands as two float16 planes each
     (16, 16, 16, 96, 24, 2, False, 3, 0),
+    (104, 104, 16, 96, 24, 2, False, 2, 0),    # block_1 as shipped: two waves (three tiles each: one full pair + an odd tile)
     (31, 45, 16, 96, 24, 2, False, 3, 3),      # odd sizes, ragged strips and segments
     (13, 13, 24, 144, 24, 1, True, 3, 0),      # block_2 (+add)
     (52, 40, 24, 144, 24, 1, True, 3, 2),

@@ -373,3 +373,26 @@ def test_round3_plan_choices_of_the_16bit_configurations():
     assert len(k5) == 2 and all(o.h == 80 and o.se_reduced == 288 for o in k5)
     first_s2 = next(o for o in p5.ops if o.kind == rt.OP_MBH and o.stride == 2)
     assert first_s2.cin == 24 and first_s2.se_reduced == 144 and first_s2.cout == 32            # mbn_h.hip's two-pass shape
+
+
+def test_split_form_refuses_weights_beyond_the_float16_range():
+    """The split forms cut every float32 operand into two float16 planes: folded weights must stay below 65504 (compiler.mbs_pack
+    refuses them at plan-build time - activations cannot be checked there: INTEGRATION.md numerics note (v))."""
+    import pytest
+    from yoloret_amd.compiler import mbs_pack, mbs_wave_pairs
+    rng = np.random.default_rng(0)
+    cin, cexp, cout = 24, 144, 24
+    we = rng.standard_normal((cexp, cin)).astype(np.float32)
+    dw = rng.standard_normal((9, cexp)).astype(np.float32)
+    wp = rng.standard_normal((cout, cexp)).astype(np.float32)
+    one = lambda n: np.ones(n, np.float32)
+    wa, tab, b2 = mbs_pack(we, one(cexp), one(cexp), dw, one(cexp), one(cexp), wp, one(cout), one(cout), 3)
+    assert wa.dtype == np.float32 and wa.size == (9 * 1 + len(mbs_wave_pairs(9, 3)) * 2) * 512 and tab.shape == (9, 11, 16) and b2.shape == (32,)
+    planes = wa.view(np.float16).reshape(-1, 2, 64, 8).astype(np.float64)
+    # expand tile 0, lane 0 (m = 0, g = 0): h + 2^-11 m reproduces the weight to 22 bits
+    got = planes[0, 0, 0, :] + planes[0, 1, 0, :] / 2048.0
+    assert np.abs(got - we[0, :8]).max() <= 2.0 ** -21 * np.abs(we[0, :8]).max()
+    big = one(cexp).copy()
+    big[3] = 7.0e4
+    with pytest.raises(AssertionError):
+        mbs_pack(we, big, one(cexp), dw, one(cexp), one(cexp), wp, one(cout), one(cout), 3)

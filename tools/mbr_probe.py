@@ -22,6 +22,7 @@ BLOCKS = {   # name: (h, w, cin, cexp, cout, stride, residual), r03 time of the 
     'block_10': ((26, 26, 48, 288, 72, 1, False), 0.0850),
 }
 BATCH = {}
+SPLIT = os.environ.get('MBR_PROBE_SPLIT', '0') != '0'    # the split form (float16 planes on the 16-bit matrix pipe): nw 3 / 6 only
 NWS = {'block_1': [2, 3], 'block_2': [3], 'block_3': [3], 'block_4': [3], 'block_6': [3], 'block_7': [6, 8], 'block_10': [6, 8]}
 
 
@@ -46,11 +47,11 @@ def main():
         shape, old = BLOCKS[name]
         h, w, cin, cexp, cout, s, res = shape
         macs = b * ((h * w * cin * cexp) + ((h + s - 1) // s) * ((w + s - 1) // s) * (9 * cexp + cexp * cout))
-        for nw in NWS[name]:
+        for nw in (([int(v) for v in os.environ['MBR_PROBE_NW'].split(',')] if os.environ.get('MBR_PROBE_NW') else [3 if shape[3] <= 144 else 6]) if SPLIT else NWS[name]):
             for segs in ([0] if os.environ.get('MBR_PROBE_ONE') else [0, 1, 2, 4, 8, 13, 26]):
                 if segs > (h + s - 1) // s:
                     continue
-                op, out, params, keep = make_block(shape + (nw, segs), dev, b=b, seed=1)
+                op, out, params, keep = make_block(shape + (nw, segs), dev, b=b, seed=1, split=SPLIT)
                 ms = timed(op, b)
                 print('%-9s nw %d segs %2d  %.4f ms  %6.1f TF  (shipped %.4f ms)' % (name, nw, segs, ms, 2 * macs / ms * 1e-9, old), flush=True)
                 del op, out, params, keep

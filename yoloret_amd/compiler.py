@@ -144,6 +144,9 @@ class Plan:
             arr = np.asarray(op.params[role][1](weights), np.float32)
             assert tuple(arr.shape) == tuple(shape), (op.name, role, arr.shape, shape)
             if dt == 0:
+                if op.kind == rt.OP_POINTWISE and role == 'wgt' and op.dtype == 0 and PW_SPLIT and arr.size and float(np.abs(arr).max()) >= 60000.0:
+                    raise ValueError('%s: a weight of %.3g is beyond the float16 range the split pointwise form needs (YOLORET_PW_SPLIT=0 '
+                                     'runs the float32-MFMA kernels)' % (op.name, float(np.abs(arr).max())))
                 blob[off:off + arr.size] = arr.ravel()
             else:
                 bits = rt.to_bits16(arr.ravel(), dt)
@@ -296,8 +299,9 @@ MBR_SHAPES = {
 # shares the FMA lanes with the depthwise stage, the 16-bit pipe does not.  (cin, cexp, cout, stride, residual) -> waves per
 # workgroup the fragments are packed for.  YOLORET_MBR_SPLIT=0 keeps the float32-MFMA form.
 MBR_SPLIT = os.environ.get('YOLORET_MBR_SPLIT', '1') != '0'
+PW_SPLIT = os.environ.get('YOLORET_PW_SPLIT', '1') != '0'     # (read by the library; here only for the weight-range check of build_blob)
 MBS_SHAPES = {
-    (16, 96, 24, 2, False): 3, (24, 144, 24, 1, True): 3, (24, 144, 24, 2, False): 3, (24, 144, 48, 2, False): 3,
+    (16, 96, 24, 2, False): 2, (24, 144, 24, 1, True): 3, (24, 144, 24, 2, False): 3, (24, 144, 48, 2, False): 3,
     (48, 288, 48, 1, True): 6, (48, 288, 72, 1, False): 6,
     (24, 144, 32, 2, False): 3, (32, 192, 32, 1, True): 4, (32, 192, 48, 2, False): 4,     # MobileNetV2 x1.4
 }

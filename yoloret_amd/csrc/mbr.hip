@@ -117,7 +117,8 @@ __device__ __forceinline__ mbr_rsrc mbr_make_rsrc(const void* base, unsigned byt
 // below), and a product needs three MFMAs - h h' into one accumulator, h m' + m h' into a second that joins with 2^-11 at the
 // end (the dropped m m' term is below 2^-24 of |x| |w|).  The weights' planes are cut by the host (compiler.mbs_pack), the
 // pixels' and the depthwise results' in registers (5 VALU operations per pair of values).  Precondition: |x| < 65504 for the
-// block input (a float16 plane has no more range; beyond it the result is NaN, not a wrong number); the depthwise
+// block input (a float16 plane has no more range; beyond it the result is undefined - the planes become inf, the sums NaN, and the
+// ReLU6 behind the expand conv turns that into 0 or 6); the depthwise
 // results are ReLU6'd.  One K = 32 step takes 8 channels per lane: the block input's channels 32 c + 8 g .. + 7, and for the
 // projection the four channels of expanded tile 2 q and the four of tile 2 q + 1 a lane holds after the depthwise stage.
 typedef _Float16 mbs_h2 __attribute__((ext_vector_type(2)));
@@ -778,6 +779,7 @@ int yr_launch_mbr(const yr_op& op, int batch, hipStream_t s) {
     if (in.c == CIN && op.se_reduced == CEXP && op.cout == COUT && op.stride == S && res == RES && nw == NW) \
         return launch_mbr<CIN, CEXP, COUT, S, NW, RES, true>(a, batch, (op.k >> 16) & 0xff, s);
         MBS_CASE(16, 96, 24, 2, 3, false)
+        MBS_CASE(16, 96, 24, 2, 2, false)     // (block_1 @208: 0.188 ms against 0.195-0.204 with three waves - one partner less at the row barrier)
         MBS_CASE(24, 144, 24, 1, 3, true)
         MBS_CASE(24, 144, 24, 2, 3, false)
         MBS_CASE(24, 144, 48, 2, 3, false)

@@ -7,7 +7,7 @@
 // error as the float32-MFMA kernel's.  The planes are cut ONCE per element, on the way from the fetch registers into LDS
 // (5 VALU operations per pair of values; weights too - their matrix stays float32 in the plan), so everything in front of the
 // LDS store - gathers, concat, up-sampling, pooling, SE gate - is pw_kernel's code, and the epilogue is too.
-// Precondition: |x|, |w| < 65504 (beyond it the result is NaN / inf, not a wrong number).
+// Precondition: |x|, |w| < 65504 (beyond it the planes are inf and the result NaN / inf - or, behind a ReLU6 epilogue, a clamped value).
 // A 32-wide k chunk per barrier pair (one MFMA step); tile shapes and index as pw_kernel's.
 #include <type_traits>
 
