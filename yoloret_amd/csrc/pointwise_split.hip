@@ -14,6 +14,9 @@
 #include "pw_common.h"
 
 #define PWS_BK 32
+#ifndef PWS_PF2_MAX_TILES
+#define PWS_PF2_MAX_TILES 4      // tiles (PT * CT) per wave up to which TWO k chunks are prefetched (8: the second register set costs a wave per SIMD - pointwise family 0.81 -> 0.89 ms on c2)
+#endif
 #define PWS_KQ (PWS_BK / 4)        // float4 quads per staged row
 #define PWS_RPP (256 / PWS_KQ)     // rows loaded per pass of the 256 threads
 #define PWS_LD (PWS_BK + 8)        // halves per LDS row: 80 bytes, an odd number of 16-byte slots
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256, pws_min_blocks(PT, CT)) void pws_kernel(PwArgs
         // barrier.  With DEPTH 2 two chunks of global loads are in flight per wave; the loop body is two steps on
         // alternating register sets and every fetch is unconditional, so the compiler counts the outstanding loads
         // exactly and a step waits only for ITS set.  A dead step (odd chunk count) stages zeros and skips the MFMAs.
-        constexpr int DEPTH = PT * CT <= 4 ? 2 : 1;
+        constexpr int DEPTH = PT * CT <= PWS_PF2_MAX_TILES ? 2 : 1;   // (two register sets of fetched chunks in flight)
         auto step = [&](int k0, Regs& R, bool live) __attribute__((always_inline)) {
             pw_unroll<A_PASSES>([&](auto P) __attribute__((always_inline)) {
                 constexpr int p = decltype(P)::value;
