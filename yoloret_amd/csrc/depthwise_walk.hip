@@ -1,15 +1,16 @@
 // Depthwise K x K (K = 5 | 3) stride-1 convolution on 16-bit maps, WALKING form (round 4): the successor of depthwise_lds.hip's
-// tile walk for the wide EfficientNet stages (efficientnet.py:501-510, kernel_size 5, more than 128 block inputs) and the
-// detection heads' MBConv depthwise stages (code/yolo3/model.py:98-114).  Same arithmetic as dw_kernel<K,1,..> and dwp_kernel -
+// tile walk for the wide EfficientNet stages (efficientnet.py:501-510, kernel_size 5, more than 128 block inputs).  The plans take
+// it for the 5 x 5 maps; the 3 x 3 maps of the detection heads (code/yolo3/model.py:98-114) stay on the tile walk, which is at the
+// memory system's rate there (depthwise.hip: launch_depthwise_t; the K = 3 instances are built and were probed bit-identical, YOLORET_DW_WALK=3).  Same arithmetic as dw_kernel<K,1,..> and dwp_kernel -
 // float32 accumulation in (ky, kx) order, BatchNorm, activation, one rounding on store: the three forms are bit-identical.
 //
 // What the tile walk paid for (profiles/r03_traffic_*): a 13 x 8 output tile needs a 17 x 12 halo tile -
 // 1.96 x the pixels, of which the memory side saw 1.46-1.6 x - and its lanes were bands of R or R - 1 rows of 4-column strips:
 // 13 rows in bands of 4 + 3 + 3 + 3 run 16 rows of instructions, 26 columns in 8-wide tiles run 32.  Here a workgroup owns 64
 // channels of a COLUMN BLOCK (at most 8 four-column strips: the whole width of a 13-, 20- or 26-wide map, half of a 52-wide
-// one; two images where both fit the 8 half-wave slots) and walks DOWN a segment of its rows: a half-wave = one strip x 32 channel pairs, the K x 4 partial sums of
-// the K output rows an input row feeds live in registers (5 x 4 packed pairs), every input row is read from LDS once and
-// every output row is finished exactly once - no band remainders, no rows recomputed inside a segment, no vertical halo
+// one; two images where both fit the 8 half-wave slots) and walks DOWN a segment of its rows: a half-wave = one strip x 32
+// channel pairs, the K x 4 partial sums of the K output rows an input row feeds live in registers (5 x 4 packed pairs), every
+// input row is read from LDS once and every output row is finished exactly once - no band remainders, no rows recomputed inside a segment, no vertical halo
 // inside a segment.  Rows arrive in groups of K through LDS-direct buffer loads (`buffer_load_dwordx4 ... lds`, zeros for
 // padding from the descriptor's range check), two group buffers, one barrier per K rows; the rows of a group are straight-line
 // code (the accumulator an input row's tap feeds is a compile-time index), the first and the last groups of a segment run a
