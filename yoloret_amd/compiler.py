@@ -561,14 +561,14 @@ def dw_se_geometry(strips, c4):
 DW_LDS = os.environ.get('YOLORET_DW_LDS', '1') != '0'
 
 
-DW_WALK = int(os.environ.get('YOLORET_DW_WALK', '1'))       # 0: the tile walk everywhere; 3: the 3x3 maps walk too (probes)
+DW_WALK = int(os.environ.get('YOLORET_DW_WALK', '1'))       # 0: the tile walk everywhere
 
 
 def dwl_geometry(h, w, k=5, se=True):
     """(rows along x, rows along y) of the squeeze-excite sums the 16-bit k x k stride-1 depthwise form writes per image.
     The walking form (depthwise_walk.hip, == dwq_geometry() / dwq_quanta() there): column blocks of at most 8 four-column
     strips x row quanta fixed by the map's height - independent of the batch and of how a launch cuts the rows into segments."""
-    if DW_WALK and (k == 5 or DW_WALK >= 3):     # launch_depthwise_t's choice (depthwise.hip)
+    if DW_WALK and k == 5:     # launch_depthwise_t's choice (depthwise.hip)
         strips = (w + 3) // 4
         q = min(8, max(1, h // 10))
         rows = round_up((h + q - 1) // q, k)      # quanta of a multiple of k rows

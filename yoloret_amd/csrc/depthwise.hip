@@ -293,10 +293,10 @@ static int launch_depthwise_t(const yr_op& op, int batch, hipStream_t s) {
         static const bool lds_form = !(getenv("YOLORET_DW_LDS") && atoi(getenv("YOLORET_DW_LDS")) == 0);
 #endif
         // (round 4: the walking form - whole column blocks, rows walked once - unless YOLORET_DW_WALK=0 keeps the tile walk for A/B runs)
-        static const int walk_form = getenv("YOLORET_DW_WALK") ? atoi(getenv("YOLORET_DW_WALK")) : 1;   // (3: the 3 x 3 maps too - probes)
+        static const int walk_form = getenv("YOLORET_DW_WALK") ? atoi(getenv("YOLORET_DW_WALK")) : 1;
         // for the 5 x 5 maps (tools/dwq_probe.sh: 26 x 26 x 672 @128 83 -> 66 us, SE form 106 -> 72; the others -1 .. -10 %); the 3 x 3
         // maps are close to the HBM rate in either form and keep the tile walk (52 x 52 x 128 @128: 32 us against 35)
-        if (lds_form && walk_form && (op.k == 5 || (walk_form >= 3 && op.k == 3)) && op.stride == 1 && in.c >= 64)
+        if (lds_form && walk_form && op.k == 5 && op.stride == 1 && in.c >= 64)
             return yr_launch_depthwise_walk(op.dtype, op.k, in.ptr, op.wgt, op.scale, op.shift, op.out, batch, in.h, in.w, a.C4, a.ld_in, a.ld_w, a.ld_out,
                                             a.pad_t, a.pad_l, a.act, const_cast<float*>(op.gate), op.gate_ld, op.se_reduced, s);
         if (lds_form && (op.k == 5 || op.k == 3) && op.stride == 1 && in.c >= 64)

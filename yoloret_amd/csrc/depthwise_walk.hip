@@ -1,7 +1,8 @@
-// Depthwise K x K (K = 5 | 3) stride-1 convolution on 16-bit maps, WALKING form (round 4): the successor of depthwise_lds.hip's
+// Depthwise K x K (K = 5) stride-1 convolution on 16-bit maps, WALKING form (round 4): the successor of depthwise_lds.hip's
 // tile walk for the wide EfficientNet stages (efficientnet.py:501-510, kernel_size 5, more than 128 block inputs).  The plans take
 // it for the 5 x 5 maps; the 3 x 3 maps of the detection heads (code/yolo3/model.py:98-114) stay on the tile walk, which is at the
-// memory system's rate there (depthwise.hip: launch_depthwise_t; the K = 3 instances are built and were probed bit-identical, YOLORET_DW_WALK=3).  Same arithmetic as dw_kernel<K,1,..> and dwp_kernel -
+// memory system's rate there (depthwise.hip: launch_depthwise_t; the K = 3 instances of this kernel were probed - bit-identical, 35 us against 32 on 52 x 52 x 128 -
+// and are not built).  Same arithmetic as dw_kernel<K,1,..> and dwp_kernel -
 // float32 accumulation in (ky, kx) order, BatchNorm, activation, one rounding on store: the three forms are bit-identical.
 //
 // What the tile walk paid for (profiles/r03_traffic_*): a 13 x 8 output tile needs a 17 x 12 halo tile -
@@ -371,14 +372,14 @@ static int launch_dwq_t(DwqArgs a, int expect_rows, hipStream_t s) {
 
 template <class T>
 static int launch_dwq_k(const DwqArgs& a, int k, int part_rows, hipStream_t s) {
-    if (k == 5) return a.part ? launch_dwq_t<T, 5, true>(a, part_rows, s) : launch_dwq_t<T, 5, false>(a, 0, s);
-    return a.part ? launch_dwq_t<T, 3, true>(a, part_rows, s) : launch_dwq_t<T, 3, false>(a, 0, s);
+    (void)k;   // (5: the 3 x 3 instances were measured against the tile walk - 52 x 52 x 128 @128: 35 us against 32, both at the HBM rate - and are not built)
+    return a.part ? launch_dwq_t<T, 5, true>(a, part_rows, s) : launch_dwq_t<T, 5, false>(a, 0, s);
 }
 
 int yr_launch_depthwise_walk(int dtype, int k, const void* in, const float* w, const float* scale, const float* shift, void* out, int B, int H, int W,
                              int C8, int ld_in, int ld_w, int ld_out, int pad_t, int pad_l, int act, float* part, int ld_part, int part_rows,
                              hipStream_t s) {
-    if (k != 3 && k != 5) { yr_set_error("depthwise (walking form): 3 x 3 and 5 x 5 only"); return YR_ERR_ARG; }
+    if (k != 5) { yr_set_error("depthwise (walking form): 5 x 5 only"); return YR_ERR_ARG; }
     DwqArgs a;
     a.in = in; a.w = w; a.scale = scale; a.shift = shift; a.out = out;
     a.B = B; a.H = H; a.W = W; a.C8 = C8;
