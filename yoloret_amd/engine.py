@@ -33,8 +33,11 @@ class Model:
         self.name = name
         self.plan = compile_graph(self.inputs[0], self.outputs, fuse, self.dtype)
         # batches of up to SMALL_BATCH images run a second plan without block fusion (compiler.py: 'latency');
-        # compiled on first use, same parameters, its own weight blob / handle / tile table
-        self.small_batch = int(os.environ.get('YOLORET_SMALL_BATCH', '4')) if fuse is True else 0
+        # compiled on first use, same parameters, its own weight blob / handle / tile table.  Default (tools/lat_sweep.py, round 4):
+        # 16-bit plans up to 2 images (lite0 @416 batch 1: 0.66 ms against 0.68, batch 4: 0.74 against 0.72); float32 plans never -
+        # since their blocks run in the split form the fused plan is the faster one at every batch (MobileNetV2 x0.75 @416 batch 1:
+        # 0.60 ms against 0.65, batch 4: 0.66 against 0.79)
+        self.small_batch = int(os.environ.get('YOLORET_SMALL_BATCH', '0' if self.dtype == 0 else '2')) if fuse is True else 0
         self._plans = {'throughput': self.plan}
         self._weights = None
         self._blobs = {}
