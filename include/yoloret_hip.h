@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define YR_ABI_VERSION 6   /* 6: split forms - k bit 7 of MBR / MBE (float16-plane fragments), se_reduced bit 16 of a float32 POINTWISE op (= keep the float32 MFMA); float32 POINTWISE ops at least 16 channels deep otherwise run on the 16-bit matrix pipe with two float16 planes per operand (pointwise_split.hip; same results to float32 rounding, |x|, |w| < 65504); 5: op kinds MBR / MBE (float32 blocks on the matrix pipe, register-chained), MBCONV removed; 4: YR_U8 images (uint8 network entry); 3: op kind MBX, pair-packed STEM weights, BN scale folded into the packed taps of STEMBLOCK / MBLANE */
+#define YR_ABI_VERSION 7   /* 7: squeeze-excite finished by its producer (yr_op.gate_out / se_w / se_hidden / sync: the "SE tail"), op kind HEAD (gathered 1x1 conv -> depthwise 3x3 -> SE of a detection-head block in one launch), yr_workspace_bytes includes the arrival counters; 6: split forms - k bit 7 of MBR / MBE (float16-plane fragments), se_reduced bit 16 of a float32 POINTWISE op (= keep the float32 MFMA); float32 POINTWISE ops at least 16 channels deep otherwise run on the 16-bit matrix pipe with two float16 planes per operand (pointwise_split.hip; same results to float32 rounding, |x|, |w| < 65504); 5: op kinds MBR / MBE (float32 blocks on the matrix pipe, register-chained), MBCONV removed; 4: YR_U8 images (uint8 network entry); 3: op kind MBX, pair-packed STEM weights, BN scale folded into the packed taps of STEMBLOCK / MBLANE */
 #define YR_MAX_SRC 4
 
 typedef enum {
@@ -172,6 +172,24 @@ typedef enum {
                             wgt = expand A fragments [T][KE][64] (YR_OP_MBR's register order, rho < KE); wgt2 = [T][11][16] as YR_OP_MBR.
                             k bit 7 = the split form (see YR_OP_MBR): wgt = the float32 words holding [T][ceil(cin / 32)][2 planes][64][8 halves].
                             Built for cin in {48, 72, 88, 120, 136, 224} (the split form: all but 224) */
+    YR_OP_HEAD = 15,     /* ABI 7: the first two thirds of a detection-head block (model.py:91-115: Conv2D 1x1 + BN + ReLU6 -> MBConvBlock's
+                            depthwise 3x3 + BN + Swish [-> SE]) in one launch, float32 (headblock.hip): the 1x1 convolution as YR_OP_POINTWISE's
+                            split form (same sources incl. up-sampling / pooling / concat gathers, a YR_X_UP2_ADD last source, an SE `gate` on a
+                            single identity source; operands as two float16 planes, |x|, |w| < 65504) over a REGION of one image with its
+                            one-pixel halo, the F-wide conv output kept in LDS, the depthwise conv (stride 1, TF SAME) computed from there,
+                            stored, and - with the SE-tail fields below - summed per channel.  The F-wide conv output never reaches HBM.
+                            h, w = the map (conv and depthwise output alike); cin = sum of src[].c; cout = F; act = the depthwise activation;
+                            k = 3 | conv activation << 8; stride = 1; wgt = Wt[F][kp], scale / shift [F] (conv BN) as POINTWISE;
+                            k bit 7 (0x80): wgt = the float32 words holding float16 planes in fragment order instead,
+                            [ceil(F / 16)][NK][2 planes][64 lanes][8 halves] with the k space cut into chunks of 32 channels PER SOURCE (NK =
+                            sum of ceil(src.c / 32); lane (m = l % 16, g = l / 16) of cout tile t, chunk j of source s: W[16 t + m][channel
+                            32 j + 8 g + i of s], zero beyond the source / beyond F; h plane, then m = f16((w - h) 2^11)) - the LDS-direct
+                            kernel (identity / up-sampled sources only; yoloret_amd.compiler.head_pack);
+                            wgt2 = float32 [10][round_up(F, 4)]: the nine depthwise taps (ky, kx) x depthwise BN scale | depthwise BN shift.
+                            res / res_ld (optional) = the float32 SE gate vector [B][res_ld] multiplied onto the single identity source on load
+                            (`gate` is taken by the sums this op writes); k bits 16-23 (optional) = cout tiles of 16 per workgroup.
+                            SE tail: gate = OUTPUT float32 [B][se_reduced][gate_ld] channel sums, one row per region (se_reduced = regions per
+                            image: yr_head_regions()) */
     YR_OP_MBX = 12       /* the first two thirds of an MBConv block WITH squeeze-excite (efficientnet.py:406-536), 16-bit
                             activations: expand 1x1 + BN + act (bf16 / f16 MFMA) -> depthwise K = 3 | 5, stride 1 | 2 + BN +
                             act, the expanded input of the depthwise conv staying in LDS; the depthwise map is stored and
@@ -218,6 +236,17 @@ typedef struct {
     const float* wgt2;   int64_t wgt2_off;
     const float* b1;     int64_t b1_off;
     const float* b2;     int64_t b2_off;
+    /* ---- ABI 7: the "SE tail" - squeeze-excite finished by the op that produces the map (csrc/se_tail.h).  An op that writes
+     * per-workgroup channel sums to `gate` (DEPTHWISE SE form, MBX, STEMBLOCK without projection, HEAD) and has gate_out set also
+     * runs the SE block's FC pair (efficientnet.py:419-434): the workgroup that completes an image's `se_reduced` rows adds them up
+     * in index order, divides by h * w and writes sigmoid(W2 . swish(W1 . mean + b1) + b2) to gate_out[b] - what an SE_FC op with
+     * k = h * w reading `gate` would have written (same values to float32 rounding), without the launch. */
+    float* gate_out;  int32_t gate_out_buf;  int32_t gate_out_ld;   /* float32 [B][gate_out_ld], gate_out_ld >= round_up(cout, 4) */
+    int32_t se_hidden;    /* hidden width R of the FC pair */
+    int32_t reserved0;
+    const float* se_w;  int64_t se_w_off;   /* W1 [ldc][R4] (Keras kernel [1,1,C,R], rows padded to R4 = round_up(R, 4)) | W2 [R][ldc] | b1 [R4] | b2 [ldc], ldc = round_up(cout, 4) */
+    uint32_t* sync;       /* [batch] arrival counters: zero before the launch, zero again after it.  Plan ops: assigned by yr_forward
+                             from the tail of the workspace (cleared at the start of every pass); yr_op_run: the caller's */
 } yr_op;
 
 /* Buffer table entry of a plan: per-image size in BYTES and either an arena
@@ -259,7 +288,8 @@ int yr_plan_io_dims(const yr_handle* h, int32_t* in_hw, int32_t* out_hwc);
 /* Copies the flat fp32 parameter blob (host) to the device; owned by the handle.
  * Replaces tf.keras.Model.load_weights (yolo.py:87) once weights are in blob order. */
 int yr_load_weights(yr_handle* h, const float* host_blob, size_t n_floats);
-/* Bytes of caller-owned device workspace yr_forward needs for `batch` images. */
+/* Bytes of caller-owned device workspace yr_forward needs for `batch` images (the arena of intermediate tensors followed by the
+ * SE-tail arrival counters of the plan's ops, 4 * batch bytes each). */
 size_t yr_workspace_bytes(const yr_handle* h, int batch);
 /* images [B,H,W,3] -> y1,y2,y3 raw logits [B,G,G,A*(C+5)], G = H/32, H/16, H/8. */
 int yr_forward(yr_handle* h, const float* images, int batch, float* y1, float* y2, float* y3,
@@ -285,6 +315,9 @@ int yr_plan_num_launches(const yr_handle* h);
 
 /* ---- single fused ops (device pointers inside `op`); parity-testable in isolation. */
 int yr_op_run(const yr_op* op, int batch, void* stream);
+/* How a YR_OP_HEAD launch cuts an h x w map into nsy x nsx regions (a function of the shape alone): the rows of the squeeze-excite
+ * sums buffer such an op writes per image = nsy * nsx (its se_reduced). */
+int yr_head_regions(int h, int w, int32_t* nsy, int32_t* nsx);
 
 /* ---- preprocessing (the step before the path): decoded uint8 [ih,iw,3] image (device) ->
  * letterboxed float32 [H,W,3] network input.  Replaces tf.io.decode_image(dtype=float32)'s /255

@@ -96,8 +96,11 @@ def test_plan_variants(monkeypatch):
     kinds = [o.kind for o in lat.ops]
     assert rt.OP_MBLANE not in kinds and rt.OP_MBCONV not in kinds and kinds[0] == rt.OP_STEMBLOCK
     # the squeeze of every SE block rides on its depthwise kernel as partial sums (no SE_MEAN launches, no merged pooling)
-    assert kinds.count(rt.OP_SE_MEAN) == 0 and kinds.count(rt.OP_DEPTHWISE) == 22 and kinds.count(rt.OP_SE_FC) == 6
-    assert sum(1 for o in lat.ops if o.kind == rt.OP_DEPTHWISE and o.gate is not None) == 6
+    # ... and (ABI 7) the FC pair of every SE block rides there too - the SE tail: no SE_FC launches either
+    assert kinds.count(rt.OP_SE_MEAN) == 0 and kinds.count(rt.OP_DEPTHWISE) == 22 and kinds.count(rt.OP_SE_FC) == 0
+    assert sum(1 for o in lat.ops if o.kind == rt.OP_DEPTHWISE and o.gate is not None and o.gate_out is not None and 'se_w' in o.params) == 6
+    # the throughput plan: the six head blocks (1x1 conv -> depthwise -> squeeze-excite) are one launch each
+    assert sum(1 for o in thr.ops if o.kind == rt.OP_HEAD and o.gate_out is not None) == 6 and rt.OP_SE_FC not in [o.kind for o in thr.ops]
     assert lat.param_shapes == thr.param_shapes and lat.total_macs() == thr.total_macs()
     assert abs(lat.algorithmic_bytes_per_image() - thr.algorithmic_bytes_per_image()) < 1
     assert [(b.h, b.w, b.c) for b in lat.output_bufs] == [(b.h, b.w, b.c) for b in thr.output_bufs]
@@ -235,7 +238,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
         assert hasattr(L, sym), 'libyoloret_hip.so does not export %s' % sym
     assert declared == set(rt.EXPORTS)
     L.yr_abi_version.restype = ctypes.c_int
-    assert L.yr_abi_version() == 6 == rt.ABI_VERSION
+    assert L.yr_abi_version() == 7 == rt.ABI_VERSION
     # struct layouts agree with the header's (the library reports its own sizeof)
     for which, st in enumerate((rt.YrSrc, rt.YrOp, rt.YrBuf)):
         assert L.yr_abi_sizeof(which) == ctypes.sizeof(st), st.__name__
@@ -264,6 +267,7 @@ SCRATCH_ALLOWED = {
     '_Z15nms_band_kernel': 200,    # the per-lane score list of the band-wise NMS
     '_Z10pwh_kernelIDF16_Li4ELi1ELi2ELi2E': 68,    # f16 direct form, four pixel tiles, gated source
     '_Z10dwq_kernelIDF16_Li5ELi1ELb1E': 16,        # f16 5x5 swish squeeze-excite walk: three values parked outside the row loop at 168 registers
+    '_Z10pws_kernelILi2ELi2ELi4ELi1ELb0E': 12,     # the 128 x 32 tile with gathered sources at 168 registers (since the k loop moved to pws_common.h; no plan of the BASELINE models picks it)
     '_Z10mbr_kernel': 12,          # split form (..ELb1EEv): the three-wave stride-1 block at 168 registers and 48 -> 288 -> 72 at 256 park two values
 }
 

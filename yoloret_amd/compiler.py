@@ -65,6 +65,8 @@ class OpRec:
         self.out = None
         self.res = None
         self.gate = None
+        self.gate_out = None  # ABI 7, the SE tail: the gate vector this op writes itself (se_hidden = the FC pair's hidden width, params['se_w'])
+        self.se_hidden = 0
         self.params = {}      # role -> (shape, numpy builder fn(weights) -> float32 array[, yr_dtype it is stored as])
         self.offsets = {}     # role -> float offset in blob
         self.macs = 0
@@ -94,11 +96,11 @@ class Plan:
                 op.out.first_def = i
             for s in op.srcs:
                 s.buf.last_use = max(s.buf.last_use, i)
-            for b in (op.res, op.gate):
+            for b in (op.res, op.gate, op.gate_out):
                 if b is not None:
                     b.last_use = max(b.last_use, i)
-                    if b is op.gate and op.kind in (rt.OP_DEPTHWISE, rt.OP_MBX, rt.OP_STEMBLOCK) and b.first_def is None:
-                        b.first_def = i          # SE form: the depthwise op WRITES its per-workgroup channel sums there
+                    if (b is op.gate and op.kind in (rt.OP_DEPTHWISE, rt.OP_MBX, rt.OP_STEMBLOCK, rt.OP_HEAD) or b is op.gate_out) and b.first_def is None:
+                        b.first_def = i          # SE form: the depthwise op WRITES its per-workgroup channel sums there (and, with the SE tail, the gate)
         self.bufs = [b for b in self.bufs if b.first_def is not None]
         for i, b in enumerate(self.bufs):
             b.id = i
@@ -172,8 +174,10 @@ class Plan:
             o.out_buf, o.out_ld = r.out.id, r.out.ld
             o.res_buf, o.res_ld = (r.res.id, r.res.ld) if r.res is not None else (-1, 0)
             o.gate_buf, o.gate_ld = (r.gate.id, r.gate.ld) if r.gate is not None else (-1, 0)
+            o.gate_out_buf, o.gate_out_ld = (r.gate_out.id, r.gate_out.ld) if r.gate_out is not None else (-1, 0)
+            o.se_hidden = r.se_hidden
             roles = {'wgt': 'wgt_off', 'scale': 'scale_off', 'shift': 'shift_off', 'wgt2': 'wgt2_off',
-                     'b1': 'b1_off', 'b2': 'b2_off'}
+                     'b1': 'b1_off', 'b2': 'b2_off', 'se_w': 'se_w_off'}
             for role, field in roles.items():
                 setattr(o, field, r.offsets.get(role, -1))
         bufs = (rt.YrBuf * len(self.bufs))()
@@ -205,12 +209,12 @@ class Plan:
             return op.h * op.w * s.c
 
         def elems_of(op):
-            elems = 0
+            elems = sum(elems_of(f) for f in getattr(op, 'absorbed', ()))   # (an SE_FC op whose work the op's SE tail does)
             if getattr(op, 'fused', None):
                 # the accounting stays conv-granular (the figure everyone computes from): a fused
                 # op (block kernels; a projection with its depthwise stage folded into the loads) is
                 # charged what its convolutions would move unfused
-                return sum(elems_of(f) for f in op.fused)
+                return elems + sum(elems_of(f) for f in op.fused)
             if getattr(op, 'accounted_in', None):
                 return 0   # the low-resolution half of a hoisted conv: charged to the conv it was split from
             if op.kind in (rt.OP_STEM, rt.OP_POINTWISE, rt.OP_DEPTHWISE):
@@ -717,6 +721,155 @@ def fold_depthwise_into_project(ops, output_buf_ids, min_pixels=0):
         out.append(d)
         i += 1
     return out
+
+
+# ---- ABI 7: detection-head blocks as ONE launch, squeeze-excite finished by its producer ------------------------------------
+# make_last_layers_efficientnet_lite (model.py:91-115) = Conv2D 1x1 + BN + ReLU6 -> MBConvBlock (expand ratio 1: depthwise 3x3 + BN +
+# Swish -> SE -> project).  Through round 4 the first two thirds were three launches (split pointwise GEMM, dw_kernel, se_fc) and the
+# F-wide conv output (F = 128 @52x52, 256 @26x26, 512 @13x13) went to HBM and back.  fuse_head_blocks turns conv + depthwise into a
+# YR_OP_HEAD op (headblock.hip: the conv over a region with halo, its output kept in LDS, depthwise from there, per-region channel
+# sums); se_tail_into_producers then hands the SE block's FC pair to whichever op writes the sums (HEAD, or a DEPTHWISE op in the SE
+# form of dw_kernel): the workgroup that completes an image runs it (se_tail.h) and the SE_FC launch disappears.
+FUSE_HEAD = os.environ.get('YOLORET_FUSE_HEAD', '1') != '0'
+FUSE_HEAD_ALL = os.environ.get('YOLORET_FUSE_HEAD', '1') == '2'     # also conv -> depthwise pairs without squeeze-excite sums
+SE_TAIL = os.environ.get('YOLORET_SE_TAIL', '1') != '0'
+SE_TAIL_LDS = 4608 - 1024 - 4      # == YR_SE_TAIL_LDS - 4 * 256 threads (se_tail.h): channels + hidden units the tail's LDS scratch holds
+HEAD_DMA = os.environ.get('YOLORET_HEAD_DMA', '1') != '0'   # head blocks without a pooled source on the LDS-direct kernel
+
+
+def head_regions(h, w):
+    """== head_geometry() in headblock.hip (yr_head_regions): (nsy, nsx) regions a YR_OP_HEAD launch cuts an h x w map into - a
+    region with its one-pixel halo (clipped to the map) fits the 192 GEMM rows of a workgroup; fewest regions wins."""
+    best = None
+    for sx in range(1, min(16, w) + 1):
+        cw = (w + sx - 1) // sx
+        rw = cw + (2 if sx > 2 else 1 if sx > 1 else 0)
+        for sy in range(1, h + 1):
+            ch = (h + sy - 1) // sy
+            rh = ch + (2 if sy > 2 else 1 if sy > 1 else 0)
+            if min(rh, h) * min(rw, w) > 192:
+                continue
+            if best is None or sy * sx < best[0]:
+                best = (sy * sx, sy, sx)
+            break
+    if best is None:
+        raise ValueError('head_regions: a %d x %d map has no region split' % (h, w))
+    return best[1], best[2]
+
+
+def head_pack(wt, seg_c, V=4):
+    """The 1x1 convolution's weights Wt [F][kp] (k space = the sources' channels, each padded to V) as the float16 planes the
+    LDS-direct head kernel reads (headblock.hip, YR_OP_HEAD with k bit 7): the k space cut into chunks of 32 channels PER SOURCE,
+    [ceil(F / 16)][NK][2 planes][64 lanes][8 halves] - lane (m = l % 16, g = l / 16) of cout tile t, chunk j of source s:
+    W[16 t + m][channel 32 j + 8 g + i of s], zero beyond the source / beyond F; h plane, then m = f16((w - h) 2^11).
+    -> the float32 words that hold them."""
+    wt = np.asarray(wt, np.float32)
+    F = wt.shape[0]
+    NT = (F + 15) // 16
+    chunks, kb = [], 0
+    for c in seg_c:
+        chunks += [(kb + 32 * j, min(32, c - 32 * j)) for j in range((c + 31) // 32)]
+        kb += round_up(c, V)
+    assert float(np.abs(wt).max()) < 60000.0, 'head_pack: a weight beyond the float16 range'
+    W = np.zeros((NT * 16, len(chunks), 32), np.float32)
+    for ci, (k0, vc) in enumerate(chunks):
+        W[:F, ci, :vc] = wt[:, k0:k0 + vc]
+    W = W.reshape(NT, 16, len(chunks), 4, 8).transpose(0, 2, 3, 1, 4)          # [t][chunk][g][m][i]  (lane = 16 g + m)
+    h = W.astype(np.float16)
+    m = ((W - h.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    out = np.stack([h, m], axis=2)                                             # [t][chunk][plane][g][m][i]
+    return np.ascontiguousarray(out).reshape(-1).view(np.float32)
+
+
+def fuse_head_blocks(ops, bufs, output_buf_ids):
+    readers = {}
+    for op in ops:
+        for s_ in op.srcs:
+            readers[id(s_.buf)] = readers.get(id(s_.buf), 0) + 1
+        for b in (op.res, op.gate):
+            if b is not None:
+                readers[id(b)] = readers.get(id(b), 0) + 1
+    out, i = [], 0
+    while i < len(ops):
+        c = ops[i]
+        d = ops[i + 1] if i + 1 < len(ops) else None
+        kp = sum(round_up(s_.c, 4) for s_ in c.srcs if s_.xform != 'up2_add')
+        ok = (d is not None and c.kind == rt.OP_POINTWISE and c.dtype == 0 and c.act in ('relu6', 'none', 'swish', 'leaky') and 'scale' in c.params
+              and c.res is None and not getattr(c, 'stride', 0) and not (c.se_reduced & 0x10000) and not getattr(c, 'accounted_in', None)
+              and all(s_.xform in ('identity', 'up2', 'maxpool2', 'maxpool4', 'up2_add') for s_ in c.srcs)
+              and (c.gate is None or (len(c.srcs) == 1 and c.srcs[0].xform == 'identity'))
+              and kp >= 16 and c.cout % 4 == 0 and c.out.external_slot < 0 and c.out.id not in output_buf_ids and readers.get(id(c.out), 0) == 1
+              and d.kind == rt.OP_DEPTHWISE and d.dtype == 0 and d.k == 3 and d.stride == 1 and len(d.srcs) == 1 and d.srcs[0].buf is c.out
+              and d.srcs[0].xform == 'identity' and d.srcs[0].c == c.cout and d.act in ('swish', 'relu6', 'none') and d.out.ld % 4 == 0
+              and d.out.dtype == 0 and not (c.h == 1 and c.w == 1) and (d.gate is not None or FUSE_HEAD_ALL))
+        if not ok:
+            out.append(c)
+            i += 1
+            continue
+        F, ldf = c.cout, round_up(c.cout, 4)
+        m = OpRec(rt.OP_HEAD, c.name.rsplit('_', 1)[0] + '_head', act=d.act, h=d.h, w=d.w, cin=c.cin, cout=F, k=3 | rt.ACT[c.act] << 8, stride=1,
+                  srcs=list(c.srcs), out=d.out, res=c.gate, macs=c.macs + d.macs, dtype=0)
+        m.fused = [c, d]
+        m.params = {'wgt': c.params['wgt'], 'scale': c.params['scale'], 'shift': c.params['shift']}
+        kseg = [s_.c for s_ in c.srcs if s_.xform != 'up2_add']
+        if all(s_.xform in ('identity', 'up2', 'up2_add') for s_ in c.srcs) and len(kseg) <= 3 and HEAD_DMA:
+            # no pooled source: the LDS-direct kernel, weights as float16 planes in fragment order (k bit 7)
+            m.k |= 0x80
+            nk = sum((c_ + 31) // 32 for c_ in kseg)
+            m.params['wgt'] = ((((F + 15) // 16) * nk * 512,), lambda wd, wf=c.params['wgt'][1], kseg=kseg: head_pack(wf(wd), kseg))
+        dp = d.params
+
+        def dw_rows(wd, dp=dp, F=F, ldf=ldf):
+            o = np.zeros((10, ldf), np.float32)
+            o[:9, :F] = (dp['wgt'][1](wd).reshape(9, -1)[:, :F] * dp['scale'][1](wd)[None, :F]).astype(np.float32)
+            o[9, :F] = dp['shift'][1](wd)[:F]
+            return o
+        m.params['wgt2'] = ((10, ldf), dw_rows)
+        if d.gate is not None:     # the squeeze-excite sums: one row per region
+            nsy, nsx = head_regions(d.h, d.w)
+            part = d.gate
+            part.h, part.w = nsy * nsx, 1
+            part.elems = part.h * part.w * part.ld
+            part.bytes = part.elems * rt.ESIZE[part.dtype]
+            m.gate, m.se_reduced = part, nsy * nsx
+        if hasattr(c, 'accounting_srcs'):
+            m.fused[0].accounting_srcs = c.accounting_srcs
+        out.append(m)
+        i += 2
+    return out
+
+
+def se_tail_into_producers(ops):
+    producer_of_sums = {id(op.gate): op for op in ops
+                        if op.gate is not None and (op.kind == rt.OP_HEAD or (op.kind == rt.OP_DEPTHWISE and not dw_uses_lds_form(op)))}
+    drop = set()
+    for fc in ops:
+        if fc.kind != rt.OP_SE_FC or len(fc.srcs) != 1 or not fc.k > 0:
+            continue
+        P = producer_of_sums.get(id(fc.srcs[0].buf))
+        if P is None or P.gate_out is not None or fc.out.external_slot >= 0:
+            continue
+        C, R = fc.cin, fc.se_reduced
+        ldc = round_up(C, 4)
+        if C != P.cout or fc.k != P.h * P.w or ldc + R > SE_TAIL_LDS:
+            continue
+        fp = fc.params
+
+        def se_w(wd, fp=fp, R=R, ldc=ldc):
+            """W1 [ldc][R4] | W2 [R][ldc] | b1 [R4] | b2 [ldc] (include/yoloret_hip.h: se_w)"""
+            r4 = round_up(R, 4)
+            w1 = np.zeros((ldc, r4), np.float32)
+            w1[:, :R] = np.asarray(fp['wgt'][1](wd), np.float32).T       # SE_FC's W1t [R][ldc]
+            b1 = np.zeros(r4, np.float32)
+            b1[:R] = fp['b1'][1](wd)
+            return np.concatenate([w1.ravel(), np.asarray(fp['wgt2'][1](wd), np.float32).ravel(), b1, np.asarray(fp['b2'][1](wd), np.float32).ravel()])
+        P.params['se_w'] = ((ldc * round_up(R, 4) + R * ldc + round_up(R, 4) + ldc,), se_w)
+        P.gate_out, P.se_hidden = fc.out, R
+        P.macs += fc.macs
+        P.absorbed = list(getattr(P, 'absorbed', ())) + [fc]
+        drop.add(id(fc))
+    return [op for op in ops if id(op) not in drop]
+
 
 
 def mbr_pack(we_t, e_scale, e_shift, dw, d_scale, d_shift, wp_t, p_scale, p_shift):
@@ -1393,6 +1546,10 @@ class Compiler:
                 if SE_PARTIALS:
                     ops = se_partials_from_depthwise(ops, self.bufs)
             ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency, dtype=self.dtype, bufs=self.bufs)
+            if FUSE_HEAD and not latency and self.dtype == 0:
+                ops = fuse_head_blocks(ops, self.bufs, set(b.id for b in outs))
+            if SE_TAIL:
+                ops = se_tail_into_producers(ops)
             fold = FOLD_DW if isinstance(FOLD_DW, str) else ('1' if FOLD_DW else '0')   # (tests assign booleans)
             if fold != '0' and not latency and self.dtype == 0:
                 ops = fold_depthwise_into_project(ops, set(b.id for b in outs), 0 if fold == '1' else FOLD_DW_MIN_PIXELS)

@@ -11,6 +11,7 @@
 // (which share K-S input rows) are processed on the same XCD and hit its L2 (the round-robin
 // default was measured to fetch each input row ~3x from HBM - profiles/r01_pmc_fetch.txt).
 #include "yr_common.h"
+#include "se_tail.h"
 #include <cstdlib>
 
 // T: element type of the input and output maps (float32, or bf16 / f16 storage: widened on load, rounded to nearest
@@ -36,6 +37,7 @@ struct DwArgs {
     // share a group of strips and each writes its own channels of that group's row.
     float* part;
     int ld_part, cw, ncb;
+    SeTail se;           // ABI 7: the workgroup that completes an image's rows also runs the SE block's FC pair (se.sums == nullptr: no)
 };
 
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
@@ -71,7 +73,8 @@ __device__ __forceinline__ void dw_store(T* p, const float4 (&v)[Q]) {
 template <int K, int S, int XT, int YT, class T, bool SE = false>
 __global__ __launch_bounds__(256) void dw_kernel(DwArgs<T> a) {
     constexpr int Q = yr_elem<T>::vec / 4;   // channel quads per lane
-    __shared__ float4 red[SE ? 256 * Q : 1];
+    __shared__ float4 red[SE ? YR_SE_TAIL_LDS / 4 : 1];   // the partial sums' meeting place (256 * Q quads), then the SE tail's scratch
+    __shared__ unsigned se_flag;
     // SE: grid (workgroups per image, B), walked in XCD-contiguous order like the plain form (adjacent strips share input rows)
     const unsigned lin = SE ? yr_xcd_swizzle(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y) : 0u;
     const unsigned se_b = SE ? lin / gridDim.x : 0u, se_blk = SE ? lin - se_b * gridDim.x : 0u;
@@ -195,9 +198,10 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs<T> a) {
                     const float4 v = red[l * Q + q];
                     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
                 }
-                *reinterpret_cast<float4*>(a.part + ((size_t)b * (gridDim.x / a.ncb) + se_row) * a.ld_part + (cv * Q + q) * 4) = s;
+                yr_st_agent4(a.part + ((size_t)b * (gridDim.x / a.ncb) + se_row) * a.ld_part + (cv * Q + q) * 4, s.x, s.y, s.z, s.w);   // (write-through: se_tail.h)
             }
         }
+        yr_se_tail_arrive<256>(a.se, b, 1u, &se_flag, reinterpret_cast<float*>(red));   // (red: YR_SE_TAIL_LDS floats)
     }
 }
 
@@ -227,6 +231,7 @@ static int launch_dw_se(DwArgs<T> a, int expect_rows, hipStream_t s) {
     YR_REQUIRE(rows == expect_rows, "depthwise: the SE partial-sum buffer must hold %d rows per image (has %d)", rows, expect_rows);
     const long long blocks = (long long)rows * a.ncb;
     YR_REQUIRE(blocks * a.B < (1ll << 31), "depthwise: grid too large");
+    a.se.arrivals = (unsigned)blocks;   // every workgroup of an image arrives once
     a.nblocks = (unsigned)blocks;
     static char nm[48];
     static const int nm_len = snprintf(nm, sizeof(nm), "dw_kernel<%d,%d,%d,1,%s,1>", K, S, XT, yr_dtype_name(yr_elem<T>::dtype));
@@ -282,6 +287,10 @@ static int launch_depthwise_t(const yr_op& op, int batch, hipStream_t s) {
     a.pad_l = (ptw > 0 ? ptw : 0) / 2;
     a.act = op.act;
     a.part = nullptr; a.ld_part = 0; a.cw = 1; a.ncb = 1;
+    {
+        const int rc = yr_make_se_tail(op, op.se_reduced, &a.se);
+        if (rc) return rc;
+    }
     if (op.gate) YR_REQUIRE(op.gate_ld % 4 == 0 && op.gate_ld >= yr_round_up(in.c, V) && ((uintptr_t)op.gate % 16) == 0, "depthwise: bad SE partial-sum buffer");
     // 16-bit 5x5 / 3x3 stride 1 on maps with at least one 64-channel chunk: the LDS-tiled form (depthwise_lds.hip, bit-identical
     // maps; its SE rows are its tiles - compiler.se_partials_from_depthwise sizes the buffer for whichever form

@@ -178,6 +178,21 @@ struct PwRow {
         }
     }
 
+    // the same for conv pixel (b, y, x) given directly (headblock.hip: the rows of a workgroup are a region of one image)
+    __device__ __forceinline__ void init_at(const PwArgs& a, int b, int y, int x, bool valid_) {
+        valid = valid_;
+        grow = MODE == 2 ? a.gate + (size_t)b * a.gate_ld : nullptr;
+        arow = s0 = s1 = s2 = s3 = nullptr;
+        if (MODE != 0) {
+            arow = a.S.s[0].ptr + ((size_t)(b * a.H + y) * a.W + x) * a.S.s[0].ld;
+        } else {
+            s0 = source_row(a.S.s[0], b, y, x) - a.S.s[0].kbase;
+            s1 = source_row(a.S.s[1], b, y, x) - a.S.s[1].kbase;
+            s2 = source_row(a.S.s[2], b, y, x) - a.S.s[2].kbase;
+            s3 = source_row(a.S.s[3], b, y, x) - a.S.s[3].kbase;
+        }
+    }
+
     // Issue the loads of the quad at k (raw k may lie beyond kp: clamped).  v: raw channels, gt: gate quad
     // (MODE 2), cv: how many of the quad's channels are real (<= 0: none).  Nothing here reads a loaded
     // register and the main load is unconditional: rows beyond M read row 0 (their outputs are never stored), the

@@ -45,6 +45,7 @@ static int dispatch(const yr_op& op, int batch, hipStream_t s) {
         case YR_OP_MBH: case YR_OP_MBX: return yr_launch_mbh(op, batch, s);
         case YR_OP_MBR: return yr_launch_mbr(op, batch, s);
         case YR_OP_MBE: return yr_launch_mbe(op, batch, s);
+        case YR_OP_HEAD: return yr_launch_head(op, batch, s);
         default: yr_set_error("unknown op kind %d", op.kind); return YR_ERR_ARG;
     }
 }
@@ -58,6 +59,8 @@ struct yr_handle {
     std::vector<yr_op> ops;
     std::vector<yr_buf> bufs;
     int64_t arena_per_image = 0;  // bytes
+    std::vector<int> sync_slot;   // per op: index of its SE-tail arrival counters [batch] behind the arena, or -1
+    int n_sync = 0;
     float* weights = nullptr;
     size_t n_weights = 0;
     std::map<int, std::vector<int>> tuned;  // batch -> per-op pointwise tile choice (1-based, 0 = heuristic)
@@ -94,6 +97,7 @@ extern "C" int yr_create(const yr_op* ops, int n_ops, const yr_buf* bufs, int n_
         if (ok) ok = op.out_dtype == h->bufs[op.out_buf].dtype;
         if (ok && op.res_buf >= 0) ok = buf_ok(op.res_buf);
         if (ok && op.gate_buf >= 0) ok = buf_ok(op.gate_buf);
+        if (ok && op.gate_out_buf >= 0) ok = buf_ok(op.gate_out_buf) && h->bufs[op.gate_out_buf].dtype == YR_F32;
         if (!ok) {
             delete h;
             yr_set_error("yr_create: op references a buffer outside the table, or with a dtype other than the buffer's");
@@ -118,8 +122,11 @@ extern "C" int yr_create(const yr_op* ops, int n_ops, const yr_buf* bufs, int n_
             int64_t rows = (int64_t)op.h * op.w;
             if (op.kind == YR_OP_SE_MEAN || op.kind == YR_OP_SE_FC) rows = 1;
             if (op.out_ld < (op.kind == YR_OP_SE_MEAN || op.kind == YR_OP_SE_FC ? op.cin : op.cout) || !fits(op.out_buf, rows * op.out_ld, op.out_dtype)) why = "the output";
-            else if (op.res_buf >= 0 && (op.res_ld < op.cout || !fits(op.res_buf, (int64_t)op.h * op.w * op.res_ld, op.dtype))) why = "the residual";
+            else if (op.kind == YR_OP_HEAD && op.res_buf >= 0 && (op.res_ld < op.cin || !fits(op.res_buf, op.res_ld, YR_F32))) why = "the source's gate";   // (HEAD: res = the SE gate vector of its single source)
+            else if (op.kind != YR_OP_HEAD && op.res_buf >= 0 && (op.res_ld < op.cout || !fits(op.res_buf, (int64_t)op.h * op.w * op.res_ld, op.dtype))) why = "the residual";
             else if (op.gate_buf >= 0 && op.gate_ld <= 0) why = "the gate";
+            else if (op.gate_out_buf >= 0 && (op.gate_buf < 0 || op.se_hidden < 1 || op.se_w_off < 0 || op.gate_out_ld < op.cout || !fits(op.gate_out_buf, op.gate_out_ld, YR_F32) ||
+                                              op.se_reduced < 1 || !fits(op.gate_buf, (int64_t)op.se_reduced * op.gate_ld, YR_F32))) why = "the squeeze-excite tail";
         }
         if (why) {
             delete h;
@@ -127,6 +134,9 @@ extern "C" int yr_create(const yr_op* ops, int n_ops, const yr_buf* bufs, int n_
             return YR_ERR_ARG;
         }
     }
+    h->sync_slot.assign(h->ops.size(), -1);
+    for (size_t i = 0; i < h->ops.size(); ++i)
+        if (h->ops[i].gate_out_buf >= 0) h->sync_slot[i] = h->n_sync++;
     *out = h;
     return YR_OK;
 }
@@ -144,10 +154,24 @@ static_assert(sizeof(yr_blob_header) == 96, "serialised plan header is 96 bytes"
 
 // Floats of the blob a parameter of `op` occupies from its offset on (0: the role is not used by this kind, or its size is
 // not modelled here - the offset alone is then range-checked).  Mirrors the layouts documented in include/yoloret_hip.h.
-static int64_t param_floats(const yr_op& op, int role) {   // role: 0 wgt, 1 scale, 2 shift, 3 wgt2, 4 b1, 5 b2
+static int64_t param_floats(const yr_op& op, int role) {   // role: 0 wgt, 1 scale, 2 shift, 3 wgt2, 4 b1, 5 b2, 6 se_w
     const int V = yr_vec_of(op.dtype);
     auto ru = [](int64_t v, int64_t m) { return (v + m - 1) / m * m; };
+    if (role == 6) {   // the SE tail's FC pair: W1t [R][ldc] | W2 [R][ldc] | b1 [round_up(R, 4)] | b2 [ldc]
+        if (op.se_hidden < 1) return -1;
+        const int64_t ldc = ru(op.cout, 4), r4 = ru(op.se_hidden, 4);
+        return ldc * r4 + (int64_t)op.se_hidden * ldc + r4 + ldc;
+    }
     switch (op.kind) {
+        case YR_OP_HEAD:
+            if (role == 3) return 10 * ru(op.cout, 4);
+            if (role == 0 && (op.k & 0x80)) {   // float16 planes in fragment order, 32-channel chunks per source
+                int64_t nk = 0;
+                for (int i = 0; i < op.nsrc; ++i)
+                    if (op.src[i].xform != YR_X_UP2_ADD) nk += (op.src[i].c + 31) / 32;
+                return ru(op.cout, 16) / 16 * nk * 512;
+            }
+            [[fallthrough]];   // (the convolution's parameters as POINTWISE)
         case YR_OP_POINTWISE: {
             int64_t kp = 0;
             for (int i = 0; i < op.nsrc; ++i)
@@ -253,11 +277,11 @@ extern "C" int yr_create_from_blob(const void* blob, size_t bytes, yr_handle** o
         p += bufs.size() * sizeof(yr_buf);
         for (yr_op& op : ops) {   // a file must not smuggle pointers in
             for (int i = 0; i < YR_MAX_SRC; ++i) op.src[i].ptr = nullptr;
-            op.out = nullptr; op.res = nullptr; op.gate = nullptr;
-            op.wgt = op.scale = op.shift = op.wgt2 = op.b1 = op.b2 = nullptr;
+            op.out = nullptr; op.res = nullptr; op.gate = nullptr; op.gate_out = nullptr; op.sync = nullptr;
+            op.wgt = op.scale = op.shift = op.wgt2 = op.b1 = op.b2 = op.se_w = nullptr;
             YR_REQUIRE(op.nsrc >= 1 && op.nsrc <= YR_MAX_SRC && yr_dtype_ok(op.dtype), "yr_create_from_blob: op with %d sources / dtype %d", op.nsrc, op.dtype);
-            const int64_t offs[6] = {op.wgt_off, op.scale_off, op.shift_off, op.wgt2_off, op.b1_off, op.b2_off};
-            for (int role = 0; role < 6; ++role) {
+            const int64_t offs[7] = {op.wgt_off, op.scale_off, op.shift_off, op.wgt2_off, op.b1_off, op.b2_off, op.se_w_off};
+            for (int role = 0; role < 7; ++role) {
                 if (offs[role] < 0) continue;   // role not used
                 const int64_t ext = param_floats(op, role);
                 YR_REQUIRE(ext >= 0 && offs[role] < (int64_t)hd.n_weight_floats && ext <= (int64_t)hd.n_weight_floats - offs[role],
@@ -312,9 +336,12 @@ extern "C" int yr_load_weights(yr_handle* h, const float* host_blob, size_t n_fl
     return YR_OK;
 }
 
+// the SE-tail arrival counters sit behind the arena: [n_sync][batch] words
+static size_t yr_sync_offset(const yr_handle* h, int batch) { return ((size_t)h->arena_per_image * (size_t)batch + 15) & ~(size_t)15; }
+
 extern "C" size_t yr_workspace_bytes(const yr_handle* h, int batch) {
     if (!h || batch <= 0) return 0;
-    return (size_t)h->arena_per_image * (size_t)batch;
+    return yr_sync_offset(h, batch) + (size_t)h->n_sync * (size_t)batch * sizeof(uint32_t);
 }
 
 extern "C" int yr_plan_num_launches(const yr_handle* h) { return h ? (int)h->ops.size() : 0; }
@@ -353,6 +380,9 @@ static int resolve_op(const yr_handle* h, size_t i, int batch, float* const ext[
     op.out = bufptr(op.out_buf);
     op.res = op.res_buf >= 0 ? bufptr(op.res_buf) : nullptr;
     op.gate = op.gate_buf >= 0 ? (const float*)bufptr(op.gate_buf) : nullptr;
+    op.gate_out = op.gate_out_buf >= 0 ? (float*)bufptr(op.gate_out_buf) : nullptr;
+    op.se_w = wptr(op.se_w_off);
+    op.sync = h->sync_slot[i] >= 0 ? reinterpret_cast<uint32_t*>(ws + yr_sync_offset(h, batch)) + (size_t)h->sync_slot[i] * (size_t)batch : nullptr;
     op.wgt = wptr(op.wgt_off); op.scale = wptr(op.scale_off); op.shift = wptr(op.shift_off);
     op.wgt2 = wptr(op.wgt2_off); op.b1 = wptr(op.b1_off); op.b2 = wptr(op.b2_off);
     if (op.out == nullptr) { yr_set_error("op %zu writes a null external buffer", i); return YR_ERR_ARG; }
@@ -379,6 +409,15 @@ static int check_forward_args(yr_handle* h, const float* images, int batch, void
     return YR_OK;
 }
 
+// The arrival counters of the SE tails (se_tail.h) must be zero when a pass starts.  Every launch leaves them zero again, so this
+// matters for a workspace's first pass (the memory is the caller's, its contents unknown) and after an aborted one - cleared on
+// every pass all the same: one 4 * n_sync * batch byte fill on the stream.
+static int clear_sync(const yr_handle* h, int batch, void* workspace, hipStream_t s) {
+    if (h->n_sync == 0) return YR_OK;
+    YR_CHECK_HIP(hipMemsetAsync(static_cast<char*>(workspace) + yr_sync_offset(h, batch), 0, (size_t)h->n_sync * (size_t)batch * sizeof(uint32_t), s));
+    return YR_OK;
+}
+
 static int fail_op(size_t i, int kind, int rc) {
     char tmp[400];
     strncpy(tmp, g_err, sizeof(tmp) - 1);
@@ -393,6 +432,8 @@ extern "C" int yr_forward(yr_handle* h, const float* images, int batch, float* y
     if (rc) return rc;
     float* ext[4] = {const_cast<float*>(images), y1, y2, y3};
     hipStream_t s = (hipStream_t)stream;
+    rc = clear_sync(h, batch, workspace, s);
+    if (rc) return rc;
     for (size_t i = 0; i < h->ops.size(); ++i) {
         yr_op op;
         rc = resolve_op(h, i, batch, ext, static_cast<char*>(workspace), &op);
@@ -418,6 +459,8 @@ extern "C" int yr_forward_profile(yr_handle* h, const float* images, int batch, 
     for (auto& e : ev) YR_CHECK_HIP(hipEventCreate(&e));
     std::vector<double> acc(n, 0.0);
     for (int it = 0; it < iters && rc == YR_OK; ++it) {
+        rc = clear_sync(h, batch, workspace, s);
+        if (rc) break;
         YR_CHECK_HIP(hipEventRecord(ev[0], s));
         for (size_t i = 0; i < n; ++i) {
             yr_op op;

@@ -52,6 +52,7 @@ bool yr_stemxp_takes(const yr_op& op);                                  // mbxr_
 int yr_launch_stemxp(const yr_op& op, int batch, hipStream_t s);   // mbxr_h.hip: a plain launch of this MBH / MBX op runs the register-chained form
 int yr_launch_mbr(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_mbe(const yr_op& op, int batch, hipStream_t s);
+int yr_launch_head(const yr_op& op, int batch, hipStream_t s);      // headblock.hip
 int yr_pointwise_num_cfgs(int dtype);
 
 static inline int yr_round_up(int v, int m) { return (v + m - 1) / m * m; }

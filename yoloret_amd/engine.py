@@ -154,7 +154,11 @@ class Model:
         return idx, h
 
     def workspace_bytes(self, batch):
-        return self.plan_for(batch).arena_bytes_per_image * batch
+        """== yr_workspace_bytes: the arena of intermediate tensors, then (ABI 7) the arrival counters of the ops that finish a
+        squeeze-excite block themselves (one word per such op and image, 16-byte aligned behind the arena)."""
+        plan = self.plan_for(batch)
+        n_sync = sum(1 for op in plan.ops if op.gate_out is not None)
+        return (plan.arena_bytes_per_image * batch + 15) // 16 * 16 + 4 * n_sync * batch
 
     def __call__(self, x, out=None, ctx=0):
         """ctx: execution context.  The plan handle is read-only during a forward; what a step owns is its WORKSPACE (the

@@ -17,7 +17,7 @@ YR_MAX_SRC = 4
 ACT = {'none': 0, None: 0, 'relu6': 1, 'swish': 2, 'sigmoid': 3, 'leaky': 4}
 XFORM = {'identity': 0, 'up2': 1, 'maxpool2': 2, 'maxpool4': 3, 'up2_add': 4, 'dw3': 5}
 OP_STEM, OP_POINTWISE, OP_DEPTHWISE, OP_SE_MEAN, OP_SE_FC, OP_WSUM, OP_GATHER, OP_MBCONV = 1, 2, 3, 4, 5, 6, 7, 8
-OP_STEMBLOCK, OP_MBLANE, OP_MBH, OP_MBX, OP_MBR, OP_MBE = 9, 10, 11, 12, 13, 14
+OP_STEMBLOCK, OP_MBLANE, OP_MBH, OP_MBX, OP_MBR, OP_MBE, OP_HEAD = 9, 10, 11, 12, 13, 14, 15
 # yr_dtype: element type of activation tensors / pointwise weights (include/yoloret_hip.h)
 DTYPE = {'f32': 0, 'float32': 0, None: 0, 'bf16': 1, 'bfloat16': 1, 'f16': 2, 'float16': 2, 'u8': 3, 'uint8': 3}   # (u8: images only)
 DTYPE_NAME = {0: 'f32', 1: 'bf16', 2: 'f16', 3: 'u8'}
@@ -55,7 +55,7 @@ def from_bits16(b, dtype):
         return b.view(np.float16).astype(np.float32)
     return (b.astype(np.uint32) << 16).view(np.float32)
 OP_NAMES = {1: 'stem', 2: 'pointwise', 3: 'depthwise', 4: 'se_mean', 5: 'se_fc', 6: 'wsum', 7: 'gather', 8: 'mbconv',
-            9: 'stemblock', 10: 'mblane', 11: 'mbh', 12: 'mbx', 13: 'mbr', 14: 'mbe'}
+            9: 'stemblock', 10: 'mblane', 11: 'mbh', 12: 'mbx', 13: 'mbr', 14: 'mbe', 15: 'head'}
 
 
 class YrSrc(ctypes.Structure):
@@ -77,7 +77,12 @@ class YrOp(ctypes.Structure):
                 ('shift', ctypes.c_void_p), ('shift_off', ctypes.c_int64),
                 ('wgt2', ctypes.c_void_p), ('wgt2_off', ctypes.c_int64),
                 ('b1', ctypes.c_void_p), ('b1_off', ctypes.c_int64),
-                ('b2', ctypes.c_void_p), ('b2_off', ctypes.c_int64)]
+                ('b2', ctypes.c_void_p), ('b2_off', ctypes.c_int64),
+                # ABI 7: the SE tail (squeeze-excite finished by the op that produces the map)
+                ('gate_out', ctypes.c_void_p), ('gate_out_buf', ctypes.c_int32), ('gate_out_ld', ctypes.c_int32),
+                ('se_hidden', ctypes.c_int32), ('reserved0', ctypes.c_int32),
+                ('se_w', ctypes.c_void_p), ('se_w_off', ctypes.c_int64),
+                ('sync', ctypes.c_void_p)]
 
 
 class YrBuf(ctypes.Structure):
@@ -85,9 +90,9 @@ class YrBuf(ctypes.Structure):
                 ('external_slot', ctypes.c_int32), ('dtype', ctypes.c_int32)]
 
 
-ABI_VERSION = 6   # == YR_ABI_VERSION of include/yoloret_hip.h
+ABI_VERSION = 7   # == YR_ABI_VERSION of include/yoloret_hip.h
 EXPORTS = ['yr_last_error', 'yr_abi_version', 'yr_abi_sizeof', 'yr_create', 'yr_create_from_blob', 'yr_plan_io_dims', 'yr_destroy', 'yr_load_weights', 'yr_workspace_bytes',
-           'yr_forward', 'yr_forward_profile', 'yr_autotune', 'yr_get_tuning', 'yr_set_tuning', 'yr_plan_num_launches', 'yr_op_run', 'yr_decode', 'yr_decode_zoom', 'yr_yolo_head', 'yr_correct_boxes',
+           'yr_forward', 'yr_forward_profile', 'yr_autotune', 'yr_get_tuning', 'yr_set_tuning', 'yr_plan_num_launches', 'yr_op_run', 'yr_head_regions', 'yr_decode', 'yr_decode_zoom', 'yr_yolo_head', 'yr_correct_boxes',
            'yr_nms', 'yr_pack_detections', 'yr_letterbox', 'yr_letterbox_batch']
 
 _lib = None
@@ -127,6 +132,7 @@ def lib():
         L.yr_get_tuning.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.yr_set_tuning.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.yr_op_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.yr_head_regions.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.yr_decode.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 5
         L.yr_decode_zoom.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_float] * 2 + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 5
         L.yr_yolo_head.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + \
@@ -192,8 +198,8 @@ def new_op(kind, act='none'):
     op = YrOp()
     op.kind = kind
     op.act = ACT[act] if not isinstance(act, int) else act
-    op.out_buf = op.res_buf = op.gate_buf = -1
-    for f in ('wgt_off', 'scale_off', 'shift_off', 'wgt2_off', 'b1_off', 'b2_off'):
+    op.out_buf = op.res_buf = op.gate_buf = op.gate_out_buf = -1
+    for f in ('wgt_off', 'scale_off', 'shift_off', 'wgt2_off', 'b1_off', 'b2_off', 'se_w_off'):
         setattr(op, f, -1)
     return op
 
