@@ -186,6 +186,11 @@ typedef enum {
                             32 j + 8 g + i of s], zero beyond the source / beyond F; h plane, then m = f16((w - h) 2^11)) - the LDS-direct
                             kernel (identity / up-sampled sources only; yoloret_amd.compiler.head_pack);
                             wgt2 = float32 [10][round_up(F, 4)]: the nine depthwise taps (ky, kx) x depthwise BN scale | depthwise BN shift.
+                            k bit 6 (0x40): the WALKING form (headwalk.hip: a wave walks a strip of 16 columns with the weights of its cout tiles
+                            in registers - YR_OP_MBE's scheme; identity sources only, at most 7 chunks of 32 channels, F % 16 == 0, conv
+                            activation ReLU6 / none): wgt = the planes of bit 7 WITH the conv's BN scale folded in, scale = that BN scale [F],
+                            shift unused, wgt2 = [F / 16][11][16]: depthwise taps x BN scale | depthwise BN shift | conv BN shift (YR_OP_MBR's
+                            table); se_reduced = yr_head_walk_rows(h, w).
                             res / res_ld (optional) = the float32 SE gate vector [B][res_ld] multiplied onto the single identity source on load
                             (`gate` is taken by the sums this op writes); k bits 16-23 (optional) = cout tiles of 16 per workgroup.
                             SE tail: gate = OUTPUT float32 [B][se_reduced][gate_ld] channel sums, one row per region (se_reduced = regions per
@@ -318,6 +323,8 @@ int yr_op_run(const yr_op* op, int batch, void* stream);
 /* How a YR_OP_HEAD launch cuts an h x w map into nsy x nsx regions (a function of the shape alone): the rows of the squeeze-excite
  * sums buffer such an op writes per image = nsy * nsx (its se_reduced). */
 int yr_head_regions(int h, int w, int32_t* nsy, int32_t* nsx);
+/* ... and of the WALKING form of YR_OP_HEAD (k bit 6): rows = strips of 14 columns x row segments (its se_reduced). */
+int yr_head_walk_rows(int h, int w, int32_t* rows);
 
 /* ---- preprocessing (the step before the path): decoded uint8 [ih,iw,3] image (device) ->
  * letterboxed float32 [H,W,3] network input.  Replaces tf.io.decode_image(dtype=float32)'s /255

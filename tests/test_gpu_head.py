@@ -46,6 +46,14 @@ def se_params(rng, c, r):
     return w1, b1, w2, b2
 
 
+def walk_ok(segs, f, pre, gated, conv_act):
+    """compiler.fuse_head_blocks' rule for the walking form"""
+    nk = sum((c + 31) // 32 for c, _ in segs)
+    nt = 2 if nk <= 4 else 1
+    return (all(xf == 'identity' for _, xf in segs) and len(segs) <= 3 and nk <= 7 and f % 16 == 0 and (f // 16) % nt == 0 and (f // 16 // nt) % 4 == 0
+            and conv_act in ('relu6', 'none') and not (gated and pre))
+
+
 def se_gate_ref(y, w1, b1, w2, b2):
     mean = nn.mean_hw(y.astype(np.float64)).astype(np.float64)
     hid = mean @ w1.astype(np.float64) + b1
@@ -53,10 +61,12 @@ def se_gate_ref(y, w1, b1, w2, b2):
     return 1.0 / (1.0 + np.exp(-(hid @ w2.astype(np.float64) + b2)))
 
 
-def run_head(dev, rng, b, h, w, segs, f, pre=False, gated=False, se=None, conv_act='relu6', dw_act='swish', tail=True, scale_x=1.0, cfg=0, tile=False, packed=None):
+def run_head(dev, rng, b, h, w, segs, f, pre=False, gated=False, se=None, conv_act='relu6', dw_act='swish', tail=True, scale_x=1.0, cfg=0, tile=False, form=None):
     """segs: [(channels, xform)] of the conv's concatenated sources; pre: an up-sampled pre-BN addend (YR_X_UP2_ADD);
     gated: SE gate on the (single identity) source; se: hidden width R (None: no squeeze-excite sums at all); tail: the op also
-    runs the FC pair (False: sums only); tile: every image of the batch is the same image (drawn once).  -> (map, gate | None)"""
+    runs the FC pair (False: sums only); tile: every image of the batch is the same image (drawn once); form: 'walk' (headwalk.hip),
+    'dma' (headblock.hip, LDS-direct), 'pws' (headblock.hip, register-staged gathers) or None = what the compiler would pick.
+    -> (map, gate | None)"""
     rt = _rt()
     nb = b
     if tile:
@@ -102,12 +112,19 @@ def run_head(dev, rng, b, h, w, segs, f, pre=False, gated=False, se=None, conv_a
     out = torch.full((b, h, w, ldf), float('nan'), dtype=torch.float32, device=dev)
     op = rt.new_op(rt.OP_HEAD, dw_act)
     op.h, op.w, op.cin, op.cout, op.stride = h, w, cin, f, 1
-    if packed is None:      # the LDS-direct kernel wherever it applies (no pooled source), as the compiler chooses
-        packed = all(xf in ('identity', 'up2') for _, xf in segs) and len(segs) <= 3
-    op.k = 3 | rt.ACT[conv_act] << 8 | cfg << 16 | (0x80 if packed else 0)
-    if packed:
-        from yoloret_amd.compiler import head_pack
+    if form is None:
+        form = 'walk' if walk_ok(segs, f, pre, gated, conv_act) else 'dma' if all(xf in ('identity', 'up2') for _, xf in segs) and len(segs) <= 3 else 'pws'
+    op.k = 3 | rt.ACT[conv_act] << 8 | cfg << 16 | {'walk': 0x40, 'dma': 0x80, 'pws': 0}[form]
+    from yoloret_amd.compiler import head_pack
+    if form == 'dma':
         wt = head_pack(wt, [c for c, _ in segs])
+    elif form == 'walk':      # planes with the conv's BN scale folded in; YR_OP_MBR's tap table [T][11][16]
+        wt = head_pack((wt * cs[:, None]).astype(np.float32), [c for c, _ in segs])
+        t16 = f // 16
+        tab = np.zeros((t16, 11, 16), np.float32)
+        tab[:, :9] = (dk.reshape(9, f) * ds[None]).astype(np.float32).reshape(9, t16, 16).transpose(1, 0, 2)
+        tab[:, 9], tab[:, 10] = dh.reshape(t16, 16), ch.reshape(t16, 16)
+        dwp = tab
     n = 0
     for t, (c, xf) in zip(srcs_dev, segs):
         op.src[n] = rt.make_src(t, c=c, xform=xf)
@@ -127,8 +144,11 @@ def run_head(dev, rng, b, h, w, segs, f, pre=False, gated=False, se=None, conv_a
     op.out, op.out_ld = out.data_ptr(), ldf
     sums = gate_out = None
     if se is not None:
-        nsy, nsx = ctypes.c_int32(), ctypes.c_int32()
-        rt.check(rt.lib().yr_head_regions(h, w, ctypes.byref(nsy), ctypes.byref(nsx)))
+        nsy, nsx = ctypes.c_int32(), ctypes.c_int32(1)
+        if form == 'walk':
+            rt.check(rt.lib().yr_head_walk_rows(h, w, ctypes.byref(nsy)))
+        else:
+            rt.check(rt.lib().yr_head_regions(h, w, ctypes.byref(nsy), ctypes.byref(nsx)))
         rows = nsy.value * nsx.value
         sums = torch.full((b, rows, ldf), float('nan'), dtype=torch.float32, device=dev)
         op.gate, op.gate_ld, op.se_reduced = sums.data_ptr(), ldf, rows
@@ -168,14 +188,24 @@ HEAD_CASES = [
     (7, 5, [(40, 'identity')], 20, False, False, 1),
     (104, 104, [(24, 'identity')], 144, False, False, 6),                      # an SE-EfficientNet stage-2 block in float32
     (9, 31, [(16, 'maxpool4'), (20, 'identity')], 36, False, False, 9),
+    # more shapes of the walking form: three sources, 5 / 7 chunks, a partial last quad (75 of 76), a map of 15 columns (two strips, one column)
+    (15, 15, [(40, 'identity'), (75, 'identity'), (64, 'identity')], 64, False, False, 16),
+    (28, 30, [(160, 'identity')], 128, True, False, 32),
+    (13, 13, [(96, 'identity'), (128, 'identity')], 64, False, False, 8),
 ]
 
 
+@pytest.mark.parametrize('form', ['walk', 'dma', 'pws'])
 @pytest.mark.parametrize('case', HEAD_CASES, ids=[str(i) for i in range(len(HEAD_CASES))])
-def test_head_block(dev, case):
+def test_head_block(dev, case, form):
+    """every case in every form that takes it (the compiler picks walk > dma > pws)"""
     h, w, segs, f, pre, gated, r = case
+    if form == 'walk' and not walk_ok(segs, f, pre, gated, 'relu6'):
+        pytest.skip('shape not built in the walking form')
+    if form == 'dma' and not (all(xf in ('identity', 'up2') for _, xf in segs) and len(segs) <= 3):
+        pytest.skip('pooled sources stay on the register-staged form')
     rng = np.random.default_rng(zlib.crc32(str(case).encode()))
-    run_head(dev, rng, 3, h, w, segs, f, pre=pre, gated=gated, se=r)
+    run_head(dev, rng, 3, h, w, segs, f, pre=pre, gated=gated, se=r, form=form)
 
 
 def test_head_block_variants(dev):

@@ -50,9 +50,15 @@ def main():
                (rng.standard_normal((f, kp)) * np.sqrt(2.0 / cin), rng.uniform(0.5, 1.5, f), rng.normal(0, 0.3, f), rng.standard_normal((10, f)) * 0.3,
                 rng.standard_normal(f * ru(r, 4) + r * f + ru(r, 4) + f) * 0.05)]
         op.nsrc, op.h, op.w, op.cin, op.cout, op.stride = n, h, w, cin, f, 1
-        packed = all(xf in ('identity', 'up2') for _, xf in segs)
+        import os
+        nk = sum((c + 31) // 32 for c, _ in segs)
+        walk = os.environ.get('YR_HEAD_FORM', 'walk') == 'walk' and all(xf == 'identity' for _, xf in segs) and nk <= 7 and not (gated and pre)
+        packed = not walk and all(xf in ('identity', 'up2') for _, xf in segs)
         if packed:
             par[0] = torch.from_numpy(head_pack(par[0].cpu().numpy(), [c for c, _ in segs])).to(dev)
+        if walk:
+            par[0] = torch.from_numpy(head_pack(par[0].cpu().numpy() * par[1].cpu().numpy()[:, None], [c for c, _ in segs])).to(dev)
+            par[3] = torch.from_numpy((rng.standard_normal((f // 16, 11, 16)) * 0.3).astype(np.float32)).to(dev)
         op.wgt, op.scale, op.shift, op.wgt2 = [p.data_ptr() for p in par[:4]]
         if gated:
             g = torch.rand((b, kp), device=dev)
@@ -60,7 +66,11 @@ def main():
             op.res, op.res_ld = g.data_ptr(), kp
         out = torch.empty((b, h, w, f), dtype=torch.float32, device=dev)
         nsy, nsx = ctypes.c_int32(), ctypes.c_int32()
-        rt.check(rt.lib().yr_head_regions(h, w, ctypes.byref(nsy), ctypes.byref(nsx)))
+        nsx = ctypes.c_int32(1)
+        if walk:
+            rt.check(rt.lib().yr_head_walk_rows(h, w, ctypes.byref(nsy)))
+        else:
+            rt.check(rt.lib().yr_head_regions(h, w, ctypes.byref(nsy), ctypes.byref(nsx)))
         rows = nsy.value * nsx.value
         sums = torch.empty((b, rows, f), dtype=torch.float32, device=dev)
         gate = torch.empty((b, f), dtype=torch.float32, device=dev)
@@ -70,7 +80,7 @@ def main():
         op.gate_out, op.gate_out_ld, op.se_hidden, op.se_w, op.sync = gate.data_ptr(), f, r, par[4].data_ptr(), sync.data_ptr()
         moved = sum(t.numel() * 4 for t in keep) + out.numel() * 4
         for cfg in cfgs:
-            op.k = 3 | 1 << 8 | cfg << 16 | (0x80 if packed else 0)
+            op.k = 3 | 1 << 8 | cfg << 16 | (0x80 if packed else 0x40 if walk else 0)
             for _ in range(3):
                 rt.run_op(op, b)
             torch.cuda.synchronize()
@@ -81,7 +91,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / 30 * 1e3
-            print('%s %dx%d K %3d F %3d regions %dx%d cfg %d  %6.1f us  %5.2f TB/s moved  (unfused chain: %.1f us)' % (name, h, w, kp, f, nsy.value, nsx.value, cfg, us, moved / us * 1e-6, old), flush=True)
+            print('%s %dx%d K %3d F %3d rows %dx%d cfg %d  %6.1f us  %5.2f TB/s moved  (unfused chain: %.1f us)' % (name, h, w, kp, f, nsy.value, nsx.value, cfg, us, moved / us * 1e-6, old), flush=True)
 
 
 if __name__ == '__main__':

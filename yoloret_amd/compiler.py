@@ -734,6 +734,8 @@ FUSE_HEAD = os.environ.get('YOLORET_FUSE_HEAD', '1') != '0'
 FUSE_HEAD_ALL = os.environ.get('YOLORET_FUSE_HEAD', '1') == '2'     # also conv -> depthwise pairs without squeeze-excite sums
 SE_TAIL = os.environ.get('YOLORET_SE_TAIL', '1') != '0'
 SE_TAIL_LDS = 4608 - 1024 - 4      # == YR_SE_TAIL_LDS - 4 * 256 threads (se_tail.h): channels + hidden units the tail's LDS scratch holds
+HEAD_WALK_MAX_NK = int(os.environ.get('YOLORET_HEAD_WALK_MAX_NK', '4'))   # (measured, MobileNetV2 x0.75 @416 batch 64: 1 chunk 52 us against the LDS-direct kernel's 95, 4 chunks 96 | 124, 6 chunks 85 | 82, 7 chunks 96 | 84: one tile per wave and 250 registers from 5 chunks on)
+HEAD_WALK = os.environ.get('YOLORET_HEAD_WALK', '1') != '0'   # head blocks of at most 7 chunks of 32 identity-source channels on the walking kernel (headwalk.hip)
 HEAD_DMA = os.environ.get('YOLORET_HEAD_DMA', '1') != '0'   # head blocks without a pooled source on the LDS-direct kernel
 
 
@@ -755,6 +757,17 @@ def head_regions(h, w):
     if best is None:
         raise ValueError('head_regions: a %d x %d map has no region split' % (h, w))
     return best[1], best[2]
+
+
+def head_walk_rows(h, w):
+    """== yr_head_walk_rows (headwalk.hip): rows of the squeeze-excite sums the walking form of YR_OP_HEAD writes per image -
+    strips of 14 columns x row segments of about 13 rows (a function of the shape)."""
+    if h <= 16:
+        sr = h
+    else:
+        ns = (h + 12) // 13
+        sr = (h + ns - 1) // ns
+    return ((w + 13) // 14) * ((h + sr - 1) // sr)
 
 
 def head_pack(wt, seg_c, V=4):
@@ -812,10 +825,28 @@ def fuse_head_blocks(ops, bufs, output_buf_ids):
         m.fused = [c, d]
         m.params = {'wgt': c.params['wgt'], 'scale': c.params['scale'], 'shift': c.params['shift']}
         kseg = [s_.c for s_ in c.srcs if s_.xform != 'up2_add']
-        if all(s_.xform in ('identity', 'up2', 'up2_add') for s_ in c.srcs) and len(kseg) <= 3 and HEAD_DMA:
+        nk = sum((c_ + 31) // 32 for c_ in kseg)
+        nt = 2 if nk <= 4 else 1
+        walk = (HEAD_WALK and all(s_.xform in ('identity', 'up2_add') for s_ in c.srcs) and len(kseg) <= 3 and nk <= HEAD_WALK_MAX_NK and F % 16 == 0 and (F // 16 // nt) % 4 == 0
+                and F // 16 % nt == 0 and c.act in ('relu6', 'none') and not (c.gate is not None and len(kseg) != len(c.srcs)) and F * 11 * 4 <= 64 * 1024)
+        if walk:
+            # the walking form (headwalk.hip, k bit 6): weights as float16 planes with the conv's BN scale folded in, YR_OP_MBR's tap table
+            m.k |= 0x40
+            cp = c.params
+
+            def planes(wd, cp=cp, kseg=kseg, F=F):
+                return head_pack((cp['wgt'][1](wd)[:F] * cp['scale'][1](wd)[:F, None]).astype(np.float32), kseg)
+
+            def tab(wd, cp=cp, dp=dp, F=F):
+                T = F // 16
+                o = np.zeros((T, 11, 16), np.float32)
+                o[:, :9] = (dp['wgt'][1](wd).reshape(9, -1)[:, :F] * dp['scale'][1](wd)[None, :F]).astype(np.float32).reshape(9, T, 16).transpose(1, 0, 2)
+                o[:, 9], o[:, 10] = dp['shift'][1](wd)[:F].reshape(T, 16), cp['shift'][1](wd)[:F].reshape(T, 16)
+                return o
+            m.params = {'wgt': (((F // 16) * nk * 512,), planes), 'scale': c.params['scale'], 'wgt2': ((F // 16, 11, 16), tab)}
+        elif all(s_.xform in ('identity', 'up2', 'up2_add') for s_ in c.srcs) and len(kseg) <= 3 and HEAD_DMA:
             # no pooled source: the LDS-direct kernel, weights as float16 planes in fragment order (k bit 7)
             m.k |= 0x80
-            nk = sum((c_ + 31) // 32 for c_ in kseg)
             m.params['wgt'] = ((((F + 15) // 16) * nk * 512,), lambda wd, wf=c.params['wgt'][1], kseg=kseg: head_pack(wf(wd), kseg))
         dp = d.params
 
@@ -824,9 +855,10 @@ def fuse_head_blocks(ops, bufs, output_buf_ids):
             o[:9, :F] = (dp['wgt'][1](wd).reshape(9, -1)[:, :F] * dp['scale'][1](wd)[None, :F]).astype(np.float32)
             o[9, :F] = dp['shift'][1](wd)[:F]
             return o
-        m.params['wgt2'] = ((10, ldf), dw_rows)
-        if d.gate is not None:     # the squeeze-excite sums: one row per region
-            nsy, nsx = head_regions(d.h, d.w)
+        if not walk:
+            m.params['wgt2'] = ((10, ldf), dw_rows)
+        if d.gate is not None:     # the squeeze-excite sums: one row per region (per strip and row segment in the walking form)
+            nsy, nsx = (head_walk_rows(d.h, d.w), 1) if walk else head_regions(d.h, d.w)
             part = d.gate
             part.h, part.w = nsy * nsx, 1
             part.elems = part.h * part.w * part.ld

@@ -113,7 +113,7 @@ __device__ __forceinline__ void head_finish(const HeadArgs& h, const HeadRegion&
     // its tiles.  The addend's loads are all issued before the first is used (one exposed round trip, not PT * CT).
     {
         const int g = lane >> 4, li = lane & 15;
-        const bool use_pre = a.pre != nullptr && !(h.exp & 4);
+        const bool use_pre = a.pre != nullptr && !(h.exp & 4), conv_relu6 = a.act == YR_ACT_RELU6;
         f32x4 pq[PT][CT];
         if (use_pre) {   // uniform
 #pragma unroll
@@ -140,7 +140,14 @@ __device__ __forceinline__ void head_finish(const HeadArgs& h, const HeadRegion&
                 f32x4 v = ac1[c][p] * 0.00048828125f + acc[c][p];
                 if (use_pre) v += pq[p][c];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = yr_apply_act(__builtin_fmaf(v[r], sc[r], sh[r]), a.act);
+                for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], sc[r], sh[r]);
+                if (conv_relu6) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], 0.f, 6.f);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = yr_apply_act(v[r], a.act);
+                }
                 *reinterpret_cast<f32x4*>(E + m * ELD + nl) = v;
             }
         }
@@ -170,6 +177,7 @@ __device__ __forceinline__ void head_finish(const HeadArgs& h, const HeadRegion&
     if (ng > NY) ng = NY;
     const int nitems = NX * QN * ng;
     f32x4 psum = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool dw_swish = h.dw_act == YR_ACT_SWISH, dw_relu6 = h.dw_act == YR_ACT_RELU6;
     if (!(h.exp & 2)) {
         for (int item = tid; item < nitems; item += NTH) {
             const int xi = (item / QN) % NX, grp = item / (QN * NX);
@@ -204,8 +212,16 @@ __device__ __forceinline__ void head_finish(const HeadArgs& h, const HeadRegion&
                 }
                 if (r - 1 >= ya) {   // output row r - 1 is complete (r - 1 < yb holds inside the loop)
                     f32x4 v = (f32x4){a0[0][0], a0[0][1], a0[1][0], a0[1][1]};
+                    if (dw_swish) {         // (uniform branches: a per-element switch made the compiler evaluate the pinned-expf paths as well)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = h.dw_act == YR_ACT_SWISH ? head_swish(v[i]) : yr_apply_act(v[i], h.dw_act);
+                        for (int i = 0; i < 4; ++i) v[i] = head_swish(v[i]);
+                    } else if (dw_relu6) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_fmed3f(v[i], 0.f, 6.f);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = yr_apply_act(v[i], h.dw_act);
+                    }
                     if (chan_ok) {
                         *reinterpret_cast<f32x4*>(outp + (size_t)(r - 1) * a.W * a.out_ld) = v;
                         psum += v;
@@ -373,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void head2_kernel(HeadArgs h) {
             __syncthreads();                                    // ... everybody's; everybody is done with the other stage
             if (ck + 1 < nk) {
                 const int ci = ck + 1, stage = ci & 1;
-        const int s = ci < n0c ? 0 : ck < n0c + n1c ? 1 : 2;
+                const int s = ci < n0c ? 0 : ci < n0c + n1c ? 1 : 2;
                 const int kl = (ci - (s == 0 ? 0 : s == 1 ? n0c : n0c + n1c)) * 32;
                 const int cs = s == 0 ? c0 : s == 1 ? c1 : c2;
                 const int cq = (cs + 3) & ~3;                          // whole quads of the source (a partial last quad is masked at the fragment)
@@ -483,6 +499,7 @@ static int launch_head(const HeadArgs& h, int batch, hipStream_t s) {
 
 int yr_launch_head(const yr_op& op, int batch, hipStream_t s) {
     YR_REQUIRE(op.dtype == YR_F32 && op.out_dtype == YR_F32, "head: float32 plans only");
+    if (op.k & 0x40) return yr_launch_head_walk(op, batch, s);   // the walking form (headwalk.hip)
     YR_REQUIRE((op.k & 0x7f) == 3 && op.stride == 1, "head: depthwise 3x3, stride 1");
     YR_REQUIRE(op.out && op.wgt && op.wgt2, "head: null pointer");
     const bool v2 = (op.k & 0x80) != 0;     // the weights are float16 planes in fragment order (compiler.head_pack)

@@ -164,8 +164,8 @@ static int64_t param_floats(const yr_op& op, int role) {   // role: 0 wgt, 1 sca
     }
     switch (op.kind) {
         case YR_OP_HEAD:
-            if (role == 3) return 10 * ru(op.cout, 4);
-            if (role == 0 && (op.k & 0x80)) {   // float16 planes in fragment order, 32-channel chunks per source
+            if (role == 3) return (op.k & 0x40) ? (int64_t)(op.cout / 16) * 176 : 10 * ru(op.cout, 4);
+            if (role == 0 && (op.k & 0xc0)) {   // float16 planes in fragment order, 32-channel chunks per source
                 int64_t nk = 0;
                 for (int i = 0; i < op.nsrc; ++i)
                     if (op.src[i].xform != YR_X_UP2_ADD) nk += (op.src[i].c + 31) / 32;

@@ -53,6 +53,7 @@ int yr_launch_stemxp(const yr_op& op, int batch, hipStream_t s);   // mbxr_h.hip
 int yr_launch_mbr(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_mbe(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_head(const yr_op& op, int batch, hipStream_t s);      // headblock.hip
+int yr_launch_head_walk(const yr_op& op, int batch, hipStream_t s); // headwalk.hip (YR_OP_HEAD with k bit 6)
 int yr_pointwise_num_cfgs(int dtype);
 
 static inline int yr_round_up(int v, int m) { return (v + m - 1) / m * m; }
