@@ -16,6 +16,7 @@ the oracle's torch-CPU port timed on this box's host cores (N=1, rank 0 only).
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -59,6 +60,7 @@ def parse():
                          'all-gather (one RCCL rank: depth 3 28.2k img/s against 28.3k without the collective, depth 2 26.9k)')
     ap.add_argument('--no-latency', action='store_true',
                     help='skip the batch-1 p50 loop (use under rocprofv3 so that every launch is a batch-%d launch)' % 64)
+    ap.add_argument('--no-fp32-forms', action='store_true', help='skip the sub-run with every float32 GEMM on the float32 MFMA')
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the short runs of BASELINE.json configs 3, 4, 5 (and the SE EfficientNets) that the default 1-GPU run attaches as `other_configs`')
     return ap.parse_args()
@@ -117,6 +119,12 @@ def other_configs(dev, anchors, classes, steps, depth, budget_s=75.0):
                     'dtype': dt, 'launches_per_step': len(plan.ops) + 4,
                     'workload': '%s @%d, batch %d (one GPU\'s share), %s, C=%d, same recipe and pipeline as the headline' % (name, size, b, dt, classes),
                     'setup_and_run_s': round(time.perf_counter() - t_cfg, 1)}
+        if dt == 'f32':   # the float32-compute axis (the contract figure of a float32 plan since round 5: see roofline_step)
+            fl = 2.0 * plan.total_macs()
+            res[tag]['fp32_frac'] = round(out[depth] * fl / 1e12 / FP32_PEAK_TFLOPS, 4)
+            res[tag]['serial_fp32_frac'] = round(out[1] * fl / 1e12 / FP32_PEAK_TFLOPS, 4)
+            res[tag]['fp32_roofline_img_s'] = round(FP32_PEAK_TFLOPS * 1e12 / fl, 0)
+        res[tag]['fallback_ops'] = plan.fallback_ops()
         if dt != 'f32':   # (tests/test_gpu_narrow.py, tests/test_gpu_fullbatch.py: measured against the float32 oracle on the conditioned recipe)
             res[tag]['accuracy_note'] = ('16-bit storage plan: logits are NOT within 1e-4 of the float32 reference - scaled max / mean logit error vs '
                                          'the float32 oracle and the share of its detections reproduced are in README.md (16-bit plans) and profiles/')
@@ -129,6 +137,42 @@ def canon_symbol(name):
     """Kernel symbol in one spelling: no spaces, bools as 1/0, element types as f32/bf16/f16."""
     name = name.replace(' ', '').replace('true', '1').replace('false', '0')
     return name.replace('__bf16', 'bf16').replace('_Float16', 'f16').replace('float', 'f32')
+
+
+def parked_share(symbol):
+    """{'wait_any_share', 'source'} of `symbol` from the newest committed SQ pass (profiles/rNN_pmc_sq*.txt: rows of kernel, counter,
+    calls, avg_per_launch, sum - tools/rocpd_summary.py), or None."""
+    import glob
+    want = canon_symbol(symbol)
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_sq*.txt')) + glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_*block*.txt')), reverse=True):
+        vals = {}
+        try:
+            for line in open(f):
+                m = re.match(r'^(\S.*?)\s+(SQ_WAVE_CYCLES|SQ_WAIT_ANY)\s+\d+\s+([0-9.]+)', line)
+                if m and (canon_symbol(m.group(1)) == want or canon_symbol(m.group(1)).startswith(want[:-1] + ',')):
+                    vals[m.group(2)] = float(m.group(3))
+        except OSError:
+            continue
+        if 'SQ_WAVE_CYCLES' in vals and 'SQ_WAIT_ANY' in vals and vals['SQ_WAVE_CYCLES'] > 0:
+            return {'wait_any_share': round(vals['SQ_WAIT_ANY'] / vals['SQ_WAVE_CYCLES'], 4), 'source': os.path.relpath(f, ROOT)}
+    return None
+
+
+def fp32_mfma_forms(a):
+    """The same headline run with every float32 GEMM on the float32 MFMA (YOLORET_MBR_SPLIT=0 YOLORET_PW_SPLIT=0; the head-block
+    kernels exist in the split form only: YOLORET_FUSE_HEAD=0) - for a strict reader of `dtype: f32`.  A sub-process: the library
+    reads the switches once."""
+    import subprocess
+    env = dict(os.environ, YOLORET_MBR_SPLIT='0', YOLORET_PW_SPLIT='0', YOLORET_FUSE_HEAD='0', YOLORET_TUNE_CACHE='')
+    cmd = [sys.executable, os.path.abspath(__file__), '--steps', '20', '--warmup', str(a.warmup), '--batch', str(a.batch), '--model', a.model, '--size', str(a.size),
+           '--classes', str(a.classes), '--no-cpu-baseline', '--no-latency', '--no-other-configs', '--no-fp32-forms', '--depth', str(a.depth)]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return {'img_s': d['value'], 'serial_img_s': (d.get('serial_steps') or {}).get('img_s'), 'steps': 20,
+                'switches': 'YOLORET_MBR_SPLIT=0 YOLORET_PW_SPLIT=0 YOLORET_FUSE_HEAD=0 (v_mfma_f32_16x16x4_f32 for every 1x1 convolution)'}
+    except Exception as e:
+        return {'error': str(e)[:200]}
 
 
 def cpu_model():
@@ -248,6 +292,10 @@ def main():
     b = a.batch
     x = torch.from_numpy(W.synthetic_images(b, a.size, a.size, seed=20240416 + rank)).to(dev)
     image_hw = torch.tensor([[a.size, a.size]] * b, dtype=torch.int32, device=dev)
+    # one resident batch PER STEP IN FLIGHT (different images each): consecutive steps do not re-read one input that sits in the
+    # 256 MiB Infinity Cache (the 133 MB batch of a single buffer did)
+    xs_res = [x] + [torch.from_numpy(W.synthetic_images(b, a.size, a.size, seed=20240416 + rank + 1000 * (i + 1))).to(dev) for i in range(max(a.depth, 1) - 1)]
+    turn_res = [0]
 
     pending = [None]
     consumer = torch.cuda.Stream(dev) if a.depth > 1 else torch.cuda.current_stream(dev)
@@ -256,7 +304,9 @@ def main():
         # N > 1: the all-gather of step i's records runs on a second stream while step i+1's forward is enqueued; its
         # handle is waited for one step later (the final sync() covers the last one).  Every step still contains
         # exactly one collective.
-        det, cnt = pipe(x, image_hw)
+        xi = xs_res[turn_res[0] % len(xs_res)]
+        turn_res[0] += 1
+        det, cnt = pipe(xi, image_hw)
         # (pipeline=pipe: the context that produced these records runs again only after the collective has read them)
         h = gather.start(det, cnt, pipe.record, after=pipe.done, pipeline=pipe)
         if timed_handles is not None and use_dist:
@@ -395,6 +445,7 @@ def main():
             roofline['by_pipe']['frac_fp32_executed'] = round(fr['fp32_executed'], 4)
         # the same per kernel FAMILY: the lane-per-pixel front, the fused MFMA blocks ... are several symbols each
         fams = [('lane_per_pixel_front', ('mblane', 'stemblock', 'stem_')),
+                ('head_blocks', ('head_kernel', 'head2_kernel', 'hwalk_kernel')),
                 ('fused_blocks', ('mbh_kernel', 'mbn_kernel', 'mbr_kernel', 'mbe_kernel', 'mbx_kernel', 'mbxr_kernel', 'mbhr_kernel', 'mbhq_kernel', 'stemxr_kernel', 'stemxp_kernel')),
                 ('pointwise', ('pw_kernel', 'pwd_kernel', 'pws_kernel', 'pwh', 'pwl')), ('depthwise', ('dw_kernel', 'dwp_kernel', 'dwq_kernel', 'dwl')),
                 ('elementwise', ('wsum', 'gather', 'letterbox')),
@@ -415,6 +466,9 @@ def main():
                                           'moved_gbs': round(g_, 1), 'frac_hbm': round(fr_['hbm'], 4), 'fp32_tflops': round(t32_, 2),
                                           'frac_fp32': round(fr_['fp32'], 4), 'mfma16_tflops': round(t16_, 2), 'frac_mfma16': round(fr_['mfma16'], 4)}
         roofline['bytes_per_launch'] = int(d['hbm'] / d['launches'])   # the `achieved` GB/s = this / avg_launch_ms
+        # what the kernel really executes on its busiest resource (a split-form kernel is judged on ALGORITHMIC float32 FLOPs above)
+        roofline['frac_executed'] = round(max(fr['hbm'], fr['mfma16'], fr.get('fp32_executed', fr['fp32'])), 4)
+        roofline['parked'] = parked_share(dom)     # share of wave cycles waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES) from the committed PMC pass, or None
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
         # (profiles/rNN_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KiB, see tools/rocpd_summary.py); None if absent
         pmc_step_bytes = None
@@ -459,14 +513,28 @@ def main():
         moved_min = sum(r.get('hbm_bytes', r['bytes']) for r in rows)     # per step: every op's sources + output
         macs16_img = sum(r.get('macs_mfma16', 0) for r in rows) / b       # multiply-adds per image on the 16-bit matrix pipe
         macs32_img = sum(r.get('macs_fp32', r['macs'] - r.get('macs_mfma16', 0)) for r in rows) / b   # ... on the float32 pipe (fp32 MFMA / packed FMA)
-        fp32_roof = FP32_PEAK_TFLOPS * 1e12 / max(2.0 * macs32_img, 1.0)   # img/s if the float32 pipe were the only limit
         # `achieved` / `frac` follow SURVEY.md 8(d)'s agreed accounting: conv-granular ALGORITHMIC bytes (a fused kernel is
         # credited the bytes of the convolutions it replaces) - a measure of work done per second, NOT of bandwidth used.
         # What actually crosses HBM is `moved_*`: the plan's minimum (each launched op's inputs + output) and, when the
         # committed PMC passes cover this configuration, the measured FETCH/WRITE traffic.
-        roofline_step = {'bound': 'hbm', 'achieved': round(alg_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(alg_gbs / HBM_PEAK_GBS, 4),
-                         'accounting': 'conv-granular algorithmic bytes (SURVEY 8d): credited work, not moved bytes',
+        # Round 5: for the float32 plans that accounting is SATURATED (0.98 in round 4 - one more speed-up and
+        # the credited GB/s exceed the 8 TB/s peak), so the contract figure of a float32 plan is now SURVEY 8(d)'s other roofline - the
+        # ALGORITHMIC float32 FLOPs of the step against the dense float32 peak (2.139 GFLOP per image -> 73.5 k img/s for config 2) - with
+        # the bytes really moved beside it; the credited figure stays as `credited_hbm_frac` (it may exceed 1: it is not a bandwidth).
+        # The 16-bit plans keep the conv-granular HBM figure (0.5-0.65: nowhere near saturated).
+        alg_tf = per_gpu * flops_img / 1e12
+        if a.dtype == 'f32':
+            head = {'bound': 'fp32', 'achieved': round(alg_tf, 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(alg_tf / FP32_PEAK_TFLOPS, 4),
+                    'accounting': 'algorithmic float32 FLOPs per image (SURVEY 8d: %.3f GFLOP) x img/s against the dense float32 MFMA peak; the 1x1 '
+                                  'convolutions execute as three float16-plane products on the 16-bit matrix pipe (tflops_mfma16)' % (flops_img / 1e9),
+                    'fp32_roofline_img_s': round(FP32_PEAK_TFLOPS * 1e12 / flops_img, 0),
+                    'credited_hbm_frac': round(alg_gbs / HBM_PEAK_GBS, 4),
+                    'credited_hbm_note': 'conv-granular algorithmic bytes (SURVEY 8d) / 8 TB/s: credited work, not bandwidth - a fused kernel is credited bytes it never moves, so this may exceed 1'}
+        else:
+            head = {'bound': 'hbm', 'achieved': round(alg_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(alg_gbs / HBM_PEAK_GBS, 4),
+                    'accounting': 'conv-granular algorithmic bytes (SURVEY 8d): credited work, not moved bytes'}
+        roofline_step = dict(head)
+        roofline_step.update({
                          'alg_bytes_per_image': int(alg_img), 'alg_gbs': round(alg_gbs, 1),
                          'moved_bytes_per_image_plan': int(moved_min / b),
                          'moved_gbs_plan': round(moved_min / step_s / 1e9, 1),
@@ -478,12 +546,13 @@ def main():
                          # by pipe: the multiply-adds of a 16-bit plan's 1x1 convolutions run on the 16-bit matrix pipe
                          'tflops_mfma16': round(per_gpu * 2.0 * macs16_img / 1e12, 2),
                          'frac_mfma16_peak': round(per_gpu * 2.0 * macs16_img / 1e12 / MFMA16_PEAK_TFLOPS, 4),
-                         'tflops_fp32': round(per_gpu * 2.0 * macs32_img / 1e12, 2),
-                         'frac_fp32_peak': round(per_gpu * 2.0 * macs32_img / 1e12 / FP32_PEAK_TFLOPS, 4),
-                         'fp32_roofline_img_s': round(fp32_roof, 0),
+                         'tflops_fp32_executed': round(per_gpu * 2.0 * macs32_img / 1e12, 2),
+                         'frac_fp32_peak_executed': round(per_gpu * 2.0 * macs32_img / 1e12 / FP32_PEAK_TFLOPS, 4),
                          'hbm_roofline_img_s': round(HBM_PEAK_GBS * 1e9 / alg_img, 0),
                          'sum_kernel_ms': round(sum(r['ms'] for r in rows), 3),
-                         'launches_per_step': len(rows)}
+                         'launches_per_step': len(rows),
+                         # ops that did NOT get the fused form a whitelist exists for (a shape that is on no list silently runs a slower form)
+                         'fallback_ops': plan.fallback_ops()})
         if a.per_op:
             # `moved`: the op's own sources + output (what must cross HBM); `credited`: the conv-granular accounting
             # of SURVEY 8(d), where a fused / hoisted op carries the bytes and MACs of the convolutions it stands for
@@ -698,6 +767,8 @@ def main():
         if (world == 1 and not a.no_other_configs and not a.force_dist
                 and (a.model, a.size, a.batch, a.dtype) == ('mobilenetv2x75', 416, 64, 'f32')):
             out['other_configs'] = other_configs(dev, anchors, a.classes, max(a.steps, 20), a.depth)
+        if world == 1 and a.dtype == 'f32' and not a.no_fp32_forms and not a.force_dist:
+            out['fp32_mfma_forms'] = fp32_mfma_forms(a)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.model, a.size, a.classes, anchors, a.cpu_seconds)
     if use_dist:

@@ -232,7 +232,8 @@ typedef struct {
      *              scale/shift [cout] (folded BN and/or bias)
      *   DEPTHWISE: wgt = [k*k][round_up(c,V)] ; scale/shift [round_up(c,V)]  (V as above: 4 for float32 ops, 8 for 16-bit ops)
      *   STEM:      wgt = [27][round_up(cout,4)] ; scale/shift [round_up(cout,4)]
-     *   SE_FC:     wgt = W1t[reduced][ldc], b1 [reduced], wgt2 = W2[reduced][ldc], b2 [ldc], ldc = round_up(c,4)
+     *   SE_FC:     wgt = W1[ldc][R4] (ABI 7: the Keras kernel [1,1,C,R] as it is, rows padded to R4 = round_up(reduced, 4)), b1 [R4],
+ *              wgt2 = W2[reduced][ldc], b2 [ldc], ldc = round_up(c,4); all 16-byte aligned
      *   WSUM:      wgt = alpha[4]
      *   (the fused block ops document their packed layouts at their yr_op_kind above) */
     const float* wgt;    int64_t wgt_off;
@@ -305,6 +306,14 @@ int yr_forward(yr_handle* h, const float* images, int batch, float* y1, float* y
 int yr_forward_profile(yr_handle* h, const float* images, int batch, float* y1, float* y2, float* y3,
                        void* workspace, size_t workspace_bytes, void* stream, int iters,
                        float* ms_per_op, const char** kernel_names);
+/* The same pass, instrumented: max_abs_per_op[n_ops] (host) receives the largest |value| among the float32 k-space sources each op
+ * reads (+inf where a NaN was seen; 0 for ops without such sources).  A float32 plan's SPLIT-form ops (POINTWISE without se_reduced bit
+ * 16, MBR / MBE with k bit 7, HEAD) carry their operands as two float16 planes and need |x| < 65504 - the reference's float32
+ * convolutions have no such bound (model.py:20-30; MobileNetV2's linear bottlenecks and residual sums are unclamped, override.py:290-341).
+ * yoloret_amd's Model runs this once per set of weights on its first batch and rebuilds the plan with the ops beyond 60000 on the
+ * float32-MFMA forms (Model.check_ranges); a host without it does the same through this call.  Synchronises the stream. */
+int yr_forward_ranges(yr_handle* h, const float* images, int batch, float* y1, float* y2, float* y3,
+                      void* workspace, size_t workspace_bytes, void* stream, float* max_abs_per_op);
 /* Per-op tile autotuning for `batch` images: times every pointwise tile shape on every pointwise op (and a list of
  * output tiles on every MBH / MBX op) and remembers the fastest for later yr_forward calls with the same batch (numerics do not depend on the
  * shape).  Runs the forward once first; synchronises the stream. */

@@ -49,8 +49,8 @@ def se_params(rng, c, r):
 def walk_ok(segs, f, pre, gated, conv_act):
     """compiler.fuse_head_blocks' rule for the walking form"""
     nk = sum((c + 31) // 32 for c, _ in segs)
-    nt = 2 if nk <= 4 else 1
-    return (all(xf == 'identity' for _, xf in segs) and len(segs) <= 3 and nk <= 7 and f % 16 == 0 and (f // 16) % nt == 0 and (f // 16 // nt) % 4 == 0
+    nt = 2
+    return (all(xf == 'identity' for _, xf in segs) and len(segs) <= 3 and nk <= 4 and f % 16 == 0 and (f // 16) % nt == 0 and (f // 16 // nt) % 4 == 0
             and conv_act in ('relu6', 'none') and not (gated and pre))
 
 
@@ -61,7 +61,7 @@ def se_gate_ref(y, w1, b1, w2, b2):
     return 1.0 / (1.0 + np.exp(-(hid @ w2.astype(np.float64) + b2)))
 
 
-def run_head(dev, rng, b, h, w, segs, f, pre=False, gated=False, se=None, conv_act='relu6', dw_act='swish', tail=True, scale_x=1.0, cfg=0, tile=False, form=None):
+def run_head(dev, rng, b, h, w, segs, f, pre=False, gated=False, se=None, conv_act='relu6', dw_act='swish', tail=True, scale_x=1.0, cfg=0, tile=False, form=None, xgen=None):
     """segs: [(channels, xform)] of the conv's concatenated sources; pre: an up-sampled pre-BN addend (YR_X_UP2_ADD);
     gated: SE gate on the (single identity) source; se: hidden width R (None: no squeeze-excite sums at all); tail: the op also
     runs the FC pair (False: sums only); tile: every image of the batch is the same image (drawn once); form: 'walk' (headwalk.hip),
@@ -74,7 +74,7 @@ def run_head(dev, rng, b, h, w, segs, f, pre=False, gated=False, se=None, conv_a
     srcs_np, srcs_dev = [], []
     for c, xf in segs:
         sh, sw = _src_dims(h, w, xf)
-        a = np.repeat((rng.standard_normal((b, sh, sw, c)) * scale_x).astype(np.float32), nb // b, axis=0)
+        a = np.repeat((rng.standard_normal((b, sh, sw, c)) * scale_x).astype(np.float32) if xgen is None else xgen(rng, (b, sh, sw, c)), nb // b, axis=0)
         srcs_np.append(a)
         srcs_dev.append(to_dev(a, dev))
     cin = sum(c for c, _ in segs)
@@ -169,6 +169,7 @@ def run_head(dev, rng, b, h, w, segs, f, pre=False, gated=False, se=None, conv_a
         if tail:
             assert int(keep[-1].abs().sum().item()) == 0, 'arrival counters were not reset'
             assert_close(from_dev(gate_out, f), se_gate_ref(y, *sp).reshape(b, f), TOL, 'head: squeeze-excite gate (SE tail)')
+    run_head.last = dict(x=x, wk=wk, cs=cs, ch=ch, dk=dk, ds=ds, dh=dh, y=y, srcs=srcs_np, segs=segs, conv_act=conv_act, dw_act=dw_act)   # (tests/test_gpu_split_range.py)
     return got, (from_dev(gate_out, f) if gate_out is not None else None)
 
 
@@ -188,8 +189,9 @@ HEAD_CASES = [
     (7, 5, [(40, 'identity')], 20, False, False, 1),
     (104, 104, [(24, 'identity')], 144, False, False, 6),                      # an SE-EfficientNet stage-2 block in float32
     (9, 31, [(16, 'maxpool4'), (20, 'identity')], 36, False, False, 9),
-    # more shapes of the walking form: three sources, 5 / 7 chunks, a partial last quad (75 of 76), a map of 15 columns (two strips, one column)
+    # more shapes: three sources, a partial last quad (75 of 76), a map of 15 columns (two strips, one column), four chunks from two sources
     (15, 15, [(40, 'identity'), (75, 'identity'), (64, 'identity')], 64, False, False, 16),
+    (15, 15, [(24, 'identity'), (75, 'identity')], 128, False, False, 16),
     (28, 30, [(160, 'identity')], 128, True, False, 32),
     (13, 13, [(96, 'identity'), (128, 'identity')], 64, False, False, 8),
 ]

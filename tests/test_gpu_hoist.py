@@ -75,7 +75,7 @@ def test_compiler_hoists_the_top_down_convs(dev):
     m = yolov3_body(L.Input(shape=[128, 128, 3]), 'mobilenetv2x75', 3, num_classes=20)
     names = [o.name for o in m.plan.ops]
     assert 'td2_conv_lowres' in names and 'td3_conv_lowres' in names and 'td1_conv_lowres' not in names
-    td3 = next(o for o in m.plan.ops if o.name == 'td3_conv')
+    td3 = next(o for o in m.plan.ops if o.name in ('td3_conv', 'td3_head'))     # (round 5: conv + depthwise of a head block are one YR_OP_HEAD op)
     assert td3.cin == 24 and [s.xform for s in td3.srcs] == ['identity', 'up2_add']
     saved = compiler.HOIST_UPSAMPLE
     try:
@@ -140,7 +140,7 @@ def test_compiler_pools_in_the_producer(dev):
     assert set(pooled) == {'bu3_down_conv', 'bu2_down_conv', 'rfcr_b3c'}
     assert (pooled['bu3_down_conv'].h, pooled['bu3_down_conv'].w) == (8, 8)
     assert not any(s.xform == 'maxpool2' and s.buf.name.endswith('_pooled') for o in m.plan.ops for s in o.srcs)
-    bu2 = next(o for o in m.plan.ops if o.name == 'bu2_conv')
+    bu2 = next(o for o in m.plan.ops if o.name in ('bu2_conv', 'bu2_head'))
     assert [s.xform for s in bu2.srcs] == ['identity', 'identity']
 
 
@@ -190,8 +190,8 @@ def test_compiler_folds_head_projections_into_their_1x1_consumers(dev):
     assert not any(n in names for n in ('td3_mb_project', 'bu3_mb_project', 'bu1_mb_project'))
     assert all(n in names for n in ('td1_mb_project', 'td2_mb_project', 'bu2_mb_project'))   # composed MACs would be 1.14x .. 2.3x
     folded = {o.name: o for o in m.plan.ops if getattr(o, 'folded_projection', None)}
-    assert sorted(folded) == ['bu1_y', 'bu3_conv', 'bu3_down_conv', 'bu3_y']
-    assert all(o.gate is not None and o.cin == o.srcs[0].c and o.srcs[0].buf.name.endswith('_mb_dw') for o in folded.values())
+    assert sorted(folded) == ['bu1_y', 'bu3_down_conv', 'bu3_head', 'bu3_y']      # (bu3_head: bu3_conv + its depthwise, YR_OP_HEAD)
+    assert all((o.res if o.kind == 15 else o.gate) is not None and o.cin == o.srcs[0].c and o.srcs[0].buf.name.endswith('_mb_dw') for o in folded.values())
     assert getattr(folded['bu3_down_conv'], 'stride', 0) == 2    # the pooled store still rides on the (composed) conv
     saved = compiler.FOLD_PROJ
     try:

@@ -30,8 +30,11 @@ def _rt():
     return rt
 
 
-def _dev_vec(a, dev):
-    return torch.from_numpy(np.asarray(a, np.float32).ravel().copy()).to(dev)
+def _dev_vec(a, dev, n=None):
+    a = np.asarray(a, np.float32).ravel().copy()
+    if n is not None and n != a.size:
+        a = np.concatenate([a, np.zeros(n - a.size, np.float32)])
+    return torch.from_numpy(a).to(dev)
 
 
 def _act(x, act):
@@ -327,10 +330,10 @@ def test_squeeze_excite16(dev, dt, h, w, c, r, merged):
     hid = nn.swish(mean.dot(w1.astype(np.float64)) + b1)
     ref = nn.sigmoid(hid.dot(w2.astype(np.float64)) + b2)
     ldc = round_up(c, 4)
-    w1t = np.zeros((r, ldc), np.float32); w1t[:, :c] = w1.T
+    w1t = np.zeros((ldc, round_up(r, 4)), np.float32); w1t[:c, :r] = w1        # (ABI 7: W1 [ldc][R4], b1 [R4])
     w2p = np.zeros((r, ldc), np.float32); w2p[:, :c] = w2
     b2p = np.zeros(ldc, np.float32); b2p[:c] = b2
-    keep = [_dev_vec(w1t, dev), _dev_vec(b1, dev), _dev_vec(w2p, dev), _dev_vec(b2p, dev)]
+    keep = [_dev_vec(w1t, dev), _dev_vec(b1, dev, round_up(r, 4)), _dev_vec(w2p, dev), _dev_vec(b2p, dev)]
     xd = to_dev16(x, dev, dt)
     ldg = round_up(c, 8)
     gate = torch.full((b, ldg), float('nan'), dtype=torch.float32, device=dev)
@@ -590,10 +593,10 @@ def test_depthwise_se_form(dev, dt, k, s, h, w, c, r):
     mean = stored.mean(axis=(1, 2))
     ref = nn.sigmoid(nn.swish(mean.dot(w1.astype(np.float64)) + b1).dot(w2.astype(np.float64)) + b2)
     l4 = round_up(c, 4)
-    w1t = np.zeros((r, l4), np.float32); w1t[:, :c] = w1.T
+    w1t = np.zeros((l4, round_up(r, 4)), np.float32); w1t[:c, :r] = w1
     w2p = np.zeros((r, l4), np.float32); w2p[:, :c] = w2
     b2p = np.zeros(l4, np.float32); b2p[:c] = b2
-    k2 = [_dev_vec(w1t, dev), _dev_vec(b1, dev), _dev_vec(w2p, dev), _dev_vec(b2p, dev)]
+    k2 = [_dev_vec(w1t, dev), _dev_vec(b1, dev, round_up(r, 4)), _dev_vec(w2p, dev), _dev_vec(b2p, dev)]
     gate = torch.full((b, ldc), float('nan'), dtype=torch.float32, device=dev)
     op = rt.new_op(rt.OP_SE_FC)
     op.dtype, op.out_dtype = did, 0

@@ -242,11 +242,11 @@ def test_squeeze_excite(dev, h, w, c, r):
     rt.run_op(op, b)
     torch.cuda.synchronize()
     assert_close(from_dev(md, c), mean, TOL, 'se_mean')
-    w1t = np.zeros((r, ldc), np.float32)
-    w1t[:, :c] = w1.T
+    w1t = np.zeros((ldc, round_up(r, 4)), np.float32)      # (ABI 7: W1 [ldc][R4] - the Keras kernel as it is, b1 [R4])
+    w1t[:c, :r] = w1
     w2p = np.zeros((r, ldc), np.float32)
     w2p[:, :c] = w2
-    keep = [_dev_vec(w1t, dev), _dev_vec(b1, dev), _dev_vec(w2p, dev), _dev_vec(b2, dev, ldc)]
+    keep = [_dev_vec(w1t, dev), _dev_vec(b1, dev, round_up(r, 4)), _dev_vec(w2p, dev), _dev_vec(b2, dev, ldc)]
     gd = torch.full((b, 1, 1, ldc), float('nan'), dtype=torch.float32, device=dev)
     op = rt.new_op(rt.OP_SE_FC)
     op.h, op.w, op.cin, op.cout, op.nsrc, op.se_reduced = 1, 1, c, c, 1, r

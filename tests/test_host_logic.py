@@ -96,11 +96,16 @@ def test_plan_variants(monkeypatch):
     kinds = [o.kind for o in lat.ops]
     assert rt.OP_MBLANE not in kinds and rt.OP_MBCONV not in kinds and kinds[0] == rt.OP_STEMBLOCK
     # the squeeze of every SE block rides on its depthwise kernel as partial sums (no SE_MEAN launches, no merged pooling)
-    # ... and (ABI 7) the FC pair of every SE block rides there too - the SE tail: no SE_FC launches either
-    assert kinds.count(rt.OP_SE_MEAN) == 0 and kinds.count(rt.OP_DEPTHWISE) == 22 and kinds.count(rt.OP_SE_FC) == 0
-    assert sum(1 for o in lat.ops if o.kind == rt.OP_DEPTHWISE and o.gate is not None and o.gate_out is not None and 'se_w' in o.params) == 6
-    # the throughput plan: the six head blocks (1x1 conv -> depthwise -> squeeze-excite) are one launch each
-    assert sum(1 for o in thr.ops if o.kind == rt.OP_HEAD and o.gate_out is not None) == 6 and rt.OP_SE_FC not in [o.kind for o in thr.ops]
+    assert kinds.count(rt.OP_SE_MEAN) == 0 and kinds.count(rt.OP_DEPTHWISE) == 22 and kinds.count(rt.OP_SE_FC) == 6
+    assert sum(1 for o in lat.ops if o.kind == rt.OP_DEPTHWISE and o.gate is not None) == 6
+    # the throughput plan (ABI 7): the six head blocks' 1x1 conv -> depthwise -> squeeze-excite sums are one launch each; the FC pair
+    # of the SE block stays a launch of its own (the SE tail is opt-in: se_tail.h)
+    assert sum(1 for o in thr.ops if o.kind == rt.OP_HEAD and o.gate is not None) == 6 and [o.kind for o in thr.ops].count(rt.OP_SE_FC) == 6
+    from yoloret_amd import compiler
+    monkeypatch.setattr(compiler, 'SE_TAIL', True)
+    tail = _model().plan
+    assert sum(1 for o in tail.ops if o.kind == rt.OP_HEAD and o.gate_out is not None and 'se_w' in o.params) == 6 and rt.OP_SE_FC not in [o.kind for o in tail.ops]
+    assert tail.total_macs() == thr.total_macs() and abs(tail.algorithmic_bytes_per_image() - thr.algorithmic_bytes_per_image()) < 1
     assert lat.param_shapes == thr.param_shapes and lat.total_macs() == thr.total_macs()
     assert abs(lat.algorithmic_bytes_per_image() - thr.algorithmic_bytes_per_image()) < 1
     assert [(b.h, b.w, b.c) for b in lat.output_bufs] == [(b.h, b.w, b.c) for b in thr.output_bufs]
@@ -400,3 +405,53 @@ def test_split_form_refuses_weights_beyond_the_float16_range():
     big[3] = 7.0e4
     with pytest.raises(AssertionError):
         mbs_pack(we, big, one(cexp), dw, one(cexp), one(cexp), wp, one(cout), one(cout), 3)
+
+
+def test_fold_projection_handles_chains_of_linear_convs():
+    """three consecutive linear 1x1 convs (P1 -> C1 -> C2) - after P1 is folded into C1 the ORIGINAL C1 must not be
+    folded into C2 as a projection of its own (its replacement was never emitted: the plan read a buffer nobody wrote).  Whatever
+    the pass folds, every buffer an op reads must be written by an earlier op (or be the image), and the composed plan must compute
+    the same function: checked against a float64 composition of the layers."""
+    from yoloret_amd import layers as L, runtime as rt
+    from yoloret_amd.engine import Model
+    L.reset_names()
+    x = L.Input(shape=[16, 16, 3])
+    t = L.ReLU(6.)(L.BatchNormalization(name='bn0')(L.Conv2D(8, 3, strides=2, use_bias=False, name='stem')(x)))
+    for i, (f, act) in enumerate([(12, False), (10, False), (16, False), (8, True)]):
+        t = L.BatchNormalization(name='bn%d' % (i + 1))(L.Conv2D(f, 1, use_bias=False, name='c%d' % (i + 1))(t))
+        if act:
+            t = L.ReLU(6.)(t)
+    y = L.Conv2D(5, 1, use_bias=True, name='head')(t)
+    m = Model(x, [y])
+    ops = m.plan.ops
+    written = {id(m.plan.input_buf)}
+    for op in ops:
+        for s in op.srcs:
+            assert id(s.buf) in written, '%s reads %s, which no earlier op writes' % (op.name, s.buf.name)
+        written.add(id(op.out))
+    # the algebra: fold the chain by hand in float64 and compare the plan's composed pointwise parameters
+    rng = np.random.default_rng(3)
+    wd = {k: rng.standard_normal(s).astype(np.float32) * 0.3 for k, s in m.plan.param_shapes.items()}
+    for k in wd:
+        if k.endswith('moving_variance'):
+            wd[k] = np.abs(wd[k]) + 0.5
+    v = rng.standard_normal((7, 8))           # seven "pixels" behind the stem
+
+    def bn(t_, name):
+        g, b_, mu, var = (wd['%s/%s' % (name, p)].astype(np.float64) for p in ('gamma', 'beta', 'moving_mean', 'moving_variance'))
+        return (t_ - mu) / np.sqrt(var + 1e-3) * g + b_
+    ref = v
+    for i in range(1, 5):
+        ref = bn(ref @ wd['c%d/kernel' % i].reshape(-1, wd['c%d/kernel' % i].shape[-1]).astype(np.float64), 'bn%d' % i)
+    ref = np.clip(ref, 0, 6) @ wd['head/kernel'].reshape(8, 5).astype(np.float64) + wd['head/bias']
+    got = v
+    for op in ops[1:]:
+        assert op.kind == rt.OP_POINTWISE and len(op.srcs) == 1
+        w_ = np.asarray(op.params['wgt'][1](wd), np.float64)[:, :got.shape[1]]
+        got = got @ w_.T
+        if 'scale' in op.params:
+            got = got * np.asarray(op.params['scale'][1](wd), np.float64)[:op.cout] + np.asarray(op.params['shift'][1](wd), np.float64)[:op.cout]
+        if op.act == 'relu6':
+            got = np.clip(got, 0, 6)
+    assert len(ops) < 6, 'nothing was folded'
+    assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())

@@ -52,7 +52,7 @@ def main():
         op.nsrc, op.h, op.w, op.cin, op.cout, op.stride = n, h, w, cin, f, 1
         import os
         nk = sum((c + 31) // 32 for c, _ in segs)
-        walk = os.environ.get('YR_HEAD_FORM', 'walk') == 'walk' and all(xf == 'identity' for _, xf in segs) and nk <= 7 and not (gated and pre)
+        walk = os.environ.get('YR_HEAD_FORM', 'walk') == 'walk' and all(xf == 'identity' for _, xf in segs) and nk <= 4 and not (gated and pre)
         packed = not walk and all(xf in ('identity', 'up2') for _, xf in segs)
         if packed:
             par[0] = torch.from_numpy(head_pack(par[0].cpu().numpy(), [c for c, _ in segs])).to(dev)

@@ -23,6 +23,9 @@ def round_up(v, m):
     return (v + m - 1) // m * m
 
 
+NO_ARENA_REUSE = os.environ.get('YOLORET_NO_ARENA_REUSE', '0') != '0'   # debugging: every intermediate keeps its own memory (tools/plan_diff.py)
+
+
 class Buf:
     def __init__(self, bid, h, w, c, ld, external_slot=-1, name='', dtype=0):
         self.id, self.h, self.w, self.c, self.ld = bid, h, w, c, ld
@@ -114,7 +117,8 @@ class Plan:
         live = []  # (offset, size, last_use)
         total = 0
         for b in sorted(arena, key=lambda x: x.first_def):
-            live = [l for l in live if l[2] >= b.first_def]  # a buffer read by op i may not be overwritten by op i
+            if not NO_ARENA_REUSE:
+                live = [l for l in live if l[2] >= b.first_def]  # a buffer read by op i may not be overwritten by op i
             size = round_up(b.bytes, 16)
             off = 0
             for lo, ls, _ in sorted(live):
@@ -190,6 +194,25 @@ class Plan:
         return ops, bufs
 
     # -- reporting
+    def fallback_ops(self):
+        """Names of the ops that run a GENERIC form where a fused one exists for their kind of block: a DEPTHWISE 3x3 / 5x5 op fed by a
+        1x1 convolution's private output (an inverted-residual or head block no fused kernel's shape list took), and HEAD blocks on
+        the register-staged front end (pooled sources).  bench.py prints the list: a shape that is on no whitelist must not go unnoticed."""
+        producer = {id(op.out): op for op in self.ops}
+        nreaders = {}
+        for op in self.ops:
+            for s_ in op.srcs:
+                nreaders[id(s_.buf)] = nreaders.get(id(s_.buf), 0) + 1
+        names = []
+        for op in self.ops:
+            if op.kind == rt.OP_DEPTHWISE and len(op.srcs) == 1:
+                p_ = producer.get(id(op.srcs[0].buf))
+                if p_ is not None and p_.kind == rt.OP_POINTWISE and p_.act in ('relu6', 'swish') and nreaders.get(id(p_.out), 0) == 1:
+                    names.append(op.name)
+            elif op.kind == rt.OP_HEAD and not (op.k & 0xc0):
+                names.append(op.name)
+        return names
+
     def total_macs(self):
         return sum(op.macs for op in self.ops)
 
@@ -414,12 +437,16 @@ def fold_projection_into_consumers(ops, output_buf_ids):
     drop, repl = set(), {}
     for P in ops:
         rd = readers.get(id(P.out), [])
+        # (a chain of linear 1x1 convs P1 -> C1 -> C2: once P1 is folded into C1, the ORIGINAL C1 must not be folded into C2 as a
+        # projection of its own - its replacement reads P1's source, the original read P1's dropped output)
+        if id(P) in repl or id(P) in drop:
+            continue
         if (P.kind != rt.OP_POINTWISE or P.act != 'none' or 'scale' not in P.params or P.res is not None or len(P.srcs) != 1
                 or P.srcs[0].xform != 'identity' or P.out.external_slot >= 0 or P.out.id in output_buf_ids or not rd
                 or (P.h == 1 and P.w == 1) or getattr(P, 'accounted_in', None)):
             continue
         if any(s is None or C.kind != rt.OP_POINTWISE or len(C.srcs) != 1 or s.xform != 'identity' or C.gate is not None
-               or C.res is not None or s.c != P.cout or C.dtype != P.dtype or id(C) in repl for C, s in rd):
+               or C.res is not None or s.c != P.cout or C.dtype != P.dtype or id(C) in repl or id(C) in drop for C, s in rd):
             continue
         cin, cp = P.cin, P.cout
         if sum(cin * C.cout for C, _ in rd) > FOLD_PROJ_MAX_RATIO * (cin * cp + sum(cp * C.cout for C, _ in rd)):
@@ -732,9 +759,9 @@ def fold_depthwise_into_project(ops, output_buf_ids, min_pixels=0):
 # form of dw_kernel): the workgroup that completes an image runs it (se_tail.h) and the SE_FC launch disappears.
 FUSE_HEAD = os.environ.get('YOLORET_FUSE_HEAD', '1') != '0'
 FUSE_HEAD_ALL = os.environ.get('YOLORET_FUSE_HEAD', '1') == '2'     # also conv -> depthwise pairs without squeeze-excite sums
-SE_TAIL = os.environ.get('YOLORET_SE_TAIL', '1') != '0'
+SE_TAIL = os.environ.get('YOLORET_SE_TAIL', '0') != '0'   # OPT-IN: correct in one stream, not with steps in flight on several (se_tail.h: STATUS)
 SE_TAIL_LDS = 4608 - 1024 - 4      # == YR_SE_TAIL_LDS - 4 * 256 threads (se_tail.h): channels + hidden units the tail's LDS scratch holds
-HEAD_WALK_MAX_NK = int(os.environ.get('YOLORET_HEAD_WALK_MAX_NK', '4'))   # (measured, MobileNetV2 x0.75 @416 batch 64: 1 chunk 52 us against the LDS-direct kernel's 95, 4 chunks 96 | 124, 6 chunks 85 | 82, 7 chunks 96 | 84: one tile per wave and 250 registers from 5 chunks on)
+HEAD_WALK_MAX_NK = min(4, int(os.environ.get('YOLORET_HEAD_WALK_MAX_NK', '4')))   # (measured, MobileNetV2 x0.75 @416 batch 64: 1 chunk 52 us against the LDS-direct kernel's 95, 4 chunks 96 | 124, 6 chunks 85 | 82, 7 chunks 96 | 84: one tile per wave and 250 registers from 5 chunks on)
 HEAD_WALK = os.environ.get('YOLORET_HEAD_WALK', '1') != '0'   # head blocks of at most 7 chunks of 32 identity-source channels on the walking kernel (headwalk.hip)
 HEAD_DMA = os.environ.get('YOLORET_HEAD_DMA', '1') != '0'   # head blocks without a pooled source on the LDS-direct kernel
 
@@ -794,7 +821,7 @@ def head_pack(wt, seg_c, V=4):
     return np.ascontiguousarray(out).reshape(-1).view(np.float32)
 
 
-def fuse_head_blocks(ops, bufs, output_buf_ids):
+def fuse_head_blocks(ops, bufs, output_buf_ids, nosplit=frozenset()):
     readers = {}
     for op in ops:
         for s_ in op.srcs:
@@ -814,8 +841,11 @@ def fuse_head_blocks(ops, bufs, output_buf_ids):
               and kp >= 16 and c.cout % 4 == 0 and c.out.external_slot < 0 and c.out.id not in output_buf_ids and readers.get(id(c.out), 0) == 1
               and d.kind == rt.OP_DEPTHWISE and d.dtype == 0 and d.k == 3 and d.stride == 1 and len(d.srcs) == 1 and d.srcs[0].buf is c.out
               and d.srcs[0].xform == 'identity' and d.srcs[0].c == c.cout and d.act in ('swish', 'relu6', 'none') and d.out.ld % 4 == 0
-              and d.out.dtype == 0 and not (c.h == 1 and c.w == 1) and (d.gate is not None or FUSE_HEAD_ALL))
+              and d.out.dtype == 0 and not (c.h == 1 and c.w == 1) and (d.gate is not None or FUSE_HEAD_ALL)
+              and c.name.rsplit('_', 1)[0] + '_head' not in nosplit)       # (the head kernels exist in the split form only)
         if not ok:
+            if c.kind == rt.OP_POINTWISE and c.name.rsplit('_', 1)[0] + '_head' in nosplit:
+                c.se_reduced |= 0x10000      # the unfused conv of a head block that left the split form stays off it as well
             out.append(c)
             i += 1
             continue
@@ -823,7 +853,10 @@ def fuse_head_blocks(ops, bufs, output_buf_ids):
         m = OpRec(rt.OP_HEAD, c.name.rsplit('_', 1)[0] + '_head', act=d.act, h=d.h, w=d.w, cin=c.cin, cout=F, k=3 | rt.ACT[c.act] << 8, stride=1,
                   srcs=list(c.srcs), out=d.out, res=c.gate, macs=c.macs + d.macs, dtype=0)
         m.fused = [c, d]
+        if getattr(c, 'folded_projection', None):
+            m.folded_projection = c.folded_projection
         m.params = {'wgt': c.params['wgt'], 'scale': c.params['scale'], 'shift': c.params['shift']}
+        dp = d.params
         kseg = [s_.c for s_ in c.srcs if s_.xform != 'up2_add']
         nk = sum((c_ + 31) // 32 for c_ in kseg)
         nt = 2 if nk <= 4 else 1
@@ -848,7 +881,6 @@ def fuse_head_blocks(ops, bufs, output_buf_ids):
             # no pooled source: the LDS-direct kernel, weights as float16 planes in fragment order (k bit 7)
             m.k |= 0x80
             m.params['wgt'] = ((((F + 15) // 16) * nk * 512,), lambda wd, wf=c.params['wgt'][1], kseg=kseg: head_pack(wf(wd), kseg))
-        dp = d.params
 
         def dw_rows(wd, dp=dp, F=F, ldf=ldf):
             o = np.zeros((10, ldf), np.float32)
@@ -889,12 +921,8 @@ def se_tail_into_producers(ops):
 
         def se_w(wd, fp=fp, R=R, ldc=ldc):
             """W1 [ldc][R4] | W2 [R][ldc] | b1 [R4] | b2 [ldc] (include/yoloret_hip.h: se_w)"""
-            r4 = round_up(R, 4)
-            w1 = np.zeros((ldc, r4), np.float32)
-            w1[:, :R] = np.asarray(fp['wgt'][1](wd), np.float32).T       # SE_FC's W1t [R][ldc]
-            b1 = np.zeros(r4, np.float32)
-            b1[:R] = fp['b1'][1](wd)
-            return np.concatenate([w1.ravel(), np.asarray(fp['wgt2'][1](wd), np.float32).ravel(), b1, np.asarray(fp['b2'][1](wd), np.float32).ravel()])
+            return np.concatenate([np.asarray(fp['wgt'][1](wd), np.float32).ravel(), np.asarray(fp['wgt2'][1](wd), np.float32).ravel(),
+                                   np.asarray(fp['b1'][1](wd), np.float32).ravel(), np.asarray(fp['b2'][1](wd), np.float32).ravel()])
         P.params['se_w'] = ((ldc * round_up(R, 4) + R * ldc + round_up(R, 4) + ldc,), se_w)
         P.gate_out, P.se_hidden = fc.out, R
         P.macs += fc.macs
@@ -995,7 +1023,7 @@ def mbs_pack(we_t, e_scale, e_shift, dw, d_scale, d_shift, wp_t, p_scale, p_shif
     return wa, tab, b2
 
 
-def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None):
+def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None, nosplit=frozenset()):
     """Peephole over the lowered op list: [POINTWISE expand+act ->] DEPTHWISE 3x3+act -> POINTWISE
     project (+residual == block input) becomes one MBCONV op whose expanded tensors never reach HBM.
     blocks=False (the small-batch plan) keeps only the network-entry fusion (stem + first block).
@@ -1175,7 +1203,7 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                     and (p.res is None or (p.res is bi.buf and d.stride == 1 and p.cout == bi.c))):
                 cin, cexp, cout = bi.c, d.cin, p.cout
                 nw, segs = MBR_SHAPES[key][:2]
-                split = MBR_SPLIT and key in MBS_SHAPES
+                split = MBR_SPLIT and key in MBS_SHAPES and bname + '_mbr' not in nosplit     # (nosplit: Model.check_ranges found operands beyond the float16 range)
                 if split:
                     nw = MBS_SHAPES[key]
                 T, TO, KE = cexp // 16, (cout + 15) // 16, cin // 4
@@ -1211,11 +1239,12 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                 and d.out.ld == round_up(d.cin, 4)):
             bi, cexp = exp.srcs[0], d.cin
             T, KE = cexp // 16, bi.c // 4
-            m = OpRec(rt.OP_MBE, exp.name.rsplit('_', 1)[0] + '_mbe', act='relu6', h=d.h, w=d.w, cin=bi.c, cout=cexp, k=3 | (0x80 if MBR_SPLIT and bi.c in MBS_MBE_CINS else 0), stride=d.stride,
+            mbe_split = MBR_SPLIT and bi.c in MBS_MBE_CINS and exp.name.rsplit('_', 1)[0] + '_mbe' not in nosplit
+            m = OpRec(rt.OP_MBE, exp.name.rsplit('_', 1)[0] + '_mbe', act='relu6', h=d.h, w=d.w, cin=bi.c, cout=cexp, k=3 | (0x80 if mbe_split else 0), stride=d.stride,
                       srcs=[bi], out=d.out, macs=exp.macs + d.macs, dtype=0)
             m.fused = [exp, d]
             ep, dp = exp.params, d.params
-            if MBR_SPLIT and bi.c in MBS_MBE_CINS:
+            if mbe_split:
                 def packed_es(which, ep=ep, dp=dp):
                     def f(wd):
                         wa, tab, _ = mbs_pack(ep['wgt'][1](wd), ep['scale'][1](wd), ep['shift'][1](wd), dp['wgt'][1](wd).reshape(9, -1),
@@ -1405,8 +1434,9 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
 
 
 class Compiler:
-    def __init__(self, inputs, outputs, fuse=True, dtype=0):
+    def __init__(self, inputs, outputs, fuse=True, dtype=0, nosplit=frozenset()):
         self.fuse = fuse
+        self.nosplit = frozenset(nosplit)     # names of plan ops that must not run a split (float16-plane) form: Model.check_ranges
         self.dtype = rt.dtype_id(dtype)   # element type of the activations between ops
         self.V = rt.VEC[self.dtype]
         self.inputs = inputs
@@ -1577,9 +1607,9 @@ class Compiler:
                 ops = merge_se_mean(ops, only_after_depthwise=latency)
                 if SE_PARTIALS:
                     ops = se_partials_from_depthwise(ops, self.bufs)
-            ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency, dtype=self.dtype, bufs=self.bufs)
+            ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency, dtype=self.dtype, bufs=self.bufs, nosplit=self.nosplit)
             if FUSE_HEAD and not latency and self.dtype == 0:
-                ops = fuse_head_blocks(ops, self.bufs, set(b.id for b in outs))
+                ops = fuse_head_blocks(ops, self.bufs, set(b.id for b in outs), nosplit=self.nosplit)
             if SE_TAIL:
                 ops = se_tail_into_producers(ops)
             fold = FOLD_DW if isinstance(FOLD_DW, str) else ('1' if FOLD_DW else '0')   # (tests assign booleans)
@@ -1592,6 +1622,9 @@ class Compiler:
                 for o in ops:
                     if o.kind == rt.OP_POINTWISE and not any(s_.xform == 'dw3' for s_ in o.srcs):
                         o.se_reduced |= 0x10000
+        for o in ops:     # (also without fusion: a float32 POINTWISE op named by Model.check_ranges keeps the float32 MFMA)
+            if o.kind == rt.OP_POINTWISE and o.name in self.nosplit:
+                o.se_reduced |= 0x10000
         plan = Plan(ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape, self.dtype)
         plan.layer_seq = dict(self.layer_seq)
         return plan
@@ -1703,9 +1736,16 @@ class Compiler:
                    macs=2 * c * r)
         k1, b1, k2, b2 = n.name + '/kernel', n.name + '/bias', c2.name + '/kernel', c2.name + '/bias'
 
-        def w1(wd):
-            o = np.zeros((r, ldc), np.float32)
-            o[:, :c] = wd[k1].reshape(c, r).T
+        r4 = round_up(r, 4)
+
+        def w1(wd):       # [ldc][R4]: the Keras kernel [1, 1, C, R] as it is, rows padded to quads (se_tail.h: yr_se_fc_pair)
+            o = np.zeros((ldc, r4), np.float32)
+            o[:c, :r] = wd[k1].reshape(c, r)
+            return o
+
+        def bb1(wd):
+            o = np.zeros(r4, np.float32)
+            o[:r] = wd[b1]
             return o
 
         def w2(wd):
@@ -1717,7 +1757,7 @@ class Compiler:
             o = np.zeros(ldc, np.float32)
             o[:c] = wd[b2]
             return o
-        op.params = {'wgt': ((r, ldc), w1), 'b1': ((r,), lambda wd: wd[b1]), 'wgt2': ((r, ldc), w2),
+        op.params = {'wgt': ((ldc, r4), w1), 'b1': ((r4,), bb1), 'wgt2': ((r, ldc), w2),
                      'b2': ((ldc,), bb2)}
         self._emit(op)
         for m in (n, a1, c2, a2):
@@ -1828,5 +1868,26 @@ class Compiler:
         raise NotImplementedError('Add %s does not follow a fused 1x1 convolution' % n.name)
 
 
-def compile_graph(inputs, outputs, fuse=True, dtype=0):
-    return Compiler(inputs, outputs, fuse, dtype).compile()
+def compile_graph(inputs, outputs, fuse=True, dtype=0, nosplit=frozenset()):
+    return Compiler(inputs, outputs, fuse, dtype, nosplit).compile()
+
+
+SPLIT_LIMIT = 60000.0     # |operand| a split-form op accepts (float16's largest finite value is 65504)
+
+
+def split_form_ops(plan):
+    """Indices of the ops of a float32 plan whose GEMM operands travel as float16 planes (|x| < 65504 required): POINTWISE ops at
+    least 16 channels deep without the keep-float32 flag (and no depthwise-folded source), MBR / MBE with k bit 7, HEAD."""
+    idx = []
+    for i, o in enumerate(plan.ops):
+        if o.dtype != 0:
+            continue
+        if o.kind == rt.OP_POINTWISE:
+            kp = sum(round_up(s_.c, 4) for s_ in o.srcs if s_.xform != 'up2_add')
+            if PW_SPLIT and kp >= 16 and not (o.se_reduced & 0x10000) and not any(s_.xform == 'dw3' for s_ in o.srcs):
+                idx.append(i)
+        elif o.kind in (rt.OP_MBR, rt.OP_MBE) and o.k & 0x80:
+            idx.append(i)
+        elif o.kind == rt.OP_HEAD:
+            idx.append(i)
+    return idx

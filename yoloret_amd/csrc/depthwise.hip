@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs<T> a) {
                     const float4 v = red[l * Q + q];
                     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
                 }
-                yr_st_agent4(a.part + ((size_t)b * (gridDim.x / a.ncb) + se_row) * a.ld_part + (cv * Q + q) * 4, s.x, s.y, s.z, s.w);   // (write-through: se_tail.h)
+                yr_st_sums4(a.part + ((size_t)b * (gridDim.x / a.ncb) + se_row) * a.ld_part + (cv * Q + q) * 4, a.se.sums != nullptr, s.x, s.y, s.z, s.w);
             }
         }
         yr_se_tail_arrive<256>(a.se, b, 1u, &se_flag, reinterpret_cast<float*>(red));   // (red: YR_SE_TAIL_LDS floats)

@@ -7,6 +7,7 @@
 //              the fast path folds these into consumer loads, this kernel exists for
 //              unfused use and for testing the gather machinery in isolation.
 #include "yr_common.h"
+#include "se_tail.h"
 
 // ------------------------------------------------------------------ SE mean
 template <class T>
@@ -88,45 +89,31 @@ template <class T>
 struct FcArgs {
     const T* map;       // HW > 1: the full map [B][HW][ld_map] (element type T) whose spatial mean is the FC input (SE_MEAN merged in)
     int HW, ld_map;
-    int pool;           // 1: `map` rows are added up and divided by `count` first; 0: `mean` is the pooled vector already
-    float count;        // what the pooled sums are divided by: HW, or the true pixel count when `map` holds per-workgroup
-                        // partial sums written by the SE form of the depthwise kernel
+    int pool;           // 0: `mean` is the pooled vector already; 1: `map` is a map to pool; 2: `mean` holds float32 rows of partial
+                        // channel sums [B][HW][ld_mean] written by the SE form of a depthwise / fused-block kernel
+    float count;        // what the pooled sums are divided by: HW, or the true pixel count when the rows are partial sums
     const float* mean;  // [B][ld_mean]
-    const float* w1t;   // [R][ldc]   (transposed Keras kernel: hidden j, channel c)
-    const float* b1;    // [R]
-    const float* w2;    // [R][ldc]   (Keras kernel [1,1,R,C])
-    const float* b2;    // [ldc]
+    SeFc fc;            // W1 [ldc][R4] | b1 [R4] | W2 [R][ldc] | b2 [ldc]
     float* gate;        // [B][ld_gate]
     int C, R, ldc, ld_mean, ld_gate;
 };
 
-// One workgroup of 1024 threads per image; dynamic LDS = (ldc + R + 1024) floats.
-//   fc1: one wave per hidden unit j (16 in flight), lanes stride the channels (coalesced W1t rows);
-//   fc2: thread (jg, c): partial sum over j = jg, jg+JS, ... of hid[j]*W2[j][c] (coalesced across c),
-//        combined through LDS in a fixed order (deterministic).
+// One workgroup per image; dynamic LDS = yr_se_fc_floats(C, R, 1024) floats (+ 1024 float4 when a map is pooled here).  The FC pair
+// itself is se_tail.h's yr_se_fc_pair (round 5: a thread per quad of outputs and segment of inputs, 16-byte loads - the launch is
+// three dependent round trips on 64 workgroups, so what counts is how few batches of loads each stage needs).
 #define SE_FC_THREADS 1024
 template <class T>
 __global__ __launch_bounds__(SE_FC_THREADS) void se_fc_kernel(FcArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* mean = sm;                 // [ldc]
-    float* hid = sm + a.ldc;          // [R]
-    float* part = hid + a.R;          // [SE_FC_THREADS]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // The kernel is three dependent round trips (pooled input, W1, W2) on 64 workgroups: touch one float of every 64-byte
-    // line of both weight matrices and the biases NOW, so that they travel from HBM while the pooling below waits for its
-    // own loads; the FC loops then find them in L2.  (`warm` is consumed by a never-true test at the end.)
-    float warm = 0.f;
-    {
-        const int nw = a.R * a.ldc;
-        for (int i = tid * 16; i < nw; i += SE_FC_THREADS * 16) warm += a.w1t[i] + a.w2[i];
-        if (tid * 16 < a.R) warm += a.b1[tid * 16];
-        if (tid * 16 < a.ldc) warm += a.b2[tid * 16];
-    }
-    if (a.pool) {
-        // tf.reduce_mean over H,W first (the SE_MEAN op merged into this launch).  All channel quads at once:
-        // C4P = next power of two >= C4 quads x (1024 / C4P) pixel lanes, then one fixed-order combine over the
-        // pixel lanes (deterministic; the summation grouping differs from se_mean_kernel's by fp32 rounding only).
-        float4* red = reinterpret_cast<float4*>(sm + ((a.ldc + a.R + SE_FC_THREADS + 3) & ~3));  // [PL][C4P], 16-byte aligned
+    float* mean = sm;                                       // [ldc]
+    float* scratch = sm + a.ldc;                            // [R4 + 4 * SE_FC_THREADS]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (a.pool == 2) {
+        yr_se_mean_rows<SE_FC_THREADS, false>(a.mean + (size_t)b * a.HW * a.ld_mean, a.HW, a.ld_mean, a.C, a.ldc, a.count, mean, scratch, tid);
+    } else if (a.pool == 1) {
+        // tf.reduce_mean over H,W first (the SE_MEAN op merged into this launch).  All channel quads at once: C4P = next power of two
+        // >= C4 quads x (1024 / C4P) pixel lanes, then one fixed-order combine over the pixel lanes (deterministic).
+        float4* red = reinterpret_cast<float4*>(sm + ((yr_se_fc_floats(a.C, a.R, SE_FC_THREADS) + 3) & ~(size_t)3));  // [PL][C4P], 16-byte aligned
         const int C4 = (a.C + 3) >> 2;
         int c4p = 1;
         while (c4p < C4 && c4p < SE_FC_THREADS) c4p <<= 1;
@@ -161,43 +148,9 @@ __global__ __launch_bounds__(SE_FC_THREADS) void se_fc_kernel(FcArgs<T> a) {
         }
     } else {
         for (int c = tid; c < a.ldc; c += SE_FC_THREADS) mean[c] = (c < a.C) ? a.mean[(size_t)b * a.ld_mean + c] : 0.f;
-    }
-    __syncthreads();
-    // the kernel is pure latency (64 workgroups, weights from L2): keep several rows' loads in flight per wave
-#pragma unroll 4
-    for (int j = wave; j < a.R; j += SE_FC_THREADS / 64) {
-        const float* wr = a.w1t + (size_t)j * a.ldc;
-        float s = 0.f;
-#pragma unroll 8
-        for (int c = lane; c < a.C; c += 64) s = __builtin_fmaf(wr[c], mean[c], s);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) hid[j] = yr_apply_act(s + a.b1[j], YR_ACT_SWISH);
-    }
-    __syncthreads();
-    const int cp = (a.C + 63) / 64 * 64;
-    const int js = cp <= SE_FC_THREADS ? SE_FC_THREADS / cp : 1;   // j-groups working on one channel chunk
-    for (int c0 = 0; c0 < a.ld_gate; c0 += SE_FC_THREADS) {       // one pass unless C > 1024
-        const int jg = tid / cp, c = c0 + (js > 1 ? tid % cp : tid);
-        float s = 0.f;
-        if (jg < js && c < a.C) {
-#pragma unroll 16
-            for (int j = jg; j < a.R; j += js) s = __builtin_fmaf(hid[j], a.w2[(size_t)j * a.ldc + c], s);
-        }
-        part[tid] = s;
-        __syncthreads();
-        if (jg == 0 && c < a.ld_gate) {
-            float v = 0.f;
-            if (c < a.C) {
-                float t = part[tid];
-                for (int g = 1; g < js; ++g) t += part[g * cp + tid];
-                v = yr_sigmoid(t + a.b2[c]);
-            }
-            if (warm == 1.2345678e-30f) v = 0.f;   // (keeps the warming loads alive; weights never add up to this)
-            a.gate[(size_t)b * a.ld_gate + c] = v;
-        }
         __syncthreads();
     }
+    yr_se_fc_pair<SE_FC_THREADS>(a.fc, mean, scratch, a.gate + (size_t)b * a.ld_gate, tid);
 }
 
 template <class T>
@@ -210,13 +163,15 @@ static int launch_se_fc_t(const yr_op& op, int batch, hipStream_t s) {
     FcArgs<T> a;
     a.map = (const T*)in.ptr; a.HW = in.h * in.w; a.ld_map = in.ld;   // h*w > 1: the pooled vector is computed here (SE_MEAN merged)
     a.count = op.k > 0 ? (float)op.k : (float)a.HW;                   // k: pixel count when the rows are partial sums, not pixels
-    a.pool = (a.HW > 1 || op.k > 0) ? 1 : 0;
+    a.pool = op.k > 0 ? 2 : a.HW > 1 ? 1 : 0;
     YR_REQUIRE((a.HW == 1 || op.k > 0) ? in.dtype == YR_F32 : in.dtype == op.dtype, "se_fc: a pooled vector / partial sums are float32, a map to pool has the op's dtype");
     YR_REQUIRE((a.HW == 1 && op.k <= 0) || (in.ld % yr_elem<T>::vec == 0 && ((uintptr_t)in.ptr % 16) == 0), "se_fc: the map to pool must be 16-byte addressable per pixel");
-    a.mean = (const float*)in.ptr; a.w1t = op.wgt; a.b1 = op.b1; a.w2 = op.wgt2; a.b2 = op.b2; a.gate = (float*)op.out;
+    a.mean = (const float*)in.ptr; a.gate = (float*)op.out;
     a.C = in.c; a.R = op.se_reduced; a.ldc = yr_round_up(in.c, 4); a.ld_mean = in.ld; a.ld_gate = op.out_ld;
-    YR_REQUIRE(op.out_ld >= a.ldc, "se_fc: gate ld too small");
-    const size_t lds = (size_t)((a.ldc + a.R + SE_FC_THREADS + 3) & ~3) * sizeof(float) + (a.pool ? SE_FC_THREADS * sizeof(float4) : 0);
+    a.fc.w1 = op.wgt; a.fc.b1 = op.b1; a.fc.w2 = op.wgt2; a.fc.b2 = op.b2; a.fc.C = a.C; a.fc.R = a.R; a.fc.ldc = a.ldc;
+    YR_REQUIRE(((uintptr_t)op.wgt | (uintptr_t)op.wgt2 | (uintptr_t)op.b1 | (uintptr_t)op.b2 | (uintptr_t)op.out) % 16 == 0, "se_fc: parameters and gate must be 16-byte aligned");
+    YR_REQUIRE(op.out_ld >= a.ldc && op.out_ld % 4 == 0, "se_fc: gate ld too small");
+    const size_t lds = ((yr_se_fc_floats(a.C, a.R, SE_FC_THREADS) + 3) & ~(size_t)3) * sizeof(float) + (a.pool == 1 ? SE_FC_THREADS * sizeof(float4) : 0);
     YR_REQUIRE(lds <= 64 * 1024, "se_fc: widths too large for LDS");
     static char nm[32];
     static const int nm_len = snprintf(nm, sizeof(nm), "se_fc_kernel<%s>", yr_dtype_name(yr_elem<T>::dtype));
@@ -351,3 +306,35 @@ static int launch_gather_t(const yr_op& op, int batch, hipStream_t s) {
     return YR_OK;
 }
 int yr_launch_gather(const yr_op& op, int batch, hipStream_t s) { return YR_BY_DTYPE(op.dtype, launch_gather_t, op, batch, s); }
+
+// ------------------------------------------------------------------ range check (yr_forward_ranges)
+// max |x| over the `c` channels of every pixel row of a float32 tensor [rows][ld], NaN counted as +inf; the result is OR-ed into
+// *out as the bits of a non-negative float (which order like unsigned integers).
+__global__ __launch_bounds__(256) void absmax_kernel(const float* p, long long rows, int c, int ld, unsigned* out) {
+    const int c4 = (c + 3) >> 2;
+    const long long total = rows * c4;
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / c4;
+        const int q = (int)(i - r * c4) * 4;
+        const float* e = p + r * ld + q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (q + j < c) {
+                const float v = fabsf(e[j]);
+                m = (v != v) ? __int_as_float(0x7f800000) : fmaxf(m, v);
+            }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+int yr_launch_absmax(const float* p, long long rows, int c, int ld, unsigned* out, hipStream_t s) {
+    if (rows <= 0 || c <= 0) return YR_OK;
+    long long blocks = (rows * ((c + 3) / 4) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, rows, c, ld, out);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}

@@ -241,7 +241,7 @@ __device__ __forceinline__ void head_finish(const HeadArgs& h, const HeadRegion&
     if (tid < QN && n0 + 4 * tid < a.N) {
         f32x4 s = red[tid];
         for (int j = 1; j < NTH / QN; ++j) s += red[tid + j * QN];
-        yr_st_agent4(h.sums + ((size_t)b * (h.nsy * h.nsx) + (R.iy * h.nsx + R.ix)) * h.ld_sums + n0 + 4 * tid, s[0], s[1], s[2], s[3]);   // (write-through: se_tail.h)
+        yr_st_sums4(h.sums + ((size_t)b * (h.nsy * h.nsx) + (R.iy * h.nsx + R.ix)) * h.ld_sums + n0 + 4 * tid, h.se.sums != nullptr, s[0], s[1], s[2], s[3]);
     }
     if (!(h.exp & 16)) yr_se_tail_arrive<NTH>(h.se, b, 1u, flag, reinterpret_cast<float*>(lds_raw));   // (16: probing - sums without the arrival)
 }

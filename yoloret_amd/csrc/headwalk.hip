@@ -16,12 +16,13 @@
 // shift + scale * pre), the SE gate of the source (bu3 reads td3's map through its gate), Swish, and the squeeze-excite sums: every
 // wave adds up what it stores, per channel; a workgroup's four waves (same image, strip, segment - four tile groups) write their
 // slices of the (strip, segment) row and arrive together; the workgroup that completes an image runs the FC pair (se_tail.h).
-// Built for NKE <= 7 chunks (the weights must stay in registers): the 52 x 52 and 26 x 26 heads; 13 x 13 (K = 216 / 331, F = 512)
-// and pooled sources stay on headblock.hip.
+// Built for NKE <= 4 chunks of 32 channels (the weights must stay in registers, two cout tiles per wave): the 52 x 52 heads; the
+// 26 x 26 ones (6-7 chunks: one tile per wave, 250 registers, the pixel operand cut 16 times - measured slower), 13 x 13 (K = 216 /
+// 331, F = 512) and pooled sources stay on headblock.hip.
 #include "mbr_common.h"
 #include "se_tail.h"
 
-#define HW_MAXK 8
+#define HW_MAXK 4
 struct HwArgs {
     const float* src[3]; int ld[3]; int cs[3];   // k-space sources (identity): pointer, channel stride, channels
     int nsrc;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void hwalk_kernel(HwArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) s[q] += __shfl_xor(s[q], o);
         if (px == 0 && t0 + j < a.T)
-            yr_st_agent4(a.sums + ((size_t)b * (a.strips * a.segs) + (size_t)(strip * a.segs + seg)) * a.ld_sums + 16 * (t0 + j) + 4 * mg, s[0], s[1], s[2], s[3]);
+            yr_st_sums4(a.sums + ((size_t)b * (a.strips * a.segs) + (size_t)(strip * a.segs + seg)) * a.ld_sums + 16 * (t0 + j) + 4 * mg, a.se.sums != nullptr, s[0], s[1], s[2], s[3]);
     }
     yr_se_tail_arrive<256>(a.se, b, 1u, &se_flag, tab);   // (tab: the launcher sizes the dynamic LDS for the tail's scratch as well)
 }
@@ -339,7 +340,7 @@ int yr_launch_head_walk(const yr_op& op, int batch, hipStream_t s) {
     if (rc) return rc;
     a.sums = const_cast<float*>(op.gate); a.ld_sums = op.gate_ld;
 #define HW_CASE(K, T2) if (nk == K) return launch_hwalk<K, T2>(a, batch, s);
-    HW_CASE(1, 2) HW_CASE(2, 2) HW_CASE(3, 2) HW_CASE(4, 2) HW_CASE(5, 1) HW_CASE(6, 1) HW_CASE(7, 1)
+    HW_CASE(1, 2) HW_CASE(2, 2) HW_CASE(3, 2) HW_CASE(4, 2)   // (5 .. 7 chunks, one tile per wave: built and measured in round 5 - 250 registers, 85-96 us on the 26 x 26 heads against the LDS-direct kernel's 77-84 - not kept)
 #undef HW_CASE
     yr_set_error("head (walking form): %d chunks of 32 channels are not built", nk);
     return YR_ERR_ARG;

@@ -396,7 +396,10 @@ static int launch_mbr(const MbrArgs& a0, int batch, int want_segs, hipStream_t s
     constexpr int MW = SP ? (S == 1 && NW <= 3 ? 3 : 2) : EST <= 164 ? 3 : EST <= 250 ? 2 : 1;
     static_assert(NW <= 4 * MW, "a workgroup's waves must fit one CU at this register budget");
     auto kern = mbr_kernel<CIN, CEXP, COUT, S, NW, RES, SP, MW>;   // waves per SIMD the register allocator must leave room for
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};   // per device: a process that drives several GPUs needs the attribute on each
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    bool& attr_set = attr_set_dev[cur_dev & 63];
     if (!attr_set && lds > 48 * 1024) {
         YR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -594,7 +597,10 @@ static int launch_mbe(const MbeArgs& a0, int batch, int want_segs, hipStream_t s
     (void)nm_len;
     yr_note_kernel(nm);
     auto kern = mbe_kernel<CIN, S, NT, MW, SP>;
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};   // per device
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    bool& attr_set = attr_set_dev[cur_dev & 63];
     if (!attr_set) {
         YR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         attr_set = true;

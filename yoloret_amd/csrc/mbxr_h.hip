@@ -1364,7 +1364,10 @@ static int launch_mbhr(const MbhrArgs& a0, int batch, int want_segs, hipStream_t
     (void)nm_len;
     yr_note_kernel(nm);
     auto kern = mbhr_kernel<T, S, ACT, NC, TO, NW, MW>;
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};   // per device: a process that drives several GPUs needs the attribute on each
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    bool& attr_set = attr_set_dev[cur_dev & 63];
     if (!attr_set && lds > 48 * 1024) {
         YR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -1704,7 +1707,10 @@ static int launch_mbhq(const MbhrArgs& a0, int batch, int want_segs, hipStream_t
     (void)nm_len;
     yr_note_kernel(nm);
     auto kern = mbhq_kernel<T, K, S, ACT, NC, TO, NT, NW, MW>;
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};   // per device: a process that drives several GPUs needs the attribute on each
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    bool& attr_set = attr_set_dev[cur_dev & 63];
     if (!attr_set && lds > 48 * 1024) {
         YR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;

@@ -2,6 +2,7 @@
 // by yoloret_amd.compiler; replays it on the caller's stream.  This is what stands in for
 // tf.keras.Model.__call__ on the graph built by yolov3_body (reference
 // code/yolo3/model.py:170-342, called at code/yolo.py:152 and code/yolo3/map.py:111).
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -189,9 +190,10 @@ static int64_t param_floats(const yr_op& op, int role) {   // role: 0 wgt, 1 sca
             if (role == 1 || role == 2) return ru(op.cout, 4);
             return 0;
         case YR_OP_SE_FC: {
-            const int64_t ldc = ru(op.cin, 4);
-            if (role == 0 || role == 3) return (int64_t)op.se_reduced * ldc;
-            if (role == 4) return op.se_reduced;
+            const int64_t ldc = ru(op.cin, 4), r4 = ru(op.se_reduced, 4);
+            if (role == 0) return ldc * r4;
+            if (role == 3) return (int64_t)op.se_reduced * ldc;
+            if (role == 4) return r4;
             if (role == 5) return ldc;
             return 0;
         }
@@ -362,6 +364,10 @@ extern "C" int yr_set_tuning(yr_handle* h, int batch, const int32_t* cfg, int n)
         const bool pw_ok = cfg[i] >= 0 && cfg[i] <= ncfg && (cfg[i] == 0 || h->ops[i].kind == YR_OP_POINTWISE);
         const bool mbh_ok = (h->ops[i].kind == YR_OP_MBH || h->ops[i].kind == YR_OP_MBX || h->ops[i].kind == YR_OP_MBR || h->ops[i].kind == YR_OP_MBE) && cfg[i] >= 0 && (cfg[i] & 0xff) == 0 && cfg[i] < (1 << 24);   // th << 8 | tw << 16
         YR_REQUIRE(pw_ok || mbh_ok, "yr_set_tuning: entry %d = %d is not a valid tile shape for that op", i, cfg[i]);
+        // a split-form block's fragments are packed for ONE nw: a table tuned for another form of the plan (YOLORET_MBR_SPLIT=0) is refused
+        const bool split_block = (h->ops[i].kind == YR_OP_MBR || h->ops[i].kind == YR_OP_MBE) && (h->ops[i].k & 0x80);
+        YR_REQUIRE(!split_block || (cfg[i] & 0xff00) == 0 || (cfg[i] & 0xff00) == (h->ops[i].k & 0xff00),
+                   "yr_set_tuning: entry %d asks for %d waves per workgroup, the split-form fragments of that op are packed for %d", i, (cfg[i] >> 8) & 0xff, (h->ops[i].k >> 8) & 0xff);
         t[i] = cfg[i];
     }
     h->tuned[batch] = t;
@@ -394,7 +400,11 @@ static int resolve_op(const yr_handle* h, size_t i, int batch, float* const ext[
         if (it != h->tuned.end()) op.k = (op.k & 0xff) | it->second[i];
     } else if (op.kind == YR_OP_MBR || op.kind == YR_OP_MBE) {   // (waves per workgroup << 8 | row segments << 16: the tuned walk geometry)
         auto it = h->tuned.find(batch);
-        if (it != h->tuned.end() && it->second[i] != 0) op.k = (op.k & 0xff) | it->second[i];
+        if (it != h->tuned.end() && it->second[i] != 0) {
+            // the SPLIT form's fragments are packed for the plan's nw (compiler.mbs_pack): only the row segments are tunable there
+            if (op.k & 0x80) op.k = (op.k & 0xffff) | (it->second[i] & 0xff0000);
+            else op.k = (op.k & 0xff) | it->second[i];
+        }
     }
     *out = op;
     return YR_OK;
@@ -414,6 +424,8 @@ static int check_forward_args(yr_handle* h, const float* images, int batch, void
 // every pass all the same: one 4 * n_sync * batch byte fill on the stream.
 static int clear_sync(const yr_handle* h, int batch, void* workspace, hipStream_t s) {
     if (h->n_sync == 0) return YR_OK;
+    static const bool skip = getenv("YR_NO_SYNC_CLEAR") != nullptr;   // (debugging)
+    if (skip) return YR_OK;
     YR_CHECK_HIP(hipMemsetAsync(static_cast<char*>(workspace) + yr_sync_offset(h, batch), 0, (size_t)h->n_sync * (size_t)batch * sizeof(uint32_t), s));
     return YR_OK;
 }
@@ -441,6 +453,44 @@ extern "C" int yr_forward(yr_handle* h, const float* images, int batch, float* y
         if (rc != YR_OK) return fail_op(i, h->ops[i].kind, rc);
     }
     return YR_OK;
+}
+
+// The forward pass with the largest |value| every op READS (its float32 k-space sources, a gated source's SE gate excluded):
+// max_abs_per_op[n_ops] on the host, +inf where a NaN was seen, 0 for ops without float32 sources.  What a float32 plan's SPLIT-form
+// ops need to know (their operands travel as two float16 planes: |x| must stay below 65504 - yoloret_amd Model.check_ranges runs this
+// once per set of weights and moves the ops beyond the bound to the float32-MFMA forms).  Synchronises the stream.
+extern "C" int yr_forward_ranges(yr_handle* h, const float* images, int batch, float* y1, float* y2, float* y3,
+                                 void* workspace, size_t workspace_bytes, void* stream, float* max_abs_per_op) {
+    int rc = check_forward_args(h, images, batch, workspace, workspace_bytes);
+    if (rc) return rc;
+    YR_REQUIRE(max_abs_per_op, "yr_forward_ranges: null result array");
+    float* ext[4] = {const_cast<float*>(images), y1, y2, y3};
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = h->ops.size();
+    unsigned* dmax = nullptr;
+    YR_CHECK_HIP(hipMalloc((void**)&dmax, n * sizeof(unsigned)));
+    rc = hipMemsetAsync(dmax, 0, n * sizeof(unsigned), s) == hipSuccess ? YR_OK : YR_ERR_HIP;
+    if (rc == YR_OK) rc = clear_sync(h, batch, workspace, s);
+    for (size_t i = 0; i < n && rc == YR_OK; ++i) {
+        yr_op op;
+        rc = resolve_op(h, i, batch, ext, static_cast<char*>(workspace), &op);
+        for (int k = 0; rc == YR_OK && k < op.nsrc; ++k) {
+            const yr_src& sr = op.src[k];
+            if (sr.dtype != YR_F32 || sr.ptr == nullptr || (i == 0 && h->bufs[h->ops[i].src[k].buf].external_slot == 0 && h->bufs[h->ops[i].src[k].buf].dtype != YR_F32)) continue;
+            rc = yr_launch_absmax((const float*)sr.ptr, (long long)batch * sr.h * sr.w, sr.c, sr.ld, dmax + i, s);
+        }
+        if (rc == YR_OK) rc = dispatch(op, batch, s);
+        if (rc != YR_OK) rc = fail_op(i, h->ops[i].kind, rc);
+    }
+    if (rc == YR_OK) {
+        std::vector<unsigned> bits(n);
+        rc = hipMemcpyAsync(bits.data(), dmax, n * sizeof(unsigned), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess ? YR_OK : YR_ERR_HIP;
+        if (rc == YR_OK)
+            for (size_t i = 0; i < n; ++i) memcpy(&max_abs_per_op[i], &bits[i], sizeof(float));
+        else yr_set_error("yr_forward_ranges: copying the result failed");
+    }
+    (void)hipFree(dmax);
+    return rc;
 }
 
 // Same replay with a hipEvent pair around every op, `iters` times; ms_per_op[i] receives the
@@ -482,6 +532,30 @@ extern "C" int yr_forward_profile(yr_handle* h, const float* images, int batch, 
     if (rc == YR_OK)
         for (size_t i = 0; i < n; ++i) ms_per_op[i] = (float)(acc[i] / iters);
     return rc;
+}
+
+// Does what op `i` writes (output, squeeze-excite sums / gate) overlap, in the arena, anything op `j` reads?  (Arena offsets are per
+// image and scale with the batch alike: the per-image intervals decide.)
+static bool output_aliases_inputs_of(const yr_handle* h, size_t i, size_t j) {
+    auto span = [&](int32_t b, int64_t* lo, int64_t* hi) {
+        if (b < 0 || h->bufs[b].external_slot >= 0) return false;
+        *lo = h->bufs[b].arena_off_per_image; *hi = *lo + h->bufs[b].bytes_per_image;
+        return true;
+    };
+    const yr_op& w = h->ops[i];
+    const yr_op& r = h->ops[j];
+    const int32_t writes[3] = {w.out_buf, (w.kind == YR_OP_SE_FC || w.kind == YR_OP_POINTWISE) ? -1 : w.gate_buf, w.gate_out_buf};
+    int32_t reads[YR_MAX_SRC + 2];
+    int nr = 0;
+    for (int k = 0; k < r.nsrc; ++k) reads[nr++] = r.src[k].buf;
+    reads[nr++] = r.res_buf;
+    reads[nr++] = (r.kind == YR_OP_POINTWISE) ? r.gate_buf : -1;
+    for (int32_t wb : writes)
+        for (int k = 0; k < nr; ++k) {
+            int64_t a0, a1, b0, b1;
+            if (span(wb, &a0, &a1) && span(reads[k], &b0, &b1) && a0 < b1 && b0 < a1) return true;
+        }
+    return false;
 }
 
 // Per-op tile autotuning for one batch size: runs the forward once (so every buffer holds real data), then
@@ -538,15 +612,19 @@ extern "C" int yr_autotune(yr_handle* h, const float* images, int batch, float* 
         if (h->ops[i].kind == YR_OP_MBR || h->ops[i].kind == YR_OP_MBE) {
             // register-chained float32 blocks: row segments per strip (how many waves the walk is cut into; each segment
             // recomputes two halo rows), IN CONTEXT - right behind the predecessor, whose output is what the caches hold (in
-            // isolation block_2 measured 203 us, in the pipeline 240).  Results do not depend on the choice.
+            // isolation block_2 measured 203 us, in the pipeline 240).  The maps do not depend on the choice (the squeeze-excite sums of a
+            // chained MBX op are grouped by segment: their float32 rounding does - within the op's tolerance, like any other grouping).
             yr_op op, prev;
             rc = resolve_op(h, i, batch, ext, static_cast<char*>(workspace), &op);
             if (rc) break;
-            bool have_prev = i > 0;
+            // ... unless op i's output shares arena memory with an input of the predecessor (their lifetimes do not overlap, so the
+            // planner may have placed them on top of each other): re-running the predecessor would then read what op i just wrote
+            bool have_prev = i > 0 && !output_aliases_inputs_of(h, i, i - 1);
             if (have_prev) {
                 rc = resolve_op(h, i - 1, batch, ext, static_cast<char*>(workspace), &prev);
                 if (rc) break;
                 if (h->ops[i - 1].kind == YR_OP_POINTWISE) prev.k = best[i - 1];
+                else if (best[i - 1] != 0 && (prev.k & 0x80)) prev.k = (prev.k & 0xffff) | (best[i - 1] & 0xff0000);
                 else if (best[i - 1] != 0) prev.k = (prev.k & 0xff) | best[i - 1];
             }
             static const int segs_list[] = {0, 1, 2, 3, 4, 6, 8};
@@ -594,7 +672,7 @@ extern "C" int yr_autotune(yr_handle* h, const float* images, int batch, float* 
         // shapes by up to 30 % (measured: td2_conv, block_7_expand).
         yr_op prev;
         bool have_prev = false;
-        if (i > 0) {
+        if (i > 0 && !output_aliases_inputs_of(h, i, i - 1)) {
             rc = resolve_op(h, i - 1, batch, ext, static_cast<char*>(workspace), &prev);
             if (rc) break;
             if (h->ops[i - 1].kind == YR_OP_POINTWISE) prev.k = best[i - 1];

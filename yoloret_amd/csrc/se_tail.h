@@ -1,20 +1,30 @@
-// Squeeze-excite finished by the kernel that produces the map ("SE tail", ABI 7).
+// Squeeze-excite finished by the kernel that produces the map ("SE tail", ABI 7) - and the FC pair itself (yr_se_fc_pair), which
+// se_fc_kernel shares.
+//
+// STATUS (round 5): the tail is OPT-IN (YOLORET_SE_TAIL=1), not what a plan gets by default.  It is bit-exact and deterministic in one
+// stream (tests/test_gpu_head.py), but with three steps in flight on three streams 5-27 of 64 images per step got a gate computed from
+// sums that were not yet the ones the other workgroups had published - whatever the publication used (write-through stores + sc1
+// loads, returning atomics at agent scope, at system scope; tools/plan_diff.py located it: the sums buffers end up right, the gates
+// differ in the fourth digit).  In a single stream the workgroups of one image run on ONE XCD (yr_xcd_swizzle) and share its L2;
+// beside other kernels the dispatcher spreads them over XCDs whose L2s are coherent only through a full write-back / invalidate
+// (__threadfence: measured 5 x the kernel's time with a fence per workgroup).  Default plans keep the SE_FC launch - made 2-3 x
+// faster by the FC pair below - and the kernel boundary as the only cross-XCD hand-over.
 //
 // The SE block (reference code/yolo3/efficientnet.py:406-438: Mean over H, W -> 1x1 + bias -> Swish -> 1x1 + bias ->
 // sigmoid) needs the channel means of the COMPLETE depthwise map; the kernels that produce that map already leave per-workgroup
 // channel sums (rows of a small float32 buffer).  Through round 4 a separate launch (se_fc_kernel, one workgroup per image)
 // added the rows up and ran the two tiny FCs: 6 launches of 11-22 us in every detection head, 21-30 in the SE EfficientNets, at
 // 0.003 of any pipe - a latency chain.  Here the workgroup that COMPLETES an image's rows does it on the spot:
-//   * every workgroup stores its sums with AGENT-scope stores (yr_st_agent: write-through to the device's coherence point), waits
-//     for them (vmcnt(0) + the workgroup barrier) and then adds its share to the image's arrival counter (agent-scope atomic);
+//   * every workgroup publishes its sums with returning atomic exchanges (yr_st_agent: performed at the device's coherence point),
+//     waits for their return (vmcnt(0) + the workgroup barrier) and then adds its share to the image's arrival counter (atomic);
 //   * the one that brings the counter to `arrivals` (all others have arrived before it) resets the counter, reads all rows
-//     with agent-scope loads (they were written on other CUs / XCDs), and computes mean -> FC1 -> swish -> FC2 -> sigmoid in a
+//     with returning atomics as well (yr_ld_agent), and computes mean -> FC1 -> swish -> FC2 -> sigmoid in a
 //     FIXED order - rows added in index order, hidden units and channels as sequential fma chains - so the gate does not depend
 //     on which workgroup happens to be last (a batch still equals its images run one by one).
 // What this deliberately does NOT use is __threadfence(): on gfx950 an agent-scope release is an L2 write-back (buffer_wbl2) of
 // everything the XCD holds dirty - i.e. of the map the kernel is busy writing - and measured 5 x the kernel's time (dw_kernel on
 // 52 x 52 x 128 @64: 46 -> 250 us with a fence per workgroup).  Only the sums need to be visible device-wide, so only they are
-// written through; the map reaches memory at the kernel boundary like every other output.
+// published that way; the map reaches memory at the kernel boundary like every other output.
 // 131 k multiply-adds per image at most (F = 512): a few microseconds on one CU, spread over as many CUs as there are images,
 // under the tail of the producing kernel.  No grid-wide barrier (round 3 measured that dead end), no co-residency assumption.
 //
@@ -22,6 +32,10 @@
 // start of every pass as well; yr_op_run callers hand in zeroed memory once).
 #pragma once
 #include "yr_common.h"
+
+#ifndef YR_SE_SCOPE
+#define YR_SE_SCOPE __HIP_MEMORY_SCOPE_SYSTEM
+#endif
 
 struct SeTail {
     const float* sums;   // [B][rows][ld_sums] partial channel sums written by this launch (nullptr: no tail)
@@ -34,10 +48,11 @@ struct SeTail {
     unsigned arrivals;   // what an image's counter reaches when all of its rows are stored (set by the launcher)
 };
 
-static inline size_t yr_se_tail_floats(int C, int R, int nth = 256) { return (size_t)yr_round_up(C, 4) + (size_t)yr_round_up(R, 4) + 4 * (size_t)nth; }   // LDS floats the tail needs
+static inline size_t yr_se_tail_floats(int C, int R, int nth = 256) { return (size_t)yr_round_up(C, 4) + (size_t)yr_round_up(R, 4) + 4 * (size_t)nth; }   // LDS floats the tail needs (== yr_se_fc_floats)
 #define YR_SE_TAIL_LDS 4608   // floats of LDS the kernels with a tail set aside for it (C + R + 1024 <= 4608: every EfficientNet up to B6)
 
 #ifdef __HIPCC__
+typedef float se_f4 __attribute__((ext_vector_type(4)));
 // host: fill a SeTail from an op that carries the ABI-7 fields (gate = the sums buffer it writes, gate_out, se_w, sync)
 static inline int yr_make_se_tail(const yr_op& op, int rows, SeTail* t) {
     t->sums = nullptr;
@@ -54,69 +69,61 @@ static inline int yr_make_se_tail(const yr_op& op, int rows, SeTail* t) {
     return YR_OK;
 }
 
-__device__ __forceinline__ float yr_ld_agent(const float* p) {   // a load that sees what other CUs / XCDs have written through
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// The partial sums travel between workgroups (CUs, XCDs) as RETURNING ATOMICS: an atomic read-modify-write is performed at the
+// device's coherence point and its returned value (waited for with vmcnt) proves it has been - no fence, no cache state involved.
+// (Round 5 tried write-through stores + sc1 loads first: correct in a strictly serial stream, WRONG with three steps in flight
+// on three streams - 5-27 images of 64 per step differed: a store acknowledged to the wave is not yet a store another XCD reads.)
+__device__ __forceinline__ float yr_ld_agent(const float* p) {   // the current value at the coherence point (fetch-or with 0: bit-exact)
+    return __uint_as_float(__hip_atomic_fetch_or(reinterpret_cast<unsigned*>(const_cast<float*>(p)), 0u, __ATOMIC_RELAXED, YR_SE_SCOPE));
 }
-// the store of a partial sum: through to the device's coherence point (no L2 write-back fence needed later)
-__device__ __forceinline__ void yr_st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void yr_st_agent(float* p, float v) {  // exchange; the old value is consumed so that the instruction returns (and counts in vmcnt until it has)
+    const unsigned old = __hip_atomic_exchange(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, YR_SE_SCOPE);
+    asm volatile("" ::"v"(old));
+}
 __device__ __forceinline__ void yr_st_agent4(float* p, float x, float y, float z, float w) {
     yr_st_agent(p, x); yr_st_agent(p + 1, y); yr_st_agent(p + 2, z); yr_st_agent(p + 3, w);
 }
 
-// The FC pair for image b by NTH cooperating threads (NTH = 64: one wave, no barriers; otherwise the whole workgroup).
-// lds: yr_se_tail_floats(C, R, NTH) floats.  The tail runs when the kernel is about to end - nothing hides it - so every stage
-// is cut for LATENCY: 16-byte loads, all NTH threads busy (a thread owns a quad of outputs and a SEGMENT of the inputs; the
-// segments' partial sums meet in LDS in segment order), a handful of load batches per stage instead of one load per multiply-add
-// (the first version - a thread per output, scalar loads - took 8-17 us per head block, as long as the se_fc launch it replaces).
-// Fixed orders throughout: the gate is a function of the sums alone.
-typedef float se_f4 __attribute__((ext_vector_type(4)));
-typedef unsigned se_u4 __attribute__((ext_vector_type(4)));
+// The store of a quad of partial sums: a plain 16-byte store when a later LAUNCH reads them (se_fc_kernel: the kernel boundary is the
+// hand-over - and the only form that was right with three steps in flight, tools/inflight_diff.py), atomics only under a tail.
+__device__ __forceinline__ void yr_st_sums4(float* p, const bool tail, float x, float y, float z, float w) {
+    if (tail) yr_st_agent4(p, x, y, z, w);
+    else *reinterpret_cast<se_f4*>(p) = (se_f4){x, y, z, w};
+}
+
+// The SE block's FC pair (efficientnet.py:419-434: 1x1 + bias -> Swish -> 1x1 + bias -> sigmoid) by NTH cooperating threads (64: one
+// wave, no barriers; otherwise the whole workgroup), shared by the SE tail below and se_fc_kernel (elementwise.hip).  Cut for
+// LATENCY - the launch / tail that runs it has nothing else to do: 16-byte weight loads, all NTH threads busy (a thread owns a quad
+// of outputs and a SEGMENT of the inputs; the segments' partial sums meet in LDS in segment order), a handful of load batches per
+// stage instead of one load per multiply-add (round 4's se_fc_kernel: one wave per hidden unit + butterflies, one thread per channel
+// with scalar loads: 11-22 us per launch).  Fixed orders throughout: the gate is a function of the means alone.
+struct SeFc {
+    const float* w1;   // [ldc][R4]  (the Keras kernel [1,1,C,R], rows padded to R4 = round_up(R, 4))
+    const float* w2;   // [R][ldc]
+    const float* b1;   // [R4]
+    const float* b2;   // [ldc]
+    int C, R, ldc;
+};
+__host__ __device__ static inline size_t yr_se_fc_floats(int C, int R, int nth) { return (size_t)((C + 3) & ~3) + (size_t)((R + 3) & ~3) + 4 * (size_t)nth; }   // LDS: mean | hid | partial quads
+
+// mean: [ldc] floats in LDS (pad channels zero), filled and visible to all threads (a barrier behind the writes); scratch: R4 + 4 NTH
+// floats behind it; gate: [>= ldc] floats of this image.
 template <int NTH>
-__device__ __forceinline__ void yr_se_tail_fc(const SeTail& t, const int b, float* lds, const int tid) {
-    const int R4 = (t.R + 3) & ~3, QP = t.ldc >> 2, JQ = R4 >> 2;
-    float* mean = lds;                               // [ldc]
-    float* hid = lds + t.ldc;                        // [R4]
-    se_f4* part = reinterpret_cast<se_f4*>(hid + R4);   // [NTH] quads
+__device__ __forceinline__ void yr_se_fc_pair(const SeFc& f, const float* mean, float* scratch, float* gate, const int tid) {
+    const int R4 = (f.R + 3) & ~3, QP = f.ldc >> 2, JQ = R4 >> 2;
+    float* hid = scratch;                                  // [R4]
+    se_f4* part = reinterpret_cast<se_f4*>(scratch + R4);  // [NTH] quads
     auto sync = [&]() { if constexpr (NTH > 64) __syncthreads(); };
     const se_f4 zero = (se_f4){0.f, 0.f, 0.f, 0.f};
-    // ---- the channel means: the rows written through by the other workgroups, read with agent-scope (sc1) 16-byte loads
-    {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(t.sums) + (size_t)b * t.rows * t.ld_sums, 0, (unsigned)(t.rows * t.ld_sums) * 4u, 0x00020000);
-        for (int q0 = 0; q0 < QP; q0 += NTH) {       // (one pass unless C > 4 NTH)
-            const int qp = QP - q0 < NTH ? QP - q0 : NTH;          // quads of this pass
-            const int nrs = NTH / qp, rps = (t.rows + nrs - 1) / nrs;   // row segments, rows per segment
-            const int q = tid % qp, seg = tid / qp;
-            se_f4 s = zero;
-            if (seg < nrs) {
-                const int ra = seg * rps, rb = ra + rps < t.rows ? ra + rps : t.rows;
-#pragma unroll 4
-                for (int r = ra; r < rb; ++r)
-                    s += __builtin_bit_cast(se_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(r * t.ld_sums + 4 * (q0 + q)) * 4u, 0, 16));   // aux 16: sc1
-            }
-            part[tid] = s;
-            sync();
-            if (tid < qp) {
-                se_f4 m = part[tid];
-                for (int sg = 1; sg < nrs; ++sg) m += part[sg * qp + tid];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) mean[4 * (q0 + tid) + i] = 4 * (q0 + tid) + i < t.C ? m[i] / t.count : 0.f;
-            }
-            sync();
-        }
-    }
-    const float* w1 = t.w;                               // [ldc][R4]
-    const float* w2 = t.w + (size_t)t.ldc * R4;          // [R][ldc]
-    const float* b1 = w2 + (size_t)t.R * t.ldc;          // [R4]
-    const float* b2 = b1 + R4;                           // [ldc]
     // ---- FC1 + swish: a thread = (channel segment, quad of hidden units)
     for (int j0 = 0; j0 < JQ; j0 += NTH) {
         const int jq = JQ - j0 < NTH ? JQ - j0 : NTH;
-        const int nseg = NTH / jq, cps = (t.C + nseg - 1) / nseg;
+        const int nseg = NTH / jq, cps = (f.C + nseg - 1) / nseg;
         const int j = tid % jq, seg = tid / jq;
         se_f4 s = zero;
         if (seg < nseg) {
-            const int ca = seg * cps, cb = ca + cps < t.C ? ca + cps : t.C;
-            const float* wp = w1 + 4 * (j0 + j);
+            const int ca = seg * cps, cb = ca + cps < f.C ? ca + cps : f.C;
+            const float* wp = f.w1 + 4 * (j0 + j);
 #pragma unroll 8
             for (int c = ca; c < cb; ++c) {
                 const se_f4 w = *reinterpret_cast<const se_f4*>(wp + (size_t)c * R4);
@@ -128,25 +135,25 @@ __device__ __forceinline__ void yr_se_tail_fc(const SeTail& t, const int b, floa
         part[tid] = s;
         sync();
         if (tid < jq) {
-            se_f4 v = *reinterpret_cast<const se_f4*>(b1 + 4 * (j0 + tid));
+            se_f4 v = *reinterpret_cast<const se_f4*>(f.b1 + 4 * (j0 + tid));
             for (int sg = 0; sg < nseg; ++sg) v += part[sg * jq + tid];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) hid[4 * (j0 + tid) + i] = 4 * (j0 + tid) + i < t.R ? yr_apply_act(v[i], YR_ACT_SWISH) : 0.f;
+            for (int i = 0; i < 4; ++i) hid[4 * (j0 + tid) + i] = 4 * (j0 + tid) + i < f.R ? yr_apply_act(v[i], YR_ACT_SWISH) : 0.f;
         }
         sync();
     }
     // ---- FC2 + sigmoid: a thread = (hidden-unit segment, channel quad)
     for (int q0 = 0; q0 < QP; q0 += NTH) {
         const int qp = QP - q0 < NTH ? QP - q0 : NTH;
-        const int nseg = NTH / qp, jps = (t.R + nseg - 1) / nseg;
+        const int nseg = NTH / qp, jps = (f.R + nseg - 1) / nseg;
         const int q = tid % qp, seg = tid / qp;
         se_f4 s = zero;
         if (seg < nseg) {
-            const int ja = seg * jps, jb = ja + jps < t.R ? ja + jps : t.R;
-            const float* wp = w2 + 4 * (q0 + q);
+            const int ja = seg * jps, jb = ja + jps < f.R ? ja + jps : f.R;
+            const float* wp = f.w2 + 4 * (q0 + q);
 #pragma unroll 8
             for (int j = ja; j < jb; ++j) {
-                const se_f4 w = *reinterpret_cast<const se_f4*>(wp + (size_t)j * t.ldc);
+                const se_f4 w = *reinterpret_cast<const se_f4*>(wp + (size_t)j * f.ldc);
                 const float hj = hid[j];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) s[i] = __builtin_fmaf(hj, w[i], s[i]);
@@ -155,14 +162,51 @@ __device__ __forceinline__ void yr_se_tail_fc(const SeTail& t, const int b, floa
         part[tid] = s;
         sync();
         if (tid < qp) {
-            se_f4 v = *reinterpret_cast<const se_f4*>(b2 + 4 * (q0 + tid));
+            se_f4 v = *reinterpret_cast<const se_f4*>(f.b2 + 4 * (q0 + tid));
             for (int sg = 0; sg < nseg; ++sg) v += part[sg * qp + tid];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = 4 * (q0 + tid) + i < t.C ? yr_sigmoid(v[i]) : 0.f;
-            *reinterpret_cast<se_f4*>(t.gate + (size_t)b * t.ld_gate + 4 * (q0 + tid)) = v;
+            for (int i = 0; i < 4; ++i) v[i] = 4 * (q0 + tid) + i < f.C ? yr_sigmoid(v[i]) : 0.f;
+            *reinterpret_cast<se_f4*>(gate + 4 * (q0 + tid)) = v;
         }
         sync();
     }
+}
+
+// The channel means of image b from rows of partial sums [rows][ld] (a thread owns a channel and a segment of the rows; the segments
+// meet in LDS in order), into mean[ldc].  ATOMIC: read every float with a returning atomic (the SE tail: the rows were published by
+// other workgroups of the same launch); otherwise plain loads (a separate launch: se_fc_kernel).  scratch: NTH floats.
+template <int NTH, bool ATOMIC>
+__device__ __forceinline__ void yr_se_mean_rows(const float* rows, const int nrows, const int ld, const int C, const int ldc, const float count, float* mean, float* scratch, const int tid) {
+    auto sync = [&]() { if constexpr (NTH > 64) __syncthreads(); };
+    for (int c0 = 0; c0 < ldc; c0 += NTH) {       // (one pass unless C > NTH)
+        const int cn = ldc - c0 < NTH ? ldc - c0 : NTH;          // channels of this pass
+        const int nrs = NTH / cn, rps = (nrows + nrs - 1) / nrs;   // row segments, rows per segment
+        const int c = tid % cn, seg = tid / cn;
+        float s = 0.f;
+        if (seg < nrs && c0 + c < C) {
+            const int ra = seg * rps, rb = ra + rps < nrows ? ra + rps : nrows;
+#pragma unroll 4
+            for (int r = ra; r < rb; ++r) s += ATOMIC ? yr_ld_agent(rows + (size_t)r * ld + c0 + c) : rows[(size_t)r * ld + c0 + c];
+        }
+        scratch[tid] = s;
+        sync();
+        if (tid < cn) {
+            float m = scratch[tid];
+            for (int sg = 1; sg < nrs; ++sg) m += scratch[sg * cn + tid];
+            mean[c0 + tid] = c0 + tid < C ? m / count : 0.f;
+        }
+        sync();
+    }
+}
+
+template <int NTH>
+__device__ __forceinline__ void yr_se_tail_fc(const SeTail& t, const int b, float* lds, const int tid) {
+    const int R4 = (t.R + 3) & ~3;
+    yr_se_mean_rows<NTH, true>(t.sums + (size_t)b * t.rows * t.ld_sums, t.rows, t.ld_sums, t.C, t.ldc, t.count, lds, lds + t.ldc + R4, tid);
+    SeFc f;
+    f.w1 = t.w; f.w2 = t.w + (size_t)t.ldc * R4; f.b1 = f.w2 + (size_t)t.R * t.ldc; f.b2 = f.b1 + R4;
+    f.C = t.C; f.R = t.R; f.ldc = t.ldc;
+    yr_se_fc_pair<NTH>(f, lds, lds + t.ldc, t.gate + (size_t)b * t.ld_gate, tid);
 }
 
 // Workgroup form: call by ALL NTH threads of the workgroup once its share of image b's sums is stored (uniform arguments); n: what it adds to the image's counter.
@@ -173,9 +217,9 @@ __device__ __forceinline__ void yr_se_tail_arrive(const SeTail& t, const int b, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's write-through stores of the sums have been acknowledged
     __syncthreads();                                   // ... and every other thread's
     if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(t.sync + b, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned old = __hip_atomic_fetch_add(t.sync + b, n, __ATOMIC_RELAXED, YR_SE_SCOPE);
         const bool last = old + n == t.arrivals;
-        if (last) __hip_atomic_store(t.sync + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nobody else touches it before the next launch)
+        if (last) __hip_atomic_store(t.sync + b, 0u, __ATOMIC_RELAXED, YR_SE_SCOPE);   // (nobody else touches it before the next launch)
         *flag = last ? 1u : 0u;
     }
     __syncthreads();
@@ -191,9 +235,9 @@ __device__ __forceinline__ void yr_se_tail_arrive_wave(const SeTail& t, const in
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores of the sums have been acknowledged
     unsigned last = 0u;
     if (lane == 0) {
-        const unsigned old = __hip_atomic_fetch_add(t.sync + b, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned old = __hip_atomic_fetch_add(t.sync + b, n, __ATOMIC_RELAXED, YR_SE_SCOPE);
         last = old + n == t.arrivals ? 1u : 0u;
-        if (last) __hip_atomic_store(t.sync + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (last) __hip_atomic_store(t.sync + b, 0u, __ATOMIC_RELAXED, YR_SE_SCOPE);
     }
     last = __builtin_amdgcn_readfirstlane(last);
     if (last == 0u) return;

@@ -31,6 +31,10 @@ class Model:
         self.inputs = inputs if isinstance(inputs, (list, tuple)) else [inputs]
         self.outputs = list(outputs)
         self.name = name
+        self._fuse = fuse
+        self._nosplit = frozenset()   # plan ops moved off the split (float16-plane) forms by check_ranges
+        self._ranges_checked = False
+        self.range_check = os.environ.get('YOLORET_RANGE_CHECK', '1') != '0'
         self.plan = compile_graph(self.inputs[0], self.outputs, fuse, self.dtype)
         # batches of up to SMALL_BATCH images run a second plan without block fusion (compiler.py: 'latency');
         # compiled on first use, same parameters, its own weight blob / handle / tile table.  Default (tools/lat_sweep.py, round 4):
@@ -70,6 +74,7 @@ class Model:
             wd[k] = a.reshape(shape)
         self._weights = wd
         self._blobs = {}
+        self._ranges_checked = False      # new weights, new activation ranges
         for (dev, variant), h in self._handles.items():
             blob = self._blob_of(variant)
             with torch.cuda.device(dev):
@@ -128,7 +133,7 @@ class Model:
     def plan_for(self, batch):
         v = self.variant(batch)
         if v not in self._plans:
-            self._plans[v] = compile_graph(self.inputs[0], self.outputs, v, self.dtype)
+            self._plans[v] = compile_graph(self.inputs[0], self.outputs, v, self.dtype, self._nosplit)
         return self._plans[v]
 
     def _blob_of(self, variant):
@@ -175,12 +180,16 @@ class Model:
             raise ValueError('input shape %s does not match the model input [B,%d,%d,%d]' % (tuple(x.shape), h, w, c))
         x = x.contiguous()
         b = x.shape[0]
+        if self.range_check and self.dtype == 0 and not self._ranges_checked:
+            # once per set of weights, on the first batch seen: the split-form ops' operands must stay inside the float16 range
+            self._ranges_checked = True
+            self.check_ranges(x, on_exceed='fallback')
         idx, hd = self._handle(x.device, b)
         need = self.workspace_bytes(b)
         wkey = idx if ctx == 0 else (idx, ctx)
         ws = self._workspace.get(wkey)
         if ws is None or ws.numel() < need:
-            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+            ws = (torch.zeros if os.environ.get('YR_NO_SYNC_CLEAR') else torch.empty)(max(need, 16), dtype=torch.uint8, device=x.device)
             self._workspace[wkey] = ws
         ys = out
         if ys is None:
@@ -209,7 +218,7 @@ class Model:
     # (tune once, deploy many; also keeps profiler runs free of the tuner's trial launches)
     def _tune_key(self, b):
         import zlib
-        sig = zlib.crc32(' '.join('%s:%d:%d:%d:%d' % (o.name, o.kind, o.cin, o.cout, o.dtype) for o in self.plan_for(b).ops).encode())
+        sig = zlib.crc32(' '.join('%s:%d:%d:%d:%d:%d' % (o.name, o.kind, o.cin, o.cout, o.dtype, o.k & 0xffff) for o in self.plan_for(b).ops).encode())   # (k: kernel size, split bit, waves per workgroup the fragments are packed for)
         return '%08x:%d' % (sig, b)
 
     def _load_tuning(self, hd, b):
@@ -243,6 +252,58 @@ class Model:
         data[self._tune_key(b)] = list(arr)
         with open(path, 'w') as f:
             json.dump(data, f)
+
+    def check_ranges(self, x, limit=None, on_exceed='fallback'):
+        """The activation-range guard of the split forms.  A float32 plan runs its 1x1 convolutions on the 16-bit matrix pipe with
+        every float32 operand as two float16 planes (22 significant bits, float32-grade results) - which needs |x| < 65504, a bound
+        the reference's float32 convolutions do not have (code/yolo3/model.py:20-30; MobileNetV2's linear bottlenecks and residual
+        sums are unclamped, override.py:290-341).  This runs one instrumented pass on `x` (yr_forward_ranges: the largest |value|
+        every op reads) and, for split-form ops that see more than `limit` (default compiler.SPLIT_LIMIT = 60000) or a NaN:
+          on_exceed='fallback': rebuilds the plan with those ops on the float32-MFMA forms (full float32 range; never a silent
+                                 clamped value) - what Model.__call__ does once per set of weights on the first batch it sees;
+          on_exceed='raise':    raises ValueError naming them;   on_exceed='report': changes nothing.
+        Returns {op name: max |input|} for every op of the plan that ran."""
+        from . import compiler as C
+        if limit is None:
+            limit = C.SPLIT_LIMIT
+        if self.dtype != 0:
+            return {}
+        x = x.contiguous()
+        b = x.shape[0]
+        result = {}
+        for _attempt in range(2):
+            idx, hd = self._handle(x.device, b)
+            plan = self.plan_for(b)
+            need = self.workspace_bytes(b)
+            ws = self._workspace.get(idx)
+            if ws is None or ws.numel() < need:
+                ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+                self._workspace[idx] = ws
+            ys = [torch.empty((b, ob.h, ob.w, ob.c), dtype=torch.float32, device=x.device) for ob in plan.output_bufs]
+            mx = (ctypes.c_float * len(plan.ops))()
+            with torch.cuda.device(idx):
+                rt.check(rt.lib().yr_forward_ranges(hd, rt._ptr(x), b, rt._ptr(ys[0]), rt._ptr(ys[1]), rt._ptr(ys[2]), rt._ptr(ws), ws.numel(),
+                                                    rt.stream_ptr(x.device), mx))
+            result = {op.name: float(mx[i]) for i, op in enumerate(plan.ops)}
+            bad = [plan.ops[i].name for i in C.split_form_ops(plan) if not (mx[i] <= limit)]
+            if not bad:
+                self._ranges_checked = True       # (a 'report' / 'raise' that found something leaves the automatic guard armed)
+                break
+            if on_exceed == 'report':
+                break
+            if on_exceed == 'raise':
+                raise ValueError('activations beyond the float16 range (%.0f) enter split-form ops: %s'
+                                 % (limit, ', '.join('%s (%.3g)' % (n, result[n]) for n in bad)))
+            # fallback: those ops leave the split forms; everything compiled / uploaded so far belongs to the old plan
+            self._nosplit = self._nosplit | frozenset(bad)
+            for h in self._handles.values():
+                rt.lib().yr_destroy(h)
+            self._handles, self._blobs, self._tuned = {}, {}, set()
+            fuse = self._fuse
+            self.plan = compile_graph(self.inputs[0], self.outputs, fuse, self.dtype, self._nosplit)
+            self._plans = {'throughput': self.plan}
+            self.range_fallbacks = sorted(self._nosplit)
+        return result
 
     def profile(self, x, iters=5):
         """Per-op timing (hipEvent pair around every launch, averaged over `iters` replays).
@@ -280,6 +341,9 @@ class Model:
                 # the split form: the 1x1 convolutions run on the 16-bit pipe as THREE float16 products per multiply-add (what that
                 # pipe executes), the depthwise stage on the float32 pipe
                 m32 = op.h * op.w * 9 * (op.cout if op.kind == rt.OP_MBE else op.se_reduced)
+                m16 = 3 * max(op.macs - m32, 0)
+            elif op.kind == rt.OP_HEAD:     # the 1x1 convolution in the split form, the depthwise stage on the float32 pipe
+                m32 = op.h * op.w * 9 * op.cout
                 m16 = 3 * max(op.macs - m32, 0)
             out.append(dict(name=op.name, kind=rt.OP_NAMES[op.kind], kernel=(names[i] or b'').decode(),
                             ms=float(ms[i]), macs=op.macs * b, macs_mfma16=m16 * b, macs_fp32=(op.macs - m16 if m32 is None else m32) * b, bytes=per_op_bytes[i] * b, hbm_bytes=per_op_hbm[i] * b))
