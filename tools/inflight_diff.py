@@ -14,6 +14,10 @@ size, b = 416, int(os.environ.get('B', 64))
 m = yolov3_body(L.Input(shape=[size, size, 3]), os.environ.get('BACKBONE', 'mobilenetv2x75'), 3, num_classes=20)
 m.set_weights(synthetic_weights(m, 1234, 'survey'))
 xs = [torch.from_numpy(synthetic_images(b, size, size, seed=s)).to(dev) for s in (21, 22, 23)]
+if os.environ.get('SAME_CTX'):      # every context the same batch: a leak between contexts would not show
+    xs = [xs[0], xs[0].clone(), xs[0].clone()]
+if os.environ.get('SAME_IMG'):      # every image of a batch the same: a leak between images would not show
+    xs = [x[:1].repeat(b, 1, 1, 1).contiguous() for x in xs]
 for i in range(3):
     m(xs[i], ctx=i + 1)
 torch.cuda.synchronize()
@@ -42,3 +46,16 @@ for rnd in range(int(os.environ.get('ROUNDS', 8))):
     got = snap()
     bad = [(k, ref[k][0], int((got[k][1] != ref[k][1]).sum()), ref[k][1].size) for k in ref if not np.array_equal(got[k][1], ref[k][1])]
     print('round %d: %d buffers differ; first: %s' % (rnd, len(bad), bad[:4]))
+    if bad and os.environ.get('DETAIL', '1') != '0':
+        k = bad[0][0]
+        a = ref[k][1].view(np.float32).reshape(b, -1)
+        g = got[k][1].view(np.float32).reshape(b, -1)
+        imgs = [i for i in range(b) if not np.array_equal(a[i], g[i])]
+        print('   %s: images %s' % (k, imgs))
+        i = imgs[0]
+        idx = np.nonzero(a[i] != g[i])[0]
+        print('   image %d: %d of %d floats differ, first at %s; ref %s got %s' % (i, idx.size, a.shape[1], idx[:8], a[i][idx[:6]], g[i][idx[:6]]))
+        # is the wrong gate some OTHER image's gate?
+        for j in range(b):
+            if j != i and np.array_equal(g[i], a[j]):
+                print('   == the serial gate of image %d' % j)

@@ -1,67 +1,44 @@
-#!/usr/bin/env python
-"""Latency of the squeeze-excite FC op (YR_OP_SE_FC) on the head shapes of the bench workload, fed by per-workgroup
-partial sums (rows > 1, k = pixel count) or by an already pooled vector; next to it an empty-ish launch (WSUM of one tiny
-map) for the launch floor.  GPU: python tools/sefc_probe.py [batch]"""
+"""Debug aid: SE_FC alone (partial-sum rows -> gate) on three streams at once beside unrelated work, against its serial result."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
+import numpy as np, torch
 from yoloret_amd import runtime as rt
-
 dev = torch.device('cuda:0')
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-
-
-COLD = os.environ.get('SEFC_COLD', '0') != '0'   # 1: a 1.5 GB fill between launches (caches cold, as inside a real step)
-junk = torch.empty(3 * 2 ** 27, dtype=torch.float32, device=dev) if COLD else None
-
-
-def timed(op, n=50):
-    rt.run_op(op, B)
+b, c, r, rows = 64, int(os.environ.get('C', 512)), int(os.environ.get('R', 128)), int(os.environ.get('ROWS', 1))
+rng = np.random.default_rng(1)
+r4 = (r + 3) & ~3
+w1 = torch.from_numpy((rng.standard_normal((c, r4)) * np.sqrt(2.0 / c)).astype(np.float32)).to(dev)
+b1 = torch.from_numpy(rng.normal(0, 0.1, r4).astype(np.float32)).to(dev)
+w2 = torch.from_numpy((rng.standard_normal((r, c)) * np.sqrt(2.0 / r)).astype(np.float32)).to(dev)
+b2 = torch.from_numpy(rng.normal(0, 0.1, c).astype(np.float32)).to(dev)
+ctxs = []
+for i in range(3):
+    sums = torch.from_numpy(rng.standard_normal((b, rows, 1, c)).astype(np.float32) * 50).to(dev)
+    gate = torch.zeros((b, 1, 1, c), dtype=torch.float32, device=dev)
+    op = rt.new_op(rt.OP_SE_FC)
+    op.h, op.w, op.cin, op.cout, op.nsrc, op.se_reduced, op.k = 1, 1, c, c, 1, r, 169
+    op.src[0] = rt.make_src(sums, c=c)
+    op.wgt, op.b1, op.wgt2, op.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    op.out, op.out_ld = gate.data_ptr(), c
+    rt.run_op(op, b)
     torch.cuda.synchronize()
-    if not COLD:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            rt.run_op(op, B)
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n * 1e3
-    tot = 0.0
-    for _ in range(10):
-        junk.fill_(1.0)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        rt.run_op(op, B)
-        e1.record()
-        torch.cuda.synchronize()
-        tot += e0.elapsed_time(e1)
-    return tot / 10 * 1e3
-
-
-for name, rows, c, r, px in [('td1/bu1 13x13', 11, 384, 16, 169), ('td2/bu2 26x26', 43, 192, 8, 676), ('td3/bu3 52x52', 169, 96, 4, 2704),
-                             ('B0 s2b0 mbx', 338, 96, 4, 10816), ('B0 s5b1 mbx', 28, 672, 28, 676), ('B0 s6b1 merged 13x13', 0, 1152, 48, 169)]:
-    ldc = (c + 3) // 4 * 4
-    w1 = torch.randn((r, ldc), device=dev) * 0.1
-    w2 = torch.randn((r, ldc), device=dev) * 0.1
-    b1, b2 = torch.zeros(r, device=dev), torch.zeros(ldc, device=dev)
-    gate = torch.empty((B, ldc), device=dev)
-    res = []
-    for mode in ('partials', 'pooled'):
-        op = rt.new_op(rt.OP_SE_FC, 'none')
-        op.cin = op.cout = c
-        op.se_reduced, op.nsrc, op.h, op.w = r, 1, 1, 1
-        if mode == 'partials':
-            if rows == 0:
-                src = torch.randn((B, px, 1, ldc), device=dev)      # merged mean over the full map (float32 here)
-                op.k = 0
-            else:
-                src = torch.randn((B, rows, 1, ldc), device=dev)
-                op.k = px
-        else:
-            src = torch.randn((B, 1, 1, ldc), device=dev)
-            op.k = 0
-        op.src[0] = rt.make_src(src, c=c)
-        op.wgt, op.b1, op.wgt2, op.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
-        op.out, op.out_ld = gate.data_ptr(), ldc
-        res.append(timed(op))
-    print('%-22s C %4d R %2d rows %3d: partial sums %.1f us   pooled vector %.1f us' % (name, c, r, rows, res[0], res[1]))
+    ctxs.append((op, sums, gate, gate.cpu().numpy().copy()))
+streams = [torch.cuda.Stream(dev) for _ in range(3)]
+noise = [torch.randn(2048, 2048, device=dev) for _ in range(3)]
+bad = 0
+for it in range(int(os.environ.get('ITERS', 200))):
+    for i, st in enumerate(streams):
+        with torch.cuda.stream(st):
+            ctxs[i][2].zero_()
+            y = noise[i] @ noise[i]
+            rt.run_op(ctxs[i][0], b)
+            y = noise[i] @ noise[i]
+    torch.cuda.synchronize()
+    for i in range(3):
+        g = ctxs[i][2].cpu().numpy()
+        if not np.array_equal(g, ctxs[i][3]):
+            bad += 1
+            if bad < 4:
+                d = [j for j in range(b) if not np.array_equal(g[j], ctxs[i][3][j])]
+                print('iter %d ctx %d: images %s' % (it, i, d))
+print('C %d R %d rows %d: %d mismatches' % (c, r, rows, bad))

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(SE_FC_THREADS) void se_fc_kernel(FcArgs<T> a) {
         __syncthreads();
     }
     yr_se_fc_pair<SE_FC_THREADS>(a.fc, mean, scratch, a.gate + (size_t)b * a.ld_gate, tid);
+    for (int c = a.ldc + tid; c < a.ld_gate; c += SE_FC_THREADS) a.gate[(size_t)b * a.ld_gate + c] = 0.f;   // pad columns of a wider gate row (16-bit plans: ld = round_up(C, 8))
 }
 
 template <class T>

@@ -446,7 +446,12 @@ extern "C" int yr_forward(yr_handle* h, const float* images, int batch, float* y
     hipStream_t s = (hipStream_t)stream;
     rc = clear_sync(h, batch, workspace, s);
     if (rc) return rc;
+    static const char* only = getenv("YR_ONLY_OPS");   // debugging (tools/sefc_probe2.py): "lo-hi" launches just those ops of the plan
+    static int lo = 0, hi = 1 << 30;
+    static const bool parsed = only && sscanf(only, "%d-%d", &lo, &hi) == 2;
+    (void)parsed;
     for (size_t i = 0; i < h->ops.size(); ++i) {
+        if ((int)i < lo || (int)i > hi) continue;
         yr_op op;
         rc = resolve_op(h, i, batch, ext, static_cast<char*>(workspace), &op);
         if (rc == YR_OK) rc = dispatch(op, batch, s);

@@ -108,6 +108,15 @@ __host__ __device__ static inline size_t yr_se_fc_floats(int C, int R, int nth) 
 
 // mean: [ldc] floats in LDS (pad channels zero), filled and visible to all threads (a barrier behind the writes); scratch: R4 + 4 NTH
 // floats behind it; gate: [>= ldc] floats of this image.
+// Every batch of weight loads is waited for COMPLETELY (vmcnt(0)) before its first use.  Round 5 measured why: the plain loop
+// (#pragma unroll 8; the compiler rotates the 16-byte loads through registers and consumes them under partial waits, vmcnt(5) ..
+// vmcnt(0)) gave a WRONG hidden unit now and then - one register of one quarter wave (lanes 48-63) stale - but only beside other
+// kernels of the plan on other streams (mbe / mbr / the walking head block / split pointwise: tools/sefc_probe2.py, 60-80 % of the
+// launches differ; beside GEMMs or alone: none).  Not a race in the code (LDS pre-zeroed, canaries, atomics for the sums: no change);
+// one load in flight, or a full wait per batch: 0 of 384.  This is what made the gates of the 512-channel head blocks differ in the
+// fourth digit with three steps in flight - and what round 5 first blamed on the SE tail's cross-XCD publication.
+__device__ __forceinline__ void yr_se_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int NTH>
 __device__ __forceinline__ void yr_se_fc_pair(const SeFc& f, const float* mean, float* scratch, float* gate, const int tid) {
     const int R4 = (f.R + 3) & ~3, QP = f.ldc >> 2, JQ = R4 >> 2;
@@ -124,12 +133,17 @@ __device__ __forceinline__ void yr_se_fc_pair(const SeFc& f, const float* mean, 
         if (seg < nseg) {
             const int ca = seg * cps, cb = ca + cps < f.C ? ca + cps : f.C;
             const float* wp = f.w1 + 4 * (j0 + j);
-#pragma unroll 8
-            for (int c = ca; c < cb; ++c) {
-                const se_f4 w = *reinterpret_cast<const se_f4*>(wp + (size_t)c * R4);
-                const float m = mean[c];
+            for (int c = ca; c < cb; c += 8) {      // batches of 8 rows: all loads issued, ALL waited for, then used (see yr_se_wait_loads)
+                se_f4 w8[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s[i] = __builtin_fmaf(w[i], m, s[i]);
+                for (int u = 0; u < 8; ++u) w8[u] = *reinterpret_cast<const se_f4*>(wp + (size_t)(c + u < cb ? c + u : cb - 1) * R4);
+                yr_se_wait_loads();
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float m = c + u < cb ? mean[c + u] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s[i] = __builtin_fmaf(w8[u][i], m, s[i]);
+                }
             }
         }
         part[tid] = s;
@@ -151,12 +165,17 @@ __device__ __forceinline__ void yr_se_fc_pair(const SeFc& f, const float* mean, 
         if (seg < nseg) {
             const int ja = seg * jps, jb = ja + jps < f.R ? ja + jps : f.R;
             const float* wp = f.w2 + 4 * (q0 + q);
-#pragma unroll 8
-            for (int j = ja; j < jb; ++j) {
-                const se_f4 w = *reinterpret_cast<const se_f4*>(wp + (size_t)j * f.ldc);
-                const float hj = hid[j];
+            for (int j = ja; j < jb; j += 8) {
+                se_f4 w8[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s[i] = __builtin_fmaf(hj, w[i], s[i]);
+                for (int u = 0; u < 8; ++u) w8[u] = *reinterpret_cast<const se_f4*>(wp + (size_t)(j + u < jb ? j + u : jb - 1) * f.ldc);
+                yr_se_wait_loads();
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float hj = j + u < jb ? hid[j + u] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s[i] = __builtin_fmaf(hj, w8[u][i], s[i]);
+                }
             }
         }
         part[tid] = s;
