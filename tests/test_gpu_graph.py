@@ -235,6 +235,27 @@ def test_odd_grids_with_all_graph_rewrites(dev, name, size):
         assert_close(y.cpu().numpy().reshape(r.shape), r, 1e-4, '%s@%d' % (name, size))
 
 
+def test_small_batch_plan_of_float32_models(dev):
+    """Round 5: a float32 model runs batches of up to 4 images on the 'nohead' variant (the throughput plan with the head blocks'
+    conv and depthwise as two launches - YR_OP_HEAD is a long chain per workgroup at a few images); same 1e-4 bar, same object."""
+    from yoloret_amd import runtime as rt
+    hw = (128, 128)
+    m, P = _build('mobilenetv2x75', hw, 20)
+    x = params.synthetic_images(6, hw[0], hw[1])
+    ref = om.yolov3_body(P, x, 'mobilenetv2x75', 3, 20)
+    m.set_weights(P.values)
+    m.small_batch = 4
+    assert m.small_variant == 'nohead' and m.variant(4) == 'nohead' and m.variant(5) == 'throughput'
+    xt = torch.from_numpy(x).to(dev)
+    small = [y.cpu().numpy() for y in m(xt[:3])]
+    big = [y.cpu().numpy() for y in m(xt)]
+    k_small, k_big = [o.kind for o in m.plan_for(3).ops], [o.kind for o in m.plan_for(6).ops]
+    assert rt.OP_HEAD not in k_small and k_big.count(rt.OP_HEAD) == 6 and k_small.count(rt.OP_MBR) == k_big.count(rt.OP_MBR) > 0
+    for i, r in enumerate(ref):
+        assert_close(small[i], r[:3], 1e-4, 'nohead plan, output %d' % i)
+        assert_close(big[i], r, 1e-4, 'throughput plan, output %d' % i)
+
+
 @pytest.mark.parametrize('model_name', ['mobilenetv2x75', 'efficientnetb0'])
 def test_small_batch_plan(dev, model_name):
     """Batches up to Model.small_batch run the plan without block fusion (its own handle, blob and tile table); it
@@ -245,7 +266,7 @@ def test_small_batch_plan(dev, model_name):
     x = params.synthetic_images(6, hw[0], hw[1])
     ref = om.yolov3_body(P, x, model_name, 3, 20)
     m.set_weights(P.values)
-    m.small_batch = 4
+    m.small_batch, m.small_variant = 4, 'latency'
     assert m.variant(2) == 'latency' and m.variant(6) == 'throughput'
     xt = torch.from_numpy(x).to(dev)
     small = [y.cpu().numpy() for y in m(xt[:2])]      # latency plan
@@ -433,7 +454,7 @@ def test_latency_plan_at_full_resolution_batch_1(dev, name, size):
     x = params.synthetic_images(1, size, size)
     ref = torch_ref.TorchReference(P, name, 3, 20)(x)   # (the torch-CPU graph: checked against the NumPy restatement in tests/test_golden.py)
     m.set_weights(P.values)
-    m.small_batch = 4
+    m.small_batch, m.small_variant = 4, 'latency'
     assert m.variant(1) == 'latency'
     kinds = set(o.kind for o in m.plan_for(1).ops)
     assert not kinds & {rt.OP_MBLANE, rt.OP_MBCONV, rt.OP_MBR, rt.OP_MBH}

@@ -89,6 +89,10 @@ def test_plan_variants(monkeypatch):
     from yoloret_amd import runtime as rt
     from yoloret_amd.weights import synthetic_weights
     monkeypatch.setenv('YOLORET_SMALL_BATCH', '4')
+    assert _model().small_variant == 'nohead'      # float32 default (round 5): the throughput plan without YR_OP_HEAD
+    nh = _model().plan_for(2)
+    assert rt.OP_HEAD not in [o.kind for o in nh.ops] and rt.OP_MBR in [o.kind for o in nh.ops]
+    monkeypatch.setenv('YOLORET_SMALL_VARIANT', 'latency')
     m = _model()
     assert m.small_batch == 4 and [m.variant(b) for b in (1, 4, 5, 64)] == ['latency', 'latency', 'throughput', 'throughput']
     lat, thr = m.plan_for(1), m.plan_for(64)

@@ -1608,7 +1608,10 @@ class Compiler:
                 if SE_PARTIALS:
                     ops = se_partials_from_depthwise(ops, self.bufs)
             ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency, dtype=self.dtype, bufs=self.bufs, nosplit=self.nosplit)
-            if FUSE_HEAD and not latency and self.dtype == 0:
+            # fuse == 'nohead': the float32 plan for a few images - the throughput plan without YR_OP_HEAD (a head block's conv + depthwise
+            # in one launch is one long chain per workgroup: at batch 1 td1 takes 43 us against 18 + 11 for its two launches;
+            # tools/lat_variants.sh, round 5: p50 @416 batch 1 / 2 / 4 / 8 = 0.606 / 0.622 / 0.666 / 0.767 ms against 0.648 / 0.656 / 0.687 / 0.766)
+            if FUSE_HEAD and not latency and self.fuse != 'nohead' and self.dtype == 0:
                 ops = fuse_head_blocks(ops, self.bufs, set(b.id for b in outs), nosplit=self.nosplit)
             if SE_TAIL:
                 ops = se_tail_into_producers(ops)

@@ -41,7 +41,10 @@ class Model:
         # 16-bit plans up to 2 images (lite0 @416 batch 1: 0.66 ms against 0.68, batch 4: 0.74 against 0.72); float32 plans never -
         # since their blocks run in the split form the fused plan is the faster one at every batch (MobileNetV2 x0.75 @416 batch 1:
         # 0.60 ms against 0.65, batch 4: 0.66 against 0.79)
-        self.small_batch = int(os.environ.get('YOLORET_SMALL_BATCH', '0' if self.dtype == 0 else '2')) if fuse is True else 0
+        # (round 5: float32 plans run batches of up to 4 images on the 'nohead' variant - block fusion and split forms kept, the head
+        # blocks' conv and depthwise as two launches: compiler.py)
+        self.small_batch = int(os.environ.get('YOLORET_SMALL_BATCH', '4' if self.dtype == 0 else '2')) if fuse is True else 0
+        self.small_variant = os.environ.get('YOLORET_SMALL_VARIANT', 'nohead' if self.dtype == 0 else 'latency')   # what those batches run
         self._plans = {'throughput': self.plan}
         self._weights = None
         self._blobs = {}
@@ -127,8 +130,9 @@ class Model:
 
     # ------------------------------------------------------------------ execution
     def variant(self, batch):
-        """Which plan a batch of this size runs: 'latency' (no block fusion) up to small_batch images."""
-        return 'latency' if 0 < batch <= self.small_batch else 'throughput'
+        """Which plan a batch of this size runs: up to small_batch images `small_variant` - 'latency' (no block fusion: 16-bit plans) or
+        'nohead' (the throughput plan without YR_OP_HEAD: float32 plans)."""
+        return self.small_variant if 0 < batch <= self.small_batch else 'throughput'
 
     def plan_for(self, batch):
         v = self.variant(batch)
