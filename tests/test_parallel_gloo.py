@@ -86,3 +86,74 @@ def test_world1_is_identity():
     d, c = torch.zeros((2, 4, 6), dtype=torch.int32), torch.zeros(2, dtype=torch.int32)
     a, b = DetectionGatherer()(d, c)
     assert a is d and b is c
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same path on REAL records: every rank turns its shard of one seeded batch of head logits into the pipeline's packed
+# records (decode -> per-class NMS -> pack: here by the CPU oracle, the checker of the GPU kernels, standing in for them),
+# the records go through shard_range + DetectionGatherer, and the product's unpack_detections() of the gathered bytes must give
+# what the unsharded batch gives - boxes, score BITS and classes, image by image in global order.
+REAL_B, REAL_HW, REAL_C, REAL_MAX = 8, (64, 96), 20, 20
+
+
+def _real_records(lo, hi):
+    sys.path.insert(0, ROOT)
+    from oracle import cpost
+    from yoloret_amd.yolo3.utils import get_anchors
+    anchors = get_anchors(os.path.join(ROOT, 'yoloret_amd', 'model_data', 'yolo_anchors.txt'))
+    rng = np.random.default_rng(2024)
+    h, w = REAL_HW
+    ys = [(rng.standard_normal((REAL_B, h // s, w // s, 3, REAL_C + 5)) * 2.0).astype(np.float32) for s in (32, 16, 8)]
+    shapes = rng.integers(40, 200, (REAL_B, 2))
+    slots = REAL_C * REAL_MAX
+    det = np.zeros((hi - lo, slots, 6), np.int32)
+    cnt = np.zeros(hi - lo, np.int32)
+    for i in range(lo, hi):
+        b, s, c, _ = cpost.yolo_eval([y[i] for y in ys], anchors, 3, REAL_C, shapes[i], REAL_MAX, 0.3, 0.5)
+        k = len(s)
+        det[i - lo, :k, 0:4] = b
+        det[i - lo, :k, 4] = s.view(np.int32)          # the score's float32 bits ride in the int32 record
+        det[i - lo, :k, 5] = c
+        cnt[i - lo] = k
+    return det, cnt
+
+
+def _real_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from yoloret_amd.parallel import DetectionGatherer, shard_range
+    from yoloret_amd.yolo3.model import unpack_detections
+    lo, hi = shard_range(REAL_B, rank, world)
+    det, cnt = _real_records(lo, hi)
+    record = torch.cat([torch.from_numpy(det).reshape(-1), torch.from_numpy(cnt)])     # DetectionPipeline.record's layout
+    d = record[:det.size].view(det.shape)
+    c = record[det.size:]
+    all_det, all_cnt = DetectionGatherer()(d, c, record)
+    res = [(b.numpy().copy(), s.numpy().copy(), k.numpy().copy()) for b, s, k in unpack_detections(all_det, all_cnt)]
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_real_records_sharded_gather_unpack_equals_unsharded():
+    from yoloret_amd.yolo3.model import unpack_detections
+    det, cnt = _real_records(0, REAL_B)
+    assert cnt.sum() > REAL_B and cnt.min() < cnt.max()      # a ragged batch of real detections
+    want = unpack_detections(torch.from_numpy(det), torch.from_numpy(cnt))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_real_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in got:
+        assert len(res) == REAL_B
+        for i, ((b, s, k), (wb, ws, wk)) in enumerate(zip(res, want)):
+            assert np.array_equal(b, wb.numpy()) and np.array_equal(s.view(np.int32), ws.numpy().view(np.int32)) and np.array_equal(k, wk.numpy()), \
+                'rank %d, image %d' % (rank, i)
