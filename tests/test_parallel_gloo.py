@@ -104,6 +104,8 @@ def _real_records(lo, hi):
     rng = np.random.default_rng(2024)
     h, w = REAL_HW
     ys = [(rng.standard_normal((REAL_B, h // s, w // s, 3, REAL_C + 5)) * 2.0).astype(np.float32) for s in (32, 16, 8)]
+    for y in ys:
+        y[..., 4] -= 5.0          # few cells carry an object: a ragged batch (some classes empty, no class full)
     shapes = rng.integers(40, 200, (REAL_B, 2))
     slots = REAL_C * REAL_MAX
     det = np.zeros((hi - lo, slots, 6), np.int32)
