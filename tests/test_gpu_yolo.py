@@ -159,6 +159,28 @@ def test_yolo_facade_loads_keras_h5(dev, tmp_path):
         assert np.array_equal(x, y)
 
 
+def test_yolo_facade_loads_the_committed_keras_h5(dev):
+    """The same on a box WITHOUT h5py: tests/golden/detector_mbv2x75_q.h5 is a full detector's checkpoint (164 layers, 64 of them under
+    Keras' automatic names with the reference's numbering gaps, gzip + shuffle chunks) written once by tests/golden/make_detector_h5.py;
+    YOLO({'model': that file}) must detect exactly what a detector holding the parameters it was written from detects."""
+    import os
+    from tests.golden.make_detector_h5 import OUT, quantized_weights
+    from yoloret_amd.yolo import YOLO
+    from yoloret_amd.yolo3.enums import BACKBONE
+    flags = {'input_size': (96, 96), 'backbone': BACKBONE.MOBILENETV2x75, 'score': 0.2, 'nms': 0.5}
+    a = YOLO(dict(flags, model='synthetic:7'))
+    a.yolo_model.model.set_weights(quantized_weights(a.yolo_model.model, 7))
+    assert os.path.getsize(OUT) < 4 << 20
+    b = YOLO(dict(flags, model=OUT))
+    wa, wb = a.yolo_model.model.get_weights(), b.yolo_model.model.get_weights()
+    assert set(wa) == set(wb) and all(np.array_equal(wa[k], wb[k]) for k in wa)
+    img = np.random.default_rng(3).integers(0, 256, (80, 120, 3), dtype=np.uint8)
+    ra, rb = a.detect_image(_png(img), draw=False), b.detect_image(_png(img), draw=False)
+    assert len(ra[0]) > 0
+    for x, y in zip(ra, rb):
+        assert np.array_equal(x, y)
+
+
 def test_map_callback_through_the_hip_model(dev, tmp_path):
     """reference code/yolo3/map.py:107-111: MAPCallback drives `self.model([image bytes])` per image.  Here the model
     is the HIP YoloModel; the ground truth written to the label file is the detector's own output (truncated to whole

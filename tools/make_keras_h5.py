@@ -59,7 +59,7 @@ def main():
                 a = z['%s/%s' % (lname, p)]
                 if p == 'depthwise_kernel':
                     a = a.reshape(a.shape + (1,))       # Keras: [kh, kw, C, 1]
-                kw = dict(compression='gzip', shuffle=True, chunks=True) if compress and a.size > 64 else {}
+                kw = dict(compression='gzip', compression_opts=9, shuffle=True, chunks=True) if compress and a.size > 64 else {}
                 g.create_dataset('%s/%s:0' % (kname, p), data=a.astype(np.float32), **kw)
     print('wrote %s: %d layers (%d automatically named)' % (out, len(names), sum(1 for l in layers if not l[2])))
 
