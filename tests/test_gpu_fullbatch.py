@@ -132,3 +132,38 @@ def test_c2_three_steps_in_flight_equal_the_serial_pipeline(dev):
     torch.cuda.synchronize()
     for d, c, ev, j in outs[-2:]:
         assert np.array_equal(d.cpu().numpy(), want[j][0]) and np.array_equal(c.cpu().numpy(), want[j][1]), j
+
+
+@pytest.mark.parametrize('name,dt,size,b', [('efficientnetb0', 'bf16', 416, 32), ('efficientnetb3', 'f16', 320, 8), ('mobilenetv2x14', 'f32', 512, 16),
+                                            ('mobilenetv2x75', 'f32', 416, 64)])
+def test_logits_of_three_contexts_in_flight_equal_the_serial_pass(dev, name, dt, size, b):
+    """Every plan family with three forward passes in flight on three streams (three contexts of one Model): the raw logits of
+    every pass equal the serial pass bit for bit, eight rounds.  Round 5 found why this needs its own test at the kernels' real
+    sizes: se_fc_kernel's weight loads, consumed under partial vmcnt waits, went wrong ONLY beside other kernels of the plan on
+    other streams (se_tail.h: yr_se_wait_loads) - a single stream, a small model or unrelated neighbours never showed it; the
+    squeeze-excite EfficientNets run 21-30 such launches per pass."""
+    from yoloret_amd import layers as L
+    from yoloret_amd.weights import synthetic_images, synthetic_weights
+    from yoloret_amd.yolo3.model import yolov3_body
+    L.set_global_policy({'f32': 'float32', 'bf16': 'mixed_bfloat16', 'f16': 'mixed_float16'}[dt])
+    try:
+        m = yolov3_body(L.Input(shape=[size, size, 3]), name, 3, num_classes=20)
+    finally:
+        L.set_global_policy('float32')
+    m.set_weights(synthetic_weights(m, 1234, 'survey'))
+    xs = [torch.from_numpy(synthetic_images(b, size, size, seed=s)).to(dev) for s in (21, 22, 23)]
+    want = []
+    for i, x in enumerate(xs):
+        want.append([y.cpu().numpy().copy() for y in m(x, ctx=i + 1)])
+    torch.cuda.synchronize()
+    assert not np.array_equal(want[0][0], want[1][0])
+    streams = [torch.cuda.Stream(dev) for _ in range(3)]
+    for rnd in range(8):
+        outs = []
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs.append(m(xs[i], ctx=i + 1))
+        torch.cuda.synchronize()
+        for i, ys in enumerate(outs):
+            for j, y in enumerate(ys):
+                assert np.array_equal(y.cpu().numpy(), want[i][j]), (rnd, i, j)
