@@ -41,7 +41,10 @@ struct HwArgs {
 __device__ __forceinline__ float hw_swish(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f)); }
 
 template <int NKE, int NT, bool PRE, bool GATED>
-__global__ __launch_bounds__(256, 2) void hwalk_kernel(HwArgs a) {
+#ifndef HW_OCC
+#define HW_OCC 2
+#endif
+__global__ __launch_bounds__(256, HW_OCC) void hwalk_kernel(HwArgs a) {
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float tab[];
     __shared__ unsigned se_flag;
