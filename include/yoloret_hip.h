@@ -191,6 +191,13 @@ typedef enum {
                             activation ReLU6 / none): wgt = the planes of bit 7 WITH the conv's BN scale folded in, scale = that BN scale [F],
                             shift unused, wgt2 = [F / 16][11][16]: depthwise taps x BN scale | depthwise BN shift | conv BN shift (YR_OP_MBR's
                             table); se_reduced = yr_head_walk_rows(h, w).
+                            16-BIT PLANS (dtype = out_dtype = bf16 | f16; headwalk_h.hip): the walking form only (k bit 6) - identity sources
+                            of the op's type (ld % 8 == 0), optionally a float32 YR_X_UP2_ADD last source, at most 8 chunks of 32 channels,
+                            F % 128 == 0; wgt = the conv's 16-bit weights in fragment order [F / 16][NK][64 lanes][8] WITHOUT the BN scale
+                            (yoloret_amd.compiler.head_pack16), scale = conv BN scale [F] float32, wgt2 as above; float32 from the
+                            accumulator on, ONE rounding at the store (the F-wide conv output is never rounded to 16 bits), the sums are
+                            those of the stored values; an SE gate (res) is folded into the stationary weights (w * g rounded once);
+                            no SE tail (gate_out must be null).
                             res / res_ld (optional) = the float32 SE gate vector [B][res_ld] multiplied onto the single identity source on load
                             (`gate` is taken by the sums this op writes); k bits 16-23 (optional) = cout tiles of 16 per workgroup.
                             SE tail: gate = OUTPUT float32 [B][se_reduced][gate_ld] channel sums, one row per region (se_reduced = regions per

@@ -274,3 +274,141 @@ def test_se_tail_of_depthwise(dev):
         assert_close(from_dev(out, c), ref, 2e-5, 'depthwise (SE tail)')
         assert int(keep[4].abs().sum().item()) == 0
         assert_close(from_dev(gate, c), se_gate_ref(ref, *sp).reshape(b, c), 2e-5, 'SE tail gate')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# YR_OP_HEAD of the 16-bit plans (headwalk_h.hip): sources and conv weights exactly representable in the 16-bit type, float32 from
+# the accumulator on, ONE rounding at the store - the bar of tests/test_gpu_narrow.py (the float64 value of the same expression
+# rounded once: half an ulp of the type + float32 noise).  The F-wide conv output is NOT rounded in between (the unfused pair of
+# launches rounds it: the fused op is the more accurate one).
+
+def run_head16(dev, dt, rng, b, h, w, segs, f, pre=False, gated=False, se=True, conv_act='relu6', dw_act='swish', tile=False):
+    from tests.util import assert_rounded_once, from_dev16, q16, to_dev16
+    from yoloret_amd.compiler import head_pack16
+    rt = _rt()
+    did = rt.dtype_id(dt)
+    nb = b
+    if tile:
+        b = 1
+    srcs_np, srcs_dev = [], []
+    for c in segs:
+        a = np.repeat(q16(rng.standard_normal((b, h, w, c)), dt), nb // b, axis=0)
+        srcs_np.append(a)
+        srcs_dev.append(to_dev16(a, dev, dt))
+    cin = sum(segs)
+    wk = q16(rng.standard_normal((cin, f)) * np.sqrt(2.0 / cin), dt)
+    kp = sum(round_up(c, 8) for c in segs)
+    wt = np.zeros((f, kp), np.float32)
+    d = kb = 0
+    for c in segs:
+        wt[:, kb:kb + c] = wk[d:d + c].T
+        d += c
+        kb += round_up(c, 8)
+    x = nn.concat(srcs_np).astype(np.float64)
+    wk64 = wk.astype(np.float64)
+    gate_np = None
+    if gated:
+        gate_np = np.repeat(rng.uniform(0.1, 1.0, (b, 1, 1, cin)).astype(np.float32), nb // b, axis=0)
+        # the kernel folds the gate into its stationary weights: w * g in float32, rounded once to the operand type
+        wg = q16(wk[None] * gate_np.reshape(nb, cin, 1), dt).astype(np.float64)     # [B][cin][f]
+        e = np.einsum('bhwc,bcf->bhwf', x, wg)
+    else:
+        e = x @ wk64
+    pre_np = None
+    if pre:
+        pre_np = np.repeat(rng.standard_normal((b, h // 2, w // 2, f)).astype(np.float32), nb // b, axis=0)
+        e = e + nn.upsample2(pre_np).astype(np.float64)
+    b = nb
+    cs = rng.uniform(0.5, 1.5, f).astype(np.float32)
+    ch = rng.normal(0, 0.3, f).astype(np.float32)
+    e = _act_np(e * cs + ch, conv_act)
+    dk = (rng.standard_normal((3, 3, f)) * np.sqrt(2.0 / 9)).astype(np.float32)
+    ds = rng.uniform(0.5, 1.5, f).astype(np.float32)
+    dh = rng.normal(0, 0.3, f).astype(np.float32)
+    y = _act_np(nn.depthwise(e, dk.astype(np.float64), 1, 'same') * ds + dh, dw_act)
+    t16 = f // 16
+    tab = np.zeros((t16, 11, 16), np.float32)
+    tab[:, :9] = (dk.reshape(9, f) * ds[None]).astype(np.float32).reshape(9, t16, 16).transpose(1, 0, 2)
+    tab[:, 9], tab[:, 10] = dh.reshape(t16, 16), ch.reshape(t16, 16)
+    frag = head_pack16(wt, segs)
+    wd = torch.from_numpy(rt.to_bits16(frag, dt).view(np.int16)).to(dev)
+    ldf = round_up(f, 8)
+    out = to_dev16(np.full((b, h, w, ldf), np.nan, np.float32), dev, dt)
+    op = rt.new_op(rt.OP_HEAD, dw_act)
+    op.dtype = op.out_dtype = did
+    op.h, op.w, op.cin, op.cout, op.stride = h, w, cin, f, 1
+    op.k = 3 | rt.ACT[conv_act] << 8 | 0x40
+    n = 0
+    for t, c in zip(srcs_dev, segs):
+        op.src[n] = rt.make_src(t, c=c, xform='identity')
+        n += 1
+    keep = [wd, _dev_vec(cs, dev), _dev_vec(tab, dev)]
+    if pre:
+        pd = to_dev(pre_np, dev, fill=0.0)
+        keep.append(pd)
+        op.src[n] = rt.make_src(pd, c=f, xform='up2_add')
+        n += 1
+    op.nsrc = n
+    op.wgt, op.scale, op.wgt2 = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
+    if gated:
+        g = to_dev(gate_np.reshape(b, 1, 1, cin), dev)
+        keep.append(g)
+        op.res, op.res_ld = g.data_ptr(), g.shape[3]
+    op.out, op.out_ld = out.data_ptr(), ldf
+    sums = None
+    if se:
+        rows = ctypes.c_int32()
+        rt.check(rt.lib().yr_head_walk_rows(h, w, ctypes.byref(rows)))
+        sums = torch.full((b, rows.value, ldf), float('nan'), dtype=torch.float32, device=dev)
+        op.gate, op.gate_ld, op.se_reduced = sums.data_ptr(), ldf, rows.value
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    got = from_dev16(out, dt, f)
+    # float32 noise of two chained stages (conv accumulation over up to 256 channels, nine taps): 1e-4 of slack beside the half ulp
+    assert_rounded_once(got, y, dt, 'head16 %s %s -> %d' % (dt, segs, f), slack=1e-4)
+    s = None
+    if se:
+        s = from_dev(sums, f)
+        assert_close(s.astype(np.float64).sum(axis=1) / (h * w), got.astype(np.float64).mean(axis=(1, 2)), 2e-5, 'head16: squeeze-excite sums of the stored values')
+    return got, s
+
+
+HEAD16_CASES = [
+    # (h, w, segs, F, pre, gated)                                       the walkable head blocks of the EfficientNet configurations
+    (52, 52, [40], 128, True, False),            # td3 (B0 @416)
+    (52, 52, [128], 128, False, True),           # bu3
+    (26, 26, [112, 96], 256, True, False),       # td2: 4 + 3 chunks
+    (26, 26, [128, 75], 256, False, False),      # bu2: a partial last octet (75 of 80)
+    (40, 40, [136, 96], 256, True, False),       # td2 (B3 @640): 5 + 3 = 8 chunks
+    (80, 80, [48], 128, True, False),            # td3 (B3)
+    # other shapes: three sources, ragged widths (two strips with one column in the second), one chunk, F = 512, no ReLU6
+    (15, 15, [40, 75, 64], 128, False, False),
+    (13, 13, [96, 128], 512, False, False),
+    (28, 30, [160], 128, True, False),
+    (7, 5, [24], 128, False, False),
+    (20, 20, [200], 256, False, True),
+]
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+@pytest.mark.parametrize('case', HEAD16_CASES, ids=[str(i) for i in range(len(HEAD16_CASES))])
+def test_head_block_16bit(dev, dt, case):
+    h, w, segs, f, pre, gated = case
+    rng = np.random.default_rng(zlib.crc32((str(case) + dt).encode()))
+    run_head16(dev, dt, rng, 3, h, w, segs, f, pre=pre, gated=gated)
+
+
+def test_head_block_16bit_variants(dev):
+    rng = np.random.default_rng(77)
+    run_head16(dev, 'bf16', rng, 2, 26, 26, [72], 128, se=False, dw_act='relu6')
+    run_head16(dev, 'f16', rng, 2, 13, 13, [120, 40], 256, conv_act='none')
+
+
+def test_head_block_16bit_batch_independent(dev):
+    """an image's stored map and its squeeze-excite sums do not depend on the batch it runs in (rows of the sums = strips x row
+    segments of the SHAPE)."""
+    for dt in ('bf16', 'f16'):
+        one, s1 = run_head16(dev, dt, np.random.default_rng(12), 1, 52, 52, [40], 128, pre=True)
+        many, sm = run_head16(dev, dt, np.random.default_rng(12), 7, 52, 52, [40], 128, pre=True, tile=True)
+        for i in range(7):
+            assert np.array_equal(many[i], one[0]) and np.array_equal(sm[i], s1[0]), 'image %d of the batch differs from the image run alone' % i

@@ -459,3 +459,49 @@ def test_fold_projection_handles_chains_of_linear_convs():
             got = np.clip(got, 0, 6)
     assert len(ops) < 6, 'nothing was folded'
     assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_head_blocks_of_the_16bit_plans_and_their_fragment_packing():
+    """Round 5: the head blocks of a 16-bit plan whose sources are identity sources (td2, td3, bu3, bu2 in every EfficientNet
+    configuration) are YR_OP_HEAD ops in the walking form (headwalk_h.hip); td1 (a pooled source) and bu1 (11 chunks of 32 channels)
+    stay conv + depthwise.  compiler.head_pack16 is the MFMA A-fragment order of a [F][kp] matrix whose k space is cut into chunks
+    of 32 channels per source; a serialised plan carrying the ops passes yr_create_from_blob's extent checks."""
+    import numpy as np
+    from yoloret_amd import compiler, layers as L, runtime as rt, weights as W
+    from yoloret_amd.yolo3.model import yolov3_body
+    for name, size, policy in [('efficientnetb0', 416, 'mixed_bfloat16'), ('efficientnetb3-lite', 640, 'mixed_float16')]:
+        p = _plan16(name, size, policy)
+        heads = {o.name: o for o in p.ops if o.kind == rt.OP_HEAD}
+        assert sorted(heads) == ['bu2_head', 'bu3_head', 'td2_head', 'td3_head'], (name, sorted(heads))
+        for o in heads.values():
+            assert o.k & 0x40 and o.dtype == p.dtype and o.out.dtype == p.dtype and o.gate is not None and o.gate.dtype == 0
+            assert o.se_reduced == compiler.head_walk_rows(o.h, o.w) == o.gate.h
+            nk = sum((s.c + 31) // 32 for s in o.srcs if s.xform != 'up2_add')
+            assert nk <= 8 and o.params['wgt'][0] == ((o.cout // 16) * nk * 512,) and o.params['wgt'][2] == p.dtype
+        assert heads['bu3_head'].res is not None and len(heads['bu3_head'].srcs) == 1          # reads td3's map through its SE gate
+        names = [o.name for o in p.ops]
+        assert 'td1_conv' in names and 'bu1_conv' in names and 'td2_conv' not in names
+    # the fragment order: lane (m, g) of tile t, chunk j of source s holds W[16 t + m][32 j + 8 g + i of s]
+    rng = np.random.default_rng(0)
+    segs = [40, 75]
+    kp = sum((c + 7) // 8 * 8 for c in segs)
+    wt = rng.standard_normal((32, kp)).astype(np.float32)
+    fr = compiler.head_pack16(wt, segs).reshape(2, 5, 4, 16, 8)           # [t][chunk][g][m][i]; chunks: 2 of source 0, 3 of source 1
+    assert np.array_equal(fr[1, 0, 2, 3], wt[16 + 3, 16:24])
+    assert np.array_equal(fr[0, 1, 0, 5], wt[5, 32:40]) and not fr[:, 1, 1:].any()            # source 0 ends at channel 40
+    assert np.array_equal(fr[1, 4, 1, 0, :3], wt[16, 40 + 64 + 8:40 + 64 + 11]) and not fr[:, 4, 1, :, 3:].any()   # 75 = 64 + 11
+    # a serialised 16-bit plan with head ops is accepted as far as a box without a GPU can tell (extent / size checks come first)
+    L.set_global_policy('mixed_bfloat16')
+    try:
+        m = yolov3_body(L.Input(shape=[64, 64, 3]), 'efficientnetb0', 3, num_classes=20)
+    finally:
+        L.set_global_policy('float32')
+    m.set_weights(W.synthetic_weights(m, 1, 'conditioned'))
+    data = m.save_plan()
+    h = ctypes.c_void_p()
+    buf = (ctypes.c_char * len(data)).from_buffer_copy(data)
+    rc = rt.lib().yr_create_from_blob(buf, len(data), ctypes.byref(h))
+    err = rt.lib().yr_last_error()
+    assert rc == 0 or (b'does not fit' not in err and b'bytes' not in err and b'parameter' not in err), err
+    if rc == 0:
+        rt.lib().yr_destroy(h)

@@ -821,6 +821,79 @@ def head_pack(wt, seg_c, V=4):
     return np.ascontiguousarray(out).reshape(-1).view(np.float32)
 
 
+def head_pack16(wt, seg_c, V=8):
+    """The 1x1 convolution's weights Wt [F][kp] (k space = the sources' channels, each padded to V = 8) in the fragment order of the
+    16-bit walking head kernel (headwalk_h.hip): [F / 16][NK][64 lanes][8] with the k space cut into chunks of 32 channels PER SOURCE -
+    lane (m = l % 16, g = l / 16) of cout tile t, chunk j of source s: W[16 t + m][channel 32 j + 8 g + i of s], zero beyond the
+    source.  float32 values; Plan.build_blob rounds them to the plan's 16-bit type (they are the conv's weights as they are: the BN
+    scale stays a float32 vector)."""
+    wt = np.asarray(wt, np.float32)
+    F = wt.shape[0]
+    assert F % 16 == 0
+    chunks, kb = [], 0
+    for c in seg_c:
+        chunks += [(kb + 32 * j, min(32, c - 32 * j)) for j in range((c + 31) // 32)]
+        kb += round_up(c, V)
+    W = np.zeros((F, len(chunks), 32), np.float32)
+    for ci, (k0, vc) in enumerate(chunks):
+        W[:, ci, :vc] = wt[:, k0:k0 + vc]
+    W = W.reshape(F // 16, 16, len(chunks), 4, 8).transpose(0, 2, 3, 1, 4)          # [t][chunk][g][m][i]  (lane = 16 g + m)
+    return np.ascontiguousarray(W).reshape(-1)
+
+
+def _head_block16(c, d, readers, output_buf_ids):
+    """A 16-bit plan's head block (conv 1x1 -> depthwise 3x3 with squeeze-excite sums) as YR_OP_HEAD in the walking form
+    (headwalk_h.hip), or None: identity sources of the plan's type (+ a float32 up2_add addend), at most HEAD_WALK16_MAX_NK chunks of
+    32 channels, F a multiple of 128 (four waves x two cout tiles per workgroup)."""
+    if d is None or not FUSE_HEAD or not HEAD_WALK:
+        return None
+    kseg = [s_.c for s_ in c.srcs if s_.xform != 'up2_add']
+    nk = sum((c_ + 31) // 32 for c_ in kseg)
+    F = c.cout
+    ok = (c.act in ('relu6', 'none') and 'scale' in c.params and c.res is None and not getattr(c, 'stride', 0) and not getattr(c, 'accounted_in', None)
+          and all(s_.xform in ('identity', 'up2_add') for s_ in c.srcs) and all(s_.buf.dtype == c.dtype and s_.buf.ld % 8 == 0 for s_ in c.srcs if s_.xform != 'up2_add')
+          and all(s_.buf.dtype == 0 for s_ in c.srcs if s_.xform == 'up2_add') and sum(s_.xform == 'up2_add' for s_ in c.srcs) <= 1
+          and (not c.srcs or c.srcs[-1].xform == 'up2_add' or all(s_.xform == 'identity' for s_ in c.srcs))
+          and 1 <= len(kseg) <= 3 and nk <= HEAD_WALK16_MAX_NK and F % 128 == 0 and F * 11 * 4 <= 64 * 1024
+          and (c.gate is None or (len(c.srcs) == 1 and c.srcs[0].xform == 'identity'))
+          and c.out.external_slot < 0 and c.out.id not in output_buf_ids and readers.get(id(c.out), 0) == 1 and c.out.dtype == c.dtype
+          and d.kind == rt.OP_DEPTHWISE and d.dtype == c.dtype and d.k == 3 and d.stride == 1 and len(d.srcs) == 1 and d.srcs[0].buf is c.out
+          and d.srcs[0].xform == 'identity' and d.srcs[0].c == F and d.act in ('swish', 'relu6', 'none') and d.out.ld % 4 == 0 and d.out.dtype == c.dtype
+          and d.res is None and d.gate_out is None and not (c.h == 1 and c.w == 1) and (d.gate is not None or FUSE_HEAD_ALL))
+    if not ok:
+        return None
+    m = OpRec(rt.OP_HEAD, c.name.rsplit('_', 1)[0] + '_head', act=d.act, h=d.h, w=d.w, cin=c.cin, cout=F, k=3 | rt.ACT[c.act] << 8 | 0x40, stride=1,
+              srcs=list(c.srcs), out=d.out, res=c.gate, macs=c.macs + d.macs, dtype=c.dtype)
+    m.fused = [c, d]
+    if getattr(c, 'folded_projection', None):
+        m.folded_projection = c.folded_projection
+    cp, dp = c.params, d.params
+
+    def frags(wd, cp=cp, kseg=kseg, F=F):
+        return head_pack16(np.asarray(cp['wgt'][1](wd), np.float32)[:F], kseg)
+
+    def tab(wd, cp=cp, dp=dp, F=F):
+        T = F // 16
+        o = np.zeros((T, 11, 16), np.float32)
+        kk = np.asarray(dp['wgt'][1](wd), np.float32).reshape(9, -1)[:, :F]
+        o[:, :9] = (kk * np.asarray(dp['scale'][1](wd), np.float32)[None, :F]).astype(np.float32).reshape(9, T, 16).transpose(1, 0, 2)
+        o[:, 9], o[:, 10] = np.asarray(dp['shift'][1](wd), np.float32)[:F].reshape(T, 16), np.asarray(cp['shift'][1](wd), np.float32)[:F].reshape(T, 16)
+        return o
+    m.params = {'wgt': (((F // 16) * nk * 512,), frags, c.dtype), 'scale': cp['scale'], 'wgt2': ((F // 16, 11, 16), tab)}
+    if d.gate is not None:     # the squeeze-excite sums: one row per (strip, row segment)
+        part = d.gate
+        part.h, part.w = head_walk_rows(d.h, d.w), 1
+        part.elems = part.h * part.w * part.ld
+        part.bytes = part.elems * rt.ESIZE[part.dtype]
+        m.gate, m.se_reduced = part, part.h
+    if hasattr(c, 'accounting_srcs'):
+        m.fused[0].accounting_srcs = c.accounting_srcs
+    return m
+
+
+HEAD_WALK16_MAX_NK = min(8, int(os.environ.get('YOLORET_HEAD_WALK16_MAX_NK', '8')))
+
+
 def fuse_head_blocks(ops, bufs, output_buf_ids, nosplit=frozenset()):
     readers = {}
     for op in ops:
@@ -834,6 +907,15 @@ def fuse_head_blocks(ops, bufs, output_buf_ids, nosplit=frozenset()):
         c = ops[i]
         d = ops[i + 1] if i + 1 < len(ops) else None
         kp = sum(round_up(s_.c, 4) for s_ in c.srcs if s_.xform != 'up2_add')
+        if c.kind == rt.OP_POINTWISE and c.dtype != 0:
+            m16 = _head_block16(c, d, readers, output_buf_ids)
+            if m16 is not None:
+                out.append(m16)
+                i += 2
+            else:
+                out.append(c)
+                i += 1
+            continue
         ok = (d is not None and c.kind == rt.OP_POINTWISE and c.dtype == 0 and c.act in ('relu6', 'none', 'swish', 'leaky') and 'scale' in c.params
               and c.res is None and not getattr(c, 'stride', 0) and not (c.se_reduced & 0x10000) and not getattr(c, 'accounted_in', None)
               and all(s_.xform in ('identity', 'up2', 'maxpool2', 'maxpool4', 'up2_add') for s_ in c.srcs)
@@ -1611,7 +1693,7 @@ class Compiler:
             # fuse == 'nohead': the float32 plan for a few images - the throughput plan without YR_OP_HEAD (a head block's conv + depthwise
             # in one launch is one long chain per workgroup: at batch 1 td1 takes 43 us against 18 + 11 for its two launches;
             # tools/lat_variants.sh, round 5: p50 @416 batch 1 / 2 / 4 / 8 = 0.606 / 0.622 / 0.666 / 0.767 ms against 0.648 / 0.656 / 0.687 / 0.766)
-            if FUSE_HEAD and not latency and self.fuse != 'nohead' and self.dtype == 0:
+            if FUSE_HEAD and not latency and self.fuse != 'nohead':
                 ops = fuse_head_blocks(ops, self.bufs, set(b.id for b in outs), nosplit=self.nosplit)
             if SE_TAIL:
                 ops = se_tail_into_producers(ops)

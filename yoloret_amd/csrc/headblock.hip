@@ -498,8 +498,8 @@ static int launch_head(const HeadArgs& h, int batch, hipStream_t s) {
 }
 
 int yr_launch_head(const yr_op& op, int batch, hipStream_t s) {
-    YR_REQUIRE(op.dtype == YR_F32 && op.out_dtype == YR_F32, "head: float32 plans only");
-    if (op.k & 0x40) return yr_launch_head_walk(op, batch, s);   // the walking form (headwalk.hip)
+    if (op.k & 0x40) return yr_launch_head_walk(op, batch, s);   // the walking form (headwalk.hip; headwalk_h.hip for the 16-bit plans)
+    YR_REQUIRE(op.dtype == YR_F32 && op.out_dtype == YR_F32, "head: the LDS-tiled forms are float32 only (16-bit plans: the walking form, k bit 6)");
     YR_REQUIRE((op.k & 0x7f) == 3 && op.stride == 1, "head: depthwise 3x3, stride 1");
     YR_REQUIRE(op.out && op.wgt && op.wgt2, "head: null pointer");
     const bool v2 = (op.k & 0x80) != 0;     // the weights are float16 planes in fragment order (compiler.head_pack)

@@ -245,9 +245,6 @@ __global__ __launch_bounds__(256, HW_OCC) void hwalk_kernel(HwArgs a) {
     yr_se_tail_arrive<256>(a.se, b, 1u, &se_flag, tab);   // (tab: the launcher sizes the dynamic LDS for the tail's scratch as well)
 }
 
-// rows of a head map a walking wave takes per segment (shape only: the squeeze-excite sums are grouped by (strip, segment))
-static inline int hw_seg_rows(int H) { return H <= 16 ? H : (H + ((H + 12) / 13) - 1) / ((H + 12) / 13); }
-
 extern "C" int yr_head_walk_rows(int h, int w, int32_t* rows) {
     YR_REQUIRE(h > 0 && w > 0 && rows, "yr_head_walk_rows: bad arguments");
     const int sr = hw_seg_rows(h);
@@ -294,6 +291,7 @@ static int launch_hwalk(HwArgs& a, int batch, hipStream_t s) {
 // folded in; scale = the conv's BN scale [F] (for the pre-BN addend); wgt2 = [T = F / 16][11][16]: depthwise taps x BN scale |
 // depthwise BN shift | conv BN shift (YR_OP_MBR's table); se_reduced = yr_head_walk_rows(h, w).
 int yr_launch_head_walk(const yr_op& op, int batch, hipStream_t s) {
+    if (op.dtype != YR_F32) return yr_launch_head_walk_h(op, batch, s);   // the 16-bit plans' twin (headwalk_h.hip)
     YR_REQUIRE(op.dtype == YR_F32 && op.out_dtype == YR_F32 && op.out && op.wgt && op.wgt2 && op.scale, "head (walking form): float32, non-null parameters");
     YR_REQUIRE((op.k & 0x3f) == 3 && op.stride == 1 && op.cout % 16 == 0 && op.out_ld % 4 == 0 && op.out_ld >= op.cout, "head (walking form): 3x3 stride 1, F a multiple of 16");
     const int act = (op.k >> 8) & 0xff;

@@ -108,3 +108,6 @@ __device__ __forceinline__ v4f mbs_mfma(mbs_u4 a, mbs_u4 b, v4f c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mbs_h8, a), __builtin_bit_cast(mbs_h8, b), c, 0, 0, 0);
 }
 
+// rows of a head map a walking wave takes per segment (headwalk.hip / headwalk_h.hip; shape only: the squeeze-excite sums are
+// grouped by (strip, segment))
+static inline int hw_seg_rows(int H) { return H <= 16 ? H : (H + ((H + 12) / 13) - 1) / ((H + 12) / 13); }

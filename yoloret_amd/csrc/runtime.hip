@@ -170,7 +170,7 @@ static int64_t param_floats(const yr_op& op, int role) {   // role: 0 wgt, 1 sca
                 int64_t nk = 0;
                 for (int i = 0; i < op.nsrc; ++i)
                     if (op.src[i].xform != YR_X_UP2_ADD) nk += (op.src[i].c + 31) / 32;
-                return ru(op.cout, 16) / 16 * nk * 512;
+                return ru(op.cout, 16) / 16 * nk * (op.dtype == YR_F32 ? 512 : 256);   // (16-bit plans, walking form: one 16-bit fragment set, headwalk_h.hip)
             }
             [[fallthrough]];   // (the convolution's parameters as POINTWISE)
         case YR_OP_POINTWISE: {
