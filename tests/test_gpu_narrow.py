@@ -439,6 +439,18 @@ def test_logits16_small(dev, dt, model_name, hw):
     _check_vs_emulation(ref, emu, got, '%s@%dx%d %s' % (model_name, hw[0], hw[1], dt))
 
 
+@pytest.mark.parametrize('dt,model_name,hw', [('bf16', 'efficientnetb0', (416, 416)), ('f16', 'efficientnetb3-lite', (320, 320)), ('bf16', 'efficientnetb0-lite', (224, 160))])
+def test_logits16_with_every_walkable_head_block_fused(dev, monkeypatch, dt, model_name, hw):
+    """The measured default fuses only td3 in a 16-bit plan (compiler.HEAD_WALK16_MAX_NK = 2); with the limit at 8 the plan
+    runs td2, td3, bu3 and bu2 on headwalk_h.hip (7 - 8 chunks, a gated source, up-sampled addends) - held to the same bar."""
+    from yoloret_amd import compiler
+    monkeypatch.setattr(compiler, 'HEAD_WALK16_MAX_NK', 8)
+    m, _, ref, emu, got = _graph16(dev, model_name, hw, 2, dt)
+    heads = [o.name for o in m.plan.ops if o.kind == _rt().OP_HEAD]
+    assert sorted(heads) == ['bu2_head', 'bu3_head', 'td2_head', 'td3_head'], heads
+    _check_vs_emulation(ref, emu, got, '%s@%dx%d %s, four head blocks fused' % (model_name, hw[0], hw[1], dt))
+
+
 # Absolute bars of the whole-graph 16-bit tests: (scaled max, scaled mean) logit error against the float32 oracle, about
 # twice what round 3 measured (profiles/r03_fullres_tests.txt).  The error is a property of model x format on RANDOM
 # weights far more than of the kernels: the squeeze-excite / swish EfficientNets sit at 5e-3 (bf16) and 1e-3 (f16), the

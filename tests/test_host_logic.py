@@ -278,6 +278,7 @@ SCRATCH_ALLOWED = {
     '_Z10dwq_kernelIDF16_Li5ELi1ELb1E': 16,        # f16 5x5 swish squeeze-excite walk: three values parked outside the row loop at 168 registers
     '_Z10pws_kernelILi2ELi2ELi4ELi1ELb0E': 12,     # the 128 x 32 tile with gathered sources at 168 registers (since the k loop moved to pws_common.h; no plan of the BASELINE models picks it)
     '_Z10mbr_kernel': 12,          # split form (..ELb1EEv): the three-wave stride-1 block at 168 registers and 48 -> 288 -> 72 at 256 park two values
+    '_Z12hwalk_kernelILi4ELi2ELb1ELb0E': 8,        # walking head, four chunks + an up-sampled addend at 256 registers (no BASELINE plan picks it)
 }
 
 
@@ -461,14 +462,17 @@ def test_fold_projection_handles_chains_of_linear_convs():
     assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
 
 
-def test_head_blocks_of_the_16bit_plans_and_their_fragment_packing():
+def test_head_blocks_of_the_16bit_plans_and_their_fragment_packing(monkeypatch):
     """Round 5: the head blocks of a 16-bit plan whose sources are identity sources (td2, td3, bu3, bu2 in every EfficientNet
-    configuration) are YR_OP_HEAD ops in the walking form (headwalk_h.hip); td1 (a pooled source) and bu1 (11 chunks of 32 channels)
-    stay conv + depthwise.  compiler.head_pack16 is the MFMA A-fragment order of a [F][kp] matrix whose k space is cut into chunks
-    of 32 channels per source; a serialised plan carrying the ops passes yr_create_from_blob's extent checks."""
+    configuration) CAN run as YR_OP_HEAD ops in the walking form (headwalk_h.hip; compiler.HEAD_WALK16_MAX_NK = 8); the measured
+    default takes the blocks of at most two chunks (td3).  td1 (a pooled source) and bu1 (11 chunks of 32 channels) stay conv +
+    depthwise.  compiler.head_pack16 is the MFMA A-fragment order of a [F][kp] matrix whose k space is cut into chunks of 32
+    channels per source; a serialised plan carrying the ops passes yr_create_from_blob's extent checks."""
     import numpy as np
     from yoloret_amd import compiler, layers as L, runtime as rt, weights as W
     from yoloret_amd.yolo3.model import yolov3_body
+    assert [o.name for o in _plan16('efficientnetb0', 416).ops if o.kind == rt.OP_HEAD] == ['td3_head']      # the default
+    monkeypatch.setattr(compiler, 'HEAD_WALK16_MAX_NK', 8)
     for name, size, policy in [('efficientnetb0', 416, 'mixed_bfloat16'), ('efficientnetb3-lite', 640, 'mixed_float16')]:
         p = _plan16(name, size, policy)
         heads = {o.name: o for o in p.ops if o.kind == rt.OP_HEAD}

@@ -891,7 +891,12 @@ def _head_block16(c, d, readers, output_buf_ids):
     return m
 
 
-HEAD_WALK16_MAX_NK = min(8, int(os.environ.get('YOLORET_HEAD_WALK16_MAX_NK', '8')))
+# (measured, round 5, SE EfficientNet-B0 bf16 @416 batch 128 | B3 f16 @640 batch 32, us, fused | conv + depthwise: td3 (2 chunks) 69 | 90, 52 | 62;
+#  td2 (7 / 8 chunks) 64 | 73, 53 | 54; bu3 (4 chunks, gated) 86 | 87, 60 | 58; bu2 (7) 62 | 57, 49 | 46 - the 16-bit pair of launches runs at
+#  3.6 - 4 TB/s on half the float32 bytes, the fused launch is bound by the depthwise stage's VALU work (DPP multiply-adds on 14 of 16
+#  lanes, 15 rows walked per 13 stored, Swish at the transcendental rate); with steps in flight all four fused: B0 +0.4 %, B3 -3.8 %.
+#  Default: the blocks of at most 2 chunks - td3.)
+HEAD_WALK16_MAX_NK = min(8, int(os.environ.get('YOLORET_HEAD_WALK16_MAX_NK', '2')))
 
 
 def fuse_head_blocks(ops, bufs, output_buf_ids, nosplit=frozenset()):

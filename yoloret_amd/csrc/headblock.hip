@@ -137,7 +137,7 @@ __device__ __forceinline__ void head_finish(const HeadArgs& h, const HeadRegion&
                 const int nl = c * 16 + g * 4;
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(ss + nl);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(ss + BN + nl);
-                f32x4 v = ac1[c][p] * 0.00048828125f + acc[c][p];
+                f32x4 v = __builtin_elementwise_fma(ac1[c][p], (f32x4){0.00048828125f, 0.00048828125f, 0.00048828125f, 0.00048828125f}, acc[c][p]);
                 if (use_pre) v += pq[p][c];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], sc[r], sh[r]);
@@ -442,11 +442,10 @@ __global__ __launch_bounds__(256, 2) void head2_kernel(HeadArgs h) {
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const pws_f2 x2 = (pws_f2){v[2 * i], v[2 * i + 1]};
-                    const pws_h2 hh = __builtin_convertvector(x2, pws_h2);
-                    const pws_h2 mm = __builtin_convertvector((x2 - __builtin_convertvector(hh, pws_f2)) * 2048.0f, pws_h2);
-                    xh[p][i] = __builtin_bit_cast(unsigned, hh);
-                    xm[p][i] = __builtin_bit_cast(unsigned, mm);
+                    unsigned hh, mm;
+                    yr_cut2(v[2 * i], v[2 * i + 1], hh, mm);
+                    xh[p][i] = hh;
+                    xm[p][i] = mm;
                 }
             }
             pws_u4 wh[CT], wm[CT];

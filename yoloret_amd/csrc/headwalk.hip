@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, HW_OCC) void hwalk_kernel(HwArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            ec[j] = e1[j] * 0.00048828125f + ec[j];
+            ec[j] = __builtin_elementwise_fma(e1[j], (v4f){0.00048828125f, 0.00048828125f, 0.00048828125f, 0.00048828125f}, ec[j]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) ec[j][i] = __builtin_amdgcn_fmed3f(ec[j][i], actmin, actmax) * live;
         }

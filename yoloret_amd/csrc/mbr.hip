@@ -200,7 +200,7 @@ __device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const i
                 for (int j = 0; j < NT; ++j) e1[j] = mbs_mfma(wem[j][c], xh[c], e1[j]);
             }
 #pragma unroll
-            for (int j = 0; j < NT; ++j) ec[j] = e1[j] * 0.00048828125f + ec[j];
+            for (int j = 0; j < NT; ++j) ec[j] = __builtin_elementwise_fma(e1[j], (v4f){0.00048828125f, 0.00048828125f, 0.00048828125f, 0.00048828125f}, ec[j]);   // (an FMA by name: the library is built without contraction)
         } else {
 #pragma unroll
             for (int q = 0; q < KE; ++q)
@@ -289,7 +289,7 @@ __device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const i
         }
         if constexpr (EMIT && SP) {
 #pragma unroll
-            for (int t = 0; t < TO; ++t) P[t] = P1[t] * 0.00048828125f + P[t];
+            for (int t = 0; t < TO; ++t) P[t] = __builtin_elementwise_fma(P1[t], (v4f){0.00048828125f, 0.00048828125f, 0.00048828125f, 0.00048828125f}, P[t]);
         }
         if constexpr (EMIT) {
             const int yl = yo + podd;   // (stride 2: lanes 8..15 hold the row below)
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256, MW) void mbe_kernel(MbeArgs a) {
                 for (int j = 0; j < NT; ++j) e1[j] = mbs_mfma(wem[j][c], xh, e1[j]);
             }
 #pragma unroll
-            for (int j = 0; j < NT; ++j) ec[j] = e1[j] * 0.00048828125f + ec[j];
+            for (int j = 0; j < NT; ++j) ec[j] = __builtin_elementwise_fma(e1[j], (v4f){0.00048828125f, 0.00048828125f, 0.00048828125f, 0.00048828125f}, ec[j]);   // (an FMA by name: the library is built without contraction)
         } else {
             float xq[KE];
 #pragma unroll

@@ -16,8 +16,10 @@ __device__ __forceinline__ float mbr_shl1(float v) {   // lane l <- lane l + 1, 
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, true));
 }
 
-// One tap ROW of the 3x3 depthwise conv for the lane's 4 channels: acc[i] += shr(e[i]) * w0[i] + e[i] * w1[i] + shl(e[i]) * w2[i].
-// The DPP shift rides on the multiply-add's first operand (v_fmac_f32_dpp: no v_mov_dpp, no extra register) and the four
+// One tap ROW of the 3x3 depthwise conv for the lane's 4 channels: acc[i] += e[i] * w1[i] + shr(e[i]) * w0[i] + shl(e[i]) * w2[i].
+// The centre tap needs no shift and runs as two v_pk_fma_f32 (round 5: 10 instead of 12 VALU slots per row - and four operands
+// fewer in the asm statement, which ended the scratch spills of the three-wave block kernels).  For the outer taps the DPP shift
+// rides on the multiply-add's first operand (v_fmac_f32_dpp: no v_mov_dpp, no extra register) and the four
 // channels' chains are interleaved tap-major, so a dependent instruction sits four slots behind its producer.  hipcc 7.2 does
 // not fold update_dpp into the fma (left to itself: 6 v_mov_b32_dpp + hazard nops per channel, one chain after the other).
 // s_nop 1: a VALU write of e[] must be two wait states ahead of a DPP read (the hazard recogniser does not look into asm).
@@ -26,23 +28,20 @@ __device__ __forceinline__ float mbr_shl1(float v) {   // lane l <- lane l + 1, 
 // slower everywhere it spilled, equal elsewhere.)
 #define MBR_DPP(ctl) " " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 __device__ __forceinline__ void mbr_dw_row(v4f& acc, const v4f e, const v4f w0, const v4f w1, const v4f w2) {
+    acc = __builtin_elementwise_fma(e, w1, acc);     // the centre tap needs no shift: two v_pk_fma_f32 instead of four v_fmac_f32
     float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
     asm("s_nop 1\n\t"
         "v_fmac_f32_dpp %0, %4, %8" MBR_DPP("row_shr:1")
         "v_fmac_f32_dpp %1, %5, %9" MBR_DPP("row_shr:1")
         "v_fmac_f32_dpp %2, %6, %10" MBR_DPP("row_shr:1")
         "v_fmac_f32_dpp %3, %7, %11" MBR_DPP("row_shr:1")
-        "v_fmac_f32 %0, %4, %12\n\t"
-        "v_fmac_f32 %1, %5, %13\n\t"
-        "v_fmac_f32 %2, %6, %14\n\t"
-        "v_fmac_f32 %3, %7, %15\n\t"
-        "v_fmac_f32_dpp %0, %4, %16" MBR_DPP("row_shl:1")
-        "v_fmac_f32_dpp %1, %5, %17" MBR_DPP("row_shl:1")
-        "v_fmac_f32_dpp %2, %6, %18" MBR_DPP("row_shl:1")
-        "v_fmac_f32_dpp %3, %7, %19" MBR_DPP("row_shl:1")
+        "v_fmac_f32_dpp %0, %4, %12" MBR_DPP("row_shl:1")
+        "v_fmac_f32_dpp %1, %5, %13" MBR_DPP("row_shl:1")
+        "v_fmac_f32_dpp %2, %6, %14" MBR_DPP("row_shl:1")
+        "v_fmac_f32_dpp %3, %7, %15" MBR_DPP("row_shl:1")
         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
         : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(w0[0]), "v"(w0[1]), "v"(w0[2]), "v"(w0[3]),
-          "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(w1[3]), "v"(w2[0]), "v"(w2[1]), "v"(w2[2]), "v"(w2[3]));
+          "v"(w2[0]), "v"(w2[1]), "v"(w2[2]), "v"(w2[3]));
     acc = (v4f){a0, a1, a2, a3};
 }
 
@@ -97,11 +96,10 @@ typedef unsigned mbs_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void mbs_split8(const float (&v)[8], mbs_u4& h, mbs_u4& m) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const mbs_h2 hh = __builtin_convertvector((v2f){v[2 * p], v[2 * p + 1]}, mbs_h2);
-        const v2f r = (v2f){v[2 * p], v[2 * p + 1]} - __builtin_convertvector(hh, v2f);
-        const mbs_h2 mm = __builtin_convertvector(r * 2048.0f, mbs_h2);
-        h[p] = __builtin_bit_cast(unsigned, hh);
-        m[p] = __builtin_bit_cast(unsigned, mm);
+        unsigned hh, mm;
+        yr_cut2(v[2 * p], v[2 * p + 1], hh, mm);     // (4 operations per pair: yr_common.h)
+        h[p] = hh;
+        m[p] = mm;
     }
 }
 __device__ __forceinline__ v4f mbs_mfma(mbs_u4 a, mbs_u4 b, v4f c) {

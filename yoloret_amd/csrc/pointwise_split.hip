@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, pws_min_blocks(PT, CT)) void pws_kernel(PwArgs
         const f32x4 sh = *reinterpret_cast<const f32x4*>(ss + BN + nl);
 #pragma unroll
         for (int p = 0; p < PT; ++p)
-            pw_finish_quad(a, ac1[c][p] * 0.00048828125f + acc[c][p], sc, sh, m0 + (wm * PT + p) * 16 + li, n0 + nl, li, vec_out, vec_res, vec_pre);
+            pw_finish_quad(a, __builtin_elementwise_fma(ac1[c][p], (f32x4){0.00048828125f, 0.00048828125f, 0.00048828125f, 0.00048828125f}, acc[c][p]), sc, sh, m0 + (wm * PT + p) * 16 + li, n0 + nl, li, vec_out, vec_res, vec_pre);
     }
 }
 

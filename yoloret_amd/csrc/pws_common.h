@@ -21,12 +21,11 @@ typedef float pws_f2 __attribute__((ext_vector_type(2)));
 
 // four float32 values -> four halves of the h plane and four of the m plane at the same position
 __device__ __forceinline__ void pws_store(_Float16* ph, _Float16* pm, int off, const float4 v) {
-    const pws_f2 a = (pws_f2){v.x, v.y}, b = (pws_f2){v.z, v.w};
-    const pws_h2 ha = __builtin_convertvector(a, pws_h2), hb = __builtin_convertvector(b, pws_h2);
-    const pws_h2 ma = __builtin_convertvector((a - __builtin_convertvector(ha, pws_f2)) * 2048.0f, pws_h2);
-    const pws_h2 mb = __builtin_convertvector((b - __builtin_convertvector(hb, pws_f2)) * 2048.0f, pws_h2);
-    *reinterpret_cast<pws_u2*>(ph + off) = (pws_u2){__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
-    *reinterpret_cast<pws_u2*>(pm + off) = (pws_u2){__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb)};
+    unsigned ha, ma, hb, mb;
+    yr_cut2(v.x, v.y, ha, ma);     // (4 operations per pair: yr_common.h)
+    yr_cut2(v.z, v.w, hb, mb);
+    *reinterpret_cast<pws_u2*>(ph + off) = (pws_u2){ha, hb};
+    *reinterpret_cast<pws_u2*>(pm + off) = (pws_u2){ma, mb};
 }
 __device__ __forceinline__ f32x4 pws_mfma(pws_u4 a, pws_u4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pws_h8, a), __builtin_bit_cast(pws_h8, b), c, 0, 0, 0);

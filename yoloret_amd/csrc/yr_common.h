@@ -170,6 +170,27 @@ template <class T> __device__ __forceinline__ void yr_st1(T* p, float v) { *p = 
      : (dt) == YR_F16 ? fn<yr_f16>(__VA_ARGS__)                              \
                       : (yr_set_error("unknown dtype %d", (int)(dt)), (int)YR_ERR_ARG))
 
+// The float16-plane cut of the SPLIT forms (mbr_common.h: x = h + 2^-11 m, h = f16(x), m = f16((x - h) 2^11)) for a pair of values,
+// 4 VALU operations: v_cvt_pk_f16_f32 (h), v_pk_mul_f32 (2^11 x), and v_fma_mixlo_f16 / v_fma_mixhi_f16, which read a float16 half
+// of h as a multiplicand, form h * -2^11 + 2^11 x in float32 (exact: x - h has at most 13 significant bits) and round it to the
+// low / high half of m - the conversions back to float32, the subtraction and the second packed conversion of the plain code
+// (6 operations; hipcc 7.2 does not select the mix instructions by itself) folded into two.  Bit-identical to the plain code
+// (tools/cut_probe.hip: 4 M pairs incl. zeros, denormals, 65504, values below 2^-24).
+__device__ __forceinline__ void yr_cut2(float x0, float x1, unsigned& h, unsigned& m) {
+    typedef float cut_f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 cut_h2 __attribute__((ext_vector_type(2)));
+    const cut_f2 x = (cut_f2){x0, x1};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, cut_h2));
+    const cut_f2 xs = x * 2048.0f;
+    const float c = -2048.0f;
+    // (two statements: m may then take the register of xs[0], which the first instruction reads before it writes.  s_nop 1: an MFMA
+    //  that reads a register as its A / B operand must be two wait states behind the VALU instruction that wrote it; hipcc's hazard
+    //  recogniser places those waits itself but does not look into asm - without them the MFMAs behind mbs_split8 read a stale m
+    //  plane (logit errors of 5e-4: the h plane alone).  A VALU or LDS consumer needs no wait: tools/cut_probe.hip.)
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(m) : "v"(h), "s"(c), "v"(xs[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1" : "+v"(m) : "v"(h), "s"(c), "v"(xs[1]));
+}
+
 // XCD-aware block order (cdna_hip_programming.md T1): hardware block b runs on XCD b % 8, each XCD has
 // its own L2.  Map hardware ids so that every XCD walks a CONTIGUOUS range of logical blocks; logical
 // neighbours (adjacent rows of a depthwise map, the cout tiles of one pixel tile) then share an L2.
