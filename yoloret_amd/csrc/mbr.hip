@@ -28,6 +28,14 @@
 
 #include "mbr_common.h"
 
+// (experiment, tools/_relink.py mbr.hip -DMBR_EXP_ONE_TAP: every tap of the stride-1 block kernel reads the SAME table entry - wrong
+//  results, one LDS read per tile and row instead of ten: what the tap reads cost)
+#ifdef MBR_EXP_ONE_TAP
+#define MBR_TB(i) tb[0]
+#else
+#define MBR_TB(i) tb[i]
+#endif
+
 struct MbrArgs {
     const float* x; float* out;
     const float* wa;   // A fragments: [T][KE + 4 * TO][64 lanes]
@@ -269,10 +277,10 @@ __device__ __forceinline__ void mbr_body(const MbrArgs& a, const int t0, const i
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const v4f* tb = reinterpret_cast<const v4f*>(tab + (t0 + j) * MBR_TAB) + mg;
-                v4f d = tb[36];   // the BN shift is the first addend
-                mbr_dw_row(d, ea[j], tb[0], tb[4], tb[8]);
-                mbr_dw_row(d, eb[j], tb[12], tb[16], tb[20]);
-                mbr_dw_row(d, ec[j], tb[24], tb[28], tb[32]);
+                v4f d = MBR_TB(36);   // the BN shift is the first addend
+                mbr_dw_row(d, ea[j], MBR_TB(0), MBR_TB(4), MBR_TB(8));
+                mbr_dw_row(d, eb[j], MBR_TB(12), MBR_TB(16), MBR_TB(20));
+                mbr_dw_row(d, ec[j], MBR_TB(24), MBR_TB(28), MBR_TB(32));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) d[i] = __builtin_amdgcn_fmed3f(d[i], 0.f, 6.f);
                 if constexpr (SP) {
