@@ -49,8 +49,8 @@ def se_params(rng, c, r):
 def walk_ok(segs, f, pre, gated, conv_act):
     """compiler.fuse_head_blocks' rule for the walking form"""
     nk = sum((c + 31) // 32 for c, _ in segs)
-    nt = 2
-    return (all(xf == 'identity' for _, xf in segs) and len(segs) <= 3 and nk <= 4 and f % 16 == 0 and (f // 16) % nt == 0 and (f // 16 // nt) % 4 == 0
+    nt = 2 if nk <= 4 else 1
+    return (all(xf == 'identity' for _, xf in segs) and len(segs) <= 3 and nk <= 7 and f % 16 == 0 and (f // 16) % nt == 0 and (f // 16 // nt) % 4 == 0
             and conv_act in ('relu6', 'none') and not (gated and pre))
 
 

@@ -761,7 +761,7 @@ FUSE_HEAD = os.environ.get('YOLORET_FUSE_HEAD', '1') != '0'
 FUSE_HEAD_ALL = os.environ.get('YOLORET_FUSE_HEAD', '1') == '2'     # also conv -> depthwise pairs without squeeze-excite sums
 SE_TAIL = os.environ.get('YOLORET_SE_TAIL', '0') != '0'   # OPT-IN: correct in one stream, not with steps in flight on several (se_tail.h: STATUS)
 SE_TAIL_LDS = 4608 - 1024 - 4      # == YR_SE_TAIL_LDS - 4 * 256 threads (se_tail.h): channels + hidden units the tail's LDS scratch holds
-HEAD_WALK_MAX_NK = min(4, int(os.environ.get('YOLORET_HEAD_WALK_MAX_NK', '4')))   # (measured, MobileNetV2 x0.75 @416 batch 64: 1 chunk 52 us against the LDS-direct kernel's 95, 4 chunks 96 | 124, 6 chunks 85 | 82, 7 chunks 96 | 84: one tile per wave and 250 registers from 5 chunks on)
+HEAD_WALK_MAX_NK = min(7, int(os.environ.get('YOLORET_HEAD_WALK_MAX_NK', '4')))   # (measured, MobileNetV2 x0.75 @416 batch 64: 1 chunk 52 us against the LDS-direct kernel's 95, 4 chunks 96 | 124, 6 chunks 85 | 82, 7 chunks 96 | 84: one tile per wave and 250 registers from 5 chunks on)
 HEAD_WALK = os.environ.get('YOLORET_HEAD_WALK', '1') != '0'   # head blocks of at most 7 chunks of 32 identity-source channels on the walking kernel (headwalk.hip)
 HEAD_DMA = os.environ.get('YOLORET_HEAD_DMA', '1') != '0'   # head blocks without a pooled source on the LDS-direct kernel
 

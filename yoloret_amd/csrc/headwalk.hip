@@ -22,7 +22,10 @@
 #include "mbr_common.h"
 #include "se_tail.h"
 
-#define HW_MAXK 4
+#define HW_MAXK 7
+#ifndef HW_NOHOIST_MIN_NKE
+#define HW_NOHOIST_MIN_NKE 5   // from this many chunks on the tap table is read inside the walk (left alone hipcc hoists the reads and spills)
+#endif
 struct HwArgs {
     const float* src[3]; int ld[3]; int cs[3];   // k-space sources (identity): pointer, channel stride, channels
     int nsrc;
@@ -199,7 +202,9 @@ __global__ __launch_bounds__(256, HW_OCC) void hwalk_kernel(HwArgs a) {
             const unsigned opix = ((unsigned)yo * (unsigned)a.W + (unsigned)xo) * (unsigned)a.ld_out * 4u;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const v4f* tb = reinterpret_cast<const v4f*>(tab + min(t0 + j, a.T - 1) * MBR_TAB) + mg;
+                unsigned toff = 0;
+                if constexpr (NKE >= HW_NOHOIST_MIN_NKE) asm volatile("" : "+v"(toff));   // (keeps the tap reads inside the walk: headwalk_h.hip's note)
+                const v4f* tb = reinterpret_cast<const v4f*>(tab + toff + min(t0 + j, a.T - 1) * MBR_TAB) + mg;
                 v4f d = tb[36];
                 mbr_dw_row(d, ea[j], tb[0], tb[4], tb[8]);
                 mbr_dw_row(d, eb[j], tb[12], tb[16], tb[20]);
@@ -341,7 +346,7 @@ int yr_launch_head_walk(const yr_op& op, int batch, hipStream_t s) {
     if (rc) return rc;
     a.sums = const_cast<float*>(op.gate); a.ld_sums = op.gate_ld;
 #define HW_CASE(K, T2) if (nk == K) return launch_hwalk<K, T2>(a, batch, s);
-    HW_CASE(1, 2) HW_CASE(2, 2) HW_CASE(3, 2) HW_CASE(4, 2)   // (5 .. 7 chunks, one tile per wave: built and measured in round 5 - 250 registers, 85-96 us on the 26 x 26 heads against the LDS-direct kernel's 77-84 - not kept)
+    HW_CASE(1, 2) HW_CASE(2, 2) HW_CASE(3, 2) HW_CASE(4, 2) HW_CASE(5, 1) HW_CASE(6, 1) HW_CASE(7, 1)   // (5 .. 7 chunks: one tile per wave; the compiler takes them when HEAD_WALK_MAX_NK allows)
 #undef HW_CASE
     yr_set_error("head (walking form): %d chunks of 32 channels are not built", nk);
     return YR_ERR_ARG;

@@ -71,18 +71,19 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
     const int row = a.C + 5;
     const int pass = (int)blockIdx.z;  // 0: the plain logits, 1: the zoom pass
     const float* src = (pass ? a.z[s] : a.y[s]) + ((size_t)b * ns + t0) * row;
-    // batches of 8 loads before their LDS stores (a store after each load would serialise the HBM round trips)
-    for (int i0 = 0; i0 < cnt * row; i0 += 256 * 8) {
-        float v[8];
+    // batches of DEC_LB loads before their LDS stores (a store after each load would serialise the HBM round trips; 32 = the whole
+    // tile of a 20-class model in ONE round trip - round 5: with batches of 8 a workgroup went to HBM four times in a row), every
+    // load unconditional at a clamped index (a predicated load gets its own branch and wait)
+    constexpr int DEC_LB = 32;
+    const int last = cnt * row - 1;
+    for (int i0 = 0; i0 <= last; i0 += 256 * DEC_LB) {
+        float v[DEC_LB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 256 + threadIdx.x;
-            v[u] = i < cnt * row ? src[i] : 0.f;
-        }
+        for (int u = 0; u < DEC_LB; ++u) v[u] = src[min(i0 + u * 256 + (int)threadIdx.x, last)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < DEC_LB; ++u) {
             const int i = i0 + u * 256 + threadIdx.x;
-            if (i < cnt * row) sm[i] = v[u];
+            if (i <= last) sm[i] = v[u];
         }
     }
     __syncthreads();
