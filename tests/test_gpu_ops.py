@@ -42,7 +42,7 @@ def _src_dims(h, w, xf):
     return {'identity': (h, w), 'up2': (h // 2, w // 2), 'maxpool2': (h * 2, w * 2), 'maxpool4': (h * 4, w * 4)}[xf]
 
 
-def run_pointwise(dev, rng, b, h, w, segs, cout, act='none', bn=True, residual=False, gate=False, out_ld=None, cfg=0):
+def run_pointwise(dev, rng, b, h, w, segs, cout, act='none', bn=True, residual=False, gate=False, out_ld=None, cfg=0, ksplit=False):
     rt = _rt()
     srcs_np, srcs_dev = [], []
     for c, xf in segs:
@@ -95,6 +95,8 @@ def run_pointwise(dev, rng, b, h, w, segs, cout, act='none', bn=True, residual=F
         keep.append(g)
         op.gate, op.gate_ld = g.data_ptr(), g.shape[3]
     op.out, op.out_ld = out.data_ptr(), out_ld
+    if ksplit:
+        op.se_reduced |= 0x20000      # the k-split form of the few-image plans (pointwise_split.hip: pwk_kernel)
     op.k = cfg            # 0: heuristic tile shape; 1..yr_pointwise_num_cfgs(): forced (15..: the LDS-free direct kernel)
     rt.run_op(op, b)
     torch.cuda.synchronize()
@@ -141,6 +143,63 @@ def test_pointwise_direct_kernel(dev, case):
         outs.append(run_pointwise(dev, rng, 3, h, w, segs, cout, act, bn, residual, gate, out_ld=cout if dense else None, cfg=cfg))
     for o in outs[1:]:
         assert np.array_equal(o, outs[0])
+
+
+@pytest.mark.parametrize('case', PW_CASES, ids=[str(i) for i in range(len(PW_CASES))])
+def test_pointwise_deep_forms(dev, case):
+    """The deep forms of the split kernel (forced tile shapes 30..36: several 32-wide k chunks per barrier pair, all of a group's loads in
+    flight at once - what the few-image passes pick) == oracle and bit-identical to the one-chunk form: the chunks are multiplied in k
+    order into the same accumulators."""
+    h, w, segs, cout, act, bn, residual, gate, dense = case
+    outs = []
+    for cfg in (0, 30, 31, 32, 33, 34, 35, 36):
+        rng = np.random.default_rng(zlib.crc32(str(case).encode()))
+        outs.append(run_pointwise(dev, rng, 3, h, w, segs, cout, act, bn, residual, gate, out_ld=cout if dense else None, cfg=cfg))
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+
+
+@pytest.mark.parametrize('case', PW_CASES, ids=[str(i) for i in range(len(PW_CASES))])
+def test_pointwise_ksplit_form(dev, case):
+    """The k-split form (se_reduced bit 17: what the float32 plan for a few images asks of its small maps - a workgroup is one 16 x 16
+    tile, its four waves split the k range and meet in LDS) == oracle at the per-op bar, with every source transform, gate, residual,
+    dense rows; it must actually be the kernel that ran where the conv is at least two chunks deep."""
+    h, w, segs, cout, act, bn, residual, gate, dense = case
+    rng = np.random.default_rng(zlib.crc32(str(case).encode()))
+    run_pointwise(dev, rng, 3, h, w, segs, cout, act, bn, residual, gate, out_ld=cout if dense else None, ksplit=True)
+    kp = sum(round_up(c, 4) for c, _ in segs)
+    name = _rt().last_kernel() if hasattr(_rt(), 'last_kernel') else None
+    if name is not None and kp >= 64:
+        assert name.startswith('pwk_kernel'), name
+
+
+def test_pointwise_ksplit_pooled_output(dev):
+    """... and with the MaxPooling2D(2) output of the bottom-up convs (rows walked in 2 x 2-quad-major order inside the 16-row tile)."""
+    rt = _rt()
+    rng = np.random.default_rng(5)
+    b, h, w, cin, cout = 2, 13, 13, 128, 96        # pooled OUTPUT dims; the conv runs at 26 x 26
+    x = rng.standard_normal((b, 2 * h, 2 * w, cin)).astype(np.float32)
+    wk = (rng.standard_normal((cin, cout)) * np.sqrt(2.0 / cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.3, cout).astype(np.float32)
+    y = np.minimum(np.maximum(nn.pointwise(x, wk) * scale + shift, 0), 6).astype(np.float32)
+    ref = y.reshape(b, h, 2, w, 2, cout).max(axis=(2, 4))
+    outs = []
+    for ks in (False, True):
+        xd = to_dev(x, dev)
+        out = torch.full((b, h, w, cout), float('nan'), dtype=torch.float32, device=dev)
+        op = rt.new_op(rt.OP_POINTWISE, 'relu6')
+        op.h, op.w, op.cin, op.cout, op.nsrc, op.stride = h, w, cin, cout, 1, 2
+        op.src[0] = rt.make_src(xd, c=cin, xform='identity')
+        keep = [_dev_vec(np.ascontiguousarray(wk.T), dev), _dev_vec(scale, dev), _dev_vec(shift, dev)]
+        op.wgt, op.scale, op.shift = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
+        op.out, op.out_ld = out.data_ptr(), cout
+        if ks:
+            op.se_reduced |= 0x20000
+        rt.run_op(op, b)
+        torch.cuda.synchronize()
+        outs.append(from_dev(out, cout))
+        assert_close(outs[-1], ref, TOL, 'pooled output, ksplit %s' % ks)
 
 
 def test_pointwise_large_m(dev):

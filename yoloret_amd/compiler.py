@@ -759,6 +759,7 @@ def fold_depthwise_into_project(ops, output_buf_ids, min_pixels=0):
 # form of dw_kernel): the workgroup that completes an image runs it (se_tail.h) and the SE_FC launch disappears.
 FUSE_HEAD = os.environ.get('YOLORET_FUSE_HEAD', '1') != '0'
 FUSE_HEAD_ALL = os.environ.get('YOLORET_FUSE_HEAD', '1') == '2'     # also conv -> depthwise pairs without squeeze-excite sums
+KSPLIT_MAX_PIXELS = int(os.environ.get('YOLORET_KSPLIT_MAX_PIXELS', str(26 * 26)))   # maps (conv pixels per image) up to which the 'nohead' plan's pointwise convs run the k-split form (0: off)
 SE_TAIL = os.environ.get('YOLORET_SE_TAIL', '0') != '0'   # OPT-IN: correct in one stream, not with steps in flight on several (se_tail.h: STATUS)
 SE_TAIL_LDS = 4608 - 1024 - 4      # == YR_SE_TAIL_LDS - 4 * 256 threads (se_tail.h): channels + hidden units the tail's LDS scratch holds
 HEAD_WALK_MAX_NK = min(7, int(os.environ.get('YOLORET_HEAD_WALK_MAX_NK', '4')))   # (measured, MobileNetV2 x0.75 @416 batch 64: 1 chunk 52 us against the LDS-direct kernel's 95, 4 chunks 96 | 124, 6 chunks 85 | 82, 7 chunks 96 | 84: one tile per wave and 250 registers from 5 chunks on)
@@ -1712,6 +1713,14 @@ class Compiler:
                 for o in ops:
                     if o.kind == rt.OP_POINTWISE and not any(s_.xform == 'dw3' for s_ in o.srcs):
                         o.se_reduced |= 0x10000
+            if self.fuse == 'nohead' and self.dtype == 0 and KSPLIT_MAX_PIXELS > 0:
+                # ... and its small maps take the K-SPLIT form of the split pointwise kernel (se_reduced bit 17; pointwise_split.hip:
+                # pwk_kernel): at 169 .. 2704 pixels a conv is a few workgroups, each one latency chain of k chunks - there a workgroup
+                # is one 16 x 16 tile and its four waves split the k range.  A property of the plan (the sums are grouped by wave).
+                for o in ops:
+                    if o.kind == rt.OP_POINTWISE and not any(s_.xform == 'dw3' for s_ in o.srcs) and not (o.se_reduced & 0x10000):
+                        if o.h * o.w * (4 if getattr(o, 'stride', 0) == 2 else 1) <= KSPLIT_MAX_PIXELS:
+                            o.se_reduced |= 0x20000
         for o in ops:     # (also without fusion: a float32 POINTWISE op named by Model.check_ranges keeps the float32 MFMA)
             if o.kind == rt.OP_POINTWISE and o.name in self.nosplit:
                 o.se_reduced |= 0x10000

@@ -332,6 +332,8 @@ __device__ __forceinline__ float4 pw_finish(float4 v, const float4& gt, int cval
 int yr_pw_launch_lds(int shape, const PwArgs& a, hipStream_t s);
 // the same tile shapes on the 16-bit matrix pipe with float32-grade operands (pointwise_split.hip: two float16 planes per operand)
 int yr_pw_launch_split(int shape, const PwArgs& a, hipStream_t s);
+// its k-split form for the passes of a few images (a workgroup = one 16 x 16 tile, the four waves split the k range; se_reduced bit 17)
+int yr_pw_launch_ksplit(const PwArgs& a, hipStream_t s);
 // 16-bit kernel (pointwise_h.hip): cfg = tile shape index 0..yr_pwh_num_cfgs()-1, or -1 for its heuristic
 int yr_pw_launch_h(int dtype, int cfg, const PwArgs& a, hipStream_t s);
 int yr_pwh_num_cfgs();

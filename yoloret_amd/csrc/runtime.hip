@@ -632,7 +632,7 @@ extern "C" int yr_autotune(yr_handle* h, const float* images, int batch, float* 
                 else if (best[i - 1] != 0 && (prev.k & 0x80)) prev.k = (prev.k & 0xffff) | (best[i - 1] & 0xff0000);
                 else if (best[i - 1] != 0) prev.k = (prev.k & 0xff) | best[i - 1];
             }
-            static const int segs_list[] = {0, 1, 2, 3, 4, 6, 8};
+            static const int segs_list[] = {0, 1, 2, 3, 4, 6, 8, 13, 18, 26};   // (13 .. 26: the few-image passes, where a strip's walk is the whole launch)
             const int base = op.k & 0xffff;     // 3 | nw << 8: the workgroup shape the plan asks for
             float best_ms = 1e30f;
             int best_cfg = 0;
