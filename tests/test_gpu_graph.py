@@ -254,6 +254,15 @@ def test_small_batch_plan_of_float32_models(dev):
     for i, r in enumerate(ref):
         assert_close(small[i], r[:3], 1e-4, 'nohead plan, output %d' % i)
         assert_close(big[i], r, 1e-4, 'throughput plan, output %d' % i)
+    # its small maps run the k-split form of the split pointwise kernel (se_reduced bit 17; a property of the plan, so a batch of the
+    # variant still equals its images run one by one, bit for bit)
+    flagged = [o.name for o in m.plan_for(3).ops if o.kind == rt.OP_POINTWISE and o.se_reduced & 0x20000]
+    assert flagged and not any(o.se_reduced & 0x20000 for o in m.plan_for(6).ops if o.kind == rt.OP_POINTWISE)
+    ran = dict((r['name'], r['kernel']) for r in m.profile(xt[:3], iters=1))
+    assert any(ran[n].startswith('pwk_kernel') for n in flagged), ran
+    one = [y.cpu().numpy() for y in m(xt[1:2])]
+    for i in range(3):
+        assert np.array_equal(one[i][0], small[i][1])
 
 
 @pytest.mark.parametrize('model_name', ['mobilenetv2x75', 'efficientnetb0'])

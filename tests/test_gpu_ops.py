@@ -146,31 +146,13 @@ def test_pointwise_direct_kernel(dev, case):
 
 
 @pytest.mark.parametrize('case', PW_CASES, ids=[str(i) for i in range(len(PW_CASES))])
-def test_pointwise_deep_forms(dev, case):
-    """The deep forms of the split kernel (forced tile shapes 30..36: several 32-wide k chunks per barrier pair, all of a group's loads in
-    flight at once - what the few-image passes pick) == oracle and bit-identical to the one-chunk form: the chunks are multiplied in k
-    order into the same accumulators."""
-    h, w, segs, cout, act, bn, residual, gate, dense = case
-    outs = []
-    for cfg in (0, 30, 31, 32, 33, 34, 35, 36):
-        rng = np.random.default_rng(zlib.crc32(str(case).encode()))
-        outs.append(run_pointwise(dev, rng, 3, h, w, segs, cout, act, bn, residual, gate, out_ld=cout if dense else None, cfg=cfg))
-    for o in outs[1:]:
-        assert np.array_equal(o, outs[0])
-
-
-@pytest.mark.parametrize('case', PW_CASES, ids=[str(i) for i in range(len(PW_CASES))])
 def test_pointwise_ksplit_form(dev, case):
     """The k-split form (se_reduced bit 17: what the float32 plan for a few images asks of its small maps - a workgroup is one 16 x 16
     tile, its four waves split the k range and meet in LDS) == oracle at the per-op bar, with every source transform, gate, residual,
-    dense rows; it must actually be the kernel that ran where the conv is at least two chunks deep."""
+    dense rows (that the plan for a few images really runs it: tests/test_gpu_graph.py)."""
     h, w, segs, cout, act, bn, residual, gate, dense = case
     rng = np.random.default_rng(zlib.crc32(str(case).encode()))
     run_pointwise(dev, rng, 3, h, w, segs, cout, act, bn, residual, gate, out_ld=cout if dense else None, ksplit=True)
-    kp = sum(round_up(c, 4) for c, _ in segs)
-    name = _rt().last_kernel() if hasattr(_rt(), 'last_kernel') else None
-    if name is not None and kp >= 64:
-        assert name.startswith('pwk_kernel'), name
 
 
 def test_pointwise_ksplit_pooled_output(dev):

@@ -1,6 +1,5 @@
 #!/usr/bin/env python
-"""Per-layer timing of every pointwise tile shape (LDS-staged 1..14, direct 15..29, the split kernel's deep forms 30..36) inside the
-real forward pass:
+"""Per-layer timing of every pointwise tile shape (LDS-staged 1..14, direct 15..29) inside the real forward pass:
     [B=64] python tools/pw_probe.py name [name ...]      (default: the gated project convs of the heads)"""
 import ctypes, os, sys
 import numpy as np
@@ -23,13 +22,12 @@ n = len(plan.ops)
 shapes = ['%dx%d' % s for s in [(256, 16), (128, 32), (128, 48), (128, 64), (128, 80), (128, 96), (128, 128), (64, 16), (64, 32),
                                  (64, 48), (64, 64), (64, 80), (64, 96), (64, 128)]] + \
          ['d%dx%d' % s for s in [(64, 16), (64, 32), (64, 48), (64, 64), (64, 80), (64, 96), (64, 128), (128, 32), (128, 48),
-                                  (128, 64), (128, 80), (128, 96), (256, 32), (256, 48), (256, 64)]] + \
-         ['deep%dx%d' % s for s in [(64, 16), (64, 32), (64, 48), (64, 64), (64, 80), (64, 96), (64, 128)]]
+                                  (128, 64), (128, 80), (128, 96), (256, 32), (256, 48), (256, 64)]]
 for name in names:
     i = next(k for k, o in enumerate(plan.ops) if o.name == name)
     o = plan.ops[i]
     row = []
-    for cfg in range(1, 37):
+    for cfg in range(1, 30):
         tab = (ctypes.c_int32 * n)()
         tab[i] = cfg
         rt.check(rt.lib().yr_set_tuning(hd, B, tab, n))
@@ -37,4 +35,4 @@ for name in names:
         row.append((ms, shapes[cfg - 1]))
     best = sorted(row)[:6]
     print('%-18s K=%d N=%d %dx%d  ' % (name, o.cin, o.cout, o.h, o.w) + '  '.join('%s %.4f' % (s, t) for t, s in best)
-          + '   | best deep ' + '%s %.4f' % min((t, s) for t, s in row if s.startswith('deep'))[::-1])
+          + '   | best direct ' + '%s %.4f' % min((t, s) for t, s in row if s.startswith('d'))[::-1])

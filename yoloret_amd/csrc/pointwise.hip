@@ -264,10 +264,6 @@ int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
     if (split && (op.se_reduced & 0x20000) && a.S.kp >= 2 * 32) return yr_pw_launch_ksplit(a, s);
     if (split && op.k >= 1 && op.k <= NCFG) return yr_pw_launch_split((op.k - 1) % NLDS, a, s);
     if (op.k >= 1 && op.k <= NCFG) return cfgs[op.k - 1].fn(a, s);
-    // NCFG + 1 .. NCFG + NDEEP: the deep forms of the split kernel's 64-row shapes (pointwise_split.hip: several k chunks per barrier
-    // pair - the same sums, the same bits); without the split form they are the LDS-staged 64-row shapes themselves
-    constexpr int NDEEP = 7;
-    if (op.k > NCFG && op.k <= NCFG + NDEEP) return split ? yr_pw_launch_split(NLDS + (op.k - NCFG - 1), a, s) : cfgs[7 + (op.k - NCFG - 1)].fn(a, s);
     // tuning override: YR_PW_CFG="BMxBN" forces one tile shape for every layer (experiments only)
     static const char* force = getenv("YR_PW_CFG");
     if (force) {
@@ -296,4 +292,4 @@ int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
 }
 
 // number of tile shapes yr_launch_pointwise can be forced to through op.k (1-based) for ops of this dtype
-int yr_pointwise_num_cfgs(int dtype) { return dtype == YR_F32 ? 36 : yr_pwh_num_cfgs(); }   // (29 + the 7 deep forms)
+int yr_pointwise_num_cfgs(int dtype) { return dtype == YR_F32 ? 29 : yr_pwh_num_cfgs(); }

@@ -94,101 +94,6 @@ __global__ __launch_bounds__(256, pws_min_blocks(PT, CT)) void pws_kernel(PwArgs
 
 
 
-// The DEEP form: KC chunks of 32 per barrier pair, all of a group's loads in flight at once (pws_k_loop_deep; same sums, same bits).  For the
-// passes of few images, where a conv is one workgroup's latency chain; one workgroup per CU is enough there.
-template <int PT, int CT, int WM, int WN, bool SIMPLE, int KC>
-__global__ __launch_bounds__(256, 1) void pwsd_kernel(PwArgs a) {
-    constexpr bool DW = false;
-    constexpr int BM = 16 * PT * WM;
-    constexpr int BN = 16 * CT * WN;
-    constexpr int A_PASSES = BM / PWS_RPP;
-    constexpr int B_PASSES = (BN + PWS_RPP - 1) / PWS_RPP;
-    // two float16 planes per operand: [rows][PWS_LD halves] each (32 k + 8 halves of padding: rows 80 bytes apart)
-    __shared__ __attribute__((aligned(16))) _Float16 lds[KC * 2 * (BM + BN) * PWS_LD];
-    static_assert(sizeof(_Float16) * KC * 2 * (BM + BN) * PWS_LD + 8 * BN <= 64 * 1024, "pwsd_kernel: the staged chunks exceed the LDS of a workgroup");
-    __shared__ __attribute__((aligned(16))) float ss[2 * BN];  // the tile's BN scale | shift (read by the epilogue)
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave % WM, wn = wave / WM;
-    // 1-D grid walked in XCD-contiguous order with the cout tile fastest: the cout tiles of one pixel
-    // tile run back to back on one XCD, so the activation tile is re-read from that XCD's L2.
-    const unsigned ntn = (a.N + BN - 1) / BN;
-    const unsigned L = yr_xcd_swizzle(blockIdx.x, gridDim.x);
-    const int m0 = (int)(L / ntn) * BM;
-    const int n0 = (int)(L % ntn) * BN;
-    const int kp = a.S.kp;
-
-    // the tile's BatchNorm scale / shift go to LDS now (behind the k loop's barriers by the time they are read):
-    // fetched in the epilogue they would cost every tile an L2 round trip with nothing left to hide it
-    if (tid < BN) {
-        const int n = n0 + tid < a.N ? n0 + tid : a.N - 1;
-        ss[tid] = a.scale ? a.scale[n] : 1.f;
-        ss[BN + tid] = a.shift ? a.shift[n] : 0.f;
-    }
-
-    // loader mapping: quad kq of row lr (+64 per pass)
-    const int lr = tid / PWS_KQ;
-    constexpr int MODE = SIMPLE ? 2 : 0;
-    const bool gated = SIMPLE && !DW && a.gate != nullptr;
-    PwRow<MODE> row[A_PASSES];
-    pw_unroll<A_PASSES>([&](auto P) __attribute__((always_inline)) {
-        constexpr int p = decltype(P)::value;
-        row[p].init(a, m0 + lr + p * PWS_RPP);
-        if constexpr (SIMPLE && !DW)
-            if (!gated) row[p].grow = a.wt;  // ungated: the gate load becomes a (cached, ignored) weight quad
-    });
-    const float* brow[B_PASSES];
-    pw_unroll<B_PASSES>([&](auto P) __attribute__((always_inline)) {
-        constexpr int p = decltype(P)::value;
-        const int n = n0 + lr + p * PWS_RPP;
-        brow[p] = a.wt + (size_t)(n < a.N ? n : 0) * kp;  // rows beyond N feed couts that are never stored
-    });
-
-    const int g = lane >> 4, li = lane & 15;
-    f32x4 acc[CT][PT], ac1[CT][PT];   // h h' | h m' + m h' (joins with 2^-11 in the epilogue)
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int p = 0; p < PT; ++p) { acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f}; ac1[c][p] = acc[c][p]; }
-    pws_k_loop_deep<256, PT, CT, WM, WN, MODE, A_PASSES, B_PASSES, KC>(a, row, brow, gated, lds, acc, ac1);
-
-    // ---- epilogue: (pre-BN addend,) BN scale/shift, activation, (residual,) (2x2 max,) store: 4 consecutive couts
-    // per lane.  Branches are uniform or guard stores only; every load is unconditional (pw_load_quad): a load under
-    // a per-lane branch is followed by its own s_waitcnt, one L2 round trip per element group with nothing to hide it.
-    const bool vec_out = (a.out_ld & 3) == 0;
-    const bool vec_res = (a.res_ld & 3) == 0, vec_pre = (a.pre_ld & 3) == 0;
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        const int nl = (wn * CT + c) * 16 + g * 4;
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(ss + nl);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(ss + BN + nl);
-#pragma unroll
-        for (int p = 0; p < PT; ++p)
-            pw_finish_quad(a, __builtin_elementwise_fma(ac1[c][p], (f32x4){0.00048828125f, 0.00048828125f, 0.00048828125f, 0.00048828125f}, acc[c][p]), sc, sh, m0 + (wm * PT + p) * 16 + li, n0 + nl, li, vec_out, vec_res, vec_pre);
-    }
-}
-
-
-
-
-template <int PT, int CT, int WM, int WN, int KC>
-static int launch_deep_cfg(const PwArgs& a, hipStream_t s) {
-    constexpr int BM = 16 * PT * WM, BN = 16 * CT * WN;
-    dim3 grid((unsigned)((a.M + BM - 1) / BM) * (unsigned)((a.N + BN - 1) / BN));
-    const bool simple = a.S.n == 1 && a.S.s[0].xform == YR_X_IDENTITY;
-    static char nm[2][48];
-    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "pwsd_kernel<%d,%d,%d,%d,0,%d>", PT, CT, WM, WN, KC) +
-                              snprintf(nm[1], sizeof(nm[1]), "pwsd_kernel<%d,%d,%d,%d,1,%d>", PT, CT, WM, WN, KC);
-    (void)nm_len;
-    yr_note_kernel(nm[simple ? 1 : 0]);
-    if (simple) hipLaunchKernelGGL((pwsd_kernel<PT, CT, WM, WN, true, KC>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((pwsd_kernel<PT, CT, WM, WN, false, KC>), grid, dim3(256), 0, s, a);
-    YR_LAUNCH_CHECK();
-    return YR_OK;
-}
-
 template <int PT, int CT, int WM, int WN>
 static int launch_split_cfg(const PwArgs& a, hipStream_t s) {
     constexpr int BM = 16 * PT * WM, BN = 16 * CT * WN;
@@ -208,7 +113,8 @@ static int launch_split_cfg(const PwArgs& a, hipStream_t s) {
 // The K-SPLIT form (round 5, the passes of a few images: se_reduced bit 17 of a POINTWISE op, set by the compiler's 'nohead' variant
 // for the maps of the heads and the last backbone stages).  At 169 .. 2704 pixels a conv is a handful of workgroups, each ONE latency
 // chain: pws_kernel walks its k chunks one barrier pair at a time, ~165 instructions of staging per chunk and wave for three MFMAs
-// (block_14_project, 720 deep: 23 chunks, 15 us - and deeper chunk groups do not help, the chain is instructions, not round trips).
+// (block_14_project, 720 deep: 23 chunks, 15 us; several chunks per barrier pair with all their loads in flight - built, bit-identical,
+// measured - is no faster: the chain is instructions, not round trips).
 // Here a workgroup is ONE 16 x 16 output tile and its four waves SPLIT THE K RANGE: wave w takes chunks w, w + 4, ..., fetches its
 // operands straight into the MFMA fragment layout (lane (li, g): row li, k = 8 g .. 8 g + 7 of the chunk - two quads per operand, all
 // loads of PWK_G chunks in flight at once), cuts the planes in registers and multiplies: no LDS, no barrier in the loop.  The four
@@ -322,14 +228,6 @@ int yr_pw_launch_split(int shape, const PwArgs& a, hipStream_t s) {
         case 11: return launch_split_cfg<1, 5, 4, 1>(a, s);
         case 12: return launch_split_cfg<1, 6, 4, 1>(a, s);
         case 13: return launch_split_cfg<1, 8, 4, 1>(a, s);
-        // the deep forms of shapes 7 .. 13 (64-row tiles): as many chunks per barrier pair as 64 KB of LDS hold
-        case 14: return launch_deep_cfg<1, 1, 4, 1, 4>(a, s);
-        case 15: return launch_deep_cfg<1, 2, 4, 1, 4>(a, s);
-        case 16: return launch_deep_cfg<1, 3, 4, 1, 3>(a, s);
-        case 17: return launch_deep_cfg<1, 4, 4, 1, 3>(a, s);
-        case 18: return launch_deep_cfg<1, 5, 4, 1, 2>(a, s);
-        case 19: return launch_deep_cfg<1, 6, 4, 1, 2>(a, s);
-        case 20: return launch_deep_cfg<1, 8, 4, 1, 2>(a, s);
         default: yr_set_error("pointwise (split form): shape %d out of range", shape); return YR_ERR_ARG;
     }
 }

@@ -146,110 +146,3 @@ __device__ __forceinline__ void pws_k_loop(const PwArgs& a, PwRow<MODE> (&row)[A
     if (pooled) k_loop(std::true_type{});
     else k_loop(std::false_type{});
 }
-
-// The same k loop with KC chunks of 32 per barrier pair (round 5: the few-image passes, where a pointwise conv is ONE workgroup's latency
-// chain - a 720-deep conv of a 13 x 13 map walked 23 barrier pairs, each behind a round trip to HBM).  Thread (lr, kq) fetches its quad of
-// each of the KC chunks, all of them in flight at once; the chunks are staged side by side in LDS (KC copies of pws_k_loop's layout) and
-// multiplied in k order into the same accumulators: the sums - and the bits - are pws_k_loop's, only the number of round trips is not.
-// One group of KC chunks is prefetched while the current one is multiplied.  lds: KC * 2 * (BM + BN) * PWS_LD halves.
-template <int NTH, int PT, int CT, int WM, int WN, int MODE, int A_PASSES, int B_PASSES, int KC>
-__device__ __forceinline__ void pws_k_loop_deep(const PwArgs& a, PwRow<MODE> (&row)[A_PASSES], const float* (&brow)[B_PASSES], const bool gated,
-                                                _Float16* lds, f32x4 (&acc)[CT][PT], f32x4 (&ac1)[CT][PT]) {
-    constexpr int RPP = NTH / PWS_KQ;
-    constexpr int BM = 16 * PT * WM, BN = 16 * CT * WN;
-    constexpr int REGION = 2 * (BM + BN) * PWS_LD;      // halves per staged chunk
-    static_assert(A_PASSES * RPP == BM && B_PASSES == (BN + RPP - 1) / RPP, "loader passes");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave % WM, wn = wave / WM;
-    const int lr = tid / PWS_KQ, kq = tid % PWS_KQ;
-    const int g = lane >> 4, li = lane & 15;
-    const int kp = a.S.kp;
-
-    auto k_loop = [&](auto pools_tag) __attribute__((always_inline)) {
-        constexpr bool POOLS = decltype(pools_tag)::value;
-        struct Regs {
-            float4 ra[A_PASSES][1], rg[A_PASSES], rb[B_PASSES];
-            int cv[A_PASSES];
-        };
-        Regs R[KC];
-        auto fetch = [&](int k0) __attribute__((always_inline)) {
-            pw_unroll<KC>([&](auto J) __attribute__((always_inline)) {
-                constexpr int j = decltype(J)::value;
-                const int kraw = k0 + j * PWS_BK + kq * 4;
-                const int k = kraw < kp ? kraw : kp - 4;
-                pw_unroll<A_PASSES>([&](auto P) __attribute__((always_inline)) {
-                    constexpr int p = decltype(P)::value;
-                    row[p].template issue<POOLS>(a, kraw, kp, R[j].ra[p][0], R[j].rg[p], R[j].cv[p]);
-                });
-                pw_unroll<B_PASSES>([&](auto P) __attribute__((always_inline)) {
-                    constexpr int p = decltype(P)::value;
-                    R[j].rb[p] = *reinterpret_cast<const float4*>(brow[p] + k);
-                });
-            });
-        };
-        fetch(0);
-        for (int k0 = 0; k0 < kp; k0 += KC * PWS_BK) {
-            pw_unroll<KC>([&](auto J) __attribute__((always_inline)) {
-                constexpr int j = decltype(J)::value;
-                _Float16* Ah = lds + j * REGION;
-                _Float16* Am = Ah + BM * PWS_LD;
-                _Float16* Bh = Ah + 2 * BM * PWS_LD;
-                _Float16* Bm = Ah + (2 * BM + BN) * PWS_LD;
-                pw_unroll<A_PASSES>([&](auto P) __attribute__((always_inline)) {
-                    constexpr int p = decltype(P)::value;
-                    const float4 v = gated ? pw_finish<2>(R[j].ra[p][0], R[j].rg[p], R[j].cv[p]) : pw_finish<1>(R[j].ra[p][0], R[j].rg[p], R[j].cv[p]);
-                    pws_store(Ah, Am, (lr + p * RPP) * PWS_LD + kq * 4, v);
-                });
-                pw_unroll<B_PASSES>([&](auto P) __attribute__((always_inline)) {
-                    constexpr int p = decltype(P)::value;
-                    const float4 v = R[j].rb[p];
-                    if ((p + 1) * RPP <= BN || lr + p * RPP < BN)
-                        pws_store(Bh, Bm, (lr + p * RPP) * PWS_LD + kq * 4, v);
-                });
-            });
-            __syncthreads();
-            fetch(k0 + KC * PWS_BK);
-            pw_unroll<KC>([&](auto J) __attribute__((always_inline)) {
-                constexpr int j = decltype(J)::value;
-                if (k0 + j * PWS_BK < kp) {          // (uniform; a dead chunk of the last group holds values of clamped addresses)
-                    const _Float16* Ah = lds + j * REGION;
-                    const _Float16* Am = Ah + BM * PWS_LD;
-                    const _Float16* Bh = Ah + 2 * BM * PWS_LD;
-                    const _Float16* Bm = Ah + (2 * BM + BN) * PWS_LD;
-                    pws_u4 wh[CT], wm_[CT], xh[PT], xm[PT];
-#pragma unroll
-                    for (int c = 0; c < CT; ++c) {
-                        wh[c] = *reinterpret_cast<const pws_u4*>(Bh + ((wn * CT + c) * 16 + li) * PWS_LD + g * 8);
-                        wm_[c] = *reinterpret_cast<const pws_u4*>(Bm + ((wn * CT + c) * 16 + li) * PWS_LD + g * 8);
-                    }
-#pragma unroll
-                    for (int p = 0; p < PT; ++p) {
-                        xh[p] = *reinterpret_cast<const pws_u4*>(Ah + ((wm * PT + p) * 16 + li) * PWS_LD + g * 8);
-                        xm[p] = *reinterpret_cast<const pws_u4*>(Am + ((wm * PT + p) * 16 + li) * PWS_LD + g * 8);
-                    }
-#pragma unroll
-                    for (int c = 0; c < CT; ++c)
-#pragma unroll
-                        for (int p = 0; p < PT; ++p) acc[c][p] = pws_mfma(wh[c], xh[p], acc[c][p]);
-#pragma unroll
-                    for (int c = 0; c < CT; ++c)
-#pragma unroll
-                        for (int p = 0; p < PT; ++p) ac1[c][p] = pws_mfma(wh[c], xm[p], ac1[c][p]);
-#pragma unroll
-                    for (int c = 0; c < CT; ++c)
-#pragma unroll
-                        for (int p = 0; p < PT; ++p) ac1[c][p] = pws_mfma(wm_[c], xh[p], ac1[c][p]);
-                }
-            });
-            __syncthreads();
-        }
-    };
-    bool pooled = false;
-    if (MODE == 0) {
-#pragma unroll
-        for (int i = 0; i < YR_MAX_SRC; ++i)
-            pooled |= a.S.s[i].xform == YR_X_MAXPOOL2 || a.S.s[i].xform == YR_X_MAXPOOL4;
-    }
-    if (pooled) k_loop(std::true_type{});
-    else k_loop(std::false_type{});
-}
