@@ -96,7 +96,7 @@ typedef enum {
                             float32 ops, se_reduced flag bits (no depthwise-folded source): bit 16 = keep the float32 MFMA (not the
                             float16-plane split form); bit 17 (round 5, no layout change) = the k-split form of the split kernel - a
                             workgroup is one 16 x 16 output tile, its four waves split the k range (pointwise_split.hip: pwk_kernel);
-                            what the compiler's few-image plan asks of maps up to 26 x 26.  The form groups the sums by wave: it
+                            what the compiler's plan for one or two images asks of maps up to 32 x 32.  The form groups the sums by wave: it
                             belongs to the plan, not to the tuner (yr_op.k is not looked at); ignored below 64 input channels. */
     YR_OP_DEPTHWISE = 3, /* DepthwiseConv2D k3/k5 s1/s2 SAME + BN + act (model.py:20-24; efficientnet.py:501-510).  With `gate` set (SE
                             form): the kernel ALSO writes per-workgroup channel sums of its output to

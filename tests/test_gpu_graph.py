@@ -245,7 +245,7 @@ def test_small_batch_plan_of_float32_models(dev):
     ref = om.yolov3_body(P, x, 'mobilenetv2x75', 3, 20)
     m.set_weights(P.values)
     m.small_batch = 4
-    assert m.small_variant == 'nohead' and m.variant(4) == 'nohead' and m.variant(5) == 'throughput'
+    assert m.small_variant == 'nohead' and m.variant(4) == 'nohead' and m.variant(2) == 'nohead_k' and m.variant(5) == 'throughput'
     xt = torch.from_numpy(x).to(dev)
     small = [y.cpu().numpy() for y in m(xt[:3])]
     big = [y.cpu().numpy() for y in m(xt)]
@@ -256,13 +256,17 @@ def test_small_batch_plan_of_float32_models(dev):
         assert_close(big[i], r, 1e-4, 'throughput plan, output %d' % i)
     # its small maps run the k-split form of the split pointwise kernel (se_reduced bit 17; a property of the plan, so a batch of the
     # variant still equals its images run one by one, bit for bit)
-    flagged = [o.name for o in m.plan_for(3).ops if o.kind == rt.OP_POINTWISE and o.se_reduced & 0x20000]
-    assert flagged and not any(o.se_reduced & 0x20000 for o in m.plan_for(6).ops if o.kind == rt.OP_POINTWISE)
-    ran = dict((r['name'], r['kernel']) for r in m.profile(xt[:3], iters=1))
+    # batches of one or two images ('nohead_k'): its small maps run the k-split form of the split pointwise kernel (se_reduced bit 17; a
+    # property of the plan, so a batch of the variant still equals its images run one by one, bit for bit)
+    flagged = [o.name for o in m.plan_for(2).ops if o.kind == rt.OP_POINTWISE and o.se_reduced & 0x20000]
+    assert flagged and not any(o.se_reduced & 0x20000 for b_ in (3, 6) for o in m.plan_for(b_).ops if o.kind == rt.OP_POINTWISE)
+    ran = dict((r['name'], r['kernel']) for r in m.profile(xt[:2], iters=1))
     assert any(ran[n].startswith('pwk_kernel') for n in flagged), ran
+    two = [y.cpu().numpy() for y in m(xt[:2])]
     one = [y.cpu().numpy() for y in m(xt[1:2])]
-    for i in range(3):
-        assert np.array_equal(one[i][0], small[i][1])
+    for i, r in enumerate(ref):
+        assert_close(two[i], r[:2], 1e-4, 'nohead_k plan, output %d' % i)
+        assert np.array_equal(one[i][0], two[i][1])
 
 
 @pytest.mark.parametrize('model_name', ['mobilenetv2x75', 'efficientnetb0'])

@@ -92,14 +92,15 @@ def test_plan_variants(monkeypatch):
     assert _model().small_variant == 'nohead'      # float32 default (round 5): the throughput plan without YR_OP_HEAD
     nh = _model().plan_for(2)
     assert rt.OP_HEAD not in [o.kind for o in nh.ops] and rt.OP_MBR in [o.kind for o in nh.ops]
-    # ... whose pointwise convs on maps of at most 26 x 26 conv pixels ask for the k-split form (se_reduced bit 17; pointwise_split.hip:
+    # ... and one or two images its 'nohead_k' twin, whose pointwise convs on maps of at most 32 x 32 conv pixels ask for the k-split form (se_reduced bit 17; pointwise_split.hip:
     # pwk_kernel) - a flag of the few-image PLAN: the throughput plan has none, and neither has a plan that keeps the float32 MFMA
     from yoloret_amd import compiler
     pw = [o for o in nh.ops if o.kind == rt.OP_POINTWISE]
     px = lambda o: o.h * o.w * (4 if getattr(o, 'stride', 0) == 2 else 1)
-    assert pw and all(bool(o.se_reduced & 0x20000) == (px(o) <= 26 * 26) for o in pw if not (o.se_reduced & 0x10000))
+    assert _model().variant(2) == 'nohead_k' and _model().variant(3) == 'nohead'
+    assert pw and all(bool(o.se_reduced & 0x20000) == (px(o) <= 32 * 32) for o in pw if not (o.se_reduced & 0x10000))
     assert any(o.se_reduced & 0x20000 for o in pw) and any(not (o.se_reduced & 0x20000) for o in pw)
-    assert not any(o.se_reduced & 0x20000 for o in _model().plan.ops if o.kind == rt.OP_POINTWISE)
+    assert not any(o.se_reduced & 0x20000 for o in _model().plan.ops + _model().plan_for(3).ops if o.kind == rt.OP_POINTWISE)
     monkeypatch.setattr(compiler, 'KSPLIT_MAX_PIXELS', 0)
     assert not any(o.se_reduced & 0x20000 for o in _model().plan_for(2).ops if o.kind == rt.OP_POINTWISE)
     monkeypatch.undo()

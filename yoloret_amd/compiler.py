@@ -759,7 +759,7 @@ def fold_depthwise_into_project(ops, output_buf_ids, min_pixels=0):
 # form of dw_kernel): the workgroup that completes an image runs it (se_tail.h) and the SE_FC launch disappears.
 FUSE_HEAD = os.environ.get('YOLORET_FUSE_HEAD', '1') != '0'
 FUSE_HEAD_ALL = os.environ.get('YOLORET_FUSE_HEAD', '1') == '2'     # also conv -> depthwise pairs without squeeze-excite sums
-KSPLIT_MAX_PIXELS = int(os.environ.get('YOLORET_KSPLIT_MAX_PIXELS', str(26 * 26)))   # maps (conv pixels per image) up to which the 'nohead' plan's pointwise convs run the k-split form (0: off)
+KSPLIT_MAX_PIXELS = int(os.environ.get('YOLORET_KSPLIT_MAX_PIXELS', str(32 * 32)))   # maps (conv pixels per image) up to which the 'nohead_k' plan's pointwise convs run the k-split form (0: off; 52 x 52 maps lose)
 SE_TAIL = os.environ.get('YOLORET_SE_TAIL', '0') != '0'   # OPT-IN: correct in one stream, not with steps in flight on several (se_tail.h: STATUS)
 SE_TAIL_LDS = 4608 - 1024 - 4      # == YR_SE_TAIL_LDS - 4 * 256 threads (se_tail.h): channels + hidden units the tail's LDS scratch holds
 HEAD_WALK_MAX_NK = min(7, int(os.environ.get('YOLORET_HEAD_WALK_MAX_NK', '4')))   # (measured, MobileNetV2 x0.75 @416 batch 64: 1 chunk 52 us against the LDS-direct kernel's 95, 4 chunks 96 | 124, 6 chunks 85 | 82, 7 chunks 96 | 84: one tile per wave and 250 registers from 5 chunks on)
@@ -1699,7 +1699,7 @@ class Compiler:
             # fuse == 'nohead': the float32 plan for a few images - the throughput plan without YR_OP_HEAD (a head block's conv + depthwise
             # in one launch is one long chain per workgroup: at batch 1 td1 takes 43 us against 18 + 11 for its two launches;
             # tools/lat_variants.sh, round 5: p50 @416 batch 1 / 2 / 4 / 8 = 0.606 / 0.622 / 0.666 / 0.767 ms against 0.648 / 0.656 / 0.687 / 0.766)
-            if FUSE_HEAD and not latency and self.fuse != 'nohead':
+            if FUSE_HEAD and not latency and self.fuse not in ('nohead', 'nohead_k'):
                 ops = fuse_head_blocks(ops, self.bufs, set(b.id for b in outs), nosplit=self.nosplit)
             if SE_TAIL:
                 ops = se_tail_into_producers(ops)
@@ -1713,8 +1713,9 @@ class Compiler:
                 for o in ops:
                     if o.kind == rt.OP_POINTWISE and not any(s_.xform == 'dw3' for s_ in o.srcs):
                         o.se_reduced |= 0x10000
-            if self.fuse == 'nohead' and self.dtype == 0 and KSPLIT_MAX_PIXELS > 0:
-                # ... and its small maps take the K-SPLIT form of the split pointwise kernel (se_reduced bit 17; pointwise_split.hip:
+            if self.fuse == 'nohead_k' and self.dtype == 0 and KSPLIT_MAX_PIXELS > 0:
+                # fuse == 'nohead_k' (one or two images: Model.ksplit_batch): the 'nohead' plan whose small maps take the K-SPLIT form of the
+                # split pointwise kernel (se_reduced bit 17; pointwise_split.hip:
                 # pwk_kernel): at 169 .. 2704 pixels a conv is a few workgroups, each one latency chain of k chunks - there a workgroup
                 # is one 16 x 16 tile and its four waves split the k range.  A property of the plan (the sums are grouped by wave).
                 for o in ops:

@@ -45,6 +45,11 @@ class Model:
         # blocks' conv and depthwise as two launches: compiler.py)
         self.small_batch = int(os.environ.get('YOLORET_SMALL_BATCH', '4' if self.dtype == 0 else '2')) if fuse is True else 0
         self.small_variant = os.environ.get('YOLORET_SMALL_VARIANT', 'nohead' if self.dtype == 0 else 'latency')   # what those batches run
+        # (... and the smallest of them - up to ksplit_batch images - on 'nohead_k': the same plan with the k-split form of the pointwise convs
+        # on its small maps (compiler.py: KSPLIT_MAX_PIXELS).  tools/lat_sweep.py, p50 of a full step in ms with / without the form:
+        # MobileNetV2 x0.75 @416 batch 1 / 2 / 4: 0.478 / 0.515 / 0.612 against 0.553 / 0.572 / 0.624; x1.4 @512: 0.615 / 0.750 / 1.053
+        # against 0.714 / 0.776 / 0.946 - at four images the wide model's 16 x 16 tiles re-fetch more than the shorter chains save)
+        self.ksplit_batch = int(os.environ.get('YOLORET_KSPLIT_BATCH', '2'))
         self._plans = {'throughput': self.plan}
         self._weights = None
         self._blobs = {}
@@ -131,8 +136,13 @@ class Model:
     # ------------------------------------------------------------------ execution
     def variant(self, batch):
         """Which plan a batch of this size runs: up to small_batch images `small_variant` - 'latency' (no block fusion: 16-bit plans) or
-        'nohead' (the throughput plan without YR_OP_HEAD: float32 plans)."""
-        return self.small_variant if 0 < batch <= self.small_batch else 'throughput'
+        'nohead' (the throughput plan without YR_OP_HEAD: float32 plans; 'nohead_k' up to ksplit_batch images: its small maps' pointwise
+        convs in the k-split form)."""
+        if not 0 < batch <= self.small_batch:
+            return 'throughput'
+        if self.small_variant == 'nohead' and batch <= self.ksplit_batch:
+            return 'nohead_k'
+        return self.small_variant
 
     def plan_for(self, batch):
         v = self.variant(batch)
