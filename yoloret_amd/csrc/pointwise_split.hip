@@ -110,8 +110,8 @@ static int launch_split_cfg(const PwArgs& a, hipStream_t s) {
     return YR_OK;
 }
 
-// The K-SPLIT form (round 5, the passes of a few images: se_reduced bit 17 of a POINTWISE op, set by the compiler's 'nohead' variant
-// for the maps of the heads and the last backbone stages).  At 169 .. 2704 pixels a conv is a handful of workgroups, each ONE latency
+// The K-SPLIT form (round 5, the passes of one or two images: se_reduced bit 17 of a POINTWISE op, set by the compiler's 'nohead_k'
+// variant for the maps of the heads and the last backbone stages).  At 169 .. 2704 pixels a conv is a handful of workgroups, each ONE latency
 // chain: pws_kernel walks its k chunks one barrier pair at a time, ~165 instructions of staging per chunk and wave for three MFMAs
 // (block_14_project, 720 deep: 23 chunks, 15 us; several chunks per barrier pair with all their loads in flight - built, bit-identical,
 // measured - is no faster: the chain is instructions, not round trips).
@@ -119,8 +119,8 @@ static int launch_split_cfg(const PwArgs& a, hipStream_t s) {
 // operands straight into the MFMA fragment layout (lane (li, g): row li, k = 8 g .. 8 g + 7 of the chunk - two quads per operand, all
 // loads of PWK_G chunks in flight at once), cuts the planes in registers and multiplies: no LDS, no barrier in the loop.  The four
 // partial accumulator pairs meet in LDS in wave order; wave 0 runs pw_kernel's epilogue.  The sums are grouped differently from
-// pws_kernel's (by wave), so the form belongs to the PLAN (a batch of the small variant equals its images run one by one through the
-// small variant), never to the tuner.  Same operand planes, same float32 accumulation: the error against float64 is the split form's.
+// pws_kernel's (by wave), so the form belongs to the PLAN (a batch of that variant equals its images run one by one through it), never to the
+// tuner.  At four images and wide layers the tiles' re-fetches cost more than the shorter chains save (MobileNetV2 x1.4 @512).  Same operand planes, same float32 accumulation: the error against float64 is the split form's.
 #define PWK_G 3     // chunks a wave has in flight
 
 template <bool SIMPLE>
