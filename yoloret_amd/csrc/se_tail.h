@@ -117,6 +117,16 @@ __host__ __device__ static inline size_t yr_se_fc_floats(int C, int R, int nth) 
 // fourth digit with three steps in flight - and what round 5 first blamed on the SE tail's cross-XCD publication.
 __device__ __forceinline__ void yr_se_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Segments a stage cuts its n inputs into: as many as give a thread two batches of 8 rows, not as many as there are threads.  The
+// segments' partial sums meet in LDS one after the other (fixed order), so every segment is a dependent LDS read of the thread that
+// owns the output: with NTH / quads segments a squeeze-excite block of 4 .. 48 hidden units (EfficientNet: 1 .. 12 quads) summed
+// 85 .. 1024 partials serially - 3 .. 27 us of a launch that should be three round trips (round 5, found at batch 1: 21 launches of
+// 12 us were 27 % of an EfficientNet-B0 pass).  The head blocks (512 channels, 128 hidden units: 32 and 8 segments) are unchanged.
+__device__ __forceinline__ int yr_se_segments(const int n, const int most) {
+    const int want = (n + 15) >> 4;
+    return want < 1 ? 1 : (want < most ? want : most);
+}
+
 template <int NTH>
 __device__ __forceinline__ void yr_se_fc_pair(const SeFc& f, const float* mean, float* scratch, float* gate, const int tid) {
     const int R4 = (f.R + 3) & ~3, QP = f.ldc >> 2, JQ = R4 >> 2;
@@ -127,7 +137,7 @@ __device__ __forceinline__ void yr_se_fc_pair(const SeFc& f, const float* mean, 
     // ---- FC1 + swish: a thread = (channel segment, quad of hidden units)
     for (int j0 = 0; j0 < JQ; j0 += NTH) {
         const int jq = JQ - j0 < NTH ? JQ - j0 : NTH;
-        const int nseg = NTH / jq, cps = (f.C + nseg - 1) / nseg;
+        const int nseg = yr_se_segments(f.C, NTH / jq), cps = (f.C + nseg - 1) / nseg;
         const int j = tid % jq, seg = tid / jq;
         se_f4 s = zero;
         if (seg < nseg) {
@@ -159,7 +169,7 @@ __device__ __forceinline__ void yr_se_fc_pair(const SeFc& f, const float* mean, 
     // ---- FC2 + sigmoid: a thread = (hidden-unit segment, channel quad)
     for (int q0 = 0; q0 < QP; q0 += NTH) {
         const int qp = QP - q0 < NTH ? QP - q0 : NTH;
-        const int nseg = NTH / qp, jps = (f.R + nseg - 1) / nseg;
+        const int nseg = yr_se_segments(f.R, NTH / qp), jps = (f.R + nseg - 1) / nseg;
         const int q = tid % qp, seg = tid / qp;
         se_f4 s = zero;
         if (seg < nseg) {
@@ -204,8 +214,21 @@ __device__ __forceinline__ void yr_se_mean_rows(const float* rows, const int nro
         float s = 0.f;
         if (seg < nrs && c0 + c < C) {
             const int ra = seg * rps, rb = ra + rps < nrows ? ra + rps : nrows;
+            if constexpr (ATOMIC) {
 #pragma unroll 4
-            for (int r = ra; r < rb; ++r) s += ATOMIC ? yr_ld_agent(rows + (size_t)r * ld + c0 + c) : rows[(size_t)r * ld + c0 + c];
+                for (int r = ra; r < rb; ++r) s += yr_ld_agent(rows + (size_t)r * ld + c0 + c);
+            } else {
+                // batches of 16 rows: all loads issued, all waited for, then added in row order (the maps of the first stages hand over
+                // hundreds of rows: at 4 loads per round trip the pooling was most of the launch there)
+                for (int r = ra; r < rb; r += 16) {
+                    float v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = rows[(size_t)(r + u < rb ? r + u : rb - 1) * ld + c0 + c];
+                    yr_se_wait_loads();
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) if (r + u < rb) s += v[u];
+                }
+            }
         }
         scratch[tid] = s;
         sync();
