@@ -76,7 +76,7 @@ def test_pointwise_split_vs_fp32_mfma(dev, shape, kind):
     devs = [to_dev(a, dev) for a in srcs]
     keep = [_dev_vec(wt, dev)]
     errs = {}
-    for form in ('split', 'fp32'):
+    for form in ('split', 'ksplit', 'fp32'):     # (ksplit: the k-split form of the plans for one or two images - the same planes, sums grouped by wave)
         out = torch.full((b, h, w, round_up(cout, 4)), float('nan'), dtype=torch.float32, device=dev)
         op = rt.new_op(rt.OP_POINTWISE, 'none')
         op.h, op.w, op.cin, op.cout, op.nsrc = h, w, cin, cout, len(segs)
@@ -84,11 +84,12 @@ def test_pointwise_split_vs_fp32_mfma(dev, shape, kind):
             op.src[i] = rt.make_src(t, c=c, xform=xf)
         op.wgt = keep[0].data_ptr()
         op.out, op.out_ld = out.data_ptr(), round_up(cout, 4)
-        op.se_reduced = 0 if form == 'split' else 0x10000      # bit 16: keep the float32 MFMA
+        op.se_reduced = {'split': 0, 'ksplit': 0x20000, 'fp32': 0x10000}[form]      # bit 16: keep the float32 MFMA; bit 17: k-split
         rt.run_op(op, b)
         torch.cuda.synchronize()
         errs[form] = err_vs_fp64(from_dev(out, cout), ref)
     check_pair(errs['split'], errs['fp32'], 'pointwise %s %s' % (shape, kind))
+    check_pair(errs['ksplit'], errs['fp32'], 'pointwise (k-split form) %s %s' % (shape, kind))
 
 
 @pytest.mark.parametrize('kind', KINDS)
