@@ -93,9 +93,10 @@ typedef enum {
                             wgt2 = the same parameters packed per channel PAIR, [round_up(cout,4)/2][27 taps x 2, times the BN
                             scale | 1 1 | BN shift 2] (STEMBLOCK's stem layout): selects the scalar-operand kernel */
     YR_OP_POINTWISE = 2, /* Conv2D 1x1 (+bias)(+BN)(+act)(+residual)  (model.py:25-30,98-114,152-155,243-251; efficientnet.py:485-496,517-533)
-                            float32 ops, se_reduced flag bits (no depthwise-folded source): bit 16 = keep the float32 MFMA (not the
+                            se_reduced flag bits (no depthwise-folded source): float32 ops, bit 16 = keep the float32 MFMA (not the
                             float16-plane split form); bit 17 (round 5, no layout change) = the k-split form of the split kernel - a
-                            workgroup is one 16 x 16 output tile, its four waves split the k range (pointwise_split.hip: pwk_kernel);
+                            workgroup is one 16 x 16 output tile, its four waves split the k range (pointwise_split.hip: pwk_kernel; 16-bit ops:
+                            one 16 x 32 tile, pointwise_h.hip: pwkh_kernel);
                             what the compiler's plan for one or two images asks of maps up to 32 x 32.  The form groups the sums by wave: it
                             belongs to the plan, not to the tuner (yr_op.k is not looked at); ignored below 64 input channels. */
     YR_OP_DEPTHWISE = 3, /* DepthwiseConv2D k3/k5 s1/s2 SAME + BN + act (model.py:20-24; efficientnet.py:501-510).  With `gate` set (SE

@@ -51,7 +51,7 @@ def _src_dims(h, w, xf):
 
 
 def run_pointwise16(dev, dt, rng, b, h, w, segs, cout, act='none', bn=True, residual=False, gate=False, out_f32=False,
-                    dense_out=False, pool=False, pre=False, cfg=0):
+                    dense_out=False, pool=False, pre=False, cfg=0, ksplit=False):
     """One 16-bit POINTWISE op through yr_op_run against float64 NumPy on the same (exactly representable) operands.
     h, w: the conv's resolution (pool=True: the output is its 2x2 max)."""
     rt = _rt()
@@ -128,6 +128,8 @@ def run_pointwise16(dev, dt, rng, b, h, w, segs, cout, act='none', bn=True, resi
         out = torch.full((b, oh, ow, out_ld), float('nan'), dtype=rt.TORCH_DTYPE[did], device=dev)
     op.out, op.out_ld = out.data_ptr(), out_ld
     op.k = cfg
+    if ksplit:
+        op.se_reduced |= 0x20000      # the k-split form of the plans for one or two images (pointwise_h.hip: pwkh_kernel)
     rt.run_op(op, b)
     torch.cuda.synchronize()
     if out_f32:
@@ -173,6 +175,16 @@ def test_pointwise16(dev, dt, case):
     h, w, segs, cout, act, bn, residual, gate, out_f32, dense, pool, pre = case
     rng = np.random.default_rng(zlib.crc32(str(case).encode()))
     run_pointwise16(dev, dt, rng, 3, h, w, segs, cout, act, bn, residual, gate, out_f32, dense, pool, pre)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('case', PW16, ids=[str(i) for i in range(len(PW16))])
+def test_pointwise16_ksplit_form(dev, dt, case):
+    """The k-split form (se_reduced bit 17: a workgroup = one 16 x 32 tile, its four waves split the k range and meet in LDS in wave
+    order; what the 16-bit plan for one or two images asks of its small maps) at the per-op bar of the other forms, every source mode."""
+    h, w, segs, cout, act, bn, residual, gate, out_f32, dense, pool, pre = case
+    rng = np.random.default_rng(zlib.crc32(str(case).encode()))
+    run_pointwise16(dev, dt, rng, 3, h, w, segs, cout, act, bn, residual, gate, out_f32, dense, pool, pre, ksplit=True)
 
 
 @pytest.mark.parametrize('dt', DTYPES)

@@ -1713,6 +1713,13 @@ class Compiler:
                 for o in ops:
                     if o.kind == rt.OP_POINTWISE and not any(s_.xform == 'dw3' for s_ in o.srcs):
                         o.se_reduced |= 0x10000
+            if latency and self.dtype != 0 and KSPLIT_MAX_PIXELS > 0:
+                # the 16-bit plan for one or two images: its small maps' pointwise convs in the k-split form too (pointwise_h.hip: pwkh_kernel -
+                # a gated projection of 1152 channels is 36 chunks behind each other in pwh_kernel: 9.8 us at one image)
+                for o in ops:
+                    if o.kind == rt.OP_POINTWISE and not any(s_.xform == 'dw3' for s_ in o.srcs):
+                        if o.h * o.w * (4 if getattr(o, 'stride', 0) == 2 else 1) <= KSPLIT_MAX_PIXELS:
+                            o.se_reduced |= 0x20000
             if self.fuse == 'nohead_k' and self.dtype == 0 and KSPLIT_MAX_PIXELS > 0:
                 # fuse == 'nohead_k' (one or two images: Model.ksplit_batch): the 'nohead' plan whose small maps take the K-SPLIT form of the
                 # split pointwise kernel (se_reduced bit 17; pointwise_split.hip:

@@ -244,6 +244,7 @@ int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
                                {128, 32, launch_direct<2, 2>}, {128, 48, launch_direct<2, 3>}, {128, 64, launch_direct<2, 4>},
                                {128, 80, launch_direct<2, 5>}, {128, 96, launch_direct<2, 6>},
                                {256, 32, launch_direct<4, 2>}, {256, 48, launch_direct<4, 3>}, {256, 64, launch_direct<4, 4>}};
+    if (narrow && (op.se_reduced & 0x20000) && a.S.kp >= 2 * 32 && a.dw_w == nullptr) return yr_pwh_launch_ksplit(op.dtype, a, s);   // (the plan asks for the k-split form)
     if (narrow) return yr_pw_launch_h(op.dtype, op.k - 1, a, s);   // bf16 / f16: pointwise_h.hip (its own tile table)
     constexpr int NLDS = 14;  // the first NLDS entries are the LDS-staged kernel (the heuristic below only ranks those)
     constexpr int NCFG = sizeof(cfgs) / sizeof(cfgs[0]);

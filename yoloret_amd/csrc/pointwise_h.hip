@@ -441,6 +441,97 @@ static int launch_h_cfg(int cfg, const PwArgs& a, hipStream_t s) {
     }
 }
 
+// The K-SPLIT form for the passes of one or two images (se_reduced bit 17 of a POINTWISE op, set by the compiler's 'latency' variant of
+// a 16-bit plan for its small maps; the float32 twin is pointwise_split.hip's pwk_kernel).  pwh_kernel gives a wave 16 pixels x 32
+// couts and the whole k range: at 169 .. 1024 pixels a gated projection of 1152 channels is 36 chunks behind each other (9.8 us at
+// one image).  Here a workgroup is ONE such tile and its four waves take the chunks w, w + 4, ... (PWKH_G of them in flight per wave);
+// the four accumulator pairs meet in LDS in wave order and wave 0 runs pwh_kernel's epilogue.
+#define PWKH_G 3
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void pwkh_kernel(PwArgs a) {
+    __shared__ f32x4 red[3][2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const unsigned ntn = (a.N + 31) / 32;
+    const unsigned L = yr_xcd_swizzle(blockIdx.x, gridDim.x);
+    const int m0 = (int)(L / ntn) * 16, n0 = (int)(L % ntn) * 32;
+    const int kp = a.S.kp, nch = (kp + 31) >> 5;
+    PwhRow<MODE, T> row;
+    row.init(a, m0 + li);
+    const T* brow[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = n0 + 8 * (li >> 2) + 4 * t + (li & 3);   // (pwh_kernel's row assignment: lane group g ends up owning couts 8 g .. 8 g + 7)
+        brow[t] = reinterpret_cast<const T*>(a.wt) + (size_t)(n < a.N ? n : 0) * kp;
+    }
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    auto run = [&](auto pools_tag) __attribute__((always_inline)) {
+        constexpr bool POOLS = decltype(pools_tag)::value;
+        for (int c0 = wave; c0 < nch; c0 += 4 * PWKH_G) {
+            pwh_u4 x[PWKH_G], w[PWKH_G][2];
+            float4 g0[PWKH_G], g1[PWKH_G];
+            int cv[PWKH_G];
+            pw_unroll<PWKH_G>([&](auto J) __attribute__((always_inline)) {
+                constexpr int j = decltype(J)::value;
+                const int kraw = (c0 + 4 * j) * 32 + g * 8;       // (beyond kp for a dead chunk: clamped addresses, cv = 0)
+                row.template issue<POOLS>(a, kraw, kp, x[j], g0[j], g1[j], cv[j]);
+                const int k = kraw < kp ? kraw : kp - 8;
+                w[j][0] = *reinterpret_cast<const pwh_u4*>(brow[0] + k);
+                w[j][1] = *reinterpret_cast<const pwh_u4*>(brow[1] + k);
+            });
+            pw_unroll<PWKH_G>([&](auto J) __attribute__((always_inline)) {
+                constexpr int j = decltype(J)::value;
+                if (c0 + 4 * j < nch) {      // (wave-uniform)
+                    const pwh_u4 xf = pwh_finish<MODE, T>(x[j], g0[j], g1[j], cv[j]);
+                    acc[0] = pwh_mfma<T>(w[j][0], xf, acc[0]);
+                    acc[1] = pwh_mfma<T>(w[j][1], xf, acc[1]);
+                }
+            });
+        }
+    };
+    bool pooled = false;
+    if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < YR_MAX_SRC; ++i)
+            pooled |= a.S.s[i].xform == YR_X_MAXPOOL2 || a.S.s[i].xform == YR_X_MAXPOOL4;
+    }
+    if (pooled) run(std::true_type{});
+    else run(std::false_type{});
+    if (wave > 0) { red[wave - 1][0][lane] = acc[0]; red[wave - 1][1][lane] = acc[1]; }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) { acc[0] += red[w][0][lane]; acc[1] += red[w][1][lane]; }   // (in wave order)
+    const int n = n0 + g * 8;
+    float sc[8], sh[8];
+    pwh_load_bn(a, n, sc, sh);
+    pwh_finish_oct<T>(a, acc[0], acc[1], sc, sh, m0 + li, n, li);
+}
+
+template <class T>
+static int launch_ksplit_t(const PwArgs& a, hipStream_t s) {
+    const int mode = (a.S.n == 1 && a.S.s[0].xform == YR_X_IDENTITY) ? (a.gate ? 2 : 1) : 0;
+    if (mode == 0 && a.gate) { yr_set_error("pointwise: an SE gate needs one identity source"); return YR_ERR_ARG; }
+    dim3 grid((unsigned)((a.M + 15) / 16) * (unsigned)((a.N + 31) / 32));
+    static char nm[3][40];
+    static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "pwkh_kernel<%s,0>", yr_dtype_name(yr_elem<T>::dtype)) +
+                              snprintf(nm[1], sizeof(nm[1]), "pwkh_kernel<%s,1>", yr_dtype_name(yr_elem<T>::dtype)) +
+                              snprintf(nm[2], sizeof(nm[2]), "pwkh_kernel<%s,2>", yr_dtype_name(yr_elem<T>::dtype));
+    (void)nm_len;
+    yr_note_kernel(nm[mode]);
+    if (mode == 1) hipLaunchKernelGGL((pwkh_kernel<T, 1>), grid, dim3(256), 0, s, a);
+    else if (mode == 2) hipLaunchKernelGGL((pwkh_kernel<T, 2>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pwkh_kernel<T, 0>), grid, dim3(256), 0, s, a);
+    YR_LAUNCH_CHECK();
+    return YR_OK;
+}
+int yr_pwh_launch_ksplit(int dtype, const PwArgs& a, hipStream_t s) {
+    if (dtype == YR_BF16) return launch_ksplit_t<yr_bf16>(a, s);
+    if (dtype == YR_F16) return launch_ksplit_t<yr_f16>(a, s);
+    yr_set_error("pointwise: dtype %d is not a 16-bit type", dtype);
+    return YR_ERR_ARG;
+}
+
 // 16-bit ops: a filled PwArgs (yr_launch_pointwise did the argument checks that do not depend on the element type);
 // cfg = op.k - 1 (autotuned tile shape) or -1: heuristic.
 int yr_pw_launch_h(int dtype, int cfg, const PwArgs& a, hipStream_t s) {

@@ -337,6 +337,8 @@ int yr_pw_launch_ksplit(const PwArgs& a, hipStream_t s);
 // 16-bit kernel (pointwise_h.hip): cfg = tile shape index 0..yr_pwh_num_cfgs()-1, or -1 for its heuristic
 int yr_pw_launch_h(int dtype, int cfg, const PwArgs& a, hipStream_t s);
 int yr_pwh_num_cfgs();
+// its k-split form for the passes of one or two images (se_reduced bit 17; a workgroup = one 16 x 32 tile, four waves split the k range)
+int yr_pwh_launch_ksplit(int dtype, const PwArgs& a, hipStream_t s);
 // its activation-stationary (pointwise_hs.hip) and all-couts k-streaming (pointwise_hq.hip) forms, variant 0..3 each;
 // -1: the form does not take this op (nothing launched, no error set)
 // what a form-specific launcher returns when the form does not take the op (the caller falls back to another form):
