@@ -166,19 +166,25 @@ def test_unfused_plan_matches_fused(dev):
     ref = om.yolov3_body(P, x, 'mobilenetv2x75', 3, 20)
     outs = {}
     from yoloret_amd import compiler
-    for fuse in ('1', '0'):
-        os.environ['YOLORET_FUSE'] = fuse
-        saved = compiler.FUSE_MAX_CIN, compiler.FUSE_MIN_PIXELS
+    for fuse in ('1', '1e', '0'):     # ('1e': the deep blocks as expand + depthwise | projection - what they ran before the weight-streaming form)
+        os.environ['YOLORET_FUSE'] = fuse[0]
+        saved = compiler.FUSE_MAX_CIN, compiler.FUSE_MIN_PIXELS, compiler.FUSE_MBK
         compiler.FUSE_MAX_CIN, compiler.FUSE_MIN_PIXELS = 1 << 20, 0  # fuse every eligible block, also the deep ones
+        compiler.FUSE_MBK = fuse == '1'
         try:
             m = yolov3_body(L.Input(shape=[hw[0], hw[1], 3]), 'mobilenetv2x75', 3, num_classes=20)
         finally:
             os.environ.pop('YOLORET_FUSE', None)
-            compiler.FUSE_MAX_CIN, compiler.FUSE_MIN_PIXELS = saved
+            compiler.FUSE_MAX_CIN, compiler.FUSE_MIN_PIXELS, compiler.FUSE_MBK = saved
         kinds = set(o.kind for o in m.plan.ops)
         fused_kinds = {rt.OP_STEMBLOCK, rt.OP_MBLANE, rt.OP_MBR, rt.OP_MBE}
         # (at 96 x 96 the lane-per-pixel kernel's minimum map size keeps block_1..3 unfused: the matrix-pipe forms carry the test)
-        assert ({rt.OP_STEMBLOCK, rt.OP_MBR, rt.OP_MBE} <= kinds) if fuse == '1' else not (fused_kinds & kinds)
+        if fuse == '1':     # block_11..15 in the weight-streaming form (k bit 6): no expand + depthwise op is left
+            assert {rt.OP_STEMBLOCK, rt.OP_MBR} <= kinds and rt.OP_MBE not in kinds and sum(1 for o in m.plan.ops if o.kind == rt.OP_MBR and o.k & 0x40) == 5
+        elif fuse == '1e':
+            assert {rt.OP_STEMBLOCK, rt.OP_MBR, rt.OP_MBE} <= kinds and not any(o.kind == rt.OP_MBR and o.k & 0x40 for o in m.plan.ops)
+        else:
+            assert not (fused_kinds & kinds)
         m.set_weights(P.values)
         outs[fuse] = [y.cpu().numpy() for y in m(torch.from_numpy(x).to(dev))]
         for y, r in zip(outs[fuse], ref):

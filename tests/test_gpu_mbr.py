@@ -151,3 +151,76 @@ def test_mbe(dev, case, split):
     rt.run_op(op, b)
     torch.cuda.synchronize()
     assert_close(from_dev(out), ref, 5e-5, 'mbe %s' % (case,))
+
+
+MBK_CASES = [
+    # the WEIGHT-STREAMING form (k bits 6, 7; csrc/mbk.hip): (h, w, cin, cexp, cout, stride, residual, rows per wave, waves per workgroup)
+    (26, 26, 72, 432, 72, 1, True, 2, 8),      # MobileNetV2 x0.75 block_11, 12: two strips, two row segments, 27 tiles (an odd last pair)
+    (13, 13, 72, 432, 72, 1, True, 2, 8),      # one segment (13 <= 16 rows), one strip
+    (37, 30, 72, 432, 72, 1, True, 2, 8),      # three segments, three strips (ragged)
+    (26, 26, 72, 432, 120, 2, False, 2, 8),    # block_13: even size (pad 0 / 1), two segments
+    (27, 31, 72, 432, 120, 2, False, 2, 8),    # odd size (pad 1 / 1): the first wave's first row lies above the image
+    (9, 7, 72, 432, 120, 2, False, 2, 8),      # tiny map, one segment
+    (13, 13, 120, 720, 120, 1, True, 1, 8),    # block_14, 15: one row per wave, two segments
+    (20, 17, 120, 720, 120, 1, True, 1, 8),    # four segments, two strips
+    (5, 5, 120, 720, 120, 1, True, 1, 8),      # fewer rows than waves
+]
+
+
+def make_block_k(case, dev, b=2, seed=None):
+    from yoloret_amd import runtime as rt
+    from yoloret_amd.compiler import mbk_pack
+    h, w, cin, cexp, cout, s, residual, rows, nw = case
+    rng = np.random.default_rng(zlib.crc32(str(case).encode()) if seed is None else seed)
+    x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
+    we = (rng.standard_normal((cin, cexp)) * np.sqrt(2.0 / cin)).astype(np.float32)
+    se, he = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
+    wd = (rng.standard_normal((3, 3, cexp)) * np.sqrt(2.0 / 9)).astype(np.float32)
+    sd, hd = rng.uniform(0.5, 1.5, cexp).astype(np.float32), rng.normal(0, 0.3, cexp).astype(np.float32)
+    wp = (rng.standard_normal((cexp, cout)) * np.sqrt(1.0 / cexp)).astype(np.float32)
+    sp, hp = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.3, cout).astype(np.float32)
+    packed = mbk_pack(we.T, se, he, wd.reshape(9, cexp), sd, hd, wp.T, sp, hp)
+    keep = [torch.from_numpy(np.ascontiguousarray(a).ravel()).to(dev) for a in packed]
+    xd = to_dev(x, dev)
+    ho, wo = (h + s - 1) // s, (w + s - 1) // s
+    op = rt.new_op(rt.OP_MBR, 'relu6')
+    op.dtype = op.out_dtype = rt.dtype_id('f32')
+    op.h, op.w, op.cin, op.cout, op.k, op.stride, op.nsrc, op.se_reduced = ho, wo, cin, cout, 3 | 0xc0 | nw << 8 | rows << 16, s, 1, cexp
+    op.src[0] = rt.make_src(xd, c=cin)
+    op.wgt, op.b2 = [k.data_ptr() for k in keep]
+    if residual:
+        op.res, op.res_ld = xd.data_ptr(), xd.shape[3]
+    out = torch.full((b, ho, wo, cout), float('nan'), dtype=torch.float32, device=dev)
+    op.out, op.out_ld = out.data_ptr(), cout
+    return op, out, (x, we, se, he, wd, sd, hd, wp, sp, hp, s, residual), keep + [xd]
+
+
+@pytest.mark.parametrize('case', MBK_CASES, ids=[str(i) for i in range(len(MBK_CASES))])
+def test_mbr_streaming_form(dev, case):
+    """The whole block in one launch where the fragments do not fit a CU's register file: same bar as the other forms (5e-5 of the
+    oracle composition); every output element written exactly once (the buffer starts as NaN)."""
+    from yoloret_amd import runtime as rt
+    op, out, params, keep = make_block_k(case, dev)
+    ref = _reference(*params)
+    rt.run_op(op, 2)
+    torch.cuda.synchronize()
+    assert_close(from_dev(out), ref, 5e-5, 'mbr streaming %s' % (case,))
+
+
+def test_mbr_streaming_form_is_batch_independent(dev):
+    """Image i of a batch of 5 equals image i run alone, bit for bit (the sums are grouped by the map's shape only)."""
+    from yoloret_amd import runtime as rt
+    case = MBK_CASES[0]
+    op, out, params, keep = make_block_k(case, dev, b=5, seed=3)
+    rt.run_op(op, 5)
+    torch.cuda.synchronize()
+    full = from_dev(out).copy()
+    x = params[0]
+    for i in (0, 4):
+        op1, out1, _, keep1 = make_block_k(case, dev, b=5, seed=3)
+        xd1 = to_dev(x[i:i + 1], dev)
+        op1.src[0] = rt.make_src(xd1, c=case[2])
+        op1.res = xd1.data_ptr()
+        rt.run_op(op1, 1)
+        torch.cuda.synchronize()
+        assert np.array_equal(from_dev(out1)[0], full[i])

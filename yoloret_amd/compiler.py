@@ -333,6 +333,17 @@ MBS_SHAPES = {
     (24, 144, 32, 2, False): 3, (32, 192, 32, 1, True): 4, (32, 192, 48, 2, False): 4,     # MobileNetV2 x1.4
 }
 MBS_MBE_CINS = (48, 72, 88, 120, 136)      # YR_OP_MBE's split form is built for these block input widths
+# The WEIGHT-STREAMING form of YR_OP_MBR (mbk.hip, round 6; k bits 6 and 7): the blocks whose fragments do not fit one CU's register
+# file as ONE launch - the pixels stay in registers (a wave owns one or two input rows of a 16-column strip and the projection
+# accumulators of its output rows), the weights stream through LDS one pair of expanded tiles at a time.  (cin, cexp, cout, stride,
+# residual) -> (input rows per wave, waves per workgroup).  Before: YR_OP_MBE + a separate projection launch (the 6x-wide depthwise map
+# written and read back: block_11 87 + 100 MB).  YOLORET_FUSE_MBK=0 switches it off.
+FUSE_MBK = os.environ.get('YOLORET_FUSE_MBK', '1') != '0'
+MBK_SHAPES = {
+    (72, 432, 72, 1, True): (2, 8),       # MobileNetV2 x0.75 block_11, 12 (26 x 26)
+    (72, 432, 120, 2, False): (2, 8),     # block_13 (26 x 26 -> 13 x 13)
+    (120, 720, 120, 1, True): (1, 8),     # block_14, 15 (13 x 13)
+}
 # float32 plans, blocks too wide for mbr.hip's one-workgroup form: expand + depthwise in one register-chained kernel (YR_OP_MBE),
 # the projection stays a pointwise op.  Block input widths built in mbr.hip (MBE_CASE).
 FUSE_MBE = os.environ.get('YOLORET_FUSE_MBE', '1') != '0'
@@ -1111,6 +1122,57 @@ def mbs_pack(we_t, e_scale, e_shift, dw, d_scale, d_shift, wp_t, p_scale, p_shif
     return wa, tab, b2
 
 
+def mbk_chunk_words(cin, cout):
+    """float32 words of one chunk of the weight-streaming form (one pair of expanded tiles): expand fragments of both tiles, project
+    fragments of the pair, the two tiles' [11][16] tables padded to 2 KB."""
+    return (4 * ((cin + 31) // 32) + 2 * ((cout + 15) // 16)) * 256 + 512
+
+
+def mbk_pack(we_t, e_scale, e_shift, dw, d_scale, d_shift, wp_t, p_scale, p_shift):
+    """Parameters of a YR_OP_MBR block in its WEIGHT-STREAMING form (k bits 6, 7; mbk.hip): ceil(T / 2) chunks, chunk q = the pair of
+    expanded tiles (2 q, 2 q + 1) = [2 tiles][NKE][2 planes][64 lanes][8 halves] expand fragments | [TO][2 planes][64][8] project
+    fragments | [2 tiles][11][16] float32 (taps x BN scale | depthwise BN shift | expand BN shift) | zeros up to 2 KB - the fragments
+    are mbs_pack's (one wave: consecutive tiles pair up), re-ordered so that a chunk is ONE contiguous piece of the blob.
+    -> (wgt [NQ * chunk words], b2 [16 TO])."""
+    wa, tab, b2 = mbs_pack(we_t, e_scale, e_shift, dw, d_scale, d_shift, wp_t, p_scale, p_shift, 1)
+    cexp = dw.shape[1] // 16 * 16
+    cout, cin = wp_t.shape[0], we_t.shape[1] // 8 * 8
+    T, TO, NKE = cexp // 16, (cout + 15) // 16, (cin + 31) // 32
+    NQ = (T + 1) // 2
+    ex = wa[:T * NKE * 512].reshape(T, NKE * 512)
+    pr = wa[T * NKE * 512:].reshape(NQ, TO * 512)
+    cw = mbk_chunk_words(cin, cout)
+    out = np.zeros((NQ, cw), np.float32)
+    for q in range(NQ):
+        o = 0
+        for t in (2 * q, 2 * q + 1):
+            if t < T:
+                out[q, o:o + NKE * 512] = ex[t]
+            o += NKE * 512
+        out[q, o:o + TO * 512] = pr[q]
+        o += TO * 512
+        for t in (2 * q, 2 * q + 1):
+            if t < T:
+                out[q, o:o + 176] = tab[t].ravel()
+            o += 176
+    return out.ravel(), b2
+
+
+def mbk_segs(stride, h, pad_t, nw, rows):
+    """Row segments the weight-streaming form cuts a map of h input rows into (mbk.hip: mbk_segs)."""
+    ho = (h + stride - 1) // stride
+    if stride == 1:
+        nr = nw * rows
+        return 1 if h <= nr else (h - nr + nr - 3) // (nr - 2) + 1
+    s = 0
+    while True:
+        ylast = s * (nw - 1) + nw - 1
+        end = ylast if 2 * ylast - pad_t + 2 >= h else ylast - 1
+        if end >= ho - 1:
+            return s + 1
+        s += 1
+
+
 def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None, nosplit=frozenset()):
     """Peephole over the lowered op list: [POINTWISE expand+act ->] DEPTHWISE 3x3+act -> POINTWISE
     project (+residual == block input) becomes one MBCONV op whose expanded tensors never reach HBM.
@@ -1284,6 +1346,28 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
             p, bi = ops[j + 1], exp.srcs[0]
             key = (bi.c, d.cin, p.cout if p.kind == rt.OP_POINTWISE else 0, d.stride, p.res is not None)
             bname = exp.name.rsplit('_', 1)[0]
+            if (FUSE_MBK and MBR_SPLIT and key in MBK_SHAPES and bname + '_mbr' not in nosplit and p.kind == rt.OP_POINTWISE and plain1(p)
+                    and p.srcs[0].buf is d.out and p.act == 'none' and 'scale' in p.params and bi.xform == 'identity'
+                    and bi.buf.ld % 4 == 0 and p.out.ld % 4 == 0 and bi.buf.dtype == 0 and p.out.dtype == 0
+                    and (p.res is None or (p.res is bi.buf and d.stride == 1 and p.cout == bi.c))):
+                # the weight-streaming form: one launch, the expanded tensor and the depthwise map stay on the CU (mbk.hip)
+                cin, cexp, cout = bi.c, d.cin, p.cout
+                rows, nw = MBK_SHAPES[key]
+                T, TO = cexp // 16, (cout + 15) // 16
+                m = OpRec(rt.OP_MBR, bname + '_mbr', act='relu6', h=p.h, w=p.w, cin=cin, cout=cout, k=3 | 0xc0 | nw << 8 | rows << 16,
+                          stride=d.stride, se_reduced=cexp, srcs=[bi], out=p.out, res=p.res, macs=exp.macs + d.macs + p.macs, dtype=0)
+                m.fused = [exp, d, p]
+                ep, dp, pp = exp.params, d.params, p.params
+
+                def packed_k(which, ep=ep, dp=dp, pp=pp):
+                    def f(wd):
+                        return mbk_pack(ep['wgt'][1](wd), ep['scale'][1](wd), ep['shift'][1](wd), dp['wgt'][1](wd).reshape(9, -1),
+                                        dp['scale'][1](wd), dp['shift'][1](wd), pp['wgt'][1](wd), pp['scale'][1](wd), pp['shift'][1](wd))[which]
+                    return f
+                m.params = {'wgt': (((T + 1) // 2 * mbk_chunk_words(cin, cout),), packed_k(0)), 'b2': ((16 * TO,), packed_k(1))}
+                out.append(m)
+                i = j + 2
+                continue
             if (key in MBR_SHAPES and (not MBR_BLOCKS or bname in MBR_BLOCKS) and p.kind == rt.OP_POINTWISE and plain1(p)
                     and (len(MBR_SHAPES[key]) < 3 or p.h * p.w <= MBR_SHAPES[key][2])
                     and p.srcs[0].buf is d.out and p.act == 'none' and 'scale' in p.params and bi.xform == 'identity'
@@ -1327,7 +1411,8 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
                 and d.out.ld == round_up(d.cin, 4)):
             bi, cexp = exp.srcs[0], d.cin
             T, KE = cexp // 16, bi.c // 4
-            mbe_split = MBR_SPLIT and bi.c in MBS_MBE_CINS and exp.name.rsplit('_', 1)[0] + '_mbe' not in nosplit
+            mbe_split = (MBR_SPLIT and bi.c in MBS_MBE_CINS and exp.name.rsplit('_', 1)[0] + '_mbe' not in nosplit
+                         and exp.name.rsplit('_', 1)[0] + '_mbr' not in nosplit)     # (... or the block's one-launch form was found out of range)
             m = OpRec(rt.OP_MBE, exp.name.rsplit('_', 1)[0] + '_mbe', act='relu6', h=d.h, w=d.w, cin=bi.c, cout=cexp, k=3 | (0x80 if mbe_split else 0), stride=d.stride,
                       srcs=[bi], out=d.out, macs=exp.macs + d.macs, dtype=0)
             m.fused = [exp, d]

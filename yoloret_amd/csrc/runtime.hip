@@ -44,7 +44,7 @@ static int dispatch(const yr_op& op, int batch, hipStream_t s) {
         case YR_OP_STEMBLOCK: return yr_launch_stemblock(op, batch, s);
         case YR_OP_MBLANE: return yr_launch_mblane(op, batch, s);
         case YR_OP_MBH: case YR_OP_MBX: return yr_launch_mbh(op, batch, s);
-        case YR_OP_MBR: return yr_launch_mbr(op, batch, s);
+        case YR_OP_MBR: return (op.k & 0x40) ? yr_launch_mbk(op, batch, s) : yr_launch_mbr(op, batch, s);
         case YR_OP_MBE: return yr_launch_mbe(op, batch, s);
         case YR_OP_HEAD: return yr_launch_head(op, batch, s);
         default: yr_set_error("unknown op kind %d", op.kind); return YR_ERR_ARG;
@@ -236,6 +236,11 @@ static int64_t param_floats(const yr_op& op, int role) {   // role: 0 wgt, 1 sca
         }
         case YR_OP_MBR: {
             const int64_t t = op.se_reduced / 16, to = ru(op.cout, 16) / 16, ke = op.cin / 4;
+            if (op.k & 0x40) {   // the weight-streaming form (mbk.hip): one chunk per pair of expanded tiles, no wgt2
+                if (role == 0) return (t + 1) / 2 * ((4 * ((op.cin + 31) / 32) + 2 * to) * 1024 + 2048) / 4;
+                if (role == 5) return 16 * to;
+                return 0;
+            }
             if (role == 0 && (op.k & 0x80)) {   // the split form: float16 planes, projection fragments per tile pair of the nw waves
                 const int64_t nw = (op.k >> 8) & 0xff, nke = (op.cin + 31) / 32;
                 if (nw < 1 || nw > t) return -1;
@@ -365,6 +370,7 @@ extern "C" int yr_set_tuning(yr_handle* h, int batch, const int32_t* cfg, int n)
         const bool mbh_ok = (h->ops[i].kind == YR_OP_MBH || h->ops[i].kind == YR_OP_MBX || h->ops[i].kind == YR_OP_MBR || h->ops[i].kind == YR_OP_MBE) && cfg[i] >= 0 && (cfg[i] & 0xff) == 0 && cfg[i] < (1 << 24);   // th << 8 | tw << 16
         YR_REQUIRE(pw_ok || mbh_ok, "yr_set_tuning: entry %d = %d is not a valid tile shape for that op", i, cfg[i]);
         // a split-form block's fragments are packed for ONE nw: a table tuned for another form of the plan (YOLORET_MBR_SPLIT=0) is refused
+        YR_REQUIRE(!(h->ops[i].kind == YR_OP_MBR && (h->ops[i].k & 0x40)) || cfg[i] == 0, "yr_set_tuning: entry %d: the weight-streaming block form has nothing to tune (must be 0)", i);
         const bool split_block = (h->ops[i].kind == YR_OP_MBR || h->ops[i].kind == YR_OP_MBE) && (h->ops[i].k & 0x80);
         YR_REQUIRE(!split_block || (cfg[i] & 0xff00) == 0 || (cfg[i] & 0xff00) == (h->ops[i].k & 0xff00),
                    "yr_set_tuning: entry %d asks for %d waves per workgroup, the split-form fragments of that op are packed for %d", i, (cfg[i] >> 8) & 0xff, (h->ops[i].k >> 8) & 0xff);
@@ -400,7 +406,7 @@ static int resolve_op(const yr_handle* h, size_t i, int batch, float* const ext[
         if (it != h->tuned.end()) op.k = (op.k & 0xff) | it->second[i];
     } else if (op.kind == YR_OP_MBR || op.kind == YR_OP_MBE) {   // (waves per workgroup << 8 | row segments << 16: the tuned walk geometry)
         auto it = h->tuned.find(batch);
-        if (it != h->tuned.end() && it->second[i] != 0) {
+        if (it != h->tuned.end() && it->second[i] != 0 && !(op.k & 0x40)) {   // (k bit 6, the weight-streaming form: its geometry is the plan's)
             // the SPLIT form's fragments are packed for the plan's nw (compiler.mbs_pack): only the row segments are tunable there
             if (op.k & 0x80) op.k = (op.k & 0xffff) | (it->second[i] & 0xff0000);
             else op.k = (op.k & 0xff) | it->second[i];
@@ -614,6 +620,7 @@ extern "C" int yr_autotune(yr_handle* h, const float* images, int batch, float* 
             best[i] = best_cfg;
             continue;
         }
+        if (h->ops[i].kind == YR_OP_MBR && (h->ops[i].k & 0x40)) continue;   // the weight-streaming form (mbk.hip): nothing to tune
         if (h->ops[i].kind == YR_OP_MBR || h->ops[i].kind == YR_OP_MBE) {
             // register-chained float32 blocks: row segments per strip (how many waves the walk is cut into; each segment
             // recomputes two halo rows), IN CONTEXT - right behind the predecessor, whose output is what the caches hold (in
@@ -629,6 +636,7 @@ extern "C" int yr_autotune(yr_handle* h, const float* images, int batch, float* 
                 rc = resolve_op(h, i - 1, batch, ext, static_cast<char*>(workspace), &prev);
                 if (rc) break;
                 if (h->ops[i - 1].kind == YR_OP_POINTWISE) prev.k = best[i - 1];
+                else if (prev.kind == YR_OP_MBR && (prev.k & 0x40)) {}
                 else if (best[i - 1] != 0 && (prev.k & 0x80)) prev.k = (prev.k & 0xffff) | (best[i - 1] & 0xff0000);
                 else if (best[i - 1] != 0) prev.k = (prev.k & 0xff) | best[i - 1];
             }

@@ -52,6 +52,7 @@ bool yr_stemxp_takes(const yr_op& op);                                  // mbxr_
 int yr_launch_stemxp(const yr_op& op, int batch, hipStream_t s);   // mbxr_h.hip: a plain launch of this MBH / MBX op runs the register-chained form
 int yr_launch_mbr(const yr_op& op, int batch, hipStream_t s);
 int yr_launch_mbe(const yr_op& op, int batch, hipStream_t s);
+int yr_launch_mbk(const yr_op& op, int batch, hipStream_t s);   // YR_OP_MBR with k bit 6: the weight-streaming form (mbk.hip)
 int yr_launch_head(const yr_op& op, int batch, hipStream_t s);      // headblock.hip
 int yr_launch_absmax(const float* p, long long rows, int c, int ld, unsigned* out, hipStream_t s);   // elementwise.hip
 int yr_launch_head_walk(const yr_op& op, int batch, hipStream_t s); // headwalk.hip (YR_OP_HEAD with k bit 6)
