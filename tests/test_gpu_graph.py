@@ -179,8 +179,8 @@ def test_unfused_plan_matches_fused(dev):
         kinds = set(o.kind for o in m.plan.ops)
         fused_kinds = {rt.OP_STEMBLOCK, rt.OP_MBLANE, rt.OP_MBR, rt.OP_MBE}
         # (at 96 x 96 the lane-per-pixel kernel's minimum map size keeps block_1..3 unfused: the matrix-pipe forms carry the test)
-        if fuse == '1':     # block_11..15 in the weight-streaming form (k bit 6): no expand + depthwise op is left
-            assert {rt.OP_STEMBLOCK, rt.OP_MBR} <= kinds and rt.OP_MBE not in kinds and sum(1 for o in m.plan.ops if o.kind == rt.OP_MBR and o.k & 0x40) == 5
+        if fuse == '1':     # block_7..15 in the weight-streaming form (k bit 6): no expand + depthwise op is left
+            assert {rt.OP_STEMBLOCK, rt.OP_MBR} <= kinds and rt.OP_MBE not in kinds and sum(1 for o in m.plan.ops if o.kind == rt.OP_MBR and o.k & 0x40) == 9
         elif fuse == '1e':
             assert {rt.OP_STEMBLOCK, rt.OP_MBR, rt.OP_MBE} <= kinds and not any(o.kind == rt.OP_MBR and o.k & 0x40 for o in m.plan.ops)
         else:

@@ -155,7 +155,9 @@ def test_mbe(dev, case, split):
 
 MBK_CASES = [
     # the WEIGHT-STREAMING form (k bits 6, 7; csrc/mbk.hip): (h, w, cin, cexp, cout, stride, residual, rows per wave, waves per workgroup)
-    (26, 26, 72, 432, 72, 1, True, 2, 8),      # MobileNetV2 x0.75 block_11, 12: two strips, two row segments, 27 tiles (an odd last pair)
+    (26, 26, 48, 288, 48, 1, True, 2, 8),      # MobileNetV2 x0.75 block_7..9: two K = 32 steps of the expand conv, 9 pairs
+    (19, 33, 48, 288, 72, 1, False, 2, 8),     # block_10 (no residual), ragged
+    (26, 26, 72, 432, 72, 1, True, 2, 8),      # block_11, 12: two strips, two row segments, 27 tiles (an odd last pair)
     (13, 13, 72, 432, 72, 1, True, 2, 8),      # one segment (13 <= 16 rows), one strip
     (37, 30, 72, 432, 72, 1, True, 2, 8),      # three segments, three strips (ragged)
     (26, 26, 72, 432, 120, 2, False, 2, 8),    # block_13: even size (pad 0 / 1), two segments
@@ -210,7 +212,7 @@ def test_mbr_streaming_form(dev, case):
 def test_mbr_streaming_form_is_batch_independent(dev):
     """Image i of a batch of 5 equals image i run alone, bit for bit (the sums are grouped by the map's shape only)."""
     from yoloret_amd import runtime as rt
-    case = MBK_CASES[0]
+    case = MBK_CASES[2]
     op, out, params, keep = make_block_k(case, dev, b=5, seed=3)
     rt.run_op(op, 5)
     torch.cuda.synchronize()

@@ -13,6 +13,8 @@ from yoloret_amd import runtime as rt          # noqa: E402
 BLOCKS = {   # name: (h, w, cin, cexp, cout, stride, residual, rows, nw), r05 time of the two launches in ms
     'block_11': ((26, 26, 72, 432, 72, 1, True, 2, 8), 0.0419 + 0.0341),
     'block_13': ((26, 26, 72, 432, 120, 2, False, 2, 8), 0.0366 + 0.0197),
+    'block_7': ((26, 26, 48, 288, 48, 1, True, 2, 8), 0.0354),
+    'block_10': ((26, 26, 48, 288, 72, 1, False, 2, 8), 0.0388),
     'block_14': ((13, 13, 120, 720, 120, 1, True, 1, 8), 0.0349 + 0.0279),
 }
 
@@ -35,7 +37,7 @@ def main():
     for name in sys.argv[1:] or list(BLOCKS):
         shape, old = BLOCKS[name]
         h, w, cin, cexp, cout, s, res = shape[:7]
-        for rows, nw in {'block_11': [(2, 8), (2, 4), (2, 6), (1, 8), (1, 16)], 'block_13': [(2, 8), (2, 4)], 'block_14': [(1, 8), (1, 4), (2, 4), (1, 13), (1, 16)]}[name]:
+        for rows, nw in {'block_7': [(2, 8)], 'block_10': [(2, 8)], 'block_11': [(2, 8), (2, 4), (2, 6), (1, 8), (1, 16)], 'block_13': [(2, 8), (2, 4)], 'block_14': [(1, 8), (1, 4), (2, 4), (1, 13), (1, 16)]}[name]:
           if os.environ.get('MBK_PROBE_CFG') and os.environ['MBK_PROBE_CFG'] != '%d,%d' % (rows, nw):
               continue
           shape = shape[:7] + (rows, nw)

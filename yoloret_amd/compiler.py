@@ -340,7 +340,9 @@ MBS_MBE_CINS = (48, 72, 88, 120, 136)      # YR_OP_MBE's split form is built for
 # written and read back: block_11 87 + 100 MB).  YOLORET_FUSE_MBK=0 switches it off.
 FUSE_MBK = os.environ.get('YOLORET_FUSE_MBK', '1') != '0'
 MBK_SHAPES = {
-    (72, 432, 72, 1, True): (2, 8),       # MobileNetV2 x0.75 block_11, 12 (26 x 26)
+    (48, 288, 48, 1, True): (2, 8),       # MobileNetV2 x0.75 block_7..9 (26 x 26): 35 us on the weight-stationary form (mbr.hip) -> 24
+    (48, 288, 72, 1, False): (2, 8),      # block_10: 39 -> 27 us
+    (72, 432, 72, 1, True): (2, 8),       # block_11, 12 (26 x 26): 42 + 34 us (expand + depthwise | projection) -> 46
     (72, 432, 120, 2, False): (2, 8),     # block_13 (26 x 26 -> 13 x 13)
     (120, 720, 120, 1, True): (1, 8),     # block_14, 15 (13 x 13)
 }

@@ -528,6 +528,8 @@ int yr_launch_mbk(const yr_op& op, int batch, hipStream_t s) {
     MBK_CASE(72, 432, 120, 2, 2, 8, false)     // block_13 (26 x 26 -> 13 x 13)
     MBK_CASE(120, 720, 120, 1, 1, 8, true)     // block_14, 15 (13 x 13)
     MBK_CASE(72, 432, 72, 1, 2, 4, true)
+    MBK_CASE(48, 288, 48, 1, 2, 8, true)       // block_7..9
+    MBK_CASE(48, 288, 72, 1, 2, 8, false)      // block_10
     MBK_CASE(72, 432, 72, 1, 1, 16, true)
     MBK_CASE(120, 720, 120, 1, 1, 13, true)
     MBK_CASE(120, 720, 120, 1, 1, 16, true)
