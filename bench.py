@@ -325,6 +325,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    if use_dist:
+        # every rank runs rank 0's tuning table (parallel.share_tuning): results never depend on the table, speeds do, and the job's
+        # step time is its slowest rank's - a rank that tuned beside a noisy neighbour must not run a different step than its peers
+        from yoloret_amd.parallel import share_tuning
+        if rank == 0:
+            model(x)
+            torch.cuda.synchronize(dev)
+        share_tuning(model, b, device=dev)
     step()  # one-time setup outside every timed/warm-up count: buffer allocation + per-layer tile autotuning
     sync()
     # The set-up also brings the device to its sustained clocks: the tuner's ~0.5 s of launches do that as a side

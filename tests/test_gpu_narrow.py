@@ -717,3 +717,38 @@ def test_depthwise_lds_form_geometry_mirror(dev):
             sums = part.sum(dim=1).double().cpu().numpy()
             ref = out.double().sum(dim=(1, 2)).cpu().numpy()
             assert np.abs(sums - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max()), (h, w)
+
+
+@pytest.mark.parametrize('dt,model_name,hw', [('bf16', 'efficientnetb0', (224, 224)), ('f16', 'efficientnetb3', (192, 160))])
+def test_se_model_results_do_not_depend_on_the_tuning_table_or_the_batch(dev, monkeypatch, dt, model_name, hw):
+    """SURVEY.md 4.1 (last row): N ranks with B / N images each must equal one rank with B.  Every rank autotunes (or installs rank 0's
+    table) per batch size, so the RESULT may not depend on a table entry or on the batch: the squeeze sums of the register-chained
+    expand + depthwise ops (YR_OP_MBX, mbxr_h.hip) leave per (strip, quantum of output rows) - quanta fixed by the map's shape, a
+    tuned row segment is a whole number of them.  Tables with 1 / 2 / 3 / 6 row segments for every chained block op, the library's own
+    choice, and image 0 of a batch of 3 run alone: bit-equal logits."""
+    import ctypes
+    monkeypatch.setenv('YOLORET_AUTOTUNE', '0')
+    rt = _rt()
+    m, x, ref, emu, base = _graph16(dev, model_name, hw, 3, dt)
+    xd = torch.from_numpy(x).to(dev)
+    chained = [i for i, o in enumerate(m.plan.ops) if o.kind in (rt.OP_MBX, rt.OP_MBH)]
+    assert sum(1 for i in chained if m.plan.ops[i].kind == rt.OP_MBX) >= 4
+    idx, hd = m._handle(xd.device, 3)
+    n = len(m.plan.ops)
+    for segs in (1, 2, 3, 6):
+        cfg = [0] * n
+        for i in chained:
+            cfg[i] = 255 << 8 | segs << 16        # the register-chained form with this many row segments per strip
+        arr = (ctypes.c_int32 * n)(*cfg)
+        if rt.lib().yr_set_tuning(hd, 3, arr, n) != 0:      # (an op the chained form is not built for refuses tile 255: leave those alone)
+            for i in chained:
+                if m.plan.ops[i].kind == rt.OP_MBH:
+                    cfg[i] = 0
+            arr = (ctypes.c_int32 * n)(*cfg)
+            rt.check(rt.lib().yr_set_tuning(hd, 3, arr, n))
+        got = [y.cpu().numpy() for y in m(xd)]
+        for g, b0 in zip(got, base):
+            assert np.array_equal(g, b0), '%d row segments change the logits' % segs
+    one = [y.cpu().numpy() for y in m(xd[:1])]
+    for g, b0 in zip(one, base):
+        assert np.array_equal(g[0], b0[0]), 'image 0 alone differs from image 0 of the batch'

@@ -159,3 +159,62 @@ def test_real_records_sharded_gather_unpack_equals_unsharded():
         for i, ((b, s, k), (wb, ws, wk)) in enumerate(zip(res, want)):
             assert np.array_equal(b, wb.numpy()) and np.array_equal(s.view(np.int32), ws.numpy().view(np.int32)) and np.array_equal(k, wk.numpy()), \
                 'rank %d, image %d' % (rank, i)
+
+
+class _FakeTunedModel:
+    """Stands in for engine.Model in share_tuning (which needs a GPU): a plan of `n` ops and a tuning table per batch size."""
+
+    def __init__(self, n, tables):
+        self._n, self.tables, self.installed = n, dict(tables), []
+
+    def plan_for(self, batch):
+        class P:
+            pass
+        p = P()
+        p.ops = [None] * self._n
+        return p
+
+    def get_tuning(self, batch, device=None):
+        return self.tables.get(batch)
+
+    def set_tuning(self, batch, table, device=None):
+        if len(table) != self._n:
+            raise ValueError('table length')
+        self.tables[batch] = list(table)
+        self.installed.append(batch)
+
+
+def _tuning_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from yoloret_amd.parallel import share_tuning
+    n = 52
+    own = [(7 * i + 100 * rank) % 29 << (8 if i % 3 else 0) for i in range(n)]       # every rank "tuned" something else
+    m = _FakeTunedModel(n, {32: own})
+    got = share_tuning(m, 32)
+    untuned = share_tuning(_FakeTunedModel(n, {}), 16)     # the source has no table for this batch: nobody installs anything
+    q.put((rank, got, m.tables[32], m.installed, untuned))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_share_tuning_installs_rank0_table_everywhere():
+    """bench.py / a multi-GPU host: rank 0 tunes, every other rank installs ITS table (one broadcast of an int per plan op) instead of
+    timing its own - the ranks then run identical steps.  (That results do not depend on the table at all is the GPU test
+    tests/test_gpu_narrow.py::test_se_model_results_do_not_depend_on_the_tuning_table_or_the_batch.)"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tuning_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    t0 = [(7 * i) % 29 << (8 if i % 3 else 0) for i in range(52)]
+    for rank, got, table, installed, untuned in res:
+        assert got == t0 and table == t0 and untuned is None
+        assert installed == ([] if rank == 0 else [32])

@@ -33,6 +33,7 @@ struct MbxrArgs {
     float* part; int ld_part, rows_cap;
     int H, W, Ho, Wo, Cin, CexpP, ld_in, ld_out, KP, pad_t, pad_l;
     int strips, segs, seg_rows, T, groups, nwaves;
+    int qrows, nquanta;   // the squeeze sums leave per (strip, quantum of qrows output rows): grouped by the map's SHAPE, whatever the segments
 };
 
 __device__ __forceinline__ xr_rsrc xr_make_rsrc(const void* base, unsigned bytes) {
@@ -592,6 +593,37 @@ __global__ __launch_bounds__(256, MW) void mbxr_kernel(MbxrArgs a) {
 #pragma unroll
         for (int q = 0; q < K - 1; ++q) ring[j][q] = (xr_f4){0.f, 0.f, 0.f, 0.f};
 
+    // ---- the squeeze: the wave's channel sums over one QUANTUM of output rows -> row (strip, quantum) of the partial-sum buffer.  Segments
+    // are whole quanta (launch_mbxr), so which wave sums a quantum changes with the tuned segmentation, WHAT is summed in which order
+    // does not: the gate - and with it the model's result - is the same for every tuning table and batch size.
+    const xr_rsrc psrc = xr_make_rsrc(a.part != nullptr ? a.part + (size_t)b * a.rows_cap * a.ld_part : reinterpret_cast<const float*>(a.x), a.part != nullptr ? (unsigned)(a.rows_cap * a.ld_part) * 4u : 0u);
+    // (the lane that stores a tile's sums: pixel 0 of its DPP row; byte offset of the lane's 4 channels of tile j within a buffer row: pch + 64 j)
+    const unsigned pch = (unsigned)(16 * t0 + 4 * mg) * 4u;
+    auto poff = [&](const int j) { return (tlive[j] && px == 0 && 16 * (t0 + j) + 4 * mg < a.ld_part) ? pch + 64u * j : XR_DEAD; };
+    if (a.part != nullptr && strip == 0 && seg == 0) {     // rows no (strip, quantum) owns: zero (the buffer is sized for the LDS-tiled form's smallest tile)
+        for (int rr = a.strips * a.nquanta; rr < a.rows_cap; ++rr)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128((xr_u4){0u, 0u, 0u, 0u}, psrc, poff(j) == XR_DEAD ? XR_DEAD : (unsigned)(rr * a.ld_part) * 4u + poff(j), 0, 0);
+    }
+    auto flush = [&](const int qi) {
+        const unsigned prow_ = (unsigned)((strip * a.nquanta + qi) * a.ld_part) * 4u;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            xr_f4 v = ssum[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {   // fixed tree over the 16 pixels of the DPP row (rotations by 8, 4, 2, 1: every lane ends with the total): deterministic
+                float t = v[i];
+                asm("v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(t));
+                v[i] = t;
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(xr_u4, v), psrc, poff(j) == XR_DEAD ? XR_DEAD : prow_ + poff(j), 0, 0);
+            ssum[j] = (xr_f4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
     auto row = [&](auto emit_c, const int k, const int yo, const XRow& xc_, XRow& xn_) {
         constexpr bool EMIT = decltype(emit_c)::value;
         const int r = rbeg + k;
@@ -715,12 +747,17 @@ __global__ __launch_bounds__(256, MW) void mbxr_kernel(MbxrArgs a) {
 #pragma unroll
         for (int q = 0; q < (K - 2) / 2; ++q) { prow(P0, k, 0, xa, xb); prow(P0, k + 1, 0, xb, xa); k += 2; }
         prow(P0, k, 0, xa, xb); k += 1;
-        for (int i = 0; i < nout; i += 2) {   // (an odd segment's last pair stores its even row only)
-            prow(P1, k, 0, xb, xa);
-            prow(P2, k + 1, 0, xa, xb);
-            prow(P3, k + 2, 0, xb, xa);
-            prow(P4, k + 3, yo0 + i, xa, xb);
-            k += 4;
+#pragma nounroll
+        for (int q0 = 0; q0 < nout; q0 += a.qrows) {     // quantum by quantum (a.qrows is even; without squeeze sums: one quantum = the segment)
+            const int q1 = min(q0 + a.qrows, nout);
+            for (int i = q0; i < q1; i += 2) {   // (an odd segment's last pair stores its even row only)
+                prow(P1, k, 0, xb, xa);
+                prow(P2, k + 1, 0, xa, xb);
+                prow(P3, k + 2, 0, xb, xa);
+                prow(P4, k + 3, yo0 + i, xa, xb);
+                k += 4;
+            }
+            if (a.part != nullptr) flush((yo0 + q0) / a.qrows);
         }
     } else {
     // rows 0 .. K - S - 1 warm the ring up; then every output row takes S input rows, the last of which emits
@@ -733,44 +770,26 @@ __global__ __launch_bounds__(256, MW) void mbxr_kernel(MbxrArgs a) {
         for (int q = 0; q < (K - S) / 2; ++q) { row(N, k, 0, xa, xb); row(N, k + 1, 0, xb, xa); k += 2; }
         row(N, k, 0, xa, xb); k += 1;
     }
-    if constexpr (S == 2) {   // (an odd warm-up: the current row's operands are in xb)
-        for (int i = 0; i < nout; ++i) {
-            row(N, k, 0, xb, xa);
-            row(Y, k + 1, yo0 + i, xa, xb);
-            k += 2;
-        }
-    } else {
-        int i = 0;
-        for (; i + 1 < nout; i += 2) {
-            row(Y, k, yo0 + i, xa, xb);
-            row(Y, k + 1, yo0 + i + 1, xb, xa);
-            k += 2;
-        }
-        if (i < nout) row(Y, k, yo0 + i, xa, xb);
-    }
-    }
-    // ---- the squeeze: this wave's channel sums over its segment -> row (strip, segment) of the partial-sum buffer
-    if (a.part != nullptr) {
-        const int prow = strip * a.segs + seg;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            xr_f4 v = ssum[j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {   // fixed butterfly over the 16 pixels of the DPP row: deterministic
-                v[i] += __shfl_xor(v[i], 8, 16);
-                v[i] += __shfl_xor(v[i], 4, 16);
-                v[i] += __shfl_xor(v[i], 2, 16);
-                v[i] += __shfl_xor(v[i], 1, 16);
+#pragma nounroll
+    for (int q0 = 0; q0 < nout; q0 += a.qrows) {     // quantum by quantum (a.qrows is even; without squeeze sums: one quantum = the segment)
+        const int q1 = min(q0 + a.qrows, nout);
+        if constexpr (S == 2) {   // (an odd warm-up: the current row's operands are in xb)
+            for (int i = q0; i < q1; ++i) {
+                row(N, k, 0, xb, xa);
+                row(Y, k + 1, yo0 + i, xa, xb);
+                k += 2;
             }
-            const int ch = 16 * (t0 + j) + 4 * mg;
-            if (tlive[j] && px == 0 && ch < a.ld_part) {
-                float* p = a.part + ((size_t)b * a.rows_cap + prow) * a.ld_part + ch;
-                *reinterpret_cast<xr_f4*>(p) = v;
-                if (strip == 0 && seg == 0)     // rows no (strip, segment) owns: zero (the buffer is sized for the LDS-tiled form's smallest tile)
-                    for (int rr = a.strips * a.segs; rr < a.rows_cap; ++rr)
-                        *reinterpret_cast<xr_f4*>(a.part + ((size_t)b * a.rows_cap + rr) * a.ld_part + ch) = (xr_f4){0.f, 0.f, 0.f, 0.f};
+        } else {
+            int i = q0;
+            for (; i + 1 < q1; i += 2) {
+                row(Y, k, yo0 + i, xa, xb);
+                row(Y, k + 1, yo0 + i + 1, xb, xa);
+                k += 2;
             }
+            if (i < q1) row(Y, k, yo0 + i, xa, xb);     // (only the image's last quantum has an odd number of rows)
         }
+        if (a.part != nullptr) flush((yo0 + q0) / a.qrows);
+    }
     }
 }
 
@@ -789,10 +808,18 @@ static int launch_mbxr(const MbxrArgs& a0, int batch, int want_segs, hipStream_t
     if (segs > max_segs) segs = max_segs;
     if (segs < 1) segs = 1;
     if (want_segs > 0) segs = want_segs < a.Ho ? want_segs : a.Ho;
-    if (a.part != nullptr && a.strips * segs > a.rows_cap) segs = a.rows_cap / a.strips;   // one row of the partial-sum buffer per (strip, segment)
-    YR_REQUIRE(segs >= 1, "mbxr: %d strips exceed the %d rows of the partial-sum buffer", a.strips, a.rows_cap);
     a.seg_rows = (a.Ho + segs - 1) / segs;
     if (S == 2 && !BC5) a.seg_rows += a.seg_rows & 1;   // (output rows are processed in pairs)
+    a.qrows = a.seg_rows + (a.seg_rows & 1); a.nquanta = 0;     // (no sums: the quantum loop runs once)
+    if (a.part != nullptr) {
+        // one row of the partial-sum buffer per (strip, quantum): the smallest even quantum from 4 rows on that fits the buffer - a
+        // function of the shape alone; a segment is a whole number of quanta
+        int q = 4;
+        while (a.strips * ((a.Ho + q - 1) / q) > a.rows_cap && q < a.Ho + 1) q += 2;
+        YR_REQUIRE(a.strips * ((a.Ho + q - 1) / q) <= a.rows_cap, "mbxr: %d strips exceed the %d rows of the partial-sum buffer", a.strips, a.rows_cap);
+        a.qrows = q; a.nquanta = (a.Ho + q - 1) / q;
+        a.seg_rows = (a.seg_rows + q - 1) / q * q;
+    }
     a.segs = (a.Ho + a.seg_rows - 1) / a.seg_rows;
     a.nwaves = batch * a.strips * a.segs * a.groups;
     static char nm[64];

@@ -624,8 +624,8 @@ extern "C" int yr_autotune(yr_handle* h, const float* images, int batch, float* 
         if (h->ops[i].kind == YR_OP_MBR || h->ops[i].kind == YR_OP_MBE) {
             // register-chained float32 blocks: row segments per strip (how many waves the walk is cut into; each segment
             // recomputes two halo rows), IN CONTEXT - right behind the predecessor, whose output is what the caches hold (in
-            // isolation block_2 measured 203 us, in the pipeline 240).  The maps do not depend on the choice (the squeeze-excite sums of a
-            // chained MBX op are grouped by segment: their float32 rounding does - within the op's tolerance, like any other grouping).
+            // isolation block_2 measured 203 us, in the pipeline 240).  Nothing an op writes depends on the choice (the squeeze-excite sums of a
+            // chained MBX op leave per quantum of output rows fixed by the map's shape; a segment is a whole number of quanta: mbxr_h.hip).
             yr_op op, prev;
             rc = resolve_op(h, i, batch, ext, static_cast<char*>(workspace), &op);
             if (rc) break;

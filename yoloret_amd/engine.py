@@ -212,8 +212,12 @@ class Model:
         yp = [rt._ptr(y) for y in ys] + [None] * (3 - len(ys))
         with torch.cuda.device(idx):
             if self.autotune and (idx, b) not in self._tuned:
-                # first call with this batch size: time every pointwise tile shape per layer once (~0.1 s);
-                # the choice changes speed only, never results
+                # first call with this batch size: time every pointwise tile shape / block segmentation per layer once (~0.1 s).
+                # The choice changes speed only, never results: every shape of a conv runs the same sum per output, the block kernels'
+                # maps do not depend on the row segments, and since round 6 neither do the squeeze sums of the register-chained
+                # expand + depthwise ops (grouped by row quanta fixed by the map's shape: tests/test_gpu_narrow.py::
+                # test_se_model_results_do_not_depend_on_the_tuning_table_or_the_batch).  The one exception is a forced LDS-tiled
+                # YR_OP_MBX (YOLORET_MBXR=0, an A/B switch): its sums are grouped by the tuned tile.
                 self._tuned.add((idx, b))
                 if not self._load_tuning(hd, b):
                     rt.check(rt.lib().yr_autotune(hd, rt._ptr(x), b, yp[0], yp[1], yp[2], rt._ptr(ws), ws.numel(),
@@ -227,6 +231,32 @@ class Model:
         return res
 
     predict = __call__
+
+    # ---- the tuning table as a value: what rank 0 broadcasts to the other ranks (parallel.share_tuning)
+    def get_tuning(self, batch, device=None):
+        """The tile / segment table yr_autotune chose for `batch` images on `device` (one int per plan op: yr_get_tuning), or None if
+        that batch size has not been tuned there."""
+        device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+        idx, hd = self._handle(device, batch)
+        n = len(self.plan_for(batch).ops)
+        arr = (ctypes.c_int32 * n)()
+        with torch.cuda.device(idx):
+            if rt.lib().yr_get_tuning(hd, batch, arr, n) != 0:
+                return None
+        return [int(v) for v in arr]
+
+    def set_tuning(self, batch, table, device=None):
+        """Installs a table (get_tuning's, from this or another process with the same plan) for `batch` images: the first call with
+        that batch size then runs no trial launches.  Raises on a table of the wrong length or with an entry the op cannot take."""
+        device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+        idx, hd = self._handle(device, batch)
+        n = len(self.plan_for(batch).ops)
+        if len(table) != n:
+            raise ValueError('tuning table of %d entries for a plan of %d ops' % (len(table), n))
+        arr = (ctypes.c_int32 * n)(*[int(v) for v in table])
+        with torch.cuda.device(idx):
+            rt.check(rt.lib().yr_set_tuning(hd, batch, arr, n))
+        self._tuned.add((idx, batch))
 
     # ---- tuning cache: YOLORET_TUNE_CACHE=<file.json> keeps the autotuned tile table across processes
     # (tune once, deploy many; also keeps profiler runs free of the tuner's trial launches)

@@ -20,6 +20,33 @@ def shard_range(global_batch, rank, world_size):
     return rank * per, (rank + 1) * per
 
 
+def share_tuning(model, batch, group=None, src=0, device=None):
+    """Every rank runs the SAME tuning table: rank `src` has tuned `batch` images (its first call did: yr_autotune), the others install
+    its table (Model.get_tuning / set_tuning) instead of timing their own.  Results do not depend on the table (engine.Model.__call__),
+    speeds do - and a rank that measured beside a noisy neighbour would otherwise run a different step than its peers and the
+    max-over-ranks step time is the slowest rank's.  The counterpart of "same variables on every replica" (reference code/train.py:55,
+    tf.distribute.MirroredStrategy).  One small broadcast (an int per plan op); a no-op for a single process.  Returns the table."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return model.get_tuning(batch, device)
+    rank = dist.get_rank(group)
+    table = model.get_tuning(batch, device) if rank == src else None
+    n = len(model.plan_for(batch).ops)
+    on_gpu = dist.get_backend(group) == 'nccl'
+    dev = (device if device is not None else torch.device('cuda', torch.cuda.current_device())) if on_gpu else torch.device('cpu')
+    # entry 0: 1 if the source has a table (an untuned source leaves everybody untuned), then the n entries
+    msg = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    if rank == src and table is not None:
+        msg[0] = 1
+        msg[1:] = torch.tensor(table, dtype=torch.int32)
+    dist.broadcast(msg, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+    got = [int(v) for v in msg.cpu().tolist()]
+    if not got[0]:
+        return None
+    if rank != src:
+        model.set_tuning(batch, got[1:], device)
+    return got[1:]
+
+
 class GatherHandle:
     """One all-gather in flight (DetectionGatherer.start).  wait() makes the CURRENT stream wait for it and returns
     (all_det [W*b,S,6], all_cnt [W*b]) - views of one of the gatherer's two result buffers, valid until the second

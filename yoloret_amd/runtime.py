@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libyoloret_hip.so')
+LIB_PATH = os.environ.get('YOLORET_LIB') or os.path.join(_HERE, 'libyoloret_hip.so')     # (YOLORET_LIB: another build of the same ABI, e.g. for same-box A/B runs)
 
 YR_MAX_SRC = 4
 ACT = {'none': 0, None: 0, 'relu6': 1, 'swish': 2, 'sigmoid': 3, 'leaky': 4}
