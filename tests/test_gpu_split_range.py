@@ -216,3 +216,61 @@ def test_check_ranges_moves_ops_off_the_split_forms(dev):
     for a, c in zip(ys, y3):
         a, c = a.cpu().numpy().astype(np.float64), c.cpu().numpy().astype(np.float64)
         assert np.abs(a - c).max() <= 2e-3 * max(1.0, np.abs(c).max())
+
+
+def test_range_guard_holds_across_plan_variants_and_for_weights(dev):
+    """(i) a model guarded at one batch size and then called at another (the few-image plan names a head block's conv
+    '<x>_conv', the throughput plan '<x>_head') keeps the offending op off the split forms - finite logits equal to the other
+    variant's; (ii) a WEIGHT beyond the float16 range moves its op to the float32 MFMA instead of failing an assertion in the
+    fragment packing; (iii) range_check_every re-arms the guard: an input that leaves the range LATER is caught."""
+    from yoloret_amd import layers as L, compiler as C
+    from yoloret_amd.weights import synthetic_images, synthetic_weights
+    from yoloret_amd.yolo3.model import yolov3_body
+    hw = 64
+    x = torch.from_numpy(synthetic_images(8, hw, hw)).to(dev)
+    m0 = yolov3_body(L.Input(shape=[hw, hw, 3]), 'mobilenetv2x75', 3, num_classes=20)
+    wd = synthetic_weights(m0, 1234, 'conditioned')
+    # (i) the input of the td1 head block's conv near 2e5: block_15's output (a linear bottleneck + residual: unclamped) feeds it
+    prod = 'block_15_project_BN/beta'
+    big = dict(wd)
+    big[prod] = (wd[prod] + 2e5).astype(np.float32)
+    outs = {}
+    for first, second in ((8, 1), (1, 8)):
+        m = yolov3_body(L.Input(shape=[hw, hw, 3]), 'mobilenetv2x75', 3, num_classes=20)
+        m.set_weights(big)
+        m.small_batch, m.small_variant, m.ksplit_batch = 4, 'nohead', 2     # (the shipped defaults; tests/conftest.py switches the few-image plan off)
+        assert m.variant(8) == 'throughput' and m.variant(1) == 'nohead_k'
+        ya = m(x[:first])                     # the guard runs here, on this variant's op names
+        assert m._nosplit
+        yb = m(x[:second])                    # ... and must hold for the other variant
+        for y in list(ya) + list(yb):
+            assert np.isfinite(y.cpu().numpy()).all(), 'a split-form op ran out of range in the %d-image plan' % second
+        split = [m.plan_for(second).ops[i].name for i in C.split_form_ops(m.plan_for(second))]
+        assert not (set(split) & C.nosplit_aliases(m._nosplit)), (second, sorted(set(split) & C.nosplit_aliases(m._nosplit)))
+        outs[first] = [y.cpu().numpy() for y in (ya if first == 8 else yb)]
+    for a, b in zip(outs[8], outs[1]):        # the batch-8 logits, guard armed at batch 8 | at batch 1: the same plan in the end
+        assert np.array_equal(a, b)
+    # (ii) one projection weight of block_3 at 1e5: mbs_pack cannot cut it into float16 planes
+    k = next(k for k in wd if k.startswith('block_3_project') and k.endswith('/kernel'))
+    heavy = dict(wd)
+    heavy[k] = wd[k].copy()
+    heavy[k].flat[5] = 1.0e5
+    m2 = yolov3_body(L.Input(shape=[hw, hw, 3]), 'mobilenetv2x75', 3, num_classes=20)
+    m2.set_weights(heavy)
+    y2 = m2(x[:8])
+    assert 'block_3_mbr' in m2._nosplit and all(np.isfinite(y.cpu().numpy()).all() for y in y2)
+    assert not ({o.name: o for o in m2.plan.ops}['block_3_mbr'].k & 0x80)
+    # (iii) ordinary weights: the guard measures the first call and, with range_check_every = 4, every 4th one after it.  (With these
+    # architectures no INPUT can drive a later activation out of range - the stem's ReLU6 bounds what follows whatever the image holds,
+    # x 1e6 included; what the periodic pass protects is a deployment whose weights are swapped in place or a float32 plan with an
+    # unbounded stem activation.)
+    m3 = yolov3_body(L.Input(shape=[hw, hw, 3]), 'mobilenetv2x75', 3, num_classes=20)
+    m3.set_weights(wd)
+    m3.range_check_every = 4
+    seen = []
+    real = m3.check_ranges
+    m3.check_ranges = lambda *a, **k: (seen.append(m3._calls), real(*a, **k))[1]
+    for i in range(9):
+        y = m3(x[:8] * (1.0e6 if i == 3 else 1.0))
+        assert all(np.isfinite(t.cpu().numpy()).all() for t in y)
+    assert seen == [1, 4, 8] and not m3._nosplit

@@ -522,3 +522,42 @@ def test_head_blocks_of_the_16bit_plans_and_their_fragment_packing(monkeypatch):
     assert rc == 0 or (b'does not fit' not in err and b'bytes' not in err and b'parameter' not in err), err
     if rc == 0:
         rt.lib().yr_destroy(h)
+
+
+def test_nosplit_names_hold_in_every_plan_variant():
+    """Model.check_ranges reports op names of the variant the first batch ran ('td1_head' in the throughput plan,
+    'td1_conv' where YR_OP_HEAD is not fused; 'block_11_mbr' | 'block_11_mbe' | 'block_11_expand').  Compiled with the SAME nosplit set,
+    no variant may keep the equivalent convolution in a split form - in either direction."""
+    from yoloret_amd import compiler as C
+    from yoloret_amd import layers as L
+    from yoloret_amd import runtime as rt
+    from yoloret_amd.yolo3.model import yolov3_body
+    m = yolov3_body(L.Input(shape=[416, 416, 3]), 'mobilenetv2x75', 3, num_classes=20)
+    assert C.nosplit_aliases(['td1_head']) == frozenset(['td1_head', 'td1_conv'])
+    assert C.nosplit_aliases(['block_11_mbe']) >= frozenset(['block_11_mbr', 'block_11_mbe', 'block_11_expand'])
+    heads = [o.name for o in m.plan.ops if o.kind == rt.OP_HEAD]
+    assert len(heads) == 6
+    for reported in (heads, [n.replace('_head', '_conv') for n in heads]):          # as the throughput plan names them | as 'nohead' does
+        for variant in (True, 'nohead', 'nohead_k'):
+            plan = C.compile_graph(m.inputs[0], m.outputs, variant, 0, frozenset(reported))
+            split = [plan.ops[i].name for i in C.split_form_ops(plan)]
+            for n in heads:
+                base = n[:-len('_head')]
+                assert base + '_head' not in split and base + '_conv' not in split, (variant, reported[0], split)
+            conv = {o.name: o for o in plan.ops}
+            assert all(conv[n.replace('_head', '_conv')].se_reduced & 0x10000 for n in heads)       # the float32 MFMA, in every variant
+    # an inverted-residual block: one-launch form (weight-streaming / register-chained) <-> expand + depthwise | projection
+    for reported in (['block_11_mbr'], ['block_11_mbe'], ['block_3_mbr']):
+        for variant in (True, 'nohead'):
+            plan = C.compile_graph(m.inputs[0], m.outputs, variant, 0, frozenset(reported))
+            base = reported[0].rsplit('_', 1)[0]
+            ops = {o.name: o for o in plan.ops}
+            blk = [o for n, o in ops.items() if n in (base + '_mbr', base + '_mbe')]
+            assert blk and all(not (o.k & 0x80) for o in blk), (reported, variant, [(o.name, hex(o.k)) for o in blk])
+    saved = C.FUSE_MBK
+    C.FUSE_MBK = False
+    try:       # ... and with the weight-streaming form off, the name it would have had still binds the expand + depthwise op
+        plan = C.compile_graph(m.inputs[0], m.outputs, True, 0, frozenset(['block_12_mbr']))
+        assert not ({o.name: o for o in plan.ops}['block_12_mbe'].k & 0x80)
+    finally:
+        C.FUSE_MBK = saved

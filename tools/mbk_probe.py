@@ -37,7 +37,7 @@ def main():
     for name in sys.argv[1:] or list(BLOCKS):
         shape, old = BLOCKS[name]
         h, w, cin, cexp, cout, s, res = shape[:7]
-        for rows, nw in {'block_7': [(2, 8)], 'block_10': [(2, 8)], 'block_11': [(2, 8), (2, 4), (2, 6), (1, 8), (1, 16)], 'block_13': [(2, 8), (2, 4)], 'block_14': [(1, 8), (1, 4), (2, 4), (1, 13), (1, 16)]}[name]:
+        for rows, nw in [BLOCKS[name][0][7:9]]:
           if os.environ.get('MBK_PROBE_CFG') and os.environ['MBK_PROBE_CFG'] != '%d,%d' % (rows, nw):
               continue
           shape = shape[:7] + (rows, nw)

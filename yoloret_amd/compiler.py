@@ -77,6 +77,14 @@ class OpRec:
         self.__dict__.update(kw)
 
 
+class WeightRangeError(ValueError):
+    """A weight of a split-form op (float16 planes) is beyond the float16 range.  `op_name`: the plan op."""
+
+    def __init__(self, op_name, msg):
+        ValueError.__init__(self, msg)
+        self.op_name = op_name
+
+
 class Plan:
     def __init__(self, ops, bufs, inputs, outputs, param_shapes, input_shape, dtype=0):
         self.ops, self.bufs = ops, bufs
@@ -143,16 +151,30 @@ class Plan:
         self.blob_floats = max(off, 4)
 
     def build_blob(self, weights):
+        """(raises WeightRangeError naming the op when a split-form op's weights do not fit float16 planes: engine.Model then rebuilds
+        the plan with that op on the float32 MFMA)"""
+        try:
+            return self._build_blob(weights)
+        except WeightRangeError:
+            raise
+
+    def _build_blob(self, weights):
         """The flat parameter blob in op order.  float32 everywhere except the pointwise weight matrices of a 16-bit
         plan, which are rounded (to nearest even) to that type here, once, and stored packed two per float slot."""
         blob = np.zeros(self.blob_floats, np.float32)
         for op, role, off, shape, dt in self.blob_layout:
-            arr = np.asarray(op.params[role][1](weights), np.float32)
+            try:
+                arr = np.asarray(op.params[role][1](weights), np.float32)
+            except AssertionError as e:      # (head_pack / mbs_pack: the planes of a weight beyond the float16 range)
+                if 'beyond the float16 range' in str(e):
+                    raise WeightRangeError(op.name, str(e))
+                raise
             assert tuple(arr.shape) == tuple(shape), (op.name, role, arr.shape, shape)
             if dt == 0:
-                if op.kind == rt.OP_POINTWISE and role == 'wgt' and op.dtype == 0 and PW_SPLIT and arr.size and float(np.abs(arr).max()) >= 60000.0:
-                    raise ValueError('%s: a weight of %.3g is beyond the float16 range the split pointwise form needs (YOLORET_PW_SPLIT=0 '
-                                     'runs the float32-MFMA kernels)' % (op.name, float(np.abs(arr).max())))
+                if (op.kind == rt.OP_POINTWISE and role == 'wgt' and op.dtype == 0 and PW_SPLIT and not (op.se_reduced & 0x10000)
+                        and arr.size and float(np.abs(arr).max()) >= 60000.0):
+                    raise WeightRangeError(op.name, '%s: a weight of %.3g is beyond the float16 range the split pointwise form needs (YOLORET_PW_SPLIT=0 '
+                                           'runs the float32-MFMA kernels)' % (op.name, float(np.abs(arr).max())))
                 blob[off:off + arr.size] = arr.ravel()
             else:
                 bits = rt.to_bits16(arr.ravel(), dt)
@@ -1611,7 +1633,7 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
 class Compiler:
     def __init__(self, inputs, outputs, fuse=True, dtype=0, nosplit=frozenset()):
         self.fuse = fuse
-        self.nosplit = frozenset(nosplit)     # names of plan ops that must not run a split (float16-plane) form: Model.check_ranges
+        self.nosplit = nosplit_aliases(nosplit)     # names of plan ops that must not run a split (float16-plane) form: Model.check_ranges
         self.dtype = rt.dtype_id(dtype)   # element type of the activations between ops
         self.V = rt.VEC[self.dtype]
         self.inputs = inputs
@@ -2067,6 +2089,24 @@ def compile_graph(inputs, outputs, fuse=True, dtype=0, nosplit=frozenset()):
 
 
 SPLIT_LIMIT = 60000.0     # |operand| a split-form op accepts (float16's largest finite value is 65504)
+
+# The same convolution has a different op name in different plan variants: a detection-head block is '<x>_head' where YR_OP_HEAD
+# fuses it and '<x>_conv' (+ '<x>_mb_depthwise') where it does not ('nohead', 'nohead_k', 'latency'); an inverted-residual block is
+# '<b>_mbr' (one launch), '<b>_mbe' (+ '<b>_project') or '<b>_expand' (...) depending on which fused form takes it.  A name
+# Model.check_ranges reports from ONE variant must move the op off the split forms in ALL of them (a model guarded at
+# batch 64 and then called at batch 1 ran the unfused conv in the split form).
+_NOSPLIT_GROUPS = (('_head', '_conv'), ('_mbr', '_mbe', '_expand'))
+
+
+def nosplit_aliases(names):
+    """names -> the same set plus every name the same convolution carries in another plan variant."""
+    out = set(names)
+    for n in names:
+        for grp in _NOSPLIT_GROUPS:
+            for suf in grp:
+                if n.endswith(suf):
+                    out.update(n[:-len(suf)] + other for other in grp)
+    return frozenset(out)
 
 
 def split_form_ops(plan):

@@ -524,21 +524,13 @@ int yr_launch_mbk(const yr_op& op, int batch, hipStream_t s) {
 #define MBK_CASE(CIN, CEXP, COUT, S, ROWS, NW, RES)                                                                            \
     if (in.c == CIN && op.se_reduced == CEXP && op.cout == COUT && op.stride == S && res == RES && nw == NW && rows == ROWS)      \
         return launch_mbk<CIN, CEXP, COUT, S, ROWS, NW, RES>(a, batch, s);
-    MBK_CASE(72, 432, 72, 1, 2, 8, true)       // MobileNetV2 x0.75 block_11, 12 (26 x 26)
+    MBK_CASE(48, 288, 48, 1, 2, 8, true)       // MobileNetV2 x0.75 block_7..9 (26 x 26)
+    MBK_CASE(48, 288, 72, 1, 2, 8, false)      // block_10
+    MBK_CASE(72, 432, 72, 1, 2, 8, true)       // block_11, 12 (26 x 26)
     MBK_CASE(72, 432, 120, 2, 2, 8, false)     // block_13 (26 x 26 -> 13 x 13)
     MBK_CASE(120, 720, 120, 1, 1, 8, true)     // block_14, 15 (13 x 13)
-    MBK_CASE(72, 432, 72, 1, 2, 4, true)
-    MBK_CASE(48, 288, 48, 1, 2, 8, true)       // block_7..9
-    MBK_CASE(48, 288, 72, 1, 2, 8, false)      // block_10
-    MBK_CASE(72, 432, 72, 1, 1, 16, true)
-    MBK_CASE(120, 720, 120, 1, 1, 13, true)
-    MBK_CASE(120, 720, 120, 1, 1, 16, true)
-    MBK_CASE(72, 432, 72, 1, 2, 6, true)
-    MBK_CASE(72, 432, 72, 1, 1, 8, true)
-    MBK_CASE(72, 432, 120, 2, 2, 4, false)
-    MBK_CASE(120, 720, 120, 1, 1, 4, true)
-    MBK_CASE(120, 720, 120, 1, 2, 4, true)
-    MBK_CASE(120, 720, 120, 1, 2, 8, true)
+    // (measured and dropped, block_11 at 64 images: 4 waves x 2 rows - two workgroups per CU - 47 us against 46; 16 waves x 1 row 47;
+    //  8 waves x 1 row 51 (two generations of workgroups); block_14: 4 waves 78 us, 2 rows per wave 58 against 49 - profiles/r06_mbk_probe.txt)
 #undef MBK_CASE
     yr_set_error("mbk: block %d -> %d -> %d stride %d res %d (nw %d, rows %d) is not built", in.c, op.se_reduced, op.cout, op.stride, (int)res, nw, rows);
     return YR_ERR_ARG;

@@ -35,6 +35,11 @@ class Model:
         self._nosplit = frozenset()   # plan ops moved off the split (float16-plane) forms by check_ranges
         self._ranges_checked = False
         self.range_check = os.environ.get('YOLORET_RANGE_CHECK', '1') != '0'
+        # The automatic guard measures the FIRST batch per set of weights.  range_check_every = N re-measures every N-th call (an
+        # instrumented pass costs about two forwards) for deployments whose inputs may drift out of the range the first batch had;
+        # 0 (default): first batch only - a later batch that pushes an activation past 65504 is NOT detected.
+        self.range_check_every = int(os.environ.get('YOLORET_RANGE_CHECK_EVERY', '0'))
+        self._calls = 0
         self.plan = compile_graph(self.inputs[0], self.outputs, fuse, self.dtype)
         # batches of up to SMALL_BATCH images run a second plan without block fusion (compiler.py: 'latency');
         # compiled on first use, same parameters, its own weight blob / handle / tile table.  Default (tools/lat_sweep.py, round 4):
@@ -153,17 +158,47 @@ class Model:
     def _blob_of(self, variant):
         if self._weights is None:
             raise RuntimeError('weights have not been set (set_weights / load_weights)')
-        if variant not in self._blobs:
-            self._blobs[variant] = self._plans[variant].build_blob(self._weights)
-        return self._blobs[variant]
+        from .compiler import WeightRangeError
+        for _attempt in range(64):
+            if variant in self._blobs:
+                return self._blobs[variant]
+            if variant not in self._plans:       # (the plans were dropped by a fallback below)
+                self._plans[variant] = compile_graph(self.inputs[0], self.outputs, self._fuse if variant == 'throughput' else variant, self.dtype, self._nosplit)
+                if variant == 'throughput':
+                    self.plan = self._plans[variant]
+            try:
+                self._blobs[variant] = self._plans[variant].build_blob(self._weights)
+            except WeightRangeError as e:
+                # a WEIGHT of a split-form op beyond the float16 range: that op runs the float32 MFMA in every plan variant (the same
+                # fallback check_ranges takes for activations) - never a failed assertion, never a clamped weight
+                if e.op_name in self._nosplit or self.dtype != 0:
+                    raise
+                self._drop_split_forms([e.op_name])
+        raise RuntimeError('no plan without out-of-range weights found')
+
+    def _drop_split_forms(self, names):
+        """The named plan ops (and what the same convolutions are called in the other plan variants: compiler.nosplit_aliases) leave
+        the split forms.  Everything compiled / uploaded so far belongs to the old plans: destroyed - after the device has finished
+        whatever other contexts still have in flight on them."""
+        from .compiler import nosplit_aliases
+        self._nosplit = nosplit_aliases(self._nosplit | frozenset(names))
+        if self._handles:
+            torch.cuda.synchronize()
+        for h in self._handles.values():
+            rt.lib().yr_destroy(h)
+        self._handles, self._blobs, self._tuned = {}, {}, set()
+        self.plan = compile_graph(self.inputs[0], self.outputs, self._fuse, self.dtype, self._nosplit)
+        self._plans = {'throughput': self.plan}
+        self.range_fallbacks = sorted(self._nosplit)
 
     def _handle(self, device, batch=0):
         idx = device.index if device.index is not None else torch.cuda.current_device()
         variant = self.variant(batch)
         h = self._handles.get((idx, variant))
         if h is None:
+            self.plan_for(batch)
+            blob = self._blob_of(variant)          # (may rebuild the plans: a weight beyond the float16 range leaves the split forms)
             plan = self.plan_for(batch)
-            blob = self._blob_of(variant)
             ops, bufs = plan.c_arrays()
             hp = ctypes.c_void_p()
             with torch.cuda.device(idx):
@@ -194,8 +229,10 @@ class Model:
             raise ValueError('input shape %s does not match the model input [B,%d,%d,%d]' % (tuple(x.shape), h, w, c))
         x = x.contiguous()
         b = x.shape[0]
-        if self.range_check and self.dtype == 0 and not self._ranges_checked:
-            # once per set of weights, on the first batch seen: the split-form ops' operands must stay inside the float16 range
+        self._calls += 1
+        if self.range_check and self.dtype == 0 and (not self._ranges_checked or (self.range_check_every > 0 and self._calls % self.range_check_every == 0)):
+            # once per set of weights, on the first batch seen (and every range_check_every-th call): the split-form ops' operands
+            # must stay inside the float16 range
             self._ranges_checked = True
             self.check_ranges(x, on_exceed='fallback')
         idx, hd = self._handle(x.device, b)
@@ -315,14 +352,14 @@ class Model:
         x = x.contiguous()
         b = x.shape[0]
         result = {}
-        for _attempt in range(2):
+        for _attempt in range(2):       # (second pass: the rebuilt plan, which must come out clean)
             idx, hd = self._handle(x.device, b)
             plan = self.plan_for(b)
             need = self.workspace_bytes(b)
-            ws = self._workspace.get(idx)
+            ws = self._workspace.get((idx, 'ranges'))      # its own arena: a step in flight on another context keeps its workspace
             if ws is None or ws.numel() < need:
                 ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
-                self._workspace[idx] = ws
+                self._workspace[(idx, 'ranges')] = ws
             ys = [torch.empty((b, ob.h, ob.w, ob.c), dtype=torch.float32, device=x.device) for ob in plan.output_bufs]
             mx = (ctypes.c_float * len(plan.ops))()
             with torch.cuda.device(idx):
@@ -338,15 +375,11 @@ class Model:
             if on_exceed == 'raise':
                 raise ValueError('activations beyond the float16 range (%.0f) enter split-form ops: %s'
                                  % (limit, ', '.join('%s (%.3g)' % (n, result[n]) for n in bad)))
-            # fallback: those ops leave the split forms; everything compiled / uploaded so far belongs to the old plan
-            self._nosplit = self._nosplit | frozenset(bad)
-            for h in self._handles.values():
-                rt.lib().yr_destroy(h)
-            self._handles, self._blobs, self._tuned = {}, {}, set()
-            fuse = self._fuse
-            self.plan = compile_graph(self.inputs[0], self.outputs, fuse, self.dtype, self._nosplit)
-            self._plans = {'throughput': self.plan}
-            self.range_fallbacks = sorted(self._nosplit)
+            # fallback: those ops leave the split forms (in every plan variant)
+            if _attempt == 1:
+                raise RuntimeError('activations beyond the float16 range still enter split-form ops after the fallback: %s'
+                                   % ', '.join('%s (%.3g)' % (n, result[n]) for n in bad))
+            self._drop_split_forms(bad)
         return result
 
     def profile(self, x, iters=5):
