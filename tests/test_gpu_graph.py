@@ -69,7 +69,7 @@ def test_logits_416_and_detections(dev):
 DECISION_NOISE = 1e-4
 
 
-def _check_detections_with_margins(ys, ref, res, hw, thr=0.2, iou=0.5):
+def _check_detections_with_margins(ys, ref, res, hw, thr=0.2, iou=0.5, num_classes=20):
     """(1) the oracle's post-processing of the GPU's own logits equals the GPU's detections bit for bit;
     (2) end to end against the oracle's logits every (image, class) NMS problem must return the SAME picks unless one
     of the oracle's decisions on that problem sat within DECISION_NOISE of a threshold - a flat
@@ -79,13 +79,13 @@ def _check_detections_with_margins(ys, ref, res, hw, thr=0.2, iou=0.5):
     flips, min_margin_all = [], np.inf
     for i in range(len(res)):
         gb, gs, gc = [t.cpu().numpy() for t in res[i]]
-        ob, os_, oc, gi = cpost.yolo_eval([y[i].cpu().numpy() for y in ys], ANCHORS, 3, 20, hw, 20, thr, iou)
+        ob, os_, oc, gi = cpost.yolo_eval([y[i].cpu().numpy() for y in ys], ANCHORS, 3, num_classes, hw, 20, thr, iou)
         assert np.array_equal(gb, ob) and np.array_equal(gs, os_) and np.array_equal(gc, oc)
-        boxes_r, scores_r = pp.decode_image([r[i] for r in ref], ANCHORS, 20, hw)
+        boxes_r, scores_r = pp.decode_image([r[i] for r in ref], ANCHORS, num_classes, hw)
         got = {}
         for c_, k_ in zip(gc.tolist(), gi.tolist()):
             got.setdefault(c_, []).append(k_)
-        for c in range(20):
+        for c in range(num_classes):
             picks, margin = pp.nms_decision_margin(boxes_r, scores_r[:, c], 20, iou, thr)
             min_margin_all = min(min_margin_all, margin)
             total += len(picks)
@@ -95,7 +95,7 @@ def _check_detections_with_margins(ys, ref, res, hw, thr=0.2, iou=0.5):
                 flips.append((i, c, margin))
     print('end-to-end detections: %d/%d picks in common; %d of %d (image, class) problems differ; smallest decision '
           'margin overall %.2e, on the differing problems %s'
-          % (agree, total, len(flips), 20 * len(res), min_margin_all, ', '.join('%.1e' % m for _, _, m in flips) or '-'))
+          % (agree, total, len(flips), num_classes * len(res), min_margin_all, ', '.join('%.1e' % m for _, _, m in flips) or '-'))
     assert total > 0
     for i, c, margin in flips:
         assert margin <= DECISION_NOISE, ('image %d class %d: picks differ although every decision of the oracle had a '
@@ -323,6 +323,64 @@ def test_full_resolution_configs(dev, name, size, b):
     for i, (y, r) in enumerate(zip(ys, ref)):
         worst = max(worst, assert_close(y.cpu().numpy().reshape(r.shape), r, 1e-4, '%s@%d y%d' % (name, size, i + 1)))
     print('%s@%d: max scaled logit error vs the torch-CPU oracle %.2e' % (name, size, worst))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The operating points the reference itself ships (code/README.md:80-93, code/main.py:79-81,171-176): MobileNetV2 x0.75 @320 on VOC
+# (C = 20) and EfficientNet-B3 @416 / @224 on COCO (C = 80: head width 255, 80 NMS problems per image, 1600-row records), evaluated in
+# MAP mode - score_threshold 0.0 (every box with a positive score is an NMS candidate) - and at the demo's 0.2.
+@pytest.mark.parametrize('name,size,classes', [('mobilenetv2x75', 320, 20), ('efficientnetb3', 416, 80), ('efficientnetb3', 224, 80)])
+def test_reference_operating_points(dev, name, size, classes):
+    from oracle import torch_ref
+    from yoloret_amd.yolo3.model import yolo_eval
+    b, hw = 2, (size, size)
+    m, P = _build(name, hw, classes)
+    x = params.synthetic_images(b, size, size)
+    ref = [np.asarray(r) for r in torch_ref.TorchReference(P, name, 3, classes)(x)]
+    m.set_weights(P.values)
+    ys = m(torch.from_numpy(x).to(dev))
+    torch.cuda.synchronize()
+    worst = 0.0
+    for i, (y, r) in enumerate(zip(ys, ref)):
+        g = size // (32 >> i)
+        assert tuple(y.shape) == (b, g, g, 3, classes + 5)
+        worst = max(worst, assert_close(y.cpu().numpy().reshape(r.shape), r, 1e-4, '%s@%d C=%d y%d' % (name, size, classes, i + 1)))
+    print('%s@%d C=%d: max scaled logit error vs the torch-CPU oracle %.2e' % (name, size, classes, worst))
+    ref5 = [r.reshape(b, r.shape[1], r.shape[2], 3, classes + 5) for r in ref]
+    for thr in (0.0, 0.2):       # MAP mode (main.py:171-176) | the demo's threshold
+        res = yolo_eval(ys, ANCHORS, 3, classes, hw, max_boxes=20, score_threshold=thr, iou_threshold=0.5)
+        assert len(res) == b
+        if thr == 0.0:           # every class has more than 20 boxes with a positive score: all classes x max_boxes rows
+            assert all(len(r[1]) == classes * 20 for r in res)
+        _check_detections_with_margins(ys, ref5, res, hw, thr=thr, num_classes=classes)
+
+
+def test_coco_width_records_packed_and_gathered(dev):
+    """C = 80 at a batch of 8: 1600 rows per image through yr_pack_detections (yolo_eval_packed) and the multi-GPU record path
+    (DetectionGatherer, one rank): the unpacked records equal the per-image lists of yolo_eval and the C oracle's, in MAP mode."""
+    from yoloret_amd.parallel import DetectionGatherer
+    from yoloret_amd.yolo3.model import yolo_eval, yolo_eval_packed, unpack_detections
+    b, hw, classes = 8, (160, 160), 80
+    m, P = _build('mobilenetv2x75', hw, classes)
+    x = params.synthetic_images(b, *hw)
+    om.yolov3_body(P, x[:1], 'mobilenetv2x75', 3, classes)
+    m.set_weights(P.values)
+    ys = m(torch.from_numpy(x).to(dev))
+    for thr in (0.0, 0.2):
+        det, cnt = yolo_eval_packed(ys, ANCHORS, 3, classes, hw, 20, thr, 0.5)
+        assert tuple(det.shape) == (b, classes * 20, 6) and tuple(cnt.shape) == (b,)
+        all_det, all_cnt = DetectionGatherer()(det, cnt)
+        res = unpack_detections(all_det, all_cnt)
+        lists = yolo_eval(ys, ANCHORS, 3, classes, hw, max_boxes=20, score_threshold=thr, iou_threshold=0.5)
+        assert len(res) == len(lists) == b
+        for i in range(b):
+            gb, gs, gc = [t.cpu().numpy() for t in res[i]]
+            lb, ls, lc = [t.cpu().numpy() for t in lists[i]]
+            ob, os_, oc, _ = cpost.yolo_eval([y[i].cpu().numpy() for y in ys], ANCHORS, 3, classes, hw, 20, thr, 0.5)
+            assert np.array_equal(gb, ob) and np.array_equal(gs, os_) and np.array_equal(gc, oc)
+            assert np.array_equal(gb, lb) and np.array_equal(gs, ls) and np.array_equal(gc, lc)
+            if thr == 0.0:
+                assert int(all_cnt[i]) == classes * 20
 
 
 def test_c2_batch64_properties(dev):
