@@ -125,12 +125,57 @@ def other_configs(dev, anchors, classes, steps, depth, budget_s=75.0):
             res[tag]['serial_fp32_frac'] = round(out[1] * fl / 1e12 / FP32_PEAK_TFLOPS, 4)
             res[tag]['fp32_roofline_img_s'] = round(FP32_PEAK_TFLOPS * 1e12 / fl, 0)
         res[tag]['fallback_ops'] = plan.fallback_ops()
+        # what the step really moves and executes: the plan's minimum traffic (every launched op's sources + output),
+        # the measured FETCH / WRITE traffic where a committed PMC pass of this configuration exists, and the multiply-adds by pipe
+        try:
+            rows = m.profile(x, iters=2)
+            moved_img = sum(r.get('hbm_bytes', r['bytes']) for r in rows) / b + n_boxes * (classes + 5) * 4 + n_boxes * (4 + classes) * 4
+            m16_img = sum(r.get('macs_mfma16', 0) for r in rows) / b
+            m32_img = sum(r.get('macs_fp32', r['macs'] - r.get('macs_mfma16', 0)) for r in rows) / b
+            pmc_img = pmc_bytes_per_image(rows, '_%s_%d_b%d_%s' % (name.replace('-', ''), size, b, dt), b)
+            for key, rate in (('', out[depth]), ('serial_', out[1])):
+                fr = {'hbm_moved_plan': rate * moved_img / 1e9 / HBM_PEAK_GBS, 'mfma16': rate * 2.0 * m16_img / 1e12 / MFMA16_PEAK_TFLOPS,
+                      'fp32_executed': rate * 2.0 * m32_img / 1e12 / FP32_PEAK_TFLOPS}
+                if pmc_img:
+                    fr['hbm_moved_pmc'] = rate * pmc_img / 1e9 / HBM_PEAK_GBS
+                res[tag][key + 'frac_hbm_moved_plan'] = round(fr['hbm_moved_plan'], 4)
+                res[tag][key + 'frac_hbm_moved_pmc'] = round(fr['hbm_moved_pmc'], 4) if pmc_img else None
+                res[tag][key + 'frac_mfma16_peak'] = round(fr['mfma16'], 4)
+                res[tag][key + 'frac_fp32_peak_executed'] = round(fr['fp32_executed'], 4)
+                res[tag][key + 'frac_executed'] = round(max(fr.values()), 4)       # the busiest resource by what is EXECUTED, not credited
+            res[tag]['moved_bytes_per_image_plan'] = int(moved_img)
+            res[tag]['moved_bytes_per_image_pmc'] = int(pmc_img) if pmc_img else None
+        except Exception as e:      # (the extra fields are diagnostics: never fail the bench line for them)
+            res[tag]['executed_fractions_error'] = str(e)[:160]
         if dt != 'f32':   # (tests/test_gpu_narrow.py, tests/test_gpu_fullbatch.py: measured against the float32 oracle on the conditioned recipe)
             res[tag]['accuracy_note'] = ('16-bit storage plan: logits are NOT within 1e-4 of the float32 reference - scaled max / mean logit error vs '
                                          'the float32 oracle and the share of its detections reproduced are in README.md (16-bit plans) and profiles/')
         del m, x, hw
         torch.cuda.empty_cache()
     return res
+
+
+def pmc_bytes_per_image(rows, tag, b):
+    """HBM bytes per image of one step from the newest committed PMC passes of a configuration (profiles/rNN_traffic<tag>.json: per kernel
+    symbol (2 x FETCH_SIZE + WRITE_SIZE) per launch, tools/rocpd_summary.py) x the launches per step of every symbol in `rows`
+    (Model.profile) - None unless every kernel of the step is covered (decode / NMS / pack are not in `rows`: the graph only)."""
+    import glob
+    try:
+        tfile = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_traffic%s.json' % tag)))[-1]
+        table = {canon_symbol(k): v for k, v in json.load(open(tfile)).items()}
+    except (IndexError, OSError, ValueError):
+        return None
+    tot = 0.0
+    for r in rows:
+        want = canon_symbol(r['kernel'])
+        t = table.get(want)
+        if t is None and want.endswith('>'):
+            hits = [v for k, v in table.items() if k.startswith(want[:-1] + ',')]
+            t = hits[0] if len(hits) == 1 else None
+        if t is None:
+            return None
+        tot += t['traffic_bytes']
+    return tot / b
 
 
 def canon_symbol(name):
@@ -199,7 +244,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(model_name, size, classes, anchors, seconds):
+def cpu_baseline(model_name, size, classes, anchors, seconds, gpu_logits=None):
     """The oracle's torch-CPU port (oneDNN) + C decode/NMS on all host cores; bounded sample.  BASELINE.md section 3: the
     throughput sample in batches of 8 (`value`, plus the median of the per-batch times, at least 5 of them) and the
     batch-1 latency the reference itself runs at (code/yolo.py:83-84): p50 over 200 runs after 20 warm-ups (fewer when
@@ -237,7 +282,29 @@ def cpu_baseline(model_name, size, classes, anchors, seconds):
         t1 = time.perf_counter()
         one(x1)
         lat.append(time.perf_counter() - t1)
-    return {'value': round(n / dt, 2), 'unit': 'img/s', 'cores': cores, 'cpu': cpu_model(), 'kind': 'port',
+    parity = None
+    if gpu_logits is not None:
+        # the checker's other job in this leg: the BENCH's own workload (SURVEY 8(d) weight recipe, which amplifies rounding noise
+        # ~1e3 x: DESIGN.md 5) is held against the oracle in float64 - the HIP path's error next to what a float32 CPU implementation
+        # (this oracle in float32) shows against the same float64 values.  The 1e-4 bar itself is enforced on the variance-preserving
+        # recipe (tests/test_gpu_graph.py); on this recipe no float32 implementation meets it against another.
+        try:
+            xs = x[:2]
+            r64 = torch_ref.TorchReference(P, model_name, 3, classes, dtype=torch.float64)(xs.astype(np.float64))
+            r32 = ref(xs)
+            g = gpu_logits(xs)
+            eg, e32 = [], []
+            for a64, a32, ag in zip(r64, r32, g):
+                den = np.maximum(1.0, np.abs(a64))
+                eg.append(np.abs(np.asarray(ag, np.float64).reshape(a64.shape) - a64) / den)
+                e32.append(np.abs(np.asarray(a32, np.float64) - a64) / den)
+            parity = {'recipe': 'survey (the bench workload)', 'images': 2,
+                      'hip_logit_err_vs_fp64': {'max': float('%.3g' % max(e.max() for e in eg)), 'mean': float('%.3g' % np.mean([e.mean() for e in eg]))},
+                      'cpu_fp32_logit_err_vs_fp64': {'max': float('%.3g' % max(e.max() for e in e32)), 'mean': float('%.3g' % np.mean([e.mean() for e in e32]))},
+                      'note': 'scaled |y - y64| / max(1, |y64|); the 1e-4 bar of north_star is enforced on the conditioned recipe (tests), where both figures are ~1e-5'}
+        except Exception as e:
+            parity = {'error': str(e)[:160]}
+    return {'value': round(n / dt, 2), 'unit': 'img/s', 'cores': cores, 'cpu': cpu_model(), 'kind': 'port', 'workload_parity': parity,
             'median_ms_b8': round(float(np.median(per_batch)) * 1e3, 2), 'runs_b8': len(per_batch),
             'p50_ms_b1': round(float(np.median(lat)) * 1e3, 2), 'runs_b1': len(lat),
             'sample': '%d images (batches of %d) of the same %s@%d workload through oracle/torch_ref.py '
@@ -777,8 +844,13 @@ def main():
             out['other_configs'] = other_configs(dev, anchors, a.classes, max(a.steps, 20), a.depth)
         if world == 1 and a.dtype == 'f32' and not a.no_fp32_forms and not a.force_dist:
             out['fp32_mfma_forms'] = fp32_mfma_forms(a)
+            # for a strict reader of `dtype: f32`: the headline's 1x1 convolutions run as three float16-plane products (22 bits per factor,
+            # float32-grade: DESIGN.md 4-5); with every GEMM on v_mfma_f32_16x16x4_f32 instead the same step gives
+            out['value_strict_fp32'] = out['fp32_mfma_forms'].get('img_s')
+            out['serial_strict_fp32'] = out['fp32_mfma_forms'].get('serial_img_s')
         if world == 1 and not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(a.model, a.size, a.classes, anchors, a.cpu_seconds)
+            out['cpu_baseline'] = cpu_baseline(a.model, a.size, a.classes, anchors, a.cpu_seconds,
+                                               gpu_logits=(lambda xs: [y.cpu().numpy() for y in model(torch.from_numpy(np.ascontiguousarray(xs)).to(dev))]) if a.dtype == 'f32' else None)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,4 +1,4 @@
-"""Debug aid: rebuild ONE object with extra flags and relink (python tools/_relink.py elementwise.hip -DX)."""
+"""Debug aid: rebuild ONE object with extra flags and relink (python tools/relink.py elementwise.hip -DX)."""
 import subprocess, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yoloret_amd import build as B
