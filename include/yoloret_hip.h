@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define YR_ABI_VERSION 7   /* 7: squeeze-excite finished by its producer (yr_op.gate_out / se_w / se_hidden / sync: the "SE tail"), op kind HEAD (gathered 1x1 conv -> depthwise 3x3 -> SE of a detection-head block in one launch), yr_workspace_bytes includes the arrival counters; 6: split forms - k bit 7 of MBR / MBE (float16-plane fragments), se_reduced bit 16 of a float32 POINTWISE op (= keep the float32 MFMA); float32 POINTWISE ops at least 16 channels deep otherwise run on the 16-bit matrix pipe with two float16 planes per operand (pointwise_split.hip; same results to float32 rounding, |x|, |w| < 65504); 5: op kinds MBR / MBE (float32 blocks on the matrix pipe, register-chained), MBCONV removed; 4: YR_U8 images (uint8 network entry); 3: op kind MBX, pair-packed STEM weights, BN scale folded into the packed taps of STEMBLOCK / MBLANE */
+#define YR_ABI_VERSION 8   /* 8: YR_OP_MBR k bit 6 = the weight-streaming form of the fused block (mbk.hip; plans of ABI 7 run unchanged - only the version word of a serialised plan differs); 7: squeeze-excite finished by its producer (yr_op.gate_out / se_w / se_hidden / sync: the "SE tail"), op kind HEAD (gathered 1x1 conv -> depthwise 3x3 -> SE of a detection-head block in one launch), yr_workspace_bytes includes the arrival counters; 6: split forms - k bit 7 of MBR / MBE (float16-plane fragments), se_reduced bit 16 of a float32 POINTWISE op (= keep the float32 MFMA); float32 POINTWISE ops at least 16 channels deep otherwise run on the 16-bit matrix pipe with two float16 planes per operand (pointwise_split.hip; same results to float32 rounding, |x|, |w| < 65504); 5: op kinds MBR / MBE (float32 blocks on the matrix pipe, register-chained), MBCONV removed; 4: YR_U8 images (uint8 network entry); 3: op kind MBX, pair-packed STEM weights, BN scale folded into the packed taps of STEMBLOCK / MBLANE */
 #define YR_MAX_SRC 4
 
 typedef enum {
@@ -169,6 +169,20 @@ typedef enum {
                                    waves in order (a wave pairs ITS tiles, an odd last one with nothing), [TO][2 planes][64][8]:
                                    Wp[16 t + m][16 tA + 4 g + i] (i < 4) | Wp[16 t + m][16 tB + 4 g + i - 4]; nw must be what the fragments were
                                    packed for (yoloret_amd.compiler.mbs_pack).  Precondition: |block input| < 65504 (undefined beyond: NaN or a ReLU6-clamped value).
+                            k bits 6 AND 7 (0xc0) = the WEIGHT-STREAMING form (ABI 8; mbk.hip): the same block in ONE launch where the fragments of both
+                            convolutions do not fit a CU's register file (MobileNetV2 x0.75 block_7..15, reference [3P] via code/yolo3/override.py:290-341).
+                            The pixels are stationary - a wave owns `rows` (1 | 2) input rows of a 16-column strip and the projection accumulators of
+                            its output rows for the whole kernel - and the weights stream through LDS one pair of expanded tiles at a time (LDS-direct
+                            buffer loads, three chunk buffers); the neighbour rows of the vertical taps are exchanged between waves through LDS, one
+                            barrier per pair.  k = 3 | 0xc0 | nw << 8 | rows << 16 (both fixed by the plan: nothing is tuned, the sums are grouped by
+                            the shape alone); wgt2 unused;
+                            wgt  = ceil(T / 2) chunks of (4 ceil(cin / 32) + 2 TO) KB + 2 KB: chunk q = pair (2 q, 2 q + 1) =
+                                   [2 tiles][ceil(cin / 32)][2 planes][64 lanes][8 halves] expand fragments (as above) |
+                                   [TO][2 planes][64][8] project fragments of the pair (Wp[16 t + m][16 (2 q) + 4 g + i] (i < 4) | [16 (2 q + 1) + 4 g + i - 4]) |
+                                   [2 tiles][11][16] float32: taps x depthwise BN scale | depthwise BN shift | expand BN shift | zeros up to 2 KB
+                                   (an odd T: the second tile of the last pair is all zeros) - yoloret_amd.compiler.mbk_pack;
+                            b2   = project BN shift [16 TO].  Same precondition as the split form.  Built for (cin, Cexp, cout, stride, rows, nw) in
+                            mbk.hip's MBK_CASE list.
                             Built for the MobileNetV2 x0.75 / x1.4 blocks (mbr.hip: MBR_CASE / MBS_CASE lists); other shapes: YR_ERR_ARG */
     YR_OP_MBE = 14,      /* the first two thirds of the MBCONV block in float32 - expand 1x1 + BN + ReLU6 -> depthwise 3x3 (stride 1 | 2) +
                             BN + ReLU6 - in YR_OP_MBR's register-chained form (mbr.hip: mbe_kernel), for blocks whose weights do not fit

@@ -260,7 +260,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
         assert hasattr(L, sym), 'libyoloret_hip.so does not export %s' % sym
     assert declared == set(rt.EXPORTS)
     L.yr_abi_version.restype = ctypes.c_int
-    assert L.yr_abi_version() == 7 == rt.ABI_VERSION
+    assert L.yr_abi_version() == 8 == rt.ABI_VERSION
     # struct layouts agree with the header's (the library reports its own sizeof)
     for which, st in enumerate((rt.YrSrc, rt.YrOp, rt.YrBuf)):
         assert L.yr_abi_sizeof(which) == ctypes.sizeof(st), st.__name__

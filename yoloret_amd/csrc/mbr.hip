@@ -28,7 +28,7 @@
 
 #include "mbr_common.h"
 
-// (experiment, tools/_relink.py mbr.hip -DMBR_EXP_ONE_TAP: every tap of the stride-1 block kernel reads the SAME table entry - wrong
+// (experiment, tools/relink.py mbr.hip -DMBR_EXP_ONE_TAP: every tap of the stride-1 block kernel reads the SAME table entry - wrong
 //  results, one LDS read per tile and row instead of ten: what the tap reads cost)
 #ifdef MBR_EXP_ONE_TAP
 #define MBR_TB(i) tb[0]

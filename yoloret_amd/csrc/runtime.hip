@@ -430,8 +430,10 @@ static int check_forward_args(yr_handle* h, const float* images, int batch, void
 // every pass all the same: one 4 * n_sync * batch byte fill on the stream.
 static int clear_sync(const yr_handle* h, int batch, void* workspace, hipStream_t s) {
     if (h->n_sync == 0) return YR_OK;
-    static const bool skip = getenv("YR_NO_SYNC_CLEAR") != nullptr;   // (debugging)
+#ifdef YR_DEBUG_HOOKS      // (python tools/relink.py runtime.hip -DYR_DEBUG_HOOKS: never in the shipped library)
+    static const bool skip = getenv("YR_NO_SYNC_CLEAR") != nullptr;
     if (skip) return YR_OK;
+#endif
     YR_CHECK_HIP(hipMemsetAsync(static_cast<char*>(workspace) + yr_sync_offset(h, batch), 0, (size_t)h->n_sync * (size_t)batch * sizeof(uint32_t), s));
     return YR_OK;
 }
@@ -452,12 +454,16 @@ extern "C" int yr_forward(yr_handle* h, const float* images, int batch, float* y
     hipStream_t s = (hipStream_t)stream;
     rc = clear_sync(h, batch, workspace, s);
     if (rc) return rc;
-    static const char* only = getenv("YR_ONLY_OPS");   // debugging (tools/sefc_probe2.py): "lo-hi" launches just those ops of the plan
+#ifdef YR_DEBUG_HOOKS      // YR_ONLY_OPS="lo-hi" launches just those ops of the plan (tools/sefc_probe2.py); a malformed value is refused
+    static const char* only = getenv("YR_ONLY_OPS");
     static int lo = 0, hi = 1 << 30;
-    static const bool parsed = only && sscanf(only, "%d-%d", &lo, &hi) == 2;
-    (void)parsed;
+    static const bool parsed = !only || (sscanf(only, "%d-%d", &lo, &hi) == 2 && lo >= 0 && hi >= lo);
+    YR_REQUIRE(parsed, "YR_ONLY_OPS=%s: want lo-hi", only);
+#endif
     for (size_t i = 0; i < h->ops.size(); ++i) {
+#ifdef YR_DEBUG_HOOKS
         if ((int)i < lo || (int)i > hi) continue;
+#endif
         yr_op op;
         rc = resolve_op(h, i, batch, ext, static_cast<char*>(workspace), &op);
         if (rc == YR_OK) rc = dispatch(op, batch, s);

@@ -240,7 +240,7 @@ class Model:
         wkey = idx if ctx == 0 else (idx, ctx)
         ws = self._workspace.get(wkey)
         if ws is None or ws.numel() < need:
-            ws = (torch.zeros if os.environ.get('YR_NO_SYNC_CLEAR') else torch.empty)(max(need, 16), dtype=torch.uint8, device=x.device)
+            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
             self._workspace[wkey] = ws
         ys = out
         if ys is None:
