@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # The parity tests run batches of 1-2 images and are meant to exercise the fused (throughput) plan; the small-batch
 # plan has its own tests (tests/test_gpu_graph.py::test_small_batch_plan, test_host_logic.py::test_plan_variants).
 os.environ.setdefault('YOLORET_SMALL_BATCH', '0')
+# ... and (round 6) on the throughput plan WITH its weight-streaming block form, which a float32 model otherwise runs from 24 images on
+# ('mid' below: tests/test_gpu_graph.py::test_small_batch_plan_of_float32_models)
+os.environ.setdefault('YOLORET_MBK_BATCH', '0')
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

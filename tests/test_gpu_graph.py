@@ -256,7 +256,7 @@ def test_small_batch_plan_of_float32_models(dev):
     small = [y.cpu().numpy() for y in m(xt[:3])]
     big = [y.cpu().numpy() for y in m(xt)]
     k_small, k_big = [o.kind for o in m.plan_for(3).ops], [o.kind for o in m.plan_for(6).ops]
-    assert rt.OP_HEAD not in k_small and k_big.count(rt.OP_HEAD) == 6 and k_small.count(rt.OP_MBR) == k_big.count(rt.OP_MBR) > 0
+    assert rt.OP_HEAD not in k_small and k_big.count(rt.OP_HEAD) == 6 and k_small.count(rt.OP_MBR) + k_small.count(rt.OP_MBE) == k_big.count(rt.OP_MBR) == 15
     for i, r in enumerate(ref):
         assert_close(small[i], r[:3], 1e-4, 'nohead plan, output %d' % i)
         assert_close(big[i], r, 1e-4, 'throughput plan, output %d' % i)
@@ -264,6 +264,14 @@ def test_small_batch_plan_of_float32_models(dev):
     # variant still equals its images run one by one, bit for bit)
     # batches of one or two images ('nohead_k'): its small maps run the k-split form of the split pointwise kernel (se_reduced bit 17; a
     # property of the plan, so a batch of the variant still equals its images run one by one, bit for bit)
+    # batches between the few-image plans and Model.mbk_batch ('mid'): the throughput plan without the weight-streaming block form
+    m.mbk_batch = 6
+    assert m.variant(5) == 'mid' and m.variant(6) == 'throughput'
+    mid = [y.cpu().numpy() for y in m(xt[:5])]
+    k6 = lambda b_: sum(1 for o in m.plan_for(b_).ops if o.kind == rt.OP_MBR and o.k & 0x40)
+    assert k6(5) == 0 and k6(6) == 9 and [o.kind for o in m.plan_for(5).ops].count(rt.OP_HEAD) == 6 and all(k6(b_) == 0 for b_ in (1, 3))
+    for i, r in enumerate(ref):
+        assert_close(mid[i], r[:5], 1e-4, 'mid plan, output %d' % i)
     flagged = [o.name for o in m.plan_for(2).ops if o.kind == rt.OP_POINTWISE and o.se_reduced & 0x20000]
     assert flagged and not any(o.se_reduced & 0x20000 for b_ in (3, 6) for o in m.plan_for(b_).ops if o.kind == rt.OP_POINTWISE)
     ran = dict((r['name'], r['kernel']) for r in m.profile(xt[:2], iters=1))

@@ -21,7 +21,7 @@ L.set_global_policy('float32')
 m.set_weights(W.synthetic_weights(m, 1234, 'survey'))
 pipe = DetectionPipeline(m, get_anchors('model_data/yolo_anchors.txt'), 20, score_threshold=0.2, iou_threshold=0.5, max_boxes=20)
 out = []
-for b in (1, 2, 4, 8):
+for b in [int(v) for v in os.environ.get("LAT_BATCHES", "1,2,4,8").split(",")]:
     x = torch.from_numpy(W.synthetic_images(b, size, size)).to(dev)
     shape = torch.tensor([[size, size]] * b, dtype=torch.int32, device=dev)
     for _ in range(30):

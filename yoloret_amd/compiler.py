@@ -1197,7 +1197,7 @@ def mbk_segs(stride, h, pad_t, nw, rows):
         s += 1
 
 
-def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None, nosplit=frozenset()):
+def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None, nosplit=frozenset(), mbk=True):
     """Peephole over the lowered op list: [POINTWISE expand+act ->] DEPTHWISE 3x3+act -> POINTWISE
     project (+residual == block input) becomes one MBCONV op whose expanded tensors never reach HBM.
     blocks=False (the small-batch plan) keeps only the network-entry fusion (stem + first block).
@@ -1370,7 +1370,7 @@ def fuse_inverted_residuals(ops, output_buf_ids, blocks=True, dtype=0, bufs=None
             p, bi = ops[j + 1], exp.srcs[0]
             key = (bi.c, d.cin, p.cout if p.kind == rt.OP_POINTWISE else 0, d.stride, p.res is not None)
             bname = exp.name.rsplit('_', 1)[0]
-            if (FUSE_MBK and MBR_SPLIT and key in MBK_SHAPES and bname + '_mbr' not in nosplit and p.kind == rt.OP_POINTWISE and plain1(p)
+            if (FUSE_MBK and mbk and MBR_SPLIT and key in MBK_SHAPES and bname + '_mbr' not in nosplit and p.kind == rt.OP_POINTWISE and plain1(p)
                     and p.srcs[0].buf is d.out and p.act == 'none' and 'scale' in p.params and bi.xform == 'identity'
                     and bi.buf.ld % 4 == 0 and p.out.ld % 4 == 0 and bi.buf.dtype == 0 and p.out.dtype == 0
                     and (p.res is None or (p.res is bi.buf and d.stride == 1 and p.cout == bi.c))):
@@ -1804,7 +1804,12 @@ class Compiler:
                 ops = merge_se_mean(ops, only_after_depthwise=latency)
                 if SE_PARTIALS:
                     ops = se_partials_from_depthwise(ops, self.bufs)
-            ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency, dtype=self.dtype, bufs=self.bufs, nosplit=self.nosplit)
+            # fuse == 'mid': the throughput plan WITHOUT the weight-streaming block form, for the batches between the few-image plans and
+            # Model.mbk_batch.  That form is one workgroup per CU whose lifetime is a chain of tile pairs - as long at 8 images as at 64 -;
+            # the forms it replaced cut a small batch into more, shorter workgroups (tools/lat_sweep.py, p50 of a step in ms with / without
+            # it: 8 images 0.826 / 0.745, 16: 0.925 / 0.896, 32: 1.293 / 1.338).  The few-image plans ('nohead', 'nohead_k') do not take it either.
+            ops = fuse_inverted_residuals(ops, set(b.id for b in outs), blocks=not latency, dtype=self.dtype, bufs=self.bufs, nosplit=self.nosplit,
+                                          mbk=self.fuse is True)
             # fuse == 'nohead': the float32 plan for a few images - the throughput plan without YR_OP_HEAD (a head block's conv + depthwise
             # in one launch is one long chain per workgroup: at batch 1 td1 takes 43 us against 18 + 11 for its two launches;
             # tools/lat_variants.sh, round 5: p50 @416 batch 1 / 2 / 4 / 8 = 0.606 / 0.622 / 0.666 / 0.767 ms against 0.648 / 0.656 / 0.687 / 0.766)

@@ -55,6 +55,10 @@ class Model:
         # MobileNetV2 x0.75 @416 batch 1 / 2 / 4: 0.478 / 0.515 / 0.612 against 0.553 / 0.572 / 0.624; x1.4 @512: 0.615 / 0.750 / 1.053
         # against 0.714 / 0.776 / 0.946 - at four images the wide model's 16 x 16 tiles re-fetch more than the shorter chains save)
         self.ksplit_batch = int(os.environ.get('YOLORET_KSPLIT_BATCH', '2'))
+        # (round 6: float32 plans run batches below mbk_batch on 'mid' - the throughput plan without the weight-streaming block form
+        # (compiler.py: a one-workgroup-per-CU chain that is as long at 8 images as at 64); tools/lat_sweep.py: p50 at 8 / 16 / 32 images
+        # 0.745 / 0.896 / 1.338 ms without the form, 0.826 / 0.925 / 1.293 with it)
+        self.mbk_batch = int(os.environ.get('YOLORET_MBK_BATCH', '24')) if (fuse is True and self.dtype == 0) else 0
         self._plans = {'throughput': self.plan}
         self._weights = None
         self._blobs = {}
@@ -140,11 +144,12 @@ class Model:
 
     # ------------------------------------------------------------------ execution
     def variant(self, batch):
-        """Which plan a batch of this size runs: up to small_batch images `small_variant` - 'latency' (no block fusion: 16-bit plans) or
+        """Which plan a batch of this size runs: from mbk_batch images on 'throughput', below it 'mid' (float32 plans: the same without the
+        weight-streaming block form); up to small_batch images `small_variant` - 'latency' (no block fusion: 16-bit plans) or
         'nohead' (the throughput plan without YR_OP_HEAD: float32 plans; 'nohead_k' up to ksplit_batch images: its small maps' pointwise
         convs in the k-split form)."""
         if not 0 < batch <= self.small_batch:
-            return 'throughput'
+            return 'mid' if 0 < batch < self.mbk_batch else 'throughput'
         if self.small_variant == 'nohead' and batch <= self.ksplit_batch:
             return 'nohead_k'
         return self.small_variant
