@@ -211,6 +211,12 @@ typedef enum {
                             activation ReLU6 / none): wgt = the planes of bit 7 WITH the conv's BN scale folded in, scale = that BN scale [F],
                             shift unused, wgt2 = [F / 16][11][16]: depthwise taps x BN scale | depthwise BN shift | conv BN shift (YR_OP_MBR's
                             table); se_reduced = yr_head_walk_rows(h, w).
+                            k bits 5 AND 6 (0x60; ABI 8): the WEIGHT-STREAMING form (headstream.hip; float32 plans): the pixels of a wave's one or two
+                            rows of a 16-column strip stay in registers over the whole k space (gathered once: identity or 2 x 2 max-pooled
+                            sources, the single source's SE gate), the conv's output channels stream past them in pairs of tiles through LDS.
+                            Parameters exactly as bit 6 alone; one to three k-space sources (YR_X_IDENTITY | YR_X_MAXPOOL2) + an optional
+                            YR_X_UP2_ADD last; at most 11 chunks of 32 channels on maps below 20 rows, 7 otherwise; F % 32 == 0; no SE tail;
+                            se_reduced = yr_head_stream_rows(h, w) (one row of sums per strip, row segment and wave).
                             16-BIT PLANS (dtype = out_dtype = bf16 | f16; headwalk_h.hip): the walking form only (k bit 6) - identity sources
                             of the op's type (ld % 8 == 0), optionally a float32 YR_X_UP2_ADD last source, at most 8 chunks of 32 channels,
                             F % 128 == 0; wgt = the conv's 16-bit weights in fragment order [F / 16][NK][64 lanes][8] WITHOUT the BN scale
@@ -361,6 +367,8 @@ int yr_op_run(const yr_op* op, int batch, void* stream);
 int yr_head_regions(int h, int w, int32_t* nsy, int32_t* nsx);
 /* ... and of the WALKING form of YR_OP_HEAD (k bit 6): rows = strips of 14 columns x row segments (its se_reduced). */
 int yr_head_walk_rows(int h, int w, int32_t* rows);
+/* ... and of its WEIGHT-STREAMING form (k bits 5 and 6): rows = strips x row segments x waves per workgroup. */
+int yr_head_stream_rows(int h, int w, int32_t* rows);
 
 /* ---- preprocessing (the step before the path): decoded uint8 [ih,iw,3] image (device) ->
  * letterboxed float32 [H,W,3] network input.  Replaces tf.io.decode_image(dtype=float32)'s /255

@@ -54,6 +54,13 @@ def walk_ok(segs, f, pre, gated, conv_act):
             and conv_act in ('relu6', 'none') and not (gated and pre))
 
 
+def stream_ok(h, segs, f, pre, gated, conv_act):
+    """compiler.fuse_head_blocks' rule for the weight-streaming form (headstream.hip)"""
+    nk = sum((c + 31) // 32 for c, _ in segs)
+    return (all(xf in ('identity', 'maxpool2') for _, xf in segs) and len(segs) <= 3 and f % 32 == 0 and nk <= (7 if h >= 20 else 11)
+            and conv_act in ('relu6', 'none') and not (gated and (len(segs) != 1 or segs[0][1] != 'identity')))
+
+
 def se_gate_ref(y, w1, b1, w2, b2):
     mean = nn.mean_hw(y.astype(np.float64)).astype(np.float64)
     hid = mean @ w1.astype(np.float64) + b1
@@ -114,11 +121,11 @@ def run_head(dev, rng, b, h, w, segs, f, pre=False, gated=False, se=None, conv_a
     op.h, op.w, op.cin, op.cout, op.stride = h, w, cin, f, 1
     if form is None:
         form = 'walk' if walk_ok(segs, f, pre, gated, conv_act) else 'dma' if all(xf in ('identity', 'up2') for _, xf in segs) and len(segs) <= 3 else 'pws'
-    op.k = 3 | rt.ACT[conv_act] << 8 | cfg << 16 | {'walk': 0x40, 'dma': 0x80, 'pws': 0}[form]
+    op.k = 3 | rt.ACT[conv_act] << 8 | cfg << 16 | {'walk': 0x40, 'stream': 0x60, 'dma': 0x80, 'pws': 0}[form]
     from yoloret_amd.compiler import head_pack
     if form == 'dma':
         wt = head_pack(wt, [c for c, _ in segs])
-    elif form == 'walk':      # planes with the conv's BN scale folded in; YR_OP_MBR's tap table [T][11][16]
+    elif form in ('walk', 'stream'):      # planes with the conv's BN scale folded in; YR_OP_MBR's tap table [T][11][16]
         wt = head_pack((wt * cs[:, None]).astype(np.float32), [c for c, _ in segs])
         t16 = f // 16
         tab = np.zeros((t16, 11, 16), np.float32)
@@ -145,7 +152,11 @@ def run_head(dev, rng, b, h, w, segs, f, pre=False, gated=False, se=None, conv_a
     sums = gate_out = None
     if se is not None:
         nsy, nsx = ctypes.c_int32(), ctypes.c_int32(1)
-        if form == 'walk':
+        if form == 'stream':
+            rt.check(rt.lib().yr_head_stream_rows(h, w, ctypes.byref(nsy)))
+            from yoloret_amd.compiler import head_stream_rows
+            assert nsy.value == head_stream_rows(h, w)
+        elif form == 'walk':
             rt.check(rt.lib().yr_head_walk_rows(h, w, ctypes.byref(nsy)))
         else:
             rt.check(rt.lib().yr_head_regions(h, w, ctypes.byref(nsy), ctypes.byref(nsx)))
@@ -197,17 +208,41 @@ HEAD_CASES = [
 ]
 
 
-@pytest.mark.parametrize('form', ['walk', 'dma', 'pws'])
+@pytest.mark.parametrize('form', ['stream', 'walk', 'dma', 'pws'])
 @pytest.mark.parametrize('case', HEAD_CASES, ids=[str(i) for i in range(len(HEAD_CASES))])
 def test_head_block(dev, case, form):
-    """every case in every form that takes it (the compiler picks walk > dma > pws)"""
+    """every case in every form that takes it (the compiler picks stream > walk > dma > pws)"""
     h, w, segs, f, pre, gated, r = case
+    if form == 'stream' and not stream_ok(h, segs, f, pre, gated, 'relu6'):
+        pytest.skip('shape not built in the weight-streaming form')
     if form == 'walk' and not walk_ok(segs, f, pre, gated, 'relu6'):
         pytest.skip('shape not built in the walking form')
     if form == 'dma' and not (all(xf in ('identity', 'up2') for _, xf in segs) and len(segs) <= 3):
         pytest.skip('pooled sources stay on the register-staged form')
     rng = np.random.default_rng(zlib.crc32(str(case).encode()))
-    run_head(dev, rng, 3, h, w, segs, f, pre=pre, gated=gated, se=r, form=form)
+    run_head(dev, rng, 3, h, w, segs, f, pre=pre, gated=gated, se=r, form=form, tail=form != 'stream')
+
+
+def test_head_stream_form_variants_and_batch_independence(dev):
+    """The weight-streaming form: no squeeze-excite sums at all, ReLU6 / no activation, a conv without activation, a pooled source
+    beside two identity ones, 11 chunks at one row per wave; an image of a batch equals the image run alone (map and sums)."""
+    rng = np.random.default_rng(7)
+    run_head(dev, rng, 2, 13, 13, [(120, 'identity')], 96, se=None, dw_act='relu6', form='stream')
+    run_head(dev, rng, 2, 26, 26, [(72, 'identity'), (96, 'identity')], 256, pre=True, se=64, tail=False, conv_act='none', dw_act='none', form='stream')
+    run_head(dev, rng, 2, 19, 33, [(40, 'identity'), (75, 'identity'), (64, 'maxpool2')], 64, se=16, tail=False, form='stream')
+    run_head(dev, rng, 2, 13, 13, [(256, 'identity'), (96, 'identity')], 512, se=128, tail=False, form='stream')     # 11 chunks
+    run_head(dev, rng, 3, 45, 61, [(128, 'identity')], 128, gated=True, se=32, tail=False, form='stream')             # odd size, many strips / segments
+    # tiny maps (a 64 x 64 input): fewer rows than waves, fewer columns than a strip
+    run_head(dev, rng, 3, 8, 8, [(24, 'identity')], 128, pre=True, se=32, tail=False, form='stream')
+    run_head(dev, rng, 3, 4, 4, [(72, 'identity'), (96, 'identity')], 256, pre=True, se=64, tail=False, form='stream')
+    run_head(dev, rng, 3, 2, 2, [(120, 'identity'), (96, 'maxpool2')], 512, se=128, tail=False, form='stream')
+    run_head(dev, rng, 3, 2, 2, [(256, 'identity'), (75, 'identity')], 512, se=128, tail=False, form='stream')
+    for case in [(52, 52, [(24, 'identity')], 128, True, 32), (13, 13, [(120, 'identity'), (96, 'maxpool2')], 512, False, 128)]:
+        h, w, segs, f, pre, r = case
+        one, _ = run_head(dev, np.random.default_rng(12), 1, h, w, segs, f, pre=pre, se=r, tail=False, form='stream')
+        many, _ = run_head(dev, np.random.default_rng(12), 5, h, w, segs, f, pre=pre, se=r, tail=False, tile=True, form='stream')
+        for i in range(5):
+            assert np.array_equal(many[i], one[0]), 'image %d of the batch differs from the image run alone' % i
 
 
 def test_head_block_variants(dev):

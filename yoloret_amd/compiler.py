@@ -800,6 +800,27 @@ SE_TAIL_LDS = 4608 - 1024 - 4      # == YR_SE_TAIL_LDS - 4 * 256 threads (se_tai
 HEAD_WALK_MAX_NK = min(7, int(os.environ.get('YOLORET_HEAD_WALK_MAX_NK', '4')))   # (measured, MobileNetV2 x0.75 @416 batch 64: 1 chunk 52 us against the LDS-direct kernel's 95, 4 chunks 96 | 124, 6 chunks 85 | 82, 7 chunks 96 | 84: one tile per wave and 250 registers from 5 chunks on)
 HEAD_WALK = os.environ.get('YOLORET_HEAD_WALK', '1') != '0'   # head blocks of at most 7 chunks of 32 identity-source channels on the walking kernel (headwalk.hip)
 HEAD_DMA = os.environ.get('YOLORET_HEAD_DMA', '1') != '0'   # head blocks without a pooled source on the LDS-direct kernel
+# Round 6: the WEIGHT-STREAMING form of YR_OP_HEAD (headstream.hip, k bits 5 and 6; mbk.hip's formulation - the pixels of a wave's one or
+# two rows stationary over the whole k space, the conv's output channels streaming past them in pairs of tiles): identity and 2 x 2
+# max-pooled sources (gathered once), up to 11 chunks of 32 channels at one row per wave (maps below 20 rows), 7 at two.
+# YOLORET_HEAD_STREAM=0 switches it off, a comma list of block names ('td2,bu2') restricts it.
+_hs = os.environ.get('YOLORET_HEAD_STREAM', '1')
+HEAD_STREAM = _hs != '0'
+HEAD_STREAM_ONLY = [b for b in _hs.split(',') if b and b not in ('0', '1')]
+
+
+def head_stream_geometry(h, w):
+    """== hs_geometry (headstream.hip): (rows per wave, waves per workgroup, strips, row segments) of the weight-streaming head form."""
+    rpw = 2 if h >= 20 else 1
+    nw = 8
+    nr = nw * rpw
+    return rpw, nw, (w + 13) // 14, 1 if h <= nr else (h - nr + nr - 3) // (nr - 2) + 1
+
+
+def head_stream_rows(h, w):
+    """== yr_head_stream_rows: rows of squeeze-excite sums that form writes per image - one per (strip, segment, wave)."""
+    rpw, nw, strips, segs = head_stream_geometry(h, w)
+    return strips * segs * nw
 
 
 def head_regions(h, w):
@@ -935,7 +956,7 @@ def _head_block16(c, d, readers, output_buf_ids):
 HEAD_WALK16_MAX_NK = min(8, int(os.environ.get('YOLORET_HEAD_WALK16_MAX_NK', '2')))
 
 
-def fuse_head_blocks(ops, bufs, output_buf_ids, nosplit=frozenset()):
+def fuse_head_blocks(ops, bufs, output_buf_ids, nosplit=frozenset(), stream_ok=True):
     readers = {}
     for op in ops:
         for s_ in op.srcs:
@@ -983,11 +1004,23 @@ def fuse_head_blocks(ops, bufs, output_buf_ids, nosplit=frozenset()):
         kseg = [s_.c for s_ in c.srcs if s_.xform != 'up2_add']
         nk = sum((c_ + 31) // 32 for c_ in kseg)
         nt = 2 if nk <= 4 else 1
-        walk = (HEAD_WALK and all(s_.xform in ('identity', 'up2_add') for s_ in c.srcs) and len(kseg) <= 3 and nk <= HEAD_WALK_MAX_NK and F % 16 == 0 and (F // 16 // nt) % 4 == 0
+        bname_h = c.name.rsplit('_', 1)[0]
+        ksrc = [s_ for s_ in c.srcs if s_.xform != 'up2_add']
+        # ... where it measured ahead (MobileNetV2 x0.75 @416, 64 images, us, streaming | before): the 26 x 26 heads - td2 48 | 69, bu2 46 | 73 -; not the
+        # 13 x 13 ones (two workgroups per image on half the chip: td1 50 | 51, bu1 56 | 37) nor the 52 x 52 ones (four generations of
+        # workgroups, each with its prologue: td3 64 | 42, bu3 103 | 81).  YOLORET_HEAD_STREAM=<names> forces it for the named blocks.
+        hs_shape = HEAD_STREAM_ONLY or (20 <= d.h <= 30 and d.w <= 28 and nk >= 5)
+        stream = (HEAD_STREAM and stream_ok and hs_shape and not SE_TAIL and (not HEAD_STREAM_ONLY or bname_h in HEAD_STREAM_ONLY)      # (the opt-in SE tail lives in the older forms) and all(s_.xform in ('identity', 'maxpool2', 'up2_add') for s_ in c.srcs)
+                  and all(s_.xform != 'up2_add' for s_ in c.srcs[:-1]) and 1 <= len(ksrc) <= 3 and F % 32 == 0 and c.act in ('relu6', 'none')
+                  and nk <= (7 if head_stream_geometry(d.h, d.w)[0] == 2 else 11) and not (c.gate is not None and (len(ksrc) != 1 or ksrc[0].xform != 'identity'))
+                  and all(s_.buf.ld % 4 == 0 for s_ in ksrc)
+                  and 4 * nk * 2048 + 2 * 10 * (2 if d.h >= 20 else 1) * 2048 + F * 11 * 4 + F * 4 <= 160 * 1024)
+        walk = (not stream and HEAD_WALK and all(s_.xform in ('identity', 'up2_add') for s_ in c.srcs) and len(kseg) <= 3 and nk <= HEAD_WALK_MAX_NK and F % 16 == 0 and (F // 16 // nt) % 4 == 0
                 and F // 16 % nt == 0 and c.act in ('relu6', 'none') and not (c.gate is not None and len(kseg) != len(c.srcs)) and F * 11 * 4 <= 64 * 1024)
-        if walk:
-            # the walking form (headwalk.hip, k bit 6): weights as float16 planes with the conv's BN scale folded in, YR_OP_MBR's tap table
-            m.k |= 0x40
+        if walk or stream:
+            # the walking form (headwalk.hip, k bit 6) / the weight-streaming form (headstream.hip, k bits 5 and 6): weights as float16
+            # planes with the conv's BN scale folded in, YR_OP_MBR's tap table
+            m.k |= 0x60 if stream else 0x40
             cp = c.params
 
             def planes(wd, cp=cp, kseg=kseg, F=F):
@@ -1010,10 +1043,10 @@ def fuse_head_blocks(ops, bufs, output_buf_ids, nosplit=frozenset()):
             o[:9, :F] = (dp['wgt'][1](wd).reshape(9, -1)[:, :F] * dp['scale'][1](wd)[None, :F]).astype(np.float32)
             o[9, :F] = dp['shift'][1](wd)[:F]
             return o
-        if not walk:
+        if not (walk or stream):
             m.params['wgt2'] = ((10, ldf), dw_rows)
         if d.gate is not None:     # the squeeze-excite sums: one row per region (per strip and row segment in the walking form)
-            nsy, nsx = (head_walk_rows(d.h, d.w), 1) if walk else head_regions(d.h, d.w)
+            nsy, nsx = (head_stream_rows(d.h, d.w), 1) if stream else (head_walk_rows(d.h, d.w), 1) if walk else head_regions(d.h, d.w)
             part = d.gate
             part.h, part.w = nsy * nsx, 1
             part.elems = part.h * part.w * part.ld
@@ -1035,6 +1068,8 @@ def se_tail_into_producers(ops):
             continue
         P = producer_of_sums.get(id(fc.srcs[0].buf))
         if P is None or P.gate_out is not None or fc.out.external_slot >= 0:
+            continue
+        if P.kind == rt.OP_HEAD and (P.k & 0x60) == 0x60:      # (the weight-streaming head form has no tail: its waves never meet)
             continue
         C, R = fc.cin, fc.se_reduced
         ldc = round_up(C, 4)
@@ -1814,7 +1849,7 @@ class Compiler:
             # in one launch is one long chain per workgroup: at batch 1 td1 takes 43 us against 18 + 11 for its two launches;
             # tools/lat_variants.sh, round 5: p50 @416 batch 1 / 2 / 4 / 8 = 0.606 / 0.622 / 0.666 / 0.767 ms against 0.648 / 0.656 / 0.687 / 0.766)
             if FUSE_HEAD and not latency and self.fuse not in ('nohead', 'nohead_k'):
-                ops = fuse_head_blocks(ops, self.bufs, set(b.id for b in outs), nosplit=self.nosplit)
+                ops = fuse_head_blocks(ops, self.bufs, set(b.id for b in outs), nosplit=self.nosplit, stream_ok=self.fuse is True)     # ('mid': the forms of round 5 - one chain per workgroup is as long at 8 images as at 64)
             if SE_TAIL:
                 ops = se_tail_into_producers(ops)
             fold = FOLD_DW if isinstance(FOLD_DW, str) else ('1' if FOLD_DW else '0')   # (tests assign booleans)

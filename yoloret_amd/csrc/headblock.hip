@@ -497,6 +497,7 @@ static int launch_head(const HeadArgs& h, int batch, hipStream_t s) {
 }
 
 int yr_launch_head(const yr_op& op, int batch, hipStream_t s) {
+    if ((op.k & 0x60) == 0x60 && op.dtype == YR_F32) return yr_launch_head_stream(op, batch, s);   // the weight-streaming form (headstream.hip)
     if (op.k & 0x40) return yr_launch_head_walk(op, batch, s);   // the walking form (headwalk.hip; headwalk_h.hip for the 16-bit plans)
     YR_REQUIRE(op.dtype == YR_F32 && op.out_dtype == YR_F32, "head: the LDS-tiled forms are float32 only (16-bit plans: the walking form, k bit 6)");
     YR_REQUIRE((op.k & 0x7f) == 3 && op.stride == 1, "head: depthwise 3x3, stride 1");

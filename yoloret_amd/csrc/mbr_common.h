@@ -106,6 +106,44 @@ __device__ __forceinline__ v4f mbs_mfma(mbs_u4 a, mbs_u4 b, v4f c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mbs_h8, a), __builtin_bit_cast(mbs_h8, b), c, 0, 0, 0);
 }
 
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) - the slices below index registers with the counter
+template <int N, class F>
+__device__ __forceinline__ void mbk_for(F&& f) {
+    if constexpr (N > 0) {
+        mbk_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// mbr_dw_row in THREE parts of equal VALU weight, so that a part can sit between two MFMAs: the centre tap (two v_pk_fma_f32), the left
+// neighbour's tap, the right neighbour's (four v_fmac_f32_dpp each).  No s_nop in front: the rows these read were written by VALU
+// instructions slices ago (or came from LDS).
+__device__ __forceinline__ void mbk_dw_part(const int part, v4f& acc, const v4f e, const v4f wt) {
+    if (part == 0) { acc = __builtin_elementwise_fma(e, wt, acc); return; }
+    float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+    if (part == 1)
+        asm("v_fmac_f32_dpp %0, %4, %8" MBR_DPP("row_shr:1") "v_fmac_f32_dpp %1, %5, %9" MBR_DPP("row_shr:1")
+            "v_fmac_f32_dpp %2, %6, %10" MBR_DPP("row_shr:1") "v_fmac_f32_dpp %3, %7, %11" MBR_DPP("row_shr:1")
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(wt[0]), "v"(wt[1]), "v"(wt[2]), "v"(wt[3]));
+    else
+        asm("v_fmac_f32_dpp %0, %4, %8" MBR_DPP("row_shl:1") "v_fmac_f32_dpp %1, %5, %9" MBR_DPP("row_shl:1")
+            "v_fmac_f32_dpp %2, %6, %10" MBR_DPP("row_shl:1") "v_fmac_f32_dpp %3, %7, %11" MBR_DPP("row_shl:1")
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(wt[0]), "v"(wt[1]), "v"(wt[2]), "v"(wt[3]));
+    acc = (v4f){a0, a1, a2, a3};
+}
+// ... and of the stride-2 tap row (even output row: own lane = E_j, row_shl:8 = O_j, row_shl:1 = E_j+1; lanes 0..7 written)
+#define MBK_DW2P(ctl)                                                                                                                 \
+    asm("v_fmac_f32_dpp %0, %4, %8" MBR_DPPM(ctl, "0x3") "v_fmac_f32_dpp %1, %5, %9" MBR_DPPM(ctl, "0x3")                                \
+        "v_fmac_f32_dpp %2, %6, %10" MBR_DPPM(ctl, "0x3") "v_fmac_f32_dpp %3, %7, %11" MBR_DPPM(ctl, "0x3")                              \
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(wt[0]), "v"(wt[1]), "v"(wt[2]), "v"(wt[3]))
+__device__ __forceinline__ void mbk_dw2_part(const int part, v4f& acc, const v4f e, const v4f wt) {
+    float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+    if (part == 0) MBK_DW2P("quad_perm:[0,1,2,3]");
+    else if (part == 1) MBK_DW2P("row_shl:8");
+    else MBK_DW2P("row_shl:1");
+    acc = (v4f){a0, a1, a2, a3};
+}
+
 // rows of a head map a walking wave takes per segment (headwalk.hip / headwalk_h.hip; shape only: the squeeze-excite sums are
 // grouped by (strip, segment))
 static inline int hw_seg_rows(int H) { return H <= 16 ? H : (H + ((H + 12) / 13) - 1) / ((H + 12) / 13); }

@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256, MW) void mbxr_kernel(MbxrArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {   // fixed tree over the 16 pixels of the DPP row (rotations by 8, 4, 2, 1: every lane ends with the total): deterministic
                 float t = v[i];
-                asm("v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                     "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                     "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                     "v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(t));

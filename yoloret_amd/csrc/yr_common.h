@@ -57,6 +57,7 @@ int yr_launch_head(const yr_op& op, int batch, hipStream_t s);      // headblock
 int yr_launch_absmax(const float* p, long long rows, int c, int ld, unsigned* out, hipStream_t s);   // elementwise.hip
 int yr_launch_head_walk(const yr_op& op, int batch, hipStream_t s); // headwalk.hip (YR_OP_HEAD with k bit 6)
 int yr_launch_head_walk_h(const yr_op& op, int batch, hipStream_t s); // headwalk_h.hip (... of a 16-bit plan)
+int yr_launch_head_stream(const yr_op& op, int batch, hipStream_t s); // headstream.hip (YR_OP_HEAD with k bits 5 and 6: the weight-streaming form)
 int yr_pointwise_num_cfgs(int dtype);
 
 static inline int yr_round_up(int v, int m) { return (v + m - 1) / m * m; }
