@@ -1009,7 +1009,9 @@ def fuse_head_blocks(ops, bufs, output_buf_ids, nosplit=frozenset(), stream_ok=T
         # ... where it measured ahead (MobileNetV2 x0.75 @416, 64 images, us, streaming | before): the 26 x 26 heads - td2 48 | 69, bu2 46 | 73 -; not the
         # 13 x 13 ones (two workgroups per image on half the chip: td1 50 | 51, bu1 56 | 37) nor the 52 x 52 ones (four generations of
         # workgroups, each with its prologue: td3 64 | 42, bu3 103 | 81).  YOLORET_HEAD_STREAM=<names> forces it for the named blocks.
-        hs_shape = HEAD_STREAM_ONLY or (20 <= d.h <= 30 and d.w <= 28 and nk >= 5)
+        # (... and, with up to four workgroups sharing an (image, strip, segment) by runs of tile pairs, td1 - 7 chunks, a pooled source: 52 -> 37 us; bu1 -
+        #  11 chunks - stays: 42 | 40)
+        hs_shape = HEAD_STREAM_ONLY or (20 <= d.h <= 30 and d.w <= 28 and nk >= 5) or (d.h < 20 and d.w <= 14 and 5 <= nk <= 8)
         stream = (HEAD_STREAM and stream_ok and hs_shape and not SE_TAIL and (not HEAD_STREAM_ONLY or bname_h in HEAD_STREAM_ONLY)      # (the opt-in SE tail lives in the older forms) and all(s_.xform in ('identity', 'maxpool2', 'up2_add') for s_ in c.srcs)
                   and all(s_.xform != 'up2_add' for s_ in c.srcs[:-1]) and 1 <= len(ksrc) <= 3 and F % 32 == 0 and c.act in ('relu6', 'none')
                   and nk <= (7 if head_stream_geometry(d.h, d.w)[0] == 2 else 11) and not (c.gate is not None and (len(ksrc) != 1 or ksrc[0].xform != 'identity'))

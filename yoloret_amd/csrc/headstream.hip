@@ -31,6 +31,7 @@ struct HsArgs {
     float* out; int ld_out;
     float* sums; int ld_sums;                    // [B][strips * segs * NW][ld_sums] or null
     int H, W, T, F, strips, segs, act, dw_act;
+    int csplit;          // workgroups that share one (image, strip, segment): each takes a contiguous run of the tile pairs (a launch-geometry choice: no result depends on it)
     unsigned wa_bytes, wt_bytes;
 };
 
@@ -52,10 +53,11 @@ __global__ __launch_bounds__(64 * NW) void hstream_kernel(HsArgs a) {
     const int lane = threadIdx.x & 63, px = lane & 15, mg = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int bid = (int)yr_xcd_swizzle(blockIdx.x, gridDim.x);
+    const int part = bid % a.csplit; bid /= a.csplit;
     const int seg = bid % a.segs; bid /= a.segs;
     const int strip = bid % a.strips;
     const int b = bid / a.strips;
-    const int NQ = a.T / 2;
+    const int Q0 = part * (a.T / 2) / a.csplit, NQ = (part + 1) * (a.T / 2) / a.csplit;     // this workgroup's tile pairs [Q0, NQ)
 
     // ---- rows of this wave (mbk.hip's rule), columns of this lane
     const int ri0 = seg * (NR - 2), out0 = seg == 0 ? 0 : ri0 + 1;
@@ -84,8 +86,8 @@ __global__ __launch_bounds__(64 * NW) void hstream_kernel(HsArgs a) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (hs_lds_ptr)(dst + p * 1024), 16, (unsigned)(qs * CHB + p * 1024 + lane * 16), 0, 0, 0);
         }
     };
-    issue_chunk(0);
-    issue_chunk(1);
+    issue_chunk(Q0);
+    issue_chunk(Q0 + 1);
     // the tables of all tiles and the conv's BN scale; the zero rows above the first / below the last wave
     for (int i = threadIdx.x; i < a.T * MBR_TAB; i += 64 * NW) tabs[i] = a.wt[i];
     for (int i = threadIdx.x; i < a.F; i += 64 * NW) lsc[i] = a.scale[i];
@@ -276,9 +278,9 @@ __global__ __launch_bounds__(64 * NW) void hstream_kernel(HsArgs a) {
     v4f ec[ROWS][2], en[ROWS][2];
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
-    {   // pair 0's conv: plain order (once)
-        conv_init(0, ec);
-        const u4* fe = reinterpret_cast<const u4*>(lds_raw) + lane;
+    {   // the first pair's conv: plain order (once)
+        conv_init(Q0, ec);
+        const u4* fe = reinterpret_cast<const u4*>(lds_raw + (Q0 & 1) * CHB) + lane;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             v4f e1[ROWS];
@@ -298,15 +300,15 @@ __global__ __launch_bounds__(64 * NW) void hstream_kernel(HsArgs a) {
             for (int i = 0; i < ROWS; ++i) ec[i][j] = __builtin_elementwise_fma(e1[i], k11, ec[i][j]);
         }
         conv_finish(ec);
-        park_rows(0, ec);
+        park_rows(Q0, ec);
     }
     // (the wait in front of the barrier is COUNTED: behind the planes of pair q + 1 - the oldest operations in flight - only this turn's
     //  stores were issued, 2 ROWS of the map + 2 of the sums, and they may stay in flight; lgkmcnt(0): the parked rows are written)
     constexpr int NST = 2 * ROWS + 2;
     constexpr std::true_type Y{};
     constexpr std::false_type N{};
-    for (int q = 0; q + 1 < NQ; ++q) {
-        if (q == 0) __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0)
+    for (int q = Q0; q + 1 < NQ; ++q) {
+        if (q == Q0) __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0)
         else __builtin_amdgcn_s_waitcnt(NST | 0x0070);                // vmcnt(NST) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         conv_init(q + 1, en);                    // (its addend loads go out BEFORE the next planes: they are waited for first)
@@ -349,7 +351,13 @@ static int launch_hstream(HsArgs& a, int batch, hipStream_t s) {
     static const int nm_len = snprintf(nm[0], sizeof(nm[0]), "hstream_kernel<%d,%d,%d,0>", NK, ROWS, NW) + snprintf(nm[1], sizeof(nm[1]), "hstream_kernel<%d,%d,%d,1>", NK, ROWS, NW);
     (void)nm_len;
     yr_note_kernel(nm[pre ? 1 : 0]);
-    const dim3 grid((unsigned)(batch * a.strips * a.segs));
+    // fewer workgroups than CUs (the 13 x 13 heads at 64 images: 128): up to four workgroups share an (image, strip, segment), each
+    // streaming its own run of tile pairs past the same pixels (every output channel is still computed by exactly one wave)
+    const int wgs = batch * a.strips * a.segs;
+    a.csplit = wgs >= 200 ? 1 : (256 + wgs - 1) / wgs;
+    if (a.csplit > 4) a.csplit = 4;
+    while (a.csplit > 1 && (a.T / 2) / a.csplit < 2) --a.csplit;
+    const dim3 grid((unsigned)(wgs * a.csplit));
 #define HS_GO(P)                                                                                                           \
     {                                                                                                                      \
         auto kern = hstream_kernel<NK, ROWS, NW, P>;                                                                       \
