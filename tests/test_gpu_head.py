@@ -243,6 +243,11 @@ def test_head_stream_form_variants_and_batch_independence(dev):
         many, _ = run_head(dev, np.random.default_rng(12), 5, h, w, segs, f, pre=pre, se=r, tail=False, tile=True, form='stream')
         for i in range(5):
             assert np.array_equal(many[i], one[0]), 'image %d of the batch differs from the image run alone' % i
+    # how many workgroups share an (image, strip, segment) follows the launch's size (1 image: four, 110 images of 13 x 13: one) - and changes nothing
+    h, w, segs, f, pre, r = (13, 13, [(120, 'identity'), (96, 'maxpool2')], 512, False, 128)
+    one, _ = run_head(dev, np.random.default_rng(13), 1, h, w, segs, f, pre=pre, se=r, tail=False, form='stream')
+    many, _ = run_head(dev, np.random.default_rng(13), 110, h, w, segs, f, pre=pre, se=r, tail=False, tile=True, form='stream')
+    assert np.array_equal(many[0], one[0]) and np.array_equal(many[109], one[0])
 
 
 def test_head_block_variants(dev):
