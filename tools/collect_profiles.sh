@@ -1,6 +1,6 @@
 #!/bin/bash
 # gpurun_out/refresh (tools/refresh_profiles.sh) -> profiles/r${ROUND}_*: one set per round.
-ROUND=${ROUND:-04}
+ROUND=${ROUND:-06}
 R=gpurun_out/refresh; P=profiles
 cp $R/bench_c2.json $P/r${ROUND}_bench.json; cp $R/bench_c2_depth1.json $P/r${ROUND}_bench_depth1.json; cp $R/bench_c2_under_rocprof.json $P/r${ROUND}_bench_under_rocprof.json
 cp $R/perop_c2.txt $P/r${ROUND}_perop.txt; cp $R/kernel_stats_c2.txt $P/r${ROUND}_kernel_stats.txt; cp $R/kernel_stats_c2_in_flight.txt $P/r${ROUND}_kernel_stats_in_flight.txt
