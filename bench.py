@@ -525,8 +525,8 @@ def main():
             roofline['by_pipe']['frac_fp32_executed'] = round(fr['fp32_executed'], 4)
         # the same per kernel FAMILY: the lane-per-pixel front, the fused MFMA blocks ... are several symbols each
         fams = [('lane_per_pixel_front', ('mblane', 'stemblock', 'stem_')),
-                ('head_blocks', ('head_kernel', 'head2_kernel', 'hwalk_kernel', 'hwalkh_kernel')),
-                ('fused_blocks', ('mbh_kernel', 'mbn_kernel', 'mbr_kernel', 'mbe_kernel', 'mbx_kernel', 'mbxr_kernel', 'mbhr_kernel', 'mbhq_kernel', 'stemxr_kernel', 'stemxp_kernel')),
+                ('head_blocks', ('head_kernel', 'head2_kernel', 'hwalk_kernel', 'hwalkh_kernel', 'hstream_kernel')),
+                ('fused_blocks', ('mbh_kernel', 'mbn_kernel', 'mbr_kernel', 'mbk_kernel', 'mbe_kernel', 'mbx_kernel', 'mbxr_kernel', 'mbhr_kernel', 'mbhq_kernel', 'stemxr_kernel', 'stemxp_kernel')),
                 ('pointwise', ('pw_kernel', 'pwd_kernel', 'pws_kernel', 'pwh', 'pwl')), ('depthwise', ('dw_kernel', 'dwp_kernel', 'dwq_kernel', 'dwl')),
                 ('elementwise', ('wsum', 'gather', 'letterbox')),
                 ('squeeze_excite', ('se_',)), ('postprocess', ('decode', 'nms', 'pack'))]
