@@ -42,6 +42,11 @@ struct MbkArgs {
 };
 
 typedef __attribute__((address_space(3))) void* mbk_lds_ptr;
+#ifdef MBK_TIMING     // (python tools/relink.py mbk.hip -DMBK_TIMING; tools/mbk_timing.py: per-phase shader-clock totals of every wave, written behind the last image of the output - a probe build)
+#define MBK_T(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define MBK_T(i)
+#endif
 
 // (EXP: ablations of tools/mbk_probe.py, -DMBK_EXPERIMENT builds only - wrong results: 1 no depthwise taps, 2 no expand MFMAs, 3 no project
 //  MFMAs, 4 no barrier in the loop, 5 no chunk loads in the loop, 6 no fragment reads from LDS in the loop)
@@ -65,6 +70,9 @@ __global__ __launch_bounds__(64 * NW) void mbk_kernel(MbkArgs a) {
     const int seg = bid % a.segs; bid /= a.segs;
     const int strip = bid % a.strips;
     const int b = bid / a.strips;
+#ifdef MBK_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- rows of this wave, columns of this lane
     int rin[ROWS];            // input rows (may lie outside the image: zero rows)
@@ -106,6 +114,12 @@ __global__ __launch_bounds__(64 * NW) void mbk_kernel(MbkArgs a) {
             if (NPIECE % NW == 0 || p < NPIECE)      // (wave-uniform)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (mbk_lds_ptr)(dst + p * 1024), 16, (unsigned)(qs * CHB + p * 1024 + lane * 16), 0, 0, 0);
         }
+    };
+    constexpr int NU = (NPIECE + NW - 1) / NW;      // pieces of a chunk per wave
+    auto issue_piece = [&](const int q, const int u) {
+        const int p = u * NW + w;
+        if (NPIECE % NW == 0 || p < NPIECE)          // (wave-uniform)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (mbk_lds_ptr)(lds_raw + (q % 3) * CHB + p * 1024), 16, (unsigned)(min(q, NQ - 1) * CHB + p * 1024 + lane * 16), 0, 0, 0);
     };
     issue_chunk(0);
     issue_chunk(NQ > 1 ? 1 : 0);
@@ -276,8 +290,17 @@ __global__ __launch_bounds__(64 * NW) void mbk_kernel(MbkArgs a) {
             for (int i = 0; i < ROWS; ++i) en[i][j] = se;
         }
         __builtin_amdgcn_sched_barrier(0);
+        MBK_T(2)
         mbk_for<NS>([&](auto SS) {
             constexpr int sl = decltype(SS)::value;
+            // chunk q + 2 goes out piece by piece in the shadow of the MFMAs (an LDS-direct load costs 100+ cycles of issue at the top
+            // of the turn, where nothing hides it: tools/mbk_timing.py) - into the buffer chunk q - 1 was read from, free since the barrier
+            if constexpr (EXP != 5) {
+                mbk_for<NU>([&](auto UU) {
+                    constexpr int u = decltype(UU)::value;
+                    if constexpr ((2 * u + 1) * NS / (2 * NU) == sl) issue_piece(q + 2, u);
+                });
+            }
             if constexpr (sl < NM) {
                 constexpr int g = sl / MPG, r = sl % MPG, kind = r / ROWS, i = r % ROWS, j = g / NKE, c = g % NKE;
                 if constexpr (r == 0 && g + 1 < NMG) {
@@ -310,6 +333,7 @@ __global__ __launch_bounds__(64 * NW) void mbk_kernel(MbkArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+        MBK_T(3)
         // phase 2 (VALU): ReLU6 of the depthwise results, the float16 planes of the pair's 8 values per lane
         u4 pf[2][2];
         pf[0][0] = fp[0]; pf[0][1] = fp[64];
@@ -324,6 +348,7 @@ __global__ __launch_bounds__(64 * NW) void mbk_kernel(MbkArgs a) {
             mbs_split8(v, bh[i], bm[i]);
         }
         __builtin_amdgcn_sched_barrier(0);
+        MBK_T(4)
         // phase 3: the projection's MFMAs with the ReLU6 of the new expanded rows (4 v_med3 per slice) in their shadow
         constexpr int MPT = 3 * NE, NM3 = TO * MPT, NV3 = ROWS * 2;
         mbk_for<(NM3 > NV3 ? NM3 : NV3)>([&](auto SS) {
@@ -346,6 +371,7 @@ __global__ __launch_bounds__(64 * NW) void mbk_kernel(MbkArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+        MBK_T(5)
     };
 
     // ONE barrier per tile pair: behind barrier q every wave has parked its rows of pair q and chunk q + 1 has landed, so the depthwise
@@ -356,10 +382,12 @@ __global__ __launch_bounds__(64 * NW) void mbk_kernel(MbkArgs a) {
     __syncthreads();
     expand(lds_raw, ec);
     park_rows(0, ec);
+    MBK_T(0)
     for (int q = 0; q + 1 < NQ; ++q) {
         __builtin_amdgcn_s_waitcnt(0x0f70);
         if (EXP != 4) __syncthreads();
-        if (EXP != 5) issue_chunk(q + 2);                      // (beyond the last chunk: the last one again, into a buffer nobody reads any more)
+        MBK_T(1)
+        if (EXP != 5 && !ILV) issue_chunk(q + 2);              // (the interleaved body issues it inside its slices; beyond the last chunk: the last one again, into a buffer nobody reads any more)
         v4f en[ROWS][2];
         // The two streams in OPPOSITE order on the two waves that share a SIMD (waves w and w + 4: a workgroup's waves go to the SIMDs
         // cyclically): between two barriers all waves run the same code from the same starting line, so with one order both waves of a
@@ -378,30 +406,46 @@ __global__ __launch_bounds__(64 * NW) void mbk_kernel(MbkArgs a) {
         park_rows(q + 1, en);
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) { ec[i][0] = en[i][0]; ec[i][1] = en[i][1]; }
+        MBK_T(6)
     }
+    // the residual and the projection's BN shift are fetched BEFORE the last pair's depthwise stage and projection: their round trip
+    // (a load nobody waits for until the stores) runs under ~1500 cycles of work instead of in front of the stores
+    v4f res[NE][RES ? TO : 1], psh[TO];
+    unsigned oaddr[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int y = S == 1 ? rin[i] : yo;
+        const bool live = emit[i] && out_lane;
+        const unsigned opix = ((unsigned)max(y, 0) * (unsigned)a.Wo + (unsigned)xo);
+        oaddr[i] = live ? opix * (unsigned)a.ld_out * 4u : MBR_DEAD;
+        if constexpr (RES) {
+#pragma unroll
+            for (int t = 0; t < TO; ++t)
+                res[i][t] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xsrc, live && 16 * t + 4 * mg < COUT ? (opix * (unsigned)a.ld_in + 16u * t + 4u * mg) * 4u : MBR_DEAD, 0, 0));
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TO; ++t) psh[t] = *reinterpret_cast<const v4f*>(a.bp + 16 * t + 4 * mg);
+    __builtin_amdgcn_sched_barrier(0);     // (the loads are issued HERE)
     __syncthreads();
     dw_project(NQ - 1, lds_raw + ((NQ - 1) % 3) * CHB, ec);
 
     // ---- BN shift, residual, store (16 bytes per lane and cout tile)
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-        const int y = S == 1 ? rin[i] : yo;
-        const bool live = emit[i] && out_lane;
-        const unsigned opix = ((unsigned)max(y, 0) * (unsigned)a.Wo + (unsigned)xo);
-        v4f res[TO];
-        if constexpr (RES) {
-#pragma unroll
-            for (int t = 0; t < TO; ++t)
-                res[t] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xsrc, live && 16 * t + 4 * mg < COUT ? (opix * (unsigned)a.ld_in + 16u * t + 4u * mg) * 4u : MBR_DEAD, 0, 0));
-        }
 #pragma unroll
         for (int t = 0; t < TO; ++t) {
             const int co = 16 * t + 4 * mg;
-            v4f v = __builtin_elementwise_fma(P1[i][t], k11, P[i][t]) + *reinterpret_cast<const v4f*>(a.bp + co);
-            if constexpr (RES) v += res[t];
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), osrc, live && co < COUT ? (opix * (unsigned)a.ld_out + (unsigned)co) * 4u : MBR_DEAD, 0, 0);
+            v4f v = __builtin_elementwise_fma(P1[i][t], k11, P[i][t]) + psh[t];
+            if constexpr (RES) v += res[i][t];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), osrc, oaddr[i] != MBR_DEAD && co < COUT ? oaddr[i] + (unsigned)co * 4u : MBR_DEAD, 0, 0);
         }
     }
+#ifdef MBK_TIMING
+    MBK_T(7)
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    if (lane < 8) reinterpret_cast<unsigned*>(a.out)[(size_t)(gridDim.x / (a.strips * a.segs)) * a.Ho * a.Wo * a.ld_out + ((size_t)blockIdx.x * NW + w) * 8 + lane] = (unsigned)tacc[lane];
+#endif
 }
 
 // segments a map of H input rows is cut into (the same formula as the kernel's row rule; compiler.mbk_segs)
