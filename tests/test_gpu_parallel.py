@@ -179,10 +179,17 @@ def _two_rank_worker(rank, world, port, q):
     m.set_weights(synthetic_weights(m, 5, 'survey'))
     gb = 8
     lo, hi = shard_range(gb, rank, world)
+    # every rank runs rank 0's tuning table (parallel.share_tuning): rank 0 tunes on its first call, rank 1 installs the table
+    from yoloret_amd.parallel import share_tuning
+    if rank == 0:
+        m(torch.from_numpy(params.synthetic_images(gb, 96, 96, seed=1)[lo:hi]).to(dev))
+        torch.cuda.synchronize()
+    table = share_tuning(m, hi - lo, device=dev)
+    assert table is not None and m.get_tuning(hi - lo, dev) == table and (0, hi - lo) in m._tuned
     pipe = DetectionPipeline(m, ANCHORS, 20, 3, max_boxes=20, score_threshold=0.2, iou_threshold=0.5, depth=2)
     g = DetectionGatherer()
     hw = torch.tensor([[96, 96]] * (hi - lo), dtype=torch.int32, device=dev)
-    outs = []
+    outs = [table]
     # consume as you go: step i is gathered before step i + 2 (which rewrites its context's buffers) is issued
     pend = []
     for seed in (1, 2, 3):
@@ -196,7 +203,7 @@ def _two_rank_worker(rank, world, port, q):
     for det, cnt, done in pend:
         done.synchronize()
         outs.append(tuple(t.clone() for t in g(det.cpu(), cnt.cpu())))
-    q.put((rank, [(d.numpy().copy(), c.numpy().copy()) for d, c in outs]))
+    q.put((rank, [outs[0]] + [(d.numpy().copy(), c.numpy().copy()) for d, c in outs[1:]]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -231,7 +238,8 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_records(dev):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    assert res[0][0] == res[1][0] and any(res[0][0]), 'both ranks must run rank 0\'s (non-trivial) tuning table'
     for rank in (0, 1):
-        assert len(res[rank]) == 3
-        for (d, c), (wd, wc) in zip(res[rank], want):
+        assert len(res[rank]) == 4
+        for (d, c), (wd, wc) in zip(res[rank][1:], want):
             assert np.array_equal(d, wd) and np.array_equal(c, wc), 'rank %d' % rank
