@@ -36,6 +36,11 @@ struct HsArgs {
 };
 
 typedef __attribute__((address_space(3))) void* hs_lds_ptr;
+#ifdef HS_TIMING      // (python tools/relink.py headstream.hip -DHS_TIMING; tools/hs_timing.py: per-phase shader-clock totals of every wave, written behind the output's last image)
+#define HS_T(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define HS_T(i)
+#endif
 
 __device__ __forceinline__ float hs_swish(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f)); }
 
@@ -49,7 +54,7 @@ __global__ __launch_bounds__(64 * NW) void hstream_kernel(HsArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];     // [2][CHB] weight planes | [2][NW + 2][NPR][2][64] v4f parked rows | [T][11][16] tables | [F] conv BN scale
     char* const xch = lds_raw + 2 * CHB;
     float* const tabs = reinterpret_cast<float*>(xch + 2 * XCB);
-    float* const lsc = tabs + a.T * MBR_TAB;
+    float* const lsc = tabs + ((a.T * MBR_TAB * 4 + 1023) & ~1023) / 4;      // (both land as whole 1 KB pieces)
     const int lane = threadIdx.x & 63, px = lane & 15, mg = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int bid = (int)yr_xcd_swizzle(blockIdx.x, gridDim.x);
@@ -58,6 +63,9 @@ __global__ __launch_bounds__(64 * NW) void hstream_kernel(HsArgs a) {
     const int strip = bid % a.strips;
     const int b = bid / a.strips;
     const int Q0 = part * (a.T / 2) / a.csplit, NQ = (part + 1) * (a.T / 2) / a.csplit;     // this workgroup's tile pairs [Q0, NQ)
+#ifdef HS_TIMING
+    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- rows of this wave (mbk.hip's rule), columns of this lane
     const int ri0 = seg * (NR - 2), out0 = seg == 0 ? 0 : ri0 + 1;
@@ -88,62 +96,93 @@ __global__ __launch_bounds__(64 * NW) void hstream_kernel(HsArgs a) {
     };
     issue_chunk(Q0);
     issue_chunk(Q0 + 1);
-    // the tables of all tiles and the conv's BN scale; the zero rows above the first / below the last wave
-    for (int i = threadIdx.x; i < a.T * MBR_TAB; i += 64 * NW) tabs[i] = a.wt[i];
-    for (int i = threadIdx.x; i < a.F; i += 64 * NW) lsc[i] = a.scale[i];
+    // the tables of all tiles and the conv's BN scale: LDS-direct too (plain loads were 6 - 11 dependent round trips per thread: a quarter of
+    // the kernel's cycles, tools/hs_timing.py); the zero rows above the first / below the last wave
+    {
+        const mbr_rsrc tsrc = mbr_make_rsrc(a.wt, a.wt_bytes), csrc_ = mbr_make_rsrc(a.scale, (unsigned)a.F * 4u);
+        const int ntp = (a.T * MBR_TAB * 4 + 1023) / 1024, ncp = (a.F * 4 + 1023) / 1024;      // (reads beyond a descriptor return zeros)
+        for (int p = w; p < ntp; p += NW)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(tsrc, (hs_lds_ptr)(reinterpret_cast<char*>(tabs) + p * 1024), 16, (unsigned)(p * 1024 + lane * 16), 0, 0, 0);
+        for (int p = w; p < ncp; p += NW)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(csrc_, (hs_lds_ptr)(reinterpret_cast<char*>(lsc) + p * 1024), 16, (unsigned)(p * 1024 + lane * 16), 0, 0, 0);
+    }
+    HS_T(8)
     if (w < 2) {
 #pragma unroll
         for (int u = 0; u < 2 * NPR * 2; ++u)
             reinterpret_cast<v4f*>(xch + (u / (NPR * 2)) * XCB + (w * (NW + 1) * NPR * 2 + u % (NPR * 2)) * 1024)[lane] = (v4f){0.f, 0.f, 0.f, 0.f};
     }
 
-    // ---- the wave's pixels over the whole k space: gathered once, gated, cut into float16 planes
+    // ---- the wave's pixels over the whole k space: gathered once, gated, cut into float16 planes.  ALL loads of a round go out
+    // before anything is used (one round trip for the identity sources; three more rounds for the other pixels of pooled sources)
     const mbr_rsrc rs0 = mbr_make_rsrc(a.src[0], 0x7effffffu);
     const mbr_rsrc rs1 = mbr_make_rsrc(a.nsrc > 1 ? a.src[1] : a.src[0], 0x7effffffu);
     const mbr_rsrc rs2 = mbr_make_rsrc(a.nsrc > 2 ? a.src[2] : a.src[0], 0x7effffffu);
     mbs_u4 xh[ROWS][NK], xm[ROWS][NK];
     float live[ROWS];
+    {
+        // groups of at most 7 chunks of one row at a time: their raw pixels next to the planes already cut must fit the registers
+        constexpr int GC = NK <= 7 ? NK : (NK + 1) / 2, NG = (NK + GC - 1) / GC;
+        const bool any_pool = (a.pool[0] | a.pool[1] | a.pool[2]) != 0;
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-        const bool row_in = rin[i] >= 0 && rin[i] < a.H;
-        live[i] = row_in && col_in ? 1.f : 0.f;
-        const int rc = min(max(rin[i], 0), a.H - 1);
+        for (int i = 0; i < ROWS; ++i) {
+            const bool row_in = rin[i] >= 0 && rin[i] < a.H;
+            live[i] = row_in && col_in ? 1.f : 0.f;
+            const int rc = min(max(rin[i], 0), a.H - 1);
 #pragma unroll
-        for (int c = 0; c < NK; ++c) {
-            const int s = c == 0 ? 0 : a.csrc[c], kl = a.ckl[c] + 8 * mg;
-            const int cs = s == 0 ? a.cs[0] : s == 1 ? a.cs[1] : a.cs[2], ld = s == 0 ? a.ld[0] : s == 1 ? a.ld[1] : a.ld[2];
-            const int pool = s == 0 ? a.pool[0] : s == 1 ? a.pool[1] : a.pool[2];
-            const int cq = (cs + 3) & ~3;
-            const int sw = pool ? 2 * a.W : a.W, sh = pool ? 2 * a.H : a.H;
-            v4f lo = (v4f){0.f, 0.f, 0.f, 0.f}, hi = lo;
-            const int np = pool ? 4 : 1;
-            for (int t = 0; t < np; ++t) {       // (uniform trip count: the four pixels of a pooled source)
-                const int yy = pool ? 2 * rc + (t >> 1) : rc, xx = pool ? 2 * xc + (t & 1) : xc;
-                const unsigned base = (unsigned)(((b * sh + yy) * sw + xx) * ld + kl) * 4u;
-                const unsigned o0 = kl < cq ? base : MBR_DEAD, o1 = kl + 4 < cq ? base + 16u : MBR_DEAD;
-                v4f l2, h2;
-                if (s == 0) { l2 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs0, o0, 0, 0)); h2 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs0, o1, 0, 0)); }
-                else if (s == 1) { l2 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs1, o0, 0, 0)); h2 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs1, o1, 0, 0)); }
-                else { l2 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs2, o0, 0, 0)); h2 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs2, o1, 0, 0)); }
-                if (t == 0) { lo = l2; hi = h2; }
-                else {
+            for (int g = 0; g < NG; ++g) {
+                v4f lo[GC], hi[GC];
+                auto fetch = [&](const int t, const bool first) {      // pixel t of a pooled source's 2 x 2 window (t = 0: every source)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { lo[e] = fmaxf(lo[e], l2[e]); hi[e] = fmaxf(hi[e], h2[e]); }
+                    for (int cc = 0; cc < GC; ++cc) {
+                        const int c = g * GC + cc;
+                        if (c >= NK) continue;
+                        const int s = c == 0 ? 0 : a.csrc[c], kl = a.ckl[c] + 8 * mg;
+                        const int cs = s == 0 ? a.cs[0] : s == 1 ? a.cs[1] : a.cs[2], ld = s == 0 ? a.ld[0] : s == 1 ? a.ld[1] : a.ld[2];
+                        const int pool = s == 0 ? a.pool[0] : s == 1 ? a.pool[1] : a.pool[2];
+                        const int cq = (cs + 3) & ~3;
+                        const int sw = pool ? 2 * a.W : a.W, sh = pool ? 2 * a.H : a.H;
+                        const int yy = pool ? 2 * rc + (t >> 1) : rc, xx = pool ? 2 * xc + (t & 1) : xc;
+                        const unsigned base = (unsigned)(((b * sh + yy) * sw + xx) * ld + kl) * 4u;
+                        const bool want = first || pool;
+                        const unsigned o0 = want && kl < cq ? base : MBR_DEAD, o1 = want && kl + 4 < cq ? base + 16u : MBR_DEAD;
+                        v4f l2, h2;
+                        if (s == 0) { l2 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs0, o0, 0, 0)); h2 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs0, o1, 0, 0)); }
+                        else if (s == 1) { l2 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs1, o0, 0, 0)); h2 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs1, o1, 0, 0)); }
+                        else { l2 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs2, o0, 0, 0)); h2 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs2, o1, 0, 0)); }
+                        if (first) { lo[cc] = l2; hi[cc] = h2; }
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { lo[cc][e] = pool ? fmaxf(lo[cc][e], l2[e]) : lo[cc][e]; hi[cc][e] = pool ? fmaxf(hi[cc][e], h2[e]) : hi[cc][e]; }
+                        }
+                    }
+                };
+                fetch(0, true);
+                if (any_pool) {      // (kernel-uniform)
+                    fetch(1, false); fetch(2, false); fetch(3, false);
+                }
+#pragma unroll
+                for (int cc = 0; cc < GC; ++cc) {
+                    const int c = g * GC + cc;
+                    if (c >= NK) continue;
+                    const int s = c == 0 ? 0 : a.csrc[c], kl = a.ckl[c] + 8 * mg;
+                    const int cs = s == 0 ? a.cs[0] : s == 1 ? a.cs[1] : a.cs[2];
+                    float v[8] = {lo[cc][0], lo[cc][1], lo[cc][2], lo[cc][3], hi[cc][0], hi[cc][1], hi[cc][2], hi[cc][3]};
+                    const int vc = cs - a.ckl[c];          // valid channels of the chunk (>= 32: all); the lanes of a partial quad may hold anything
+                    if (a.gate != nullptr) {               // (uniform) the SE gate of the single source
+                        const float* gp = a.gate + (size_t)b * a.gate_ld + kl;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = 8 * mg + e < vc ? v[e] * gp[e] : 0.f;
+                    } else if (vc < 32) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = 8 * mg + e < vc ? v[e] : 0.f;
+                    }
+                    mbs_split8(v, xh[i][c], xm[i][c]);
                 }
             }
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            const int vc = cs - a.ckl[c];          // valid channels of the chunk (>= 32: all); the lanes of a partial quad may hold anything
-            if (a.gate != nullptr) {               // (uniform) the SE gate of the single source
-                const float* gp = a.gate + (size_t)b * a.gate_ld + kl;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 8 * mg + e < vc ? v[e] * gp[e] : 0.f;
-            } else if (vc < 32) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 8 * mg + e < vc ? v[e] : 0.f;
-            }
-            mbs_split8(v, xh[i][c], xm[i][c]);
         }
     }
+    HS_T(9)
     const mbr_rsrc prs = mbr_make_rsrc(PRE ? a.pre + (size_t)b * (a.H >> 1) * (a.W >> 1) * a.pre_ld : a.src[0], PRE ? (unsigned)((a.H >> 1) * (a.W >> 1) * a.pre_ld) * 4u : 0u);
     const mbr_rsrc osrc = mbr_make_rsrc(a.out + (size_t)b * a.H * a.W * a.ld_out, (unsigned)(a.H * a.W * a.ld_out) * 4u);
     const mbr_rsrc ssrc = mbr_make_rsrc(a.sums != nullptr ? a.sums + (size_t)b * (a.strips * a.segs * NW) * a.ld_sums : a.src[0],
@@ -161,7 +200,13 @@ __global__ __launch_bounds__(64 * NW) void hstream_kernel(HsArgs a) {
     const v4f k11 = (v4f){0.00048828125f, 0.00048828125f, 0.00048828125f, 0.00048828125f};
 
     // ---- conv of tile pair q out of chunk buffer cb: BN shift (+ scale x the up-sampled addend) as the accumulators' first value
+    // the up-sampled addend of the pair being multiplied: loaded at the top of the turn, added behind its MFMAs (the widest two-row
+    // form has no registers for that and adds at once)
+    constexpr bool LATE = PRE && !(NK >= 7 && ROWS == 2);
+    v4f pv[LATE ? ROWS : 1][2];
+    int pvq = 0;
     auto conv_init = [&](const int q, v4f (&en)[ROWS][2]) {
+        pvq = q;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int t = 2 * q + j;
@@ -169,10 +214,9 @@ __global__ __launch_bounds__(64 * NW) void hstream_kernel(HsArgs a) {
 #pragma unroll
             for (int i = 0; i < ROWS; ++i) {
                 en[i][j] = se;
-                if constexpr (PRE) {
-                    const v4f p = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(prs, ppix[i] + 64u * t, 0, 0));
-                    en[i][j] = reinterpret_cast<const v4f*>(lsc + 16 * t)[mg] * p + se;     // (acc + pre) * scale + shift, the scale folded into the planes
-                }
+                if constexpr (LATE) pv[i][j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(prs, ppix[i] + 64u * t, 0, 0));
+                else if constexpr (PRE)
+                    en[i][j] = reinterpret_cast<const v4f*>(lsc + 16 * t)[mg] * __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(prs, ppix[i] + 64u * t, 0, 0)) + se;
             }
         }
     };
@@ -180,9 +224,11 @@ __global__ __launch_bounds__(64 * NW) void hstream_kernel(HsArgs a) {
 #pragma unroll
         for (int i = 0; i < ROWS; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (LATE) en[i][j] = reinterpret_cast<const v4f*>(lsc + 16 * (2 * pvq + j))[mg] * pv[i][j] + en[i][j];     // (acc + pre) * scale + shift, the scale folded into the planes
 #pragma unroll
                 for (int s = 0; s < 4; ++s) en[i][j][s] = __builtin_amdgcn_fmed3f(en[i][j][s], actmin, actmax) * live[i];
+            }
     };
     auto park_rows = [&](const int q, const v4f (&ec)[ROWS][2]) {
         v4f* park = reinterpret_cast<v4f*>(xch + (q & 1) * XCB) + lane;        // [NW + 2][NPR: first | last row][2 tiles][64]
@@ -216,6 +262,7 @@ __global__ __launch_bounds__(64 * NW) void hstream_kernel(HsArgs a) {
         if constexpr (CONV) { fr[0][0] = fe[0]; fr[0][1] = fe[64]; }
         tp[0][0] = tbq[0]; tp[0][1] = tbq[4]; tp[0][2] = tbq[8];
         __builtin_amdgcn_sched_barrier(0);
+        HS_T(3)
         mbk_for<NS>([&](auto SS) {
             constexpr int sl = decltype(SS)::value;
             if constexpr (CONV && sl < NM) {
@@ -272,12 +319,14 @@ __global__ __launch_bounds__(64 * NW) void hstream_kernel(HsArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+        HS_T(4)
     };
 
     // ONE barrier per tile pair: behind barrier q every wave has parked its rows of pair q and the planes of pair q + 1 have landed.
     v4f ec[ROWS][2], en[ROWS][2];
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
+    HS_T(10)
     {   // the first pair's conv: plain order (once)
         conv_init(Q0, ec);
         const u4* fe = reinterpret_cast<const u4*>(lds_raw + (Q0 & 1) * CHB) + lane;
@@ -302,6 +351,7 @@ __global__ __launch_bounds__(64 * NW) void hstream_kernel(HsArgs a) {
         conv_finish(ec);
         park_rows(Q0, ec);
     }
+    HS_T(0)
     // (the wait in front of the barrier is COUNTED: behind the planes of pair q + 1 - the oldest operations in flight - only this turn's
     //  stores were issued, 2 ROWS of the map + 2 of the sums, and they may stay in flight; lgkmcnt(0): the parked rows are written)
     constexpr int NST = 2 * ROWS + 2;
@@ -311,17 +361,31 @@ __global__ __launch_bounds__(64 * NW) void hstream_kernel(HsArgs a) {
         if (q == Q0) __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0)
         else __builtin_amdgcn_s_waitcnt(NST | 0x0070);                // vmcnt(NST) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
+        HS_T(1)
         conv_init(q + 1, en);                    // (its addend loads go out BEFORE the next planes: they are waited for first)
-        issue_chunk(q + 2);                      // into the buffer pair q's planes were read from (beyond the last pair: the last one again)
+        issue_chunk(q + 2);
+        HS_T(2)                      // into the buffer pair q's planes were read from (beyond the last pair: the last one again)
         step(Y, q, lds_raw + ((q + 1) & 1) * CHB, ec, en);
         conv_finish(en);
         park_rows(q + 1, en);
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) { ec[i][0] = en[i][0]; ec[i][1] = en[i][1]; }
+        HS_T(5)
     }
     __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
+    HS_T(6)
     step(N, NQ - 1, lds_raw, ec, en);
+#ifdef HS_TIMING
+    HS_T(7)
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    {
+        unsigned tv = 0;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) tv = lane == i ? (unsigned)tacc[i] : tv;
+        if (lane < 12) reinterpret_cast<unsigned*>(a.out)[(size_t)(gridDim.x / (a.strips * a.segs * a.csplit)) * a.H * a.W * a.ld_out + ((size_t)blockIdx.x * NW + w) * 16 + lane] = tv;
+    }
+#endif
 }
 
 // rows of the squeeze-excite sums the weight-streaming form writes per image: one per (strip, segment, wave) - a function of the shape
@@ -344,7 +408,7 @@ extern "C" int yr_head_stream_rows(int h, int w, int32_t* rows) {
 template <int NK, int ROWS, int NW>
 static int launch_hstream(HsArgs& a, int batch, hipStream_t s) {
     constexpr int CHB = 2 * NK * 2048, NPR = ROWS > 1 ? 2 : 1;
-    const size_t lds = (size_t)2 * CHB + (size_t)2 * (NW + 2) * NPR * 2 * 1024 + (size_t)a.T * MBR_TAB * 4 + (size_t)a.F * 4;
+    const size_t lds = (size_t)2 * CHB + (size_t)2 * (NW + 2) * NPR * 2 * 1024 + (size_t)((a.T * MBR_TAB * 4 + 1023) & ~1023) + (size_t)((a.F * 4 + 1023) & ~1023);
     YR_REQUIRE(lds <= 160 * 1024, "head (weight-streaming form): %zu bytes of LDS", lds);
     const bool pre = a.pre != nullptr;
     static char nm[2][48];
