@@ -42,7 +42,7 @@ def _src_dims(h, w, xf):
     return {'identity': (h, w), 'up2': (h // 2, w // 2), 'maxpool2': (h * 2, w * 2), 'maxpool4': (h * 4, w * 4)}[xf]
 
 
-def run_pointwise(dev, rng, b, h, w, segs, cout, act='none', bn=True, residual=False, gate=False, out_ld=None, cfg=0, ksplit=False):
+def run_pointwise(dev, rng, b, h, w, segs, cout, act='none', bn=True, residual=False, gate=False, out_ld=None, cfg=0, ksplit=False, stream=False):
     rt = _rt()
     srcs_np, srcs_dev = [], []
     for c, xf in segs:
@@ -82,6 +82,10 @@ def run_pointwise(dev, rng, b, h, w, segs, cout, act='none', bn=True, residual=F
     for i, (t, (c, xf)) in enumerate(zip(srcs_dev, segs)):
         op.src[i] = rt.make_src(t, c=c, xform=xf)
     keep = [_dev_vec(wt, dev)]
+    if stream:            # the pixel-stationary form (pointwise_stream.hip): se_reduced bit 18, the weights as float16 planes
+        from yoloret_amd import compiler
+        keep = [_dev_vec(compiler.head_pack(wt, [kp], nk=compiler.pwt_chunks(kp)), dev)]
+        op.se_reduced |= 0x40000
     op.wgt = keep[0].data_ptr()
     if bn:
         keep += [_dev_vec(scale, dev), _dev_vec(shift, dev)]
@@ -155,6 +159,35 @@ def test_pointwise_ksplit_form(dev, case):
     run_pointwise(dev, rng, 3, h, w, segs, cout, act, bn, residual, gate, out_ld=cout if dense else None, ksplit=True)
 
 
+@pytest.mark.parametrize('b', [3, 40])
+@pytest.mark.parametrize('case', PW_CASES, ids=[str(i) for i in range(len(PW_CASES))])
+def test_pointwise_stream_form(dev, case, b):
+    """The pixel-stationary form (se_reduced bit 18: what the throughput plan asks of its 1x1 convs - a wave keeps the float16 planes of
+    its 16 or 32 pixels over the whole k space, the cout tiles' host-cut planes sit in LDS) == oracle at the per-op bar with every
+    source transform, gate, residual and dense rows, and BIT-IDENTICAL to the tiled split kernel: the same three MFMAs per chunk in
+    the same order (so a plan may mix the two forms across its variants)."""
+    from yoloret_amd import compiler
+    h, w, segs, cout, act, bn, residual, gate, dense = case
+    kp = sum(round_up(c, 4) for c, _ in segs)
+    if (kp < 16 or not compiler.pwt_chunks(kp) or h * w == 1 or any(xf.startswith('maxpool') for _, xf in segs) or residual
+            or act not in ('none', 'relu6')):
+        pytest.skip('not a shape of the form')
+    outs = []
+    for st in (False, True):
+        rng = np.random.default_rng(zlib.crc32(str(case).encode()))
+        outs.append(run_pointwise(dev, rng, b, h, w, segs, cout, act, bn, residual, gate, out_ld=cout if dense else None, stream=st))
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_pointwise_stream_form_many_tiles_per_wave(dev):
+    """... at a pixel count where a wave walks several pixel tiles (bu3_y's shape at 50 images), gated."""
+    outs = []
+    for st in (False, True):
+        rng = np.random.default_rng(11)
+        outs.append(run_pointwise(dev, rng, 50, 52, 52, [(128, 'identity')], 75, 'none', True, False, True, out_ld=75, stream=st))
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_pointwise_ksplit_pooled_output(dev):
     """... and with the MaxPooling2D(2) output of the bottom-up convs (rows walked in 2 x 2-quad-major order inside the 16-row tile)."""
     rt = _rt()
@@ -167,7 +200,7 @@ def test_pointwise_ksplit_pooled_output(dev):
     y = np.minimum(np.maximum(nn.pointwise(x, wk) * scale + shift, 0), 6).astype(np.float32)
     ref = y.reshape(b, h, 2, w, 2, cout).max(axis=(2, 4))
     outs = []
-    for ks in (False, True):
+    for ks in (False, True, 'stream'):
         xd = to_dev(x, dev)
         out = torch.full((b, h, w, cout), float('nan'), dtype=torch.float32, device=dev)
         op = rt.new_op(rt.OP_POINTWISE, 'relu6')
@@ -176,7 +209,12 @@ def test_pointwise_ksplit_pooled_output(dev):
         keep = [_dev_vec(np.ascontiguousarray(wk.T), dev), _dev_vec(scale, dev), _dev_vec(shift, dev)]
         op.wgt, op.scale, op.shift = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
         op.out, op.out_ld = out.data_ptr(), cout
-        if ks:
+        if ks == 'stream':
+            from yoloret_amd import compiler
+            keep[0] = _dev_vec(compiler.head_pack(np.ascontiguousarray(wk.T), [cin], nk=compiler.pwt_chunks(cin)), dev)
+            op.wgt = keep[0].data_ptr()
+            op.se_reduced |= 0x40000
+        elif ks:
             op.se_reduced |= 0x20000
         rt.run_op(op, b)
         torch.cuda.synchronize()

@@ -201,12 +201,13 @@ def test_check_ranges_moves_ops_off_the_split_forms(dev):
     names = {o.name: o for o in m2.plan.ops}
     assert all(not (names[n].k & 0x80) for n in m2._nosplit if n in names and names[n].kind in (13, 14))
     # ... and the values are those of a plan that never used a split form
-    saved = C.MBR_SPLIT, C.FUSE_HEAD
-    C.MBR_SPLIT, C.FUSE_HEAD = False, False
+    saved = C.MBR_SPLIT, C.FUSE_HEAD, C.PW_STREAM
+    C.MBR_SPLIT, C.FUSE_HEAD, C.PW_STREAM = False, False, False     # (PW_STREAM: that form's weights are stored as float16 planes)
     try:
         m3 = yolov3_body(L.Input(shape=[64, 64, 3]), 'mobilenetv2x75', 3, num_classes=20)
+        m3.plan_for(2)
     finally:
-        C.MBR_SPLIT, C.FUSE_HEAD = saved
+        C.MBR_SPLIT, C.FUSE_HEAD, C.PW_STREAM = saved
     for o in m3.plan.ops:
         if o.kind == 2:
             o.se_reduced |= 0x10000

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libyoloret_hip.so')
-SOURCES = ['runtime.hip', 'pointwise.hip', 'pointwise_lds.hip', 'pointwise_split.hip', 'pointwise_h.hip', 'pointwise_hs.hip', 'pointwise_hq.hip', 'depthwise.hip', 'depthwise_lds.hip', 'depthwise_walk.hip', 'stem.hip', 'elementwise.hip', 'postprocess.hip',
+SOURCES = ['runtime.hip', 'pointwise.hip', 'pointwise_lds.hip', 'pointwise_split.hip', 'pointwise_stream.hip', 'pointwise_h.hip', 'pointwise_hs.hip', 'pointwise_hq.hip', 'depthwise.hip', 'depthwise_lds.hip', 'depthwise_walk.hip', 'stem.hip', 'elementwise.hip', 'postprocess.hip',
            'preprocess.hip', 'stemblock.hip', 'stemblock_h.hip', 'mblane.hip', 'mbh.hip', 'mbn_h.hip', 'mbr.hip', 'mbk.hip', 'mbxr_h.hip', 'headblock.hip', 'headwalk.hip', 'headwalk_h.hip', 'headstream.hip']
 # -ffp-contract=off: decode/NMS must match the oracle's IEEE operation order bit for bit;
 # every intended fused multiply-add in the kernels is an explicit fmaf / MFMA.

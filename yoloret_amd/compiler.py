@@ -171,7 +171,7 @@ class Plan:
                 raise
             assert tuple(arr.shape) == tuple(shape), (op.name, role, arr.shape, shape)
             if dt == 0:
-                if (op.kind == rt.OP_POINTWISE and role == 'wgt' and op.dtype == 0 and PW_SPLIT and not (op.se_reduced & 0x10000)
+                if (op.kind == rt.OP_POINTWISE and role == 'wgt' and op.dtype == 0 and PW_SPLIT and not (op.se_reduced & 0x50000)     # (bit 18: planes - head_pack has checked)
                         and arr.size and float(np.abs(arr).max()) >= 60000.0):
                     raise WeightRangeError(op.name, '%s: a weight of %.3g is beyond the float16 range the split pointwise form needs (YOLORET_PW_SPLIT=0 '
                                            'runs the float32-MFMA kernels)' % (op.name, float(np.abs(arr).max())))
@@ -361,6 +361,35 @@ MBS_MBE_CINS = (48, 72, 88, 120, 136)      # YR_OP_MBE's split form is built for
 # residual) -> (input rows per wave, waves per workgroup).  Before: YR_OP_MBE + a separate projection launch (the 6x-wide depthwise map
 # written and read back: block_11 87 + 100 MB).  YOLORET_FUSE_MBK=0 switches it off.
 FUSE_MBK = os.environ.get('YOLORET_FUSE_MBK', '1') != '0'
+# the pixel-stationary form of the float32 plans' 1x1 convs (pointwise_stream.hip; se_reduced bit 18, the weights stored as float16 planes)
+PW_STREAM = os.environ.get('YOLORET_PW_STREAM', '1') != '0'
+PWT_CHUNKS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16)      # (yr_pwt_chunks)
+
+
+def pwt_chunks(kp):
+    """Chunks of 32 channels the pixel-stationary pointwise form runs a k space of kp channels with (0: it does not take it)."""
+    nk = (kp + 31) // 32
+    return next((v for v in PWT_CHUNKS if v >= nk), 0)
+
+
+def pw_stream_form(o):
+    """Turn the float32 POINTWISE op o into its pixel-stationary form if it can take it: se_reduced bit 18, 'wgt' as head_pack planes."""
+    if (o.kind != rt.OP_POINTWISE or o.dtype != 0 or (o.se_reduced & 0x70000) or any(s_.xform in ('dw3', 'maxpool2', 'maxpool4', 'up2_add') for s_ in o.srcs)
+            or o.res is not None or o.act not in ('none', 'relu6')
+            or 'wgt' not in o.params or (len(o.params['wgt']) > 2 and o.params['wgt'][2] != 0)):
+        return False
+    (cout, kp), fn = o.params['wgt'][0], o.params['wgt'][1]
+    nk = pwt_chunks(kp)
+    if kp < 16 or not nk or o.out.dtype != 0 or (o.h == 1 and o.w == 1):
+        return False
+    nt = (cout + 15) // 16
+
+    def planes(wd, fn=fn, cout=cout, kp=kp, nk=nk):
+        return head_pack(np.asarray(fn(wd), np.float32).reshape(cout, kp), [kp], nk=nk)
+    o.params = dict(o.params)
+    o.params['wgt'] = ((nt * nk * 512,), planes, 0)
+    o.se_reduced |= 0x40000
+    return True
 MBK_SHAPES = {
     (48, 288, 48, 1, True): (2, 8),       # MobileNetV2 x0.75 block_7..9 (26 x 26): 35 us on the weight-stationary form (mbr.hip) -> 24
     (48, 288, 72, 1, False): (2, 8),      # block_10: 39 -> 27 us
@@ -854,8 +883,9 @@ def head_walk_rows(h, w):
     return ((w + 13) // 14) * ((h + sr - 1) // sr)
 
 
-def head_pack(wt, seg_c, V=4):
-    """The 1x1 convolution's weights Wt [F][kp] (k space = the sources' channels, each padded to V) as the float16 planes the
+def head_pack(wt, seg_c, V=4, nk=None):
+    """(nk: pad the chunk list with zero chunks to this length - the pixel-stationary pointwise form is built for some chunk counts only.)
+    The 1x1 convolution's weights Wt [F][kp] (k space = the sources' channels, each padded to V) as the float16 planes the
     LDS-direct head kernel reads (headblock.hip, YR_OP_HEAD with k bit 7): the k space cut into chunks of 32 channels PER SOURCE,
     [ceil(F / 16)][NK][2 planes][64 lanes][8 halves] - lane (m = l % 16, g = l / 16) of cout tile t, chunk j of source s:
     W[16 t + m][channel 32 j + 8 g + i of s], zero beyond the source / beyond F; h plane, then m = f16((w - h) 2^11).
@@ -868,10 +898,12 @@ def head_pack(wt, seg_c, V=4):
         chunks += [(kb + 32 * j, min(32, c - 32 * j)) for j in range((c + 31) // 32)]
         kb += round_up(c, V)
     assert float(np.abs(wt).max()) < 60000.0, 'head_pack: a weight beyond the float16 range'
-    W = np.zeros((NT * 16, len(chunks), 32), np.float32)
+    nch = len(chunks) if nk is None else nk
+    assert nch >= len(chunks)
+    W = np.zeros((NT * 16, nch, 32), np.float32)
     for ci, (k0, vc) in enumerate(chunks):
         W[:F, ci, :vc] = wt[:, k0:k0 + vc]
-    W = W.reshape(NT, 16, len(chunks), 4, 8).transpose(0, 2, 3, 1, 4)          # [t][chunk][g][m][i]  (lane = 16 g + m)
+    W = W.reshape(NT, 16, nch, 4, 8).transpose(0, 2, 3, 1, 4)          # [t][chunk][g][m][i]  (lane = 16 g + m)
     h = W.astype(np.float16)
     m = ((W - h.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
     out = np.stack([h, m], axis=2)                                             # [t][chunk][plane][g][m][i]
@@ -1883,6 +1915,11 @@ class Compiler:
         for o in ops:     # (also without fusion: a float32 POINTWISE op named by Model.check_ranges keeps the float32 MFMA)
             if o.kind == rt.OP_POINTWISE and o.name in self.nosplit:
                 o.se_reduced |= 0x10000
+        if PW_STREAM and PW_SPLIT and self.fuse is True and self.dtype == 0:
+            # the throughput plan's 1x1 convs in the pixel-stationary form (pointwise_stream.hip): HBM-bound launches that the tiled kernel
+            # ran at a third of the memory rate
+            for o in ops:
+                pw_stream_form(o)
         plan = Plan(ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape, self.dtype)
         plan.layer_seq = dict(self.layer_seq)
         return plan

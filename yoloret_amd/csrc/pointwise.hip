@@ -262,6 +262,10 @@ int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
     const bool split = split_on && a.S.kp >= 16 && !(op.se_reduced & 0x10000);   // (bit 16 of se_reduced: the plan asks for the float32 MFMA - its few-image form)   // (a 16- or 24-deep conv pads its one step with zeros: the MFMAs are not what it waits for)
     // bit 17 of se_reduced: the plan asks for the k-split form (the 'nohead' variant's small maps; pointwise_split.hip) - a property of the
     // PLAN like the split form itself, so the tuner's index is not looked at
+    if (op.se_reduced & 0x40000) {     // bit 18: the pixel-stationary form - op.wgt holds float16 planes, no other kernel can read them
+        YR_REQUIRE(split, "pointwise: the plan stores this op's weights as float16 planes (se_reduced bit 18) but the split form is off");
+        return yr_pw_launch_stream(a, s);
+    }
     if (split && (op.se_reduced & 0x20000) && a.S.kp >= 2 * 32) return yr_pw_launch_ksplit(a, s);
     if (split && op.k >= 1 && op.k <= NCFG) return yr_pw_launch_split((op.k - 1) % NLDS, a, s);
     if (op.k >= 1 && op.k <= NCFG) return cfgs[op.k - 1].fn(a, s);

@@ -334,6 +334,10 @@ int yr_pw_launch_lds(int shape, const PwArgs& a, hipStream_t s);
 int yr_pw_launch_split(int shape, const PwArgs& a, hipStream_t s);
 // its k-split form for the passes of a few images (a workgroup = one 16 x 16 tile, the four waves split the k range; se_reduced bit 17)
 int yr_pw_launch_ksplit(const PwArgs& a, hipStream_t s);
+// its pixel-stationary form (pointwise_stream.hip; se_reduced bit 18: a.wt holds the weights' float16 planes, compiler.head_pack over
+// yr_pwt_chunks(kp) chunks of 32 channels); yr_pwt_chunks: 0 = the form does not take a k space this deep
+int yr_pw_launch_stream(const PwArgs& a, hipStream_t s);
+int yr_pwt_chunks(int kp);
 // 16-bit kernel (pointwise_h.hip): cfg = tile shape index 0..yr_pwh_num_cfgs()-1, or -1 for its heuristic
 int yr_pw_launch_h(int dtype, int cfg, const PwArgs& a, hipStream_t s);
 int yr_pwh_num_cfgs();

@@ -177,6 +177,8 @@ static int64_t param_floats(const yr_op& op, int role) {   // role: 0 wgt, 1 sca
             int64_t kp = 0;
             for (int i = 0; i < op.nsrc; ++i)
                 if (op.src[i].xform != YR_X_UP2_ADD) kp += ru(op.src[i].c, V);
+            if (role == 0 && op.kind == YR_OP_POINTWISE && op.dtype == YR_F32 && (op.se_reduced & 0x40000))     // the pixel-stationary form: float16 planes (pointwise_stream.hip)
+                return ru(op.cout, 16) / 16 * (int64_t)yr_pwt_chunks((int)kp) * 512;
             if (role == 0) return op.dtype == YR_F32 ? (int64_t)op.cout * kp : ((int64_t)op.cout * kp + 1) / 2;
             if (role == 1 || role == 2) return op.cout;
             return 0;
@@ -671,6 +673,7 @@ extern "C" int yr_autotune(yr_handle* h, const float* images, int batch, float* 
             continue;
         }
         if (h->ops[i].kind != YR_OP_POINTWISE) continue;
+        if (h->ops[i].dtype == YR_F32 && (h->ops[i].se_reduced & 0x40000)) continue;   // the pixel-stationary form (pointwise_stream.hip): nothing to tune
         const int ncfg = yr_pointwise_num_cfgs(h->ops[i].dtype);
         yr_op op;
         rc = resolve_op(h, i, batch, ext, static_cast<char*>(workspace), &op);
