@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define YR_ABI_VERSION 8   /* 8: YR_OP_MBR k bit 6 = the weight-streaming form of the fused block (mbk.hip; plans of ABI 7 run unchanged - only the version word of a serialised plan differs); 7: squeeze-excite finished by its producer (yr_op.gate_out / se_w / se_hidden / sync: the "SE tail"), op kind HEAD (gathered 1x1 conv -> depthwise 3x3 -> SE of a detection-head block in one launch), yr_workspace_bytes includes the arrival counters; 6: split forms - k bit 7 of MBR / MBE (float16-plane fragments), se_reduced bit 16 of a float32 POINTWISE op (= keep the float32 MFMA); float32 POINTWISE ops at least 16 channels deep otherwise run on the 16-bit matrix pipe with two float16 planes per operand (pointwise_split.hip; same results to float32 rounding, |x|, |w| < 65504); 5: op kinds MBR / MBE (float32 blocks on the matrix pipe, register-chained), MBCONV removed; 4: YR_U8 images (uint8 network entry); 3: op kind MBX, pair-packed STEM weights, BN scale folded into the packed taps of STEMBLOCK / MBLANE */
+#define YR_ABI_VERSION 9   /* 9: float32 POINTWISE se_reduced bit 18 = the pixel-stationary form (pointwise_stream.hip: `wgt` holds the weights' float16 planes in fragment order) and bit 19 = its two-output form (gate_out / se_hidden / reserved0 = a second conv of the same source); plans of ABI 8 run unchanged - only the version word of a serialised plan differs; 8: YR_OP_MBR k bit 6 = the weight-streaming form of the fused block (mbk.hip; plans of ABI 7 run unchanged - only the version word of a serialised plan differs); 7: squeeze-excite finished by its producer (yr_op.gate_out / se_w / se_hidden / sync: the "SE tail"), op kind HEAD (gathered 1x1 conv -> depthwise 3x3 -> SE of a detection-head block in one launch), yr_workspace_bytes includes the arrival counters; 6: split forms - k bit 7 of MBR / MBE (float16-plane fragments), se_reduced bit 16 of a float32 POINTWISE op (= keep the float32 MFMA); float32 POINTWISE ops at least 16 channels deep otherwise run on the 16-bit matrix pipe with two float16 planes per operand (pointwise_split.hip; same results to float32 rounding, |x|, |w| < 65504); 5: op kinds MBR / MBE (float32 blocks on the matrix pipe, register-chained), MBCONV removed; 4: YR_U8 images (uint8 network entry); 3: op kind MBX, pair-packed STEM weights, BN scale folded into the packed taps of STEMBLOCK / MBLANE */
 #define YR_MAX_SRC 4
 
 typedef enum {
@@ -98,7 +98,17 @@ typedef enum {
                             workgroup is one 16 x 16 output tile, its four waves split the k range (pointwise_split.hip: pwk_kernel; 16-bit ops:
                             one 16 x 32 tile, pointwise_h.hip: pwkh_kernel);
                             what the compiler's plan for one or two images asks of maps up to 32 x 32.  The form groups the sums by wave: it
-                            belongs to the plan, not to the tuner (yr_op.k is not looked at); ignored below 64 input channels. */
+                            belongs to the plan, not to the tuner (yr_op.k is not looked at); ignored below 64 input channels.
+                            bit 18 (ABI 9, float32 ops without bit 16 / 17; identity | up2 sources, no residual / up2_add, act none | ReLU6,
+                            k space <= 384 channels): the PIXEL-STATIONARY form (pointwise_stream.hip) - `wgt` is NOT Wt[cout][kp] but its float16
+                            planes in MFMA fragment order, [ceil(cout / 16)][NK][2 planes h | m][64 lanes][8 halves] as float32 words with
+                            NK = yr_pwt_chunks(kp) chunks of 32 channels (lane (m, g) of tile t, chunk c: W[16 t + m][32 c + 8 g + i], zero
+                            beyond cout / kp; h = f16(w), m = f16((w - h) 2^11): compiler.head_pack).  Results are bit-identical to the tiled
+                            split kernel's.  bit 19 (with bit 18): TWO outputs - a second 1x1 conv of the same (gated) single identity source in
+                            the same launch: gate_out / gate_out_buf / gate_out_ld = its output (float32), se_hidden = its couts,
+                            reserved0 = its yr_act | pooled << 8 (MaxPooling2D(2) of its result, like stride = 2 for the first); its cout tiles
+                            follow the first output's in `wgt`, and scale / shift are [16 (tiles of the first + tiles of the second)]
+                            floats, each output's values padded to a multiple of 16. */
     YR_OP_DEPTHWISE = 3, /* DepthwiseConv2D k3/k5 s1/s2 SAME + BN + act (model.py:20-24; efficientnet.py:501-510).  With `gate` set (SE
                             form): the kernel ALSO writes per-workgroup channel sums of its output to
                             gate = float32 [B][se_reduced rows][gate_ld] (rows: compiler.dw_se_geometry == depthwise.hip) - the squeeze of squeeze-excite (efficientnet.py:417) as an
@@ -282,7 +292,7 @@ typedef struct {
      * k = h * w reading `gate` would have written (same values to float32 rounding), without the launch. */
     float* gate_out;  int32_t gate_out_buf;  int32_t gate_out_ld;   /* float32 [B][gate_out_ld], gate_out_ld >= round_up(cout, 4) */
     int32_t se_hidden;    /* hidden width R of the FC pair */
-    int32_t reserved0;
+    int32_t reserved0;    /* a two-output POINTWISE op (se_reduced bit 19): the second output's yr_act | pooled << 8; else 0 */
     const float* se_w;  int64_t se_w_off;   /* W1 [ldc][R4] (Keras kernel [1,1,C,R], rows padded to R4 = round_up(R, 4)) | W2 [R][ldc] | b1 [R4] | b2 [ldc], ldc = round_up(cout, 4) */
     uint32_t* sync;       /* [batch] arrival counters: zero before the launch, zero again after it.  Plan ops: assigned by yr_forward
                              from the tail of the workspace (cleared at the start of every pass); yr_op_run: the caller's */
@@ -368,6 +378,9 @@ int yr_head_regions(int h, int w, int32_t* nsy, int32_t* nsx);
 /* ... and of the WALKING form of YR_OP_HEAD (k bit 6): rows = strips of 14 columns x row segments (its se_reduced). */
 int yr_head_walk_rows(int h, int w, int32_t* rows);
 /* ... and of its WEIGHT-STREAMING form (k bits 5 and 6): rows = strips x row segments x waves per workgroup. */
+/* chunks of 32 channels the pixel-stationary POINTWISE form (se_reduced bit 18) runs a k space of kp channels with - what the plan
+ * pads the weight planes to (1 .. 10, 12, 16); 0: the form does not take a k space this deep. */
+int yr_pwt_chunks(int kp);
 int yr_head_stream_rows(int h, int w, int32_t* rows);
 
 /* ---- preprocessing (the step before the path): decoded uint8 [ih,iw,3] image (device) ->

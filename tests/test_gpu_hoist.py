@@ -136,9 +136,11 @@ def test_compiler_pools_in_the_producer(dev):
     from yoloret_amd import layers as L
     from yoloret_amd.yolo3.model import yolov3_body
     m = yolov3_body(L.Input(shape=[128, 128, 3]), 'mobilenetv2x75', 3, num_classes=20)
-    pooled = {o.name: o for o in m.plan.ops if getattr(o, 'stride', 0) == 2 and o.kind == 2}
+    pooled = {o.name: (o.h, o.w) for o in m.plan.ops if getattr(o, 'stride', 0) == 2 and o.kind == 2}
+    # (the throughput plan runs a down conv as the SECOND output of the launch that also computes the head's y conv: compiler.fuse_stream_pairs)
+    pooled.update({o.second_name: (o.gate_out.h, o.gate_out.w) for o in m.plan.ops if o.kind == 2 and (getattr(o, 'reserved0', 0) >> 8) & 1})
     assert set(pooled) == {'bu3_down_conv', 'bu2_down_conv', 'rfcr_b3c'}
-    assert (pooled['bu3_down_conv'].h, pooled['bu3_down_conv'].w) == (8, 8)
+    assert pooled['bu3_down_conv'] == (8, 8)
     assert not any(s.xform == 'maxpool2' and s.buf.name.endswith('_pooled') for o in m.plan.ops for s in o.srcs)
     bu2 = next(o for o in m.plan.ops if o.name in ('bu2_conv', 'bu2_head'))
     assert [s.xform for s in bu2.srcs] == ['identity', 'identity']
@@ -190,9 +192,10 @@ def test_compiler_folds_head_projections_into_their_1x1_consumers(dev):
     assert not any(n in names for n in ('td3_mb_project', 'bu3_mb_project', 'bu1_mb_project'))
     assert all(n in names for n in ('td1_mb_project', 'td2_mb_project', 'bu2_mb_project'))   # composed MACs would be 1.14x .. 2.3x
     folded = {o.name: o for o in m.plan.ops if getattr(o, 'folded_projection', None)}
-    assert sorted(folded) == ['bu1_y', 'bu3_down_conv', 'bu3_head', 'bu3_y']      # (bu3_head: bu3_conv + its depthwise, YR_OP_HEAD)
+    pair = folded['bu3_y']       # bu3's y conv and down conv: one launch with two outputs (compiler.fuse_stream_pairs), both composed
+    assert sorted(folded) == ['bu1_y', 'bu3_head', 'bu3_y'] and pair.second_name == 'bu3_down_conv' and all(f.folded_projection for f in pair.fused)      # (bu3_head: bu3_conv + its depthwise, YR_OP_HEAD)
     assert all((o.res if o.kind == 15 else o.gate) is not None and o.cin == o.srcs[0].c and o.srcs[0].buf.name.endswith('_mb_dw') for o in folded.values())
-    assert getattr(folded['bu3_down_conv'], 'stride', 0) == 2    # the pooled store still rides on the (composed) conv
+    assert (pair.reserved0 >> 8) & 1    # the pooled store still rides on the (composed) conv
     saved = compiler.FOLD_PROJ
     try:
         compiler.FOLD_PROJ = False

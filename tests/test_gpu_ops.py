@@ -188,6 +188,66 @@ def test_pointwise_stream_form_many_tiles_per_wave(dev):
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize('gated', [False, True])
+@pytest.mark.parametrize('shape', [(52, 52, 128, 75, 128, 40), (26, 26, 75, 75, 256, 3), (8, 12, 40, 20, 48, 5)])
+def test_pointwise_stream_two_outputs(dev, shape, gated):
+    """The two-output form (se_reduced bits 18 + 19: a head's y conv and the bottom-up path's down conv read the same gated map in ONE
+    launch - first output dense and unpooled, second ReLU6 + MaxPooling2D(2)) == each conv run alone on the tiled split kernel, bit
+    for bit (bu3_y + bu3_down_conv and bu2_y + bu2_down_conv of MobileNetV2 x0.75 @416, and a ragged small case)."""
+    from yoloret_amd import compiler
+    rt = _rt()
+    h, w, cin, n1, n2, b = shape
+    rng = np.random.default_rng(zlib.crc32(str(shape).encode()))
+    ld = round_up(cin, 4)
+    x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
+    xd = to_dev(x, dev)
+    w1 = (rng.standard_normal((n1, ld)) * np.sqrt(2.0 / cin)).astype(np.float32)
+    w2 = (rng.standard_normal((n2, ld)) * np.sqrt(2.0 / cin)).astype(np.float32)
+    w1[:, cin:] = 0
+    w2[:, cin:] = 0
+    sc1, sh1 = rng.uniform(0.5, 1.5, n1).astype(np.float32), rng.normal(0, 0.3, n1).astype(np.float32)
+    sc2, sh2 = rng.uniform(0.5, 1.5, n2).astype(np.float32), rng.normal(0, 0.3, n2).astype(np.float32)
+    g = to_dev(rng.uniform(0.1, 1.0, (b, 1, 1, ld)).astype(np.float32), dev) if gated else None
+
+    def single(wt, sc, sh, n, act, pooled, out_ld):
+        oh, ow = (h // 2, w // 2) if pooled else (h, w)
+        out = torch.full((b, oh, ow, out_ld), float('nan'), dtype=torch.float32, device=dev)
+        op = rt.new_op(rt.OP_POINTWISE, act)
+        op.h, op.w, op.cin, op.cout, op.nsrc, op.stride = oh, ow, cin, n, 1, 2 if pooled else 0
+        op.src[0] = rt.make_src(xd, c=cin)
+        keep = [_dev_vec(wt, dev), _dev_vec(sc, dev), _dev_vec(sh, dev)]
+        op.wgt, op.scale, op.shift = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
+        if gated:
+            op.gate, op.gate_ld = g.data_ptr(), ld
+        op.out, op.out_ld = out.data_ptr(), out_ld
+        rt.run_op(op, b)
+        torch.cuda.synchronize()
+        return from_dev(out, n)
+    ref1 = single(w1, sc1, sh1, n1, 'none', False, n1)
+    ref2 = single(w2, sc2, sh2, n2, 'relu6', True, round_up(n2, 4))
+    nk = compiler.pwt_chunks(ld)
+    ta, tb = (n1 + 15) // 16, (n2 + 15) // 16
+    planes = np.concatenate([compiler.head_pack(w1, [ld], nk=nk), compiler.head_pack(w2, [ld], nk=nk)])
+    sc, sh = np.ones(16 * (ta + tb), np.float32), np.zeros(16 * (ta + tb), np.float32)
+    sc[:n1], sc[16 * ta:16 * ta + n2], sh[:n1], sh[16 * ta:16 * ta + n2] = sc1, sc2, sh1, sh2
+    out1 = torch.full((b, h, w, n1), float('nan'), dtype=torch.float32, device=dev)
+    out2 = torch.full((b, h // 2, w // 2, round_up(n2, 4)), float('nan'), dtype=torch.float32, device=dev)
+    op = rt.new_op(rt.OP_POINTWISE, 'none')
+    op.h, op.w, op.cin, op.cout, op.nsrc = h, w, cin, n1, 1
+    op.src[0] = rt.make_src(xd, c=cin)
+    keep = [_dev_vec(planes, dev), _dev_vec(sc, dev), _dev_vec(sh, dev)]
+    op.wgt, op.scale, op.shift = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
+    if gated:
+        op.gate, op.gate_ld = g.data_ptr(), ld
+    op.out, op.out_ld = out1.data_ptr(), n1
+    op.gate_out, op.gate_out_ld, op.se_hidden, op.reserved0 = out2.data_ptr(), round_up(n2, 4), n2, rt.ACT['relu6'] | 1 << 8
+    op.se_reduced |= 0xc0000
+    rt.run_op(op, b)
+    torch.cuda.synchronize()
+    assert np.array_equal(from_dev(out1, n1), ref1)
+    assert np.array_equal(from_dev(out2, n2), ref2)
+
+
 def test_pointwise_ksplit_pooled_output(dev):
     """... and with the MaxPooling2D(2) output of the bottom-up convs (rows walked in 2 x 2-quad-major order inside the 16-row tile)."""
     rt = _rt()

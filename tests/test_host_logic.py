@@ -28,10 +28,10 @@ def test_macs_match_survey(name, size, macs_m):
 
 def test_plan_structure_and_accounting():
     from yoloret_amd import compiler, runtime as rt
-    knobs = ('FUSE_MAX_CIN', 'FUSE_STEM', 'HOIST_UPSAMPLE', 'POOL_IN_PRODUCER', 'MERGE_SE_MEAN', 'FOLD_DW', 'FUSE_MBR', 'FOLD_PROJ', 'FUSE_MBE', 'FOLD_WSUM')
+    knobs = ('FUSE_MAX_CIN', 'FUSE_STEM', 'HOIST_UPSAMPLE', 'POOL_IN_PRODUCER', 'MERGE_SE_MEAN', 'FOLD_DW', 'FUSE_MBR', 'FOLD_PROJ', 'FUSE_MBE', 'FOLD_WSUM', 'PW_STREAM_PAIRS')
     saved = [getattr(compiler, k) for k in knobs]
     try:
-        for k, v in zip(knobs, (0, False, False, False, False, False, False, False, False, False)):   # every rewrite off: the plan = SURVEY.md Appendix B rows
+        for k, v in zip(knobs, (0, False, False, False, False, False, False, False, False, False, False)):   # every rewrite off: the plan = SURVEY.md Appendix B rows
             setattr(compiler, k, v)
         p = _model().plan
     finally:
@@ -260,7 +260,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
         assert hasattr(L, sym), 'libyoloret_hip.so does not export %s' % sym
     assert declared == set(rt.EXPORTS)
     L.yr_abi_version.restype = ctypes.c_int
-    assert L.yr_abi_version() == 8 == rt.ABI_VERSION
+    assert L.yr_abi_version() == 9 == rt.ABI_VERSION
     # struct layouts agree with the header's (the library reports its own sizeof)
     for which, st in enumerate((rt.YrSrc, rt.YrOp, rt.YrBuf)):
         assert L.yr_abi_sizeof(which) == ctypes.sizeof(st), st.__name__
@@ -522,6 +522,23 @@ def test_head_blocks_of_the_16bit_plans_and_their_fragment_packing(monkeypatch):
     assert rc == 0 or (b'does not fit' not in err and b'bytes' not in err and b'parameter' not in err), err
     if rc == 0:
         rt.lib().yr_destroy(h)
+
+
+def test_stream_form_chunk_counts_agree_between_compiler_and_library():
+    """compiler.pwt_chunks (what the plan pads a pixel-stationary conv's weight planes to) == yr_pwt_chunks (what the kernel is built
+    for); the throughput plan of the headline model carries the form and its two-output pairs, the other variants do not."""
+    import ctypes
+    from yoloret_amd import compiler, runtime as rt
+    L = rt.lib()
+    L.yr_pwt_chunks.argtypes, L.yr_pwt_chunks.restype = [ctypes.c_int], ctypes.c_int
+    assert all(L.yr_pwt_chunks(kp) == compiler.pwt_chunks(kp) for kp in range(4, 700, 4))
+    m = _model()
+    tp = [o for o in m.plan_for(64).ops if o.kind == rt.OP_POINTWISE]
+    assert sum(bool(o.se_reduced & 0x40000) for o in tp) >= 10 and sorted(o.name for o in tp if o.se_reduced & 0x80000) == ['bu2_y', 'bu3_y']
+    assert all(o.gate_out is not None and o.se_hidden > 0 for o in tp if o.se_reduced & 0x80000)
+    m.small_batch, m.mbk_batch = 4, 24
+    for b in (1, 3, 10):        # 'nohead_k', 'nohead', 'mid'
+        assert m.variant(b) != 'throughput' and not any(o.se_reduced & 0xc0000 for o in m.plan_for(b).ops if o.kind == rt.OP_POINTWISE)
 
 
 def test_nosplit_names_hold_in_every_plan_variant():

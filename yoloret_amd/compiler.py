@@ -70,6 +70,7 @@ class OpRec:
         self.gate = None
         self.gate_out = None  # ABI 7, the SE tail: the gate vector this op writes itself (se_hidden = the FC pair's hidden width, params['se_w'])
         self.se_hidden = 0
+        self.reserved0 = 0    # (a two-output POINTWISE op: the second output's activation | pooled << 8)
         self.params = {}      # role -> (shape, numpy builder fn(weights) -> float32 array[, yr_dtype it is stored as])
         self.offsets = {}     # role -> float offset in blob
         self.macs = 0
@@ -202,6 +203,7 @@ class Plan:
             o.gate_buf, o.gate_ld = (r.gate.id, r.gate.ld) if r.gate is not None else (-1, 0)
             o.gate_out_buf, o.gate_out_ld = (r.gate_out.id, r.gate_out.ld) if r.gate_out is not None else (-1, 0)
             o.se_hidden = r.se_hidden
+            o.reserved0 = getattr(r, 'reserved0', 0)
             roles = {'wgt': 'wgt_off', 'scale': 'scale_off', 'shift': 'shift_off', 'wgt2': 'wgt2_off',
                      'b1': 'b1_off', 'b2': 'b2_off', 'se_w': 'se_w_off'}
             for role, field in roles.items():
@@ -363,6 +365,7 @@ MBS_MBE_CINS = (48, 72, 88, 120, 136)      # YR_OP_MBE's split form is built for
 FUSE_MBK = os.environ.get('YOLORET_FUSE_MBK', '1') != '0'
 # the pixel-stationary form of the float32 plans' 1x1 convs (pointwise_stream.hip; se_reduced bit 18, the weights stored as float16 planes)
 PW_STREAM = os.environ.get('YOLORET_PW_STREAM', '1') != '0'
+PW_STREAM_MID = os.environ.get('YOLORET_PW_STREAM_MID', '0') != '0'     # ... in the 'mid' plan variant (batches below Model.mbk_batch) too
 PWT_CHUNKS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16)      # (yr_pwt_chunks)
 
 
@@ -370,6 +373,66 @@ def pwt_chunks(kp):
     """Chunks of 32 channels the pixel-stationary pointwise form runs a k space of kp channels with (0: it does not take it)."""
     nk = (kp + 31) // 32
     return next((v for v in PWT_CHUNKS if v >= nk), 0)
+
+
+PW_STREAM_PAIRS = os.environ.get('YOLORET_PW_STREAM_PAIRS', '1') != '0'
+
+
+def fuse_stream_pairs(ops, output_buf_ids=()):
+    """Two pixel-stationary POINTWISE ops over the SAME (gated) map - a head's y conv and the down conv of the bottom-up path (reference
+    code/yolo3/model.py:139-151) - become one launch with two outputs (se_reduced bit 19): the map is read once.  The first output is
+    the one a plan output aliases (if any); the second travels as gate_out / se_hidden (couts) / reserved0 (activation | pooled << 8),
+    its tiles behind the first's in the weight planes, scale and shift padded to the tiles."""
+    if not PW_STREAM_PAIRS:
+        return ops
+    ops = list(ops)
+
+    def conv_dims(o):
+        f = 2 if o.stride == 2 else 1
+        return o.h * f, o.w * f
+
+    def ok(o):
+        return (o.kind == rt.OP_POINTWISE and (o.se_reduced & 0xc0000) == 0x40000 and len(o.srcs) == 1 and o.srcs[0].xform == 'identity'
+                and o.gate_out is None)
+    i = 0
+    while i < len(ops):
+        a = ops[i]
+        if ok(a):
+            for j in range(i + 1, len(ops)):
+                b = ops[j]
+                if (ok(b) and b.srcs[0].buf is a.srcs[0].buf and b.srcs[0].c == a.srcs[0].c and b.gate is a.gate and conv_dims(a) == conv_dims(b)
+                        and b.out is not a.out and b.out.dtype == 0 and a.out.dtype == 0):
+                    first, second = (b, a) if (b.out.external_slot >= 0 or b.out.id in output_buf_ids) and not (a.out.external_slot >= 0 or a.out.id in output_buf_ids) else (a, b)
+                    if second.out.external_slot >= 0 or second.out.id in output_buf_ids:
+                        continue        # (two plan outputs: the second output is an arena buffer)
+                    m = OpRec(rt.OP_POINTWISE, first.name, act=first.act, h=first.h, w=first.w, cin=first.cin, cout=first.cout, k=first.k, stride=first.stride,
+                              se_reduced=first.se_reduced | 0x80000, srcs=list(first.srcs), out=first.out, gate=first.gate, macs=first.macs + second.macs, dtype=0)
+                    m.gate_out, m.se_hidden, m.reserved0 = second.out, second.cout, rt.ACT[second.act] | ((1 if second.stride == 2 else 0) << 8)
+                    m.fused = [first, second]
+                    m.second_name = second.name
+                    if getattr(first, 'folded_projection', None):
+                        m.folded_projection = first.folded_projection
+                    ta, tb = (first.cout + 15) // 16, (second.cout + 15) // 16
+                    fp, sp = first.params, second.params
+
+                    def planes(wd, fp=fp, sp=sp):
+                        return np.concatenate([np.asarray(fp['wgt'][1](wd), np.float32).ravel(), np.asarray(sp['wgt'][1](wd), np.float32).ravel()])
+
+                    def vec(role, fp=fp, sp=sp, ta=ta, tb=tb, na=first.cout, nb=second.cout):
+                        def f(wd):
+                            o = np.full(16 * (ta + tb), 1.0 if role == 'scale' else 0.0, np.float32)      # (a conv without BN scale / bias: 1 / 0)
+                            if role in fp:
+                                o[:na] = np.asarray(fp[role][1](wd), np.float32).ravel()[:na]
+                            if role in sp:
+                                o[16 * ta:16 * ta + nb] = np.asarray(sp[role][1](wd), np.float32).ravel()[:nb]
+                            return o
+                        return f
+                    m.params = {'wgt': ((fp['wgt'][0][0] + sp['wgt'][0][0],), planes, 0), 'scale': ((16 * (ta + tb),), vec('scale')), 'shift': ((16 * (ta + tb),), vec('shift'))}
+                    ops[i] = m
+                    del ops[j]
+                    break
+        i += 1
+    return ops
 
 
 def pw_stream_form(o):
@@ -380,6 +443,8 @@ def pw_stream_form(o):
         return False
     (cout, kp), fn = o.params['wgt'][0], o.params['wgt'][1]
     nk = pwt_chunks(kp)
+    if nk > 12:       # (512 channels at 13 x 13: 20 us against the tiled kernel's 18 - one wave's chain over 16 chunks)
+        return False
     if kp < 16 or not nk or o.out.dtype != 0 or (o.h == 1 and o.w == 1):
         return False
     nt = (cout + 15) // 16
@@ -1915,11 +1980,13 @@ class Compiler:
         for o in ops:     # (also without fusion: a float32 POINTWISE op named by Model.check_ranges keeps the float32 MFMA)
             if o.kind == rt.OP_POINTWISE and o.name in self.nosplit:
                 o.se_reduced |= 0x10000
-        if PW_STREAM and PW_SPLIT and self.fuse is True and self.dtype == 0:
+        if PW_STREAM and PW_SPLIT and (self.fuse is True or (self.fuse == 'mid' and PW_STREAM_MID)) and self.dtype == 0:
             # the throughput plan's 1x1 convs in the pixel-stationary form (pointwise_stream.hip): HBM-bound launches that the tiled kernel
             # ran at a third of the memory rate
             for o in ops:
                 pw_stream_form(o)
+            if self.fuse is True:
+                ops = fuse_stream_pairs(ops, set(b.id for b in outs))
         plan = Plan(ops, self.bufs, in_buf, outs, self.param_shapes, self.inputs.shape, self.dtype)
         plan.layer_seq = dict(self.layer_seq)
         return plan

@@ -159,6 +159,7 @@ int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
     PwArgs a;
     yr_op op = op_in;
     a.pre = nullptr; a.pre_ld = 0;
+    a.out2 = nullptr; a.out2_ld = a.N2 = a.act2 = a.pool2 = 0;
     YR_REQUIRE(yr_dtype_ok(op.dtype) && (op.out_dtype == op.dtype || op.out_dtype == YR_F32),
                "pointwise: dtype %d / out_dtype %d unsupported (the output has the op's dtype or is float32)", op.dtype, op.out_dtype);
     const bool narrow = op.dtype != YR_F32;
@@ -264,6 +265,11 @@ int yr_launch_pointwise(const yr_op& op_in, int batch, hipStream_t s) {
     // PLAN like the split form itself, so the tuner's index is not looked at
     if (op.se_reduced & 0x40000) {     // bit 18: the pixel-stationary form - op.wgt holds float16 planes, no other kernel can read them
         YR_REQUIRE(split, "pointwise: the plan stores this op's weights as float16 planes (se_reduced bit 18) but the split form is off");
+        if (op.se_reduced & 0x80000) {     // bit 19: a second conv of the same source in the same launch (its output: gate_out, its width: se_hidden)
+            YR_REQUIRE(op.gate_out != nullptr && op.se_hidden >= 1 && op.gate_out_ld >= op.se_hidden, "pointwise: the second output of a two-output op is missing or too narrow");
+            a.out2 = op.gate_out; a.out2_ld = op.gate_out_ld; a.N2 = op.se_hidden;
+            a.act2 = op.reserved0 & 0xff; a.pool2 = (op.reserved0 >> 8) & 1;
+        }
         return yr_pw_launch_stream(a, s);
     }
     if (split && (op.se_reduced & 0x20000) && a.S.kp >= 2 * 32) return yr_pw_launch_ksplit(a, s);

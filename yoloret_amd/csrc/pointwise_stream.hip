@@ -40,6 +40,10 @@ struct PwtArgs {
     int ntiles;              // pixel tiles (ceil(M / (16 ROWS)))
     PwtDiv d_hw, d_wq, d_hwq;   // H W | W / 2 | (H / 2) (W / 2)
     unsigned in_bytes, out_bytes, gate_bytes;
+    // two outputs (PwArgs::out2): cout tiles [0, TA) belong to the first, [TA, T) to the second; quad: GEMM rows are walked in 2 x 2-quad-major
+    // order (one of the outputs is pooled)
+    int TA, quad;
+    unsigned out2_bytes;
 };
 
 // waves per workgroup, from the measured register needs (16 / 12 / 8 waves: 128 / 168 / 256 registers)
@@ -61,7 +65,7 @@ extern "C" int yr_pwt_dbg_read(unsigned* dst, int n) { return (int)hipMemcpyFrom
 
 // GEMM row -> conv pixel (pw_pixel_of_row with the divisions by multiplication)
 __device__ __forceinline__ int pwt_pixel_of_row(const PwArgs& a, const PwtArgs& x, int m) {
-    if (!a.pool) return m;
+    if (!x.quad) return m;
     const int q = m >> 2, sub = m & 3;
     const int wq = a.W >> 1, hwq = (a.H >> 1) * wq;
     const int b = pwt_div(q, x.d_hwq), r = q - b * hwq;
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(64 * pwt_waves(NK, ROWS, MODE)) void pwt_kernel(PwA
     }
     // (unconditional loads, selected afterwards: a load under a branch is waited for at the join - with the planes in flight in front of it)
     const int bn_i = (int)threadIdx.x;      // (run <= 32 tiles: 512 couts)
-    const int bn_n = bn_i < 16 * run && 16 * t0 + bn_i < a.N ? 16 * t0 + bn_i : 0;
+    const int bn_n = bn_i < 16 * run && (a.out2 != nullptr || 16 * t0 + bn_i < a.N) ? 16 * t0 + bn_i : 0;      // (two outputs: the vectors are padded to the tiles)
     const float bn_sl = (a.scale ? a.scale : x.planes)[bn_n], bn_hl = (a.shift ? a.shift : x.planes)[bn_n];
 
     // ---- a wave walks its pixel tiles; the loads of a tile go out ALL AT ONCE (one round trip), and those of the first tile before the
@@ -103,11 +107,13 @@ __global__ __launch_bounds__(64 * pwt_waves(NK, ROWS, MODE)) void pwt_kernel(PwA
     const int stride = x.nwg * NW;
     int tile = wg + x.nwg * w;
     const mbr_rsrc xsrc = mbr_make_rsrc(a.S.s[0].ptr, x.in_bytes), osrc = mbr_make_rsrc(a.out, x.out_bytes);
+    const mbr_rsrc osrc2 = mbr_make_rsrc(a.out2 ? a.out2 : a.out, a.out2 ? x.out2_bytes : 16u);
     const mbr_rsrc gsrc = mbr_make_rsrc(MODE == 2 ? a.gate : a.S.s[0].ptr, MODE == 2 ? x.gate_bytes : 16u);
     PwRow<0> row[MODE == 0 ? ROWS : 1];
     float4 xa[ROWS][NK][2];
     int cv[MODE == 0 ? ROWS : 1][MODE == 0 ? NK : 1][2];
     unsigned goff[ROWS];      // MODE 2: byte offset of the pixel's gate row
+    int pix[ROWS];            // conv pixel of the lane's GEMM row (= the row, unless the rows are walked in quad-major order)
     // the gate's quads, two chunks at a time and one pair ahead of the cut that uses them (read one by one at their cut, each is an L2 round
     // trip in front of it: 16 chunks, 18 k cycles)
     constexpr int GQ = 2, NGQ = (NK + GQ - 1) / GQ;
@@ -129,6 +135,7 @@ __global__ __launch_bounds__(64 * pwt_waves(NK, ROWS, MODE)) void pwt_kernel(PwA
             const int m = (tile * ROWS + i) * 16 + li;
             if constexpr (MODE == 0) {
                 row[i].init(a, m);
+                pix[i] = pw_pixel_of_row(a, m < a.M ? m : 0);
                 pw_unroll<NK * 2>([&](auto U) __attribute__((always_inline)) {
                     constexpr int u = decltype(U)::value, c = u / 2, q = u % 2;
                     float4 unused;
@@ -137,6 +144,7 @@ __global__ __launch_bounds__(64 * pwt_waves(NK, ROWS, MODE)) void pwt_kernel(PwA
             } else {
                 // one identity source: 32-bit offsets into a buffer descriptor; a quad beyond the k space (or of a row beyond M) reads zeros
                 const int mm = pwt_pixel_of_row(a, x, m < a.M ? m : 0);
+                pix[i] = mm;
                 const unsigned poff = (unsigned)mm * (unsigned)ldsrc * 4u;
                 if constexpr (MODE == 2) goff[i] = (unsigned)pwt_div(mm, x.d_hw) * (unsigned)a.gate_ld * 4u;
                 pw_unroll<NK * 2>([&](auto U) __attribute__((always_inline)) {
@@ -199,12 +207,13 @@ __global__ __launch_bounds__(64 * pwt_waves(NK, ROWS, MODE)) void pwt_kernel(PwA
         });
         PWT_T(2)
         // ---- where the lane's quads go: output row (pooled: the window's row, kept by the lane of its first pixel)
-        unsigned obase[ROWS];
+        unsigned obase[ROWS], obase2[ROWS];
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
             const int m = (tile * ROWS + i) * 16 + li;
-            const bool keep = m < a.M && (!a.pool || (li & 3) == 0);
-            obase[i] = keep ? (unsigned)(a.pool ? m >> 2 : m) * (unsigned)a.out_ld * 4u : MBR_DEAD;
+            const bool keep = m < a.M && (!a.pool || (li & 3) == 0), keep2 = m < a.M && (!a.pool2 || (li & 3) == 0);
+            obase[i] = keep ? (unsigned)(a.pool ? m >> 2 : pix[i]) * (unsigned)a.out_ld * 4u : MBR_DEAD;
+            obase2[i] = keep2 && a.out2 ? (unsigned)(a.pool2 ? m >> 2 : pix[i]) * (unsigned)a.out2_ld * 4u : MBR_DEAD;
         }
         for (int t = 0; t < run; ++t) {
             const pws_u4* fe = reinterpret_cast<const pws_u4*>(lds_raw + (size_t)t * TB) + lane;     // [NK][2 planes][64]
@@ -223,25 +232,34 @@ __global__ __launch_bounds__(64 * pwt_waves(NK, ROWS, MODE)) void pwt_kernel(PwA
             }
             const f32x4 sc = *reinterpret_cast<const f32x4*>(ss + 16 * t + 4 * g);
             const f32x4 sh = *reinterpret_cast<const f32x4*>(ss + 16 * run + 16 * t + 4 * g);
-            const int n = 16 * (t0 + t) + 4 * g, cnt = a.N - n;       // real couts of the lane's quad (<= 0: none)
+            const bool second = t0 + t >= x.TA;      // (uniform) a tile of the second output
+            const int n = 16 * (t0 + t - (second ? x.TA : 0)) + 4 * g, cnt = (second ? a.N2 : a.N) - n;       // real couts of the lane's quad (<= 0: none)
+            const bool clamp_t = second ? a.act2 != YR_ACT_NONE : clamp, pool_t = second ? a.pool2 != 0 : a.pool != 0;
 #pragma unroll
             for (int i = 0; i < ROWS; ++i) {
                 f32x4 v = __builtin_elementwise_fma(ac1[i], k11, acc[i]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], sc[r], sh[r]);
-                if (clamp) {      // (uniform) ReLU6
+                if (clamp_t) {      // (uniform) ReLU6
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], 0.f, 6.f);
                 }
-                if (a.pool) {     // (uniform) MaxPooling2D(2) across the 4 adjacent lanes of a window
+                if (pool_t) {     // (uniform) MaxPooling2D(2) across the 4 adjacent lanes of a window
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         v[r] = fmaxf(v[r], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[r]), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
                         v[r] = fmaxf(v[r], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[r]), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
                     }
                 }
-                const unsigned off = obase[i] == MBR_DEAD || cnt <= 0 ? MBR_DEAD : obase[i] + 4u * (unsigned)n;
-                if (cnt >= 4) {
+                const unsigned ob = second ? obase2[i] : obase[i];
+                const unsigned off = ob == MBR_DEAD || cnt <= 0 ? MBR_DEAD : ob + 4u * (unsigned)n;
+                if (second) {
+                    if (cnt >= 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), osrc2, off, 0, 0);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), osrc2, r < cnt ? off + 4u * r : MBR_DEAD, 0, 0);
+                    }
+                } else if (cnt >= 4) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), osrc, off, 0, 0);
                 } else {          // (the last quad of a dense 75-wide row)
 #pragma unroll
@@ -315,7 +333,7 @@ static int launch_pwt(const PwArgs& a, PwtArgs& x, hipStream_t s) {
 }
 
 // chunk counts the form is built for (a k space in between runs the next one: its planes are padded with zero chunks by the compiler)
-int yr_pwt_chunks(int kp) {
+extern "C" int yr_pwt_chunks(int kp) {
     static const int sizes[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16};
     const int nk = (kp + 31) / 32;
     for (int v : sizes)
@@ -331,7 +349,11 @@ int yr_pw_launch_stream(const PwArgs& a, hipStream_t s) {
     for (int i = 0; i < a.S.n; ++i)
         YR_REQUIRE(a.S.s[i].xform != YR_X_MAXPOOL2 && a.S.s[i].xform != YR_X_MAXPOOL4, "pointwise (pixel-stationary form): no pooled source");
     PwtArgs x;
-    x.planes = a.wt; x.T = (a.N + 15) / 16;
+    x.TA = (a.N + 15) / 16;
+    x.planes = a.wt; x.T = x.TA + (a.out2 ? (a.N2 + 15) / 16 : 0);
+    x.quad = a.pool || (a.out2 && a.pool2);
+    if (a.out2) YR_REQUIRE(a.act2 == YR_ACT_NONE || a.act2 == YR_ACT_RELU6, "pointwise (pixel-stationary form): activation %d of the second output", a.act2);
+    if (x.quad) YR_REQUIRE(a.H % 2 == 0 && a.W % 2 == 0, "pointwise (pixel-stationary form): a pooled output needs an even map");
     x.plane_bytes = (unsigned)x.T * (unsigned)nk * 2048u;
     x.d_hw = pwt_div_make((unsigned)(a.H * a.W));
     x.d_wq = pwt_div_make((unsigned)(a.W >> 1 > 0 ? a.W >> 1 : 1));
@@ -339,6 +361,9 @@ int yr_pw_launch_stream(const PwArgs& a, hipStream_t s) {
     const long long inb = (long long)a.M * a.S.s[0].ld * 4, outb = (long long)(a.pool ? a.M / 4 : a.M) * a.out_ld * 4;
     YR_REQUIRE(inb < 0x7f000000ll && outb < 0x7f000000ll, "pointwise (pixel-stationary form): a map of %lld bytes is beyond the 32-bit offsets", inb > outb ? inb : outb);
     x.in_bytes = (unsigned)inb; x.out_bytes = (unsigned)outb;
+    const long long outb2 = a.out2 ? (long long)(a.pool2 ? a.M / 4 : a.M) * a.out2_ld * 4 : 0;
+    YR_REQUIRE(outb2 < 0x7f000000ll, "pointwise (pixel-stationary form): a second output of %lld bytes is beyond the 32-bit offsets", outb2);
+    x.out2_bytes = (unsigned)outb2;
     x.gate_bytes = a.gate ? (unsigned)((long long)(a.M / (a.H * a.W)) * a.gate_ld * 4) : 0u;
     // two rows of 16 pixels per wave where every wave of the chip still gets a tile
     const bool two = nk <= 6 && (long long)a.M >= 256ll * pwt_waves(nk, 2, 2) * 32;

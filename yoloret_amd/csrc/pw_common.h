@@ -47,6 +47,10 @@ struct PwArgs {
     // 16-bit ops (pointwise_h.hip; the float32 kernels ignore it): sources, weights and residual are bf16 / f16 behind the
     // type-erased pointers above; out_f32 = 1: `out` is float32 all the same (logit outputs, hoisted partial sums)
     int out_f32;
+    // the pixel-stationary form's SECOND output (se_reduced bit 19 of a POINTWISE op; null: none): another 1x1 conv of the same (gated) source -
+    // its couts follow the first one's in the weight planes and in scale / shift (each padded to a multiple of 16)
+    float* out2;
+    int out2_ld, N2, act2, pool2;
 };
 
 // GEMM row -> conv pixel.  Plain: identity.  Pooled output: rows are walked in 2x2-quad-major order, so the four
@@ -337,7 +341,7 @@ int yr_pw_launch_ksplit(const PwArgs& a, hipStream_t s);
 // its pixel-stationary form (pointwise_stream.hip; se_reduced bit 18: a.wt holds the weights' float16 planes, compiler.head_pack over
 // yr_pwt_chunks(kp) chunks of 32 channels); yr_pwt_chunks: 0 = the form does not take a k space this deep
 int yr_pw_launch_stream(const PwArgs& a, hipStream_t s);
-int yr_pwt_chunks(int kp);
+extern "C" int yr_pwt_chunks(int kp);
 // 16-bit kernel (pointwise_h.hip): cfg = tile shape index 0..yr_pwh_num_cfgs()-1, or -1 for its heuristic
 int yr_pw_launch_h(int dtype, int cfg, const PwArgs& a, hipStream_t s);
 int yr_pwh_num_cfgs();

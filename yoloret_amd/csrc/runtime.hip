@@ -126,6 +126,12 @@ extern "C" int yr_create(const yr_op* ops, int n_ops, const yr_buf* bufs, int n_
             else if (op.kind == YR_OP_HEAD && op.res_buf >= 0 && (op.res_ld < op.cin || !fits(op.res_buf, op.res_ld, YR_F32))) why = "the source's gate";   // (HEAD: res = the SE gate vector of its single source)
             else if (op.kind != YR_OP_HEAD && op.res_buf >= 0 && (op.res_ld < op.cout || !fits(op.res_buf, (int64_t)op.h * op.w * op.res_ld, op.dtype))) why = "the residual";
             else if (op.gate_buf >= 0 && op.gate_ld <= 0) why = "the gate";
+            else if (op.kind == YR_OP_POINTWISE && op.gate_out_buf >= 0) {
+                // the second output of a two-output conv (se_reduced bits 18 + 19): se_hidden couts, its own pooling in reserved0
+                const int64_t ch = (int64_t)op.h * (op.stride == 2 ? 2 : 1), cw = (int64_t)op.w * (op.stride == 2 ? 2 : 1), p2 = ((op.reserved0 >> 8) & 1) ? 2 : 1;
+                if ((op.se_reduced & 0xc0000) != 0xc0000 || op.dtype != YR_F32 || op.se_hidden < 1 || op.gate_out_ld < op.se_hidden || !fits(op.gate_out_buf, (ch / p2) * (cw / p2) * op.gate_out_ld, YR_F32))
+                    why = "the second output";
+            }
             else if (op.gate_out_buf >= 0 && (op.gate_buf < 0 || op.se_hidden < 1 || op.se_w_off < 0 || op.gate_out_ld < op.cout || !fits(op.gate_out_buf, op.gate_out_ld, YR_F32) ||
                                               op.se_reduced < 1 || !fits(op.gate_buf, (int64_t)op.se_reduced * op.gate_ld, YR_F32))) why = "the squeeze-excite tail";
         }
@@ -137,7 +143,7 @@ extern "C" int yr_create(const yr_op* ops, int n_ops, const yr_buf* bufs, int n_
     }
     h->sync_slot.assign(h->ops.size(), -1);
     for (size_t i = 0; i < h->ops.size(); ++i)
-        if (h->ops[i].gate_out_buf >= 0) h->sync_slot[i] = h->n_sync++;
+        if (h->ops[i].gate_out_buf >= 0 && h->ops[i].kind != YR_OP_POINTWISE) h->sync_slot[i] = h->n_sync++;      // (a POINTWISE op's gate_out is its second output)
     *out = h;
     return YR_OK;
 }
@@ -177,8 +183,11 @@ static int64_t param_floats(const yr_op& op, int role) {   // role: 0 wgt, 1 sca
             int64_t kp = 0;
             for (int i = 0; i < op.nsrc; ++i)
                 if (op.src[i].xform != YR_X_UP2_ADD) kp += ru(op.src[i].c, V);
-            if (role == 0 && op.kind == YR_OP_POINTWISE && op.dtype == YR_F32 && (op.se_reduced & 0x40000))     // the pixel-stationary form: float16 planes (pointwise_stream.hip)
-                return ru(op.cout, 16) / 16 * (int64_t)yr_pwt_chunks((int)kp) * 512;
+            if (op.kind == YR_OP_POINTWISE && op.dtype == YR_F32 && (op.se_reduced & 0x40000)) {     // the pixel-stationary form: float16 planes (pointwise_stream.hip)
+                const int64_t tiles = ru(op.cout, 16) / 16 + ((op.se_reduced & 0x80000) ? ru(op.se_hidden, 16) / 16 : 0);      // (bit 19: the second output's tiles behind the first's)
+                if (role == 0) return tiles * (int64_t)yr_pwt_chunks((int)kp) * 512;
+                if ((role == 1 || role == 2) && (op.se_reduced & 0x80000)) return 16 * tiles;
+            }
             if (role == 0) return op.dtype == YR_F32 ? (int64_t)op.cout * kp : ((int64_t)op.cout * kp + 1) / 2;
             if (role == 1 || role == 2) return op.cout;
             return 0;

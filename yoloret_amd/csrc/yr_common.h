@@ -59,7 +59,7 @@ int yr_launch_head_walk(const yr_op& op, int batch, hipStream_t s); // headwalk.
 int yr_launch_head_walk_h(const yr_op& op, int batch, hipStream_t s); // headwalk_h.hip (... of a 16-bit plan)
 int yr_launch_head_stream(const yr_op& op, int batch, hipStream_t s); // headstream.hip (YR_OP_HEAD with k bits 5 and 6: the weight-streaming form)
 int yr_pointwise_num_cfgs(int dtype);
-int yr_pwt_chunks(int kp);   // chunks of 32 channels the pixel-stationary pointwise form (pointwise_stream.hip) runs a k space with; 0: not taken
+extern "C" int yr_pwt_chunks(int kp);   // chunks of 32 channels the pixel-stationary pointwise form (pointwise_stream.hip) runs a k space with; 0: not taken
 
 static inline int yr_round_up(int v, int m) { return (v + m - 1) / m * m; }
 // channels per 16 bytes of a tensor of this yr_dtype: the granule of `ld` and of the pointwise k-space

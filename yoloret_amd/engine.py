@@ -372,6 +372,7 @@ class Model:
                                                     rt.stream_ptr(x.device), mx))
             result = {op.name: float(mx[i]) for i, op in enumerate(plan.ops)}
             bad = [plan.ops[i].name for i in C.split_form_ops(plan) if not (mx[i] <= limit)]
+            bad += [plan.ops[i].second_name for i in C.split_form_ops(plan) if not (mx[i] <= limit) and getattr(plan.ops[i], 'second_name', None)]   # (a two-output conv: both convs read that map)
             if not bad:
                 self._ranges_checked = True       # (a 'report' / 'raise' that found something leaves the automatic guard armed)
                 break

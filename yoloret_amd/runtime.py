@@ -90,9 +90,9 @@ class YrBuf(ctypes.Structure):
                 ('external_slot', ctypes.c_int32), ('dtype', ctypes.c_int32)]
 
 
-ABI_VERSION = 8   # == YR_ABI_VERSION of include/yoloret_hip.h
+ABI_VERSION = 9   # == YR_ABI_VERSION of include/yoloret_hip.h
 EXPORTS = ['yr_last_error', 'yr_abi_version', 'yr_abi_sizeof', 'yr_create', 'yr_create_from_blob', 'yr_plan_io_dims', 'yr_destroy', 'yr_load_weights', 'yr_workspace_bytes',
-           'yr_forward', 'yr_forward_profile', 'yr_forward_ranges', 'yr_autotune', 'yr_get_tuning', 'yr_set_tuning', 'yr_plan_num_launches', 'yr_op_run', 'yr_head_regions', 'yr_head_walk_rows', 'yr_head_stream_rows', 'yr_decode', 'yr_decode_zoom', 'yr_yolo_head', 'yr_correct_boxes',
+           'yr_forward', 'yr_forward_profile', 'yr_forward_ranges', 'yr_autotune', 'yr_get_tuning', 'yr_set_tuning', 'yr_plan_num_launches', 'yr_op_run', 'yr_head_regions', 'yr_head_walk_rows', 'yr_head_stream_rows', 'yr_pwt_chunks', 'yr_decode', 'yr_decode_zoom', 'yr_yolo_head', 'yr_correct_boxes',
            'yr_nms', 'yr_pack_detections', 'yr_letterbox', 'yr_letterbox_batch']
 
 _lib = None
