@@ -527,7 +527,7 @@ def main():
         fams = [('lane_per_pixel_front', ('mblane', 'stemblock', 'stem_')),
                 ('head_blocks', ('head_kernel', 'head2_kernel', 'hwalk_kernel', 'hwalkh_kernel', 'hstream_kernel')),
                 ('fused_blocks', ('mbh_kernel', 'mbn_kernel', 'mbr_kernel', 'mbk_kernel', 'mbe_kernel', 'mbx_kernel', 'mbxr_kernel', 'mbhr_kernel', 'mbhq_kernel', 'stemxr_kernel', 'stemxp_kernel')),
-                ('pointwise', ('pw_kernel', 'pwd_kernel', 'pws_kernel', 'pwh', 'pwl')), ('depthwise', ('dw_kernel', 'dwp_kernel', 'dwq_kernel', 'dwl')),
+                ('pointwise', ('pw_kernel', 'pwd_kernel', 'pws_kernel', 'pwt_kernel', 'pwk_kernel', 'pwh', 'pwl')), ('depthwise', ('dw_kernel', 'dwp_kernel', 'dwq_kernel', 'dwl')),
                 ('elementwise', ('wsum', 'gather', 'letterbox')),
                 ('squeeze_excite', ('se_',)), ('postprocess', ('decode', 'nms', 'pack'))]
         known = tuple(p_ for _, ps in fams for p_ in ps)
