@@ -191,6 +191,10 @@ def test_pointwise_stream_form_many_tiles_per_wave(dev):
 @pytest.mark.parametrize('gated', [False, True])
 @pytest.mark.parametrize('shape', [(52, 52, 128, 75, 128, 40), (26, 26, 75, 75, 256, 3), (8, 12, 40, 20, 48, 5)])
 def test_pointwise_stream_two_outputs(dev, shape, gated):
+    _two_outputs(dev, shape, gated)
+
+
+def _two_outputs(dev, shape, gated):
     """The two-output form (se_reduced bits 18 + 19: a head's y conv and the bottom-up path's down conv read the same gated map in ONE
     launch - first output dense and unpooled, second ReLU6 + MaxPooling2D(2)) == each conv run alone on the tiled split kernel, bit
     for bit (bu3_y + bu3_down_conv and bu2_y + bu2_down_conv of MobileNetV2 x0.75 @416, and a ragged small case)."""
@@ -246,6 +250,22 @@ def test_pointwise_stream_two_outputs(dev, shape, gated):
     torch.cuda.synchronize()
     assert np.array_equal(from_dev(out1, n1), ref1)
     assert np.array_equal(from_dev(out2, n2), ref2)
+    return from_dev(out1, n1), from_dev(out2, n2)
+
+
+def test_pointwise_stream_form_cuts_a_batch_beyond_the_32_bit_offsets(dev, monkeypatch):
+    """The kernel addresses its maps through buffer descriptors (32-bit offsets): a batch whose maps pass 2 GB runs as several launches
+    over whole images.  With the limit lowered to three images' worth the result is the uncut one, bit for bit (gated, pooled second
+    output: every pointer that moves with the cut)."""
+    shape = (26, 26, 75, 75, 256, 7)
+    monkeypatch.delenv('YR_PWT_MAX_BYTES', raising=False)
+    import tests.test_gpu_ops as me
+    outs = []
+    for lim in (None, str(3 * 26 * 26 * 76 * 4 + 100)):
+        if lim:
+            monkeypatch.setenv('YR_PWT_MAX_BYTES', lim)
+        outs.append(me._two_outputs(dev, shape, True))
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[1]))
 
 
 def test_pointwise_ksplit_pooled_output(dev):

@@ -15,6 +15,9 @@
 // Two rows of 16 pixels per wave halve the LDS traffic of the weight fragments (what bounds the multiply phase: 2 KB per three
 // MFMAs) and are taken when there are pixels enough for every wave of the chip.
 // No result depends on the launch geometry: a cout of a pixel is one accumulator chain over the k chunks in ascending order.
+#include <algorithm>
+#include <cstdlib>
+
 #include "pws_common.h"
 #include "mbr_common.h"
 
@@ -341,7 +344,7 @@ extern "C" int yr_pwt_chunks(int kp) {
     return 0;
 }
 
-int yr_pw_launch_stream(const PwArgs& a, hipStream_t s) {
+static int pwt_launch_images(const PwArgs& a, hipStream_t s) {
     const int nk = yr_pwt_chunks(a.S.kp);
     YR_REQUIRE(nk > 0, "pointwise (pixel-stationary form): a k space of %d channels is beyond 16 chunks", a.S.kp);
     YR_REQUIRE(a.dw_w == nullptr && a.pre == nullptr && a.res == nullptr, "pointwise (pixel-stationary form): no depthwise-folded source, addend or residual");
@@ -377,4 +380,30 @@ int yr_pw_launch_stream(const PwArgs& a, hipStream_t s) {
 #undef PWT_CASE
 #undef PWT_CASE1
     return YR_ERR_ARG;
+}
+
+// The kernel addresses its maps through 32-bit offsets (buffer descriptors): a batch whose maps pass 2 GB runs as several launches over
+// runs of whole images (no result depends on the cut).
+int yr_pw_launch_stream(const PwArgs& a0, hipStream_t s) {
+    const long long hw = (long long)a0.H * a0.W;
+    const int B = (int)(a0.M / hw);
+    long long per_image = (a0.pool ? hw / 4 : hw) * a0.out_ld * 4;
+    if (a0.out2) per_image = std::max(per_image, (a0.pool2 ? hw / 4 : hw) * a0.out2_ld * 4);
+    for (int i = 0; i < a0.S.n; ++i) per_image = std::max(per_image, (long long)a0.S.s[i].h * a0.S.s[i].w * a0.S.s[i].ld * 4);
+    const char* lim = getenv("YR_PWT_MAX_BYTES");      // (tests: a small limit exercises the cut)
+    const long long fit = (lim && atoll(lim) > 0 ? atoll(lim) : 0x7e000000ll) / (per_image > 0 ? per_image : 1);
+    if (fit >= B || (long long)B * hw != a0.M) return pwt_launch_images(a0, s);
+    YR_REQUIRE(fit >= 1, "pointwise (pixel-stationary form): one image's map of %lld bytes is beyond the 32-bit offsets", per_image);
+    for (int b0 = 0; b0 < B; b0 += (int)fit) {
+        PwArgs a = a0;
+        const int n = B - b0 < fit ? B - b0 : (int)fit;
+        a.M = (int)(n * hw);
+        for (int i = 0; i < a.S.n; ++i) a.S.s[i].ptr += (size_t)b0 * a.S.s[i].h * a.S.s[i].w * a.S.s[i].ld;
+        if (a.gate) a.gate += (size_t)b0 * a.gate_ld;
+        a.out += (size_t)b0 * (a.pool ? hw / 4 : hw) * a.out_ld;
+        if (a.out2) a.out2 += (size_t)b0 * (a.pool2 ? hw / 4 : hw) * a.out2_ld;
+        const int rc = pwt_launch_images(a, s);
+        if (rc) return rc;
+    }
+    return YR_OK;
 }
