@@ -253,6 +253,19 @@ def _two_outputs(dev, shape, gated):
     return from_dev(out1, n1), from_dev(out2, n2)
 
 
+def test_pointwise_stream_form_two_rows_per_wave(dev, monkeypatch):
+    """The form with 32 pixels per wave (YR_PWT_ROWS=2: built, measured behind 16 pixels per wave, kept for experiments) computes the
+    same bits: single and two-output launches, gated."""
+    monkeypatch.setenv('YR_PWT_ROWS', '2')
+    _two_outputs(dev, (52, 52, 128, 75, 128, 9), True)
+    _two_outputs(dev, (8, 12, 40, 20, 48, 5), False)
+    outs = []
+    for st in (False, True):
+        rng = np.random.default_rng(12)
+        outs.append(run_pointwise(dev, rng, 7, 26, 26, [(75, 'identity')], 128, 'relu6', True, False, False, stream=st))
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_pointwise_stream_form_cuts_a_batch_beyond_the_32_bit_offsets(dev, monkeypatch):
     """The kernel addresses its maps through buffer descriptors (32-bit offsets): a batch whose maps pass 2 GB runs as several launches
     over whole images.  With the limit lowered to three images' worth the result is the uncut one, bit for bit (gated, pooled second

@@ -12,8 +12,7 @@
 //     cut into float16 planes in registers; the waves of a CU drift apart, so one's round trip hides behind the others' MFMAs;
 //   * per cout tile: 3 ROWS NK MFMAs (the split form's three products per chunk, in pws_kernel's order: the results are
 //     bit-identical to pws_kernel's), then BN, ReLU6 | none, (2 x 2 max,) one 16-byte store per lane.
-// Two rows of 16 pixels per wave halve the LDS traffic of the weight fragments (what bounds the multiply phase: 2 KB per three
-// MFMAs) and are taken when there are pixels enough for every wave of the chip.
+// (A two-row form - 32 pixels per wave, half the LDS traffic of the weight fragments - is built and measured behind: YR_PWT_ROWS=2.)
 // No result depends on the launch geometry: a cout of a pixel is one accumulator chain over the k chunks in ascending order.
 #include <algorithm>
 #include <cstdlib>
@@ -368,8 +367,10 @@ static int pwt_launch_images(const PwArgs& a, hipStream_t s) {
     YR_REQUIRE(outb2 < 0x7f000000ll, "pointwise (pixel-stationary form): a second output of %lld bytes is beyond the 32-bit offsets", outb2);
     x.out2_bytes = (unsigned)outb2;
     x.gate_bytes = a.gate ? (unsigned)((long long)(a.M / (a.H * a.W)) * a.gate_ld * 4) : 0u;
-    // two rows of 16 pixels per wave where every wave of the chip still gets a tile
-    const bool two = nk <= 6 && (long long)a.M >= 256ll * pwt_waves(nk, 2, 2) * 32;
+    // 32 pixels per wave (half the fragment reads from LDS) measured behind 16 once the kernel was persistent and lean: bu3's two-output
+    // launch 60 against 50 us, the 26 x 26 convs 14-28 against 14-23 (YR_PWT_ROWS=2 forces it: experiments)
+    const char* rows_env = getenv("YR_PWT_ROWS");
+    const bool two = rows_env && atoi(rows_env) == 2 && nk <= 6;
 #define PWT_CASE(K) if (nk == K) return two ? launch_pwt<K, 2>(a, x, s) : launch_pwt<K, 1>(a, x, s);
 #define PWT_CASE1(K) if (nk == K) return launch_pwt<K, 1>(a, x, s);
 #ifdef PWT_ONLY
