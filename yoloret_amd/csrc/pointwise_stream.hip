@@ -49,7 +49,12 @@ struct PwtArgs {
 };
 
 // waves per workgroup, from the measured register needs (16 / 12 / 8 waves: 128 / 168 / 256 registers)
-constexpr int pwt_waves(int nk, int rows, int mode) {
+#ifndef PWT_MAX_WAVES
+#define PWT_MAX_WAVES 16      // (experiments: -DPWT_MAX_WAVES=8 | 12 leaves room on the CU for the kernels of other steps in flight)
+#endif
+constexpr int pwt_waves_fit(int nk, int rows, int mode);
+constexpr int pwt_waves(int nk, int rows, int mode) { return pwt_waves_fit(nk, rows, mode) < PWT_MAX_WAVES ? pwt_waves_fit(nk, rows, mode) : PWT_MAX_WAVES; }
+constexpr int pwt_waves_fit(int nk, int rows, int mode) {
     const int nkr = nk * rows;
     if (mode == 0) return nkr <= 6 ? 16 : nkr <= 10 ? 12 : 8;
     if (mode == 1) return nkr <= 9 ? 16 : nkr <= 12 ? 12 : 8;
