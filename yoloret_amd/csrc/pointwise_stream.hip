@@ -359,6 +359,7 @@ static int pwt_launch_images(const PwArgs& a, hipStream_t s) {
     x.TA = (a.N + 15) / 16;
     x.planes = a.wt; x.T = x.TA + (a.out2 ? (a.N2 + 15) / 16 : 0);
     x.quad = a.pool || (a.out2 && a.pool2);
+    if (a.out2) YR_REQUIRE(a.S.n == 1 && a.S.s[0].xform == YR_X_IDENTITY, "pointwise (pixel-stationary form): two outputs need a single identity source");
     if (a.out2) YR_REQUIRE(a.act2 == YR_ACT_NONE || a.act2 == YR_ACT_RELU6, "pointwise (pixel-stationary form): activation %d of the second output", a.act2);
     if (x.quad) YR_REQUIRE(a.H % 2 == 0 && a.W % 2 == 0, "pointwise (pixel-stationary form): a pooled output needs an even map");
     x.plane_bytes = (unsigned)x.T * (unsigned)nk * 2048u;
