@@ -363,6 +363,22 @@ def test_reference_operating_points(dev, name, size, classes):
         _check_detections_with_margins(ys, ref5, res, hw, thr=thr, num_classes=classes)
 
 
+@pytest.mark.parametrize('name', ['efficientnetb1', 'efficientnetb2', 'efficientnetb4', 'efficientnetb5'])
+def test_other_efficientnet_widths(dev, name):
+    """The compound-scaling table's other widths (code/yolo3/efficientnet.py:231-244; the reference wires B3 only, model.py:205-217):
+    whole-graph float32 logits within 1e-4 of the torch-CPU oracle at 128 x 128 - shapes no kernel's shape list was written for."""
+    from oracle import torch_ref
+    b, size, classes = 2, 128, 20
+    m, P = _build(name, (size, size), classes)
+    x = params.synthetic_images(b, size, size)
+    ref = [np.asarray(r) for r in torch_ref.TorchReference(P, name, 3, classes)(x)]
+    m.set_weights(P.values)
+    ys = m(torch.from_numpy(x).to(dev))
+    torch.cuda.synchronize()
+    for i, (y, r) in enumerate(zip(ys, ref)):
+        assert_close(y.cpu().numpy().reshape(r.shape), r, 1e-4, '%s@%d y%d' % (name, size, i + 1))
+
+
 def test_coco_width_records_packed_and_gathered(dev):
     """C = 80 at a batch of 8: 1600 rows per image through yr_pack_detections (yolo_eval_packed) and the multi-GPU record path
     (DetectionGatherer, one rank): the unpacked records equal the per-image lists of yolo_eval and the C oracle's, in MAP mode."""

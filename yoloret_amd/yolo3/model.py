@@ -24,6 +24,7 @@ from .. import layers as L
 from .. import runtime as rt
 from ..engine import Model
 from ..layers import WeightedSum  # model.py:117-137
+from . import efficientnet as _effnet
 from .efficientnet import BlockArgs, EfficientNetB0, EfficientNetB3, MBConvBlock, get_model_params
 from .override import mobilenet_v2
 from .utils import compose
@@ -90,7 +91,8 @@ def _conv_bn_relu6(filters, name, bn_name):
                    L.BatchNormalization(momentum=0.9, name=bn_name), L.ReLU(6., name=name + '_relu6'))
 
 
-_EFFNET_BUILDERS = {'efficientnetb0': EfficientNetB0, 'efficientnetb3': EfficientNetB3}
+# (the reference wires B3 only, model.py:205-217; its efficientnet.py:231-244 scales B0 .. B7 and the taps are stage ends, so every width builds)
+_EFFNET_BUILDERS = {'efficientnetb%d' % i: getattr(_effnet, 'EfficientNetB%d' % i) for i in range(8)}
 
 
 def yolov3_body(inputs, model_name, num_anchors, **kwargs):
@@ -98,7 +100,8 @@ def yolov3_body(inputs, model_name, num_anchors, **kwargs):
     mapping images [B,H,W,3] to [y1,y2,y3] = raw logits [B,G,G,num_anchors,num_classes+5]
     for strides 32/16/8.  ``inputs``: ``yoloret_amd.layers.Input(shape=[H,W,3])``.
     ``model_name`` in {'mobilenetv2x75','mobilenetv2x14','efficientnetb3'} as in the reference,
-    plus the build-defined 'efficientnetb0' and '<efficientnet>-lite' variants.
+    plus the build-defined 'efficientnetb0' .. 'efficientnetb7' (the other widths of efficientnet.py:231-244) and '<efficientnet>-lite'
+    variants.
     kwargs: num_classes, drop_rate, data_format, batch_norm_momentum, batch_norm_epsilon,
     drop_connect_rate (efficientnet.py:259-265); unknown keys raise ValueError."""
     L.reset_names()
